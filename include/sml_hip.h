@@ -1,0 +1,159 @@
+/*
+ * sml_hip.h -- C ABI of libsml_hip.so, the MI355X (gfx950) implementation of the
+ * SML per-period retraining hot path.
+ *
+ * The reference (zyang1580/SML) has no FFI: the path sits behind a Python module
+ * surface.  Each entry point below names the reference code it replaces
+ * (paths relative to the reference checkout).  The Python host side
+ * (sml_amd/engine.py) binds these with ctypes; INTEGRATION.md shows the stub a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative SML_E* code and never
+ *     throws; sml_last_error() returns a thread-local message for the last failure;
+ *   - every device buffer is a caller-owned raw device pointer (e.g. a torch
+ *     tensor's data_ptr()); the library never frees or retains it past the call;
+ *   - every launch goes to the caller's hipStream_t (passed as void*), is
+ *     asynchronous and performs no hidden synchronisation, except where noted;
+ *   - scratch lives in an opaque sml_ctx; scalars (losses) are written to device
+ *     memory supplied by the caller;
+ *   - tables are row-major fp32 [rows, d]; d in {32, 64, 128}; indices are int64
+ *     exactly as the reference's DataLoader yields them (model/transfer.py:466-468);
+ *   - theta (the transfer net) is ONE flat fp32 buffer holding the user net then the
+ *     item net, each laid out as sml_theta_offset() reports (16-byte aligned tensors
+ *     in the reference's state_dict order: conv1.weight, conv1.bias, conv2.weight,
+ *     conv2.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias; model/conv_transfer.py:23-34).
+ */
+#ifndef SML_HIP_H
+#define SML_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SML_OK 0
+#define SML_EINVAL (-1)   /* bad argument (unsupported d, null pointer, size mismatch) */
+#define SML_EHIP (-2)     /* a HIP runtime call failed; see sml_last_error() */
+#define SML_ENOMEM (-3)
+#define SML_ESTATE (-4)   /* call sequence error (e.g. packed weights stale) */
+
+/* loss selection: ConvTransfer_com.run_MF(BCE=True) is the reference default
+ * (model/conv_transfer.py:113-126); BPR is its BCE=False branch (:128-134) */
+#define SML_LOSS_BCE 0
+#define SML_LOSS_BPR 1
+#define SML_LOSS_BPR_NORM 2   /* BPR with score / ||u'|| (norm=True, :130-132) */
+
+typedef struct sml_ctx sml_ctx;
+
+const char* sml_last_error(void);
+int sml_version(void);
+
+/* ---- context ------------------------------------------------------------------ */
+/* Scratch for batches of up to max_batch triples at width d on `device`. */
+int sml_ctx_create(sml_ctx** out, int device, int d, int max_batch);
+int sml_ctx_destroy(sml_ctx* ctx);
+
+/* ---- theta layout ------------------------------------------------------------- */
+/* Floats in one net's flat block / offset of tensor `which` (0..7 in state_dict
+ * order) inside it.  The full theta buffer is 2 * sml_theta_net_size(d) floats. */
+int64_t sml_theta_net_size(int d);
+int64_t sml_theta_offset(int d, int which);
+/* Rebuild the MFMA operand images of fc1/fc2 after theta was written by the host
+ * (construction, load_state_dict).  The TR-stage Adam keeps them current itself. */
+int sml_theta_pack(sml_ctx* ctx, const float* theta, void* stream);
+
+/* ---- a5/a6/a10: transfer net forward ------------------------------------------- */
+/* ConvTransfer_com.forward (model/conv_transfer.py:92-110) for `net` (0 = user
+ * transfer, 1 = item transfer): out[n,:] = net(x_t[n,:], x_hat[n,:]).  Rows are
+ * contiguous; out may alias neither input.  Used for meta_train.updata
+ * (model/transfer.py:884-902) over whole tables. */
+int sml_transfer_forward(sml_ctx* ctx, const float* theta, int net, const float* x_t,
+                         const float* x_hat, float* out, int64_t n_rows, void* stream);
+
+/* ---- a8: MF stage (meta_train.MF_train_onestage inner loop, model/transfer.py:463-511) */
+typedef struct {
+    float* w_user;         /* MFbase.user_laten.weight [U,d] (trainable W_hat) */
+    float* w_item;         /* MFbase.item_laten.weight [I,d] */
+    const float* last_user;/* last_user_weight  W_{t-1} [U,d] */
+    const float* last_item;/* last_item_weight  W_{t-1} [I,d] */
+    float* m_user; float* v_user;   /* Adam exp_avg / exp_avg_sq, same shape as the tables */
+    float* m_item; float* v_item;
+    int32_t* step_user;    /* [U] last Adam step applied to each row (lazy replay) */
+    int32_t* step_item;    /* [I] */
+    int64_t n_user, n_item;
+} sml_mf_tables;
+
+/* One epoch over n pre-drawn triples (u,i,j) int64 [n,3], in batches of `batch`:
+ * 6 gathers -> run_MF -> + l2*0.5*sum(x_hat^2) -> backward to the W_hat rows ->
+ * Adam(lr, betas 0.9/0.999, eps 1e-8, wd 0) with the DENSE semantics of
+ * torch.optim.Adam reproduced lazily per row (rows not in a batch still take their
+ * zero-gradient steps; they are replayed when the row is next touched or flushed).
+ * *step is the optimiser's global step counter (in: steps done; out: + n_batches).
+ * batch_loss[n_batches] (device) receives each batch's loss as the reference's
+ * loss_batch (model/transfer.py:488).  Asynchronous. */
+int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
+                       const int64_t* triples, int64_t n, int batch, float lr, float l2,
+                       int loss_kind, int64_t* step, float* batch_loss, void* stream);
+/* Replay every pending zero-gradient Adam step so the tables can be read out
+ * (before save_MF_weight / updata / evaluation; model/transfer.py:518, 777, 832). */
+int sml_mf_adam_flush(sml_ctx* ctx, const sml_mf_tables* t, float lr, int64_t step, void* stream);
+
+/* ---- a9: TR stage (meta_train.transfer_train_onestage inner loop, model/transfer.py:701-728) */
+typedef struct {
+    const float* last_user; const float* last_item;   /* W_{t-1} */
+    const float* hat_user;  const float* hat_item;    /* user_weight_hat / item_weight_hat */
+    int64_t n_user, n_item;
+} sml_tr_tables;
+
+/* One epoch: per batch, run_MF(norm=False) forward, backward to theta, then
+ * Adam(lr, weight_decay added to the gradient) on theta (and m, v: flat buffers of
+ * the same layout).  theta_grad (2*net_size floats, may be NULL for internal
+ * scratch) receives each batch's flat gradient.  With grad_hook == NULL the whole
+ * epoch is queued asynchronously.  A non-NULL grad_hook is called on the host after
+ * each batch's backward has been queued on `stream` and before its Adam step is
+ * queued, with the flat theta-gradient buffer: the multi-GPU path all-reduces it
+ * there (on the same stream).  loss_scale multiplies loss and gradients
+ * (B_local / B_global when a global batch is split over ranks; 1 otherwise). */
+typedef int (*sml_grad_hook)(void* user, float* grad, int64_t n_floats, int64_t batch_index);
+int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v, float* theta_grad,
+                       const sml_tr_tables* t, const int64_t* triples, int64_t n, int batch,
+                       float lr, float weight_decay, int loss_kind, float loss_scale,
+                       int64_t* step, float* batch_loss, sml_grad_hook grad_hook, void* hook_user,
+                       void* stream);
+
+/* ---- a3: bare fused embed + loss + SGD write-back ------------------------------ */
+/* gather 3 rows, 2 dot products, BCE (model/baseline.py:188-201) or BPR
+ * (model/MF.py:139-144 without biases) loss, gradients, and synchronous minibatch
+ * SGD: W -= lr * dL/dW with duplicate rows' gradients summed before the write.
+ * dtype_bytes: 4 (fp32 tables) or 2 (fp16 tables, fp32 arithmetic).
+ * batch_loss[n_batches] as above. */
+int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n_user,
+                             int64_t n_item, int dtype_bytes, const int64_t* triples, int64_t n,
+                             int batch, float lr, float lam_user, float lam_item, int loss_kind,
+                             float* batch_loss, void* stream);
+
+/* ---- a2: MFbasemode.forward (model/MF.py:34-43) --------------------------------- */
+int sml_mf_forward(sml_ctx* ctx, const float* w_user, const float* w_item, const int64_t* user,
+                   const int64_t* item, int64_t n, int norm, float* uemb, float* iemb, float* score,
+                   void* stream);
+
+/* ---- a13: evaluation (MFbasemode.test, model/MF.py:45-80) ------------------------ */
+/* rows int64 [n, n_cols]: col 0 user, col 1 the positive, cols 2.. negatives.
+ * rank[r] = #{candidates scoring strictly above the positive} (= the position
+ * torch.topk assigns it for tie-free scores). */
+int sml_eval_ranks(sml_ctx* ctx, const float* w_user, const float* w_item, const int64_t* rows,
+                   int64_t n, int n_cols, int32_t* rank, void* stream);
+/* hits = #{rank < topk}, ndcg = sum 1/log2(rank+2) over hits; out[0]=hits, out[1]=ndcg (device). */
+int sml_eval_metrics(sml_ctx* ctx, const int32_t* rank, int64_t n, int topk, float* out, void* stream);
+
+/* ---- self test ------------------------------------------------------------------ */
+/* Checks the MFMA operand/accumulator lane maps this library assumes against a
+ * scalar loop on the device.  Synchronous.  Returns 0 if they hold. */
+int sml_selftest(int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SML_HIP_H */

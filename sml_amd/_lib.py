@@ -1,0 +1,95 @@
+"""ctypes binding of libsml_hip.so (C ABI declared in include/sml_hip.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  If the shared
+object is missing or cannot be loaded this module raises, and so does every
+caller (sml_amd.engine, model.*, evalution.*).
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  -- must come first: it loads the HIP runtime (libamdhip64.so.7) this library binds to
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsml_hip.so")
+
+c_f32p = ctypes.POINTER(ctypes.c_float)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_void = ctypes.c_void_p
+
+GRAD_HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64)
+
+LOSS_BCE, LOSS_BPR, LOSS_BPR_NORM = 0, 1, 2
+
+
+class MFTables(ctypes.Structure):
+    _fields_ = [("w_user", c_void), ("w_item", c_void), ("last_user", c_void), ("last_item", c_void),
+                ("m_user", c_void), ("v_user", c_void), ("m_item", c_void), ("v_item", c_void),
+                ("step_user", c_void), ("step_item", c_void), ("n_user", ctypes.c_int64), ("n_item", ctypes.c_int64)]
+
+
+class TRTables(ctypes.Structure):
+    _fields_ = [("last_user", c_void), ("last_item", c_void), ("hat_user", c_void), ("hat_item", c_void),
+                ("n_user", ctypes.c_int64), ("n_item", ctypes.c_int64)]
+
+
+# every exported symbol of include/sml_hip.h: name -> (restype, argtypes)
+SIGNATURES = {
+    "sml_last_error": (ctypes.c_char_p, []),
+    "sml_version": (ctypes.c_int, []),
+    "sml_ctx_create": (ctypes.c_int, [ctypes.POINTER(c_void), ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "sml_ctx_destroy": (ctypes.c_int, [c_void]),
+    "sml_theta_net_size": (ctypes.c_int64, [ctypes.c_int]),
+    "sml_theta_offset": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int]),
+    "sml_theta_pack": (ctypes.c_int, [c_void, c_void, c_void]),
+    "sml_transfer_forward": (ctypes.c_int, [c_void, c_void, ctypes.c_int, c_void, c_void, c_void, ctypes.c_int64, c_void]),
+    "sml_mf_stage_epoch": (ctypes.c_int, [c_void, c_void, ctypes.POINTER(MFTables), c_void, ctypes.c_int64, ctypes.c_int,
+                                          ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.POINTER(ctypes.c_int64),
+                                          c_void, c_void]),
+    "sml_mf_adam_flush": (ctypes.c_int, [c_void, ctypes.POINTER(MFTables), ctypes.c_float, ctypes.c_int64, c_void]),
+    "sml_tr_stage_epoch": (ctypes.c_int, [c_void, c_void, c_void, c_void, c_void, ctypes.POINTER(TRTables), c_void,
+                                          ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int,
+                                          ctypes.c_float, ctypes.POINTER(ctypes.c_int64), c_void, GRAD_HOOK, c_void,
+                                          c_void]),
+    "sml_embed_loss_sgd_epoch": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
+                                                c_void, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                                ctypes.c_float, ctypes.c_int, c_void, c_void]),
+    "sml_mf_forward": (ctypes.c_int, [c_void, c_void, c_void, c_void, c_void, ctypes.c_int64, ctypes.c_int, c_void,
+                                      c_void, c_void, c_void]),
+    "sml_eval_ranks": (ctypes.c_int, [c_void, c_void, c_void, c_void, ctypes.c_int64, ctypes.c_int, c_void, c_void]),
+    "sml_eval_metrics": (ctypes.c_int, [c_void, c_void, ctypes.c_int64, ctypes.c_int, c_void, c_void]),
+    "sml_selftest": (ctypes.c_int, [ctypes.c_int]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libsml_hip.so (once). Raises RuntimeError if it is missing or unloadable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libsml_hip.so not found at %s: build it with `python -m sml_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise RuntimeError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class SmlError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().sml_last_error()
+        raise SmlError("%s failed (%d): %s" % (what, rc, msg.decode(errors="replace") if msg else ""))

@@ -1,0 +1,117 @@
+"""Command line of main_yelp.py / main_news.py (reference main_yelp.py:10-172,
+main_news.py:8-232): same flags, defaults, type quirks, seeding order and banner."""
+import argparse
+import os
+
+import numpy as np
+import torch
+
+# (flag, kwargs) in the reference's order.  Quirks kept on purpose: the type=bool flags are
+# True for ANY non-empty string, and Load_W_hat / clip_grad / need_adaptive have no type at
+# all (a value given on the command line arrives as a non-empty, hence truthy, string).
+_COMMON = [
+    ("--data_path", dict(default='/home/sml/dataset/', help='dataset path')),
+    ("--multi_num", dict(type=int, default=10, help='outer loop count (stop condition of SML)')),
+    ("--MF_lr", dict(type=float, default=0.01, help='learning rate of the MF step')),
+    ("--MF_epochs", dict(type=int, default=1, help='epochs of the MF step')),
+    ("--l2", dict(type=float, default=1e-6, help='L2 weight of the MF step')),
+    ("--MF_batch_size", dict(type=int, default=1024, help='batch size of the MF step')),
+    ("--laten", dict(type=int, default=64, help='embedding width')),
+    ("--pre_model", dict(default=None, help='pretrained MF model (whole-module pickle)')),
+    ("--MF_sample", dict(default="all", help='MF negative sampling: all or alone')),
+    ("--Load_W_hat", dict(default=False, help='reload W_hat into MF after transfer training')),
+    ("--clip_grad", dict(default=False, help='(unused in the final reference version)')),
+    ("--need_adaptive", dict(default=False, help='(unused in the final reference version)')),
+    ("--maxnorm_grad", dict(type=float, default=3.0, help='(unused in the final reference version)')),
+    ("--TR_lr", dict(type=float, default=0.001, help='learning rate of the transfer step')),
+    ("--TR_l2", dict(type=float, default=0.0001, help='weight decay of the transfer step')),
+    ("--TR_epochs", dict(type=int, default=1, help='epochs of the transfer step')),
+    ("--TR_batch_size", dict(type=int, default=256, help='batch size of the transfer step')),
+    ("--TR_sample_type", dict(default="alone", help='negatives of the transfer step: all or alone')),
+    ("--TR_with_MF_bias", dict(type=bool, default=False, help='feed the MF bias to the transfer net')),
+    ("--TR_stop_", dict(type=bool, default=False, help='freeze the transfer net during the test periods')),
+    ("--transfer_type", dict(default="conv_com", help='transfer architecture (conv_com)')),
+    ("--seed", dict(type=int, default=2000, help='random seed')),
+    ("--numworkers", dict(type=int, default=4, help='accepted for compatibility; batches are built in-process')),
+    ("--cuda", dict(type=int, default=0, help='which GPU')),
+    ("--topK", dict(type=int, default=20, help='K of the in-training recall/ndcg prints')),
+    ("--pass_num", dict(type=int, default=1, help='offline passes (1 in the final reference version)')),
+    ("--norm", dict(type=bool, default=False, help='(unused in the final reference version)')),
+    ("--Lambda_lr", dict(type=float, default=0.01, help='(unused)')),
+    ("--min_l2", dict(type=float, default=0.0001, help='(unused)')),
+    ("--set_t_as_tt", dict(type=bool, default=False, help='(unused)')),
+    ("--tqdm", dict(type=bool, default=False, help='(unused)')),
+    ("--need_writer", dict(type=bool, default=False, help='tensorboard summaries')),
+    ("--test_in_TR_Train", dict(type=bool, default=False, help='(unused)')),
+]
+
+_PER_DATASET = {
+    "yelp": dict(data_name="yelp", multi_num=10, MF_epochs=1, TR_epochs=1,
+                 pre_model="/home/sml/save_model/sml/yelp/BCE_init.pkl",
+                 periods=40, train_from=10, test_from=30),
+    "news": dict(data_name="news", multi_num=7, MF_epochs=2, TR_epochs=2,
+                 pre_model="/home/sml/save_model/sml/news/BCE_init.pkl",
+                 periods=63, train_from=21, test_from=48),
+}
+
+
+def get_parse(which="yelp"):
+    cfg = _PER_DATASET[which]
+    parser = argparse.ArgumentParser(description='MF and TR(transfer) parameters in our SML.')
+    parser.add_argument('--data_name', default=cfg["data_name"], help='dataset name: yelp or news (i.e Adressa)')
+    for flag, kw in _COMMON:
+        kw = dict(kw)
+        name = flag[2:]
+        if name in cfg:
+            kw["default"] = cfg[name]
+        parser.add_argument(flag, **kw)
+    return parser
+
+
+def _banner(args, which):
+    stars = "*********************  parameters information ****************************************" \
+        if which == "yelp" else "**********  SML parameters ***************"
+    print(stars)
+    print(args)
+    print("stop:", args.TR_stop_)
+    if args.Load_W_hat:
+        print("load w_hat:", args.Load_W_hat)
+    print("TR sample type", args.TR_sample_type)
+    print("MF sample type:", args.MF_sample)
+    print("MF: lr:{},l2:{},batch_size:{},laten:{},epoch:{}".format(args.MF_lr, args.l2, args.MF_batch_size,
+                                                                     args.laten, args.MF_epochs))
+    print("TR: lr:{},l2:{},batch_size:{},epoch:{}".format(args.TR_lr, args.TR_l2, args.TR_batch_size, args.TR_epochs))
+    print("top k:", args.topK)
+    print(stars + ("\n" if which == "yelp" else ""))
+
+
+def main(which, argv=None):
+    from data import dataset2
+    from model import transfer
+
+    cfg = _PER_DATASET[which]
+    args = get_parse(which).parse_args(argv)
+    if which == "yelp" and "LOCAL_RANK" not in os.environ:
+        os.environ["CUDA_VISIBLE_DEVICES"] = str(args.cuda)      # reference main_yelp.py:125
+    if which == "yelp":
+        print("###(multi num,l2)", 10, 1e-06)                     # the reference's (unused) sweep banner
+    # seeding order of the reference (main_yelp.py:137-139)
+    torch.manual_seed(args.seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(args.seed + 1)
+    np.random.seed(args.seed + 2)
+    _banner(args, which)
+    file_list = [str(i) for i in range(0, cfg["periods"])]
+    test_list = [str(j) for j in range(cfg["test_from"], cfg["periods"])]
+    sets = dataset2.transfer_data(args, path=args.data_path, datasetname=args.data_name, file_path_list=file_list,
+                                  test_list=test_list, validation_list=None,
+                                  online_train_time=round(cfg["train_from"]), online_test_time=round(cfg["test_from"]))
+    meta = transfer.meta_train(args, sets, sets.user_number, sets.item_number, args.laten)
+    meta.run(args)
+    if which == "yelp":
+        print("@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@TR:L2:", 1e-06)
+    print("##")
+    print("##")
+    if which == "yelp":
+        print("\n")
+    return meta

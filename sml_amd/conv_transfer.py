@@ -1,0 +1,99 @@
+"""Transfer net: the module surface of the reference's model/conv_transfer.py.
+
+`one_transfer` and `ConvTransfer_com` keep the reference's constructor signatures,
+sub-module names (conv1, conv2, fc1, fc2; user_transfer then item_transfer -- the
+creation order fixes the RNG draw sequence and state_dict keys) and parameter
+shapes, so state_dicts are interchangeable.  The arithmetic runs in libsml_hip.so:
+the engine re-points the parameters into one flat device buffer (HipEngine.adopt)
+and the kernels read it directly.
+"""
+import torch
+import torch.nn as nn
+
+from .engine import get_engine
+
+
+def Gelu(x):
+    """x * sigmoid(1.702 x) -- reference model/conv_transfer.py:9-10 (not erf GELU)."""
+    return x * torch.sigmoid(1.702 * x)
+
+
+class one_transfer(nn.Module):
+    """conv1 (1->10, kernel (k,1)) -> Gelu -> conv2 (10->5, 1x1) -> flatten -> Gelu ->
+    fc1 (5d->512) -> Gelu -> fc2 (512->out).  reference model/conv_transfer.py:18-50.
+    A parameter container: the forward pass is ConvTransfer_com's, on the HIP engine."""
+
+    def __init__(self, input_dim, out_dim, kernel=2):
+        super(one_transfer, self).__init__()
+        self.hidden_dim = input_dim
+        self.out_channel = 10
+        self.conv1 = nn.Conv2d(1, self.out_channel, (kernel, 1), stride=1)
+        self.out_channel2 = 5
+        self.conv2 = nn.Conv2d(self.out_channel, self.out_channel2, (1, 1), stride=1)
+        self.fc1 = nn.Linear(input_dim * self.out_channel2, 512)
+        self.fc2 = nn.Linear(512, out_dim)
+        self.kernel = kernel
+        print("kernel:", kernel)
+
+    def forward(self, x):
+        raise RuntimeError("one_transfer is evaluated through ConvTransfer_com (HIP engine), not stand-alone")
+
+
+class ConvTransfer_com(nn.Module):
+    """reference model/conv_transfer.py:87-135."""
+
+    def __init__(self, in_dim, out_dim):
+        super(ConvTransfer_com, self).__init__()
+        if in_dim != out_dim:
+            raise ValueError("ConvTransfer_com: in_dim must equal out_dim (the reference always passes the same)")
+        self.user_transfer = one_transfer(in_dim, out_dim, kernel=3)
+        self.item_transfer = one_transfer(in_dim, out_dim, kernel=3)
+        self.dim = in_dim
+
+    def _engine(self, like):
+        if like.device.type != "cuda":
+            raise RuntimeError("ConvTransfer_com runs on the HIP engine only: inputs must be on a GPU; "
+                               "there is no CPU path")
+        eng = getattr(self, "_sml_engine", None)
+        return eng if eng is not None else get_engine(like.device, self.dim)
+
+    def forward(self, x_t, x_hat, type):
+        """x_com = x_t * detach(x_hat) / ||x_t||; stack (x_t, x_hat, x_com); run the user or
+        item net.  Inference only (no autograd graph)."""
+        if type not in ("user", "item"):
+            raise TypeError("convtransfer has not this type")
+        return self._engine(x_t).transfer_forward(self, x_t, x_hat, type)
+
+    def run_MF(self, user_weight_last, user_weight_hat, item_weight_last, item_weight_hat, negitem_weight_last,
+               negitem_weight_hat, norm=False, adpative=False, BCE=True):
+        """Loss value of one batch (reference model/conv_transfer.py:113-135): BCE by
+        default, BPR when BCE=False (optionally with score / ||u'||).  Returns a 0-dim
+        tensor without a graph; training goes through HipEngine.*_stage_epoch."""
+        un = self.forward(user_weight_last, user_weight_hat, "user")
+        im = self.forward(item_weight_last, item_weight_hat, "item")
+        nn_ = self.forward(negitem_weight_last, negitem_weight_hat, "item")
+        s_pos = (un * im).sum(-1)
+        s_neg = (un * nn_).sum(-1)
+        if BCE:
+            return -torch.mean(torch.log(torch.sigmoid(s_pos) + 1e-15)) \
+                   - torch.mean(torch.log(1 - torch.sigmoid(s_neg) + 1e-15))
+        score = s_pos - s_neg
+        if norm:
+            score = score / (un ** 2).sum(-1).sqrt()
+        return -torch.sum(torch.nn.functional.logsigmoid(score))
+
+
+def _out_of_scope(name):
+    class _Stub(nn.Module):
+        def __init__(self, *a, **k):
+            raise NotImplementedError(
+                "%s is one of the reference's unused transfer variants (model/conv_transfer.py header: "
+                "'we only use ConvTransfer_com and one_transfer'); it is outside this build's scope" % name)
+    _Stub.__name__ = name
+    return _Stub
+
+
+ConvTransfer = _out_of_scope("ConvTransfer")
+ConvTransfer_com2 = _out_of_scope("ConvTransfer_com2")
+ConvTransfer_com3 = _out_of_scope("ConvTransfer_com3")
+one_transfer_com = _out_of_scope("one_transfer_com")

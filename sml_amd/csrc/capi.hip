@@ -1,0 +1,494 @@
+// C ABI of libsml_hip.so (see include/sml_hip.h): context, scratch, per-epoch launch loops.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sml_hip.h"
+#include "sml_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* what, const char* detail) {
+    g_err = std::string(what) + ": " + (detail ? detail : "");
+    return code;
+}
+#define HIPCHK(expr)                                                                  \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess) return fail(SML_EHIP, #expr, hipGetErrorString(_e));    \
+    } while (0)
+
+struct DevGuard {
+    int prev = -1;
+    bool changed = false;
+    explicit DevGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) changed = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DevGuard() { if (changed) (void)hipSetDevice(prev); }
+};
+
+template <typename T>
+struct Buf {
+    T* p = nullptr;
+    size_t cap = 0;   // elements
+    hipError_t ensure(size_t need) {
+        if (need <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = need + need / 8;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
+        if (e != hipSuccess) return e;
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+bool d_ok(int d) { return d == 32 || d == 64 || d == 128; }
+
+}  // namespace
+
+struct sml_ctx {
+    int device = 0, d = 32, max_batch = 0;
+    // transfer-net workspaces, 3*B slots each
+    Buf<float> out, dout, dx, xin, z1, a1, dz1;
+    Buf<float> pk, grad, convg, loss_part;
+    // sorted occurrence lists of an epoch
+    Buf<uint64_t> key_u, key_u2, key_i, key_i2;
+    Buf<uint32_t> val_u, val_u2, val_i, val_i2;
+    Buf<char> cub_tmp;
+    // Adam schedule of the MF optimiser
+    Buf<SmlSched> sched;
+    int sched_len = 0;
+    float sched_lr = -1.0f;
+    Buf<int32_t> dummy;
+
+    void release_all() {
+        out.release(); dout.release(); dx.release(); xin.release(); z1.release(); a1.release(); dz1.release();
+        pk.release(); grad.release(); convg.release(); loss_part.release();
+        key_u.release(); key_u2.release(); key_i.release(); key_i2.release();
+        val_u.release(); val_u2.release(); val_i.release(); val_i2.release();
+        cub_tmp.release(); sched.release(); dummy.release();
+    }
+};
+
+namespace {
+
+// step_size / bc2_sqrt exactly as torch.optim.Adam computes them on the host (double), rounded once
+SmlSched sched_entry(double lr, int64_t k) {
+    SmlSched s;
+    if (k <= 0) { s.step_size = 0.f; s.bc2_sqrt = 1.f; return s; }
+    const double bc1 = 1.0 - std::pow((double)0.9, (double)k);
+    const double bc2 = 1.0 - std::pow((double)0.999, (double)k);
+    s.step_size = (float)(lr / bc1);
+    s.bc2_sqrt = (float)std::sqrt(bc2);
+    return s;
+}
+
+int ensure_sched(sml_ctx* c, float lr, int64_t upto) {
+    if (c->sched_lr == lr && upto < c->sched_len) return SML_OK;
+    int64_t len = c->sched_len > 0 && c->sched_lr == lr ? c->sched_len : 0;
+    while (len <= upto) len = len ? len * 2 : 65536;
+    if (len > (int64_t)1 << 30) return fail(SML_EINVAL, "adam schedule", "step counter too large");
+    std::vector<SmlSched> h((size_t)len);
+    for (int64_t k = 0; k < len; ++k) h[(size_t)k] = sched_entry((double)lr, k);
+    // growth is rare; a blocking copy keeps the host buffer's lifetime trivial
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(c->sched.ensure((size_t)len));
+    HIPCHK(hipMemcpy(c->sched.p, h.data(), (size_t)len * sizeof(SmlSched), hipMemcpyHostToDevice));
+    c->sched_len = (int)len;
+    c->sched_lr = lr;
+    return SML_OK;
+}
+
+int ensure_transfer_ws(sml_ctx* c, int B, bool tr_stage) {
+    const size_t slots = (size_t)3 * B, d = (size_t)c->d;
+    HIPCHK(c->out.ensure(slots * d));
+    HIPCHK(c->dout.ensure(slots * d));
+    HIPCHK(c->xin.ensure(slots * 3 * d));
+    HIPCHK(c->z1.ensure(slots * SML_HID));
+    if (tr_stage) {
+        HIPCHK(c->a1.ensure(slots * SML_C2 * d));
+        HIPCHK(c->dz1.ensure(slots * SML_HID));
+        HIPCHK(c->convg.ensure((slots / SML_R + 4) * 104));
+        HIPCHK(c->grad.ensure((size_t)2 * sml_net_size(c->d)));
+    } else {
+        HIPCHK(c->dx.ensure(slots * d));
+    }
+    return SML_OK;
+}
+
+int ensure_pk(sml_ctx* c) {
+    HIPCHK(c->pk.ensure((size_t)2 * sml_pk_size(c->d)));
+    return SML_OK;
+}
+
+int ceil_log2(int64_t x) { int b = 0; while (((int64_t)1 << b) < x) ++b; return b; }
+
+// sort every batch's occurrences by row (stable): users [n], items [2n]
+int sort_epoch(sml_ctx* c, const int64_t* tri, int64_t n, int batch, hipStream_t st) {
+    HIPCHK(c->key_u.ensure((size_t)n)); HIPCHK(c->key_u2.ensure((size_t)n));
+    HIPCHK(c->val_u.ensure((size_t)n)); HIPCHK(c->val_u2.ensure((size_t)n));
+    HIPCHK(c->key_i.ensure((size_t)2 * n)); HIPCHK(c->key_i2.ensure((size_t)2 * n));
+    HIPCHK(c->val_i.ensure((size_t)2 * n)); HIPCHK(c->val_i2.ensure((size_t)2 * n));
+    HIPCHK(sml_launch_build_keys(tri, n, batch, c->key_u.p, c->val_u.p, c->key_i.p, c->val_i.p, st));
+    const int64_t nb = (n + batch - 1) / batch;
+    const int end_bit = 32 + ceil_log2(nb + 1);
+    size_t tmp1 = 0, tmp2 = 0;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp1, c->key_u.p, c->key_u2.p, c->val_u.p, c->val_u2.p, (int)n, 0,
+                                              end_bit, st));
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, c->key_i.p, c->key_i2.p, c->val_i.p, c->val_i2.p,
+                                              (int)(2 * n), 0, end_bit, st));
+    size_t tmp = tmp1 > tmp2 ? tmp1 : tmp2;
+    HIPCHK(c->cub_tmp.ensure(tmp + 256));
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tmp, c->key_u.p, c->key_u2.p, c->val_u.p, c->val_u2.p, (int)n,
+                                              0, end_bit, st));
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tmp, c->key_i.p, c->key_i2.p, c->val_i.p, c->val_i2.p,
+                                              (int)(2 * n), 0, end_bit, st));
+    return SML_OK;
+}
+
+int tiles_of(int rows) { return (rows + SML_R - 1) / SML_R; }
+
+}  // namespace
+
+extern "C" {
+
+const char* sml_last_error(void) { return g_err.c_str(); }
+int sml_version(void) { return 1; }
+
+int64_t sml_theta_net_size(int d) { return d_ok(d) ? sml_net_size(d) : -1; }
+int64_t sml_theta_offset(int d, int which) {
+    if (!d_ok(d)) return -1;
+    switch (which) {
+        case 0: return SML_OFF_C1W;
+        case 1: return SML_OFF_C1B;
+        case 2: return SML_OFF_C2W;
+        case 3: return SML_OFF_C2B;
+        case 4: return SML_OFF_F1W;
+        case 5: return sml_off_f1b(d);
+        case 6: return sml_off_f2w(d);
+        case 7: return sml_off_f2b(d);
+        default: return -1;
+    }
+}
+
+int sml_ctx_create(sml_ctx** out, int device, int d, int max_batch) {
+    if (!out || !d_ok(d) || max_batch <= 0) return fail(SML_EINVAL, "sml_ctx_create", "d must be 32/64/128, max_batch > 0");
+    int n_dev = 0;
+    HIPCHK(hipGetDeviceCount(&n_dev));
+    if (device < 0 || device >= n_dev) return fail(SML_EINVAL, "sml_ctx_create", "no such device");
+    sml_ctx* c = new (std::nothrow) sml_ctx();
+    if (!c) return fail(SML_ENOMEM, "sml_ctx_create", "host allocation");
+    c->device = device; c->d = d; c->max_batch = max_batch;
+    *out = c;
+    return SML_OK;
+}
+
+int sml_ctx_destroy(sml_ctx* ctx) {
+    if (!ctx) return SML_OK;
+    { DevGuard g(ctx->device); ctx->release_all(); }
+    delete ctx;
+    return SML_OK;
+}
+
+int sml_theta_pack(sml_ctx* ctx, const float* theta, void* stream) {
+    if (!ctx || !theta) return fail(SML_EINVAL, "sml_theta_pack", "null argument");
+    DevGuard g(ctx->device);
+    int rc = ensure_pk(ctx); if (rc) return rc;
+    HIPCHK(sml_launch_theta_pack(ctx->d, theta, ctx->pk.p, (hipStream_t)stream));
+    return SML_OK;
+}
+
+int sml_transfer_forward(sml_ctx* ctx, const float* theta, int net, const float* x_t, const float* x_hat, float* out,
+                         int64_t n_rows, void* stream) {
+    if (!ctx || !theta || !x_t || !x_hat || !out || (net != 0 && net != 1) || n_rows < 0 || n_rows > 0x7fffffff)
+        return fail(SML_EINVAL, "sml_transfer_forward", "bad argument");
+    if (n_rows == 0) return SML_OK;
+    DevGuard g(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = ensure_pk(ctx); if (rc) return rc;
+    HIPCHK(sml_launch_theta_pack(ctx->d, theta, ctx->pk.p, st));
+    SmlFwdArgs a;
+    memset(&a, 0, sizeof(a));
+    SmlSeg& s = a.seg[0];
+    s.theta = theta + (int64_t)net * sml_net_size(ctx->d);
+    s.pk = ctx->pk.p + (int64_t)net * sml_pk_size(ctx->d);
+    s.xt_tab = x_t; s.xh_tab = x_hat; s.n_rows = (int)n_rows; s.out = out;
+    a.tiles0 = tiles_of((int)n_rows);
+    a.seg[1] = s; a.seg[1].n_rows = 0;
+    HIPCHK(sml_launch_fwd(ctx->d, a, a.tiles0, st));
+    return SML_OK;
+}
+
+int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t, const int64_t* triples, int64_t n,
+                       int batch, float lr, float l2, int loss_kind, int64_t* step, float* batch_loss, void* stream) {
+    if (!ctx || !theta || !t || !triples || !step || !batch_loss || n <= 0 || batch <= 0)
+        return fail(SML_EINVAL, "sml_mf_stage_epoch", "bad argument");
+    if (batch > ctx->max_batch) return fail(SML_EINVAL, "sml_mf_stage_epoch", "batch exceeds ctx max_batch");
+    if (n > 0x3fffffff) return fail(SML_EINVAL, "sml_mf_stage_epoch", "epoch too long");
+    if (loss_kind < 0 || loss_kind > 2) return fail(SML_EINVAL, "sml_mf_stage_epoch", "loss_kind");
+    DevGuard g(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    const int d = ctx->d;
+    const int64_t nb = (n + batch - 1) / batch;
+    int rc;
+    if ((rc = ensure_pk(ctx))) return rc;
+    if ((rc = ensure_transfer_ws(ctx, batch, false))) return rc;
+    if ((rc = ensure_sched(ctx, lr, *step + nb + 1))) return rc;
+    const int lstride = (batch * (d / 4) + 255) / 256;
+    HIPCHK(ctx->loss_part.ensure((size_t)nb * lstride));
+    HIPCHK(sml_launch_theta_pack(d, theta, ctx->pk.p, st));
+    if ((rc = sort_epoch(ctx, triples, n, batch, st))) return rc;
+    HIPCHK(hipMemsetAsync(ctx->loss_part.p, 0, (size_t)nb * lstride * sizeof(float), st));
+    const int64_t ns = sml_net_size(d), ps = sml_pk_size(d);
+    for (int64_t b = 0; b < nb; ++b) {
+        const int B = (int)((n - b * batch) < batch ? (n - b * batch) : batch);
+        const int64_t* tri = triples + b * batch * 3;
+        const int cur = (int)(*step + 1 + b);
+        SmlFwdArgs f;
+        memset(&f, 0, sizeof(f));
+        for (int s = 0; s < 2; ++s) {
+            SmlSeg& sg = f.seg[s];
+            sg.theta = theta + s * ns; sg.pk = ctx->pk.p + s * ps;
+            sg.xt_tab = s ? t->last_item : t->last_user;
+            sg.xh_tab = s ? t->w_item : t->w_user;
+            sg.m_tab = s ? t->m_item : t->m_user; sg.v_tab = s ? t->v_item : t->v_user;
+            sg.last_tab = s ? t->step_item : t->step_user;
+            sg.tri = tri; sg.B = B; sg.is_item = s; sg.n_rows = s ? 2 * B : B;
+            const int64_t slot0 = s ? B : 0;
+            sg.out = ctx->out.p + slot0 * d; sg.z1 = ctx->z1.p + slot0 * SML_HID; sg.xin = ctx->xin.p + slot0 * 3 * d;
+            sg.a1 = nullptr;
+        }
+        f.tiles0 = tiles_of(B); f.cur_step = cur; f.sched = ctx->sched.p;
+        const int tiles = f.tiles0 + tiles_of(2 * B);
+        HIPCHK(sml_launch_fwd(d, f, tiles, st));
+        SmlLossArgs L;
+        L.out = ctx->out.p; L.xin = ctx->xin.p; L.dout = ctx->dout.p; L.loss_part = ctx->loss_part.p + b * lstride;
+        L.B = B; L.kind = loss_kind; L.l2 = l2; L.scale = 1.0f;
+        HIPCHK(sml_launch_pair_loss(d, L, nullptr, st));
+        SmlBwdArgs w;
+        memset(&w, 0, sizeof(w));
+        for (int s = 0; s < 2; ++s) {
+            SmlBwdSeg& sg = w.seg[s];
+            const int64_t slot0 = s ? B : 0;
+            sg.theta = theta + s * ns; sg.pk = ctx->pk.p + s * ps;
+            sg.dout = ctx->dout.p + slot0 * d; sg.z1 = ctx->z1.p + slot0 * SML_HID; sg.xin = ctx->xin.p + slot0 * 3 * d;
+            sg.dx = ctx->dx.p + slot0 * d; sg.dz1 = nullptr; sg.n_rows = s ? 2 * B : B;
+        }
+        w.tiles0 = f.tiles0; w.l2 = l2; w.convg_part = nullptr;
+        HIPCHK(sml_launch_bwd(d, w, tiles, st));
+        SmlSegUpdArgs u;
+        memset(&u, 0, sizeof(u));
+        u.key_u = ctx->key_u2.p + b * batch; u.val_u = ctx->val_u2.p + b * batch; u.n_u = B;
+        u.key_i = ctx->key_i2.p + 2 * b * batch; u.val_i = ctx->val_i2.p + 2 * b * batch; u.n_i = 2 * B;
+        u.dx = ctx->dx.p; u.w_user = t->w_user; u.w_item = t->w_item;
+        u.m_user = t->m_user; u.v_user = t->v_user; u.m_item = t->m_item; u.v_item = t->v_item;
+        u.last_user = t->step_user; u.last_item = t->step_item; u.sched = ctx->sched.p; u.cur_step = cur; u.lr = lr;
+        HIPCHK(sml_launch_seg_adam(d, u, st));
+    }
+    HIPCHK(sml_launch_loss_finalize(ctx->loss_part.p, (int)nb, lstride, nullptr, batch_loss, st));
+    *step += nb;
+    return SML_OK;
+}
+
+int sml_mf_adam_flush(sml_ctx* ctx, const sml_mf_tables* t, float lr, int64_t step, void* stream) {
+    if (!ctx || !t || step < 0) return fail(SML_EINVAL, "sml_mf_adam_flush", "bad argument");
+    if (step == 0) return SML_OK;
+    DevGuard g(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = ensure_sched(ctx, lr, step + 1))) return rc;
+    HIPCHK(sml_launch_adam_flush(ctx->d, t->w_user, t->m_user, t->v_user, t->step_user, t->n_user, ctx->sched.p, (int)step, st));
+    HIPCHK(sml_launch_adam_flush(ctx->d, t->w_item, t->m_item, t->v_item, t->step_item, t->n_item, ctx->sched.p, (int)step, st));
+    return SML_OK;
+}
+
+int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v, float* theta_grad,
+                       const sml_tr_tables* t, const int64_t* triples, int64_t n, int batch, float lr,
+                       float weight_decay, int loss_kind, float loss_scale, int64_t* step, float* batch_loss,
+                       sml_grad_hook grad_hook, void* hook_user, void* stream) {
+    if (!ctx || !theta || !adam_m || !adam_v || !t || !triples || !step || !batch_loss || n <= 0 || batch <= 0)
+        return fail(SML_EINVAL, "sml_tr_stage_epoch", "bad argument");
+    if (batch > ctx->max_batch) return fail(SML_EINVAL, "sml_tr_stage_epoch", "batch exceeds ctx max_batch");
+    if (loss_kind < 0 || loss_kind > 2) return fail(SML_EINVAL, "sml_tr_stage_epoch", "loss_kind");
+    DevGuard g(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    const int d = ctx->d;
+    const int64_t nb = (n + batch - 1) / batch;
+    int rc;
+    if ((rc = ensure_pk(ctx))) return rc;
+    if ((rc = ensure_transfer_ws(ctx, batch, true))) return rc;
+    float* grad = theta_grad ? theta_grad : ctx->grad.p;
+    const int lstride = (batch * (d / 4) + 255) / 256;
+    HIPCHK(ctx->loss_part.ensure((size_t)nb * lstride));
+    HIPCHK(sml_launch_theta_pack(d, theta, ctx->pk.p, st));
+    HIPCHK(hipMemsetAsync(ctx->loss_part.p, 0, (size_t)nb * lstride * sizeof(float), st));
+    HIPCHK(hipMemsetAsync(grad, 0, (size_t)2 * sml_net_size(d) * sizeof(float), st));
+    const int64_t ns = sml_net_size(d), ps = sml_pk_size(d);
+    for (int64_t b = 0; b < nb; ++b) {
+        const int B = (int)((n - b * batch) < batch ? (n - b * batch) : batch);
+        const int64_t* tri = triples + b * batch * 3;
+        SmlFwdArgs f;
+        memset(&f, 0, sizeof(f));
+        for (int s = 0; s < 2; ++s) {
+            SmlSeg& sg = f.seg[s];
+            sg.theta = theta + s * ns; sg.pk = ctx->pk.p + s * ps;
+            sg.xt_tab = s ? t->last_item : t->last_user;
+            sg.xh_tab = s ? t->hat_item : t->hat_user;
+            sg.tri = tri; sg.B = B; sg.is_item = s; sg.n_rows = s ? 2 * B : B;
+            const int64_t slot0 = s ? B : 0;
+            sg.out = ctx->out.p + slot0 * d; sg.z1 = ctx->z1.p + slot0 * SML_HID; sg.xin = ctx->xin.p + slot0 * 3 * d;
+            sg.a1 = ctx->a1.p + slot0 * SML_C2 * d;
+        }
+        f.tiles0 = tiles_of(B); f.cur_step = 0; f.sched = nullptr;
+        const int tiles = f.tiles0 + tiles_of(2 * B);
+        HIPCHK(sml_launch_fwd(d, f, tiles, st));
+        SmlLossArgs L;
+        L.out = ctx->out.p; L.xin = nullptr; L.dout = ctx->dout.p; L.loss_part = ctx->loss_part.p + b * lstride;
+        L.B = B; L.kind = loss_kind; L.l2 = 0.0f; L.scale = loss_scale;
+        HIPCHK(sml_launch_pair_loss(d, L, nullptr, st));
+        SmlBwdArgs w;
+        memset(&w, 0, sizeof(w));
+        SmlWgArgs wg;
+        memset(&wg, 0, sizeof(wg));
+        for (int s = 0; s < 2; ++s) {
+            SmlBwdSeg& sg = w.seg[s];
+            const int64_t slot0 = s ? B : 0;
+            sg.theta = theta + s * ns; sg.pk = ctx->pk.p + s * ps;
+            sg.dout = ctx->dout.p + slot0 * d; sg.z1 = ctx->z1.p + slot0 * SML_HID; sg.xin = ctx->xin.p + slot0 * 3 * d;
+            sg.dx = nullptr; sg.dz1 = ctx->dz1.p + slot0 * SML_HID; sg.n_rows = s ? 2 * B : B;
+            SmlWgSeg& q = wg.seg[s];
+            q.dz1 = sg.dz1; q.a1 = ctx->a1.p + slot0 * SML_C2 * d; q.dout = sg.dout; q.z1 = sg.z1;
+            q.grad = grad + s * ns; q.n_rows = sg.n_rows;
+        }
+        w.tiles0 = f.tiles0; w.l2 = 0.0f; w.convg_part = ctx->convg.p;
+        HIPCHK(sml_launch_bwd(d, w, tiles, st));
+        HIPCHK(sml_launch_wgrad(d, wg, st));
+        SmlThetaAdamArgs ad;
+        memset(&ad, 0, sizeof(ad));
+        const SmlSched sc = sched_entry((double)lr, *step + 1 + b);
+        ad.theta = theta; ad.m = adam_m; ad.v = adam_v; ad.grad = grad; ad.pk = ctx->pk.p;
+        ad.convg_part = ctx->convg.p; ad.tiles0 = f.tiles0; ad.tiles_total = tiles;
+        ad.weight_decay = weight_decay; ad.step_size = sc.step_size; ad.bc2_sqrt = sc.bc2_sqrt;
+        if (grad_hook) {
+            ad.grad_only = 1;
+            HIPCHK(sml_launch_theta_adam(d, ad, st));
+            const int hr = grad_hook(hook_user, grad, 2 * ns, b);
+            if (hr != 0) return fail(SML_ESTATE, "sml_tr_stage_epoch", "grad_hook failed");
+            ad.grad_only = 0; ad.convg_part = nullptr;
+            HIPCHK(sml_launch_theta_adam(d, ad, st));
+        } else {
+            ad.grad_only = 0;
+            HIPCHK(sml_launch_theta_adam(d, ad, st));
+        }
+    }
+    HIPCHK(sml_launch_loss_finalize(ctx->loss_part.p, (int)nb, lstride, nullptr, batch_loss, st));
+    *step += nb;
+    return SML_OK;
+}
+
+int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n_user, int64_t n_item, int dtype_bytes,
+                             const int64_t* triples, int64_t n, int batch, float lr, float lam_user, float lam_item,
+                             int loss_kind, float* batch_loss, void* stream) {
+    if (!ctx || !w_user || !w_item || !triples || !batch_loss || n <= 0 || batch <= 0 || n_user <= 0 || n_item <= 0)
+        return fail(SML_EINVAL, "sml_embed_loss_sgd_epoch", "bad argument");
+    if (dtype_bytes != 4 && dtype_bytes != 2) return fail(SML_EINVAL, "sml_embed_loss_sgd_epoch", "dtype_bytes must be 4 or 2");
+    if (loss_kind != SML_LOSS_BCE && loss_kind != SML_LOSS_BPR) return fail(SML_EINVAL, "sml_embed_loss_sgd_epoch", "loss_kind");
+    if (batch > ctx->max_batch) return fail(SML_EINVAL, "sml_embed_loss_sgd_epoch", "batch exceeds ctx max_batch");
+    if (n > 0x3fffffff) return fail(SML_EINVAL, "sml_embed_loss_sgd_epoch", "epoch too long");
+    DevGuard g(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    const int d = ctx->d;
+    const int64_t nb = (n + batch - 1) / batch;
+    int rc;
+    HIPCHK(ctx->dx.ensure((size_t)3 * batch * d));
+    const int lpr = d * dtype_bytes / 16;
+    const int lstride = (int)(((int64_t)batch * lpr + 255) / 256);
+    HIPCHK(ctx->loss_part.ensure((size_t)nb * lstride));
+    if ((rc = sort_epoch(ctx, triples, n, batch, st))) return rc;
+    HIPCHK(hipMemsetAsync(ctx->loss_part.p, 0, (size_t)nb * lstride * sizeof(float), st));
+    for (int64_t b = 0; b < nb; ++b) {
+        const int B = (int)((n - b * batch) < batch ? (n - b * batch) : batch);
+        SmlBareArgs a;
+        a.w_user = w_user; a.w_item = w_item; a.tri = triples + b * batch * 3; a.B = B; a.dx = ctx->dx.p;
+        a.loss_part = ctx->loss_part.p + b * lstride; a.kind = loss_kind; a.lam_user = lam_user; a.lam_item = lam_item;
+        HIPCHK(sml_launch_bare_grad(d, dtype_bytes, a, nullptr, st));
+        SmlSegUpdArgs u;
+        memset(&u, 0, sizeof(u));
+        u.key_u = ctx->key_u2.p + b * batch; u.val_u = ctx->val_u2.p + b * batch; u.n_u = B;
+        u.key_i = ctx->key_i2.p + 2 * b * batch; u.val_i = ctx->val_i2.p + 2 * b * batch; u.n_i = 2 * B;
+        u.dx = ctx->dx.p; u.w_user = w_user; u.w_item = w_item; u.lr = lr;
+        HIPCHK(sml_launch_seg_sgd(d, dtype_bytes, u, st));
+    }
+    HIPCHK(sml_launch_loss_finalize(ctx->loss_part.p, (int)nb, lstride, nullptr, batch_loss, st));
+    return SML_OK;
+}
+
+int sml_mf_forward(sml_ctx* ctx, const float* w_user, const float* w_item, const int64_t* user, const int64_t* item,
+                   int64_t n, int norm, float* uemb, float* iemb, float* score, void* stream) {
+    if (!ctx || !w_user || !w_item || !user || !item || !uemb || !iemb || !score || n < 0)
+        return fail(SML_EINVAL, "sml_mf_forward", "bad argument");
+    if (n == 0) return SML_OK;
+    DevGuard g(ctx->device);
+    HIPCHK(sml_launch_mf_forward(ctx->d, w_user, w_item, user, item, n, norm, uemb, iemb, score, (hipStream_t)stream));
+    return SML_OK;
+}
+
+int sml_eval_ranks(sml_ctx* ctx, const float* w_user, const float* w_item, const int64_t* rows, int64_t n, int n_cols,
+                   int32_t* rank, void* stream) {
+    if (!ctx || !w_user || !w_item || !rows || !rank || n < 0 || n_cols < 2)
+        return fail(SML_EINVAL, "sml_eval_ranks", "bad argument");
+    if (n == 0) return SML_OK;
+    DevGuard g(ctx->device);
+    HIPCHK(sml_launch_eval_ranks(ctx->d, w_user, w_item, rows, n, n_cols, rank, (hipStream_t)stream));
+    return SML_OK;
+}
+
+int sml_eval_metrics(sml_ctx* ctx, const int32_t* rank, int64_t n, int topk, float* out, void* stream) {
+    if (!ctx || !rank || !out || n < 0) return fail(SML_EINVAL, "sml_eval_metrics", "bad argument");
+    DevGuard g(ctx->device);
+    HIPCHK(sml_launch_eval_metrics(rank, n, topk, out, (hipStream_t)stream));
+    return SML_OK;
+}
+
+int sml_selftest(int device) {
+    DevGuard g(device);
+    const int M = 32, K = 16;
+    std::vector<float> A(M * K), W(M * K), ref(M * M, 0.f), got(M * M, 0.f);
+    for (int i = 0; i < M * K; ++i) {
+        A[i] = (float)((i * 37 + 11) % 23) - 11.0f;          // asymmetric integer data: exact in fp32
+        W[i] = (float)((i * 53 + 5) % 19) - 9.0f + (float)(i / K);
+    }
+    for (int r = 0; r < M; ++r)
+        for (int c = 0; c < M; ++c) {
+            float s = 0.f;
+            for (int k = 0; k < K; ++k) s += A[r * K + k] * W[c * K + k];
+            ref[r * M + c] = s;
+        }
+    float *dA = nullptr, *dW = nullptr, *dP = nullptr, *dO = nullptr;
+    HIPCHK(hipMalloc((void**)&dA, A.size() * 4)); HIPCHK(hipMalloc((void**)&dW, W.size() * 4));
+    HIPCHK(hipMalloc((void**)&dP, 512 * 4)); HIPCHK(hipMalloc((void**)&dO, got.size() * 4));
+    HIPCHK(hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dW, W.data(), W.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(sml_launch_selftest(dA, dW, dP, dO, nullptr));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(got.data(), dO, got.size() * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(dA); (void)hipFree(dW); (void)hipFree(dP); (void)hipFree(dO);
+    for (int i = 0; i < M * M; ++i)
+        if (got[i] != ref[i]) {
+            char buf[128];
+            snprintf(buf, sizeof(buf), "element (%d,%d): got %g want %g", i / M, i % M, got[i], ref[i]);
+            return fail(SML_ESTATE, "sml_selftest: MFMA lane map mismatch", buf);
+        }
+    return SML_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,474 @@
+// Embedding-row kernels for gfx950: pair loss (BCE/BPR), the bare fused embed+loss
+// gradient pass, deterministic segmented SGD / lazy-Adam row updates, Adam flush,
+// MFbasemode.forward and the evaluation rank kernel.
+//
+// Row access pattern: a row of d elements is owned by LPR = d*sizeof(T)/16 adjacent
+// lanes, 16 bytes per lane, so every gather is a set of full 128/256-byte line reads
+// and a wavefront carries 64/LPR rows at once; dot products finish with xor-shuffles
+// inside the lane group (no LDS).
+#include <hip/hip_fp16.h>
+#include "sml_dev.h"
+#include "sml_kernels.h"
+#include "../../include/sml_hip.h"
+
+namespace {
+
+template <typename T> struct RowVec;
+template <> struct RowVec<float> {
+    static constexpr int VEC = 4;
+    __device__ static void load(const float* p, float (&x)[4]) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+        x[0] = v[0]; x[1] = v[1]; x[2] = v[2]; x[3] = v[3];
+    }
+    __device__ static void store(float* p, const float (&x)[4]) {
+        f32x4 v; v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+        *reinterpret_cast<f32x4*>(p) = v;
+    }
+};
+template <> struct RowVec<__half> {
+    static constexpr int VEC = 8;
+    __device__ static void load(const __half* p, float (&x)[8]) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(p);
+        const __half2* h = reinterpret_cast<const __half2*>(&raw);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float2 f = __half22float2(h[i]); x[2 * i] = f.x; x[2 * i + 1] = f.y; }
+    }
+    __device__ static void store(__half* p, const float (&x)[8]) {
+        uint4 raw;
+        __half2* h = reinterpret_cast<__half2*>(&raw);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h[i] = __floats2half2_rn(x[2 * i], x[2 * i + 1]);
+        *reinterpret_cast<uint4*>(p) = raw;
+    }
+};
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int off = LPR / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// deterministic 256-thread block sum; result valid in thread 0
+__device__ __forceinline__ float block_sum256(float v, float* sh4) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh4[0] + sh4[1] + sh4[2] + sh4[3];
+}
+
+// loss term and d loss / d s_pos, d loss / d s_neg for one pair
+// BCE: model/conv_transfer.py:124-126 (means over the batch -> inv_b); BPR: :128-134 (sum)
+__device__ __forceinline__ void pair_terms(int kind, float sp, float sn, float inv_b, float& lt, float& dsp,
+                                           float& dsn) {
+    if (kind == SML_LOSS_BCE) {
+        const float gp = sml_sigmoid(sp), gn = sml_sigmoid(sn);
+        const float ap = gp + 1e-15f, an = (1.0f - gn) + 1e-15f;
+        lt = -(logf(ap) + logf(an)) * inv_b;
+        dsp = -inv_b * gp * (1.0f - gp) / ap;
+        dsn = inv_b * gn * (1.0f - gn) / an;
+    } else {
+        const float x = sp - sn;
+        // -logsigmoid(x) = max(-x,0) + log1p(exp(-|x|))
+        lt = fmaxf(-x, 0.0f) + log1pf(expf(-fabsf(x)));
+        const float g = -sml_sigmoid(-x);
+        dsp = g;
+        dsn = -g;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// pair loss on transferred rows: out = [u' | i' | n'] -> dout, loss partials (+ l2 term)
+// ------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void k_pair_loss(SmlLossArgs a) {
+    constexpr int LPR = D / 4;
+    __shared__ float sh4[4];
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int t = gid / LPR, sub = gid % LPR;
+    float contrib = 0.0f;
+    if (t < a.B) {
+        float u[4], it[4], ng[4];
+        RowVec<float>::load(a.out + (int64_t)t * D + sub * 4, u);
+        RowVec<float>::load(a.out + (int64_t)(a.B + t) * D + sub * 4, it);
+        RowVec<float>::load(a.out + (int64_t)(2 * a.B + t) * D + sub * 4, ng);
+        float sp = 0.f, sn = 0.f, uu = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { sp += u[k] * it[k]; sn += u[k] * ng[k]; uu += u[k] * u[k]; }
+        sp = group_sum<LPR>(sp); sn = group_sum<LPR>(sn);
+        float lt, dsp, dsn;
+        float du[4], di[4], dn[4];
+        if (a.kind == SML_LOSS_BPR_NORM) {
+            uu = group_sum<LPR>(uu);
+            const float nu = sqrtf(uu);
+            float d0, d1;
+            pair_terms(SML_LOSS_BPR, (sp - sn) / nu, 0.0f, 1.0f, lt, d0, d1);
+            const float c = (sp - sn) / (nu * nu * nu);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                du[k] = a.scale * d0 * ((it[k] - ng[k]) / nu - c * u[k]);
+                di[k] = a.scale * d0 * u[k] / nu;
+                dn[k] = -di[k];
+            }
+        } else {
+            pair_terms(a.kind, sp, sn, 1.0f / (float)a.B, lt, dsp, dsn);
+            dsp *= a.scale; dsn *= a.scale;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { du[k] = dsp * it[k] + dsn * ng[k]; di[k] = dsp * u[k]; dn[k] = dsn * u[k]; }
+        }
+        RowVec<float>::store(a.dout + (int64_t)t * D + sub * 4, du);
+        RowVec<float>::store(a.dout + (int64_t)(a.B + t) * D + sub * 4, di);
+        RowVec<float>::store(a.dout + (int64_t)(2 * a.B + t) * D + sub * 4, dn);
+        if (sub == 0) contrib = lt * a.scale;
+        if (a.xin != nullptr) {   // + l2 * 0.5 * sum(u_hat^2 + i_hat^2 + n_hat^2)   (model/transfer.py:486-488)
+            float x[4], s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+                RowVec<float>::load(a.xin + ((int64_t)(w * a.B + t) * 3 + 1) * D + sub * 4, x);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s += x[k] * x[k];
+            }
+            contrib += 0.5f * a.l2 * s * a.scale;
+        }
+    }
+    const float tot = block_sum256(contrib, sh4);
+    if (threadIdx.x == 0) a.loss_part[blockIdx.x] = tot;
+}
+
+__global__ void k_loss_finalize(const float* __restrict__ part, int n_batches, int stride, float* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_batches) return;
+    float s = 0.0f;
+    for (int i = 0; i < stride; ++i) s += part[(int64_t)b * stride + i];
+    out[b] = s;
+}
+
+// ------------------------------------------------------------------------------------
+// bare fused embed + loss gradient pass: gather u,i,j rows, two dot
+// products, loss, per-occurrence gradient rows.  model/baseline.py:188-201 (BCE),
+// model/MF.py:139-144 without biases (BPR).
+// ------------------------------------------------------------------------------------
+template <int D, typename T>
+__global__ __launch_bounds__(256) void k_bare_grad(SmlBareArgs a) {
+    constexpr int VEC = RowVec<T>::VEC;
+    constexpr int LPR = D / VEC;
+    __shared__ float sh4[4];
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int t = gid / LPR, sub = gid % LPR;
+    float contrib = 0.0f;
+    if (t < a.B) {
+        const int64_t iu = a.tri[(int64_t)t * 3], ii = a.tri[(int64_t)t * 3 + 1], in = a.tri[(int64_t)t * 3 + 2];
+        float u[VEC], it[VEC], ng[VEC];
+        RowVec<T>::load(reinterpret_cast<const T*>(a.w_user) + iu * D + sub * VEC, u);
+        RowVec<T>::load(reinterpret_cast<const T*>(a.w_item) + ii * D + sub * VEC, it);
+        RowVec<T>::load(reinterpret_cast<const T*>(a.w_item) + in * D + sub * VEC, ng);
+        float sp = 0.f, sn = 0.f, sq_u = 0.f, sq_i = 0.f;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            sp += u[k] * it[k]; sn += u[k] * ng[k];
+            sq_u += u[k] * u[k]; sq_i += it[k] * it[k] + ng[k] * ng[k];
+        }
+        sp = group_sum<LPR>(sp); sn = group_sum<LPR>(sn);
+        float lt, dsp, dsn;
+        pair_terms(a.kind, sp, sn, 1.0f / (float)a.B, lt, dsp, dsn);
+        float* gu = a.dx + (int64_t)t * D + sub * VEC;
+        float* gi = a.dx + (int64_t)(a.B + t) * D + sub * VEC;
+        float* gn = a.dx + (int64_t)(2 * a.B + t) * D + sub * VEC;
+#pragma unroll
+        for (int h = 0; h < VEC / 4; ++h) {
+            float x[4], y[4], z[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = h * 4 + k;
+                x[k] = dsp * it[e] + dsn * ng[e] + a.lam_user * u[e];
+                y[k] = dsp * u[e] + a.lam_item * it[e];
+                z[k] = dsn * u[e] + a.lam_item * ng[e];
+            }
+            RowVec<float>::store(gu + h * 4, x);
+            RowVec<float>::store(gi + h * 4, y);
+            RowVec<float>::store(gn + h * 4, z);
+        }
+        contrib = (sub == 0 ? lt : 0.0f) + 0.5f * (a.lam_user * sq_u + a.lam_item * sq_i);
+    }
+    const float tot = block_sum256(contrib, sh4);
+    if (threadIdx.x == 0) a.loss_part[blockIdx.x] = tot;
+}
+
+// ------------------------------------------------------------------------------------
+// sort keys: (batch << 32) | row, value = slot of the occurrence inside its batch
+// ------------------------------------------------------------------------------------
+__global__ void k_build_keys(const int64_t* __restrict__ tri, int64_t n, int batch, uint64_t* __restrict__ key_u,
+                             uint32_t* __restrict__ val_u, uint64_t* __restrict__ key_i, uint32_t* __restrict__ val_i) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int64_t b = e / batch;
+    const int64_t rem = n - b * batch;
+    const uint32_t Bb = (uint32_t)(rem < batch ? rem : batch);
+    const uint32_t t = (uint32_t)(e - b * batch);
+    const uint64_t hi = (uint64_t)b << 32;
+    key_u[e] = hi | (uint32_t)tri[e * 3];
+    val_u[e] = t;
+    key_i[e] = hi | (uint32_t)tri[e * 3 + 1];
+    val_i[e] = Bb + t;
+    key_i[n + e] = hi | (uint32_t)tri[e * 3 + 2];
+    val_i[n + e] = 2 * Bb + t;
+}
+
+// ------------------------------------------------------------------------------------
+// segmented row update: one lane group per sorted occurrence; the group at the head of
+// a run of equal keys sums the run's gradient rows in order (deterministic) and writes
+// the row once.  OPT 0: SGD.  OPT 1: Adam with the skipped zero-gradient steps replayed.
+// ------------------------------------------------------------------------------------
+template <int D, typename T, int OPT>
+__global__ __launch_bounds__(256) void k_seg_update(SmlSegUpdArgs a) {
+    constexpr int VEC = RowVec<T>::VEC;
+    constexpr int LPR = D / VEC;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    int pos = gid / LPR;
+    const int sub = gid % LPR;
+    const uint64_t* keys; const uint32_t* vals; int n;
+    T* w; float* mt; float* vt; int32_t* last;
+    if (pos < a.n_u) {
+        keys = a.key_u; vals = a.val_u; n = a.n_u;
+        w = reinterpret_cast<T*>(a.w_user); mt = a.m_user; vt = a.v_user; last = a.last_user;
+    } else {
+        pos -= a.n_u;
+        if (pos >= a.n_i) return;
+        keys = a.key_i; vals = a.val_i; n = a.n_i;
+        w = reinterpret_cast<T*>(a.w_item); mt = a.m_item; vt = a.v_item; last = a.last_item;
+    }
+    const uint64_t key = keys[pos];
+    if (pos > 0 && keys[pos - 1] == key) return;
+    float g[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) g[k] = 0.0f;
+    for (int q = pos; q < n && keys[q] == key; ++q) {
+        const float* src = a.dx + (int64_t)vals[q] * D + sub * VEC;
+#pragma unroll
+        for (int h = 0; h < VEC / 4; ++h) {
+            float x[4];
+            RowVec<float>::load(src + h * 4, x);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[h * 4 + k] += x[k];
+        }
+    }
+    const int64_t row = (uint32_t)key;
+    float p[VEC];
+    RowVec<T>::load(w + row * D + sub * VEC, p);
+    if (OPT == 0) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) p[k] -= a.lr * g[k];
+        RowVec<T>::store(w + row * D + sub * VEC, p);
+    } else {
+        float m[4], v[4];
+        RowVec<float>::load(mt + row * D + sub * 4, m);
+        RowVec<float>::load(vt + row * D + sub * 4, v);
+        const int from = last[row];
+        const SmlSched sc = a.sched[a.cur_step];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            adam_replay(p[k], m[k], v[k], from, a.cur_step - 1, a.sched);
+            adam_apply(p[k], m[k], v[k], g[k], sc);
+        }
+        RowVec<T>::store(w + row * D + sub * VEC, p);
+        RowVec<float>::store(mt + row * D + sub * 4, m);
+        RowVec<float>::store(vt + row * D + sub * 4, v);
+        if (sub == 0) last[row] = a.cur_step;
+    }
+}
+
+// bring every row up to `cur_step` (all pending steps have zero gradient)
+template <int D>
+__global__ __launch_bounds__(256) void k_adam_flush(float* __restrict__ w, float* __restrict__ mt, float* __restrict__ vt,
+                                                    int32_t* __restrict__ last, int64_t rows,
+                                                    const SmlSched* __restrict__ sched, int cur_step) {
+    constexpr int LPR = D / 4;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = gid / LPR;
+    const int sub = (int)(gid % LPR);
+    if (row >= rows) return;
+    const int from = last[row];
+    if (from >= cur_step) return;
+    float p[4], m[4], v[4];
+    RowVec<float>::load(w + row * D + sub * 4, p);
+    RowVec<float>::load(mt + row * D + sub * 4, m);
+    RowVec<float>::load(vt + row * D + sub * 4, v);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) adam_replay(p[k], m[k], v[k], from, cur_step, sched);
+    RowVec<float>::store(w + row * D + sub * 4, p);
+    RowVec<float>::store(mt + row * D + sub * 4, m);
+    RowVec<float>::store(vt + row * D + sub * 4, v);
+    if (sub == 0) last[row] = cur_step;   // the row's lanes share this wavefront: all have read `from`
+}
+
+// ------------------------------------------------------------------------------------
+// MFbasemode.forward (model/MF.py:34-43)
+// ------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void k_mf_forward(const float* __restrict__ wu, const float* __restrict__ wi,
+                                                    const int64_t* __restrict__ user, const int64_t* __restrict__ item,
+                                                    int64_t n, int norm, float* __restrict__ uemb,
+                                                    float* __restrict__ iemb, float* __restrict__ score) {
+    constexpr int LPR = D / 4;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t t = gid / LPR;
+    const int sub = (int)(gid % LPR);
+    if (t >= n) return;
+    float u[4], it[4];
+    RowVec<float>::load(wu + user[t] * D + sub * 4, u);
+    RowVec<float>::load(wi + item[t] * D + sub * 4, it);
+    float s = 0.f, uu = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s += u[k] * it[k]; uu += u[k] * u[k]; }
+    s = group_sum<LPR>(s);
+    if (norm) s = s / sqrtf(group_sum<LPR>(uu));
+    RowVec<float>::store(uemb + t * D + sub * 4, u);
+    RowVec<float>::store(iemb + t * D + sub * 4, it);
+    if (sub == 0) score[t] = s;
+}
+
+// ------------------------------------------------------------------------------------
+// evaluation: rank of the positive among 1+neg candidates (MFbasemode.test, model/MF.py:45-60)
+// one wavefront per test row; 64/LPR candidate rows in flight per step, unrolled x4
+// ------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void k_eval_ranks(const float* __restrict__ wu, const float* __restrict__ wi,
+                                                    const int64_t* __restrict__ rows, int64_t n, int n_cols,
+                                                    int32_t* __restrict__ rank) {
+    constexpr int LPR = D / 4;
+    constexpr int G = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int grp = lane / LPR, sub = lane % LPR;
+    const int64_t* R = rows + r * n_cols;
+    float u[4], x[4];
+    RowVec<float>::load(wu + R[0] * D + sub * 4, u);
+    RowVec<float>::load(wi + R[1] * D + sub * 4, x);
+    float s0 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s0 += u[k] * x[k];
+    s0 = group_sum<LPR>(s0);
+    int cnt = 0;
+    int c = 2 + grp;
+    for (; c + 3 * G < n_cols; c += 4 * G) {
+        float y[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) RowVec<float>::load(wi + R[c + j * G] * D + sub * 4, y[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += u[k] * y[j][k];
+            s = group_sum<LPR>(s);
+            cnt += (s > s0) ? 1 : 0;
+        }
+    }
+    for (; c < n_cols; c += G) {
+        RowVec<float>::load(wi + R[c] * D + sub * 4, x);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s += u[k] * x[k];
+        s = group_sum<LPR>(s);
+        cnt += (s > s0) ? 1 : 0;
+    }
+    int tot = (sub == 0) ? cnt : 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off, 64);
+    if (lane == 0) rank[r] = tot;
+}
+
+// hits and NDCG sum over ranks (model/MF.py:60-78): hit iff rank < topk, NDCG = 1/log2(rank+2)
+__global__ __launch_bounds__(256) void k_eval_metrics(const int32_t* __restrict__ rank, int64_t n, int topk,
+                                                      float* __restrict__ out) {
+    __shared__ float sh4[4];
+    float hits = 0.f, nd = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const int rk = rank[i];
+        if (rk < topk) { hits += 1.0f; nd += 1.0f / log2f((float)rk + 2.0f); }
+    }
+    const float h = block_sum256(hits, sh4);
+    __syncthreads();
+    const float d = block_sum256(nd, sh4);
+    if (threadIdx.x == 0) { out[0] = h; out[1] = d; }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------- launchers
+#define SML_DISPATCH_D(d, ...)              \
+    switch (d) {                             \
+        case 32: { constexpr int DD = 32; __VA_ARGS__; } break;   \
+        case 64: { constexpr int DD = 64; __VA_ARGS__; } break;   \
+        case 128: { constexpr int DD = 128; __VA_ARGS__; } break; \
+        default: return hipErrorInvalidValue; \
+    }
+
+hipError_t sml_launch_pair_loss(int d, const SmlLossArgs& a, int* n_blocks, hipStream_t st) {
+    const int lpr = d / 4;
+    const int nb = (a.B * lpr + 255) / 256;
+    if (n_blocks) *n_blocks = nb;
+    SML_DISPATCH_D(d, k_pair_loss<DD><<<dim3(nb), dim3(256), 0, st>>>(a));
+    return hipGetLastError();
+}
+hipError_t sml_launch_loss_finalize(const float* part, int n_batches, int stride, const int*, float* out, hipStream_t st) {
+    k_loss_finalize<<<dim3((n_batches + 63) / 64), dim3(64), 0, st>>>(part, n_batches, stride, out);
+    return hipGetLastError();
+}
+hipError_t sml_launch_bare_grad(int d, int dtype_bytes, const SmlBareArgs& a, int* n_blocks, hipStream_t st) {
+    const int lpr = d * dtype_bytes / 16;
+    const int nb = (int)(((int64_t)a.B * lpr + 255) / 256);
+    if (n_blocks) *n_blocks = nb;
+    if (dtype_bytes == 4) {
+        SML_DISPATCH_D(d, k_bare_grad<DD, float><<<dim3(nb), dim3(256), 0, st>>>(a));
+    } else if (dtype_bytes == 2) {
+        SML_DISPATCH_D(d, k_bare_grad<DD, __half><<<dim3(nb), dim3(256), 0, st>>>(a));
+    } else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+hipError_t sml_launch_build_keys(const int64_t* tri, int64_t n, int batch, uint64_t* key_u, uint32_t* val_u,
+                                 uint64_t* key_i, uint32_t* val_i, hipStream_t st) {
+    k_build_keys<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(tri, n, batch, key_u, val_u, key_i, val_i);
+    return hipGetLastError();
+}
+hipError_t sml_launch_seg_adam(int d, const SmlSegUpdArgs& a, hipStream_t st) {
+    const int lpr = d / 4;
+    const int nb = (int)(((int64_t)(a.n_u + a.n_i) * lpr + 255) / 256);
+    SML_DISPATCH_D(d, k_seg_update<DD, float, 1><<<dim3(nb), dim3(256), 0, st>>>(a));
+    return hipGetLastError();
+}
+hipError_t sml_launch_seg_sgd(int d, int dtype_bytes, const SmlSegUpdArgs& a, hipStream_t st) {
+    const int lpr = d * dtype_bytes / 16;
+    const int nb = (int)(((int64_t)(a.n_u + a.n_i) * lpr + 255) / 256);
+    if (dtype_bytes == 4) {
+        SML_DISPATCH_D(d, k_seg_update<DD, float, 0><<<dim3(nb), dim3(256), 0, st>>>(a));
+    } else if (dtype_bytes == 2) {
+        SML_DISPATCH_D(d, k_seg_update<DD, __half, 0><<<dim3(nb), dim3(256), 0, st>>>(a));
+    } else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+hipError_t sml_launch_adam_flush(int d, float* w, float* m, float* v, int32_t* last, int64_t rows,
+                                 const SmlSched* sched, int cur_step, hipStream_t st) {
+    const int lpr = d / 4;
+    const int64_t nb = (rows * lpr + 255) / 256;
+    SML_DISPATCH_D(d, k_adam_flush<DD><<<dim3((unsigned)nb), dim3(256), 0, st>>>(w, m, v, last, rows, sched, cur_step));
+    return hipGetLastError();
+}
+hipError_t sml_launch_mf_forward(int d, const float* wu, const float* wi, const int64_t* user, const int64_t* item,
+                                 int64_t n, int norm, float* uemb, float* iemb, float* score, hipStream_t st) {
+    const int lpr = d / 4;
+    const int64_t nb = (n * lpr + 255) / 256;
+    SML_DISPATCH_D(d, k_mf_forward<DD><<<dim3((unsigned)nb), dim3(256), 0, st>>>(wu, wi, user, item, n, norm, uemb, iemb, score));
+    return hipGetLastError();
+}
+hipError_t sml_launch_eval_ranks(int d, const float* wu, const float* wi, const int64_t* rows, int64_t n, int n_cols,
+                                 int32_t* rank, hipStream_t st) {
+    const int64_t nb = (n + 3) / 4;
+    SML_DISPATCH_D(d, k_eval_ranks<DD><<<dim3((unsigned)nb), dim3(256), 0, st>>>(wu, wi, rows, n, n_cols, rank));
+    return hipGetLastError();
+}
+hipError_t sml_launch_eval_metrics(const int32_t* rank, int64_t n, int topk, float* out, hipStream_t st) {
+    k_eval_metrics<<<dim3(1), dim3(256), 0, st>>>(rank, n, topk, out);
+    return hipGetLastError();
+}

@@ -1,0 +1,116 @@
+// Host-visible kernel argument blocks and launcher prototypes (internal to libsml_hip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sml_dev.h"
+
+// One contiguous run of rows that goes through one net.
+struct SmlSeg {
+    const float* theta;      // this net's flat parameter block
+    const float* pk;         // this net's MFMA operand images
+    const float* xt_tab;     // x_t source  (table when tri != null, else contiguous rows)
+    const float* xh_tab;     // x_hat source
+    const float* m_tab;      // lazy Adam state of the x_hat table (null: rows are current)
+    const float* v_tab;
+    const int32_t* last_tab;
+    const int64_t* tri;      // [B,3] (u,i,j) or null for identity indexing
+    int B;                   // triples in this batch
+    int is_item;             // 0: rows = tri[:,0]; 1: rows = tri[:,1] then tri[:,2]
+    int n_rows;
+    float* out;              // [n_rows, d]
+    float* z1;               // optional saves for backward
+    float* xin;              // [n_rows, 3, d]  (x_t, x_hat, x_com)
+    float* a1;               // [n_rows, 5d]
+};
+struct SmlFwdArgs {
+    SmlSeg seg[2];
+    int tiles0;              // tiles of seg[0]; the rest belong to seg[1]
+    int cur_step;            // Adam step about to be applied (replay runs to cur_step-1)
+    const SmlSched* sched;
+};
+
+struct SmlBwdSeg {
+    const float* theta;
+    const float* pk;
+    const float* dout;       // [n_rows, d]
+    const float* z1;         // [n_rows, 512]
+    const float* xin;        // [n_rows, 3, d]
+    float* dx;               // MF stage: [n_rows, d] gradient w.r.t. x_hat (+ l2*x_hat); null in TR stage
+    float* dz1;              // TR stage: [n_rows, 512]; null in MF stage
+    int n_rows;
+};
+struct SmlBwdArgs {
+    SmlBwdSeg seg[2];
+    int tiles0;
+    float l2;
+    float* convg_part;       // TR stage: [tiles, 104] per-tile conv1/conv2 gradient partials; else null
+};
+
+struct SmlWgSeg {
+    const float* dz1; const float* a1; const float* dout; const float* z1;
+    float* grad;             // this net's flat gradient block
+    int n_rows;
+};
+struct SmlWgArgs { SmlWgSeg seg[2]; };
+
+struct SmlThetaAdamArgs {
+    float* theta; float* m; float* v; float* grad; float* pk;
+    const float* convg_part; // null: conv gradients already in grad (after an all-reduce)
+    int tiles0, tiles_total;
+    int grad_only;           // 1: only finish the flat gradient (sum the conv partials), no update
+    float weight_decay, step_size, bc2_sqrt;
+};
+
+hipError_t sml_launch_fwd(int d, const SmlFwdArgs& a, int tiles_total, hipStream_t st);
+hipError_t sml_launch_bwd(int d, const SmlBwdArgs& a, int tiles_total, hipStream_t st);
+hipError_t sml_launch_wgrad(int d, const SmlWgArgs& a, hipStream_t st);
+hipError_t sml_launch_theta_adam(int d, const SmlThetaAdamArgs& a, hipStream_t st);
+hipError_t sml_launch_theta_pack(int d, const float* theta, float* pk, hipStream_t st);
+hipError_t sml_launch_selftest(const float* A, const float* W, float* pk, float* out, hipStream_t st);
+
+// ---- mf_kernels.hip ------------------------------------------------------------------
+struct SmlLossArgs {
+    const float* out;        // [3B, d]: u' rows, i' rows, n' rows
+    const float* xin;        // [3B, 3, d] or null (no l2 term)
+    float* dout;             // [3B, d]
+    float* loss_part;        // [gridDim.x] partial sums of this batch
+    int B;
+    int kind;                // SML_LOSS_*
+    float l2;
+    float scale;             // multiplies loss and gradients (multi-GPU: B_local / B_global)
+};
+hipError_t sml_launch_pair_loss(int d, const SmlLossArgs& a, int* n_blocks, hipStream_t st);
+hipError_t sml_launch_loss_finalize(const float* part, int n_batches, int stride, const int* counts,
+                                    float* out, hipStream_t st);
+
+struct SmlSegUpdArgs {
+    // sorted occurrences of this batch: key = (batch << 32) | row, val = slot in [0, 3B)
+    const uint64_t* key_u; const uint32_t* val_u; int n_u;     // user occurrences (B)
+    const uint64_t* key_i; const uint32_t* val_i; int n_i;     // item occurrences (2B)
+    const float* dx;         // [3B, d] per-occurrence gradients
+    void* w_user; void* w_item;
+    float* m_user; float* v_user; float* m_item; float* v_item;   // Adam only
+    int32_t* last_user; int32_t* last_item;                       // Adam only
+    const SmlSched* sched; int cur_step;                          // Adam only
+    float lr;                                                     // SGD only
+};
+hipError_t sml_launch_seg_adam(int d, const SmlSegUpdArgs& a, hipStream_t st);
+hipError_t sml_launch_seg_sgd(int d, int dtype_bytes, const SmlSegUpdArgs& a, hipStream_t st);
+hipError_t sml_launch_adam_flush(int d, float* w, float* m, float* v, int32_t* last, int64_t rows,
+                                 const SmlSched* sched, int cur_step, hipStream_t st);
+hipError_t sml_launch_build_keys(const int64_t* tri, int64_t n, int batch, uint64_t* key_u, uint32_t* val_u,
+                                 uint64_t* key_i, uint32_t* val_i, hipStream_t st);
+
+struct SmlBareArgs {
+    const void* w_user; const void* w_item;
+    const int64_t* tri; int B;
+    float* dx;               // [3B, d] per-occurrence gradients (fp32)
+    float* loss_part;
+    int kind; float lam_user, lam_item;
+};
+hipError_t sml_launch_bare_grad(int d, int dtype_bytes, const SmlBareArgs& a, int* n_blocks, hipStream_t st);
+hipError_t sml_launch_mf_forward(int d, const float* wu, const float* wi, const int64_t* user, const int64_t* item,
+                                 int64_t n, int norm, float* uemb, float* iemb, float* score, hipStream_t st);
+hipError_t sml_launch_eval_ranks(int d, const float* wu, const float* wi, const int64_t* rows, int64_t n,
+                                 int n_cols, int32_t* rank, hipStream_t st);
+hipError_t sml_launch_eval_metrics(const int32_t* rank, int64_t n, int topk, float* out, hipStream_t st);

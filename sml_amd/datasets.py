@@ -1,0 +1,262 @@
+"""Period data source and batch supply (reference data/dataset2.py, data/dataset.py).
+
+The classes keep the reference's names and per-item semantics, and add a
+vectorised `epoch_triples(order)` that yields a whole epoch's (user, item, neg)
+triples at once with the SAME random-number consumption as a
+DataLoader(shuffle=True, num_workers=0) pass over `__getitem__`, so the host
+never loops over single items in Python.  `loader_order(n)` reproduces the two
+draws such a DataLoader pass makes from torch's global generator.
+"""
+import copy
+import os
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+
+def loader_base_seed_draw():
+    """The draw every DataLoader iteration makes on creation (_BaseDataLoaderIter.__init__)."""
+    return int(torch.empty((), dtype=torch.int64).random_().item())
+
+
+def loader_order(n, shuffle=True):
+    """Index order of one DataLoader(num_workers=0) pass over n items, consuming torch's
+    global RNG exactly as DataLoader + RandomSampler do (base seed, then sampler seed)."""
+    loader_base_seed_draw()
+    if not shuffle:
+        return np.arange(n, dtype=np.int64)
+    seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return torch.randperm(n, generator=g).numpy()
+
+
+class testDataset(Dataset):
+    """reference data/dataset2.py:160-170"""
+
+    def __init__(self, dataset):
+        super(testDataset, self).__init__()
+        self.data = dataset
+
+    def __len__(self):
+        return self.data.shape[0]
+
+    def __getitem__(self, idx):
+        return self.data[idx]
+
+
+class trainDataset_withPreSample(Dataset):
+    """Rows [user, item, c2, c3, ...] with pre-sampled negatives; each full pass over the
+    data uses ONE column as the negative (reference data/dataset2.py:172-201).  Quirk kept:
+    the candidate columns are 1..C-1, so column 1 (the positive itself) can be drawn."""
+
+    def __init__(self, input_dataset):
+        super(trainDataset_withPreSample, self).__init__()
+        self.all_data = copy.deepcopy(input_dataset)
+        self.data_len = input_dataset.shape[0]
+        self.neg_all = input_dataset.shape[1] - 2
+        self.neg_flag = np.arange(1, self.all_data.shape[1])
+        np.random.shuffle(self.neg_flag)
+        self.used_neg_count = 0
+        self.have_read = 0
+
+    def __len__(self):
+        return self.data_len
+
+    def _advance(self, reads):
+        self.have_read += reads
+        if self.have_read >= self.data_len:
+            self.have_read = 0
+            self.used_neg_count += 1
+            if self.used_neg_count >= self.neg_all:
+                np.random.shuffle(self.neg_flag)
+                self.used_neg_count = 0
+
+    def __getitem__(self, idx):
+        row = self.all_data[idx]
+        out = (row[0], row[1], row[self.neg_flag[self.used_neg_count]])
+        self._advance(1)
+        return out
+
+    def epoch_triples(self, order):
+        """One full pass in `order` -> int64 [n,3]."""
+        if self.have_read != 0 or len(order) != self.data_len:
+            raise ValueError("epoch_triples needs a whole pass starting at a pass boundary")
+        col = self.neg_flag[self.used_neg_count]
+        tri = np.ascontiguousarray(self.all_data[order][:, [0, 1, col]], dtype=np.int64)
+        self._advance(self.data_len)
+        return tri
+
+
+class offlineDataset_withsample(Dataset):
+    """(user, item) pairs; the negative is drawn per access, uniformly from the items that
+    occur in this set, rejecting the user's own items (reference data/dataset.py:41-71)."""
+
+    def __init__(self, dataset):
+        super(offlineDataset_withsample, self).__init__()
+        self.user = dataset[:, 0]
+        self.item = dataset[:, 1]
+        print("user max:", self.user.max())
+        print("user max:", self.item.max())     # (sic) the reference prints the item max under this label
+        self.item_all = np.unique(self.item)
+        self.user_list = {}
+        for u, i in zip(self.user.tolist(), self.item.tolist()):
+            self.user_list.setdefault(u, []).append(i)
+        self._stride = int(self.item_all.max()) + 1
+        self._pairs = np.unique(self.user.astype(np.int64) * self._stride + self.item.astype(np.int64))
+
+    def __len__(self):
+        return self.user.shape[0]
+
+    def __getitem__(self, idx):
+        user, item = self.user[idx], self.item[idx]
+        neg = np.random.choice(self.item_all, 1)[0]
+        while neg in self.user_list[user]:
+            neg = np.random.choice(self.item_all, 1)[0]
+        return (user, item, neg)
+
+    def _is_own(self, users, items):
+        code = users.astype(np.int64) * self._stride + items.astype(np.int64)
+        pos = np.searchsorted(self._pairs, code)
+        pos[pos >= self._pairs.shape[0]] = 0
+        return self._pairs[pos] == code
+
+    def epoch_triples(self, order):
+        """Same triples, and same numpy global-RNG end state, as calling __getitem__ for
+        every index of `order` in turn.  np.random.choice(a, 1) is one legacy
+        randint(0, len(a)) draw, and a batch of such draws is the same stream, so the
+        candidates are drawn in blocks and the (rare) rejections are resolved in order."""
+        order = np.asarray(order)
+        n = order.shape[0]
+        users = self.user[order].astype(np.int64)
+        pop = self.item_all.shape[0]
+        state0 = np.random.get_state()
+        slack = 64 + n // 16
+        while True:
+            cand = self.item_all[np.random.randint(0, pop, size=n + slack)]
+            negs = np.empty(n, dtype=np.int64)
+            e, shift, ok = 0, 0, True
+            while e < n:
+                bad = self._is_own(users[e:], cand[e + shift:n + shift])
+                f = int(np.argmax(bad)) if bad.any() else n - e
+                negs[e:e + f] = cand[e + shift:e + f + shift]
+                e += f
+                if e >= n:
+                    break
+                # element e: redraw until accepted, each redraw consumes one more candidate
+                while True:
+                    shift += 1
+                    if e + shift >= n + slack:
+                        ok = False
+                        break
+                    if not self._is_own(users[e:e + 1], cand[e + shift:e + shift + 1])[0]:
+                        break
+                if not ok:
+                    break
+                negs[e] = cand[e + shift]
+                e += 1
+            if ok:
+                break
+            np.random.set_state(state0)
+            slack *= 4
+        # leave the global generator exactly where n + shift single draws would
+        np.random.set_state(state0)
+        np.random.randint(0, pop, size=n + shift)
+        return np.stack([users, self.item[order].astype(np.int64), negs], axis=1)
+
+
+class transfer_data(object):
+    """Per-stage period data (reference data/dataset2.py:203-351).
+
+    Layout under path/datasetname/: information.npy = [n_interactions, n_user, n_item],
+    train/<p>.npy int [n,2], test/<p>.npy int [n, 2+neg]."""
+
+    def __init__(self, args, path="dataset/", datasetname="News", online_train_time=21, file_path_list=None,
+                 test_list=None, validation_list=None, online_test_time=48):
+        self.TR_sample_type = args.TR_sample_type
+        self.TR_stop_ = args.TR_stop_
+        self.MF_sample = args.MF_sample
+        self.current_as_set_tt = args.set_t_as_tt
+        self.path = path
+        self.dataname = datasetname
+        self.file_list = file_path_list
+        self.test_list = test_list
+        self.val_list = validation_list
+        self.len = len(file_path_list)
+        self.online_trian_time = online_train_time
+        self.online_test_time = online_test_time
+        self.start_test_time = online_test_time
+        self.test_count = 0
+        information = np.load(self._file("information.npy"))
+        self.inter_all, self.user_number, self.item_number = information[0], information[1], information[2]
+        print(information)
+        users, items, total = set(), set(), 0
+        for f in self.file_list:     # the reference prints (#interactions, #users, #items) of all train files
+            a = self._load("train", f)
+            total += a.shape[0]
+            users.update(np.unique(a[:, 0]).tolist())
+            items.update(np.unique(a[:, 1]).tolist())
+        print(total, len(users), len(items))
+
+    def _file(self, *parts):
+        return os.path.join(self.path + self.dataname, *parts)
+
+    def _load(self, split, name):
+        return np.load(self._file(split, name + ".npy"))
+
+    def reinit(self):
+        self.test_count = 0
+        self.start_test_time = copy.deepcopy(self.online_test_time)
+
+    def _set_t(self, now):
+        if self.MF_sample == "alone":
+            return self._load("train", self.file_list[now])
+        if self.MF_sample == "all":
+            return self._load("test", self.file_list[now])
+        raise TypeError("now such type when read next train sets")
+
+    def _set_tt(self, now, label):
+        src = now if self.current_as_set_tt else now + 1
+        if self.TR_sample_type == "alone":
+            p = self._file("train", self.file_list[src] + ".npy")
+            print(label, p)
+            return np.load(p)
+        if self.TR_sample_type == "all":
+            return self._load("test", self.file_list[src])
+        raise TypeError("no such TR sample type")
+
+    def next_train(self, d_time):
+        """-> (set_t, set_tt, now_test, val) for stage d_time; (None,)*4 past the last period.
+        Branches as the reference (data/dataset2.py:257-351): pure online training before
+        online_test_time; afterwards test-then-train (or, with TR_stop_, test only)."""
+        now = self.online_trian_time + d_time
+        if now + 1 >= self.len:
+            return None, None, None, None
+        print("now time:", now)
+        print("will be test data:", now + 1)
+        if now + 1 < self.start_test_time:
+            set_t = self._set_t(now)
+            val = self._load("test", self.file_list[now + 1])
+            print("now time:", self.file_list[now])
+            set_tt = self._set_tt(now, "set_tt is:" if not self.current_as_set_tt else "set tt is:")
+            if self.TR_sample_type == "all":
+                print("t+1 data stes", self.file_list[now + 1])
+            return set_t, set_tt, None, val
+        if self.TR_stop_:
+            set_t = self._set_t(now)
+            print("now time:", self.file_list[now])
+            print("will be test data:", self.test_list[self.test_count])
+            now_test = self._load("test", self.test_list[self.test_count])
+            self.test_count += 1
+            return set_t, None, now_test, now_test
+        set_t = self._set_t(now)
+        val = self._load("test", self.file_list[now + 1])
+        set_tt = self._set_tt(now, "settt is:")
+        if self.TR_sample_type == "all":
+            print("set_tt is", self.file_list[now + 1])
+            print("t+1 datasets,", self.file_list[now + 1])
+        now_test = self._load("test", self.test_list[self.test_count])
+        print("real test:", self.test_list[self.test_count])
+        self.test_count += 1
+        return set_t, set_tt, now_test, val

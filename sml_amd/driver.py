@@ -1,0 +1,370 @@
+"""SML sequential-retraining driver: the module surface of the reference's
+model/transfer.py `meta_train` with its inner loops on the HIP engine.
+
+Control flow, state names, hyper-parameter handling, random-number consumption and
+printed lines follow the reference (model/transfer.py:302-1029) so the class drops
+into main_yelp.py / main_news.py; the three hot loops
+  MF_train_onestage       (model/transfer.py:417-534)
+  transfer_train_onestage (model/transfer.py:644-749)
+  updata                  (model/transfer.py:884-902)
+are single calls into libsml_hip.so per epoch / per table, with whole-epoch triples
+built by sml_amd.datasets instead of a per-item DataLoader.
+"""
+import copy
+import time
+
+import numpy as np
+import torch
+
+from . import datasets as D
+from .conv_transfer import ConvTransfer_com
+from .evaluation import DeviceRows, test_model
+from .mf import MFbasemode
+
+SampleDaset = D.offlineDataset_withsample
+PreSampleDatast = D.trainDataset_withPreSample
+
+
+def _default_device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("SML on this build needs a GPU: torch.cuda.is_available() is False and "
+                           "there is no CPU path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _make_engine(device, d, max_batch):
+    from .engine import HipEngine
+    return HipEngine(device, d, max_batch)
+
+
+def _np(x):
+    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+
+
+class _OptimizerInfo(object):
+    """What the reference exposes as MF_optimizer / transfer_optimizer, reduced to the
+    hyper-parameters; the Adam state itself lives in the engine."""
+
+    def __init__(self, lr, weight_decay):
+        self.param_groups = [dict(lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=weight_decay)]
+
+
+class meta_train(object):
+    def __init__(self, args, datasets, user_num, item_num, laten_dim):
+        self.device = _default_device()
+        if args.data_name != 'yelp':
+            # the reference builds (and then discards) a fresh MF model here, which advances
+            # the global RNG before the transfer net is initialised (model/transfer.py:314-317)
+            MFbasemode(num_user=user_num, num_item=item_num, laten_factor=laten_dim)
+        # whole-module pickle, class path model.MF.MFbasemode (model/transfer.py:322-325)
+        self.MFbase = torch.load(args.pre_model, map_location='cpu', weights_only=False).to(self.device)
+        table_dim = self.MFbase.user_laten.weight.shape[1]
+        if table_dim != laten_dim:
+            raise ValueError("--laten %d does not match the checkpoint's embedding width %d" % (laten_dim, table_dim))
+
+        self.transfer_type = args.transfer_type
+        self.with_MF_bias = args.TR_with_MF_bias
+        self.test_in_TR_train = args.test_in_TR_Train
+        self.TR_train_sampleTYpe = args.TR_sample_type
+        print("with MF bias:", self.with_MF_bias)
+        print("transfer type:", self.transfer_type)
+        self.need_writer = args.need_writer
+        self.MF_TrainDataset = {'alone': SampleDaset, 'all': PreSampleDatast}.get(args.MF_sample)
+        self.writer = None
+        if args.need_writer:
+            from torch.utils.tensorboard import SummaryWriter   # optional dependency, imported lazily
+            tag = "m-num" + str(args.multi_num) + "-MF-lr" + str(args.MF_lr) + "-l2-" + str(args.l2) + "e-" + \
+                  str(args.MF_epochs) + "--TR-lr" + str(args.TR_lr) + "-l2-" + str(args.TR_l2) + "-e-" + \
+                  str(args.TR_epochs) + str(args.TR_sample_type) + "user-norm" + str(args.norm)
+            self.writer = SummaryWriter(comment=tag)
+        if self.with_MF_bias:
+            raise NotImplementedError("--TR_with_MF_bias (bias column fed to the transfer net) is outside this "
+                                      "build's scope: kernels exist for d in {32, 64, 128}")
+        # W_{t-1}, W_hat_t, previous W_hat (model/transfer.py:358-364)
+        wu, wi = self.MFbase.user_laten.weight.data, self.MFbase.item_laten.weight.data
+        self.last_user_weight = torch.zeros_like(wu)
+        self.last_item_weight = torch.zeros_like(wi)
+        self.user_weight_hat = wu.clone()
+        self.item_weight_hat = wi.clone()
+        self.last_user_weight_hat = self.user_weight_hat.clone()
+        self.last_item_weight_hat = self.item_weight_hat.clone()
+
+        if self.transfer_type == "conv_com":
+            self.transfer = ConvTransfer_com(laten_dim, laten_dim).to(self.device)
+            self.transfer_type = "transfer2"
+        elif self.transfer_type in ("transfer", "transfer2", "GRU", "transfer3", "conv", "conv_com2"):
+            raise NotImplementedError("transfer type %r is one of the reference's unused variants "
+                                      "(model/transfer.py:1-4); only conv_com is built" % self.transfer_type)
+        else:
+            raise TypeError("No such type transfer!!!")
+
+        self.dataset = datasets
+        self.engine = _make_engine(self.device, laten_dim, max(args.MF_batch_size, args.TR_batch_size))
+        self.MFbase._sml_engine = self.engine
+        self.transfer._sml_engine = self.engine
+        self.MF_optimizer = _OptimizerInfo(args.MF_lr, 0)
+        self.transfer_optimizer = _OptimizerInfo(args.TR_lr, args.TR_l2)
+
+        self.recall, self.ndcg, self.test_num = [], [], []
+        self.recall_5, self.ndcg_5 = [], []
+        self.recall_10, self.ndcg_10 = [], []
+        self.MF_itr = 0
+        self.TR_itr = 0
+        self.timing = {"mf": 0.0, "tr": 0.0, "updata": 0.0, "eval": 0.0, "mf_triples": 0, "tr_triples": 0}
+        self._rows_cache = {}
+
+    # ------------------------------------------------------------------ helpers
+    def get_next_data(self, stage_id):
+        return self.dataset.next_train(stage_id)
+
+    def _rows(self, arr):
+        """Device-resident copy of a test array (cached per array object)."""
+        key = id(arr)
+        hit = self._rows_cache.get(key)
+        if hit is None or hit[0] is not arr:
+            if len(self._rows_cache) > 4:
+                self._rows_cache.clear()
+            hit = (arr, DeviceRows(arr, self.device))
+            self._rows_cache[key] = hit
+        return hit[1]
+
+    def _test(self, rows, topK):
+        t0 = time.time()
+        out = test_model(self.MFbase, rows, topK=topK)
+        self.timing["eval"] += time.time() - t0
+        return out
+
+    # ------------------------------------------------------------------ hot loop 1
+    def MF_train_onestage(self, args, set_t, stage_id, val=None):
+        """Train W_hat on D_t with theta frozen (reference model/transfer.py:417-534)."""
+        if args.need_adaptive:
+            raise NotImplementedError("--need_adaptive is marked 'not used in the final version' by the reference "
+                                      "and is outside this build's scope")
+        self.transfer.eval()
+        if val is not None:
+            val = self._rows(val)
+        print("******MF (inner) training ******")
+        train_set = self.MF_TrainDataset(set_t)
+        if val is not None:
+            recall, ndcg = self._test(val, args.topK)
+            print("before train MF test:recall:{:.4f} ndcg:{:.4f}".format(recall, ndcg))
+            self._log_mf(args, recall, ndcg, None)
+        for epoch in range(args.MF_epochs):
+            self.MFbase.train()
+            self.transfer.eval()
+            order = D.loader_order(len(train_set), shuffle=True)
+            triples = train_set.epoch_triples(order)
+            t0 = time.time()
+            losses = self.engine.mf_stage_epoch(self.MFbase, self.transfer, self.last_user_weight,
+                                                self.last_item_weight, triples, args.MF_batch_size,
+                                                args.MF_lr, args.l2, norm=args.norm, bce=True)
+            self.engine.mf_flush(self.MFbase)
+            losses = _np(losses)
+            self.timing["mf"] += time.time() - t0
+            self.timing["mf_triples"] += triples.shape[0]
+            loss_all = np.float32(0)
+            for l in losses.astype(np.float32):
+                loss_all = np.float32(loss_all + l)
+            loss_all = float(np.float32(loss_all / np.float32(len(losses)))) / args.MF_batch_size
+            if val is not None:
+                recall, ndcg = self._test(val, args.topK)
+                print("MF-stage:", stage_id, "epoch:", epoch, "loss:{:.5f}".format(loss_all),
+                      "recall:{:.4f}".format(recall), "ndcg:{:.4f}".format(ndcg))
+                self._log_mf(args, recall, ndcg, loss_all)
+            else:
+                print("MF-stage:", stage_id, "epoch:", epoch, "loss:", loss_all)
+
+    def _log_mf(self, args, recall, ndcg, loss):
+        if self.writer is None:
+            return
+        self.writer.add_scalar("Acc/MF-recall" + str(args.topK), recall, self.MF_itr)
+        self.writer.add_scalar("Acc/MF-ndcg" + str(args.topK), float(ndcg), self.MF_itr)
+        if loss is not None:
+            self.writer.add_scalar("Loss/MF-loss", loss, self.MF_itr)
+        self.writer.add_scalar("norm/user-norm", float((self.MFbase.user_laten.weight.data ** 2).sum(-1).mean()),
+                               self.MF_itr)
+        self.MF_itr += 1
+
+    # ------------------------------------------------------------------ hot loop 2
+    def transfer_train_onestage(self, args, set_tt, stage_id, compute_performance=False, val=None):
+        """Train theta on D_{t+1} with the tables frozen (reference model/transfer.py:644-749)."""
+        if args.clip_grad:
+            raise NotImplementedError("--clip_grad is marked 'not used in the final version' by the reference "
+                                      "and is outside this build's scope")
+        print("********* this is Transfer model training stage ***********")
+        self.MFbase.eval()
+        now_test = None
+        if self.TR_train_sampleTYpe == "alone":
+            train_set = SampleDaset(set_tt)
+            compute_performance = False
+            if val is not None:
+                now_test = self._rows(val)
+                compute_performance = True
+        elif self.TR_train_sampleTYpe == 'all':
+            now_test = self._rows(set_tt)
+            train_set = PreSampleDatast(set_tt)
+            compute_performance = True
+        else:
+            raise TypeError("no such TR sample type")
+        if compute_performance:
+            recall, ndcg = self._test(now_test, args.topK)
+            print("before train transfer test:recall:{:.4f} ndcg:{:.4f}".format(recall, ndcg))
+            if self.writer is not None:
+                self.writer.add_scalar("Acc/tr-TR-recall@" + str(args.topK), recall, self.TR_itr)
+                self.writer.add_scalar("Acc/tr-TR-ndcg@" + str(args.topK), float(ndcg), self.TR_itr)
+                self.TR_itr += 1
+        s_time = time.time()
+        for epoch in range(args.TR_epochs):
+            self.transfer.train()
+            order = D.loader_order(len(train_set), shuffle=True)
+            triples = train_set.epoch_triples(order)
+            t0 = time.time()
+            losses = _np(self.engine.tr_stage_epoch(self.transfer, self.last_user_weight, self.last_item_weight,
+                                                    self.user_weight_hat, self.item_weight_hat, triples,
+                                                    args.TR_batch_size, args.TR_lr, args.TR_l2, bce=True))
+            self.timing["tr"] += time.time() - t0
+            self.timing["tr_triples"] += triples.shape[0]
+            loss_all = np.float32(0)
+            for l in losses.astype(np.float32):
+                loss_all = np.float32(loss_all + l)
+            loss_all = float(np.float32(loss_all / np.float32(len(losses))))
+            print("one epcohs TR time cost:", time.time() - s_time)
+            if self.writer is not None:
+                self.writer.add_scalar("Loss/TR-loss", loss_all / args.TR_batch_size, self.TR_itr)
+            if compute_performance:
+                self.updata()
+                recall, ndcg = self._test(now_test, args.topK)
+                # (the full-width punctuation is the reference's, model/transfer.py:741)
+                print("stage:{}, epcoh：{}，loss:{:.4f},*****val result  reacll:{:.4f}  ndcg:{:.4f}".format(
+                    stage_id, epoch, loss_all / args.TR_batch_size, recall, ndcg))
+                if self.writer is not None:
+                    self.writer.add_scalar("Acc/tr-TR-recall@" + str(args.topK), recall, self.TR_itr)
+                    self.writer.add_scalar("Acc/tr-TR-ndcg@" + str(args.topK), float(ndcg), self.TR_itr)
+            else:
+                print("stage:", stage_id, "epoch:", epoch, "transfer train loss:", loss_all / args.TR_batch_size)
+        print("stage ", stage_id, " transfer trained finished!!!!")
+
+    # ------------------------------------------------------------------ one period
+    def _real_test(self, now_test):
+        """recall/ndcg @20, @10, @5 on the coming period (model/transfer.py:846-868)."""
+        self.test_num.append(now_test.shape[0])
+        rows = self._rows(now_test)
+        for k, tag, rl, nl in ((20, "", self.recall, self.ndcg), (10, "@10 ", self.recall_10, self.ndcg_10),
+                               (5, "@5 ", self.recall_5, self.ndcg_5)):
+            recall, ndcg = self._test(rows, k)
+            print("test result --------- {}reacll:{:.4f}  ndcg:{:.4f}".format(tag, recall, ndcg))
+            rl.append(recall)
+            nl.append(ndcg.cpu().numpy())
+
+    def train_one_stage3(self, args, stage_id):
+        """One period of SML (reference model/transfer.py:753-881).  False when no data is left."""
+        self.save_MF_weight(save_as='last')
+        set_t, set_tt, now_test, val = self.get_next_data(stage_id)
+        if set_t is None:
+            return False
+        if now_test is not None and set_tt is None:
+            # --TR_stop_: theta frozen during the test periods
+            s_time = time.time()
+            print("stop train transfer while test###!!!!!")
+            args.MF_epochs = 2
+            self.MF_train_onestage(args, set_t, stage_id, val=val)
+            self.MFbase.eval()
+            self.save_MF_weight(save_as='hat')
+            self.updata()
+            print("only traning time cost:", time.time() - s_time)
+            self._real_test(now_test)
+            print("include test time cost:", time.time() - s_time)
+            return True
+        for phase in range(args.multi_num):
+            self.MF_train_onestage(args, set_t, stage_id, val=val)
+            self.MFbase.eval()
+            self.save_MF_weight(save_as='hat')
+            if self.writer is not None:
+                self.writer.add_scalars("Scale/user_weight", {"weight_hat": torch.norm(self.user_weight_hat).item(),
+                                                              "weight_last": torch.norm(self.last_user_weight).item()},
+                                        stage_id)
+                self.writer.add_scalars("Scale/item_weight", {"weight_hat": torch.norm(self.item_weight_hat).item(),
+                                                              "weight_last": torch.norm(self.last_item_weight).item()},
+                                        stage_id)
+            self.updata()
+            if now_test is not None and phase == 0:
+                # test D_{t+1} with the first outer loop's model, before it trains theta
+                self._real_test(now_test)
+            self.transfer_train_onestage(args, set_tt, stage_id, val=val)
+            if args.Load_W_hat:
+                self.load_MFbase_weight(self.user_weight_hat, self.item_weight_hat)
+        self.updata()
+        return True
+
+    # ------------------------------------------------------------------ hot loop 3
+    def updata(self):
+        """W <- transfer(W_{t-1}, W_hat) over every user and item row (model/transfer.py:884-902)."""
+        self.MFbase.eval()
+        self.transfer.eval()
+        if self.transfer_type != 'transfer2':
+            raise TypeError("No such type transfer!!!")
+        t0 = time.time()
+        self.engine.updata(self.transfer, self.last_user_weight, self.user_weight_hat, self.last_item_weight,
+                           self.item_weight_hat, self.MFbase.user_laten.weight.data, self.MFbase.item_laten.weight.data)
+        self.timing["updata"] += time.time() - t0
+
+    def save_MF_weight(self, save_as="last"):
+        """'last': W_{t-1} <- W.  'hat': previous W_hat <- W_hat; W_hat <- W.  (model/transfer.py:911-943)"""
+        wu, wi = self.MFbase.user_laten.weight.data, self.MFbase.item_laten.weight.data
+        if save_as == "last":
+            self.last_user_weight.copy_(wu)
+            self.last_item_weight.copy_(wi)
+        elif save_as == "hat":
+            self.last_user_weight_hat.copy_(self.user_weight_hat)
+            self.last_item_weight_hat.copy_(self.item_weight_hat)
+            self.user_weight_hat.copy_(wu)
+            self.item_weight_hat.copy_(wi)
+        else:
+            raise TypeError("save MFbase weight type is wrong")
+
+    def load_MFbase_weight(self, user_weight, item_weight):
+        """Overwrite the MF tables in place; the Adam moments are left as they are, as in
+        the reference (model/transfer.py:945-959, note at :764)."""
+        self.MFbase.user_laten.weight.data.copy_(user_weight)
+        self.MFbase.item_laten.weight.data.copy_(item_weight)
+
+    # ------------------------------------------------------------------ the sequence
+    def run(self, args):
+        """All periods, then the weighted averages (reference model/transfer.py:965-1029)."""
+        pass_num = args.pass_num
+        for pass_id in range(pass_num):
+            stage_id = 0
+            self.dataset.reinit()
+            while True:
+                if self.train_one_stage3(args, stage_id):
+                    stage_id += 1
+                    if pass_id < (pass_num - 1) and stage_id >= 19:
+                        break
+                    continue
+                print(str(pass_id) + "--trained over!!!!!")
+                self._report()
+                break
+
+    def _report(self):
+        test_num = np.array(self.test_num)
+        n3 = round(test_num.shape[0] * 1 / 3)
+        val_num = test_num[0:n3]
+        test_num = test_num[n3:-1]        # the last period is dropped, as in the reference
+        recall = np.array(self.recall)
+        ndcg = np.array(self.ndcg)
+        print(test_num)
+        print(recall)
+        print(ndcg)
+        print("include stage 0 of test:")
+        val_w = val_num * 1.0 / val_num.sum()
+        test_w = test_num * 1.0 / test_num.sum()
+        for k, rl, nl in ((20, self.recall, self.ndcg), (10, self.recall_10, self.ndcg_10),
+                          (5, self.recall_5, self.ndcg_5)):
+            recall = np.array(rl)
+            ndcg = np.array(nl)
+            if k != 20:
+                print("\n")
+            print("val average recall@%d:" % k, (recall[0:n3] * val_w).sum())
+            print("val average ndcg@%d:" % k, (ndcg[0:n3] * val_w).sum())
+            print("test average recall@%d:" % k, (recall[n3:-1] * test_w).sum())
+            print("test average ndcg@%d:" % k, (ndcg[n3:-1] * test_w).sum())

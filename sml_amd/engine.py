@@ -1,0 +1,274 @@
+"""HipEngine: the host-side handle on libsml_hip.so for one GPU.
+
+Everything numerical on the SML hot path goes through this object; it owns the
+sml_ctx (scratch), the flat theta buffer the transfer module's parameters are
+re-pointed into, and the Adam state of both optimisers.  torch is used for device
+memory, streams and (in sml_amd.dist) RCCL -- not for arithmetic on the path.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+NET_PARAM_ORDER = ("conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias",
+                   "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias")
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+class HipEngine(object):
+    def __init__(self, device, d, max_batch=4096):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipEngine needs a GPU (torch.cuda.is_available() is False); there is no CPU path")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("HipEngine device must be a cuda (HIP) device, got %s" % device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.d = int(d)
+        self.max_batch = int(max_batch)
+        h = ctypes.c_void_p()
+        check(self.lib.sml_ctx_create(ctypes.byref(h), self.device.index, self.d, self.max_batch), "sml_ctx_create")
+        self._ctx = h
+        self.net_size = int(self.lib.sml_theta_net_size(self.d))
+        self.offsets = [int(self.lib.sml_theta_offset(self.d, w)) for w in range(8)]
+        self._flat = {}       # id(transfer) -> (flat theta, [(param, off, numel)])
+        self.mf_state = None  # lazy-Adam state of the MF tables
+        self.mf_step = 0      # torch.optim.Adam's step counter; never resets (reference model/transfer.py:392)
+        self.tr_state = None  # (m, v) flat, theta layout
+        self.tr_step = 0
+        self.grad_hook = None  # set by sml_amd.dist for the multi-GPU TR stage
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self.lib.sml_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, t, dtype):
+        if isinstance(t, np.ndarray):
+            t = torch.from_numpy(np.ascontiguousarray(t))
+        t = t.to(device=self.device, dtype=dtype)
+        return t if t.is_contiguous() else t.contiguous()
+
+    def _table(self, t):
+        if t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous() or t.shape[-1] != self.d:
+            raise ValueError("expected a contiguous fp32 [rows,%d] tensor on %s, got %s %s on %s"
+                             % (self.d, self.device, tuple(t.shape), t.dtype, t.device))
+        return t
+
+    def adopt(self, transfer):
+        """Re-point the transfer module's parameters into one flat device buffer
+        (user net then item net, layout sml_theta_offset) and return that buffer."""
+        key = id(transfer)
+        ent = self._flat.get(key)
+        if ent is not None:
+            flat, views = ent
+            if all(p.data_ptr() == flat.data_ptr() + 4 * off for (p, off, _) in views):
+                return flat
+        flat = torch.zeros(2 * self.net_size, device=self.device, dtype=torch.float32)
+        views = []
+        for ni, net in enumerate((transfer.user_transfer, transfer.item_transfer)):
+            named = dict(net.named_parameters())
+            for w, name in enumerate(NET_PARAM_ORDER):
+                p = named[name]
+                off = ni * self.net_size + self.offsets[w]
+                n = p.numel()
+                flat[off:off + n].copy_(p.data.reshape(-1).to(self.device, torch.float32))
+                p.data = flat[off:off + n].view(p.shape)
+                views.append((p, off, n))
+        self._flat[key] = (flat, views)
+        return flat
+
+    # ------------------------------------------------------------------ a5/a6/a10
+    def transfer_forward(self, transfer, x_t, x_hat, which):
+        net = {"user": 0, "item": 1}.get(which)
+        if net is None:
+            raise TypeError("convtransfer has not this type")
+        theta = self.adopt(transfer)
+        x_t = self._table(self._dev(x_t, torch.float32))
+        x_hat = self._table(self._dev(x_hat.detach(), torch.float32))
+        out = torch.empty_like(x_t)
+        check(self.lib.sml_transfer_forward(self._ctx, _ptr(theta), net, _ptr(x_t), _ptr(x_hat), _ptr(out),
+                                            x_t.shape[0], self._stream()), "sml_transfer_forward")
+        return out
+
+    def updata(self, transfer, last_user, hat_user, last_item, hat_item, out_user, out_item):
+        theta = self.adopt(transfer)
+        for net, (xt, xh, out) in enumerate(((last_user, hat_user, out_user), (last_item, hat_item, out_item))):
+            xt, xh, out = self._table(xt), self._table(xh), self._table(out)
+            if out.data_ptr() in (xt.data_ptr(), xh.data_ptr()):
+                raise ValueError("updata output may not alias its inputs")
+            check(self.lib.sml_transfer_forward(self._ctx, _ptr(theta), net, _ptr(xt), _ptr(xh), _ptr(out),
+                                                xt.shape[0], self._stream()), "sml_transfer_forward")
+
+    # ------------------------------------------------------------------ a8
+    def _mf_tables(self, mfbase, last_user, last_item):
+        wu, wi = self._table(mfbase.user_laten.weight.data), self._table(mfbase.item_laten.weight.data)
+        if self.mf_state is None or self.mf_state["m_u"].shape != wu.shape or self.mf_state["m_i"].shape != wi.shape:
+            z = lambda t: torch.zeros_like(t)
+            self.mf_state = dict(m_u=z(wu), v_u=z(wu), m_i=z(wi), v_i=z(wi),
+                                 s_u=torch.full((wu.shape[0],), self.mf_step, device=self.device, dtype=torch.int32),
+                                 s_i=torch.full((wi.shape[0],), self.mf_step, device=self.device, dtype=torch.int32))
+        s = self.mf_state
+        t = _lib.MFTables()
+        t.w_user, t.w_item = wu.data_ptr(), wi.data_ptr()
+        t.last_user = self._table(last_user).data_ptr() if last_user is not None else 0
+        t.last_item = self._table(last_item).data_ptr() if last_item is not None else 0
+        t.m_user, t.v_user, t.m_item, t.v_item = (s["m_u"].data_ptr(), s["v_u"].data_ptr(),
+                                                  s["m_i"].data_ptr(), s["v_i"].data_ptr())
+        t.step_user, t.step_item = s["s_u"].data_ptr(), s["s_i"].data_ptr()
+        t.n_user, t.n_item = wu.shape[0], wi.shape[0]
+        return t
+
+    @staticmethod
+    def _loss_kind(bce, norm):
+        if bce:
+            return _lib.LOSS_BCE
+        return _lib.LOSS_BPR_NORM if norm else _lib.LOSS_BPR
+
+    def mf_stage_epoch(self, mfbase, transfer, last_user, last_item, triples, batch_size, lr, l2, norm=False, bce=True):
+        theta = self.adopt(transfer)
+        tri = self._dev(triples, torch.int64)
+        n = tri.shape[0]
+        nb = (n + batch_size - 1) // batch_size
+        t = self._mf_tables(mfbase, last_user, last_item)
+        self._mf_lr = float(lr)
+        losses = torch.empty(nb, device=self.device, dtype=torch.float32)
+        step = ctypes.c_int64(self.mf_step)
+        check(self.lib.sml_mf_stage_epoch(self._ctx, _ptr(theta), ctypes.byref(t), _ptr(tri), n, int(batch_size),
+                                          float(lr), float(l2), self._loss_kind(bce, norm), ctypes.byref(step),
+                                          _ptr(losses), self._stream()), "sml_mf_stage_epoch")
+        self.mf_step = step.value
+        return losses
+
+    def mf_flush(self, mfbase):
+        """Replay pending zero-gradient Adam steps so the tables can be read."""
+        if self.mf_state is None or self.mf_step == 0:
+            return
+        t = self._mf_tables(mfbase, None, None)
+        check(self.lib.sml_mf_adam_flush(self._ctx, ctypes.byref(t), float(self._mf_lr), self.mf_step, self._stream()),
+              "sml_mf_adam_flush")
+
+    # ------------------------------------------------------------------ a9
+    def tr_stage_epoch(self, transfer, last_user, last_item, hat_user, hat_item, triples, batch_size, lr,
+                       weight_decay, bce=True, loss_scale=1.0):
+        theta = self.adopt(transfer)
+        if self.tr_state is None or self.tr_state[0].shape != theta.shape:
+            self.tr_state = (torch.zeros_like(theta), torch.zeros_like(theta), torch.zeros_like(theta))
+        m, v, grad = self.tr_state
+        tri = self._dev(triples, torch.int64)
+        n = tri.shape[0]
+        nb = (n + batch_size - 1) // batch_size
+        t = _lib.TRTables()
+        t.last_user, t.last_item = self._table(last_user).data_ptr(), self._table(last_item).data_ptr()
+        t.hat_user, t.hat_item = self._table(hat_user).data_ptr(), self._table(hat_item).data_ptr()
+        t.n_user, t.n_item = last_user.shape[0], last_item.shape[0]
+        losses = torch.empty(nb, device=self.device, dtype=torch.float32)
+        step = ctypes.c_int64(self.tr_step)
+        if self.grad_hook is not None:
+            hook_fn = self.grad_hook
+
+            def _cb(_user, _grad, _n, b):
+                try:
+                    hook_fn(grad, int(b))
+                    return 0
+                except Exception:  # surfaced as SML_ESTATE by the library
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            cb = _lib.GRAD_HOOK(_cb)
+        else:
+            cb = ctypes.cast(None, _lib.GRAD_HOOK)
+        check(self.lib.sml_tr_stage_epoch(self._ctx, _ptr(theta), _ptr(m), _ptr(v), _ptr(grad), ctypes.byref(t),
+                                          _ptr(tri), n, int(batch_size), float(lr), float(weight_decay),
+                                          self._loss_kind(bce, False), float(loss_scale), ctypes.byref(step),
+                                          _ptr(losses), cb, None, self._stream()), "sml_tr_stage_epoch")
+        self.tr_step = step.value
+        return losses
+
+    # ------------------------------------------------------------------ a3
+    def bare_epoch(self, w_user, w_item, triples, batch_size, lr, lam_user, lam_item, bce=True):
+        if w_user.dtype not in (torch.float32, torch.float16) or w_item.dtype != w_user.dtype:
+            raise ValueError("tables must both be fp32 or both fp16")
+        for w in (w_user, w_item):
+            if w.device != self.device or not w.is_contiguous() or w.shape[-1] != self.d:
+                raise ValueError("tables must be contiguous [rows,%d] on %s" % (self.d, self.device))
+        tri = self._dev(triples, torch.int64)
+        n = tri.shape[0]
+        nb = (n + batch_size - 1) // batch_size
+        losses = torch.empty(nb, device=self.device, dtype=torch.float32)
+        check(self.lib.sml_embed_loss_sgd_epoch(self._ctx, _ptr(w_user), _ptr(w_item), w_user.shape[0], w_item.shape[0],
+                                                w_user.element_size(), _ptr(tri), n, int(batch_size), float(lr),
+                                                float(lam_user), float(lam_item),
+                                                _lib.LOSS_BCE if bce else _lib.LOSS_BPR, _ptr(losses), self._stream()),
+              "sml_embed_loss_sgd_epoch")
+        return losses
+
+    # ------------------------------------------------------------------ a2
+    def mf_forward(self, w_user, w_item, user, item, norm=False):
+        wu, wi = self._table(w_user), self._table(w_item)
+        user, item = self._dev(user, torch.int64), self._dev(item, torch.int64)
+        n = user.shape[0]
+        ue = torch.empty(n, self.d, device=self.device, dtype=torch.float32)
+        ie = torch.empty_like(ue)
+        sc = torch.empty(n, device=self.device, dtype=torch.float32)
+        check(self.lib.sml_mf_forward(self._ctx, _ptr(wu), _ptr(wi), _ptr(user), _ptr(item), n, int(bool(norm)),
+                                      _ptr(ue), _ptr(ie), _ptr(sc), self._stream()), "sml_mf_forward")
+        return ue, ie, sc
+
+    # ------------------------------------------------------------------ a13
+    def eval_ranks(self, user_tab, item_tab, rows):
+        wu, wi = self._table(user_tab), self._table(item_tab)
+        rows = self._dev(rows, torch.int64)
+        n, c = rows.shape
+        rank = torch.empty(n, device=self.device, dtype=torch.int32)
+        check(self.lib.sml_eval_ranks(self._ctx, _ptr(wu), _ptr(wi), _ptr(rows), n, c, _ptr(rank), self._stream()),
+              "sml_eval_ranks")
+        return rank
+
+    def eval_metrics(self, ranks, topk):
+        out = torch.empty(2, device=self.device, dtype=torch.float32)
+        check(self.lib.sml_eval_metrics(self._ctx, _ptr(ranks), ranks.shape[0], int(topk), _ptr(out), self._stream()),
+              "sml_eval_metrics")
+        h = out.cpu()
+        return float(h[0]), float(h[1])
+
+    def selftest(self):
+        check(self.lib.sml_selftest(self.device.index), "sml_selftest")
+
+
+_engines = {}
+
+
+def get_engine(device, d, max_batch=4096):
+    """Process-wide engine for (device, d)."""
+    dev = torch.device(device)
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    key = (str(dev), int(d))
+    eng = _engines.get(key)
+    if eng is None or eng.max_batch < max_batch:
+        eng_new = HipEngine(dev, d, max(max_batch, eng.max_batch if eng else 0))
+        if eng is not None:   # keep optimiser state and adopted thetas across a scratch resize
+            for k in ("_flat", "mf_state", "mf_step", "tr_state", "tr_step", "grad_hook"):
+                setattr(eng_new, k, getattr(eng, k))
+            if hasattr(eng, "_mf_lr"):
+                eng_new._mf_lr = eng._mf_lr
+        _engines[key] = eng = eng_new
+    return eng

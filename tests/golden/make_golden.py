@@ -1,0 +1,434 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container, where the reference checkout is mounted at
+/root/reference (read-only).  Nothing from the reference is copied: this script
+drives the reference's own classes on seeded inputs and records inputs and
+outputs as .npz data.  The GPU box never sees /root/reference; tests there read
+only the committed fixtures.
+
+Harness-side shims (the reference is untouched):
+  1. a stub torch.utils.tensorboard.SummaryWriter (tensorboard is not installed),
+  2. Tensor.cuda / Module.cuda -> identity (there is no GPU here),
+  3. torch.load(..., weights_only=False) for the whole-module checkpoint pickle,
+  4. test_model's NDCG wrapped back into a tensor (numpy.float32 has no .cpu()).
+
+Fixtures:  G1 transfer forward, G2 run_MF loss and
+gradients, G3 MF-stage steps, G4 TR-stage steps, G5 updata, G6 evaluation,
+G7 end-to-end main_yelp.py log on a tiny 40-period dataset, G8 batch supply,
+G9 parameter initialisation.
+
+usage: python tests/golden/make_golden.py [--ref /root/reference]
+"""
+import argparse
+import contextlib
+import io
+import os
+import runpy
+import shutil
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+
+
+# --------------------------------------------------------------------------- shims
+def install_shims(ref):
+    if "torch.utils.tensorboard" not in sys.modules:
+        tb = types.ModuleType("torch.utils.tensorboard")
+
+        class SummaryWriter(object):
+            def __init__(self, *a, **k):
+                pass
+
+            def add_scalar(self, *a, **k):
+                pass
+
+            def add_scalars(self, *a, **k):
+                pass
+
+        tb.SummaryWriter = SummaryWriter
+        sys.modules["torch.utils.tensorboard"] = tb
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    torch.cuda.manual_seed = lambda *a, **k: None
+    _orig_load = torch.load
+
+    def _load(f, *a, **k):
+        k["weights_only"] = False
+        return _orig_load(f, *a, **k)
+
+    torch.load = _load
+    sys.path.insert(0, ref)
+    sys.path.insert(1, REPO)  # for sml_amd.synth (the build's own generator)
+    import model.transfer as T
+
+    _orig_tm = T.test_model
+
+    def _tm(*a, **k):
+        r, n = _orig_tm(*a, **k)
+        return r, torch.as_tensor(np.float32(n))
+
+    T.test_model = _tm
+    return T
+
+
+def sd_np(module, prefix=""):
+    return {prefix + k: v.detach().cpu().numpy().copy() for k, v in module.state_dict().items()}
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print("wrote", name, "%.1f KB" % (os.path.getsize(path) / 1024.0))
+
+
+class Args(object):
+    """Minimal args namespace with the reference's defaults (main_yelp.py:10-120)."""
+
+    def __init__(self, **kw):
+        d = dict(data_name="yelp", data_path="", multi_num=2, MF_lr=0.01, MF_epochs=1, l2=1e-6,
+                 MF_batch_size=32, laten=32, pre_model="", MF_sample="all", Load_W_hat=False,
+                 clip_grad=False, need_adaptive=False, maxnorm_grad=3.0, TR_lr=0.001, TR_l2=1e-4,
+                 TR_epochs=1, TR_batch_size=16, TR_sample_type="alone", TR_with_MF_bias=False,
+                 TR_stop_=False, transfer_type="conv_com", seed=2000, numworkers=0, cuda=0, topK=20,
+                 pass_num=1, norm=False, Lambda_lr=0.01, min_l2=1e-4, set_t_as_tt=False, tqdm=False,
+                 need_writer=False, test_in_TR_Train=False)
+        d.update(kw)
+        self.__dict__.update(d)
+
+
+# --------------------------------------------------------------------------- G1 / G2 / G9
+def gen_g1_g2_g9(T):
+    from model.conv_transfer import ConvTransfer_com
+    from model.MF import MFbasemode
+
+    for d in (32, 64):
+        torch.manual_seed(100 + d)
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = ConvTransfer_com(d, d)
+        g = torch.Generator().manual_seed(7 + d)
+        x_t = torch.randn(64, d, generator=g)
+        x_hat = torch.randn(64, d, generator=g)
+        with torch.no_grad():
+            yu = net(x_t, x_hat, "user")
+            yi = net(x_t, x_hat, "item")
+        out = sd_np(net, "theta.")
+        out.update(x_t=x_t.numpy(), x_hat=x_hat.numpy(), y_user=yu.numpy(), y_item=yi.numpy())
+        save("g1_transfer_forward_d%d.npz" % d, **out)
+
+        # G2: run_MF loss + gradients (w.r.t. x_hat inputs and theta)
+        B = 48
+        ten = [torch.randn(B, d, generator=g) * 0.7 for _ in range(6)]
+        res = {}
+        for tag, kw in (("bce", dict()), ("bpr", dict(BCE=False)), ("bprnorm", dict(BCE=False, norm=True))):
+            ins = [t.clone() for t in ten]
+            for k in (1, 3, 5):
+                ins[k].requires_grad_(True)
+            net.zero_grad()
+            loss = net.run_MF(*ins, **kw)
+            loss.backward()
+            res["loss_" + tag] = loss.detach().numpy()
+            res["gu_" + tag] = ins[1].grad.numpy().copy()
+            res["gi_" + tag] = ins[3].grad.numpy().copy()
+            res["gn_" + tag] = ins[5].grad.numpy().copy()
+            for k, p in net.named_parameters():
+                res["gtheta_%s.%s" % (tag, k)] = p.grad.detach().numpy().copy()
+        out = sd_np(net, "theta.")
+        out.update(res)
+        for k, nm in enumerate(("ul", "uh", "il", "ih", "nl", "nh")):
+            out[nm] = ten[k].numpy()
+        save("g2_run_mf_d%d.npz" % d, **out)
+
+    # G9: creation order / RNG draw order of the parameter initialisers
+    torch.manual_seed(2000)
+    mf = MFbasemode(37, 23, 32)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = ConvTransfer_com(32, 32)
+    out = sd_np(mf, "mf.")
+    out.update(sd_np(net, "theta."))
+    out["mf_keys"] = np.array(list(mf.state_dict().keys()))
+    out["theta_keys"] = np.array(list(net.state_dict().keys()))
+    save("g9_init.npz", **out)
+
+
+# --------------------------------------------------------------------------- G3 / G4 / G5
+class _FakeData(object):
+    user_number = 0
+    item_number = 0
+
+
+def build_meta(T, tmp, U, I, d, args, seed):
+    """Construct the reference meta_train on a seeded random checkpoint."""
+    from model.MF import MFbasemode
+
+    torch.manual_seed(seed)
+    mf = MFbasemode(U, I, d)
+    ck = os.path.join(tmp, "init_%d.pkl" % seed)
+    torch.save(mf, ck)
+    args.pre_model = ck
+    args.laten = d
+    with contextlib.redirect_stdout(io.StringIO()):
+        meta = T.meta_train(args, _FakeData(), U, I, d)
+    return meta
+
+
+def gen_g3_g4_g5(T, tmp):
+    from data.dataset2 import trainDataset_withPreSample
+    from data.dataset import offlineDataset_withsample
+
+    U, I, d = 50, 40, 32
+    args = Args(MF_batch_size=32, TR_batch_size=16, MF_epochs=2, TR_epochs=2)
+    meta = build_meta(T, tmp, U, I, d, args, seed=31)
+    rng = np.random.RandomState(5)
+    # the transfer net only sees non-trivial x_t after a 'last' save; make W_{t-1} != W_hat
+    meta.save_MF_weight("last")
+    with torch.no_grad():
+        meta.MFbase.user_laten.weight.add_(0.05 * torch.randn(U, d))
+        meta.MFbase.item_laten.weight.add_(0.05 * torch.randn(I, d))
+
+    out = {}
+    out.update(sd_np(meta.transfer, "theta0."))
+    out["W_user0"] = meta.MFbase.user_laten.weight.detach().numpy().copy()
+    out["W_item0"] = meta.MFbase.item_laten.weight.detach().numpy().copy()
+    out["Wlast_user"] = meta.last_user_weight.numpy().copy()
+    out["Wlast_item"] = meta.last_item_weight.numpy().copy()
+
+    # period data: set_t in the 'test' layout [n, 2+neg] (MF_sample == 'all')
+    n_t, neg = 200, 9
+    users = rng.randint(0, U, size=n_t)
+    users[:40] = 3  # heavy duplicates
+    items = rng.randint(0, I, size=n_t)
+    negs = rng.randint(0, I - 1, size=(n_t, neg))
+    negs += negs >= items[:, None]
+    set_t = np.concatenate([users[:, None], items[:, None], negs], axis=1).astype(np.int64)
+    out["set_t"] = set_t
+
+    # record batches in DataLoader order through a recording dataset wrapper
+    log = []
+
+    class RecMF(trainDataset_withPreSample):
+        def __getitem__(self, idx):
+            r = trainDataset_withPreSample.__getitem__(self, idx)
+            log.append((int(r[0]), int(r[1]), int(r[2])))
+            return r
+
+    meta.MF_TrainDataset = RecMF
+    losses = []
+    orig_run = meta.transfer.run_MF
+
+    def rec_run(*a, **k):
+        l = orig_run(*a, **k)
+        losses.append(float(l.detach()))
+        return l
+
+    meta.transfer.run_MF = rec_run
+    torch.manual_seed(77)
+    np.random.seed(78)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        meta.MF_train_onestage(args, set_t, 0, val=None)
+    out["mf_log"] = np.array(buf.getvalue())
+    out["mf_triples"] = np.array(log, dtype=np.int64)  # [epochs*n_t, 3] in consumption order
+    out["mf_runmf_loss"] = np.array(losses, dtype=np.float64)
+    out["W_user1"] = meta.MFbase.user_laten.weight.detach().numpy().copy()
+    out["W_item1"] = meta.MFbase.item_laten.weight.detach().numpy().copy()
+    st = meta.MF_optimizer.state
+    pu, pi = meta.MFbase.user_laten.weight, meta.MFbase.item_laten.weight
+    out["adam_m_user"] = st[pu]["exp_avg"].numpy().copy()
+    out["adam_v_user"] = st[pu]["exp_avg_sq"].numpy().copy()
+    out["adam_m_item"] = st[pi]["exp_avg"].numpy().copy()
+    out["adam_v_item"] = st[pi]["exp_avg_sq"].numpy().copy()
+    out["adam_step"] = np.array(float(st[pu]["step"]))
+    out["hp_mf"] = np.array([args.MF_lr, args.l2, args.MF_batch_size, args.MF_epochs], dtype=np.float64)
+    save("g3_mf_stage.npz", **out)
+
+    # ---- G5 updata (after save 'hat'), then G4 TR-stage steps on the same state
+    meta.MFbase.eval()
+    meta.save_MF_weight("hat")
+    g5 = {}
+    g5.update(sd_np(meta.transfer, "theta."))
+    g5["Wlast_user"] = meta.last_user_weight.numpy().copy()
+    g5["Wlast_item"] = meta.last_item_weight.numpy().copy()
+    g5["What_user"] = meta.user_weight_hat.numpy().copy()
+    g5["What_item"] = meta.item_weight_hat.numpy().copy()
+    meta.updata()
+    g5["Wnew_user"] = meta.MFbase.user_laten.weight.detach().numpy().copy()
+    g5["Wnew_item"] = meta.MFbase.item_laten.weight.detach().numpy().copy()
+    save("g5_updata.npz", **g5)
+
+    g4 = {}
+    g4.update(sd_np(meta.transfer, "theta0."))
+    g4["Wlast_user"] = g5["Wlast_user"]
+    g4["Wlast_item"] = g5["Wlast_item"]
+    g4["What_user"] = g5["What_user"]
+    g4["What_item"] = g5["What_item"]
+    n_tt = 90
+    set_tt = np.stack([rng.randint(0, U, size=n_tt), rng.randint(0, I // 2, size=n_tt)], axis=1).astype(np.int64)
+    g4["set_tt"] = set_tt
+    log2 = []
+
+    class RecTR(offlineDataset_withsample):
+        def __getitem__(self, idx):
+            r = offlineDataset_withsample.__getitem__(self, idx)
+            log2.append((int(r[0]), int(r[1]), int(r[2])))
+            return r
+
+    T.SampleDaset = RecTR
+    losses.clear()
+    torch.manual_seed(177)
+    np.random.seed(178)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        meta.transfer_train_onestage(args, set_tt, 0, val=None)
+    T.SampleDaset = offlineDataset_withsample
+    g4["tr_log"] = np.array(buf.getvalue())
+    g4["tr_triples"] = np.array(log2, dtype=np.int64)
+    g4["tr_runmf_loss"] = np.array(losses, dtype=np.float64)
+    g4.update(sd_np(meta.transfer, "theta1."))
+    ost = meta.transfer_optimizer.state
+    for k, p in meta.transfer.named_parameters():
+        g4["adam_m." + k] = ost[p]["exp_avg"].numpy().copy()
+        g4["adam_v." + k] = ost[p]["exp_avg_sq"].numpy().copy()
+    g4["adam_step"] = np.array(float(ost[next(meta.transfer.parameters())]["step"]))
+    g4["hp_tr"] = np.array([args.TR_lr, args.TR_l2, args.TR_batch_size, args.TR_epochs], dtype=np.float64)
+    save("g4_tr_stage.npz", **g4)
+
+
+# --------------------------------------------------------------------------- G6 eval
+def gen_g6(T):
+    from model.MF import MFbasemode
+    from data.dataset2 import testDataset
+
+    torch.manual_seed(11)
+    U, I, d, n, neg = 60, 150, 32, 97, 99
+    mf = MFbasemode(U, I, d)
+    rng = np.random.RandomState(12)
+    users = rng.randint(0, U, size=n)
+    pos = rng.randint(0, I, size=n)
+    rows = np.zeros((n, 2 + neg), dtype=np.int64)
+    for r in range(n):
+        cand = np.setdiff1d(np.arange(I), [pos[r]])
+        rows[r, 0] = users[r]
+        rows[r, 1] = pos[r]
+        rows[r, 2:] = rng.choice(cand, size=neg, replace=False)  # distinct items: tie-free
+    out = sd_np(mf, "mf.")
+    out["rows"] = rows
+    for K in (5, 10, 20):
+        with torch.no_grad():
+            hit, ndcg, idx = mf.test(torch.from_numpy(rows), topK=K)
+        out["hit_%d" % K] = np.array(float(hit))
+        out["ndcg_%d" % K] = np.array(float(ndcg))
+        out["hitidx_%d" % K] = idx.numpy().copy()
+        loader = torch.utils.data.DataLoader(testDataset(rows), batch_size=32, num_workers=0)
+        import evalution.evaluation2 as E
+        r, nd = E.test_model(mf, loader, topK=K)
+        out["recall_%d" % K] = np.array(float(r))
+        out["ndcgavg_%d" % K] = np.array(float(nd))
+    save("g6_eval.npz", **out)
+
+
+# --------------------------------------------------------------------------- G8 batch supply
+def gen_g8(T):
+    from data.dataset2 import trainDataset_withPreSample
+    from data.dataset import offlineDataset_withsample
+
+    rng = np.random.RandomState(21)
+    n, neg, U, I = 70, 6, 20, 30
+    items = rng.randint(0, I, size=n)
+    negs = rng.randint(0, I - 1, size=(n, neg))
+    negs += negs >= items[:, None]
+    table = np.concatenate([rng.randint(0, U, size=(n, 1)), items[:, None], negs], axis=1).astype(np.int64)
+    out = {"table": table}
+    torch.manual_seed(501)
+    np.random.seed(502)
+    ds = trainDataset_withPreSample(table)
+    dl = torch.utils.data.DataLoader(ds, batch_size=16, shuffle=True, num_workers=0)
+    seq = []
+    for ep in range(8):  # > neg epochs: exercises the column switch and the reshuffle of neg_flag
+        for (u, i, j) in dl:
+            seq.append(torch.stack([u, i, j], 1).numpy())
+    out["presample_seq"] = np.concatenate(seq, 0)
+    pairs = np.stack([rng.randint(0, U, size=n), rng.randint(0, 12, size=n)], axis=1).astype(np.int64)
+    out["pairs"] = pairs
+    torch.manual_seed(503)
+    np.random.seed(504)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ds2 = offlineDataset_withsample(pairs)
+    dl2 = torch.utils.data.DataLoader(ds2, batch_size=16, shuffle=True, num_workers=0)
+    seq = []
+    for ep in range(3):
+        for (u, i, j) in dl2:
+            seq.append(torch.stack([torch.as_tensor(u), torch.as_tensor(i), torch.as_tensor(j)], 1).numpy())
+    out["withsample_seq"] = np.concatenate(seq, 0)
+    save("g8_batches.npz", **out)
+
+
+# --------------------------------------------------------------------------- G7 end to end
+def gen_g7(T, ref, tmp):
+    from sml_amd import synth
+    from model.MF import MFbasemode
+
+    root = os.path.join(tmp, "data") + "/"
+    U, I, d = 300, 120, 32
+    synth.write_dataset(root, "yelp", n_periods=40, n_inter=160, n_user=U, n_item=I, neg=49,
+                        a_user=0.8, a_item=0.8, seed=2000)
+    torch.manual_seed(4242)
+    mf = MFbasemode(U, I, d)
+    with torch.no_grad():  # a small-norm init behaves like a pretrained MF (scores not saturated)
+        mf.user_laten.weight.mul_(0.3)
+        mf.item_laten.weight.mul_(0.3)
+    ck = os.path.join(tmp, "BCE_init.pkl")
+    torch.save(mf, ck)
+    argv = ["main_yelp.py", "--data_path", root, "--pre_model", ck, "--laten", str(d), "--multi_num", "2",
+            "--numworkers", "0", "--MF_batch_size", "64", "--TR_batch_size", "32"]
+    buf = io.StringIO()
+    old = sys.argv
+    sys.argv = argv
+    try:
+        with contextlib.redirect_stdout(buf):
+            runpy.run_path(os.path.join(ref, "main_yelp.py"), run_name="__main__")
+    finally:
+        sys.argv = old
+    log = buf.getvalue()
+    out = sd_np(mf, "mf.")
+    out["log"] = np.array(log)
+    out["argv"] = np.array(argv[5:])
+    out["dataset"] = np.array([40, 160, U, I, 49, 2000], dtype=np.int64)
+    out["dataset_zipf"] = np.array([0.8, 0.8])
+    save("g7_end_to_end.npz", **out)
+    # a reference-pickled whole-module checkpoint: the on-disk contract for --pre_model
+    shutil.copy(ck, os.path.join(HERE, "ref_BCE_init_tiny.pkl"))
+    print("log lines:", len(log.splitlines()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    T = install_shims(a.ref)
+    tmp = tempfile.mkdtemp(prefix="sml_golden_")
+    try:
+        only = set(a.only.split(",")) if a.only else None
+        if not only or "g1" in only:
+            gen_g1_g2_g9(T)
+        if not only or "g3" in only:
+            gen_g3_g4_g5(T, tmp)
+        if not only or "g6" in only:
+            gen_g6(T)
+        if not only or "g8" in only:
+            gen_g8(T)
+        if not only or "g7" in only:
+            gen_g7(T, a.ref, tmp)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
