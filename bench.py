@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- SML per-period retraining throughput on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one full SML retrain period (reference meta_train.train_one_stage3,
+model/transfer.py:753-792: multi_num x [MF epoch, updata, TR epoch, updata] with the
+validation evaluations the reference performs) on a Yelp-shaped synthetic period
+(BASELINE.json configs[1]: U=60,000, I=123,000, 75,000 interactions, 999 negatives,
+d=32, MF batch 1024, TR batch 256, multi_num 10).  Inputs (every epoch's triples,
+validation rows, tables) are resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0.  `value` = training triples (MF + TR stage) per second,
+whole job.  Extra objects: `roofline` for the kernel that dominates GPU time (measured
+with HIP events inside this process) and `cpu_baseline` (the CPU oracle timed on a
+bounded sample of the same workload, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--d", type=int, default=32)
+    ap.add_argument("--users", type=int, default=60000)
+    ap.add_argument("--items", type=int, default=123000)
+    ap.add_argument("--inter", type=int, default=75000)
+    ap.add_argument("--neg", type=int, default=999)
+    ap.add_argument("--multi_num", type=int, default=10)
+    ap.add_argument("--no-val", action="store_true", help="skip the validation evaluations (not the reference default)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def build_state(engine, U, I, d, device, seed):
+    from sml_amd.conv_transfer import ConvTransfer_com
+    from sml_amd.mf import MFbasemode
+    from sml_amd.period import PeriodState
+    import contextlib, io
+    torch.manual_seed(seed)
+    mf = MFbasemode(U, I, d)
+    with torch.no_grad():   # pretrained-MF-like scale (scores not saturated)
+        mf.user_laten.weight.mul_(0.3)
+        mf.item_laten.weight.mul_(0.3)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = ConvTransfer_com(d, d)
+    mf, net = mf.to(device), net.to(device)
+    mf._sml_engine = engine
+    net._sml_engine = engine
+    engine.adopt(net)
+    return PeriodState(mf, net)
+
+
+def kernel_work(name, a, hp, U_local):
+    """Algorithmic work of one period per kernel class: (bound, unit_work_total, launches_expected).
+    Bytes for HBM-bound kernels, FLOP for the MFMA-bound ones."""
+    d, n = a.d, a.inter
+    nb_mf = -(-n // hp.MF_batch_size)
+    nb_tr = -(-n // hp.TR_batch_size)
+    evals = 0 if a.no_val else hp.multi_num * (2 + hp.MF_epochs + hp.TR_epochs)
+    n_updata = hp.multi_num * (1 + (hp.TR_epochs if not a.no_val else 0)) + 1
+    rows_fwd = hp.multi_num * (hp.MF_epochs + hp.TR_epochs) * 3 * n + n_updata * (U_local + a.items)
+    f_row = 6304.0 * d                      # conv prologue + fc1 + fc2 forward, FLOP per row
+    b_row = (2.0 * d * 512 + 2.0 * 512 * 5 * d) + 160.0 * d   # dA2 + dA1 GEMMs + per-coordinate tail
+    if name == "k_eval_ranks":
+        per = n * ((2 + a.neg) * d * 4 + (2 + a.neg) * 8 + 4)
+        return "hbm", per * evals, evals
+    if name == "k_transfer_fwd":
+        return "mfma", rows_fwd * f_row, hp.multi_num * (hp.MF_epochs * nb_mf + hp.TR_epochs * nb_tr) + 2 * n_updata
+    if name == "k_transfer_bwd":
+        return "mfma", hp.multi_num * (hp.MF_epochs + hp.TR_epochs) * 3 * n * b_row, hp.multi_num * (hp.MF_epochs * nb_mf + hp.TR_epochs * nb_tr)
+    if name == "k_transfer_wgrad":
+        return "mfma", hp.multi_num * hp.TR_epochs * 3 * n * (2.0 * 512 * 5 * d + 2.0 * 512 * d), hp.multi_num * hp.TR_epochs * nb_tr
+    if name == "k_seg_update_adam":
+        # per occurrence: gradient row read + (p, m, v) read and write
+        return "hbm", hp.multi_num * hp.MF_epochs * 3 * n * (d * 4 * 7 + 12), hp.multi_num * hp.MF_epochs * nb_mf
+    if name == "k_adam_flush":
+        return "hbm", hp.multi_num * hp.MF_epochs * (U_local + a.items) * (d * 4 * 6 + 8), 2 * hp.multi_num * hp.MF_epochs
+    return None, 0.0, 0
+
+
+def cpu_baseline(a, hp):
+    """The CPU oracle (oracle/sml_oracle.py, kind 'port') on a bounded sample of the same
+    period: full-size tables (dense Adam cost scales with the table), 4 MF batches, 8 TR
+    batches, updata over 1/16 of the rows, evaluation of 1024 rows; scaled to one period."""
+    from oracle import sml_oracle as O
+    from sml_amd.conv_transfer import ConvTransfer_com
+    from sml_amd.mf import MFbasemode
+    import contextlib, io
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(1)
+    U, I, d, n = a.users, a.items, a.d, a.inter
+    mf = MFbasemode(U, I, d)
+    with torch.no_grad():
+        mf.user_laten.weight.mul_(0.3)
+        mf.item_laten.weight.mul_(0.3)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = ConvTransfer_com(d, d)
+    eng = O.OracleEngine(d)
+    lu, li = mf.user_laten.weight.detach() * 0.9, mf.item_laten.weight.detach() * 0.9
+    rng = np.random.RandomState(0)
+    n_mf, n_tr = 4 * hp.MF_batch_size, 8 * hp.TR_batch_size
+    tri = lambda k: torch.from_numpy(np.stack([rng.randint(0, U, k), rng.randint(0, I, k), rng.randint(0, I, k)], 1))
+    t0 = time.time(); eng.mf_stage_epoch(mf, net, lu, li, tri(n_mf), hp.MF_batch_size, hp.MF_lr, hp.l2); t_mf = time.time() - t0
+    hu, hi = mf.user_laten.weight.detach().clone(), mf.item_laten.weight.detach().clone()
+    t0 = time.time(); eng.tr_stage_epoch(net, lu, li, hu, hi, tri(n_tr), hp.TR_batch_size, hp.TR_lr, hp.TR_l2); t_tr = time.time() - t0
+    ru, ri = U // 16, I // 16
+    ou, oi = torch.empty(ru, d), torch.empty(ri, d)
+    t0 = time.time(); eng.updata(net, lu[:ru], hu[:ru], li[:ri], hi[:ri], ou, oi); t_up = (time.time() - t0) * 16
+    rows = torch.from_numpy(np.concatenate([rng.randint(0, U, (1024, 1)), rng.randint(0, I, (1024, 1 + a.neg))], 1))
+    t0 = time.time(); O.eval_ranks(hu, hi, rows); t_ev = (time.time() - t0) * n / 1024.0
+    evals = 0 if a.no_val else hp.multi_num * (2 + hp.MF_epochs + hp.TR_epochs)
+    n_updata = hp.multi_num * (1 + (hp.TR_epochs if not a.no_val else 0)) + 1
+    period_s = hp.multi_num * (hp.MF_epochs * t_mf * n / n_mf + hp.TR_epochs * t_tr * n / n_tr) + n_updata * t_up + evals * t_ev
+    triples = hp.multi_num * (hp.MF_epochs + hp.TR_epochs) * n
+    return {"value": triples / period_s, "unit": "triples/s", "cores": cores, "kind": "port",
+            "sample": "oracle on full-size tables: %d MF triples, %d TR triples, updata on 1/16 of rows, eval of 1024 rows; "
+                      "scaled to one period (est. %.1f s/period: MF %.1f s, TR %.1f s, updata %.1f s, eval %.1f s)"
+                      % (n_mf, n_tr, period_s, hp.multi_num * hp.MF_epochs * t_mf * n / n_mf,
+                         hp.multi_num * hp.TR_epochs * t_tr * n / n_tr, n_updata * t_up, evals * t_ev)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if a.gpus != 1 and world == 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    from sml_amd.engine import HipEngine
+    from sml_amd.period import Hyper, run_period, synth_plan
+    hp = Hyper(multi_num=a.multi_num)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+        from sml_amd import dist as smldist
+    engine = HipEngine(device, a.d, max(hp.MF_batch_size, hp.TR_batch_size))
+    # weak scaling: every rank owns a shard of `users` users and processes its own period of
+    # `inter` interactions over them; items are replicated
+    U_local = a.users
+    st = build_state(engine, U_local, a.items, a.d, device, seed=2000 + rank)
+    if world > 1:
+        smldist.attach(engine, st, dist, hp)
+    n_plans = min(a.steps + a.warmup, 2)
+    plans = [synth_plan(100 + 17 * rank + p, a.inter, U_local, a.items, a.neg, hp, device, with_val=not a.no_val)
+             for p in range(max(n_plans, 1))]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for w in range(a.warmup):
+        run_period(engine, st, plans[w % len(plans)], hp)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(a.steps):
+        run_period(engine, st, plans[(a.warmup + s) % len(plans)], hp)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    triples_per_period = plans[0].n_train_triples()
+    value = a.steps * triples_per_period * world / dt
+
+    out = {"metric": "SML retrain-period training triples/s (MF + transfer stages), Yelp-shaped synthetic, d=%d" % a.d,
+           "value": value, "unit": "triples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "yelp_period: users=%d items=%d interactions/period=%d neg=%d d=%d multi_num=%d "
+                                  "MF_batch=%d TR_batch=%d val_eval=%s" % (a.users, a.items, a.inter, a.neg, a.d,
+                                                                           hp.multi_num, hp.MF_batch_size, hp.TR_batch_size,
+                                                                           not a.no_val),
+                      "parallelism": "users row-sharded x%d, items replicated" % world if world > 1 else "single GPU"}}
+
+    if not a.no_roofline:
+        engine.profile(True)
+        run_period(engine, st, plans[0], hp)
+        torch.cuda.synchronize(device)
+        prof = engine.profile_read()
+        engine.profile(False)
+        if prof and rank == 0:
+            dom = max(prof.items(), key=lambda kv: kv[1][1])
+            name, (cnt, ms) = dom
+            bound, work, _ = kernel_work(name, a, hp, U_local)
+            kern = {k: {"launches": c, "total_ms": round(m, 3), "avg_us": round(1000.0 * m / c, 2)} for k, (c, m) in prof.items()}
+            if bound is not None and cnt:
+                per_launch = work / cnt
+                avg_s = ms / 1000.0 / cnt
+                if bound == "hbm":
+                    ach, peak, unit = per_launch / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
+                else:
+                    ach, peak, unit = per_launch / avg_s / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+                out["roofline"] = {"kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
+                                   "frac": ach / peak, "traffic": None, "launches": cnt,
+                                   "avg_launch_us": 1e6 * avg_s, "algorithmic_per_launch": per_launch}
+            out["kernels"] = kern
+    if rank == 0 and world == 1 and not a.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(a, hp)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

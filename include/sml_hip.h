@@ -148,6 +148,16 @@ int sml_eval_ranks(sml_ctx* ctx, const float* w_user, const float* w_item, const
 /* hits = #{rank < topk}, ndcg = sum 1/log2(rank+2) over hits; out[0]=hits, out[1]=ndcg (device). */
 int sml_eval_metrics(sml_ctx* ctx, const int32_t* rank, int64_t n, int topk, float* out, void* stream);
 
+/* ---- measurement ------------------------------------------------------------------ */
+/* Optional HIP-event timing of every kernel launch on the caller's stream, by kernel class
+ * (bench.py's roofline leg).  Off by default; when on, each launch is bracketed by two
+ * event records.  sml_prof_get synchronises on the last recorded event. */
+int sml_prof_enable(sml_ctx* ctx, int on);
+int sml_prof_reset(sml_ctx* ctx);
+int sml_prof_classes(void);
+const char* sml_prof_name(int cls);
+int sml_prof_get(sml_ctx* ctx, int cls, int64_t* count, double* total_ms);
+
 /* ---- self test ------------------------------------------------------------------ */
 /* Checks the MFMA operand/accumulator lane maps this library assumes against a
  * scalar loop on the device.  Synchronous.  Returns 0 if they hold. */

@@ -58,6 +58,11 @@ SIGNATURES = {
                                       c_void, c_void, c_void]),
     "sml_eval_ranks": (ctypes.c_int, [c_void, c_void, c_void, c_void, ctypes.c_int64, ctypes.c_int, c_void, c_void]),
     "sml_eval_metrics": (ctypes.c_int, [c_void, c_void, ctypes.c_int64, ctypes.c_int, c_void, c_void]),
+    "sml_prof_enable": (ctypes.c_int, [c_void, ctypes.c_int]),
+    "sml_prof_reset": (ctypes.c_int, [c_void]),
+    "sml_prof_classes": (ctypes.c_int, []),
+    "sml_prof_name": (ctypes.c_char_p, [ctypes.c_int]),
+    "sml_prof_get": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]),
     "sml_selftest": (ctypes.c_int, [ctypes.c_int]),
 }
 

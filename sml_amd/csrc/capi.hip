@@ -53,6 +53,44 @@ struct Buf {
 
 bool d_ok(int d) { return d == 32 || d == 64 || d == 128; }
 
+// ---- optional per-kernel-class timing with HIP events on the caller's stream -------------
+enum ProfClass { PC_FWD = 0, PC_BWD, PC_WGRAD, PC_THETA_ADAM, PC_PAIR_LOSS, PC_SEG_ADAM, PC_SEG_SGD, PC_BARE_GRAD,
+                 PC_EVAL_RANKS, PC_FLUSH, PC_PACK, PC_SORT, PC_MISC, PC_COUNT };
+const char* const kProfNames[PC_COUNT] = {"k_transfer_fwd", "k_transfer_bwd", "k_transfer_wgrad", "k_theta_adam",
+                                          "k_pair_loss", "k_seg_update_adam", "k_seg_update_sgd", "k_bare_grad",
+                                          "k_eval_ranks", "k_adam_flush", "k_theta_pack", "sort_epoch", "misc"};
+struct Prof {
+    bool on = false;
+    std::vector<hipEvent_t> ev;     // pairs
+    std::vector<int> cls;
+    size_t used = 0;                // pairs in flight
+    double total_ms[PC_COUNT] = {0};
+    int64_t count[PC_COUNT] = {0};
+    static constexpr size_t kPairs = 4096;
+    void drain() {
+        if (!used) return;
+        (void)hipEventSynchronize(ev[2 * used - 1]);
+        for (size_t i = 0; i < used; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) == hipSuccess) { total_ms[cls[i]] += ms; count[cls[i]]++; }
+        }
+        used = 0;
+    }
+    void begin(int c, hipStream_t st) {
+        if (!on) return;
+        if (ev.empty()) { ev.resize(2 * kPairs); cls.resize(kPairs); for (auto& e : ev) (void)hipEventCreate(&e); }
+        if (used == kPairs) drain();
+        cls[used] = c;
+        (void)hipEventRecord(ev[2 * used], st);
+    }
+    void end(hipStream_t st) {
+        if (!on) return;
+        (void)hipEventRecord(ev[2 * used + 1], st);
+        ++used;
+    }
+    void release() { drain(); for (auto& e : ev) (void)hipEventDestroy(e); ev.clear(); }
+};
+
 }  // namespace
 
 struct sml_ctx {
@@ -69,8 +107,10 @@ struct sml_ctx {
     int sched_len = 0;
     float sched_lr = -1.0f;
     Buf<int32_t> dummy;
+    Prof prof;
 
     void release_all() {
+        prof.release();
         out.release(); dout.release(); dx.release(); xin.release(); z1.release(); a1.release(); dz1.release();
         pk.release(); grad.release(); convg.release(); loss_part.release();
         key_u.release(); key_u2.release(); key_i.release(); key_i2.release();
@@ -203,19 +243,20 @@ int sml_theta_pack(sml_ctx* ctx, const float* theta, void* stream) {
     if (!ctx || !theta) return fail(SML_EINVAL, "sml_theta_pack", "null argument");
     DevGuard g(ctx->device);
     int rc = ensure_pk(ctx); if (rc) return rc;
-    HIPCHK(sml_launch_theta_pack(ctx->d, theta, ctx->pk.p, (hipStream_t)stream));
+    hipStream_t st = (hipStream_t)stream;
+    ctx->prof.begin(PC_PACK, st); HIPCHK(sml_launch_theta_pack(ctx->d, theta, ctx->pk.p, st)); ctx->prof.end(st);
     return SML_OK;
 }
 
 int sml_transfer_forward(sml_ctx* ctx, const float* theta, int net, const float* x_t, const float* x_hat, float* out,
                          int64_t n_rows, void* stream) {
+    if (n_rows == 0) return SML_OK;
     if (!ctx || !theta || !x_t || !x_hat || !out || (net != 0 && net != 1) || n_rows < 0 || n_rows > 0x7fffffff)
         return fail(SML_EINVAL, "sml_transfer_forward", "bad argument");
-    if (n_rows == 0) return SML_OK;
     DevGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     int rc = ensure_pk(ctx); if (rc) return rc;
-    HIPCHK(sml_launch_theta_pack(ctx->d, theta, ctx->pk.p, st));
+    ctx->prof.begin(PC_PACK, st); HIPCHK(sml_launch_theta_pack(ctx->d, theta, ctx->pk.p, st)); ctx->prof.end(st);
     SmlFwdArgs a;
     memset(&a, 0, sizeof(a));
     SmlSeg& s = a.seg[0];
@@ -224,7 +265,7 @@ int sml_transfer_forward(sml_ctx* ctx, const float* theta, int net, const float*
     s.xt_tab = x_t; s.xh_tab = x_hat; s.n_rows = (int)n_rows; s.out = out;
     a.tiles0 = tiles_of((int)n_rows);
     a.seg[1] = s; a.seg[1].n_rows = 0;
-    HIPCHK(sml_launch_fwd(ctx->d, a, a.tiles0, st));
+    ctx->prof.begin(PC_FWD, st); HIPCHK(sml_launch_fwd(ctx->d, a, a.tiles0, st)); ctx->prof.end(st);
     return SML_OK;
 }
 
@@ -245,8 +286,8 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
     if ((rc = ensure_sched(ctx, lr, *step + nb + 1))) return rc;
     const int lstride = (batch * (d / 4) + 255) / 256;
     HIPCHK(ctx->loss_part.ensure((size_t)nb * lstride));
-    HIPCHK(sml_launch_theta_pack(d, theta, ctx->pk.p, st));
-    if ((rc = sort_epoch(ctx, triples, n, batch, st))) return rc;
+    ctx->prof.begin(PC_PACK, st); HIPCHK(sml_launch_theta_pack(d, theta, ctx->pk.p, st)); ctx->prof.end(st);
+    ctx->prof.begin(PC_SORT, st); rc = sort_epoch(ctx, triples, n, batch, st); ctx->prof.end(st); if (rc) return rc;
     HIPCHK(hipMemsetAsync(ctx->loss_part.p, 0, (size_t)nb * lstride * sizeof(float), st));
     const int64_t ns = sml_net_size(d), ps = sml_pk_size(d);
     for (int64_t b = 0; b < nb; ++b) {
@@ -269,11 +310,11 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
         }
         f.tiles0 = tiles_of(B); f.cur_step = cur; f.sched = ctx->sched.p;
         const int tiles = f.tiles0 + tiles_of(2 * B);
-        HIPCHK(sml_launch_fwd(d, f, tiles, st));
+        ctx->prof.begin(PC_FWD, st); HIPCHK(sml_launch_fwd(d, f, tiles, st)); ctx->prof.end(st);
         SmlLossArgs L;
         L.out = ctx->out.p; L.xin = ctx->xin.p; L.dout = ctx->dout.p; L.loss_part = ctx->loss_part.p + b * lstride;
         L.B = B; L.kind = loss_kind; L.l2 = l2; L.scale = 1.0f;
-        HIPCHK(sml_launch_pair_loss(d, L, nullptr, st));
+        ctx->prof.begin(PC_PAIR_LOSS, st); HIPCHK(sml_launch_pair_loss(d, L, nullptr, st)); ctx->prof.end(st);
         SmlBwdArgs w;
         memset(&w, 0, sizeof(w));
         for (int s = 0; s < 2; ++s) {
@@ -284,7 +325,7 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
             sg.dx = ctx->dx.p + slot0 * d; sg.dz1 = nullptr; sg.n_rows = s ? 2 * B : B;
         }
         w.tiles0 = f.tiles0; w.l2 = l2; w.convg_part = nullptr;
-        HIPCHK(sml_launch_bwd(d, w, tiles, st));
+        ctx->prof.begin(PC_BWD, st); HIPCHK(sml_launch_bwd(d, w, tiles, st)); ctx->prof.end(st);
         SmlSegUpdArgs u;
         memset(&u, 0, sizeof(u));
         u.key_u = ctx->key_u2.p + b * batch; u.val_u = ctx->val_u2.p + b * batch; u.n_u = B;
@@ -292,9 +333,9 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
         u.dx = ctx->dx.p; u.w_user = t->w_user; u.w_item = t->w_item;
         u.m_user = t->m_user; u.v_user = t->v_user; u.m_item = t->m_item; u.v_item = t->v_item;
         u.last_user = t->step_user; u.last_item = t->step_item; u.sched = ctx->sched.p; u.cur_step = cur; u.lr = lr;
-        HIPCHK(sml_launch_seg_adam(d, u, st));
+        ctx->prof.begin(PC_SEG_ADAM, st); HIPCHK(sml_launch_seg_adam(d, u, st)); ctx->prof.end(st);
     }
-    HIPCHK(sml_launch_loss_finalize(ctx->loss_part.p, (int)nb, lstride, nullptr, batch_loss, st));
+    ctx->prof.begin(PC_MISC, st); HIPCHK(sml_launch_loss_finalize(ctx->loss_part.p, (int)nb, lstride, nullptr, batch_loss, st)); ctx->prof.end(st);
     *step += nb;
     return SML_OK;
 }
@@ -306,8 +347,8 @@ int sml_mf_adam_flush(sml_ctx* ctx, const sml_mf_tables* t, float lr, int64_t st
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if ((rc = ensure_sched(ctx, lr, step + 1))) return rc;
-    HIPCHK(sml_launch_adam_flush(ctx->d, t->w_user, t->m_user, t->v_user, t->step_user, t->n_user, ctx->sched.p, (int)step, st));
-    HIPCHK(sml_launch_adam_flush(ctx->d, t->w_item, t->m_item, t->v_item, t->step_item, t->n_item, ctx->sched.p, (int)step, st));
+    ctx->prof.begin(PC_FLUSH, st); HIPCHK(sml_launch_adam_flush(ctx->d, t->w_user, t->m_user, t->v_user, t->step_user, t->n_user, ctx->sched.p, (int)step, st));
+    HIPCHK(sml_launch_adam_flush(ctx->d, t->w_item, t->m_item, t->v_item, t->step_item, t->n_item, ctx->sched.p, (int)step, st)); ctx->prof.end(st);
     return SML_OK;
 }
 
@@ -329,7 +370,7 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
     float* grad = theta_grad ? theta_grad : ctx->grad.p;
     const int lstride = (batch * (d / 4) + 255) / 256;
     HIPCHK(ctx->loss_part.ensure((size_t)nb * lstride));
-    HIPCHK(sml_launch_theta_pack(d, theta, ctx->pk.p, st));
+    ctx->prof.begin(PC_PACK, st); HIPCHK(sml_launch_theta_pack(d, theta, ctx->pk.p, st)); ctx->prof.end(st);
     HIPCHK(hipMemsetAsync(ctx->loss_part.p, 0, (size_t)nb * lstride * sizeof(float), st));
     HIPCHK(hipMemsetAsync(grad, 0, (size_t)2 * sml_net_size(d) * sizeof(float), st));
     const int64_t ns = sml_net_size(d), ps = sml_pk_size(d);
@@ -350,11 +391,11 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
         }
         f.tiles0 = tiles_of(B); f.cur_step = 0; f.sched = nullptr;
         const int tiles = f.tiles0 + tiles_of(2 * B);
-        HIPCHK(sml_launch_fwd(d, f, tiles, st));
+        ctx->prof.begin(PC_FWD, st); HIPCHK(sml_launch_fwd(d, f, tiles, st)); ctx->prof.end(st);
         SmlLossArgs L;
         L.out = ctx->out.p; L.xin = nullptr; L.dout = ctx->dout.p; L.loss_part = ctx->loss_part.p + b * lstride;
         L.B = B; L.kind = loss_kind; L.l2 = 0.0f; L.scale = loss_scale;
-        HIPCHK(sml_launch_pair_loss(d, L, nullptr, st));
+        ctx->prof.begin(PC_PAIR_LOSS, st); HIPCHK(sml_launch_pair_loss(d, L, nullptr, st)); ctx->prof.end(st);
         SmlBwdArgs w;
         memset(&w, 0, sizeof(w));
         SmlWgArgs wg;
@@ -370,8 +411,8 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
             q.grad = grad + s * ns; q.n_rows = sg.n_rows;
         }
         w.tiles0 = f.tiles0; w.l2 = 0.0f; w.convg_part = ctx->convg.p;
-        HIPCHK(sml_launch_bwd(d, w, tiles, st));
-        HIPCHK(sml_launch_wgrad(d, wg, st));
+        ctx->prof.begin(PC_BWD, st); HIPCHK(sml_launch_bwd(d, w, tiles, st)); ctx->prof.end(st);
+        ctx->prof.begin(PC_WGRAD, st); HIPCHK(sml_launch_wgrad(d, wg, st)); ctx->prof.end(st);
         SmlThetaAdamArgs ad;
         memset(&ad, 0, sizeof(ad));
         const SmlSched sc = sched_entry((double)lr, *step + 1 + b);
@@ -380,17 +421,17 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
         ad.weight_decay = weight_decay; ad.step_size = sc.step_size; ad.bc2_sqrt = sc.bc2_sqrt;
         if (grad_hook) {
             ad.grad_only = 1;
-            HIPCHK(sml_launch_theta_adam(d, ad, st));
+            ctx->prof.begin(PC_THETA_ADAM, st); HIPCHK(sml_launch_theta_adam(d, ad, st)); ctx->prof.end(st);
             const int hr = grad_hook(hook_user, grad, 2 * ns, b);
             if (hr != 0) return fail(SML_ESTATE, "sml_tr_stage_epoch", "grad_hook failed");
             ad.grad_only = 0; ad.convg_part = nullptr;
-            HIPCHK(sml_launch_theta_adam(d, ad, st));
+            ctx->prof.begin(PC_THETA_ADAM, st); HIPCHK(sml_launch_theta_adam(d, ad, st)); ctx->prof.end(st);
         } else {
             ad.grad_only = 0;
-            HIPCHK(sml_launch_theta_adam(d, ad, st));
+            ctx->prof.begin(PC_THETA_ADAM, st); HIPCHK(sml_launch_theta_adam(d, ad, st)); ctx->prof.end(st);
         }
     }
-    HIPCHK(sml_launch_loss_finalize(ctx->loss_part.p, (int)nb, lstride, nullptr, batch_loss, st));
+    ctx->prof.begin(PC_MISC, st); HIPCHK(sml_launch_loss_finalize(ctx->loss_part.p, (int)nb, lstride, nullptr, batch_loss, st)); ctx->prof.end(st);
     *step += nb;
     return SML_OK;
 }
@@ -413,22 +454,22 @@ int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n
     const int lpr = d * dtype_bytes / 16;
     const int lstride = (int)(((int64_t)batch * lpr + 255) / 256);
     HIPCHK(ctx->loss_part.ensure((size_t)nb * lstride));
-    if ((rc = sort_epoch(ctx, triples, n, batch, st))) return rc;
+    ctx->prof.begin(PC_SORT, st); rc = sort_epoch(ctx, triples, n, batch, st); ctx->prof.end(st); if (rc) return rc;
     HIPCHK(hipMemsetAsync(ctx->loss_part.p, 0, (size_t)nb * lstride * sizeof(float), st));
     for (int64_t b = 0; b < nb; ++b) {
         const int B = (int)((n - b * batch) < batch ? (n - b * batch) : batch);
         SmlBareArgs a;
         a.w_user = w_user; a.w_item = w_item; a.tri = triples + b * batch * 3; a.B = B; a.dx = ctx->dx.p;
         a.loss_part = ctx->loss_part.p + b * lstride; a.kind = loss_kind; a.lam_user = lam_user; a.lam_item = lam_item;
-        HIPCHK(sml_launch_bare_grad(d, dtype_bytes, a, nullptr, st));
+        ctx->prof.begin(PC_BARE_GRAD, st); HIPCHK(sml_launch_bare_grad(d, dtype_bytes, a, nullptr, st)); ctx->prof.end(st);
         SmlSegUpdArgs u;
         memset(&u, 0, sizeof(u));
         u.key_u = ctx->key_u2.p + b * batch; u.val_u = ctx->val_u2.p + b * batch; u.n_u = B;
         u.key_i = ctx->key_i2.p + 2 * b * batch; u.val_i = ctx->val_i2.p + 2 * b * batch; u.n_i = 2 * B;
         u.dx = ctx->dx.p; u.w_user = w_user; u.w_item = w_item; u.lr = lr;
-        HIPCHK(sml_launch_seg_sgd(d, dtype_bytes, u, st));
+        ctx->prof.begin(PC_SEG_SGD, st); HIPCHK(sml_launch_seg_sgd(d, dtype_bytes, u, st)); ctx->prof.end(st);
     }
-    HIPCHK(sml_launch_loss_finalize(ctx->loss_part.p, (int)nb, lstride, nullptr, batch_loss, st));
+    ctx->prof.begin(PC_MISC, st); HIPCHK(sml_launch_loss_finalize(ctx->loss_part.p, (int)nb, lstride, nullptr, batch_loss, st)); ctx->prof.end(st);
     return SML_OK;
 }
 
@@ -448,14 +489,41 @@ int sml_eval_ranks(sml_ctx* ctx, const float* w_user, const float* w_item, const
         return fail(SML_EINVAL, "sml_eval_ranks", "bad argument");
     if (n == 0) return SML_OK;
     DevGuard g(ctx->device);
-    HIPCHK(sml_launch_eval_ranks(ctx->d, w_user, w_item, rows, n, n_cols, rank, (hipStream_t)stream));
+    hipStream_t st = (hipStream_t)stream;
+    ctx->prof.begin(PC_EVAL_RANKS, st); HIPCHK(sml_launch_eval_ranks(ctx->d, w_user, w_item, rows, n, n_cols, rank, st)); ctx->prof.end(st);
     return SML_OK;
 }
 
 int sml_eval_metrics(sml_ctx* ctx, const int32_t* rank, int64_t n, int topk, float* out, void* stream) {
     if (!ctx || !rank || !out || n < 0) return fail(SML_EINVAL, "sml_eval_metrics", "bad argument");
     DevGuard g(ctx->device);
-    HIPCHK(sml_launch_eval_metrics(rank, n, topk, out, (hipStream_t)stream));
+    hipStream_t st = (hipStream_t)stream;
+    ctx->prof.begin(PC_MISC, st); HIPCHK(sml_launch_eval_metrics(rank, n, topk, out, st)); ctx->prof.end(st);
+    return SML_OK;
+}
+
+int sml_prof_enable(sml_ctx* ctx, int on) {
+    if (!ctx) return fail(SML_EINVAL, "sml_prof_enable", "null ctx");
+    DevGuard g(ctx->device);
+    if (!on) ctx->prof.drain();
+    ctx->prof.on = on != 0;
+    return SML_OK;
+}
+int sml_prof_reset(sml_ctx* ctx) {
+    if (!ctx) return fail(SML_EINVAL, "sml_prof_reset", "null ctx");
+    DevGuard g(ctx->device);
+    ctx->prof.drain();
+    for (int i = 0; i < PC_COUNT; ++i) { ctx->prof.total_ms[i] = 0; ctx->prof.count[i] = 0; }
+    return SML_OK;
+}
+int sml_prof_classes(void) { return PC_COUNT; }
+const char* sml_prof_name(int cls) { return (cls >= 0 && cls < PC_COUNT) ? kProfNames[cls] : ""; }
+int sml_prof_get(sml_ctx* ctx, int cls, int64_t* count, double* total_ms) {
+    if (!ctx || cls < 0 || cls >= PC_COUNT || !count || !total_ms) return fail(SML_EINVAL, "sml_prof_get", "bad argument");
+    DevGuard g(ctx->device);
+    ctx->prof.drain();
+    *count = ctx->prof.count[cls];
+    *total_ms = ctx->prof.total_ms[cls];
     return SML_OK;
 }
 

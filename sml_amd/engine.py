@@ -249,6 +249,22 @@ class HipEngine(object):
         h = out.cpu()
         return float(h[0]), float(h[1])
 
+    # ------------------------------------------------------------------ measurement
+    def profile(self, on):
+        check(self.lib.sml_prof_enable(self._ctx, int(bool(on))), "sml_prof_enable")
+        if on:
+            check(self.lib.sml_prof_reset(self._ctx), "sml_prof_reset")
+
+    def profile_read(self):
+        """{kernel class: (launches, total ms)} measured with HIP events since profile(True)."""
+        out = {}
+        for c in range(self.lib.sml_prof_classes()):
+            cnt, ms = ctypes.c_int64(0), ctypes.c_double(0.0)
+            check(self.lib.sml_prof_get(self._ctx, c, ctypes.byref(cnt), ctypes.byref(ms)), "sml_prof_get")
+            if cnt.value:
+                out[self.lib.sml_prof_name(c).decode()] = (cnt.value, ms.value)
+        return out
+
     def selftest(self):
         check(self.lib.sml_selftest(self.device.index), "sml_selftest")
 

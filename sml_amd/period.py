@@ -1,0 +1,136 @@
+"""One SML retrain period as a sequence of engine calls on HBM-resident inputs.
+
+This is the compute of meta_train.train_one_stage3 (reference model/transfer.py:753-792,
+the online-training branch with the validation prints the reference always makes)
+with the batch supply hoisted out: every epoch's (user, item, neg) triples and the
+validation rows are device tensors before the period starts.  bench.py times this.
+"""
+import numpy as np
+import torch
+
+from . import synth
+
+
+class Hyper(object):
+    """The reference's hot-path defaults (main_yelp.py:24-73)."""
+
+    def __init__(self, **kw):
+        self.multi_num = 10
+        self.MF_epochs = 1
+        self.TR_epochs = 1
+        self.MF_batch_size = 1024
+        self.TR_batch_size = 256
+        self.MF_lr = 0.01
+        self.l2 = 1e-6
+        self.TR_lr = 0.001
+        self.TR_l2 = 1e-4
+        self.topK = 20
+        self.__dict__.update(kw)
+
+
+class PeriodState(object):
+    """W (inside MFbase), W_{t-1}, W_hat, previous W_hat, theta -- the driver's state
+    (reference model/transfer.py:347-364, 381)."""
+
+    def __init__(self, mfbase, transfer):
+        self.MFbase = mfbase
+        self.transfer = transfer
+        wu, wi = mfbase.user_laten.weight.data, mfbase.item_laten.weight.data
+        self.last_user, self.last_item = torch.zeros_like(wu), torch.zeros_like(wi)
+        self.hat_user, self.hat_item = wu.clone(), wi.clone()
+        self.prev_hat_user, self.prev_hat_item = wu.clone(), wi.clone()
+
+
+class PeriodPlan(object):
+    """HBM-resident inputs of one period."""
+
+    def __init__(self, val_rows, mf_triples, tr_triples):
+        self.val_rows = val_rows          # int64 [n, 2+neg] or None
+        self.mf_triples = mf_triples      # [phase][epoch] -> int64 [n,3]
+        self.tr_triples = tr_triples
+
+    def n_train_triples(self):
+        return sum(t.shape[0] for ph in self.mf_triples for t in ph) + \
+               sum(t.shape[0] for ph in self.tr_triples for t in ph)
+
+
+def synth_plan(seed, n_inter, n_user, n_item, neg, hp, device, user_lo=0, user_hi=None, with_val=True):
+    """Synthetic period in the reference's data semantics: D_t rows carry pre-sampled
+    negatives (MF_sample 'all': one negative column per epoch), D_{t+1} pairs get a uniform
+    negative from the period's items (TR_sample_type 'alone'), validation rows carry `neg`
+    negatives.  Users are drawn from [user_lo, user_hi) (a rank's shard)."""
+    rng = np.random.RandomState(seed)
+    user_hi = n_user if user_hi is None else user_hi
+    span = user_hi - user_lo
+
+    def period(n):
+        train, test = synth.sample_period(rng, n, span, n_item, neg=neg)
+        train[:, 0] += user_lo
+        test[:, 0] += user_lo
+        return train, test
+
+    _, set_t = period(n_inter)
+    set_tt, val = period(n_inter)
+    mf, tr = [], []
+    for ph in range(hp.multi_num):
+        eps = []
+        for ep in range(hp.MF_epochs):
+            order = rng.permutation(n_inter)
+            col = 2 + rng.randint(0, neg)
+            eps.append(torch.from_numpy(np.ascontiguousarray(set_t[order][:, [0, 1, col]])).to(device))
+        mf.append(eps)
+        eps = []
+        items = np.unique(set_tt[:, 1])
+        for ep in range(hp.TR_epochs):
+            order = rng.permutation(n_inter)
+            negs = items[rng.randint(0, items.shape[0], size=n_inter)]
+            tri = np.concatenate([set_tt[order], negs[:, None]], axis=1)
+            eps.append(torch.from_numpy(np.ascontiguousarray(tri)).to(device))
+        tr.append(eps)
+    val_rows = torch.from_numpy(val).to(device) if with_val else None
+    return PeriodPlan(val_rows, mf, tr)
+
+
+def run_period(engine, st, plan, hp, record=None):
+    """Execute one period.  Returns (last MF batch losses, last TR batch losses) device tensors."""
+    mf, net = st.MFbase, st.transfer
+    wu, wi = mf.user_laten.weight.data, mf.item_laten.weight.data
+
+    def evaluate(tag):
+        if plan.val_rows is None:
+            return
+        ranks = engine.eval_ranks(wu, wi, plan.val_rows)
+        hits, ndcg = engine.eval_metrics(ranks, hp.topK)
+        if record is not None:
+            n = plan.val_rows.shape[0]
+            record.append((tag, hits / n, ndcg / n))
+
+    def updata():
+        engine.updata(net, st.last_user, st.hat_user, st.last_item, st.hat_item, wu, wi)
+
+    # save_MF_weight('last')
+    st.last_user.copy_(wu)
+    st.last_item.copy_(wi)
+    mf_loss = tr_loss = None
+    for ph in range(hp.multi_num):
+        evaluate("before MF")
+        for tri in plan.mf_triples[ph]:
+            mf_loss = engine.mf_stage_epoch(mf, net, st.last_user, st.last_item, tri, hp.MF_batch_size,
+                                            hp.MF_lr, hp.l2, norm=False, bce=True)
+            engine.mf_flush(mf)
+            evaluate("MF epoch")
+        # save_MF_weight('hat')
+        st.prev_hat_user.copy_(st.hat_user)
+        st.prev_hat_item.copy_(st.hat_item)
+        st.hat_user.copy_(wu)
+        st.hat_item.copy_(wi)
+        updata()
+        evaluate("before TR")
+        for tri in plan.tr_triples[ph]:
+            tr_loss = engine.tr_stage_epoch(net, st.last_user, st.last_item, st.hat_user, st.hat_item, tri,
+                                            hp.TR_batch_size, hp.TR_lr, hp.TR_l2, bce=True)
+            if plan.val_rows is not None:
+                updata()
+                evaluate("TR epoch")
+    updata()
+    return mf_loss, tr_loss
