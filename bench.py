@@ -97,13 +97,15 @@ def kernel_work(name, a, hp, U_local):
 
 def cpu_baseline(a, hp):
     """The CPU oracle (oracle/sml_oracle.py, kind 'port') on a bounded sample of the same
-    period: full-size tables (dense Adam cost scales with the table), 4 MF batches, 8 TR
-    batches, updata over 1/16 of the rows, evaluation of 1024 rows; scaled to one period."""
+    period: full-size tables (dense Adam cost scales with the table), 8 MF batches, 16 TR
+    batches, updata over 1/16 of the rows, evaluation of 2048 rows; scaled to one period."""
     from oracle import sml_oracle as O
     from sml_amd.conv_transfer import ConvTransfer_com
     from sml_amd.mf import MFbasemode
     import contextlib, io
-    cores = os.cpu_count() or 1
+    # intra-op threading of the oracle's small tensors stops scaling near 16 threads (and with
+    # one thread per core of a 256-core host each op drowns in fork/join cost): use <= 16
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     torch.manual_seed(1)
     U, I, d, n = a.users, a.items, a.d, a.inter
@@ -116,7 +118,7 @@ def cpu_baseline(a, hp):
     eng = O.OracleEngine(d)
     lu, li = mf.user_laten.weight.detach() * 0.9, mf.item_laten.weight.detach() * 0.9
     rng = np.random.RandomState(0)
-    n_mf, n_tr = 4 * hp.MF_batch_size, 8 * hp.TR_batch_size
+    n_mf, n_tr = 8 * hp.MF_batch_size, 16 * hp.TR_batch_size
     tri = lambda k: torch.from_numpy(np.stack([rng.randint(0, U, k), rng.randint(0, I, k), rng.randint(0, I, k)], 1))
     t0 = time.time(); eng.mf_stage_epoch(mf, net, lu, li, tri(n_mf), hp.MF_batch_size, hp.MF_lr, hp.l2); t_mf = time.time() - t0
     hu, hi = mf.user_laten.weight.detach().clone(), mf.item_laten.weight.detach().clone()
@@ -124,14 +126,14 @@ def cpu_baseline(a, hp):
     ru, ri = U // 16, I // 16
     ou, oi = torch.empty(ru, d), torch.empty(ri, d)
     t0 = time.time(); eng.updata(net, lu[:ru], hu[:ru], li[:ri], hi[:ri], ou, oi); t_up = (time.time() - t0) * 16
-    rows = torch.from_numpy(np.concatenate([rng.randint(0, U, (1024, 1)), rng.randint(0, I, (1024, 1 + a.neg))], 1))
-    t0 = time.time(); O.eval_ranks(hu, hi, rows); t_ev = (time.time() - t0) * n / 1024.0
+    rows = torch.from_numpy(np.concatenate([rng.randint(0, U, (2048, 1)), rng.randint(0, I, (2048, 1 + a.neg))], 1))
+    t0 = time.time(); O.eval_ranks(hu, hi, rows); t_ev = (time.time() - t0) * n / 2048.0
     evals = 0 if a.no_val else hp.multi_num * (2 + hp.MF_epochs + hp.TR_epochs)
     n_updata = hp.multi_num * (1 + (hp.TR_epochs if not a.no_val else 0)) + 1
     period_s = hp.multi_num * (hp.MF_epochs * t_mf * n / n_mf + hp.TR_epochs * t_tr * n / n_tr) + n_updata * t_up + evals * t_ev
     triples = hp.multi_num * (hp.MF_epochs + hp.TR_epochs) * n
     return {"value": triples / period_s, "unit": "triples/s", "cores": cores, "kind": "port",
-            "sample": "oracle on full-size tables: %d MF triples, %d TR triples, updata on 1/16 of rows, eval of 1024 rows; "
+            "sample": "oracle on full-size tables: %d MF triples, %d TR triples, updata on 1/16 of rows, eval of 2048 rows; "
                       "scaled to one period (est. %.1f s/period: MF %.1f s, TR %.1f s, updata %.1f s, eval %.1f s)"
                       % (n_mf, n_tr, period_s, hp.multi_num * hp.MF_epochs * t_mf * n / n_mf,
                          hp.multi_num * hp.TR_epochs * t_tr * n / n_tr, n_updata * t_up, evals * t_ev)}
