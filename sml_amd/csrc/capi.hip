@@ -148,8 +148,12 @@ int ensure_sched(sml_ctx* c, float lr, int64_t upto) {
     return SML_OK;
 }
 
+int tiles_of(int rows) { return (rows + SML_R - 1) / SML_R; }
+
+// slot layout of a batch: users at [0, B), items at [ioff, ioff + 2B), ioff = B rounded up to a
+// tile; both runs padded to whole tiles so the kernels store tile rows unconditionally
 int ensure_transfer_ws(sml_ctx* c, int B, bool tr_stage) {
-    const size_t slots = (size_t)3 * B, d = (size_t)c->d;
+    const size_t slots = (size_t)SML_R * (tiles_of(B) + tiles_of(2 * B)), d = (size_t)c->d;
     HIPCHK(c->out.ensure(slots * d));
     HIPCHK(c->dout.ensure(slots * d));
     HIPCHK(c->xin.ensure(slots * 3 * d));
@@ -173,12 +177,12 @@ int ensure_pk(sml_ctx* c) {
 int ceil_log2(int64_t x) { int b = 0; while (((int64_t)1 << b) < x) ++b; return b; }
 
 // sort every batch's occurrences by row (stable): users [n], items [2n]
-int sort_epoch(sml_ctx* c, const int64_t* tri, int64_t n, int batch, hipStream_t st) {
+int sort_epoch(sml_ctx* c, const int64_t* tri, int64_t n, int batch, int pad_tiles, hipStream_t st) {
     HIPCHK(c->key_u.ensure((size_t)n)); HIPCHK(c->key_u2.ensure((size_t)n));
     HIPCHK(c->val_u.ensure((size_t)n)); HIPCHK(c->val_u2.ensure((size_t)n));
     HIPCHK(c->key_i.ensure((size_t)2 * n)); HIPCHK(c->key_i2.ensure((size_t)2 * n));
     HIPCHK(c->val_i.ensure((size_t)2 * n)); HIPCHK(c->val_i2.ensure((size_t)2 * n));
-    HIPCHK(sml_launch_build_keys(tri, n, batch, c->key_u.p, c->val_u.p, c->key_i.p, c->val_i.p, st));
+    HIPCHK(sml_launch_build_keys(tri, n, batch, pad_tiles, c->key_u.p, c->val_u.p, c->key_i.p, c->val_i.p, st));
     const int64_t nb = (n + batch - 1) / batch;
     const int end_bit = 32 + ceil_log2(nb + 1);
     size_t tmp1 = 0, tmp2 = 0;
@@ -194,8 +198,6 @@ int sort_epoch(sml_ctx* c, const int64_t* tri, int64_t n, int batch, hipStream_t
                                               (int)(2 * n), 0, end_bit, st));
     return SML_OK;
 }
-
-int tiles_of(int rows) { return (rows + SML_R - 1) / SML_R; }
 
 }  // namespace
 
@@ -287,7 +289,7 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
     const int lstride = (batch * (d / 4) + 255) / 256;
     HIPCHK(ctx->loss_part.ensure((size_t)nb * lstride));
     ctx->prof.begin(PC_PACK, st); HIPCHK(sml_launch_theta_pack(d, theta, ctx->pk.p, st)); ctx->prof.end(st);
-    ctx->prof.begin(PC_SORT, st); rc = sort_epoch(ctx, triples, n, batch, st); ctx->prof.end(st); if (rc) return rc;
+    ctx->prof.begin(PC_SORT, st); rc = sort_epoch(ctx, triples, n, batch, 1, st); ctx->prof.end(st); if (rc) return rc;
     HIPCHK(hipMemsetAsync(ctx->loss_part.p, 0, (size_t)nb * lstride * sizeof(float), st));
     const int64_t ns = sml_net_size(d), ps = sml_pk_size(d);
     for (int64_t b = 0; b < nb; ++b) {
@@ -304,7 +306,7 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
             sg.m_tab = s ? t->m_item : t->m_user; sg.v_tab = s ? t->v_item : t->v_user;
             sg.last_tab = s ? t->step_item : t->step_user;
             sg.tri = tri; sg.B = B; sg.is_item = s; sg.n_rows = s ? 2 * B : B;
-            const int64_t slot0 = s ? B : 0;
+            const int64_t slot0 = s ? (int64_t)SML_R * tiles_of(B) : 0;
             sg.out = ctx->out.p + slot0 * d; sg.z1 = ctx->z1.p + slot0 * SML_HID; sg.xin = ctx->xin.p + slot0 * 3 * d;
             sg.a1 = nullptr;
         }
@@ -313,13 +315,13 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
         ctx->prof.begin(PC_FWD, st); HIPCHK(sml_launch_fwd(d, f, tiles, st)); ctx->prof.end(st);
         SmlLossArgs L;
         L.out = ctx->out.p; L.xin = ctx->xin.p; L.dout = ctx->dout.p; L.loss_part = ctx->loss_part.p + b * lstride;
-        L.B = B; L.kind = loss_kind; L.l2 = l2; L.scale = 1.0f;
+        L.B = B; L.ioff = SML_R * tiles_of(B); L.kind = loss_kind; L.l2 = l2; L.scale = 1.0f;
         ctx->prof.begin(PC_PAIR_LOSS, st); HIPCHK(sml_launch_pair_loss(d, L, nullptr, st)); ctx->prof.end(st);
         SmlBwdArgs w;
         memset(&w, 0, sizeof(w));
         for (int s = 0; s < 2; ++s) {
             SmlBwdSeg& sg = w.seg[s];
-            const int64_t slot0 = s ? B : 0;
+            const int64_t slot0 = s ? (int64_t)SML_R * tiles_of(B) : 0;
             sg.theta = theta + s * ns; sg.pk = ctx->pk.p + s * ps;
             sg.dout = ctx->dout.p + slot0 * d; sg.z1 = ctx->z1.p + slot0 * SML_HID; sg.xin = ctx->xin.p + slot0 * 3 * d;
             sg.dx = ctx->dx.p + slot0 * d; sg.dz1 = nullptr; sg.n_rows = s ? 2 * B : B;
@@ -385,7 +387,7 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
             sg.xt_tab = s ? t->last_item : t->last_user;
             sg.xh_tab = s ? t->hat_item : t->hat_user;
             sg.tri = tri; sg.B = B; sg.is_item = s; sg.n_rows = s ? 2 * B : B;
-            const int64_t slot0 = s ? B : 0;
+            const int64_t slot0 = s ? (int64_t)SML_R * tiles_of(B) : 0;
             sg.out = ctx->out.p + slot0 * d; sg.z1 = ctx->z1.p + slot0 * SML_HID; sg.xin = ctx->xin.p + slot0 * 3 * d;
             sg.a1 = ctx->a1.p + slot0 * SML_C2 * d;
         }
@@ -394,7 +396,7 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
         ctx->prof.begin(PC_FWD, st); HIPCHK(sml_launch_fwd(d, f, tiles, st)); ctx->prof.end(st);
         SmlLossArgs L;
         L.out = ctx->out.p; L.xin = nullptr; L.dout = ctx->dout.p; L.loss_part = ctx->loss_part.p + b * lstride;
-        L.B = B; L.kind = loss_kind; L.l2 = 0.0f; L.scale = loss_scale;
+        L.B = B; L.ioff = SML_R * tiles_of(B); L.kind = loss_kind; L.l2 = 0.0f; L.scale = loss_scale;
         ctx->prof.begin(PC_PAIR_LOSS, st); HIPCHK(sml_launch_pair_loss(d, L, nullptr, st)); ctx->prof.end(st);
         SmlBwdArgs w;
         memset(&w, 0, sizeof(w));
@@ -402,7 +404,7 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
         memset(&wg, 0, sizeof(wg));
         for (int s = 0; s < 2; ++s) {
             SmlBwdSeg& sg = w.seg[s];
-            const int64_t slot0 = s ? B : 0;
+            const int64_t slot0 = s ? (int64_t)SML_R * tiles_of(B) : 0;
             sg.theta = theta + s * ns; sg.pk = ctx->pk.p + s * ps;
             sg.dout = ctx->dout.p + slot0 * d; sg.z1 = ctx->z1.p + slot0 * SML_HID; sg.xin = ctx->xin.p + slot0 * 3 * d;
             sg.dx = nullptr; sg.dz1 = ctx->dz1.p + slot0 * SML_HID; sg.n_rows = s ? 2 * B : B;
@@ -454,7 +456,7 @@ int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n
     const int lpr = d * dtype_bytes / 16;
     const int lstride = (int)(((int64_t)batch * lpr + 255) / 256);
     HIPCHK(ctx->loss_part.ensure((size_t)nb * lstride));
-    ctx->prof.begin(PC_SORT, st); rc = sort_epoch(ctx, triples, n, batch, st); ctx->prof.end(st); if (rc) return rc;
+    ctx->prof.begin(PC_SORT, st); rc = sort_epoch(ctx, triples, n, batch, 0, st); ctx->prof.end(st); if (rc) return rc;
     HIPCHK(hipMemsetAsync(ctx->loss_part.p, 0, (size_t)nb * lstride * sizeof(float), st));
     for (int64_t b = 0; b < nb; ++b) {
         const int B = (int)((n - b * batch) < batch ? (n - b * batch) : batch);

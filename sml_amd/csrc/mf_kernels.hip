@@ -91,8 +91,8 @@ __global__ __launch_bounds__(256) void k_pair_loss(SmlLossArgs a) {
     if (t < a.B) {
         float u[4], it[4], ng[4];
         RowVec<float>::load(a.out + (int64_t)t * D + sub * 4, u);
-        RowVec<float>::load(a.out + (int64_t)(a.B + t) * D + sub * 4, it);
-        RowVec<float>::load(a.out + (int64_t)(2 * a.B + t) * D + sub * 4, ng);
+        RowVec<float>::load(a.out + (int64_t)(a.ioff + t) * D + sub * 4, it);
+        RowVec<float>::load(a.out + (int64_t)(a.ioff + a.B + t) * D + sub * 4, ng);
         float sp = 0.f, sn = 0.f, uu = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { sp += u[k] * it[k]; sn += u[k] * ng[k]; uu += u[k] * u[k]; }
@@ -118,14 +118,15 @@ __global__ __launch_bounds__(256) void k_pair_loss(SmlLossArgs a) {
             for (int k = 0; k < 4; ++k) { du[k] = dsp * it[k] + dsn * ng[k]; di[k] = dsp * u[k]; dn[k] = dsn * u[k]; }
         }
         RowVec<float>::store(a.dout + (int64_t)t * D + sub * 4, du);
-        RowVec<float>::store(a.dout + (int64_t)(a.B + t) * D + sub * 4, di);
-        RowVec<float>::store(a.dout + (int64_t)(2 * a.B + t) * D + sub * 4, dn);
+        RowVec<float>::store(a.dout + (int64_t)(a.ioff + t) * D + sub * 4, di);
+        RowVec<float>::store(a.dout + (int64_t)(a.ioff + a.B + t) * D + sub * 4, dn);
         if (sub == 0) contrib = lt * a.scale;
         if (a.xin != nullptr) {   // + l2 * 0.5 * sum(u_hat^2 + i_hat^2 + n_hat^2)   (model/transfer.py:486-488)
             float x[4], s = 0.f;
 #pragma unroll
             for (int w = 0; w < 3; ++w) {
-                RowVec<float>::load(a.xin + ((int64_t)(w * a.B + t) * 3 + 1) * D + sub * 4, x);
+                const int slot = (w == 0) ? t : a.ioff + (w - 1) * a.B + t;
+                RowVec<float>::load(a.xin + ((int64_t)slot * 3 + 1) * D + sub * 4, x);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) s += x[k] * x[k];
             }
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(256) void k_bare_grad(SmlBareArgs a) {
 // ------------------------------------------------------------------------------------
 // sort keys: (batch << 32) | row, value = slot of the occurrence inside its batch
 // ------------------------------------------------------------------------------------
-__global__ void k_build_keys(const int64_t* __restrict__ tri, int64_t n, int batch, uint64_t* __restrict__ key_u,
+__global__ void k_build_keys(const int64_t* __restrict__ tri, int64_t n, int batch, int pad_tiles, uint64_t* __restrict__ key_u,
                              uint32_t* __restrict__ val_u, uint64_t* __restrict__ key_i, uint32_t* __restrict__ val_i) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
@@ -206,13 +207,14 @@ __global__ void k_build_keys(const int64_t* __restrict__ tri, int64_t n, int bat
     const int64_t rem = n - b * batch;
     const uint32_t Bb = (uint32_t)(rem < batch ? rem : batch);
     const uint32_t t = (uint32_t)(e - b * batch);
+    const uint32_t ioff = pad_tiles ? ((Bb + SML_R - 1) / SML_R) * SML_R : Bb;   // first item slot of the batch
     const uint64_t hi = (uint64_t)b << 32;
     key_u[e] = hi | (uint32_t)tri[e * 3];
     val_u[e] = t;
     key_i[e] = hi | (uint32_t)tri[e * 3 + 1];
-    val_i[e] = Bb + t;
+    val_i[e] = ioff + t;
     key_i[n + e] = hi | (uint32_t)tri[e * 3 + 2];
-    val_i[n + e] = 2 * Bb + t;
+    val_i[n + e] = ioff + Bb + t;
 }
 
 // ------------------------------------------------------------------------------------
@@ -243,14 +245,32 @@ __global__ __launch_bounds__(256) void k_seg_update(SmlSegUpdArgs a) {
     float g[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) g[k] = 0.0f;
-    for (int q = pos; q < n && keys[q] == key; ++q) {
-        const float* src = a.dx + (int64_t)vals[q] * D + sub * VEC;
+    // run length first, then the rows: 8 independent loads in flight, summed in order (deterministic)
+    int len;
+    {   // upper bound of `key` in the sorted run [pos, n): ~log2(n) dependent loads, not one per duplicate
+        int lo = pos + 1, hi2 = n;
+        while (lo < hi2) {
+            const int mid = (lo + hi2) >> 1;
+            if (keys[mid] == key) lo = mid + 1; else hi2 = mid;
+        }
+        len = lo - pos;
+    }
+    for (int q0 = 0; q0 < len; q0 += 8) {
+        float x[8][VEC];
 #pragma unroll
-        for (int h = 0; h < VEC / 4; ++h) {
-            float x[4];
-            RowVec<float>::load(src + h * 4, x);
+        for (int j = 0; j < 8; ++j) {
+            if (q0 + j < len) {
+                const float* src = a.dx + (int64_t)vals[pos + q0 + j] * D + sub * VEC;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) g[h * 4 + k] += x[k];
+                for (int h = 0; h < VEC / 4; ++h) RowVec<float>::load(src + h * 4, reinterpret_cast<float(&)[4]>(x[j][h * 4]));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (q0 + j < len) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) g[k] += x[j][k];
+            }
         }
     }
     const int64_t row = (uint32_t)key;
@@ -427,9 +447,9 @@ hipError_t sml_launch_bare_grad(int d, int dtype_bytes, const SmlBareArgs& a, in
     } else return hipErrorInvalidValue;
     return hipGetLastError();
 }
-hipError_t sml_launch_build_keys(const int64_t* tri, int64_t n, int batch, uint64_t* key_u, uint32_t* val_u,
-                                 uint64_t* key_i, uint32_t* val_i, hipStream_t st) {
-    k_build_keys<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(tri, n, batch, key_u, val_u, key_i, val_i);
+hipError_t sml_launch_build_keys(const int64_t* tri, int64_t n, int batch, int pad_tiles, uint64_t* key_u,
+                                 uint32_t* val_u, uint64_t* key_i, uint32_t* val_i, hipStream_t st) {
+    k_build_keys<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(tri, n, batch, pad_tiles, key_u, val_u, key_i, val_i);
     return hipGetLastError();
 }
 hipError_t sml_launch_seg_adam(int d, const SmlSegUpdArgs& a, hipStream_t st) {

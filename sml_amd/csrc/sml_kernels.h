@@ -75,6 +75,7 @@ struct SmlLossArgs {
     float* dout;             // [3B, d]
     float* loss_part;        // [gridDim.x] partial sums of this batch
     int B;
+    int ioff;                // first item slot (B rounded up to a whole tile): i' at ioff+t, n' at ioff+B+t
     int kind;                // SML_LOSS_*
     float l2;
     float scale;             // multiplies loss and gradients (multi-GPU: B_local / B_global)
@@ -98,8 +99,8 @@ hipError_t sml_launch_seg_adam(int d, const SmlSegUpdArgs& a, hipStream_t st);
 hipError_t sml_launch_seg_sgd(int d, int dtype_bytes, const SmlSegUpdArgs& a, hipStream_t st);
 hipError_t sml_launch_adam_flush(int d, float* w, float* m, float* v, int32_t* last, int64_t rows,
                                  const SmlSched* sched, int cur_step, hipStream_t st);
-hipError_t sml_launch_build_keys(const int64_t* tri, int64_t n, int batch, uint64_t* key_u, uint32_t* val_u,
-                                 uint64_t* key_i, uint32_t* val_i, hipStream_t st);
+hipError_t sml_launch_build_keys(const int64_t* tri, int64_t n, int batch, int pad_tiles, uint64_t* key_u,
+                                 uint32_t* val_u, uint64_t* key_i, uint32_t* val_i, hipStream_t st);
 
 struct SmlBareArgs {
     const void* w_user; const void* w_item;

@@ -12,9 +12,15 @@
 
 namespace {
 
+__host__ __device__ constexpr bool conv_slot_used_host(int off) {
+    return (off < 30) || (off >= SML_OFF_C1B && off < SML_OFF_C1B + 10) ||
+           (off >= SML_OFF_C2W && off < SML_OFF_C2W + 50) || (off >= SML_OFF_C2B && off < SML_OFF_C2B + 5);
+}
+
 // ------------------------------------------------------------------------------------
 // prologue shared by forward and backward: per-coordinate conv1 -> Gelu -> conv2
-// (model/conv_transfer.py:38-44).  cw points at the net's flat block (uniform -> SGPRs).
+// (model/conv_transfer.py:38-44).  cw = the net's 104 conv floats staged in LDS (every
+// lane reads the same address: a broadcast, no bank conflict).
 // ------------------------------------------------------------------------------------
 struct Pro {
     float h1p[SML_C1];
@@ -22,7 +28,7 @@ struct Pro {
     float h2p[SML_C2];
 };
 
-__device__ __forceinline__ void conv_prologue(const float* __restrict__ cw, float x0, float x1, float x2, Pro& o) {
+__device__ __forceinline__ void conv_prologue(const float* cw, float x0, float x1, float x2, Pro& o) {
 #pragma unroll
     for (int c = 0; c < SML_C1; ++c) {
         float s = cw[SML_OFF_C1B + c];
@@ -47,8 +53,37 @@ __device__ __forceinline__ int64_t seg_row_index(const SmlSeg& s, int r) {
     return r < s.B ? s.tri[(int64_t)r * 3 + 1] : s.tri[(int64_t)(r - s.B) * 3 + 2];
 }
 
+// acc[t] += A(32 x 8*NK, from LDS rows) * B(image tiles), with the B operand images prefetched
+// PFD k-steps ahead in a register ring (fully unrolled, so every ring index is static).
+//   arow : this lane's LDS row pointer (+ 4*hi), advanced 8 floats per k-step
+//   bimg : image base; tile t, k-step ks lives at bimg[(tile_of(t) * ksteps_total + ks0 + ks) * 64 + lane]
+template <int NT, int NK, int PFD, typename TileOf>
+__device__ __forceinline__ void mma_rows(f32x16 (&acc)[NT], const float* arow, const f32x4* __restrict__ bimg,
+                                         int ksteps_total, int ks0, int lane, TileOf tile_of) {
+    f32x4 ring[PFD][NT];
+#pragma unroll
+    for (int i = 0; i < PFD && i < NK; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) ring[i][t] = bimg[(tile_of(t) * ksteps_total + ks0 + i) * 64 + lane];
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(arow + (ks0 + ks) * 8);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t] = mfma32(av[e], ring[ks % PFD][t][e], acc[t]);
+        if (ks + PFD < NK) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                ring[ks % PFD][t] = bimg[(tile_of(t) * ksteps_total + ks0 + ks + PFD) * 64 + lane];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
-// forward: rows -> out, optionally saving z1 / (x_t, x_hat, x_com) / a1 for backward
+// forward: rows -> out, optionally saving z1 / (x_t, x_hat, x_com) / a1 for backward.
+// The z1 / xin / a1 scratch is padded to whole tiles by the caller, so those stores are
+// unconditional; `out` may be a table (updata) and is bounds-checked.
 // ------------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(256) void k_transfer_fwd(SmlFwdArgs a) {
@@ -58,9 +93,10 @@ __global__ __launch_bounds__(256) void k_transfer_fwd(SmlFwdArgs a) {
     constexpr int KS1 = K1 / 8;
     constexpr int EPT = SML_R * D / 256;
     constexpr int JT = D / 32;
-    __shared__ __attribute__((aligned(16))) float smem[SML_R * S1 + SML_R * S2];
+    __shared__ __attribute__((aligned(16))) float smem[SML_R * S1 + SML_R * S2 + 104];
     float* A1s = smem;
     float* a2s = smem + SML_R * S1;
+    float* cws = smem + SML_R * S1 + SML_R * S2;
     float* xts = a2s;                    // [32][D+1], dead before a2s is written
     float* nrm = a2s + SML_R * (D + 1);
     float* part = smem;                  // [4][32][D+1], aliases A1s after fc1
@@ -69,31 +105,50 @@ __global__ __launch_bounds__(256) void k_transfer_fwd(SmlFwdArgs a) {
     const int sidx = (int)blockIdx.x >= a.tiles0;
     const SmlSeg& sg = a.seg[sidx];
     const int row0 = ((int)blockIdx.x - (sidx ? a.tiles0 : 0)) * SML_R;
-    const float* __restrict__ cw = sg.theta;
+    const float* __restrict__ theta = sg.theta;
+    if (tid < 104) cws[tid] = theta[tid];
 
-    // ---- P1: gather x_t and x_hat (with the pending zero-gradient Adam steps replayed)
+    // ---- P1: gather x_t and x_hat; all index loads, then all row loads, are in flight together
     float xt[EPT], xh[EPT];
+    {
+        int64_t idx[EPT];
+        bool ok[EPT];
 #pragma unroll
-    for (int q = 0; q < EPT; ++q) {
-        const int e = q * 256 + tid, r = e / D, w = e % D;
-        const int row = row0 + r;
-        float vt = 1.0f, vh = 0.0f;
-        if (row < sg.n_rows) {
-            const int64_t idx = seg_row_index(sg, row);
-            vt = sg.xt_tab[idx * D + w];
-            vh = sg.xh_tab[idx * D + w];
-            if (sg.last_tab != nullptr) {
-                float m = sg.m_tab[idx * D + w], v = sg.v_tab[idx * D + w];
-                adam_replay(vh, m, v, sg.last_tab[idx], a.cur_step - 1, a.sched);
-            }
+        for (int q = 0; q < EPT; ++q) {
+            const int row = row0 + (q * 256 + tid) / D;
+            ok[q] = row < sg.n_rows;
+            idx[q] = ok[q] ? seg_row_index(sg, row) : 0;
         }
-        xt[q] = vt;
-        xh[q] = vh;
-        xts[r * (D + 1) + w] = vt;
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int w = (q * 256 + tid) % D;
+            xt[q] = sg.xt_tab[idx[q] * D + w];
+            xh[q] = sg.xh_tab[idx[q] * D + w];
+        }
+        if (sg.last_tab != nullptr) {      // replay the row's pending zero-gradient Adam steps
+            float m[EPT], v[EPT];
+            int from[EPT];
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) {
+                const int w = (q * 256 + tid) % D;
+                m[q] = sg.m_tab[idx[q] * D + w];
+                v[q] = sg.v_tab[idx[q] * D + w];
+                from[q] = sg.last_tab[idx[q]];
+            }
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) adam_replay(xh[q], m[q], v[q], from[q], a.cur_step - 1, a.sched);
+        }
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int e = q * 256 + tid;
+            if (!ok[q]) { xt[q] = 1.0f; xh[q] = 0.0f; }
+            xts[(e / D) * (D + 1) + (e % D)] = xt[q];
+        }
     }
     __syncthreads();
     if (tid < SML_R) {
         float s = 0.0f;
+#pragma unroll 8
         for (int w = 0; w < D; ++w) { const float t = xts[tid * (D + 1) + w]; s += t * t; }
         nrm[tid] = sqrtf(s);
     }
@@ -105,14 +160,14 @@ __global__ __launch_bounds__(256) void k_transfer_fwd(SmlFwdArgs a) {
         const int row = row0 + r;
         const float xc = (xt[q] * xh[q]) / nrm[r];     // no epsilon, as model/conv_transfer.py:99
         Pro p;
-        conv_prologue(cw, xt[q], xh[q], xc, p);
+        conv_prologue(cws, xt[q], xh[q], xc, p);
 #pragma unroll
         for (int c = 0; c < SML_C2; ++c) {
             const float v = sml_gelu(p.h2p[c]);
             A1s[r * S1 + c * D + w] = v;
-            if (sg.a1 != nullptr && row < sg.n_rows) sg.a1[(int64_t)row * K1 + c * D + w] = v;
+            if (sg.a1 != nullptr) sg.a1[(int64_t)row * K1 + c * D + w] = v;
         }
-        if (sg.xin != nullptr && row < sg.n_rows) {
+        if (sg.xin != nullptr) {
             float* x = sg.xin + (int64_t)row * 3 * D;
             x[w] = xt[q];
             x[D + w] = xh[q];
@@ -128,29 +183,19 @@ __global__ __launch_bounds__(256) void k_transfer_fwd(SmlFwdArgs a) {
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[t][q] = 0.0f;
-        const f32x4* __restrict__ P1 = reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p1(D));
-        const float* arow = A1s + l31 * S1 + 4 * hi;
-#pragma unroll 2
-        for (int ks = 0; ks < KS1; ++ks) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(arow + ks * 8);
-            f32x4 bv[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) bv[t] = P1[((wv * 4 + t) * KS1 + ks) * 64 + lane];
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[t] = mfma32(av[e], bv[t][e], acc[t]);
-        }
+        mma_rows<4, KS1, 2>(acc, A1s + l31 * S1 + 4 * hi, reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p1(D)),
+                            KS1, 0, lane, [wv](int t) { return wv * 4 + t; });
         // + bias, save z1, Gelu -> a2 tile.  (xts/nrm are dead: every wave passed the barrier above)
+        float* z1 = sg.z1;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int n = (wv * 4 + t) * 32 + l31;
-            const float bias = cw[sml_off_f1b(D) + n];
+            const float bias = theta[sml_off_f1b(D) + n];
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int r = mfma32_row(q, lane);
                 const float z = acc[t][q] + bias;
-                if (sg.z1 != nullptr && row0 + r < sg.n_rows) sg.z1[(int64_t)(row0 + r) * SML_HID + n] = z;
+                if (z1 != nullptr) z1[(int64_t)(row0 + r) * SML_HID + n] = z;
                 a2s[r * S2 + n] = sml_gelu(z);
             }
         }
@@ -164,20 +209,9 @@ __global__ __launch_bounds__(256) void k_transfer_fwd(SmlFwdArgs a) {
         for (int t = 0; t < JT; ++t)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[t][q] = 0.0f;
-        const f32x4* __restrict__ P2 = reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p2(D));
-        const float* arow = a2s + l31 * S2 + 4 * hi;
-#pragma unroll 2
-        for (int kk = 0; kk < 16; ++kk) {
-            const int ks = wv * 16 + kk;
-            const f32x4 av = *reinterpret_cast<const f32x4*>(arow + ks * 8);
-            f32x4 bv[JT];
-#pragma unroll
-            for (int t = 0; t < JT; ++t) bv[t] = P2[(t * 64 + ks) * 64 + lane];
-#pragma unroll
-            for (int t = 0; t < JT; ++t)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[t] = mfma32(av[e], bv[t][e], acc[t]);
-        }
+        mma_rows<JT, 16, (JT == 1 ? 8 : 4)>(acc, a2s + l31 * S2 + 4 * hi,
+                                            reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p2(D)), 64, wv * 16, lane,
+                                            [](int t) { return t; });
 #pragma unroll
         for (int t = 0; t < JT; ++t)
 #pragma unroll
@@ -188,7 +222,7 @@ __global__ __launch_bounds__(256) void k_transfer_fwd(SmlFwdArgs a) {
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
         const int e = q * 256 + tid, r = e / D, j = e % D;
-        float s = cw[sml_off_f2b(D) + j];
+        float s = theta[sml_off_f2b(D) + j];
 #pragma unroll
         for (int w4 = 0; w4 < 4; ++w4) s += part[(w4 * SML_R + r) * (D + 1) + j];
         if (row0 + r < sg.n_rows) sg.out[(int64_t)(row0 + r) * D + j] = s;
@@ -196,7 +230,8 @@ __global__ __launch_bounds__(256) void k_transfer_fwd(SmlFwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
-// backward: dOut -> (MF stage) dx_hat + l2*x_hat, or (TR stage) dZ1 rows + conv-grad partials
+// backward: dOut -> (MF stage) dx_hat + l2*x_hat, or (TR stage) dZ1 rows + conv-grad partials.
+// dx / dz1 scratch is padded to whole tiles (unconditional stores).
 // ------------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(256) void k_transfer_bwd(SmlBwdArgs a) {
@@ -206,26 +241,35 @@ __global__ __launch_bounds__(256) void k_transfer_bwd(SmlBwdArgs a) {
     constexpr int KSD = D / 8;
     constexpr int EPT = SML_R * D / 256;
     constexpr int KSPLIT = (D == 32) ? 4 : (D == 64 ? 2 : 1);   // waves along the n reduction
-    constexpr int TSPLIT = 4 / KSPLIT;                           // waves along the 5D outputs
     constexpr int PSTR = K1 + 1;
     constexpr int SZ_A = SML_R * S2 + SML_R * SD;
     constexpr int SZ_B = KSPLIT * SML_R * PSTR;
-    __shared__ __attribute__((aligned(16))) float smem[SZ_A > SZ_B ? SZ_A : SZ_B];
+    constexpr int SZ = SZ_A > SZ_B ? SZ_A : SZ_B;
+    __shared__ __attribute__((aligned(16))) float smem[SZ + 104];
     __shared__ float red[4][104];
     float* dZs = smem;                    // [32][516]
     float* dOs = smem + SML_R * S2;       // [32][D+4]
     float* part = smem;                   // [KSPLIT][32][5D+1], aliases dZs after the second GEMM
+    float* cws = smem + SZ;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int sidx = (int)blockIdx.x >= a.tiles0;
     const SmlBwdSeg& sg = a.seg[sidx];
     const int row0 = ((int)blockIdx.x - (sidx ? a.tiles0 : 0)) * SML_R;
-    const float* __restrict__ cw = sg.theta;
+    if (tid < 104) cws[tid] = sg.theta[tid];
 
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
         const int e = q * 256 + tid, r = e / D, j = e % D;
         dOs[r * SD + j] = (row0 + r < sg.n_rows) ? sg.dout[(int64_t)(row0 + r) * D + j] : 0.0f;
+    }
+    // the (x_t, x_hat, x_com) rows of the tail: issue the loads now, use them after both GEMMs
+    float x0[EPT], x1[EPT], x2[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int e = q * 256 + tid, r = e / D, w = e % D;
+        const float* x = sg.xin + (int64_t)(row0 + r) * 3 * D;
+        x0[q] = x[w]; x1[q] = x[D + w]; x2[q] = x[2 * D + w];
     }
     __syncthreads();
     // ---- dA2[32 x 512] = dOut[32 x D] * W2 ; dZ1 = dA2 * Gelu'(z1)
@@ -235,30 +279,23 @@ __global__ __launch_bounds__(256) void k_transfer_bwd(SmlBwdArgs a) {
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[t][q] = 0.0f;
-        const f32x4* __restrict__ P2B = reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p2b(D));
-        const float* arow = dOs + l31 * SD + 4 * hi;
-#pragma unroll
-        for (int ks = 0; ks < KSD; ++ks) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(arow + ks * 8);
-            f32x4 bv[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) bv[t] = P2B[((wv * 4 + t) * KSD + ks) * 64 + lane];
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[t] = mfma32(av[e], bv[t][e], acc[t]);
-        }
+        // z1 of this wave's 4 column tiles: issue with the GEMM, consume in its epilogue
+        mma_rows<4, KSD, (KSD < 4 ? KSD : 4)>(acc, dOs + l31 * SD + 4 * hi,
+                                              reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p2b(D)), KSD, 0, lane,
+                                              [wv](int t) { return wv * 4 + t; });
+        float* dz1 = sg.dz1;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int n = (wv * 4 + t) * 32 + l31;
+            float z[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) z[q] = sg.z1[(int64_t)(row0 + mfma32_row(q, lane)) * SML_HID + n];
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int r = mfma32_row(q, lane);
-                const bool ok = row0 + r < sg.n_rows;
-                const float z = ok ? sg.z1[(int64_t)(row0 + r) * SML_HID + n] : 0.0f;
-                const float dz = acc[t][q] * sml_gelu_grad(z);
+                const float dz = acc[t][q] * sml_gelu_grad(z[q]);
                 dZs[r * S2 + n] = dz;
-                if (sg.dz1 != nullptr && ok) sg.dz1[(int64_t)(row0 + r) * SML_HID + n] = dz;
+                if (dz1 != nullptr) dz1[(int64_t)(row0 + r) * SML_HID + n] = dz;
             }
         }
     }
@@ -272,20 +309,8 @@ __global__ __launch_bounds__(256) void k_transfer_bwd(SmlBwdArgs a) {
         for (int t = 0; t < 5; ++t)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[t][q] = 0.0f;
-        const f32x4* __restrict__ P1B = reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p1b(D));
-        const float* arow = dZs + l31 * S2 + 4 * hi;
-#pragma unroll 2
-        for (int kk = 0; kk < KPER; ++kk) {
-            const int ks = kq * KPER + kk;
-            const f32x4 av = *reinterpret_cast<const f32x4*>(arow + ks * 8);
-            f32x4 bv[5];
-#pragma unroll
-            for (int t = 0; t < 5; ++t) bv[t] = P1B[((tq * 5 + t) * 64 + ks) * 64 + lane];
-#pragma unroll
-            for (int t = 0; t < 5; ++t)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[t] = mfma32(av[e], bv[t][e], acc[t]);
-        }
+        mma_rows<5, KPER, 2>(acc, dZs + l31 * S2 + 4 * hi, reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p1b(D)), 64,
+                             kq * KPER, lane, [tq](int t) { return tq * 5 + t; });
         __syncthreads();                        // every wave is done reading dZs
 #pragma unroll
         for (int t = 0; t < 5; ++t)
@@ -306,13 +331,8 @@ __global__ __launch_bounds__(256) void k_transfer_bwd(SmlBwdArgs a) {
         const int e = q * 256 + tid, r = e / D, w = e % D;
         const int row = row0 + r;
         const bool ok = row < sg.n_rows;
-        float x0 = 1.0f, x1 = 0.0f, x2 = 0.0f;
-        if (ok) {
-            const float* x = sg.xin + (int64_t)row * 3 * D;
-            x0 = x[w]; x1 = x[D + w]; x2 = x[2 * D + w];
-        }
         Pro p;
-        conv_prologue(cw, x0, x1, x2, p);
+        conv_prologue(cws, x0[q], x1[q], x2[q], p);
         float dh2p[SML_C2];
 #pragma unroll
         for (int c = 0; c < SML_C2; ++c) {
@@ -327,17 +347,17 @@ __global__ __launch_bounds__(256) void k_transfer_bwd(SmlBwdArgs a) {
         for (int c = 0; c < SML_C1; ++c) {
             float s = 0.0f;
 #pragma unroll
-            for (int o = 0; o < SML_C2; ++o) s += dh2p[o] * cw[SML_OFF_C2W + o * SML_C1 + c];
+            for (int o = 0; o < SML_C2; ++o) s += dh2p[o] * cws[SML_OFF_C2W + o * SML_C1 + c];
             dh1p[c] = s * sml_gelu_grad(p.h1p[c]);
-            dxh += dh1p[c] * cw[SML_OFF_C1W + c * 3 + 1];
+            dxh += dh1p[c] * cws[SML_OFF_C1W + c * 3 + 1];
         }
-        if (sg.dx != nullptr && ok) sg.dx[(int64_t)row * D + w] = dxh + a.l2 * x1;
+        if (sg.dx != nullptr) sg.dx[(int64_t)row * D + w] = dxh + a.l2 * x1[q];
         if (want_cg && ok) {
 #pragma unroll
             for (int c = 0; c < SML_C1; ++c) {
-                cg[SML_OFF_C1W + c * 3 + 0] += dh1p[c] * x0;
-                cg[SML_OFF_C1W + c * 3 + 1] += dh1p[c] * x1;
-                cg[SML_OFF_C1W + c * 3 + 2] += dh1p[c] * x2;
+                cg[SML_OFF_C1W + c * 3 + 0] += dh1p[c] * x0[q];
+                cg[SML_OFF_C1W + c * 3 + 1] += dh1p[c] * x1[q];
+                cg[SML_OFF_C1W + c * 3 + 2] += dh1p[c] * x2[q];
                 cg[SML_OFF_C1B + c] += dh1p[c];
             }
 #pragma unroll
@@ -352,6 +372,7 @@ __global__ __launch_bounds__(256) void k_transfer_bwd(SmlBwdArgs a) {
         // deterministic tree: lanes (xor shuffles), then waves in index order
 #pragma unroll
         for (int i = 0; i < 104; ++i) {
+            if (!conv_slot_used_host(i)) continue;
             float v = cg[i];
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -390,21 +411,32 @@ __global__ __launch_bounds__(256) void k_transfer_wgrad(SmlWgArgs a) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
     float colsum = 0.0f;
-    const int nsteps = (sg.n_rows + 7) / 8;
-    for (int st = wv; st < nsteps; st += 4) {
-        float av[4], bv[4];
+    // each wave takes a contiguous quarter of the batch rows, 32 rows (4 k-steps) per trip with all
+    // 32 operand loads of the trip in flight before its 16 MFMAs
+    const int rows_per_wave = ((sg.n_rows + 127) / 128) * 32;
+    const int r_begin = wv * rows_per_wave;
+    const int r_end = min(sg.n_rows, r_begin + rows_per_wave);
+    for (int rb = r_begin; rb < r_end; rb += 32) {
+        float av[4][4], bv[4][4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int r = st * 8 + 4 * hi + e;
-            const bool ok = r < sg.n_rows;
-            av[e] = ok ? Asrc[(int64_t)r * lda + ti * 32 + l31] : 0.0f;
-            float b = ok ? Bsrc[(int64_t)r * ldb + tj * 32 + l31] : 0.0f;
-            if (!is_w1) b = ok ? sml_gelu(b) : 0.0f;
-            bv[e] = b;
-            colsum += av[e];
-        }
+        for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = mfma32(av[e], bv[e], acc);
+            for (int e = 0; e < 4; ++e) {
+                const int r = rb + s4 * 8 + 4 * hi + e;
+                const bool ok = r < r_end;
+                av[s4][e] = ok ? Asrc[(int64_t)r * lda + ti * 32 + l31] : 0.0f;
+                bv[s4][e] = ok ? Bsrc[(int64_t)r * ldb + tj * 32 + l31] : 0.0f;
+            }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = rb + s4 * 8 + 4 * hi + e;
+                float b = bv[s4][e];
+                if (!is_w1) b = (r < r_end) ? sml_gelu(b) : 0.0f;
+                colsum += av[s4][e];
+                acc = mfma32(av[s4][e], b, acc);
+            }
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) part[wv][mfma32_row(q, lane)][l31] = acc[q];
@@ -453,10 +485,7 @@ __global__ __launch_bounds__(256) void k_theta_pack(const float* __restrict__ th
     pack_store<D>(pk + (int64_t)net * sml_pk_size(D), off, theta[i]);
 }
 
-__device__ __forceinline__ bool conv_slot_used(int off) {
-    return (off < 30) || (off >= SML_OFF_C1B && off < SML_OFF_C1B + 10) ||
-           (off >= SML_OFF_C2W && off < SML_OFF_C2W + 50) || (off >= SML_OFF_C2B && off < SML_OFF_C2B + 5);
-}
+__device__ __forceinline__ bool conv_slot_used(int off) { return conv_slot_used_host(off); }
 
 template <int D>
 __global__ __launch_bounds__(256) void k_theta_adam(SmlThetaAdamArgs a) {
