@@ -85,6 +85,26 @@ typedef struct {
     int64_t n_user, n_item;
 } sml_mf_tables;
 
+/* Multi-GPU exchange of the MF stage (NULL on one GPU).  Users are row-sharded: a rank only
+ * sees triples of users it owns, so user rows never leave the rank.  Item tables are
+ * replicated; every batch, after the backward pass has been queued on `stream`, `hook` is
+ * called on the host to all-gather each rank's per-occurrence item-gradient rows
+ * (dx_local[item_off .. item_off + 2*batch) -> dx_items_all[world][2*batch][d]); the item
+ * update then runs over the GLOBAL occurrence list (key_items/val_items: every batch's
+ * world*2*B_b occurrences sorted by (batch << 32 | item row), value = slot in dx_items_all),
+ * so all replicas apply the identical summed update.  loss_scale = B_local / B_global. */
+typedef int (*sml_mf_hook)(void* user, int64_t batch_index);
+typedef struct {
+    int world;
+    const uint64_t* key_items;
+    const uint32_t* val_items;
+    float* dx_local;        /* caller-owned scratch, >= (3*batch + 64) * d floats */
+    float* dx_items_all;    /* caller-owned, world * 2*batch * d floats */
+    sml_mf_hook hook;
+    void* hook_user;
+    float loss_scale;
+} sml_mf_exchange;
+
 /* One epoch over n pre-drawn triples (u,i,j) int64 [n,3], in batches of `batch`:
  * 6 gathers -> run_MF -> + l2*0.5*sum(x_hat^2) -> backward to the W_hat rows ->
  * Adam(lr, betas 0.9/0.999, eps 1e-8, wd 0) with the DENSE semantics of
@@ -95,7 +115,8 @@ typedef struct {
  * loss_batch (model/transfer.py:488).  Asynchronous. */
 int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
                        const int64_t* triples, int64_t n, int batch, float lr, float l2,
-                       int loss_kind, int64_t* step, float* batch_loss, void* stream);
+                       int loss_kind, int64_t* step, float* batch_loss, const sml_mf_exchange* xchg,
+                       void* stream);
 /* Replay every pending zero-gradient Adam step so the tables can be read out
  * (before save_MF_weight / updata / evaluation; model/transfer.py:518, 777, 832). */
 int sml_mf_adam_flush(sml_ctx* ctx, const sml_mf_tables* t, float lr, int64_t step, void* stream);

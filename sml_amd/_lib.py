@@ -18,6 +18,7 @@ c_i32p = ctypes.POINTER(ctypes.c_int32)
 c_void = ctypes.c_void_p
 
 GRAD_HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64)
+MF_HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64)
 
 LOSS_BCE, LOSS_BPR, LOSS_BPR_NORM = 0, 1, 2
 
@@ -26,6 +27,11 @@ class MFTables(ctypes.Structure):
     _fields_ = [("w_user", c_void), ("w_item", c_void), ("last_user", c_void), ("last_item", c_void),
                 ("m_user", c_void), ("v_user", c_void), ("m_item", c_void), ("v_item", c_void),
                 ("step_user", c_void), ("step_item", c_void), ("n_user", ctypes.c_int64), ("n_item", ctypes.c_int64)]
+
+
+class MFExchange(ctypes.Structure):
+    _fields_ = [("world", ctypes.c_int), ("key_items", c_void), ("val_items", c_void), ("dx_local", c_void),
+                ("dx_items_all", c_void), ("hook", MF_HOOK), ("hook_user", c_void), ("loss_scale", ctypes.c_float)]
 
 
 class TRTables(ctypes.Structure):
@@ -45,7 +51,7 @@ SIGNATURES = {
     "sml_transfer_forward": (ctypes.c_int, [c_void, c_void, ctypes.c_int, c_void, c_void, c_void, ctypes.c_int64, c_void]),
     "sml_mf_stage_epoch": (ctypes.c_int, [c_void, c_void, ctypes.POINTER(MFTables), c_void, ctypes.c_int64, ctypes.c_int,
                                           ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.POINTER(ctypes.c_int64),
-                                          c_void, c_void]),
+                                          c_void, ctypes.POINTER(MFExchange), c_void]),
     "sml_mf_adam_flush": (ctypes.c_int, [c_void, ctypes.POINTER(MFTables), ctypes.c_float, ctypes.c_int64, c_void]),
     "sml_tr_stage_epoch": (ctypes.c_int, [c_void, c_void, c_void, c_void, c_void, ctypes.POINTER(TRTables), c_void,
                                           ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int,

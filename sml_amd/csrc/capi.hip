@@ -272,12 +272,15 @@ int sml_transfer_forward(sml_ctx* ctx, const float* theta, int net, const float*
 }
 
 int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t, const int64_t* triples, int64_t n,
-                       int batch, float lr, float l2, int loss_kind, int64_t* step, float* batch_loss, void* stream) {
+                       int batch, float lr, float l2, int loss_kind, int64_t* step, float* batch_loss,
+                       const sml_mf_exchange* xchg, void* stream) {
     if (!ctx || !theta || !t || !triples || !step || !batch_loss || n <= 0 || batch <= 0)
         return fail(SML_EINVAL, "sml_mf_stage_epoch", "bad argument");
     if (batch > ctx->max_batch) return fail(SML_EINVAL, "sml_mf_stage_epoch", "batch exceeds ctx max_batch");
     if (n > 0x3fffffff) return fail(SML_EINVAL, "sml_mf_stage_epoch", "epoch too long");
     if (loss_kind < 0 || loss_kind > 2) return fail(SML_EINVAL, "sml_mf_stage_epoch", "loss_kind");
+    if (xchg && (xchg->world < 1 || !xchg->key_items || !xchg->val_items || !xchg->dx_local || !xchg->dx_items_all || !xchg->hook))
+        return fail(SML_EINVAL, "sml_mf_stage_epoch", "incomplete exchange descriptor");
     DevGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     const int d = ctx->d;
@@ -292,6 +295,7 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
     ctx->prof.begin(PC_SORT, st); rc = sort_epoch(ctx, triples, n, batch, 1, st); ctx->prof.end(st); if (rc) return rc;
     HIPCHK(hipMemsetAsync(ctx->loss_part.p, 0, (size_t)nb * lstride * sizeof(float), st));
     const int64_t ns = sml_net_size(d), ps = sml_pk_size(d);
+    float* dx_buf = xchg ? xchg->dx_local : ctx->dx.p;
     for (int64_t b = 0; b < nb; ++b) {
         const int B = (int)((n - b * batch) < batch ? (n - b * batch) : batch);
         const int64_t* tri = triples + b * batch * 3;
@@ -315,7 +319,7 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
         ctx->prof.begin(PC_FWD, st); HIPCHK(sml_launch_fwd(d, f, tiles, st)); ctx->prof.end(st);
         SmlLossArgs L;
         L.out = ctx->out.p; L.xin = ctx->xin.p; L.dout = ctx->dout.p; L.loss_part = ctx->loss_part.p + b * lstride;
-        L.B = B; L.ioff = SML_R * tiles_of(B); L.kind = loss_kind; L.l2 = l2; L.scale = 1.0f;
+        L.B = B; L.ioff = SML_R * tiles_of(B); L.kind = loss_kind; L.l2 = l2; L.scale = xchg ? xchg->loss_scale : 1.0f;
         ctx->prof.begin(PC_PAIR_LOSS, st); HIPCHK(sml_launch_pair_loss(d, L, nullptr, st)); ctx->prof.end(st);
         SmlBwdArgs w;
         memset(&w, 0, sizeof(w));
@@ -324,7 +328,7 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
             const int64_t slot0 = s ? (int64_t)SML_R * tiles_of(B) : 0;
             sg.theta = theta + s * ns; sg.pk = ctx->pk.p + s * ps;
             sg.dout = ctx->dout.p + slot0 * d; sg.z1 = ctx->z1.p + slot0 * SML_HID; sg.xin = ctx->xin.p + slot0 * 3 * d;
-            sg.dx = ctx->dx.p + slot0 * d; sg.dz1 = nullptr; sg.n_rows = s ? 2 * B : B;
+            sg.dx = dx_buf + slot0 * d; sg.dz1 = nullptr; sg.n_rows = s ? 2 * B : B;
         }
         w.tiles0 = f.tiles0; w.l2 = l2; w.convg_part = nullptr;
         ctx->prof.begin(PC_BWD, st); HIPCHK(sml_launch_bwd(d, w, tiles, st)); ctx->prof.end(st);
@@ -332,7 +336,15 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
         memset(&u, 0, sizeof(u));
         u.key_u = ctx->key_u2.p + b * batch; u.val_u = ctx->val_u2.p + b * batch; u.n_u = B;
         u.key_i = ctx->key_i2.p + 2 * b * batch; u.val_i = ctx->val_i2.p + 2 * b * batch; u.n_i = 2 * B;
-        u.dx = ctx->dx.p; u.w_user = t->w_user; u.w_item = t->w_item;
+        u.dx = dx_buf; u.dx_i = dx_buf; u.w_user = t->w_user; u.w_item = t->w_item;
+        if (xchg) {
+            // every rank contributes 2*B item occurrences of this batch (equal B on all ranks)
+            if (xchg->hook(xchg->hook_user, b) != 0) return fail(SML_ESTATE, "sml_mf_stage_epoch", "exchange hook failed");
+            u.key_i = xchg->key_items + (int64_t)xchg->world * 2 * b * batch;
+            u.val_i = xchg->val_items + (int64_t)xchg->world * 2 * b * batch;
+            u.n_i = xchg->world * 2 * B;
+            u.dx_i = xchg->dx_items_all;
+        }
         u.m_user = t->m_user; u.v_user = t->v_user; u.m_item = t->m_item; u.v_item = t->v_item;
         u.last_user = t->step_user; u.last_item = t->step_item; u.sched = ctx->sched.p; u.cur_step = cur; u.lr = lr;
         ctx->prof.begin(PC_SEG_ADAM, st); HIPCHK(sml_launch_seg_adam(d, u, st)); ctx->prof.end(st);
@@ -468,7 +480,7 @@ int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n
         memset(&u, 0, sizeof(u));
         u.key_u = ctx->key_u2.p + b * batch; u.val_u = ctx->val_u2.p + b * batch; u.n_u = B;
         u.key_i = ctx->key_i2.p + 2 * b * batch; u.val_i = ctx->val_i2.p + 2 * b * batch; u.n_i = 2 * B;
-        u.dx = ctx->dx.p; u.w_user = w_user; u.w_item = w_item; u.lr = lr;
+        u.dx = ctx->dx.p; u.dx_i = ctx->dx.p; u.w_user = w_user; u.w_item = w_item; u.lr = lr;
         ctx->prof.begin(PC_SEG_SGD, st); HIPCHK(sml_launch_seg_sgd(d, dtype_bytes, u, st)); ctx->prof.end(st);
     }
     ctx->prof.begin(PC_MISC, st); HIPCHK(sml_launch_loss_finalize(ctx->loss_part.p, (int)nb, lstride, nullptr, batch_loss, st)); ctx->prof.end(st);

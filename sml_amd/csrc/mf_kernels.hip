@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_pair_loss(SmlLossArgs a) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) s += x[k] * x[k];
             }
-            contrib += 0.5f * a.l2 * s * a.scale;
+            contrib += 0.5f * a.l2 * s;   // a sum over rows, not a batch mean: never rescaled
         }
     }
     const float tot = block_sum256(contrib, sh4);
@@ -230,6 +230,7 @@ __global__ __launch_bounds__(256) void k_seg_update(SmlSegUpdArgs a) {
     int pos = gid / LPR;
     const int sub = gid % LPR;
     const uint64_t* keys; const uint32_t* vals; int n;
+    const float* dx = a.dx;
     T* w; float* mt; float* vt; int32_t* last;
     if (pos < a.n_u) {
         keys = a.key_u; vals = a.val_u; n = a.n_u;
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(256) void k_seg_update(SmlSegUpdArgs a) {
     } else {
         pos -= a.n_u;
         if (pos >= a.n_i) return;
-        keys = a.key_i; vals = a.val_i; n = a.n_i;
+        keys = a.key_i; vals = a.val_i; n = a.n_i; dx = a.dx_i;
         w = reinterpret_cast<T*>(a.w_item); mt = a.m_item; vt = a.v_item; last = a.last_item;
     }
     const uint64_t key = keys[pos];
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256) void k_seg_update(SmlSegUpdArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             if (q0 + j < len) {
-                const float* src = a.dx + (int64_t)vals[pos + q0 + j] * D + sub * VEC;
+                const float* src = dx + (int64_t)vals[pos + q0 + j] * D + sub * VEC;
 #pragma unroll
                 for (int h = 0; h < VEC / 4; ++h) RowVec<float>::load(src + h * 4, reinterpret_cast<float(&)[4]>(x[j][h * 4]));
             }

@@ -88,7 +88,8 @@ struct SmlSegUpdArgs {
     // sorted occurrences of this batch: key = (batch << 32) | row, val = slot in [0, 3B)
     const uint64_t* key_u; const uint32_t* val_u; int n_u;     // user occurrences (B)
     const uint64_t* key_i; const uint32_t* val_i; int n_i;     // item occurrences (2B)
-    const float* dx;         // [3B, d] per-occurrence gradients
+    const float* dx;         // per-occurrence gradient rows the user values index
+    const float* dx_i;       // ... and the item values index (the all-gathered buffer on several GPUs)
     void* w_user; void* w_item;
     float* m_user; float* v_user; float* m_item; float* v_item;   // Adam only
     int32_t* last_user; int32_t* last_item;                       // Adam only

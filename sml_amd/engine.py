@@ -44,6 +44,7 @@ class HipEngine(object):
         self.tr_state = None  # (m, v) flat, theta layout
         self.tr_step = 0
         self.grad_hook = None  # set by sml_amd.dist for the multi-GPU TR stage
+        self.dist = None       # sml_amd.dist.DistContext when the job spans several GPUs
 
     def close(self):
         if getattr(self, "_ctx", None):
@@ -151,9 +152,30 @@ class HipEngine(object):
         self._mf_lr = float(lr)
         losses = torch.empty(nb, device=self.device, dtype=torch.float32)
         step = ctypes.c_int64(self.mf_step)
+        xp = None
+        if self.dist is not None:
+            ex = self.dist.mf_exchange(tri, int(batch_size), self.d)
+            hook_fn = ex["hook"]
+
+            def _cb(_user, b):
+                try:
+                    hook_fn(int(b))
+                    return 0
+                except Exception:
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            x = _lib.MFExchange()
+            x.world = ex["world"]
+            x.key_items, x.val_items = ex["keys"].data_ptr(), ex["vals"].data_ptr()
+            x.dx_local, x.dx_items_all = ex["dx_local"].data_ptr(), ex["dx_all"].data_ptr()
+            x.hook = _lib.MF_HOOK(_cb)
+            x.hook_user = None
+            x.loss_scale = ex["loss_scale"]
+            xp = ctypes.byref(x)
         check(self.lib.sml_mf_stage_epoch(self._ctx, _ptr(theta), ctypes.byref(t), _ptr(tri), n, int(batch_size),
                                           float(lr), float(l2), self._loss_kind(bce, norm), ctypes.byref(step),
-                                          _ptr(losses), self._stream()), "sml_mf_stage_epoch")
+                                          _ptr(losses), xp, self._stream()), "sml_mf_stage_epoch")
         self.mf_step = step.value
         return losses
 
@@ -167,8 +189,10 @@ class HipEngine(object):
 
     # ------------------------------------------------------------------ a9
     def tr_stage_epoch(self, transfer, last_user, last_item, hat_user, hat_item, triples, batch_size, lr,
-                       weight_decay, bce=True, loss_scale=1.0):
+                       weight_decay, bce=True, loss_scale=None):
         theta = self.adopt(transfer)
+        if loss_scale is None:
+            loss_scale = self.dist.tr_loss_scale() if self.dist is not None else 1.0
         if self.tr_state is None or self.tr_state[0].shape != theta.shape:
             self.tr_state = (torch.zeros_like(theta), torch.zeros_like(theta), torch.zeros_like(theta))
         m, v, grad = self.tr_state

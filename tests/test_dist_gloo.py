@@ -1,0 +1,136 @@
+"""N > 1 path on CPU: two gloo ranks run the product's distributed logic (sml_amd.dist:
+user sharding, global item-occurrence lists, item-gradient all-gather, theta-gradient
+all-reduce, loss scaling) against a one-process run of the same global batches."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from conftest import make_mf, make_transfer, quiet  # noqa: E402
+from _cpu_engine import CpuDistEngine, CpuEngine    # noqa: E402
+
+U, I, D, B = 40, 30, 32, 16
+LR, L2, TR_LR, TR_WD = 0.01, 1e-6, 1e-3, 1e-4
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _data(n, seed=0):
+    """Per-rank triples (users inside the rank's shard) and shared initial state."""
+    from sml_amd import dist as SD
+    g = torch.Generator().manual_seed(seed)
+    tri = []
+    for r in range(2):
+        lo, hi = SD.user_range(U, 2, r)
+        u = torch.randint(lo, hi, (n,), generator=g)
+        u[:5] = lo                                   # duplicates inside a batch
+        i = torch.randint(0, I, (n,), generator=g)
+        j = torch.randint(0, I, (n,), generator=g)
+        j[3] = i[3]
+        tri.append(torch.stack([u, i, j], 1))
+    wu = torch.randn(U, D, generator=g) * 0.3
+    wi = torch.randn(I, D, generator=g) * 0.3
+    torch.manual_seed(seed + 1)
+    with quiet():
+        net = make_transfer(D)
+    return tri, wu, wi, {k: v.clone() for k, v in net.state_dict().items()}
+
+
+def _run_rank(rank, port, n, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    try:
+        from sml_amd import dist as SD
+        from sml_amd.period import PeriodState
+        tri, wu, wi, sd = _data(n)
+        mf = make_mf(U, I, D, wu.numpy(), wi.numpy())
+        with quiet():
+            net = make_transfer(D)
+        if rank == 0:
+            net.load_state_dict(sd)                   # rank 1 starts from different values: attach must sync
+        else:
+            with torch.no_grad():
+                mf.item_laten.weight.add_(1.0)
+        st = PeriodState(mf, net)
+        eng = CpuDistEngine(d=D)
+        SD.attach(eng, st, dist)
+        lu, li = wu * 0.9, wi * 0.9
+        l_mf = eng.mf_stage_epoch(mf, net, lu, li, tri[rank], B, LR, L2)
+        hu, hi = mf.user_laten.weight.detach().clone(), mf.item_laten.weight.detach().clone()
+        l_tr = eng.tr_stage_epoch(net, lu, li, hu, hi, tri[rank], B, TR_LR, TR_WD)
+        torch.save(dict(wu=mf.user_laten.weight.detach(), wi=mf.item_laten.weight.detach(),
+                        theta={k: v.clone() for k, v in net.state_dict().items()}, l_mf=l_mf, l_tr=l_tr),
+                   os.path.join(out, "rank%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [64, 60])        # 60: ragged last batch (12 per rank)
+def test_two_ranks_equal_one_rank_global_batches(tmp_path, n):
+    mp.spawn(_run_rank, args=(_free_port(), n, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(str(tmp_path), "rank0.pt"), weights_only=False)
+    r1 = torch.load(os.path.join(str(tmp_path), "rank1.pt"), weights_only=False)
+    # replicas: item table and theta identical on both ranks
+    assert torch.equal(r0["wi"], r1["wi"])
+    for k in r0["theta"]:
+        assert torch.equal(r0["theta"][k], r1["theta"][k]), k
+    # one process, global batches = [rank0 batch b ; rank1 batch b], batch size 2B
+    from sml_amd import dist as SD
+    tri, wu, wi, sd = _data(n)
+    glob = torch.cat([torch.cat([tri[0][b:b + B], tri[1][b:b + B]]) for b in range(0, n, B)])
+    mf = make_mf(U, I, D, wu.numpy(), wi.numpy())
+    with quiet():
+        net = make_transfer(D)
+    net.load_state_dict(sd)
+    eng = CpuEngine(d=D)
+    lu, li = wu * 0.9, wi * 0.9
+    l_mf = eng.mf_stage_epoch(mf, net, lu, li, glob, 2 * B, LR, L2)
+    hu, hi = mf.user_laten.weight.detach().clone(), mf.item_laten.weight.detach().clone()
+    # the TR stage of each rank saw ITS user rows updated and the shared item table
+    lo1, hi1 = SD.user_range(U, 2, 1)
+    wu_dist = r0["wu"].clone()
+    wu_dist[lo1:hi1] = r1["wu"][lo1:hi1]
+    np.testing.assert_allclose(wu_dist.numpy(), hu.numpy(), rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(r0["wi"].numpy(), hi.numpy(), rtol=2e-4, atol=2e-6)
+    l_tr = eng.tr_stage_epoch(net, lu, li, hu, hi, glob, 2 * B, TR_LR, TR_WD)
+    for k, v in net.state_dict().items():
+        np.testing.assert_allclose(r0["theta"][k].numpy(), v.numpy(), rtol=5e-4, atol=5e-6)
+    # losses: the global batch loss is the sum of the ranks' scaled parts
+    np.testing.assert_allclose(r0["l_mf"] + r1["l_mf"], l_mf, rtol=1e-5)
+    np.testing.assert_allclose(r0["l_tr"] + r1["l_tr"], l_tr, rtol=1e-5)
+
+
+def test_user_range_and_item_lists():
+    from sml_amd import dist as SD
+    assert [SD.user_range(10, 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert SD.owner_of(torch.tensor([0, 2, 3, 9]), 10, 4).tolist() == [0, 0, 1, 3]
+    tri = torch.tensor([[[0, 5, 7], [1, 5, 2], [2, 9, 5]], [[3, 7, 5], [4, 1, 1], [5, 5, 0]]])   # world 2, n 3
+    keys, vals = SD.global_item_lists(tri, batch=2)
+    rows, bat = (keys & 0xffffffff).tolist(), (keys >> 32).tolist()
+    assert bat == sorted(bat) and bat.count(0) == 8 and bat.count(1) == 4
+    for b in (0, 1):
+        seg = [r for r, bb in zip(rows, bat) if bb == b]
+        assert seg == sorted(seg)
+    # value = slot in [world][2*batch]: rank q positives q*4 + t, negatives q*4 + B_b + t
+    lookup = {}
+    for q in range(2):
+        for e in range(3):
+            b, t = divmod(e, 2)
+            Bb = min(2, 3 - 2 * b)
+            lookup[(b, q * 4 + t)] = int(tri[q, e, 1])
+            lookup[(b, q * 4 + Bb + t)] = int(tri[q, e, 2])
+    for k, v, b in zip(rows, vals.tolist(), bat):
+        assert lookup[(b, v)] == k

@@ -355,3 +355,39 @@ def test_g7_end_to_end_on_gpu(tmp_path, monkeypatch):
     monkeypatch.setenv("LOCAL_RANK", "0")          # keep main from rewriting CUDA_VISIBLE_DEVICES
     got, want = run_g7(tmp_path, monkeypatch)
     check_g7(got, want, exact_lines=40)
+
+
+# ----------------------------------------------------------------------------- multi-GPU plumbing on one GPU
+def test_exchange_path_on_one_rank_rccl_group_equals_plain_path():
+    """A 1-rank RCCL group drives the real exchange code (global item lists, all-gather of
+    item-gradient rows into the gathered buffer, theta-gradient all-reduce hook): results
+    must equal the plain single-GPU path bit for bit."""
+    import socket
+    import torch.distributed as dist
+    from sml_amd import dist as SD
+    from sml_amd.period import PeriodState
+    z = golden("g3_mf_stage.npz")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device(DEV))
+    try:
+        outs = []
+        for use_dist in (False, True):
+            eng = engine(32)
+            lr, l2, B, _ = z["hp_mf"]
+            U, d = z["W_user0"].shape
+            mf = make_mf(U, z["W_item0"].shape[0], d, z["W_user0"], z["W_item0"], device=DEV)
+            net = make_transfer(d, z, prefix="theta0.", device=DEV)
+            if use_dist:
+                SD.attach(eng, PeriodState(mf, net), dist)
+            tri = torch.from_numpy(z["mf_triples"][:200])
+            lu, li = T(z["Wlast_user"], DEV), T(z["Wlast_item"], DEV)
+            l1 = eng.mf_stage_epoch(mf, net, lu, li, tri, int(B), lr, l2)
+            eng.mf_flush(mf)
+            hu, hi = mf.user_laten.weight.detach().clone(), mf.item_laten.weight.detach().clone()
+            l2_ = eng.tr_stage_epoch(net, lu, li, hu, hi, tri[:, [0, 1, 2]], 16, 1e-3, 1e-4)
+            outs.append((l1.cpu(), l2_.cpu(), hu.cpu(), hi.cpu(), eng.adopt(net).cpu().clone()))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+    finally:
+        dist.destroy_process_group()
