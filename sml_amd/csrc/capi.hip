@@ -148,7 +148,8 @@ int ensure_sched(sml_ctx* c, float lr, int64_t upto) {
     return SML_OK;
 }
 
-int tiles_of(int rows) { return (rows + SML_R - 1) / SML_R; }
+int tiles_of(int rows) { return (rows + SML_R - 1) / SML_R; }          // 32-row padding units
+int wg_tiles(int rows, int mt) { const int r = SML_TM * mt; return (rows + r - 1) / r; }   // workgroups
 
 // slot layout of a batch: users at [0, B), items at [ioff, ioff + 2B), ioff = B rounded up to a
 // tile; both runs padded to whole tiles so the kernels store tile rows unconditionally
@@ -161,7 +162,7 @@ int ensure_transfer_ws(sml_ctx* c, int B, bool tr_stage) {
     if (tr_stage) {
         HIPCHK(c->a1.ensure(slots * SML_C2 * d));
         HIPCHK(c->dz1.ensure(slots * SML_HID));
-        HIPCHK(c->convg.ensure((slots / SML_R + 4) * 104));
+        HIPCHK(c->convg.ensure((slots / SML_TM + 4) * SML_CG));
         HIPCHK(c->grad.ensure((size_t)2 * sml_net_size(c->d)));
     } else {
         HIPCHK(c->dx.ensure(slots * d));
@@ -265,9 +266,10 @@ int sml_transfer_forward(sml_ctx* ctx, const float* theta, int net, const float*
     s.theta = theta + (int64_t)net * sml_net_size(ctx->d);
     s.pk = ctx->pk.p + (int64_t)net * sml_pk_size(ctx->d);
     s.xt_tab = x_t; s.xh_tab = x_hat; s.n_rows = (int)n_rows; s.out = out;
-    a.tiles0 = tiles_of((int)n_rows);
+    const int mt = n_rows > 8192 ? 2 : 1;     // table-sized calls: 32 rows per workgroup halve the weight traffic
+    a.tiles0 = wg_tiles((int)n_rows, mt);
     a.seg[1] = s; a.seg[1].n_rows = 0;
-    ctx->prof.begin(PC_FWD, st); HIPCHK(sml_launch_fwd(ctx->d, a, a.tiles0, st)); ctx->prof.end(st);
+    ctx->prof.begin(PC_FWD, st); HIPCHK(sml_launch_fwd(ctx->d, mt, a, a.tiles0, st)); ctx->prof.end(st);
     return SML_OK;
 }
 
@@ -314,9 +316,9 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
             sg.out = ctx->out.p + slot0 * d; sg.z1 = ctx->z1.p + slot0 * SML_HID; sg.xin = ctx->xin.p + slot0 * 3 * d;
             sg.a1 = nullptr;
         }
-        f.tiles0 = tiles_of(B); f.cur_step = cur; f.sched = ctx->sched.p;
-        const int tiles = f.tiles0 + tiles_of(2 * B);
-        ctx->prof.begin(PC_FWD, st); HIPCHK(sml_launch_fwd(d, f, tiles, st)); ctx->prof.end(st);
+        f.tiles0 = wg_tiles(B, 1); f.cur_step = cur; f.sched = ctx->sched.p;
+        const int tiles = f.tiles0 + wg_tiles(2 * B, 1);
+        ctx->prof.begin(PC_FWD, st); HIPCHK(sml_launch_fwd(d, 1, f, tiles, st)); ctx->prof.end(st);
         SmlLossArgs L;
         L.out = ctx->out.p; L.xin = ctx->xin.p; L.dout = ctx->dout.p; L.loss_part = ctx->loss_part.p + b * lstride;
         L.B = B; L.ioff = SML_R * tiles_of(B); L.kind = loss_kind; L.l2 = l2; L.scale = xchg ? xchg->loss_scale : 1.0f;
@@ -331,7 +333,7 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
             sg.dx = dx_buf + slot0 * d; sg.dz1 = nullptr; sg.n_rows = s ? 2 * B : B;
         }
         w.tiles0 = f.tiles0; w.l2 = l2; w.convg_part = nullptr;
-        ctx->prof.begin(PC_BWD, st); HIPCHK(sml_launch_bwd(d, w, tiles, st)); ctx->prof.end(st);
+        ctx->prof.begin(PC_BWD, st); HIPCHK(sml_launch_bwd(d, 1, w, tiles, st)); ctx->prof.end(st);
         SmlSegUpdArgs u;
         memset(&u, 0, sizeof(u));
         u.key_u = ctx->key_u2.p + b * batch; u.val_u = ctx->val_u2.p + b * batch; u.n_u = B;
@@ -403,9 +405,9 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
             sg.out = ctx->out.p + slot0 * d; sg.z1 = ctx->z1.p + slot0 * SML_HID; sg.xin = ctx->xin.p + slot0 * 3 * d;
             sg.a1 = ctx->a1.p + slot0 * SML_C2 * d;
         }
-        f.tiles0 = tiles_of(B); f.cur_step = 0; f.sched = nullptr;
-        const int tiles = f.tiles0 + tiles_of(2 * B);
-        ctx->prof.begin(PC_FWD, st); HIPCHK(sml_launch_fwd(d, f, tiles, st)); ctx->prof.end(st);
+        f.tiles0 = wg_tiles(B, 1); f.cur_step = 0; f.sched = nullptr;
+        const int tiles = f.tiles0 + wg_tiles(2 * B, 1);
+        ctx->prof.begin(PC_FWD, st); HIPCHK(sml_launch_fwd(d, 1, f, tiles, st)); ctx->prof.end(st);
         SmlLossArgs L;
         L.out = ctx->out.p; L.xin = nullptr; L.dout = ctx->dout.p; L.loss_part = ctx->loss_part.p + b * lstride;
         L.B = B; L.ioff = SML_R * tiles_of(B); L.kind = loss_kind; L.l2 = 0.0f; L.scale = loss_scale;
@@ -425,7 +427,7 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
             q.grad = grad + s * ns; q.n_rows = sg.n_rows;
         }
         w.tiles0 = f.tiles0; w.l2 = 0.0f; w.convg_part = ctx->convg.p;
-        ctx->prof.begin(PC_BWD, st); HIPCHK(sml_launch_bwd(d, w, tiles, st)); ctx->prof.end(st);
+        ctx->prof.begin(PC_BWD, st); HIPCHK(sml_launch_bwd(d, 1, w, tiles, st)); ctx->prof.end(st);
         ctx->prof.begin(PC_WGRAD, st); HIPCHK(sml_launch_wgrad(d, wg, st)); ctx->prof.end(st);
         SmlThetaAdamArgs ad;
         memset(&ad, 0, sizeof(ad));
@@ -543,7 +545,7 @@ int sml_prof_get(sml_ctx* ctx, int cls, int64_t* count, double* total_ms) {
 
 int sml_selftest(int device) {
     DevGuard g(device);
-    const int M = 32, K = 16;
+    const int M = 16, K = 32;
     std::vector<float> A(M * K), W(M * K), ref(M * M, 0.f), got(M * M, 0.f);
     for (int i = 0; i < M * K; ++i) {
         A[i] = (float)((i * 37 + 11) % 23) - 11.0f;          // asymmetric integer data: exact in fp32

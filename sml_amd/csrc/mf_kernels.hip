@@ -226,6 +226,11 @@ template <int D, typename T, int OPT>
 __global__ __launch_bounds__(256) void k_seg_update(SmlSegUpdArgs a) {
     constexpr int VEC = RowVec<T>::VEC;
     constexpr int LPR = D / VEC;
+    __shared__ SmlSched swin[OPT == 1 ? SML_SW : 1];
+    if (OPT == 1) {                       // the Adam schedule of the last SML_SW steps, staged once per block
+        sched_window_load(swin, a.sched, a.cur_step, threadIdx.x);
+        __syncthreads();
+    }
     const int gid = blockIdx.x * 256 + threadIdx.x;
     int pos = gid / LPR;
     const int sub = gid % LPR;
@@ -286,10 +291,10 @@ __global__ __launch_bounds__(256) void k_seg_update(SmlSegUpdArgs a) {
         RowVec<float>::load(mt + row * D + sub * 4, m);
         RowVec<float>::load(vt + row * D + sub * 4, v);
         const int from = last[row];
-        const SmlSched sc = a.sched[a.cur_step];
+        const SmlSched sc = swin[SML_SW - 1];      // = sched[cur_step]
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            adam_replay(p[k], m[k], v[k], from, a.cur_step - 1, a.sched);
+            adam_replay_w(p[k], m[k], v[k], from, a.cur_step - 1, a.sched, swin, a.cur_step);
             adam_apply(p[k], m[k], v[k], g[k], sc);
         }
         RowVec<T>::store(w + row * D + sub * VEC, p);
@@ -305,6 +310,9 @@ __global__ __launch_bounds__(256) void k_adam_flush(float* __restrict__ w, float
                                                     int32_t* __restrict__ last, int64_t rows,
                                                     const SmlSched* __restrict__ sched, int cur_step) {
     constexpr int LPR = D / 4;
+    __shared__ SmlSched swin[SML_SW];
+    sched_window_load(swin, sched, cur_step, threadIdx.x);
+    __syncthreads();
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t row = gid / LPR;
     const int sub = (int)(gid % LPR);
@@ -316,7 +324,7 @@ __global__ __launch_bounds__(256) void k_adam_flush(float* __restrict__ w, float
     RowVec<float>::load(mt + row * D + sub * 4, m);
     RowVec<float>::load(vt + row * D + sub * 4, v);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) adam_replay(p[k], m[k], v[k], from, cur_step, sched);
+    for (int k = 0; k < 4; ++k) adam_replay_w(p[k], m[k], v[k], from, cur_step, sched, swin, cur_step);
     RowVec<float>::store(w + row * D + sub * 4, p);
     RowVec<float>::store(mt + row * D + sub * 4, m);
     RowVec<float>::store(vt + row * D + sub * 4, v);

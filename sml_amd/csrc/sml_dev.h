@@ -9,7 +9,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define SML_HID 512   // fc1 width                    (reference model/conv_transfer.py:33)
 #define SML_C1 10     // conv1 output channels        (model/conv_transfer.py:26-27)
 #define SML_C2 5      // conv2 output channels        (model/conv_transfer.py:29-30)
-#define SML_R 32      // rows per workgroup tile = M of v_mfma_f32_32x32x2_f32
+#define SML_R 32      // padding unit of the per-batch scratch runs (covers 16- and 32-row workgroup tiles)
+#define SML_TM 16     // rows of one MFMA row-tile = M of v_mfma_f32_16x16x4_f32
 
 // ---- flat layout of one net inside theta (floats; every tensor 16-byte aligned) ----
 #define SML_OFF_C1W 0      // [10][3]
@@ -23,9 +24,10 @@ __host__ __device__ constexpr int sml_off_f2b(int d) { return sml_off_f2w(d) + S
 __host__ __device__ constexpr int sml_net_size(int d) { return sml_off_f2b(d) + d; }
 
 // ---- MFMA operand images ("packed" weights), per net --------------------------------
-// Each image stores, for output tile T (32 columns) and k-step S (8 reduction indices),
-// 64 lanes x 4 floats: lane l, element e = W[col = T*32 + (l&31)][red = S*8 + 4*(l>>5) + e]
-// so one wave-wide 16-byte load feeds four v_mfma_f32_32x32x2_f32 (k pairs {e, 4+e}).
+// Each image stores, for output tile T (16 columns) and k-step S (16 reduction indices),
+// 64 lanes x 4 floats: lane l, element e = W[col = T*16 + (l&15)][red = S*16 + 4*(l>>4) + e]
+// so one wave-wide 16-byte load feeds four v_mfma_f32_16x16x4_f32 (MFMA e covers the four
+// reduction indices {S*16 + 4g + e, g = 0..3}; the A operand uses the same split).
 //   P1  : fc1 forward    Z1 = A1 * W1^T   cols n (512), red k (5d)      W = fc1.weight[n][k]
 //   P1B : fc1 backward   dA1 = dZ1 * W1   cols k (5d),  red n (512)     W = fc1.weight[n][k]
 //   P2  : fc2 forward    Out = a2 * W2^T  cols j (d),   red n (512)     W = fc2.weight[j][n]
@@ -36,13 +38,20 @@ __host__ __device__ constexpr int sml_pk_p2(int d) { return 2 * SML_HID * SML_C2
 __host__ __device__ constexpr int sml_pk_p2b(int d) { return 2 * SML_HID * SML_C2 * d + SML_HID * d; }
 __host__ __device__ constexpr int sml_pk_size(int d) { return 2 * SML_HID * SML_C2 * d + 2 * SML_HID * d; }
 
-__device__ __forceinline__ int pk_index(int ksteps, int tile, int kstep, int lane, int e) {
-    return ((tile * ksteps + kstep) * 64 + lane) * 4 + e;
+// element (col, red) -> position in an image with `ksteps` k-steps (of 16) per tile
+__host__ __device__ constexpr int pk_pos(int ksteps, int col, int red) {
+    return ((((col >> 4) * ksteps + (red >> 4)) * 64) + ((col & 15) + 16 * ((red >> 2) & 3))) * 4 + (red & 3);
 }
-// element (col, red) -> position in an image with `ksteps` k-steps per tile
-__device__ __forceinline__ int pk_pos(int ksteps, int col, int red) {
-    return pk_index(ksteps, col >> 5, red >> 3, (col & 31) + 32 * ((red >> 2) & 1), red & 3);
+
+// conv1/conv2 parameters (95 floats of the 104-float head of a net) <-> compact index 0..94
+__host__ __device__ constexpr bool conv_slot_used_host(int off) {
+    return (off < 30) || (off >= SML_OFF_C1B && off < SML_OFF_C1B + 10) ||
+           (off >= SML_OFF_C2W && off < SML_OFF_C2W + 50) || (off >= SML_OFF_C2B && off < SML_OFF_C2B + 5);
 }
+__host__ __device__ constexpr int conv_compact(int off) {
+    return off < 30 ? off : off < SML_OFF_C2W ? off - 2 : off < SML_OFF_C2B ? off - 4 : off - 6;
+}
+#define SML_CG 96     // compact conv-gradient vector (95 used)
 
 // sigmoid on the transcendental unit: v_exp_f32 (2^x) and v_rcp_f32, each ~1 ulp -- the result is
 // within ~3e-7 relative of the correctly rounded value, far inside the 1e-4 parity budget, at
@@ -62,6 +71,11 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 // accumulator register q of lane l holds D[row][col = l&31]:
 __device__ __forceinline__ int mfma32_row(int q, int lane) { return (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5); }
+// v_mfma_f32_16x16x4_f32: lane l supplies A[i = l&15][k = l>>4], B[k = l>>4][j = l&15];
+// accumulator register q of lane l holds D[row = 4*(l>>4) + q][col = l&15]
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
 
 // ---- Adam (torch.optim.Adam single-tensor path; reference model/transfer.py:392-393) ----
 #define SML_BETA1 0.9f
@@ -81,4 +95,17 @@ __device__ __forceinline__ void adam_apply(float& p, float& m, float& v, float g
 __device__ __forceinline__ void adam_replay(float& p, float& m, float& v, int from, int to,
                                             const SmlSched* __restrict__ sched) {
     for (int k = from + 1; k <= to; ++k) adam_apply(p, m, v, 0.0f, sched[k]);
+}
+// the same with the most recent SML_SW schedule entries staged in LDS (win[i] = sched[wbase + i]):
+// a dependent global load per replayed step would dominate the loop otherwise
+#define SML_SW 256
+__device__ __forceinline__ void sched_window_load(SmlSched* win, const SmlSched* __restrict__ sched, int upto,
+                                                  int tid) {
+    const int wbase = upto - SML_SW + 1;
+    if (tid < SML_SW) { const int k = wbase + tid; if (k >= 0) win[tid] = sched[k]; }
+}
+__device__ __forceinline__ void adam_replay_w(float& p, float& m, float& v, int from, int to,
+                                              const SmlSched* __restrict__ sched, const SmlSched* win, int upto) {
+    const int wbase = upto - SML_SW + 1;
+    for (int k = from + 1; k <= to; ++k) adam_apply(p, m, v, 0.0f, k >= wbase ? win[k - wbase] : sched[k]);
 }

@@ -43,7 +43,7 @@ struct SmlBwdArgs {
     SmlBwdSeg seg[2];
     int tiles0;
     float l2;
-    float* convg_part;       // TR stage: [tiles, 104] per-tile conv1/conv2 gradient partials; else null
+    float* convg_part;       // TR stage: [tiles, SML_CG] per-tile compact conv1/conv2 gradient partials; else null
 };
 
 struct SmlWgSeg {
@@ -61,8 +61,8 @@ struct SmlThetaAdamArgs {
     float weight_decay, step_size, bc2_sqrt;
 };
 
-hipError_t sml_launch_fwd(int d, const SmlFwdArgs& a, int tiles_total, hipStream_t st);
-hipError_t sml_launch_bwd(int d, const SmlBwdArgs& a, int tiles_total, hipStream_t st);
+hipError_t sml_launch_fwd(int d, int mt, const SmlFwdArgs& a, int tiles_total, hipStream_t st);   // mt row-tiles of 16 per workgroup
+hipError_t sml_launch_bwd(int d, int mt, const SmlBwdArgs& a, int tiles_total, hipStream_t st);
 hipError_t sml_launch_wgrad(int d, const SmlWgArgs& a, hipStream_t st);
 hipError_t sml_launch_theta_adam(int d, const SmlThetaAdamArgs& a, hipStream_t st);
 hipError_t sml_launch_theta_pack(int d, const float* theta, float* pk, hipStream_t st);

@@ -1,33 +1,28 @@
 // Transfer-net kernels for gfx950: ConvTransfer_com / one_transfer of the reference
 // (model/conv_transfer.py:18-50, 87-135) forward, backward-to-input, backward-to-theta
-// and the theta Adam step, with fc1/fc2 on v_mfma_f32_32x32x2_f32 (exact fp32).
+// and the theta Adam step, with fc1/fc2 on v_mfma_f32_16x16x4_f32 (exact fp32).
 //
-// Tiling: one 256-thread workgroup (4 waves, one per SIMD) carries a tile of SML_R = 32
-// rows through the WHOLE net, so the per-coordinate 3->10->5 prologue, both GEMMs and
-// the Gelu epilogues never leave the CU: activations live in LDS, weights stream from
-// L2 as pre-arranged MFMA operand images (sml_dev.h), one 16-byte load per lane per
-// four MFMAs.
+// Tiling: one 512-thread workgroup (8 waves, two per SIMD so one wave's operand loads and
+// VALU epilogues overlap the other's MFMAs) carries MT row-tiles of 16 rows through the
+// WHOLE net, so the per-coordinate 3->10->5 prologue, both GEMMs and the Gelu epilogues
+// never leave the CU: activations live in LDS, weights stream from L2 as pre-arranged MFMA
+// operand images (sml_dev.h), one 16-byte load per lane per four MFMAs, prefetched through
+// a small register ring.  MT = 1 for a training batch (a TR batch is only 768 rows: more,
+// shorter tiles keep more CUs busy and halve the serial chain); MT = 2 for table-sized calls
+// (updata), where reusing each weight fragment for 32 rows halves the L2 traffic.
 #include "sml_dev.h"
 #include "sml_kernels.h"
 
 namespace {
 
-__host__ __device__ constexpr bool conv_slot_used_host(int off) {
-    return (off < 30) || (off >= SML_OFF_C1B && off < SML_OFF_C1B + 10) ||
-           (off >= SML_OFF_C2W && off < SML_OFF_C2W + 50) || (off >= SML_OFF_C2B && off < SML_OFF_C2B + 5);
-}
-
-// ------------------------------------------------------------------------------------
-// prologue shared by forward and backward: per-coordinate conv1 -> Gelu -> conv2
-// (model/conv_transfer.py:38-44).  cw = the net's 104 conv floats staged in LDS (every
-// lane reads the same address: a broadcast, no bank conflict).
-// ------------------------------------------------------------------------------------
 struct Pro {
     float h1p[SML_C1];
     float h1[SML_C1];
     float h2p[SML_C2];
 };
 
+// per-coordinate conv1 -> Gelu -> conv2 (model/conv_transfer.py:38-44).  cw = the net's 104
+// conv floats staged in LDS (all lanes read one address: a broadcast).
 __device__ __forceinline__ void conv_prologue(const float* cw, float x0, float x1, float x2, Pro& o) {
 #pragma unroll
     for (int c = 0; c < SML_C1; ++c) {
@@ -53,13 +48,14 @@ __device__ __forceinline__ int64_t seg_row_index(const SmlSeg& s, int r) {
     return r < s.B ? s.tri[(int64_t)r * 3 + 1] : s.tri[(int64_t)(r - s.B) * 3 + 2];
 }
 
-// acc[t] += A(32 x 8*NK, from LDS rows) * B(image tiles), with the B operand images prefetched
-// PFD k-steps ahead in a register ring (fully unrolled, so every ring index is static).
-//   arow : this lane's LDS row pointer (+ 4*hi), advanced 8 floats per k-step
-//   bimg : image base; tile t, k-step ks lives at bimg[(tile_of(t) * ksteps_total + ks0 + ks) * 64 + lane]
-template <int NT, int NK, int PFD, typename TileOf>
-__device__ __forceinline__ void mma_rows(f32x16 (&acc)[NT], const float* arow, const f32x4* __restrict__ bimg,
-                                         int ksteps_total, int ks0, int lane, TileOf tile_of) {
+// acc[mt][t] += A(MT x 16 rows x 16*NK, LDS) * B(image tiles).  B operand images are prefetched
+// PFD k-steps ahead in a register ring; the loop is fully unrolled so ring indices are static.
+//   arow : this lane's LDS pointer (row l&15, column 4*(l>>4)); M-tile mt is a_mt floats further
+//   bimg : tile t, k-step ks at bimg[(tile_of(t) * ksteps_total + ks0 + ks) * 64 + lane]
+template <int MT, int NT, int NK, int PFD, typename TileOf>
+__device__ __forceinline__ void mma16_rows(f32x4 (&acc)[MT][NT], const float* arow, int a_mt,
+                                           const f32x4* __restrict__ bimg, int ksteps_total, int ks0, int lane,
+                                           TileOf tile_of) {
     f32x4 ring[PFD][NT];
 #pragma unroll
     for (int i = 0; i < PFD && i < NK; ++i)
@@ -67,11 +63,15 @@ __device__ __forceinline__ void mma_rows(f32x16 (&acc)[NT], const float* arow, c
         for (int t = 0; t < NT; ++t) ring[i][t] = bimg[(tile_of(t) * ksteps_total + ks0 + i) * 64 + lane];
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(arow + (ks0 + ks) * 8);
+        f32x4 av[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(arow + mt * a_mt + (ks0 + ks) * 16);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[t] = mfma32(av[e], ring[ks % PFD][t][e], acc[t]);
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[mt][t] = mfma16(av[mt][e], ring[ks % PFD][t][e], acc[mt][t]);
         if (ks + PFD < NK) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -80,33 +80,54 @@ __device__ __forceinline__ void mma_rows(f32x16 (&acc)[NT], const float* arow, c
     }
 }
 
+template <int MT, int NT>
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[MT][NT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[mt][t][q] = 0.0f;
+}
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
 // ------------------------------------------------------------------------------------
 // forward: rows -> out, optionally saving z1 / (x_t, x_hat, x_com) / a1 for backward.
 // The z1 / xin / a1 scratch is padded to whole tiles by the caller, so those stores are
 // unconditional; `out` may be a table (updata) and is bounds-checked.
 // ------------------------------------------------------------------------------------
-template <int D>
-__global__ __launch_bounds__(256) void k_transfer_fwd(SmlFwdArgs a) {
+template <int D, int MT>
+__global__ __launch_bounds__(512) void k_transfer_fwd(SmlFwdArgs a) {
+    constexpr int R = SML_TM * MT;
     constexpr int K1 = SML_C2 * D;       // fc1 reduction length
-    constexpr int S1 = K1 + 4;           // LDS row stride of A1 (S1/4 odd: conflict-free b128 reads)
+    constexpr int S1 = K1 + 4;           // LDS row strides (multiples of 4 floats: 16-byte aligned b128 reads)
     constexpr int S2 = SML_HID + 4;
-    constexpr int KS1 = K1 / 8;
-    constexpr int EPT = SML_R * D / 256;
-    constexpr int JT = D / 32;
-    __shared__ __attribute__((aligned(16))) float smem[SML_R * S1 + SML_R * S2 + 104];
+    constexpr int KS1 = K1 / 16;
+    constexpr int EPT = R * D / 512;
+    constexpr int JT = D / 16;                                    // fc2 column tiles
+    constexpr int KSPL = (D == 32) ? 8 : (D == 64 ? 4 : 2);       // fc2: waves along K ...
+    constexpr int JSPL = 8 / KSPL;                                // ... x waves along the columns
+    constexpr int JTW = JT / JSPL;
+    constexpr int KPW = 32 / KSPL;                                // fc2 k-steps per wave
+    constexpr int REG0 = cmax(R * S1, KSPL * R * (D + 1));
+    __shared__ __attribute__((aligned(16))) float smem[REG0 + R * S2 + 104];
+    __shared__ SmlSched swin[SML_SW];
     float* A1s = smem;
-    float* a2s = smem + SML_R * S1;
-    float* cws = smem + SML_R * S1 + SML_R * S2;
-    float* xts = a2s;                    // [32][D+1], dead before a2s is written
-    float* nrm = a2s + SML_R * (D + 1);
-    float* part = smem;                  // [4][32][D+1], aliases A1s after fc1
+    float* a2s = smem + REG0;
+    float* cws = smem + REG0 + R * S2;
+    float* xts = a2s;                    // [R][D+1], dead before a2s is written
+    float* nrm = a2s + R * (D + 1);
+    float* part = smem;                  // [KSPL][R][D+1], aliases A1s after fc1
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
     const int sidx = (int)blockIdx.x >= a.tiles0;
     const SmlSeg& sg = a.seg[sidx];
-    const int row0 = ((int)blockIdx.x - (sidx ? a.tiles0 : 0)) * SML_R;
+    const int row0 = ((int)blockIdx.x - (sidx ? a.tiles0 : 0)) * R;
     const float* __restrict__ theta = sg.theta;
     if (tid < 104) cws[tid] = theta[tid];
+    const bool lazy = sg.last_tab != nullptr;
+    if (lazy) sched_window_load(swin, a.sched, a.cur_step - 1, tid);
 
     // ---- P1: gather x_t and x_hat; all index loads, then all row loads, are in flight together
     float xt[EPT], xh[EPT];
@@ -115,38 +136,41 @@ __global__ __launch_bounds__(256) void k_transfer_fwd(SmlFwdArgs a) {
         bool ok[EPT];
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
-            const int row = row0 + (q * 256 + tid) / D;
+            const int row = row0 + (q * 512 + tid) / D;
             ok[q] = row < sg.n_rows;
             idx[q] = ok[q] ? seg_row_index(sg, row) : 0;
         }
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
-            const int w = (q * 256 + tid) % D;
+            const int w = (q * 512 + tid) % D;
             xt[q] = sg.xt_tab[idx[q] * D + w];
             xh[q] = sg.xh_tab[idx[q] * D + w];
         }
-        if (sg.last_tab != nullptr) {      // replay the row's pending zero-gradient Adam steps
-            float m[EPT], v[EPT];
-            int from[EPT];
+        float m[EPT], v[EPT];
+        int from[EPT];
+        if (lazy) {
 #pragma unroll
             for (int q = 0; q < EPT; ++q) {
-                const int w = (q * 256 + tid) % D;
+                const int w = (q * 512 + tid) % D;
                 m[q] = sg.m_tab[idx[q] * D + w];
                 v[q] = sg.v_tab[idx[q] * D + w];
                 from[q] = sg.last_tab[idx[q]];
             }
-#pragma unroll
-            for (int q = 0; q < EPT; ++q) adam_replay(xh[q], m[q], v[q], from[q], a.cur_step - 1, a.sched);
         }
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
-            const int e = q * 256 + tid;
+            const int e = q * 512 + tid;
             if (!ok[q]) { xt[q] = 1.0f; xh[q] = 0.0f; }
             xts[(e / D) * (D + 1) + (e % D)] = xt[q];
         }
+        __syncthreads();                   // xts, cws and the schedule window are in LDS
+        if (lazy) {                        // replay the rows' pending zero-gradient Adam steps
+#pragma unroll
+            for (int q = 0; q < EPT; ++q)
+                if (ok[q]) adam_replay_w(xh[q], m[q], v[q], from[q], a.cur_step - 1, a.sched, swin, a.cur_step - 1);
+        }
     }
-    __syncthreads();
-    if (tid < SML_R) {
+    if (tid < R) {
         float s = 0.0f;
 #pragma unroll 8
         for (int w = 0; w < D; ++w) { const float t = xts[tid * (D + 1) + w]; s += t * t; }
@@ -156,7 +180,7 @@ __global__ __launch_bounds__(256) void k_transfer_fwd(SmlFwdArgs a) {
     // ---- P2: x_com, conv1, Gelu, conv2, Gelu -> A1 tile (channel-major flatten c*D + w)
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
-        const int e = q * 256 + tid, r = e / D, w = e % D;
+        const int e = q * 512 + tid, r = e / D, w = e % D;
         const int row = row0 + r;
         const float xc = (xt[q] * xh[q]) / nrm[r];     // no epsilon, as model/conv_transfer.py:99
         Pro p;
@@ -176,169 +200,202 @@ __global__ __launch_bounds__(256) void k_transfer_fwd(SmlFwdArgs a) {
     }
     __syncthreads();
 
-    // ---- fc1: Z1[32 x 512] = A1[32 x K1] * W1^T ; wave wv owns n-tiles 4wv..4wv+3
+    // ---- fc1: Z1[R x 512] = A1[R x K1] * W1^T ; wave wv owns column tiles 4wv..4wv+3 (of 32)
     {
-        f32x16 acc[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[t][q] = 0.0f;
-        mma_rows<4, KS1, 2>(acc, A1s + l31 * S1 + 4 * hi, reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p1(D)),
-                            KS1, 0, lane, [wv](int t) { return wv * 4 + t; });
+        f32x4 acc[MT][4];
+        zero_acc(acc);
+        mma16_rows<MT, 4, KS1, 2>(acc, A1s + l15 * S1 + 4 * g4, SML_TM * S1,
+                                  reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p1(D)), KS1, 0, lane,
+                                  [wv](int t) { return wv * 4 + t; });
         // + bias, save z1, Gelu -> a2 tile.  (xts/nrm are dead: every wave passed the barrier above)
         float* z1 = sg.z1;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int n = (wv * 4 + t) * 32 + l31;
+            const int n = (wv * 4 + t) * 16 + l15;
             const float bias = theta[sml_off_f1b(D) + n];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int r = mfma32_row(q, lane);
-                const float z = acc[t][q] + bias;
-                if (z1 != nullptr) z1[(int64_t)(row0 + r) * SML_HID + n] = z;
-                a2s[r * S2 + n] = sml_gelu(z);
-            }
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = mt * SML_TM + 4 * g4 + q;
+                    const float z = acc[mt][t][q] + bias;
+                    if (z1 != nullptr) z1[(int64_t)(row0 + r) * SML_HID + n] = z;
+                    a2s[r * S2 + n] = sml_gelu(z);
+                }
         }
     }
     __syncthreads();
 
-    // ---- fc2: Out[32 x D] = a2[32 x 512] * W2^T ; the four waves split K = 512
+    // ---- fc2: Out[R x D] = a2[R x 512] * W2^T ; waves = KSPL (along K = 512) x JSPL (column tiles)
     {
-        f32x16 acc[JT];
+        const int kq = wv % KSPL, jq = wv / KSPL;
+        f32x4 acc[MT][JTW];
+        zero_acc(acc);
+        mma16_rows<MT, JTW, KPW, (KPW < 4 ? KPW : 4)>(acc, a2s + l15 * S2 + 4 * g4, SML_TM * S2,
+                                                      reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p2(D)), 32,
+                                                      kq * KPW, lane, [jq](int t) { return jq * JTW + t; });
 #pragma unroll
-        for (int t = 0; t < JT; ++t)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[t][q] = 0.0f;
-        mma_rows<JT, 16, (JT == 1 ? 8 : 4)>(acc, a2s + l31 * S2 + 4 * hi,
-                                            reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p2(D)), 64, wv * 16, lane,
-                                            [](int t) { return t; });
+            for (int t = 0; t < JTW; ++t)
 #pragma unroll
-        for (int t = 0; t < JT; ++t)
-#pragma unroll
-            for (int q = 0; q < 16; ++q)
-                part[(wv * SML_R + mfma32_row(q, lane)) * (D + 1) + t * 32 + l31] = acc[t][q];
+                for (int q = 0; q < 4; ++q)
+                    part[(kq * R + mt * SML_TM + 4 * g4 + q) * (D + 1) + (jq * JTW + t) * 16 + l15] = acc[mt][t][q];
     }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
-        const int e = q * 256 + tid, r = e / D, j = e % D;
+        const int e = q * 512 + tid, r = e / D, j = e % D;
         float s = theta[sml_off_f2b(D) + j];
 #pragma unroll
-        for (int w4 = 0; w4 < 4; ++w4) s += part[(w4 * SML_R + r) * (D + 1) + j];
+        for (int k = 0; k < KSPL; ++k) s += part[(k * R + r) * (D + 1) + j];
         if (row0 + r < sg.n_rows) sg.out[(int64_t)(row0 + r) * D + j] = s;
     }
+}
+
+// sum 96 per-lane values over the wavefront with 96 shuffles instead of 6 x 96: at each step
+// the two halves of the lane pair split the remaining vector (a transposed butterfly), so after
+// masks 32..2 each lane holds 3 complete-but-for-one-bit sums; a last plain step finishes them.
+// Lane l (even) ends with v[0..2] = totals of compact indices base(l) + 0..2.  Deterministic.
+__device__ __forceinline__ void wave_sum96(float (&v)[SML_CG], int lane) {
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int mask = 32 >> s;
+        const int half = (SML_CG / 2) >> s;
+        const bool up = (lane & mask) != 0;
+#pragma unroll
+        for (int i = 0; i < half; ++i) {
+            const float send = up ? v[i] : v[i + half];
+            const float keep = up ? v[i + half] : v[i];
+            v[i] = keep + __shfl_xor(send, mask, 64);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) v[i] += __shfl_xor(v[i], 1, 64);
+}
+__device__ __forceinline__ int wave_sum96_base(int lane) {
+    return ((lane >> 5) & 1) * 48 + ((lane >> 4) & 1) * 24 + ((lane >> 3) & 1) * 12 + ((lane >> 2) & 1) * 6 +
+           ((lane >> 1) & 1) * 3;
 }
 
 // ------------------------------------------------------------------------------------
 // backward: dOut -> (MF stage) dx_hat + l2*x_hat, or (TR stage) dZ1 rows + conv-grad partials.
 // dx / dz1 scratch is padded to whole tiles (unconditional stores).
 // ------------------------------------------------------------------------------------
-template <int D>
-__global__ __launch_bounds__(256) void k_transfer_bwd(SmlBwdArgs a) {
+template <int D, int MT, bool TR>
+__global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
+    constexpr int R = SML_TM * MT;
     constexpr int K1 = SML_C2 * D;
     constexpr int S2 = SML_HID + 4;
     constexpr int SD = D + 4;
-    constexpr int KSD = D / 8;
-    constexpr int EPT = SML_R * D / 256;
-    constexpr int KSPLIT = (D == 32) ? 4 : (D == 64 ? 2 : 1);   // waves along the n reduction
+    constexpr int KSD = D / 16;
+    constexpr int EPT = R * D / 512;
+    constexpr int KSPL = (D == 32) ? 4 : (D == 64 ? 2 : 1);      // dA1: waves along the n reduction ...
+    constexpr int TSPL = 8 / KSPL;                                // ... x waves along the 5D outputs (5 tiles each)
+    constexpr int KPER = 32 / KSPL;
     constexpr int PSTR = K1 + 1;
-    constexpr int SZ_A = SML_R * S2 + SML_R * SD;
-    constexpr int SZ_B = KSPLIT * SML_R * PSTR;
-    constexpr int SZ = SZ_A > SZ_B ? SZ_A : SZ_B;
+    constexpr int SZ = cmax(R * S2 + R * SD, KSPL * R * PSTR);
+    static_assert((K1 / 16) == 5 * TSPL, "5 column tiles per wave");
     __shared__ __attribute__((aligned(16))) float smem[SZ + 104];
-    __shared__ float red[4][104];
-    float* dZs = smem;                    // [32][516]
-    float* dOs = smem + SML_R * S2;       // [32][D+4]
-    float* part = smem;                   // [KSPLIT][32][5D+1], aliases dZs after the second GEMM
+    __shared__ float red[8][SML_CG];
+    float* dZs = smem;                    // [R][516]
+    float* dOs = smem + R * S2;           // [R][D+4]
+    float* part = smem;                   // [KSPL][R][5D+1], aliases dZs after the second GEMM
     float* cws = smem + SZ;
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
     const int sidx = (int)blockIdx.x >= a.tiles0;
     const SmlBwdSeg& sg = a.seg[sidx];
-    const int row0 = ((int)blockIdx.x - (sidx ? a.tiles0 : 0)) * SML_R;
+    const int row0 = ((int)blockIdx.x - (sidx ? a.tiles0 : 0)) * R;
     if (tid < 104) cws[tid] = sg.theta[tid];
 
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
-        const int e = q * 256 + tid, r = e / D, j = e % D;
+        const int e = q * 512 + tid, r = e / D, j = e % D;
         dOs[r * SD + j] = (row0 + r < sg.n_rows) ? sg.dout[(int64_t)(row0 + r) * D + j] : 0.0f;
     }
-    // the (x_t, x_hat, x_com) rows of the tail: issue the loads now, use them after both GEMMs
-    float x0[EPT], x1[EPT], x2[EPT];
-#pragma unroll
-    for (int q = 0; q < EPT; ++q) {
-        const int e = q * 256 + tid, r = e / D, w = e % D;
-        const float* x = sg.xin + (int64_t)(row0 + r) * 3 * D;
-        x0[q] = x[w]; x1[q] = x[D + w]; x2[q] = x[2 * D + w];
+    // the (x_t, x_hat, x_com) rows of the tail: with one element per thread issue the loads now and
+    // use them after both GEMMs; with more (d > 32) load them in the tail to keep registers free
+    constexpr bool PRELOAD = (EPT == 1);
+    float x0p = 0.f, x1p = 0.f, x2p = 0.f;
+    if (PRELOAD) {
+        const float* x = sg.xin + (int64_t)(row0 + tid / D) * 3 * D;
+        x0p = x[tid % D]; x1p = x[D + tid % D]; x2p = x[2 * D + tid % D];
     }
     __syncthreads();
-    // ---- dA2[32 x 512] = dOut[32 x D] * W2 ; dZ1 = dA2 * Gelu'(z1)
+    // ---- dA2[R x 512] = dOut[R x D] * W2 ; dZ1 = dA2 * Gelu'(z1) ; wave wv owns column tiles 4wv..4wv+3
     {
-        f32x16 acc[4];
+        f32x4 acc[MT][4];
+        zero_acc(acc);
+        float z[MT][4][4];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[t][q] = 0.0f;
-        // z1 of this wave's 4 column tiles: issue with the GEMM, consume in its epilogue
-        mma_rows<4, KSD, (KSD < 4 ? KSD : 4)>(acc, dOs + l31 * SD + 4 * hi,
-                                              reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p2b(D)), KSD, 0, lane,
-                                              [wv](int t) { return wv * 4 + t; });
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    z[mt][t][q] = sg.z1[(int64_t)(row0 + mt * SML_TM + 4 * g4 + q) * SML_HID + (wv * 4 + t) * 16 + l15];
+        mma16_rows<MT, 4, KSD, KSD>(acc, dOs + l15 * SD + 4 * g4, SML_TM * SD,
+                                    reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p2b(D)), KSD, 0, lane,
+                                    [wv](int t) { return wv * 4 + t; });
         float* dz1 = sg.dz1;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int n = (wv * 4 + t) * 32 + l31;
-            float z[16];
+            const int n = (wv * 4 + t) * 16 + l15;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) z[q] = sg.z1[(int64_t)(row0 + mfma32_row(q, lane)) * SML_HID + n];
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int r = mfma32_row(q, lane);
-                const float dz = acc[t][q] * sml_gelu_grad(z[q]);
-                dZs[r * S2 + n] = dz;
-                if (dz1 != nullptr) dz1[(int64_t)(row0 + r) * SML_HID + n] = dz;
-            }
+                for (int q = 0; q < 4; ++q) {
+                    const int r = mt * SML_TM + 4 * g4 + q;
+                    const float dz = acc[mt][t][q] * sml_gelu_grad(z[mt][t][q]);
+                    dZs[r * S2 + n] = dz;
+                    if (TR) dz1[(int64_t)(row0 + r) * SML_HID + n] = dz;
+                }
         }
     }
     __syncthreads();
-    // ---- dA1[32 x 5D] = dZ1[32 x 512] * W1 ; waves = KSPLIT (reduction) x TSPLIT (5 tiles each)
+    // ---- dA1[R x 5D] = dZ1[R x 512] * W1 ; waves = KSPL (reduction) x TSPL (5 column tiles each)
     {
-        const int kq = wv % KSPLIT, tq = wv / KSPLIT;
-        constexpr int KPER = 64 / KSPLIT;      // k-steps (of 8) per wave
-        f32x16 acc[5];
-#pragma unroll
-        for (int t = 0; t < 5; ++t)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[t][q] = 0.0f;
-        mma_rows<5, KPER, 2>(acc, dZs + l31 * S2 + 4 * hi, reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p1b(D)), 64,
-                             kq * KPER, lane, [tq](int t) { return tq * 5 + t; });
+        const int kq = wv % KSPL, tq = wv / KSPL;
+        f32x4 acc[MT][5];
+        zero_acc(acc);
+        mma16_rows<MT, 5, KPER, 2>(acc, dZs + l15 * S2 + 4 * g4, SML_TM * S2,
+                                   reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p1b(D)), 32, kq * KPER, lane,
+                                   [tq](int t) { return tq * 5 + t; });
         __syncthreads();                        // every wave is done reading dZs
 #pragma unroll
-        for (int t = 0; t < 5; ++t)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int q = 0; q < 16; ++q)
-                part[(kq * SML_R + mfma32_row(q, lane)) * PSTR + (tq * 5 + t) * 32 + l31] = acc[t][q];
+            for (int t = 0; t < 5; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    part[(kq * R + mt * SML_TM + 4 * g4 + q) * PSTR + (tq * 5 + t) * 16 + l15] = acc[mt][t][q];
     }
     __syncthreads();
     // ---- per-coordinate tail: Gelu'(h2) -> conv2^T -> Gelu'(h1) -> conv1^T (row 1 = x_hat)
-    float cg[104];
-    const bool want_cg = a.convg_part != nullptr;
-    if (want_cg) {
+    float cg[TR ? SML_CG : 1];
+    if constexpr (TR) {
 #pragma unroll
-        for (int i = 0; i < 104; ++i) cg[i] = 0.0f;
+        for (int i = 0; i < SML_CG; ++i) cg[i] = 0.0f;
     }
-#pragma unroll
+#pragma unroll 1
     for (int q = 0; q < EPT; ++q) {
-        const int e = q * 256 + tid, r = e / D, w = e % D;
+        const int e = q * 512 + tid, r = e / D, w = e % D;
         const int row = row0 + r;
         const bool ok = row < sg.n_rows;
+        float x0 = x0p, x1 = x1p, x2 = x2p;
+        if (!PRELOAD) {
+            const float* x = sg.xin + (int64_t)row * 3 * D;
+            x0 = x[w]; x1 = x[D + w]; x2 = x[2 * D + w];
+        }
         Pro p;
-        conv_prologue(cws, x0[q], x1[q], x2[q], p);
+        conv_prologue(cws, x0, x1, x2, p);
         float dh2p[SML_C2];
 #pragma unroll
         for (int c = 0; c < SML_C2; ++c) {
             float s = 0.0f;
 #pragma unroll
-            for (int k = 0; k < KSPLIT; ++k) s += part[(k * SML_R + r) * PSTR + c * D + w];
+            for (int k = 0; k < KSPL; ++k) s += part[(k * R + r) * PSTR + c * D + w];
             dh2p[c] = s * sml_gelu_grad(p.h2p[c]);
         }
         float dxh = 0.0f;
@@ -351,42 +408,43 @@ __global__ __launch_bounds__(256) void k_transfer_bwd(SmlBwdArgs a) {
             dh1p[c] = s * sml_gelu_grad(p.h1p[c]);
             dxh += dh1p[c] * cws[SML_OFF_C1W + c * 3 + 1];
         }
-        if (sg.dx != nullptr) sg.dx[(int64_t)row * D + w] = dxh + a.l2 * x1[q];
-        if (want_cg && ok) {
+        if (!TR) sg.dx[(int64_t)row * D + w] = dxh + a.l2 * x1;
+        if constexpr (TR) if (ok) {
 #pragma unroll
             for (int c = 0; c < SML_C1; ++c) {
-                cg[SML_OFF_C1W + c * 3 + 0] += dh1p[c] * x0[q];
-                cg[SML_OFF_C1W + c * 3 + 1] += dh1p[c] * x1[q];
-                cg[SML_OFF_C1W + c * 3 + 2] += dh1p[c] * x2[q];
-                cg[SML_OFF_C1B + c] += dh1p[c];
+                cg[conv_compact(SML_OFF_C1W + c * 3 + 0)] += dh1p[c] * x0;
+                cg[conv_compact(SML_OFF_C1W + c * 3 + 1)] += dh1p[c] * x1;
+                cg[conv_compact(SML_OFF_C1W + c * 3 + 2)] += dh1p[c] * x2;
+                cg[conv_compact(SML_OFF_C1B + c)] += dh1p[c];
             }
 #pragma unroll
             for (int o = 0; o < SML_C2; ++o) {
 #pragma unroll
-                for (int c = 0; c < SML_C1; ++c) cg[SML_OFF_C2W + o * SML_C1 + c] += dh2p[o] * p.h1[c];
-                cg[SML_OFF_C2B + o] += dh2p[o];
+                for (int c = 0; c < SML_C1; ++c) cg[conv_compact(SML_OFF_C2W + o * SML_C1 + c)] += dh2p[o] * p.h1[c];
+                cg[conv_compact(SML_OFF_C2B + o)] += dh2p[o];
             }
         }
     }
-    if (want_cg) {
-        // deterministic tree: lanes (xor shuffles), then waves in index order
+    if constexpr (TR) {
+        wave_sum96(cg, lane);
+        if ((lane & 1) == 0) {
+            const int base = wave_sum96_base(lane);
 #pragma unroll
-        for (int i = 0; i < 104; ++i) {
-            if (!conv_slot_used_host(i)) continue;
-            float v = cg[i];
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-            if (lane == 0) red[wv][i] = v;
+            for (int i = 0; i < 3; ++i) red[wv][base + i] = cg[i];
         }
         __syncthreads();
-        if (tid < 104)
-            a.convg_part[(int64_t)blockIdx.x * 104 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        if (tid < SML_CG) {
+            float s = 0.0f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) s += red[w8][tid];
+            a.convg_part[(int64_t)blockIdx.x * SML_CG + tid] = s;
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------
 // weight gradients (TR stage): dW1 = dZ1^T A1, db1, dW2 = dOut^T Gelu(z1), db2
-// one workgroup per 32x32 output tile; the four waves split the batch rows
+// one workgroup per 32x32 output tile (v_mfma_f32_32x32x2_f32); the four waves split the batch rows
 // ------------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(256) void k_transfer_wgrad(SmlWgArgs a) {
@@ -467,12 +525,12 @@ __device__ __forceinline__ void pack_store(float* __restrict__ pk, int off, floa
     constexpr int K1 = SML_C2 * D;
     if (off >= SML_OFF_F1W && off < sml_off_f1b(D)) {
         const int n = (off - SML_OFF_F1W) / K1, k = (off - SML_OFF_F1W) % K1;
-        pk[sml_pk_p1(D) + pk_pos(K1 / 8, n, k)] = p;
-        pk[sml_pk_p1b(D) + pk_pos(SML_HID / 8, k, n)] = p;
+        pk[sml_pk_p1(D) + pk_pos(K1 / 16, n, k)] = p;
+        pk[sml_pk_p1b(D) + pk_pos(SML_HID / 16, k, n)] = p;
     } else if (off >= sml_off_f2w(D) && off < sml_off_f2b(D)) {
         const int j = (off - sml_off_f2w(D)) / SML_HID, n = (off - sml_off_f2w(D)) % SML_HID;
-        pk[sml_pk_p2(D) + pk_pos(SML_HID / 8, j, n)] = p;
-        pk[sml_pk_p2b(D) + pk_pos(D / 8, n, j)] = p;
+        pk[sml_pk_p2(D) + pk_pos(SML_HID / 16, j, n)] = p;
+        pk[sml_pk_p2b(D) + pk_pos(D / 16, n, j)] = p;
     }
 }
 
@@ -485,8 +543,6 @@ __global__ __launch_bounds__(256) void k_theta_pack(const float* __restrict__ th
     pack_store<D>(pk + (int64_t)net * sml_pk_size(D), off, theta[i]);
 }
 
-__device__ __forceinline__ bool conv_slot_used(int off) { return conv_slot_used_host(off); }
-
 template <int D>
 __global__ __launch_bounds__(256) void k_theta_adam(SmlThetaAdamArgs a) {
     constexpr int NS = sml_net_size(D);
@@ -495,11 +551,12 @@ __global__ __launch_bounds__(256) void k_theta_adam(SmlThetaAdamArgs a) {
     const int net = i / NS, off = i % NS;
     float g;
     if (off < SML_OFF_F1W) {
-        if (!conv_slot_used(off)) return;
+        if (!conv_slot_used_host(off)) return;
         if (a.convg_part != nullptr) {
             g = 0.0f;
             const int t0 = net ? a.tiles0 : 0, t1 = net ? a.tiles_total : a.tiles0;
-            for (int t = t0; t < t1; ++t) g += a.convg_part[(int64_t)t * 104 + off];
+            const int c = conv_compact(off);
+            for (int t = t0; t < t1; ++t) g += a.convg_part[(int64_t)t * SML_CG + c];
             a.grad[i] = g;                           // keep the flat gradient complete (all-reduce input)
         } else {
             g = a.grad[i];
@@ -517,26 +574,22 @@ __global__ __launch_bounds__(256) void k_theta_adam(SmlThetaAdamArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
-// lane-map self test: D = A(32 x 16) * W(32 cols x 16)^T through the same operand paths
+// lane-map self test: D = A(16 x 32) * W(16 cols x 32)^T through the same operand paths
 // ------------------------------------------------------------------------------------
 __global__ void k_selftest(const float* __restrict__ A, const float* __restrict__ W, float* __restrict__ pk,
                            float* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float As[32 * 20];
-    const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
-    for (int e = lane; e < 32 * 16; e += 64) {
-        As[(e / 16) * 20 + (e % 16)] = A[e];
-        pk[pk_pos(2, e / 16, e % 16)] = W[e];       // W[col][red]
+    __shared__ __attribute__((aligned(16))) float As[16 * 36];
+    const int lane = threadIdx.x, l15 = lane & 15, g4 = lane >> 4;
+    for (int e = lane; e < 16 * 32; e += 64) {
+        As[(e / 32) * 36 + (e % 32)] = A[e];
+        pk[pk_pos(2, e / 32, e % 32)] = W[e];       // W[col][red]
     }
     __syncthreads();
-    f32x16 acc;
-    for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
-    const f32x4* P = reinterpret_cast<const f32x4*>(pk);
-    for (int ks = 0; ks < 2; ++ks) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(As + l31 * 20 + ks * 8 + 4 * hi);
-        const f32x4 bv = P[(0 * 2 + ks) * 64 + lane];
-        for (int e = 0; e < 4; ++e) acc = mfma32(av[e], bv[e], acc);
-    }
-    for (int q = 0; q < 16; ++q) out[mfma32_row(q, lane) * 32 + l31] = acc[q];
+    f32x4 acc[1][1];
+    zero_acc(acc);
+    mma16_rows<1, 1, 2, 2>(acc, As + l15 * 36 + 4 * g4, 0, reinterpret_cast<const f32x4*>(pk), 2, 0, lane,
+                           [](int) { return 0; });
+    for (int q = 0; q < 4; ++q) out[(4 * g4 + q) * 16 + l15] = acc[0][0][q];
 }
 
 }  // namespace
@@ -550,14 +603,18 @@ __global__ void k_selftest(const float* __restrict__ A, const float* __restrict_
         default: return hipErrorInvalidValue; \
     }
 
-hipError_t sml_launch_fwd(int d, const SmlFwdArgs& a, int tiles_total, hipStream_t st) {
+hipError_t sml_launch_fwd(int d, int mt, const SmlFwdArgs& a, int tiles_total, hipStream_t st) {
     if (tiles_total <= 0) return hipSuccess;
-    SML_DISPATCH_D(d, k_transfer_fwd<DD><<<dim3(tiles_total), dim3(256), 0, st>>>(a));
+    if (mt == 1) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 1><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }
+    else if (mt == 2) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 2><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
-hipError_t sml_launch_bwd(int d, const SmlBwdArgs& a, int tiles_total, hipStream_t st) {
+hipError_t sml_launch_bwd(int d, int mt, const SmlBwdArgs& a, int tiles_total, hipStream_t st) {
     if (tiles_total <= 0) return hipSuccess;
-    SML_DISPATCH_D(d, k_transfer_bwd<DD><<<dim3(tiles_total), dim3(256), 0, st>>>(a));
+    if (mt != 1) return hipErrorInvalidValue;      // backward only ever sees training batches
+    if (a.convg_part != nullptr) { SML_DISPATCH_D(d, k_transfer_bwd<DD, 1, true><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }
+    else { SML_DISPATCH_D(d, k_transfer_bwd<DD, 1, false><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }
     return hipGetLastError();
 }
 hipError_t sml_launch_wgrad(int d, const SmlWgArgs& a, hipStream_t st) {
