@@ -291,7 +291,7 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
     if ((rc = ensure_pk(ctx))) return rc;
     if ((rc = ensure_transfer_ws(ctx, batch, false))) return rc;
     if ((rc = ensure_sched(ctx, lr, *step + nb + 1))) return rc;
-    const int lstride = (batch * (d / 4) + 255) / 256;
+    const int lstride = wg_tiles(batch, 1) + wg_tiles(2 * batch, 1);     // one loss partial per backward workgroup
     HIPCHK(ctx->loss_part.ensure((size_t)nb * lstride));
     ctx->prof.begin(PC_PACK, st); HIPCHK(sml_launch_theta_pack(d, theta, ctx->pk.p, st)); ctx->prof.end(st);
     ctx->prof.begin(PC_SORT, st); rc = sort_epoch(ctx, triples, n, batch, 1, st); ctx->prof.end(st); if (rc) return rc;
@@ -319,20 +319,18 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
         f.tiles0 = wg_tiles(B, 1); f.cur_step = cur; f.sched = ctx->sched.p;
         const int tiles = f.tiles0 + wg_tiles(2 * B, 1);
         ctx->prof.begin(PC_FWD, st); HIPCHK(sml_launch_fwd(d, 1, f, tiles, st)); ctx->prof.end(st);
-        SmlLossArgs L;
-        L.out = ctx->out.p; L.xin = ctx->xin.p; L.dout = ctx->dout.p; L.loss_part = ctx->loss_part.p + b * lstride;
-        L.B = B; L.ioff = SML_R * tiles_of(B); L.kind = loss_kind; L.l2 = l2; L.scale = xchg ? xchg->loss_scale : 1.0f;
-        ctx->prof.begin(PC_PAIR_LOSS, st); HIPCHK(sml_launch_pair_loss(d, L, nullptr, st)); ctx->prof.end(st);
         SmlBwdArgs w;
         memset(&w, 0, sizeof(w));
         for (int s = 0; s < 2; ++s) {
             SmlBwdSeg& sg = w.seg[s];
             const int64_t slot0 = s ? (int64_t)SML_R * tiles_of(B) : 0;
             sg.theta = theta + s * ns; sg.pk = ctx->pk.p + s * ps;
-            sg.dout = ctx->dout.p + slot0 * d; sg.z1 = ctx->z1.p + slot0 * SML_HID; sg.xin = ctx->xin.p + slot0 * 3 * d;
+            sg.dout = ctx->dout.p + slot0 * d; sg.is_item = s; sg.z1 = ctx->z1.p + slot0 * SML_HID; sg.xin = ctx->xin.p + slot0 * 3 * d;
             sg.dx = dx_buf + slot0 * d; sg.dz1 = nullptr; sg.n_rows = s ? 2 * B : B;
         }
         w.tiles0 = f.tiles0; w.l2 = l2; w.convg_part = nullptr;
+        w.out_all = ctx->out.p; w.B = B; w.ioff = SML_R * tiles_of(B); w.kind = loss_kind;
+        w.scale = xchg ? xchg->loss_scale : 1.0f; w.loss_part = ctx->loss_part.p + b * lstride;
         ctx->prof.begin(PC_BWD, st); HIPCHK(sml_launch_bwd(d, 1, w, tiles, st)); ctx->prof.end(st);
         SmlSegUpdArgs u;
         memset(&u, 0, sizeof(u));
@@ -384,7 +382,7 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
     if ((rc = ensure_pk(ctx))) return rc;
     if ((rc = ensure_transfer_ws(ctx, batch, true))) return rc;
     float* grad = theta_grad ? theta_grad : ctx->grad.p;
-    const int lstride = (batch * (d / 4) + 255) / 256;
+    const int lstride = wg_tiles(batch, 1) + wg_tiles(2 * batch, 1);
     HIPCHK(ctx->loss_part.ensure((size_t)nb * lstride));
     ctx->prof.begin(PC_PACK, st); HIPCHK(sml_launch_theta_pack(d, theta, ctx->pk.p, st)); ctx->prof.end(st);
     HIPCHK(hipMemsetAsync(ctx->loss_part.p, 0, (size_t)nb * lstride * sizeof(float), st));
@@ -408,10 +406,6 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
         f.tiles0 = wg_tiles(B, 1); f.cur_step = 0; f.sched = nullptr;
         const int tiles = f.tiles0 + wg_tiles(2 * B, 1);
         ctx->prof.begin(PC_FWD, st); HIPCHK(sml_launch_fwd(d, 1, f, tiles, st)); ctx->prof.end(st);
-        SmlLossArgs L;
-        L.out = ctx->out.p; L.xin = nullptr; L.dout = ctx->dout.p; L.loss_part = ctx->loss_part.p + b * lstride;
-        L.B = B; L.ioff = SML_R * tiles_of(B); L.kind = loss_kind; L.l2 = 0.0f; L.scale = loss_scale;
-        ctx->prof.begin(PC_PAIR_LOSS, st); HIPCHK(sml_launch_pair_loss(d, L, nullptr, st)); ctx->prof.end(st);
         SmlBwdArgs w;
         memset(&w, 0, sizeof(w));
         SmlWgArgs wg;
@@ -420,30 +414,35 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
             SmlBwdSeg& sg = w.seg[s];
             const int64_t slot0 = s ? (int64_t)SML_R * tiles_of(B) : 0;
             sg.theta = theta + s * ns; sg.pk = ctx->pk.p + s * ps;
-            sg.dout = ctx->dout.p + slot0 * d; sg.z1 = ctx->z1.p + slot0 * SML_HID; sg.xin = ctx->xin.p + slot0 * 3 * d;
+            sg.dout = ctx->dout.p + slot0 * d; sg.is_item = s; sg.z1 = ctx->z1.p + slot0 * SML_HID; sg.xin = ctx->xin.p + slot0 * 3 * d;
             sg.dx = nullptr; sg.dz1 = ctx->dz1.p + slot0 * SML_HID; sg.n_rows = s ? 2 * B : B;
             SmlWgSeg& q = wg.seg[s];
             q.dz1 = sg.dz1; q.a1 = ctx->a1.p + slot0 * SML_C2 * d; q.dout = sg.dout; q.z1 = sg.z1;
             q.grad = grad + s * ns; q.n_rows = sg.n_rows;
         }
         w.tiles0 = f.tiles0; w.l2 = 0.0f; w.convg_part = ctx->convg.p;
+        w.out_all = ctx->out.p; w.B = B; w.ioff = SML_R * tiles_of(B); w.kind = loss_kind;
+        w.scale = loss_scale; w.loss_part = ctx->loss_part.p + b * lstride;
         ctx->prof.begin(PC_BWD, st); HIPCHK(sml_launch_bwd(d, 1, w, tiles, st)); ctx->prof.end(st);
-        ctx->prof.begin(PC_WGRAD, st); HIPCHK(sml_launch_wgrad(d, wg, st)); ctx->prof.end(st);
-        SmlThetaAdamArgs ad;
-        memset(&ad, 0, sizeof(ad));
         const SmlSched sc = sched_entry((double)lr, *step + 1 + b);
-        ad.theta = theta; ad.m = adam_m; ad.v = adam_v; ad.grad = grad; ad.pk = ctx->pk.p;
-        ad.convg_part = ctx->convg.p; ad.tiles0 = f.tiles0; ad.tiles_total = tiles;
-        ad.weight_decay = weight_decay; ad.step_size = sc.step_size; ad.bc2_sqrt = sc.bc2_sqrt;
-        if (grad_hook) {
-            ad.grad_only = 1;
+        if (!grad_hook) {
+            // one GPU: the weight-gradient workgroups take the Adam step for the tiles they own
+            wg.theta = theta; wg.m = adam_m; wg.v = adam_v; wg.pk = ctx->pk.p;
+            wg.convg_part = ctx->convg.p; wg.tiles0 = f.tiles0; wg.tiles_total = tiles;
+            wg.weight_decay = weight_decay; wg.step_size = sc.step_size; wg.bc2_sqrt = sc.bc2_sqrt;
+            ctx->prof.begin(PC_WGRAD, st); HIPCHK(sml_launch_wgrad(d, wg, st)); ctx->prof.end(st);
+        } else {
+            ctx->prof.begin(PC_WGRAD, st); HIPCHK(sml_launch_wgrad(d, wg, st)); ctx->prof.end(st);
+            SmlThetaAdamArgs ad;
+            memset(&ad, 0, sizeof(ad));
+            ad.theta = theta; ad.m = adam_m; ad.v = adam_v; ad.grad = grad; ad.pk = ctx->pk.p;
+            ad.convg_part = ctx->convg.p; ad.tiles0 = f.tiles0; ad.tiles_total = tiles;
+            ad.weight_decay = weight_decay; ad.step_size = sc.step_size; ad.bc2_sqrt = sc.bc2_sqrt;
+            ad.grad_only = 1;                  // finish the flat gradient (conv partials), all-reduce, then step
             ctx->prof.begin(PC_THETA_ADAM, st); HIPCHK(sml_launch_theta_adam(d, ad, st)); ctx->prof.end(st);
             const int hr = grad_hook(hook_user, grad, 2 * ns, b);
             if (hr != 0) return fail(SML_ESTATE, "sml_tr_stage_epoch", "grad_hook failed");
             ad.grad_only = 0; ad.convg_part = nullptr;
-            ctx->prof.begin(PC_THETA_ADAM, st); HIPCHK(sml_launch_theta_adam(d, ad, st)); ctx->prof.end(st);
-        } else {
-            ad.grad_only = 0;
             ctx->prof.begin(PC_THETA_ADAM, st); HIPCHK(sml_launch_theta_adam(d, ad, st)); ctx->prof.end(st);
         }
     }

@@ -58,26 +58,6 @@ __device__ __forceinline__ float block_sum256(float v, float* sh4) {
     return sh4[0] + sh4[1] + sh4[2] + sh4[3];
 }
 
-// loss term and d loss / d s_pos, d loss / d s_neg for one pair
-// BCE: model/conv_transfer.py:124-126 (means over the batch -> inv_b); BPR: :128-134 (sum)
-__device__ __forceinline__ void pair_terms(int kind, float sp, float sn, float inv_b, float& lt, float& dsp,
-                                           float& dsn) {
-    if (kind == SML_LOSS_BCE) {
-        const float gp = sml_sigmoid(sp), gn = sml_sigmoid(sn);
-        const float ap = gp + 1e-15f, an = (1.0f - gn) + 1e-15f;
-        lt = -(logf(ap) + logf(an)) * inv_b;
-        dsp = -inv_b * gp * (1.0f - gp) / ap;
-        dsn = inv_b * gn * (1.0f - gn) / an;
-    } else {
-        const float x = sp - sn;
-        // -logsigmoid(x) = max(-x,0) + log1p(exp(-|x|))
-        lt = fmaxf(-x, 0.0f) + log1pf(expf(-fabsf(x)));
-        const float g = -sml_sigmoid(-x);
-        dsp = g;
-        dsn = -g;
-    }
-}
-
 // ------------------------------------------------------------------------------------
 // pair loss on transferred rows: out = [u' | i' | n'] -> dout, loss partials (+ l2 term)
 // ------------------------------------------------------------------------------------

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/sml_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -76,6 +77,27 @@ __device__ __forceinline__ int mfma32_row(int q, int lane) { return (q & 3) + 8 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+
+// loss term and d loss / d s_pos, d loss / d s_neg for one pair
+// BCE: model/conv_transfer.py:124-126 (means over the batch -> inv_b); BPR: :128-134 (sum)
+__device__ __forceinline__ void pair_terms(int kind, float sp, float sn, float inv_b, float& lt, float& dsp,
+                                           float& dsn) {
+    if (kind == SML_LOSS_BCE) {
+        const float gp = sml_sigmoid(sp), gn = sml_sigmoid(sn);
+        const float ap = gp + 1e-15f, an = (1.0f - gn) + 1e-15f;
+        lt = -(logf(ap) + logf(an)) * inv_b;
+        dsp = -inv_b * gp * (1.0f - gp) / ap;
+        dsn = inv_b * gn * (1.0f - gn) / an;
+    } else {
+        const float x = sp - sn;
+        // -logsigmoid(x) = max(-x,0) + log1p(exp(-|x|))
+        lt = fmaxf(-x, 0.0f) + log1pf(expf(-fabsf(x)));
+        const float g = -sml_sigmoid(-x);
+        dsp = g;
+        dsn = -g;
+    }
+}
+
 
 // ---- Adam (torch.optim.Adam single-tensor path; reference model/transfer.py:392-393) ----
 #define SML_BETA1 0.9f

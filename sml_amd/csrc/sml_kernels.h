@@ -32,7 +32,8 @@ struct SmlFwdArgs {
 struct SmlBwdSeg {
     const float* theta;
     const float* pk;
-    const float* dout;       // [n_rows, d]
+    float* dout;             // [n_rows, d] this run's dOut rows (written in the TR stage for the weight gradients)
+    int is_item;             // 0: rows are the batch's users; 1: positives then negatives
     const float* z1;         // [n_rows, 512]
     const float* xin;        // [n_rows, 3, d]
     float* dx;               // MF stage: [n_rows, d] gradient w.r.t. x_hat (+ l2*x_hat); null in TR stage
@@ -43,6 +44,9 @@ struct SmlBwdArgs {
     SmlBwdSeg seg[2];
     int tiles0;
     float l2;
+    // the pair loss is evaluated here: out rows of the whole batch (u' at t, i' at ioff+t, n' at ioff+B+t)
+    const float* out_all; int B; int ioff; int kind; float scale;
+    float* loss_part;        // [tiles] this batch's per-workgroup loss partials
     float* convg_part;       // TR stage: [tiles, SML_CG] per-tile compact conv1/conv2 gradient partials; else null
 };
 
@@ -51,7 +55,15 @@ struct SmlWgSeg {
     float* grad;             // this net's flat gradient block
     int n_rows;
 };
-struct SmlWgArgs { SmlWgSeg seg[2]; };
+struct SmlWgArgs {
+    SmlWgSeg seg[2];
+    // fused Adam (single-GPU path): every workgroup owns a fully reduced tile of a weight
+    // gradient, so it can take the Adam step for those weights (and refresh their operand-image
+    // entries) on the spot; two extra workgroups finish the conv parameters.  null theta: off.
+    float* theta; float* m; float* v; float* pk;
+    const float* convg_part; int tiles0, tiles_total;
+    float weight_decay, step_size, bc2_sqrt;
+};
 
 struct SmlThetaAdamArgs {
     float* theta; float* m; float* v; float* grad; float* pk;

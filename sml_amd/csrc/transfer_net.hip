@@ -298,6 +298,8 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
     static_assert((K1 / 16) == 5 * TSPL, "5 column tiles per wave");
     __shared__ __attribute__((aligned(16))) float smem[SZ + 104];
     __shared__ float red[8][SML_CG];
+    __shared__ float cf[4][SML_TM * MT];
+    __shared__ float lred[8];
     float* dZs = smem;                    // [R][516]
     float* dOs = smem + R * S2;           // [R][D+4]
     float* part = smem;                   // [KSPL][R][5D+1], aliases dZs after the second GEMM
@@ -309,10 +311,68 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
     const int row0 = ((int)blockIdx.x - (sidx ? a.tiles0 : 0)) * R;
     if (tid < 104) cws[tid] = sg.theta[tid];
 
+    // ---- pair loss (model/conv_transfer.py:120-134) for this tile's rows: every row fetches the three
+    // transferred rows of its triple, one thread per row forms the two scores and the loss terms,
+    // then dOut is written element-wise.  User tiles own the loss value (each triple once).
+    float* O3 = smem;                     // [3][R][D+1], aliases dZs (not yet live)
+    float ou[EPT], oi[EPT], on[EPT];
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
-        const int e = q * 512 + tid, r = e / D, j = e % D;
-        dOs[r * SD + j] = (row0 + r < sg.n_rows) ? sg.dout[(int64_t)(row0 + r) * D + j] : 0.0f;
+        const int e = q * 512 + tid, r = e / D, w = e % D;
+        const int row = row0 + r;
+        ou[q] = oi[q] = on[q] = 0.0f;
+        if (row < sg.n_rows) {
+            const int t = (sg.is_item && row >= a.B) ? row - a.B : row;
+            ou[q] = a.out_all[(int64_t)t * D + w];
+            oi[q] = a.out_all[(int64_t)(a.ioff + t) * D + w];
+            on[q] = a.out_all[(int64_t)(a.ioff + a.B + t) * D + w];
+        }
+        O3[(0 * R + r) * (D + 1) + w] = ou[q];
+        O3[(1 * R + r) * (D + 1) + w] = oi[q];
+        O3[(2 * R + r) * (D + 1) + w] = on[q];
+    }
+    __syncthreads();
+    float lsum = 0.0f;
+    if (tid < R) {
+        float sp = 0.f, sn = 0.f, uu = 0.f;
+#pragma unroll 8
+        for (int w = 0; w < D; ++w) {
+            const float u = O3[(0 * R + tid) * (D + 1) + w];
+            sp += u * O3[(1 * R + tid) * (D + 1) + w];
+            sn += u * O3[(2 * R + tid) * (D + 1) + w];
+            uu += u * u;
+        }
+        float lt, d0, d1, inv_nu = 1.0f, cc = 0.0f;
+        if (a.kind == SML_LOSS_BPR_NORM) {
+            const float nu = sqrtf(uu);
+            inv_nu = 1.0f / nu;
+            cc = (sp - sn) / (nu * nu * nu);
+            pair_terms(SML_LOSS_BPR, (sp - sn) * inv_nu, 0.0f, 1.0f, lt, d0, d1);
+            d1 = -d0;
+        } else {
+            pair_terms(a.kind, sp, sn, 1.0f / (float)a.B, lt, d0, d1);
+        }
+        cf[0][tid] = d0 * a.scale; cf[1][tid] = d1 * a.scale; cf[2][tid] = inv_nu; cf[3][tid] = cc;
+        if (!sg.is_item && row0 + tid < sg.n_rows) lsum = lt * a.scale;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int e = q * 512 + tid, r = e / D, w = e % D;
+        const int row = row0 + r;
+        const float d0 = cf[0][r], d1 = cf[1][r];
+        float g;
+        if (a.kind == SML_LOSS_BPR_NORM) {
+            const float inv_nu = cf[2][r], cc = cf[3][r];
+            if (!sg.is_item) g = d0 * ((oi[q] - on[q]) * inv_nu - cc * ou[q]);
+            else g = ((row < a.B) ? d0 : d1) * ou[q] * inv_nu;
+        } else {
+            if (!sg.is_item) g = d0 * oi[q] + d1 * on[q];
+            else g = ((row < a.B) ? d0 : d1) * ou[q];
+        }
+        if (row >= sg.n_rows) g = 0.0f;
+        dOs[r * SD + w] = g;
+        if (TR) sg.dout[(int64_t)row * D + w] = g;
     }
     // the (x_t, x_hat, x_com) rows of the tail: with one element per thread issue the loads now and
     // use them after both GEMMs; with more (d > 32) load them in the tail to keep registers free
@@ -408,7 +468,10 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
             dh1p[c] = s * sml_gelu_grad(p.h1p[c]);
             dxh += dh1p[c] * cws[SML_OFF_C1W + c * 3 + 1];
         }
-        if (!TR) sg.dx[(int64_t)row * D + w] = dxh + a.l2 * x1;
+        if (!TR) {
+            sg.dx[(int64_t)row * D + w] = dxh + a.l2 * x1;
+            if (ok) lsum += 0.5f * a.l2 * x1 * x1;      // + l2 * 0.5 * sum(x_hat^2), model/transfer.py:486-488
+        }
         if constexpr (TR) if (ok) {
 #pragma unroll
             for (int c = 0; c < SML_C1; ++c) {
@@ -425,6 +488,12 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
             }
         }
     }
+    {   // this workgroup's share of the batch loss: lanes, then waves in index order (deterministic)
+        float v = lsum;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) lred[wv] = v;
+    }
     if constexpr (TR) {
         wave_sum96(cg, lane);
         if ((lane & 1) == 0) {
@@ -439,6 +508,28 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
             for (int w8 = 0; w8 < 8; ++w8) s += red[w8][tid];
             a.convg_part[(int64_t)blockIdx.x * SML_CG + tid] = s;
         }
+    } else {
+        __syncthreads();
+    }
+    if (tid == 0) {
+        float s = 0.0f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) s += lred[w8];
+        a.loss_part[blockIdx.x] = s;
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void pack_store(float* __restrict__ pk, int off, float p) {
+    constexpr int K1 = SML_C2 * D;
+    if (off >= SML_OFF_F1W && off < sml_off_f1b(D)) {
+        const int n = (off - SML_OFF_F1W) / K1, k = (off - SML_OFF_F1W) % K1;
+        pk[sml_pk_p1(D) + pk_pos(K1 / 16, n, k)] = p;
+        pk[sml_pk_p1b(D) + pk_pos(SML_HID / 16, k, n)] = p;
+    } else if (off >= sml_off_f2w(D) && off < sml_off_f2b(D)) {
+        const int j = (off - sml_off_f2w(D)) / SML_HID, n = (off - sml_off_f2w(D)) % SML_HID;
+        pk[sml_pk_p2(D) + pk_pos(SML_HID / 16, j, n)] = p;
+        pk[sml_pk_p2b(D) + pk_pos(D / 16, n, j)] = p;
     }
 }
 
@@ -454,7 +545,26 @@ __global__ __launch_bounds__(256) void k_transfer_wgrad(SmlWgArgs a) {
     constexpr int T1 = 16 * KT, T2 = JT * 16, TN = T1 + T2;
     __shared__ float part[4][32][33];
     __shared__ float csum[4][32];
+    constexpr int NS = sml_net_size(D);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const bool fuse = a.theta != nullptr;
+    SmlSched sc; sc.step_size = a.step_size; sc.bc2_sqrt = a.bc2_sqrt;
+    if ((int)blockIdx.x >= 2 * TN) {
+        // conv1/conv2 parameters of one net: sum the backward tiles' partials in order, then Adam
+        const int net = (int)blockIdx.x - 2 * TN;
+        if (tid < 95) {
+            const int off = tid < 30 ? tid : tid < 40 ? tid + 2 : tid < 90 ? tid + 4 : tid + 6;
+            const int t0 = net ? a.tiles0 : 0, t1 = net ? a.tiles_total : a.tiles0;
+            float g = 0.0f;
+            for (int t = t0; t < t1; ++t) g += a.convg_part[(int64_t)t * SML_CG + tid];
+            const int64_t i = (int64_t)net * NS + off;
+            a.seg[net].grad[off] = g;
+            float p = a.theta[i], m = a.m[i], v = a.v[i];
+            adam_apply(p, m, v, g + a.weight_decay * p, sc);
+            a.theta[i] = p; a.m[i] = m; a.v[i] = v;
+        }
+        return;
+    }
     const int net = (int)blockIdx.x / TN;
     const int tl = (int)blockIdx.x % TN;
     const SmlWgSeg& sg = a.seg[net];
@@ -502,17 +612,26 @@ __global__ __launch_bounds__(256) void k_transfer_wgrad(SmlWgArgs a) {
     if (lane < 32) csum[wv][lane] = colsum;
     __syncthreads();
     float* __restrict__ g = sg.grad;
+    auto finish = [&](int off, float gsum) {
+        g[off] = gsum;
+        if (fuse) {
+            const int64_t i = (int64_t)net * NS + off;
+            float p = a.theta[i], m = a.m[i], v = a.v[i];
+            adam_apply(p, m, v, gsum + a.weight_decay * p, sc);
+            a.theta[i] = p; a.m[i] = m; a.v[i] = v;
+            pack_store<D>(a.pk + (int64_t)net * sml_pk_size(D), off, p);
+        }
+    };
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int e = q * 256 + tid, i = e >> 5, j = e & 31;
         const float s = part[0][i][j] + part[1][i][j] + part[2][i][j] + part[3][i][j];
-        if (is_w1) g[SML_OFF_F1W + (int64_t)(ti * 32 + i) * K1 + tj * 32 + j] = s;
-        else g[sml_off_f2w(D) + (int64_t)(ti * 32 + i) * SML_HID + tj * 32 + j] = s;
+        finish(is_w1 ? SML_OFF_F1W + (ti * 32 + i) * K1 + tj * 32 + j
+                     : sml_off_f2w(D) + (ti * 32 + i) * SML_HID + tj * 32 + j, s);
     }
     if (tj == 0 && tid < 32) {
         const float s = csum[0][tid] + csum[1][tid] + csum[2][tid] + csum[3][tid];
-        if (is_w1) g[sml_off_f1b(D) + ti * 32 + tid] = s;
-        else g[sml_off_f2b(D) + ti * 32 + tid] = s;
+        finish(is_w1 ? sml_off_f1b(D) + ti * 32 + tid : sml_off_f2b(D) + ti * 32 + tid, s);
     }
 }
 
@@ -520,20 +639,6 @@ __global__ __launch_bounds__(256) void k_transfer_wgrad(SmlWgArgs a) {
 // theta Adam (torch.optim.Adam with weight_decay added to the gradient,
 // model/transfer.py:393, 728) + refresh of the MFMA operand images
 // ------------------------------------------------------------------------------------
-template <int D>
-__device__ __forceinline__ void pack_store(float* __restrict__ pk, int off, float p) {
-    constexpr int K1 = SML_C2 * D;
-    if (off >= SML_OFF_F1W && off < sml_off_f1b(D)) {
-        const int n = (off - SML_OFF_F1W) / K1, k = (off - SML_OFF_F1W) % K1;
-        pk[sml_pk_p1(D) + pk_pos(K1 / 16, n, k)] = p;
-        pk[sml_pk_p1b(D) + pk_pos(SML_HID / 16, k, n)] = p;
-    } else if (off >= sml_off_f2w(D) && off < sml_off_f2b(D)) {
-        const int j = (off - sml_off_f2w(D)) / SML_HID, n = (off - sml_off_f2w(D)) % SML_HID;
-        pk[sml_pk_p2(D) + pk_pos(SML_HID / 16, j, n)] = p;
-        pk[sml_pk_p2b(D) + pk_pos(D / 16, n, j)] = p;
-    }
-}
-
 template <int D>
 __global__ __launch_bounds__(256) void k_theta_pack(const float* __restrict__ theta, float* __restrict__ pk) {
     constexpr int NS = sml_net_size(D);
@@ -619,7 +724,8 @@ hipError_t sml_launch_bwd(int d, int mt, const SmlBwdArgs& a, int tiles_total, h
 }
 hipError_t sml_launch_wgrad(int d, const SmlWgArgs& a, hipStream_t st) {
     const int tn = 16 * (SML_C2 * d / 32) + (d / 32) * 16;
-    SML_DISPATCH_D(d, k_transfer_wgrad<DD><<<dim3(2 * tn), dim3(256), 0, st>>>(a));
+    const int extra = a.theta != nullptr ? 2 : 0;        // fused Adam: + one conv-parameter workgroup per net
+    SML_DISPATCH_D(d, k_transfer_wgrad<DD><<<dim3(2 * tn + extra), dim3(256), 0, st>>>(a));
     return hipGetLastError();
 }
 hipError_t sml_launch_theta_adam(int d, const SmlThetaAdamArgs& a, hipStream_t st) {
