@@ -206,67 +206,119 @@ template <int D, typename T, int OPT>
 __global__ __launch_bounds__(256) void k_seg_update(SmlSegUpdArgs a) {
     constexpr int VEC = RowVec<T>::VEC;
     constexpr int LPR = D / VEC;
+    constexpr int G = 64 / LPR;             // lane groups (sorted positions) per wavefront
+    constexpr int LONG = 8;                 // runs longer than this are summed by the whole wavefront
     __shared__ SmlSched swin[OPT == 1 ? SML_SW : 1];
     if (OPT == 1) {                       // the Adam schedule of the last SML_SW steps, staged once per block
         sched_window_load(swin, a.sched, a.cur_step, threadIdx.x);
         __syncthreads();
     }
     const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / LPR, sub = lane % LPR;
     int pos = gid / LPR;
-    const int sub = gid % LPR;
-    const uint64_t* keys; const uint32_t* vals; int n;
-    const float* dx = a.dx;
-    T* w; float* mt; float* vt; int32_t* last;
-    if (pos < a.n_u) {
-        keys = a.key_u; vals = a.val_u; n = a.n_u;
-        w = reinterpret_cast<T*>(a.w_user); mt = a.m_user; vt = a.v_user; last = a.last_user;
-    } else {
-        pos -= a.n_u;
-        if (pos >= a.n_i) return;
-        keys = a.key_i; vals = a.val_i; n = a.n_i; dx = a.dx_i;
-        w = reinterpret_cast<T*>(a.w_item); mt = a.m_item; vt = a.v_item; last = a.last_item;
+    // which table this position belongs to (a wavefront may straddle the user/item boundary)
+    int is_item = 0, n = a.n_u;
+    if (pos >= a.n_u) { pos -= a.n_u; is_item = 1; n = a.n_i; }
+    const bool valid = pos < n;
+    const uint64_t* keys = is_item ? a.key_i : a.key_u;
+    uint64_t key = 0;
+    bool head = false;
+    int len = 0;
+    if (valid) {
+        key = keys[pos];
+        // the neighbourhood in one batch of independent loads: most runs are 1-8 long
+        uint64_t nb[LONG + 1];
+        nb[0] = pos > 0 ? keys[pos - 1] : ~key;
+#pragma unroll
+        for (int j = 1; j <= LONG; ++j) nb[j] = pos + j < n ? keys[pos + j] : ~key;
+        head = nb[0] != key;
+        if (head) {
+            len = 1;
+#pragma unroll
+            for (int j = 1; j <= LONG; ++j) len += (len == j && nb[j] == key) ? 1 : 0;
+            if (len > LONG) {   // a hot row: upper bound of `key` in (pos+LONG, n) by bisection
+                int lo = pos + LONG + 1, hi2 = n;
+                while (lo < hi2) {
+                    const int mid = (lo + hi2) >> 1;
+                    if (keys[mid] == key) lo = mid + 1; else hi2 = mid;
+                }
+                len = lo - pos;
+            }
+        }
     }
-    const uint64_t key = keys[pos];
-    if (pos > 0 && keys[pos - 1] == key) return;
     float g[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) g[k] = 0.0f;
-    // run length first, then the rows: 8 independent loads in flight, summed in order (deterministic)
-    int len;
-    {   // upper bound of `key` in the sorted run [pos, n): ~log2(n) dependent loads, not one per duplicate
-        int lo = pos + 1, hi2 = n;
-        while (lo < hi2) {
-            const int mid = (lo + hi2) >> 1;
-            if (keys[mid] == key) lo = mid + 1; else hi2 = mid;
-        }
-        len = lo - pos;
-    }
-    for (int q0 = 0; q0 < len; q0 += 8) {
-        float x[8][VEC];
+    // ---- short runs: the head's own lane group sums them, up to LONG rows in flight, in slot order
+    if (head && len <= LONG) {
+        const uint32_t* vals = is_item ? a.val_i : a.val_u;
+        const float* dx = is_item ? a.dx_i : a.dx;
+        float x[LONG][VEC];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (q0 + j < len) {
-                const float* src = dx + (int64_t)vals[pos + q0 + j] * D + sub * VEC;
+        for (int j = 0; j < LONG; ++j)
+            if (j < len) {
+                const float* src = dx + (int64_t)vals[pos + j] * D + sub * VEC;
 #pragma unroll
                 for (int h = 0; h < VEC / 4; ++h) RowVec<float>::load(src + h * 4, reinterpret_cast<float(&)[4]>(x[j][h * 4]));
             }
-        }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (q0 + j < len) {
+        for (int j = 0; j < LONG; ++j)
+            if (j < len) {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) g[k] += x[j][k];
             }
+    }
+    // ---- long runs (hot rows): the wavefront's G lane groups each sum a strided share, then the
+    // shares are added across groups in a fixed xor order (deterministic)
+    unsigned long long todo = __ballot(head && len > LONG && sub == 0);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int l_pos = __shfl(pos, leader, 64), l_len = __shfl(len, leader, 64), l_item = __shfl(is_item, leader, 64);
+        const uint32_t* vals = l_item ? a.val_i : a.val_u;
+        const float* dx = l_item ? a.dx_i : a.dx;
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+        for (int q0 = grp; q0 < l_len; q0 += 4 * G) {
+            float x[4][VEC];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (q0 + j * G < l_len) {
+                    const float* src = dx + (int64_t)vals[l_pos + q0 + j * G] * D + sub * VEC;
+#pragma unroll
+                    for (int h = 0; h < VEC / 4; ++h) RowVec<float>::load(src + h * 4, reinterpret_cast<float(&)[4]>(x[j][h * 4]));
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (q0 + j * G < l_len) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] += x[j][k];
+                }
+        }
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] += __shfl_xor(acc[k], off, 64);
+        if (lane / LPR == leader / LPR) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) g[k] = acc[k];
         }
     }
+    if (!head) return;
+    T* w = reinterpret_cast<T*>(is_item ? a.w_item : a.w_user);
     const int64_t row = (uint32_t)key;
     float p[VEC];
     RowVec<T>::load(w + row * D + sub * VEC, p);
-    if (OPT == 0) {
+    if constexpr (OPT == 0) {
 #pragma unroll
         for (int k = 0; k < VEC; ++k) p[k] -= a.lr * g[k];
         RowVec<T>::store(w + row * D + sub * VEC, p);
     } else {
+        float* mt = is_item ? a.m_item : a.m_user;
+        float* vt = is_item ? a.v_item : a.v_user;
+        int32_t* last = is_item ? a.last_item : a.last_user;
         float m[4], v[4];
         RowVec<float>::load(mt + row * D + sub * 4, m);
         RowVec<float>::load(vt + row * D + sub * 4, v);
