@@ -45,7 +45,56 @@ def parse():
     ap.add_argument("--no-val", action="store_true", help="skip the validation evaluations (not the reference default)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--workload", default="yelp_period", choices=["yelp_period", "bare"],
+                    help="yelp_period: the headline SML retrain period (default).  bare: the a3 fused embed+loss+SGD "
+                         "step alone on large synthetic tables (HBM roofline study; not the headline metric)")
+    ap.add_argument("--bare-batch", type=int, default=65536)
+    ap.add_argument("--bare-triples", type=int, default=1 << 22)
+    ap.add_argument("--bare-dtype", default="f32", choices=["f32", "f16"])
+    ap.add_argument("--item-zipf", type=float, default=1.0)
     return ap.parse_args()
+
+
+def bench_bare(a, device):
+    """a3 alone: synchronous minibatch SGD on (user, pos, neg) triples over large tables."""
+    from sml_amd import synth
+    from sml_amd.engine import HipEngine
+    eng = HipEngine(device, a.d, a.bare_batch)
+    dt = torch.float32 if a.bare_dtype == "f32" else torch.float16
+    g = torch.Generator(device=device).manual_seed(4)
+    wu = (torch.randn(a.users, a.d, device=device, generator=g) * 0.1).to(dt)
+    wi = (torch.randn(a.items, a.d, device=device, generator=g) * 0.1).to(dt)
+    rng = np.random.RandomState(4)
+    u, i, j = synth.synth_triples(rng, a.bare_triples, a.users, a.items, a_user=0.0, a_item=a.item_zipf)
+    tri = torch.from_numpy(np.stack([u, i, j], 1)).to(device)
+    for _ in range(a.warmup):
+        eng.bare_epoch(wu, wi, tri, a.bare_batch, 0.05, 1e-6, 1e-6, bce=True)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        eng.bare_epoch(wu, wi, tri, a.bare_batch, 0.05, 1e-6, 1e-6, bce=True)
+    torch.cuda.synchronize(device)
+    dtm = time.perf_counter() - t0
+    eng.profile(True)
+    eng.bare_epoch(wu, wi, tri, a.bare_batch, 0.05, 1e-6, 1e-6, bce=True)
+    torch.cuda.synchronize(device)
+    prof = eng.profile_read()
+    eng.profile(False)
+    s = wu.element_size()
+    a_sgd = 24 + 6 * a.d * s                       # int64 (u,i,j) + 3 rows read + 3 rows written
+    n = a.bare_triples
+    t_grad, t_seg = prof["k_bare_grad"][1] / 1e3, prof["k_seg_update_sgd"][1] / 1e3
+    ach = n * a_sgd / (t_grad + t_seg) / 1e9
+    out = {"metric": "bare embed+loss+SGD step triples/s (a3), synthetic uniform users / Zipf(%g) items, d=%d %s" % (a.item_zipf, a.d, a.bare_dtype),
+           "value": a.steps * n / dtm, "unit": "triples/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": 1000.0 * dtm / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": a.bare_dtype, "data": "synthetic",
+           "config": {"workload": "bare: users=%d items=%d triples/epoch=%d batch=%d" % (a.users, a.items, n, a.bare_batch)},
+           "roofline": {"kernel": "k_bare_grad + k_seg_update_sgd (one a3 step)", "bound": "hbm", "achieved": ach,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                        "algorithmic_bytes_per_triple": a_sgd},
+           "kernels": {k: {"launches": c, "total_ms": round(m, 3), "avg_us": round(1000.0 * m / c, 2)} for k, (c, m) in prof.items()}}
+    print(json.dumps(out))
 
 
 def build_state(engine, U, I, d, device, seed):
@@ -93,6 +142,19 @@ def kernel_work(name, a, hp, U_local):
     if name == "k_adam_flush":
         return "hbm", hp.multi_num * hp.MF_epochs * (U_local + a.items) * (d * 4 * 6 + 8), 2 * hp.multi_num * hp.MF_epochs
     return None, 0.0, 0
+
+
+def pmc_traffic(kernel):
+    """Fabric bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
+    (profiles/r01_final_pmc_fetch_write_per_launch.json: FETCH_SIZE and WRITE_SIZE in separate passes;
+    units KB; FETCH doubled per the gfx950 correction in MI355X_MICROARCH.md).  PMC cannot be read from
+    inside the process, so this is null whenever no committed summary covers the kernel."""
+    path = os.path.join(REPO, "profiles", "r01_final_pmc_fetch_write_per_launch.json")
+    try:
+        d = json.load(open(path)).get(kernel)
+        return (2.0 * d["FETCH_SIZE"]["avg_counter_per_launch"] + d["WRITE_SIZE"]["avg_counter_per_launch"]) * 1024.0
+    except Exception:
+        return None
 
 
 def cpu_baseline(a, hp):
@@ -149,6 +211,8 @@ def main():
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    if a.workload == "bare":
+        return bench_bare(a, device)
     from sml_amd.engine import HipEngine
     from sml_amd.period import Hyper, run_period, synth_plan
     hp = Hyper(multi_num=a.multi_num)
@@ -217,7 +281,7 @@ def main():
                 else:
                     ach, peak, unit = per_launch / avg_s / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
                 out["roofline"] = {"kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
-                                   "frac": ach / peak, "traffic": None, "launches": cnt,
+                                   "frac": ach / peak, "traffic": pmc_traffic(name), "launches": cnt,
                                    "avg_launch_us": 1e6 * avg_s, "algorithmic_per_launch": per_launch}
             out["kernels"] = kern
     if rank == 0 and world == 1 and not a.no_cpu:

@@ -440,19 +440,25 @@ __global__ __launch_bounds__(256) void k_eval_ranks(const float* __restrict__ wu
     if (lane == 0) rank[r] = tot;
 }
 
-// hits and NDCG sum over ranks (model/MF.py:60-78): hit iff rank < topk, NDCG = 1/log2(rank+2)
-__global__ __launch_bounds__(256) void k_eval_metrics(const int32_t* __restrict__ rank, int64_t n, int topk,
-                                                      float* __restrict__ out) {
-    __shared__ float sh4[4];
+// hits and NDCG sum over ranks (model/MF.py:60-78): hit iff rank < topk, NDCG = 1/log2(rank+2).
+// One 1024-thread block; fixed reduction tree (deterministic).
+__global__ __launch_bounds__(1024) void k_eval_metrics(const int32_t* __restrict__ rank, int64_t n, int topk,
+                                                       float* __restrict__ out) {
+    __shared__ float sh[2][16];
     float hits = 0.f, nd = 0.f;
-    for (int64_t i = threadIdx.x; i < n; i += 256) {
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
         const int rk = rank[i];
         if (rk < topk) { hits += 1.0f; nd += 1.0f / log2f((float)rk + 2.0f); }
     }
-    const float h = block_sum256(hits, sh4);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { hits += __shfl_xor(hits, off, 64); nd += __shfl_xor(nd, off, 64); }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = hits; sh[1][threadIdx.x >> 6] = nd; }
     __syncthreads();
-    const float d = block_sum256(nd, sh4);
-    if (threadIdx.x == 0) { out[0] = h; out[1] = d; }
+    if (threadIdx.x == 0) {
+        float h = 0.f, d = 0.f;
+        for (int w = 0; w < 16; ++w) { h += sh[0][w]; d += sh[1][w]; }
+        out[0] = h; out[1] = d;
+    }
 }
 
 }  // namespace
@@ -530,6 +536,6 @@ hipError_t sml_launch_eval_ranks(int d, const float* wu, const float* wi, const 
     return hipGetLastError();
 }
 hipError_t sml_launch_eval_metrics(const int32_t* rank, int64_t n, int topk, float* out, hipStream_t st) {
-    k_eval_metrics<<<dim3(1), dim3(256), 0, st>>>(rank, n, topk, out);
+    k_eval_metrics<<<dim3(1), dim3(1024), 0, st>>>(rank, n, topk, out);
     return hipGetLastError();
 }
