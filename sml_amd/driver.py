@@ -128,9 +128,30 @@ class meta_train(object):
             self._rows_cache[key] = hit
         return hit[1]
 
+    def _touch_tables(self):
+        """The MF tables changed: cached validation ranks are stale."""
+        self._version = getattr(self, "_version", 0) + 1
+
+    def _ranks(self, rows):
+        """Rank of every row's positive under the current tables; reused while the tables are unchanged
+        (the reference re-evaluates identical tables several times per phase, and @20/@10/@5 share ranks)."""
+        key = (id(rows), getattr(self, "_version", 0))
+        hit = getattr(self, "_rank_cache", None)
+        if hit is None or hit[0] != key:
+            ranks = self.engine.eval_ranks(self.MFbase.user_laten.weight.data, self.MFbase.item_laten.weight.data,
+                                           rows.rows)
+            self._rank_cache = hit = (key, ranks)
+        return hit[1]
+
+    def _metrics(self, ranks, n, topK):
+        hits, ndcg = self.engine.eval_metrics(ranks, topK)
+        return hits / n, torch.tensor(np.float32(ndcg / n))
+
     def _test(self, rows, topK):
+        """recall@K, ndcg@K of the current tables on `rows` (reference evalution/evaluation2.py:8-26)."""
         t0 = time.time()
-        out = test_model(self.MFbase, rows, topK=topK)
+        D.loader_base_seed_draw()          # the draw the reference's DataLoader iteration makes
+        out = self._metrics(self._ranks(rows), rows.rows.shape[0], topK)
         self.timing["eval"] += time.time() - t0
         return out
 
@@ -159,6 +180,7 @@ class meta_train(object):
                                                 self.last_item_weight, triples, args.MF_batch_size,
                                                 args.MF_lr, args.l2, norm=args.norm, bce=True)
             self.engine.mf_flush(self.MFbase)
+            self._touch_tables()
             losses = _np(losses)
             self.timing["mf"] += time.time() - t0
             self.timing["mf_triples"] += triples.shape[0]
@@ -206,22 +228,41 @@ class meta_train(object):
             compute_performance = True
         else:
             raise TypeError("no such TR sample type")
-        if compute_performance:
-            recall, ndcg = self._test(now_test, args.topK)
+        def report_before(recall, ndcg):
             print("before train transfer test:recall:{:.4f} ndcg:{:.4f}".format(recall, ndcg))
             if self.writer is not None:
                 self.writer.add_scalar("Acc/tr-TR-recall@" + str(args.topK), recall, self.TR_itr)
                 self.writer.add_scalar("Acc/tr-TR-ndcg@" + str(args.topK), float(ndcg), self.TR_itr)
                 self.TR_itr += 1
+
+        pending = None
+        if compute_performance:
+            # this evaluation only READS the MF tables and the TR epoch never writes them: queue it on the
+            # engine's side stream, let it run underneath the first TR epoch, print it in its place
+            cached = getattr(self, "_rank_cache", None)
+            fresh = cached is not None and cached[0] == (id(now_test), getattr(self, "_version", 0))
+            if hasattr(self.engine, "eval_async") and args.TR_epochs > 0 and not fresh:
+                D.loader_base_seed_draw()
+                pending = self.engine.eval_async(self.MFbase.user_laten.weight.data,
+                                                 self.MFbase.item_laten.weight.data, now_test.rows, args.topK)
+            else:
+                report_before(*self._test(now_test, args.topK))
         s_time = time.time()
         for epoch in range(args.TR_epochs):
             self.transfer.train()
             order = D.loader_order(len(train_set), shuffle=True)
             triples = train_set.epoch_triples(order)
             t0 = time.time()
-            losses = _np(self.engine.tr_stage_epoch(self.transfer, self.last_user_weight, self.last_item_weight,
-                                                    self.user_weight_hat, self.item_weight_hat, triples,
-                                                    args.TR_batch_size, args.TR_lr, args.TR_l2, bce=True))
+            losses = self.engine.tr_stage_epoch(self.transfer, self.last_user_weight, self.last_item_weight,
+                                                self.user_weight_hat, self.item_weight_hat, triples,
+                                                args.TR_batch_size, args.TR_lr, args.TR_l2, bce=True)
+            if pending is not None:
+                hits, ndcg = self.engine.eval_result(pending)
+                self._rank_cache = ((id(now_test), getattr(self, "_version", 0)), pending[2])
+                pending = None
+                n_rows = now_test.rows.shape[0]
+                report_before(hits / n_rows, torch.tensor(np.float32(ndcg / n_rows)))
+            losses = _np(losses)
             self.timing["tr"] += time.time() - t0
             self.timing["tr_triples"] += triples.shape[0]
             loss_all = np.float32(0)
@@ -306,6 +347,7 @@ class meta_train(object):
         t0 = time.time()
         self.engine.updata(self.transfer, self.last_user_weight, self.user_weight_hat, self.last_item_weight,
                            self.item_weight_hat, self.MFbase.user_laten.weight.data, self.MFbase.item_laten.weight.data)
+        self._touch_tables()
         self.timing["updata"] += time.time() - t0
 
     def save_MF_weight(self, save_as="last"):
@@ -327,6 +369,7 @@ class meta_train(object):
         the reference (model/transfer.py:945-959, note at :764)."""
         self.MFbase.user_laten.weight.data.copy_(user_weight)
         self.MFbase.item_laten.weight.data.copy_(item_weight)
+        self._touch_tables()
 
     # ------------------------------------------------------------------ the sequence
     def run(self, args):

@@ -266,6 +266,31 @@ class HipEngine(object):
               "sml_eval_ranks")
         return rank
 
+    def eval_async(self, user_tab, item_tab, rows, topk):
+        """Queue ranks + metrics on the engine's side stream (ordered after everything already queued on the
+        current stream) and return a handle; `eval_result(handle)` waits for it.  Lets an evaluation that
+        only READS the tables run underneath kernels that do not write them (e.g. the TR epoch)."""
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            ranks = self.eval_ranks(user_tab, item_tab, rows)
+            out = torch.empty(2, device=self.device, dtype=torch.float32)
+            check(self.lib.sml_eval_metrics(self._ctx, _ptr(ranks), ranks.shape[0], int(topk), _ptr(out),
+                                            self._stream()), "sml_eval_metrics")
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        for t in (user_tab, item_tab, rows):
+            t.record_stream(self._side)
+        return (out, ev, ranks)
+
+    def eval_result(self, handle):
+        out, ev, _ = handle
+        ev.synchronize()
+        h = out.cpu()
+        return float(h[0]), float(h[1])
+
     def eval_metrics(self, ranks, topk):
         out = torch.empty(2, device=self.device, dtype=torch.float32)
         check(self.lib.sml_eval_metrics(self._ctx, _ptr(ranks), ranks.shape[0], int(topk), _ptr(out), self._stream()),

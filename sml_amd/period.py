@@ -91,22 +91,38 @@ def synth_plan(seed, n_inter, n_user, n_item, neg, hp, device, user_lo=0, user_h
     return PeriodPlan(val_rows, mf, tr)
 
 
-def run_period(engine, st, plan, hp, record=None):
-    """Execute one period.  Returns (last MF batch losses, last TR batch losses) device tensors."""
+def run_period(engine, st, plan, hp, record=None, overlap=True):
+    """Execute one period.  Returns (last MF batch losses, last TR batch losses) device tensors.
+
+    Validation scheduling (results identical to evaluating in place):
+      * an evaluation of tables that were not modified since the previous evaluation of the same rows
+        returns the previous result (the reference's "before train MF" numbers always repeat the
+        preceding "val result" line);
+      * the "before train transfer" evaluation only reads W, which the TR epoch never writes, so it is
+        queued on a side stream and runs underneath the TR epoch."""
     mf, net = st.MFbase, st.transfer
     wu, wi = mf.user_laten.weight.data, mf.item_laten.weight.data
+    state = {"version": 0, "cached": None}
 
-    def evaluate(tag):
-        if plan.val_rows is None:
-            return
-        ranks = engine.eval_ranks(wu, wi, plan.val_rows)
-        hits, ndcg = engine.eval_metrics(ranks, hp.topK)
+    def note(tag, hits, ndcg):
         if record is not None:
             n = plan.val_rows.shape[0]
             record.append((tag, hits / n, ndcg / n))
 
+    def evaluate(tag):
+        if plan.val_rows is None:
+            return
+        if state["cached"] is not None and state["cached"][0] == state["version"]:
+            note(tag, *state["cached"][1])
+            return
+        ranks = engine.eval_ranks(wu, wi, plan.val_rows)
+        res = engine.eval_metrics(ranks, hp.topK)
+        state["cached"] = (state["version"], res)
+        note(tag, *res)
+
     def updata():
         engine.updata(net, st.last_user, st.hat_user, st.last_item, st.hat_item, wu, wi)
+        state["version"] += 1
 
     # save_MF_weight('last')
     st.last_user.copy_(wu)
@@ -118,6 +134,7 @@ def run_period(engine, st, plan, hp, record=None):
             mf_loss = engine.mf_stage_epoch(mf, net, st.last_user, st.last_item, tri, hp.MF_batch_size,
                                             hp.MF_lr, hp.l2, norm=False, bce=True)
             engine.mf_flush(mf)
+            state["version"] += 1
             evaluate("MF epoch")
         # save_MF_weight('hat')
         st.prev_hat_user.copy_(st.hat_user)
@@ -125,10 +142,19 @@ def run_period(engine, st, plan, hp, record=None):
         st.hat_user.copy_(wu)
         st.hat_item.copy_(wi)
         updata()
-        evaluate("before TR")
+        pending = None
+        if plan.val_rows is not None and overlap and hasattr(engine, "eval_async") and plan.tr_triples[ph]:
+            pending = engine.eval_async(wu, wi, plan.val_rows, hp.topK)      # "before TR", under the first TR epoch
+        else:
+            evaluate("before TR")
         for tri in plan.tr_triples[ph]:
             tr_loss = engine.tr_stage_epoch(net, st.last_user, st.last_item, st.hat_user, st.hat_item, tri,
                                             hp.TR_batch_size, hp.TR_lr, hp.TR_l2, bce=True)
+            if pending is not None:
+                res = engine.eval_result(pending)
+                pending = None
+                state["cached"] = (state["version"], res)
+                note("before TR", *res)
             if plan.val_rows is not None:
                 updata()
                 evaluate("TR epoch")

@@ -428,3 +428,29 @@ def test_main_news_path_end_to_end(tmp_path, monkeypatch):
         assert all(0.0 <= r <= 1.0 for r in meta.recall)
     assert any(l.startswith("test average recall@20:") for l in logs[0])
     assert logs[0] == logs[1]
+
+
+def test_period_validation_overlap_and_cache_do_not_change_results():
+    """run_period with the side-stream / memoised validation schedule records exactly the
+    numbers of the plain in-place schedule, and leaves identical tables and theta."""
+    from sml_amd.period import Hyper, PeriodState, run_period, synth_plan
+    hp = Hyper(multi_num=2, MF_batch_size=256, TR_batch_size=64)
+    outs = []
+    for overlap in (False, True):
+        torch.manual_seed(3)
+        eng = engine(32, 256)
+        mf = make_mf(500, 400, 32, device=DEV)
+        with torch.no_grad():
+            mf.user_laten.weight.mul_(0.3); mf.item_laten.weight.mul_(0.3)
+        net = make_transfer(32, device=DEV)
+        st = PeriodState(mf, net)
+        plan = synth_plan(11, 1500, 500, 400, 49, hp, DEV)
+        rec = []
+        run_period(eng, st, plan, hp, record=rec, overlap=overlap)
+        torch.cuda.synchronize()
+        outs.append((rec, mf.user_laten.weight.detach().clone(), eng.adopt(net).clone()))
+    assert [r[0] for r in outs[0][0]] == [r[0] for r in outs[1][0]] and len(outs[0][0]) == 8
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    # the memoised "before MF" of phase 2 repeats phase 1's "TR epoch" line, as in the reference's log
+    assert outs[1][0][4][1:] == outs[1][0][3][1:]
