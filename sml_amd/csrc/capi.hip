@@ -107,6 +107,9 @@ struct sml_ctx {
     int sched_len = 0;
     float sched_lr = -1.0f;
     Buf<int32_t> dummy;
+    Buf<uint32_t> hot_list;
+    Buf<int> hot_count, hot_first;
+    Buf<float> hot_part;
     Prof prof;
 
     void release_all() {
@@ -116,6 +119,7 @@ struct sml_ctx {
         key_u.release(); key_u2.release(); key_i.release(); key_i2.release();
         val_u.release(); val_u2.release(); val_i.release(); val_i2.release();
         cub_tmp.release(); sched.release(); dummy.release();
+        hot_list.release(); hot_count.release(); hot_first.release(); hot_part.release();
     }
 };
 
@@ -471,6 +475,17 @@ int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n
     HIPCHK(ctx->loss_part.ensure((size_t)nb * lstride));
     ctx->prof.begin(PC_SORT, st); rc = sort_epoch(ctx, triples, n, batch, 0, st); ctx->prof.end(st); if (rc) return rc;
     HIPCHK(hipMemsetAsync(ctx->loss_part.p, 0, (size_t)nb * lstride * sizeof(float), st));
+    // hot rows: with large batches a popular item collects thousands of occurrences per batch
+    const int hot_cap = 3 * batch / SML_HOT + 8;
+    const bool hot = batch >= 4096 && hot_cap <= SML_HOT_MAXCAP;
+    const int hot_chunks = 3 * batch / SML_HOT_CHUNK + hot_cap;
+    if (hot) {
+        HIPCHK(ctx->hot_list.ensure((size_t)2 * hot_cap));
+        HIPCHK(ctx->hot_first.ensure((size_t)hot_cap));
+        HIPCHK(ctx->hot_count.ensure((size_t)nb));
+        HIPCHK(ctx->hot_part.ensure((size_t)hot_chunks * d));
+        HIPCHK(hipMemsetAsync(ctx->hot_count.p, 0, (size_t)nb * sizeof(int), st));
+    }
     for (int64_t b = 0; b < nb; ++b) {
         const int B = (int)((n - b * batch) < batch ? (n - b * batch) : batch);
         SmlBareArgs a;
@@ -482,7 +497,12 @@ int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n
         u.key_u = ctx->key_u2.p + b * batch; u.val_u = ctx->val_u2.p + b * batch; u.n_u = B;
         u.key_i = ctx->key_i2.p + 2 * b * batch; u.val_i = ctx->val_i2.p + 2 * b * batch; u.n_i = 2 * B;
         u.dx = ctx->dx.p; u.dx_i = ctx->dx.p; u.w_user = w_user; u.w_item = w_item; u.lr = lr;
+        if (hot) {
+            u.hot_list = ctx->hot_list.p; u.hot_count = ctx->hot_count.p + b; u.hot_first = ctx->hot_first.p;
+            u.hot_part = ctx->hot_part.p; u.hot_cap = hot_cap;
+        }
         ctx->prof.begin(PC_SEG_SGD, st); HIPCHK(sml_launch_seg_sgd(d, dtype_bytes, u, st)); ctx->prof.end(st);
+        if (hot) { ctx->prof.begin(PC_SEG_SGD, st); HIPCHK(sml_launch_hot_rows(d, dtype_bytes, u, hot_chunks, st)); ctx->prof.end(st); }
     }
     ctx->prof.begin(PC_MISC, st); HIPCHK(sml_launch_loss_finalize(ctx->loss_part.p, (int)nb, lstride, nullptr, batch_loss, st)); ctx->prof.end(st);
     return SML_OK;

@@ -117,12 +117,16 @@ __global__ __launch_bounds__(256) void k_pair_loss(SmlLossArgs a) {
     if (threadIdx.x == 0) a.loss_part[blockIdx.x] = tot;
 }
 
-__global__ void k_loss_finalize(const float* __restrict__ part, int n_batches, int stride, float* __restrict__ out) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// one wavefront per batch: lanes stride over the batch's partials, fixed-order tree (deterministic)
+__global__ __launch_bounds__(64) void k_loss_finalize(const float* __restrict__ part, int n_batches, int stride,
+                                                     float* __restrict__ out) {
+    const int b = blockIdx.x;
     if (b >= n_batches) return;
     float s = 0.0f;
-    for (int i = 0; i < stride; ++i) s += part[(int64_t)b * stride + i];
-    out[b] = s;
+    for (int i = threadIdx.x; i < stride; i += 64) s += part[(int64_t)b * stride + i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (threadIdx.x == 0) out[b] = s;
 }
 
 // ------------------------------------------------------------------------------------
@@ -247,6 +251,17 @@ __global__ __launch_bounds__(256) void k_seg_update(SmlSegUpdArgs a) {
             }
         }
     }
+    if (OPT == 0 && a.hot_list != nullptr && head && len > SML_HOT) {
+        // a hot row: hand the run to the workgroup-level reducers (k_hot_partial / k_hot_apply)
+        if (sub == 0) {
+            const int slot = atomicAdd(a.hot_count, 1);
+            if (slot < a.hot_cap) {
+                a.hot_list[2 * slot] = (uint32_t)pos | ((uint32_t)is_item << 31);
+                a.hot_list[2 * slot + 1] = (uint32_t)len;
+            }
+        }
+        head = false;
+    }
     float g[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) g[k] = 0.0f;
@@ -334,6 +349,116 @@ __global__ __launch_bounds__(256) void k_seg_update(SmlSegUpdArgs a) {
         RowVec<float>::store(vt + row * D + sub * 4, v);
         if (sub == 0) last[row] = a.cur_step;
     }
+}
+
+// ------------------------------------------------------------------------------------
+// hot rows: chunk partial sums.  One workgroup per (hot run, chunk of SML_HOT_CHUNK occurrences);
+// the flattened chunk index -> (run, chunk) map is a prefix sum over the hot list, recomputed per
+// workgroup in LDS (the list has at most a few thousand entries).  Fixed summation order.
+// ------------------------------------------------------------------------------------
+template <int D, typename T>
+__global__ __launch_bounds__(256) void k_hot_partial(SmlSegUpdArgs a) {
+    constexpr int VEC = 4;
+    constexpr int LPR = D / VEC;
+    constexpr int GB = 256 / LPR;            // lane groups per workgroup
+    __shared__ int pre[SML_HOT_MAXCAP + 1];
+    __shared__ int tsum[257];
+    __shared__ __attribute__((aligned(16))) float rows[GB][D];
+    const int tid = threadIdx.x;
+    const int nh = min(*a.hot_count, a.hot_cap);
+    if (nh == 0) return;
+    // exclusive prefix of chunk counts: each thread owns a contiguous slice, then a serial pass over 256 sums
+    const int per = (nh + 255) / 256;
+    int local = 0;
+    for (int e = tid * per; e < min(nh, (tid + 1) * per); ++e)
+        local += ((int)a.hot_list[2 * e + 1] + SML_HOT_CHUNK - 1) / SML_HOT_CHUNK;
+    tsum[tid + 1] = local;
+    __syncthreads();
+    if (tid == 0) { tsum[0] = 0; for (int i = 1; i <= 256; ++i) tsum[i] += tsum[i - 1]; }
+    __syncthreads();
+    {
+        int run = tsum[tid];
+        for (int e = tid * per; e < min(nh, (tid + 1) * per); ++e) {
+            pre[e] = run;
+            run += ((int)a.hot_list[2 * e + 1] + SML_HOT_CHUNK - 1) / SML_HOT_CHUNK;
+        }
+        if (tid == 255) pre[nh] = tsum[256];
+    }
+    __syncthreads();
+    const int w = blockIdx.x;
+    if (w >= pre[nh]) return;
+    int lo = 0, hi2 = nh - 1;                 // largest h with pre[h] <= w
+    while (lo < hi2) { const int mid = (lo + hi2 + 1) >> 1; if (pre[mid] <= w) lo = mid; else hi2 = mid - 1; }
+    const int h = lo, c = w - pre[h];
+    if (c == 0 && tid == 0) a.hot_first[h] = w;
+    const uint32_t packed = a.hot_list[2 * h];
+    const int is_item = packed >> 31, pos0 = (int)(packed & 0x7fffffffu), len = (int)a.hot_list[2 * h + 1];
+    const uint32_t* vals = is_item ? a.val_i : a.val_u;
+    const float* dx = is_item ? a.dx_i : a.dx;
+    const int q_begin = c * SML_HOT_CHUNK, q_end = min(len, q_begin + SML_HOT_CHUNK);
+    const int grp = tid / LPR, sub = tid % LPR;
+    float acc[VEC] = {0.f, 0.f, 0.f, 0.f};
+    for (int q0 = q_begin + grp; q0 < q_end; q0 += 8 * GB) {
+        float x[8][VEC];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (q0 + j * GB < q_end) RowVec<float>::load(dx + (int64_t)vals[pos0 + q0 + j * GB] * D + sub * VEC, x[j]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (q0 + j * GB < q_end) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] += x[j][k];
+            }
+    }
+    RowVec<float>::store(&rows[grp][sub * VEC], acc);
+    __syncthreads();
+    if (tid < D) {
+        float s2 = 0.0f;
+#pragma unroll 8
+        for (int g2 = 0; g2 < GB; ++g2) s2 += rows[g2][tid];
+        a.hot_part[(int64_t)w * D + tid] = s2;
+    }
+}
+
+// hot rows: sum each run's chunk partials in order and take the SGD step
+template <int D, typename T>
+__global__ __launch_bounds__(256) void k_hot_apply(SmlSegUpdArgs a) {
+    constexpr int VEC = RowVec<T>::VEC;
+    constexpr int LPR = D / VEC;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int h = gid / LPR, sub = gid % LPR;
+    const int nh = min(*a.hot_count, a.hot_cap);
+    if (h >= nh) return;
+    const uint32_t packed = a.hot_list[2 * h];
+    const int is_item = packed >> 31, pos0 = (int)(packed & 0x7fffffffu), len = (int)a.hot_list[2 * h + 1];
+    const int first = a.hot_first[h], nchunks = (len + SML_HOT_CHUNK - 1) / SML_HOT_CHUNK;
+    float g[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) g[k] = 0.0f;
+    for (int c0 = 0; c0 < nchunks; c0 += 8) {
+        float x[8][VEC];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (c0 + j < nchunks) {
+                const float* src = a.hot_part + (int64_t)(first + c0 + j) * D + sub * VEC;
+#pragma unroll
+                for (int hh = 0; hh < VEC / 4; ++hh) RowVec<float>::load(src + hh * 4, reinterpret_cast<float(&)[4]>(x[j][hh * 4]));
+            }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (c0 + j < nchunks) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) g[k] += x[j][k];
+            }
+    }
+    const uint64_t* keys = is_item ? a.key_i : a.key_u;
+    const int64_t row = (uint32_t)keys[pos0];
+    T* w = reinterpret_cast<T*>(is_item ? a.w_item : a.w_user);
+    float p[VEC];
+    RowVec<T>::load(w + row * D + sub * VEC, p);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) p[k] -= a.lr * g[k];
+    RowVec<T>::store(w + row * D + sub * VEC, p);
 }
 
 // bring every row up to `cur_step` (all pending steps have zero gradient)
@@ -480,7 +605,7 @@ hipError_t sml_launch_pair_loss(int d, const SmlLossArgs& a, int* n_blocks, hipS
     return hipGetLastError();
 }
 hipError_t sml_launch_loss_finalize(const float* part, int n_batches, int stride, const int*, float* out, hipStream_t st) {
-    k_loss_finalize<<<dim3((n_batches + 63) / 64), dim3(64), 0, st>>>(part, n_batches, stride, out);
+    k_loss_finalize<<<dim3(n_batches), dim3(64), 0, st>>>(part, n_batches, stride, out);
     return hipGetLastError();
 }
 hipError_t sml_launch_bare_grad(int d, int dtype_bytes, const SmlBareArgs& a, int* n_blocks, hipStream_t st) {
@@ -512,6 +637,18 @@ hipError_t sml_launch_seg_sgd(int d, int dtype_bytes, const SmlSegUpdArgs& a, hi
         SML_DISPATCH_D(d, k_seg_update<DD, float, 0><<<dim3(nb), dim3(256), 0, st>>>(a));
     } else if (dtype_bytes == 2) {
         SML_DISPATCH_D(d, k_seg_update<DD, __half, 0><<<dim3(nb), dim3(256), 0, st>>>(a));
+    } else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+hipError_t sml_launch_hot_rows(int d, int dtype_bytes, const SmlSegUpdArgs& a, int max_chunks, hipStream_t st) {
+    const int lpr = d * dtype_bytes / 16;
+    const int nb_apply = (a.hot_cap * lpr + 255) / 256;
+    if (dtype_bytes == 4) {
+        SML_DISPATCH_D(d, k_hot_partial<DD, float><<<dim3(max_chunks), dim3(256), 0, st>>>(a));
+        SML_DISPATCH_D(d, k_hot_apply<DD, float><<<dim3(nb_apply), dim3(256), 0, st>>>(a));
+    } else if (dtype_bytes == 2) {
+        SML_DISPATCH_D(d, k_hot_partial<DD, __half><<<dim3(max_chunks), dim3(256), 0, st>>>(a));
+        SML_DISPATCH_D(d, k_hot_apply<DD, __half><<<dim3(nb_apply), dim3(256), 0, st>>>(a));
     } else return hipErrorInvalidValue;
     return hipGetLastError();
 }

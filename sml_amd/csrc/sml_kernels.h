@@ -107,7 +107,18 @@ struct SmlSegUpdArgs {
     int32_t* last_user; int32_t* last_item;                       // Adam only
     const SmlSched* sched; int cur_step;                          // Adam only
     float lr;                                                     // SGD only
+    // hot rows (SGD, large batches): runs longer than SML_HOT are appended here instead of being summed by
+    // one wavefront; k_hot_partial / k_hot_apply reduce them with whole workgroups.  null: off.
+    uint32_t* hot_list;      // [hot_cap][2]: (pos | is_item << 31), len
+    int* hot_count;          // this batch's counter (zeroed by the caller)
+    int* hot_first;          // [hot_cap] first chunk index of each hot run
+    float* hot_part;         // [hot_chunks][d] chunk partial sums
+    int hot_cap;
 };
+#define SML_HOT 512          // runs longer than this take the hot path
+#define SML_HOT_CHUNK 1024   // occurrences per workgroup in k_hot_partial
+#define SML_HOT_MAXCAP 8192
+hipError_t sml_launch_hot_rows(int d, int dtype_bytes, const SmlSegUpdArgs& a, int max_chunks, hipStream_t st);
 hipError_t sml_launch_seg_adam(int d, const SmlSegUpdArgs& a, hipStream_t st);
 hipError_t sml_launch_seg_sgd(int d, int dtype_bytes, const SmlSegUpdArgs& a, hipStream_t st);
 hipError_t sml_launch_adam_flush(int d, float* w, float* m, float* v, int32_t* last, int64_t rows,

@@ -454,3 +454,35 @@ def test_period_validation_overlap_and_cache_do_not_change_results():
     assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
     # the memoised "before MF" of phase 2 repeats phase 1's "TR epoch" line, as in the reference's log
     assert outs[1][0][4][1:] == outs[1][0][3][1:]
+
+
+def test_bare_step_hot_rows_vs_oracle():
+    """Large batch with Zipf-style hot rows: an item with ~3,000 occurrences (as positive and as
+    negative) and a user with ~700 in one 8,192-triple batch go through the hot-row path
+    (hot list -> chunk partials -> apply) and must still equal synchronous minibatch SGD."""
+    torch.manual_seed(21)
+    U, I, d, B = 5000, 3000, 32, 8192
+    n = 2 * B + 1000                                        # two full batches + a ragged one
+    wu, wi = torch.randn(U, d) * 0.3, torch.randn(I, d) * 0.3
+    u = torch.randint(0, U, (n,)); i = torch.randint(0, I, (n,)); j = torch.randint(0, I, (n,))
+    i[0:B:3] = 7            # ~2,700 positives on item 7 in batch 0
+    j[1:B:25] = 7           # ... and ~330 negatives
+    u[2:B:12] = 11          # ~680 occurrences of user 11
+    i[B:2 * B:2] = 9        # 4,096 in batch 1: spans several 1,024-occurrence chunks
+    tri = torch.stack([u, i, j], 1)
+    gu, gi = wu.clone().to(DEV), wi.clone().to(DEV)
+    eng = engine(d, B)
+    losses = eng.bare_epoch(gu, gi, tri, B, 0.05, 1e-4, 1e-4, bce=True).cpu().numpy()
+    ou, oi = wu.clone(), wi.clone()
+    want = [O.bare_step(ou, oi, tri[b0:b0 + B, 0], tri[b0:b0 + B, 1], tri[b0:b0 + B, 2], 0.05, 1e-4, 1e-4)
+            for b0 in range(0, n, B)]
+    np.testing.assert_allclose(losses, want, rtol=1e-4)
+    close(gu.cpu().numpy(), ou.numpy(), 1e-4)
+    close(gi.cpu().numpy(), oi.numpy(), 1e-4)
+    np.testing.assert_allclose(gi[7].cpu().numpy(), oi[7].numpy(), rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(gi[9].cpu().numpy(), oi[9].numpy(), rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(gu[11].cpu().numpy(), ou[11].numpy(), rtol=2e-4, atol=1e-6)
+    # deterministic: a second run from the same state gives bit-identical tables
+    g2u, g2i = wu.clone().to(DEV), wi.clone().to(DEV)
+    eng.bare_epoch(g2u, g2i, tri, B, 0.05, 1e-4, 1e-4, bce=True)
+    assert torch.equal(g2u, gu) and torch.equal(g2i, gi)
