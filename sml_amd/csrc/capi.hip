@@ -93,15 +93,29 @@ struct Prof {
 
 }  // namespace
 
+// sorted / compacted occurrence lists of one epoch (two sets: one may be prepared on a side
+// stream while the other is in use)
+struct IndexSet {
+    Buf<uint64_t> key_u, key_u2, key_i, key_i2;
+    Buf<uint32_t> val_u, val_u2, val_i, val_i2;
+    Buf<uint8_t> uniq, dup_u, dup_i;
+    Buf<int> off_u, off_i, n_sel;
+    Buf<char> cub_tmp;
+    int64_t n = -1; int batch = 0; const void* triples = nullptr;   // what was prepared here
+    void release() {
+        key_u.release(); key_u2.release(); key_i.release(); key_i2.release();
+        val_u.release(); val_u2.release(); val_i.release(); val_i2.release();
+        uniq.release(); dup_u.release(); dup_i.release(); off_u.release(); off_i.release(); n_sel.release();
+        cub_tmp.release();
+    }
+};
+
 struct sml_ctx {
     int device = 0, d = 32, max_batch = 0;
+    IndexSet ix[2];
     // transfer-net workspaces, 3*B slots each
     Buf<float> out, dout, dx, xin, z1, a1, dz1;
     Buf<float> pk, grad, convg, loss_part;
-    // sorted occurrence lists of an epoch
-    Buf<uint64_t> key_u, key_u2, key_i, key_i2;
-    Buf<uint32_t> val_u, val_u2, val_i, val_i2;
-    Buf<char> cub_tmp;
     // Adam schedule of the MF optimiser
     Buf<SmlSched> sched;
     int sched_len = 0;
@@ -116,9 +130,8 @@ struct sml_ctx {
         prof.release();
         out.release(); dout.release(); dx.release(); xin.release(); z1.release(); a1.release(); dz1.release();
         pk.release(); grad.release(); convg.release(); loss_part.release();
-        key_u.release(); key_u2.release(); key_i.release(); key_i2.release();
-        val_u.release(); val_u2.release(); val_i.release(); val_i2.release();
-        cub_tmp.release(); sched.release(); dummy.release();
+        ix[0].release(); ix[1].release();
+        sched.release(); dummy.release();
         hot_list.release(); hot_count.release(); hot_first.release(); hot_part.release();
     }
 };
@@ -182,7 +195,7 @@ int ensure_pk(sml_ctx* c) {
 int ceil_log2(int64_t x) { int b = 0; while (((int64_t)1 << b) < x) ++b; return b; }
 
 // sort every batch's occurrences by row (stable): users [n], items [2n]
-int sort_epoch(sml_ctx* c, const int64_t* tri, int64_t n, int batch, int pad_tiles, hipStream_t st) {
+int sort_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_tiles, hipStream_t st) {
     HIPCHK(c->key_u.ensure((size_t)n)); HIPCHK(c->key_u2.ensure((size_t)n));
     HIPCHK(c->val_u.ensure((size_t)n)); HIPCHK(c->val_u2.ensure((size_t)n));
     HIPCHK(c->key_i.ensure((size_t)2 * n)); HIPCHK(c->key_i2.ensure((size_t)2 * n));
@@ -298,7 +311,7 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
     const int lstride = wg_tiles(batch, 1) + wg_tiles(2 * batch, 1);     // one loss partial per backward workgroup
     HIPCHK(ctx->loss_part.ensure((size_t)nb * lstride));
     ctx->prof.begin(PC_PACK, st); HIPCHK(sml_launch_theta_pack(d, theta, ctx->pk.p, st)); ctx->prof.end(st);
-    ctx->prof.begin(PC_SORT, st); rc = sort_epoch(ctx, triples, n, batch, 1, st); ctx->prof.end(st); if (rc) return rc;
+    ctx->prof.begin(PC_SORT, st); rc = sort_epoch(&ctx->ix[0], triples, n, batch, 1, st); ctx->prof.end(st); if (rc) return rc;
     HIPCHK(hipMemsetAsync(ctx->loss_part.p, 0, (size_t)nb * lstride * sizeof(float), st));
     const int64_t ns = sml_net_size(d), ps = sml_pk_size(d);
     float* dx_buf = xchg ? xchg->dx_local : ctx->dx.p;
@@ -338,8 +351,8 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
         ctx->prof.begin(PC_BWD, st); HIPCHK(sml_launch_bwd(d, 1, w, tiles, st)); ctx->prof.end(st);
         SmlSegUpdArgs u;
         memset(&u, 0, sizeof(u));
-        u.key_u = ctx->key_u2.p + b * batch; u.val_u = ctx->val_u2.p + b * batch; u.n_u = B;
-        u.key_i = ctx->key_i2.p + 2 * b * batch; u.val_i = ctx->val_i2.p + 2 * b * batch; u.n_i = 2 * B;
+        u.key_u = ctx->ix[0].key_u2.p + b * batch; u.val_u = ctx->ix[0].val_u2.p + b * batch; u.n_u = B;
+        u.key_i = ctx->ix[0].key_i2.p + 2 * b * batch; u.val_i = ctx->ix[0].val_i2.p + 2 * b * batch; u.n_i = 2 * B;
         u.dx = dx_buf; u.dx_i = dx_buf; u.w_user = t->w_user; u.w_item = t->w_item;
         if (xchg) {
             // every rank contributes 2*B item occurrences of this batch (equal B on all ranks)
@@ -455,15 +468,58 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
     return SML_OK;
 }
 
+namespace {
+// sort + unique marks + duplicates-only compaction + per-batch offsets of one epoch, into index set X
+int bare_prepare(sml_ctx* ctx, IndexSet* X, const int64_t* triples, int64_t n, int batch, hipStream_t st) {
+    const int64_t nb = (n + batch - 1) / batch;
+    int rc;
+    if ((rc = sort_epoch(X, triples, n, batch, 0, st))) return rc;
+    // occurrences whose row is unique in its batch are updated in place by the gradient pass; the
+    // segmented update then only sees the duplicated occurrences: compact the sorted lists (stable
+    // select, so slot order inside a run is kept) and find every batch's range in them -- all on
+    // the device, no host round trip
+    HIPCHK(X->uniq.ensure((size_t)3 * nb * batch));
+    HIPCHK(X->dup_u.ensure((size_t)n)); HIPCHK(X->dup_i.ensure((size_t)2 * n));
+    HIPCHK(X->off_u.ensure((size_t)nb + 1)); HIPCHK(X->off_i.ensure((size_t)nb + 1)); HIPCHK(X->n_sel.ensure(4));
+    HIPCHK(sml_launch_mark_unique(X->key_u2.p, X->val_u2.p, X->key_i2.p, X->val_i2.p, n, batch, X->uniq.p, X->dup_u.p,
+                                  X->dup_i.p, st));
+    size_t t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+    HIPCHK(hipcub::DeviceSelect::Flagged(nullptr, t1, X->key_u2.p, X->dup_u.p, X->key_u.p, X->n_sel.p, (int)n, st));
+    HIPCHK(hipcub::DeviceSelect::Flagged(nullptr, t2, X->val_u2.p, X->dup_u.p, X->val_u.p, X->n_sel.p + 1, (int)n, st));
+    HIPCHK(hipcub::DeviceSelect::Flagged(nullptr, t3, X->key_i2.p, X->dup_i.p, X->key_i.p, X->n_sel.p + 2, (int)(2 * n), st));
+    HIPCHK(hipcub::DeviceSelect::Flagged(nullptr, t4, X->val_i2.p, X->dup_i.p, X->val_i.p, X->n_sel.p + 3, (int)(2 * n), st));
+    size_t tmp = t1 > t2 ? t1 : t2; tmp = tmp > t3 ? tmp : t3; tmp = tmp > t4 ? tmp : t4;
+    HIPCHK(X->cub_tmp.ensure(tmp + 256));
+    HIPCHK(hipcub::DeviceSelect::Flagged(X->cub_tmp.p, tmp, X->key_u2.p, X->dup_u.p, X->key_u.p, X->n_sel.p, (int)n, st));
+    HIPCHK(hipcub::DeviceSelect::Flagged(X->cub_tmp.p, tmp, X->val_u2.p, X->dup_u.p, X->val_u.p, X->n_sel.p + 1, (int)n, st));
+    HIPCHK(hipcub::DeviceSelect::Flagged(X->cub_tmp.p, tmp, X->key_i2.p, X->dup_i.p, X->key_i.p, X->n_sel.p + 2, (int)(2 * n), st));
+    HIPCHK(hipcub::DeviceSelect::Flagged(X->cub_tmp.p, tmp, X->val_i2.p, X->dup_i.p, X->val_i.p, X->n_sel.p + 3, (int)(2 * n), st));
+    HIPCHK(sml_launch_batch_offsets(X->key_u.p, X->n_sel.p, (int)nb, X->off_u.p, st));
+    HIPCHK(sml_launch_batch_offsets(X->key_i.p, X->n_sel.p + 2, (int)nb, X->off_i.p, st));
+    X->n = n; X->batch = batch; X->triples = triples;
+    return SML_OK;
+}
+}  // namespace
+
+int sml_embed_loss_sgd_prepare(sml_ctx* ctx, const int64_t* triples, int64_t n, int batch, int slot, void* stream) {
+    if (!ctx || !triples || n <= 0 || batch <= 0 || (slot != 0 && slot != 1))
+        return fail(SML_EINVAL, "sml_embed_loss_sgd_prepare", "bad argument");
+    if (batch > ctx->max_batch) return fail(SML_EINVAL, "sml_embed_loss_sgd_prepare", "batch exceeds ctx max_batch");
+    if (n > 0x3fffffff) return fail(SML_EINVAL, "sml_embed_loss_sgd_prepare", "epoch too long");
+    DevGuard g(ctx->device);
+    return bare_prepare(ctx, &ctx->ix[slot], triples, n, batch, (hipStream_t)stream);
+}
+
 int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n_user, int64_t n_item, int dtype_bytes,
                              const int64_t* triples, int64_t n, int batch, float lr, float lam_user, float lam_item,
-                             int loss_kind, float* batch_loss, void* stream) {
+                             int loss_kind, float* batch_loss, int prepared_slot, void* stream) {
     if (!ctx || !w_user || !w_item || !triples || !batch_loss || n <= 0 || batch <= 0 || n_user <= 0 || n_item <= 0)
         return fail(SML_EINVAL, "sml_embed_loss_sgd_epoch", "bad argument");
     if (dtype_bytes != 4 && dtype_bytes != 2) return fail(SML_EINVAL, "sml_embed_loss_sgd_epoch", "dtype_bytes must be 4 or 2");
     if (loss_kind != SML_LOSS_BCE && loss_kind != SML_LOSS_BPR) return fail(SML_EINVAL, "sml_embed_loss_sgd_epoch", "loss_kind");
     if (batch > ctx->max_batch) return fail(SML_EINVAL, "sml_embed_loss_sgd_epoch", "batch exceeds ctx max_batch");
     if (n > 0x3fffffff) return fail(SML_EINVAL, "sml_embed_loss_sgd_epoch", "epoch too long");
+    if (prepared_slot < -1 || prepared_slot > 1) return fail(SML_EINVAL, "sml_embed_loss_sgd_epoch", "prepared_slot");
     DevGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     const int d = ctx->d;
@@ -473,7 +529,13 @@ int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n
     const int lpr = d * dtype_bytes / 16;
     const int lstride = (int)(((int64_t)batch * lpr + 255) / 256);
     HIPCHK(ctx->loss_part.ensure((size_t)nb * lstride));
-    ctx->prof.begin(PC_SORT, st); rc = sort_epoch(ctx, triples, n, batch, 0, st); ctx->prof.end(st); if (rc) return rc;
+    IndexSet* X = &ctx->ix[prepared_slot < 0 ? 0 : prepared_slot];
+    if (prepared_slot < 0) {
+        ctx->prof.begin(PC_SORT, st); rc = bare_prepare(ctx, X, triples, n, batch, st); ctx->prof.end(st);
+        if (rc) return rc;
+    } else if (X->n != n || X->batch != batch || X->triples != triples) {
+        return fail(SML_ESTATE, "sml_embed_loss_sgd_epoch", "index set was prepared for other triples");
+    }
     HIPCHK(hipMemsetAsync(ctx->loss_part.p, 0, (size_t)nb * lstride * sizeof(float), st));
     // hot rows: with large batches a popular item collects thousands of occurrences per batch
     const int hot_cap = 3 * batch / SML_HOT + 8;
@@ -491,12 +553,16 @@ int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n
         SmlBareArgs a;
         a.w_user = w_user; a.w_item = w_item; a.tri = triples + b * batch * 3; a.B = B; a.dx = ctx->dx.p;
         a.loss_part = ctx->loss_part.p + b * lstride; a.kind = loss_kind; a.lam_user = lam_user; a.lam_item = lam_item;
+        a.uniq = X->uniq.p + (size_t)3 * b * batch; a.lr = lr;
         ctx->prof.begin(PC_BARE_GRAD, st); HIPCHK(sml_launch_bare_grad(d, dtype_bytes, a, nullptr, st)); ctx->prof.end(st);
         SmlSegUpdArgs u;
         memset(&u, 0, sizeof(u));
-        u.key_u = ctx->key_u2.p + b * batch; u.val_u = ctx->val_u2.p + b * batch; u.n_u = B;
-        u.key_i = ctx->key_i2.p + 2 * b * batch; u.val_i = ctx->val_i2.p + 2 * b * batch; u.n_i = 2 * B;
-        u.dx = ctx->dx.p; u.dx_i = ctx->dx.p; u.w_user = w_user; u.w_item = w_item; u.lr = lr;
+        // compacted (duplicates-only) lists of the whole epoch; the kernels slice out batch b themselves.
+        // The grid still covers the worst case (every occurrence duplicated); surplus groups exit at once.
+        u.key_u = X->key_u.p; u.val_u = X->val_u.p; u.n_u = B;
+        u.key_i = X->key_i.p; u.val_i = X->val_i.p; u.n_i = 2 * B;
+        u.off_u = X->off_u.p; u.off_i = X->off_i.p; u.batch_index = (int)b;
+        u.dx = ctx->dx.p; u.dx_i = ctx->dx.p; u.w_user = w_user; u.w_item = w_item; u.lr = lr; u.skip_single = 0;
         if (hot) {
             u.hot_list = ctx->hot_list.p; u.hot_count = ctx->hot_count.p + b; u.hot_first = ctx->hot_first.p;
             u.hot_part = ctx->hot_part.p; u.hot_cap = hot_cap;

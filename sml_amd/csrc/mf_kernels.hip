@@ -157,23 +157,33 @@ __global__ __launch_bounds__(256) void k_bare_grad(SmlBareArgs a) {
         sp = group_sum<LPR>(sp); sn = group_sum<LPR>(sn);
         float lt, dsp, dsn;
         pair_terms(a.kind, sp, sn, 1.0f / (float)a.B, lt, dsp, dsn);
-        float* gu = a.dx + (int64_t)t * D + sub * VEC;
-        float* gi = a.dx + (int64_t)(a.B + t) * D + sub * VEC;
-        float* gn = a.dx + (int64_t)(2 * a.B + t) * D + sub * VEC;
+        // gradient rows.  An occurrence whose row appears ONCE in this batch is read by nobody else in
+        // the batch, so its synchronous-SGD update is applied in place right here (exact); the others
+        // hand their gradient row to the segmented update.
+        float gx[VEC], gy[VEC], gz[VEC];
 #pragma unroll
-        for (int h = 0; h < VEC / 4; ++h) {
-            float x[4], y[4], z[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int e = h * 4 + k;
-                x[k] = dsp * it[e] + dsn * ng[e] + a.lam_user * u[e];
-                y[k] = dsp * u[e] + a.lam_item * it[e];
-                z[k] = dsn * u[e] + a.lam_item * ng[e];
-            }
-            RowVec<float>::store(gu + h * 4, x);
-            RowVec<float>::store(gi + h * 4, y);
-            RowVec<float>::store(gn + h * 4, z);
+        for (int e = 0; e < VEC; ++e) {
+            gx[e] = dsp * it[e] + dsn * ng[e] + a.lam_user * u[e];
+            gy[e] = dsp * u[e] + a.lam_item * it[e];
+            gz[e] = dsn * u[e] + a.lam_item * ng[e];
         }
+        const bool one_u = a.uniq != nullptr && a.uniq[t], one_i = a.uniq != nullptr && a.uniq[a.B + t],
+                   one_n = a.uniq != nullptr && a.uniq[2 * a.B + t];
+        auto emit = [&](bool in_place, T* wrow, const float (&row)[VEC], const float (&g)[VEC], float* dxrow) {
+            if (in_place) {
+                float nw[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) nw[e] = row[e] - a.lr * g[e];
+                RowVec<T>::store(wrow, nw);
+            } else {
+#pragma unroll
+                for (int h = 0; h < VEC / 4; ++h)
+                    RowVec<float>::store(dxrow + h * 4, reinterpret_cast<const float(&)[4]>(g[h * 4]));
+            }
+        };
+        emit(one_u, reinterpret_cast<T*>(a.w_user) + iu * D + sub * VEC, u, gx, a.dx + (int64_t)t * D + sub * VEC);
+        emit(one_i, reinterpret_cast<T*>(a.w_item) + ii * D + sub * VEC, it, gy, a.dx + (int64_t)(a.B + t) * D + sub * VEC);
+        emit(one_n, reinterpret_cast<T*>(a.w_item) + in * D + sub * VEC, ng, gz, a.dx + (int64_t)(2 * a.B + t) * D + sub * VEC);
         contrib = (sub == 0 ? lt : 0.0f) + 0.5f * (a.lam_user * sq_u + a.lam_item * sq_i);
     }
     const float tot = block_sum256(contrib, sh4);
@@ -201,6 +211,48 @@ __global__ void k_build_keys(const int64_t* __restrict__ tri, int64_t n, int bat
     val_i[n + e] = ioff + Bb + t;
 }
 
+// per epoch: occurrence (batch b, slot s) is "unique" iff its sorted neighbours carry other keys
+__global__ void k_mark_unique(const uint64_t* __restrict__ key_u, const uint32_t* __restrict__ val_u,
+                              const uint64_t* __restrict__ key_i, const uint32_t* __restrict__ val_i, int64_t n,
+                              int batch, uint8_t* __restrict__ uniq, uint8_t* __restrict__ dup_u,
+                              uint8_t* __restrict__ dup_i) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= 3 * n) return;
+    const bool item = p >= n;
+    const uint64_t* keys = item ? key_i : key_u;
+    const uint32_t* vals = item ? val_i : val_u;
+    const int64_t q = item ? p - n : p, m = item ? 2 * n : n;
+    const uint64_t k = keys[q];
+    const bool one = (q == 0 || keys[q - 1] != k) && (q + 1 >= m || keys[q + 1] != k);
+    const int64_t b = (int64_t)(k >> 32);
+    uniq[b * 3 * batch + vals[q]] = one ? 1 : 0;
+    (item ? dup_i : dup_u)[q] = one ? 0 : 1;       // selection flags of the compacted (duplicates-only) lists
+}
+
+// off[b] = first compacted position whose batch field is >= b  (off[nb] = number selected)
+__global__ void k_batch_offsets(const uint64_t* __restrict__ keys, const int* __restrict__ n_sel, int nb,
+                                int* __restrict__ off) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nb) return;
+    const int n = *n_sel;
+    int lo = 0, hi = n;
+    const uint64_t want = (uint64_t)b << 32;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < want) lo = mid + 1; else hi = mid; }
+    off[b] = lo;
+}
+
+// this batch's slice of the (possibly compacted) sorted lists
+struct SegLists { const uint64_t* key_u; const uint32_t* val_u; int n_u; const uint64_t* key_i; const uint32_t* val_i; int n_i; };
+__device__ __forceinline__ SegLists seg_lists(const SmlSegUpdArgs& a) {
+    SegLists L{a.key_u, a.val_u, a.n_u, a.key_i, a.val_i, a.n_i};
+    if (a.off_u != nullptr) {
+        const int u0 = a.off_u[a.batch_index], i0 = a.off_i[a.batch_index];
+        L.key_u += u0; L.val_u += u0; L.n_u = a.off_u[a.batch_index + 1] - u0;
+        L.key_i += i0; L.val_i += i0; L.n_i = a.off_i[a.batch_index + 1] - i0;
+    }
+    return L;
+}
+
 // ------------------------------------------------------------------------------------
 // segmented row update: one lane group per sorted occurrence; the group at the head of
 // a run of equal keys sums the run's gradient rows in order (deterministic) and writes
@@ -222,10 +274,11 @@ __global__ __launch_bounds__(256) void k_seg_update(SmlSegUpdArgs a) {
     const int grp = lane / LPR, sub = lane % LPR;
     int pos = gid / LPR;
     // which table this position belongs to (a wavefront may straddle the user/item boundary)
-    int is_item = 0, n = a.n_u;
-    if (pos >= a.n_u) { pos -= a.n_u; is_item = 1; n = a.n_i; }
+    const SegLists L = seg_lists(a);
+    int is_item = 0, n = L.n_u;
+    if (pos >= L.n_u) { pos -= L.n_u; is_item = 1; n = L.n_i; }
     const bool valid = pos < n;
-    const uint64_t* keys = is_item ? a.key_i : a.key_u;
+    const uint64_t* keys = is_item ? L.key_i : L.key_u;
     uint64_t key = 0;
     bool head = false;
     int len = 0;
@@ -251,6 +304,7 @@ __global__ __launch_bounds__(256) void k_seg_update(SmlSegUpdArgs a) {
             }
         }
     }
+    if (OPT == 0 && a.skip_single && len == 1) head = false;     // applied in place by k_bare_grad
     if (OPT == 0 && a.hot_list != nullptr && head && len > SML_HOT) {
         // a hot row: hand the run to the workgroup-level reducers (k_hot_partial / k_hot_apply)
         if (sub == 0) {
@@ -267,7 +321,7 @@ __global__ __launch_bounds__(256) void k_seg_update(SmlSegUpdArgs a) {
     for (int k = 0; k < VEC; ++k) g[k] = 0.0f;
     // ---- short runs: the head's own lane group sums them, up to LONG rows in flight, in slot order
     if (head && len <= LONG) {
-        const uint32_t* vals = is_item ? a.val_i : a.val_u;
+        const uint32_t* vals = is_item ? L.val_i : L.val_u;
         const float* dx = is_item ? a.dx_i : a.dx;
         float x[LONG][VEC];
 #pragma unroll
@@ -291,7 +345,7 @@ __global__ __launch_bounds__(256) void k_seg_update(SmlSegUpdArgs a) {
         const int leader = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
         const int l_pos = __shfl(pos, leader, 64), l_len = __shfl(len, leader, 64), l_item = __shfl(is_item, leader, 64);
-        const uint32_t* vals = l_item ? a.val_i : a.val_u;
+        const uint32_t* vals = l_item ? L.val_i : L.val_u;
         const float* dx = l_item ? a.dx_i : a.dx;
         float acc[VEC];
 #pragma unroll
@@ -393,7 +447,8 @@ __global__ __launch_bounds__(256) void k_hot_partial(SmlSegUpdArgs a) {
     if (c == 0 && tid == 0) a.hot_first[h] = w;
     const uint32_t packed = a.hot_list[2 * h];
     const int is_item = packed >> 31, pos0 = (int)(packed & 0x7fffffffu), len = (int)a.hot_list[2 * h + 1];
-    const uint32_t* vals = is_item ? a.val_i : a.val_u;
+    const SegLists L = seg_lists(a);
+    const uint32_t* vals = is_item ? L.val_i : L.val_u;
     const float* dx = is_item ? a.dx_i : a.dx;
     const int q_begin = c * SML_HOT_CHUNK, q_end = min(len, q_begin + SML_HOT_CHUNK);
     const int grp = tid / LPR, sub = tid % LPR;
@@ -451,7 +506,8 @@ __global__ __launch_bounds__(256) void k_hot_apply(SmlSegUpdArgs a) {
                 for (int k = 0; k < VEC; ++k) g[k] += x[j][k];
             }
     }
-    const uint64_t* keys = is_item ? a.key_i : a.key_u;
+    const SegLists L = seg_lists(a);
+    const uint64_t* keys = is_item ? L.key_i : L.key_u;
     const int64_t row = (uint32_t)keys[pos0];
     T* w = reinterpret_cast<T*>(is_item ? a.w_item : a.w_user);
     float p[VEC];
@@ -617,6 +673,17 @@ hipError_t sml_launch_bare_grad(int d, int dtype_bytes, const SmlBareArgs& a, in
     } else if (dtype_bytes == 2) {
         SML_DISPATCH_D(d, k_bare_grad<DD, __half><<<dim3(nb), dim3(256), 0, st>>>(a));
     } else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+hipError_t sml_launch_mark_unique(const uint64_t* key_u, const uint32_t* val_u, const uint64_t* key_i,
+                                  const uint32_t* val_i, int64_t n, int batch, uint8_t* uniq, uint8_t* dup_u,
+                                  uint8_t* dup_i, hipStream_t st) {
+    k_mark_unique<<<dim3((unsigned)((3 * n + 255) / 256)), dim3(256), 0, st>>>(key_u, val_u, key_i, val_i, n, batch, uniq,
+                                                                                 dup_u, dup_i);
+    return hipGetLastError();
+}
+hipError_t sml_launch_batch_offsets(const uint64_t* keys, const int* n_sel, int nb, int* off, hipStream_t st) {
+    k_batch_offsets<<<dim3((nb + 1 + 63) / 64), dim3(64), 0, st>>>(keys, n_sel, nb, off);
     return hipGetLastError();
 }
 hipError_t sml_launch_build_keys(const int64_t* tri, int64_t n, int batch, int pad_tiles, uint64_t* key_u,

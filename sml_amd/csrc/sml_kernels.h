@@ -107,6 +107,9 @@ struct SmlSegUpdArgs {
     int32_t* last_user; int32_t* last_item;                       // Adam only
     const SmlSched* sched; int cur_step;                          // Adam only
     float lr;                                                     // SGD only
+    int skip_single;         // SGD: runs of length 1 were already applied in place by k_bare_grad
+    // compacted lists (duplicated occurrences only, whole epoch): this batch's range is off[b]..off[b+1]
+    const int* off_u; const int* off_i; int batch_index;
     // hot rows (SGD, large batches): runs longer than SML_HOT are appended here instead of being summed by
     // one wavefront; k_hot_partial / k_hot_apply reduce them with whole workgroups.  null: off.
     uint32_t* hot_list;      // [hot_cap][2]: (pos | is_item << 31), len
@@ -123,11 +126,17 @@ hipError_t sml_launch_seg_adam(int d, const SmlSegUpdArgs& a, hipStream_t st);
 hipError_t sml_launch_seg_sgd(int d, int dtype_bytes, const SmlSegUpdArgs& a, hipStream_t st);
 hipError_t sml_launch_adam_flush(int d, float* w, float* m, float* v, int32_t* last, int64_t rows,
                                  const SmlSched* sched, int cur_step, hipStream_t st);
+hipError_t sml_launch_mark_unique(const uint64_t* key_u, const uint32_t* val_u, const uint64_t* key_i,
+                                  const uint32_t* val_i, int64_t n, int batch, uint8_t* uniq, uint8_t* dup_u,
+                                  uint8_t* dup_i, hipStream_t st);
+hipError_t sml_launch_batch_offsets(const uint64_t* keys, const int* n_sel, int nb, int* off, hipStream_t st);
 hipError_t sml_launch_build_keys(const int64_t* tri, int64_t n, int batch, int pad_tiles, uint64_t* key_u,
                                  uint32_t* val_u, uint64_t* key_i, uint32_t* val_i, hipStream_t st);
 
 struct SmlBareArgs {
-    const void* w_user; const void* w_item;
+    void* w_user; void* w_item;
+    const uint8_t* uniq;     // [3B] 1: this occurrence's row occurs once in the batch -> updated in place here
+    float lr;
     const int64_t* tri; int B;
     float* dx;               // [3B, d] per-occurrence gradients (fp32)
     float* loss_part;

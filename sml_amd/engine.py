@@ -227,20 +227,46 @@ class HipEngine(object):
         return losses
 
     # ------------------------------------------------------------------ a3
-    def bare_epoch(self, w_user, w_item, triples, batch_size, lr, lam_user, lam_item, bce=True):
+    def bare_prepare(self, triples, batch_size):
+        """Build the index lists of a coming bare epoch on the engine's side stream (sort by (batch,row),
+        unique marks, duplicates-only compaction) while earlier work keeps the main stream busy.
+        Returns a handle for bare_epoch(prepared=...)."""
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        tri = self._dev(triples, torch.int64)
+        slot = self._prep_slot = 1 - getattr(self, "_prep_slot", 1)
+        cur = torch.cuda.current_stream(self.device)
+        self._side.wait_stream(cur)          # the slot's previous user (two epochs back) has been queued before this
+        with torch.cuda.stream(self._side):
+            check(self.lib.sml_embed_loss_sgd_prepare(self._ctx, _ptr(tri), tri.shape[0], int(batch_size), slot,
+                                                      self._stream()), "sml_embed_loss_sgd_prepare")
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        tri.record_stream(self._side)
+        return dict(slot=slot, event=ev, tri=tri, batch=int(batch_size))
+
+    def bare_epoch(self, w_user, w_item, triples, batch_size, lr, lam_user, lam_item, bce=True, prepared=None):
         if w_user.dtype not in (torch.float32, torch.float16) or w_item.dtype != w_user.dtype:
             raise ValueError("tables must both be fp32 or both fp16")
         for w in (w_user, w_item):
             if w.device != self.device or not w.is_contiguous() or w.shape[-1] != self.d:
                 raise ValueError("tables must be contiguous [rows,%d] on %s" % (self.d, self.device))
-        tri = self._dev(triples, torch.int64)
+        slot = -1
+        if prepared is not None:
+            if prepared["batch"] != int(batch_size):
+                raise ValueError("prepared for another batch size")
+            tri, slot = prepared["tri"], prepared["slot"]
+            torch.cuda.current_stream(self.device).wait_event(prepared["event"])
+        else:
+            tri = self._dev(triples, torch.int64)
         n = tri.shape[0]
         nb = (n + batch_size - 1) // batch_size
         losses = torch.empty(nb, device=self.device, dtype=torch.float32)
         check(self.lib.sml_embed_loss_sgd_epoch(self._ctx, _ptr(w_user), _ptr(w_item), w_user.shape[0], w_item.shape[0],
                                                 w_user.element_size(), _ptr(tri), n, int(batch_size), float(lr),
                                                 float(lam_user), float(lam_item),
-                                                _lib.LOSS_BCE if bce else _lib.LOSS_BPR, _ptr(losses), self._stream()),
+                                                _lib.LOSS_BCE if bce else _lib.LOSS_BPR, _ptr(losses), slot,
+                                                self._stream()),
               "sml_embed_loss_sgd_epoch")
         return losses
 

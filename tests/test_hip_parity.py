@@ -486,3 +486,27 @@ def test_bare_step_hot_rows_vs_oracle():
     g2u, g2i = wu.clone().to(DEV), wi.clone().to(DEV)
     eng.bare_epoch(g2u, g2i, tri, B, 0.05, 1e-4, 1e-4, bce=True)
     assert torch.equal(g2u, gu) and torch.equal(g2i, gi)
+
+
+def test_bare_epoch_prepared_on_side_stream_equals_inline():
+    """Index lists prepared on the side stream (double-buffered) give bit-identical results to the
+    inline preparation, across several pipelined epochs."""
+    torch.manual_seed(2)
+    U, I, d, B = 3000, 2000, 32, 4096
+    wu, wi = torch.randn(U, d) * 0.3, torch.randn(I, d) * 0.3
+    tris = [torch.stack([torch.randint(0, U, (3 * B + 77,)), torch.randint(0, I, (3 * B + 77,)),
+                         torch.randint(0, I, (3 * B + 77,))], 1) for _ in range(4)]
+    eng = engine(d, B)
+    a_u, a_i = wu.clone().to(DEV), wi.clone().to(DEV)
+    la = [eng.bare_epoch(a_u, a_i, t, B, 0.05, 1e-4, 1e-4).cpu() for t in tris]
+    b_u, b_i = wu.clone().to(DEV), wi.clone().to(DEV)
+    lb = []
+    nxt = eng.bare_prepare(tris[0], B)
+    for e in range(4):
+        cur = nxt
+        if e + 1 < 4:
+            nxt = eng.bare_prepare(tris[e + 1], B)
+        lb.append(eng.bare_epoch(b_u, b_i, tris[e], B, 0.05, 1e-4, 1e-4, prepared=cur).cpu())
+    for x, y in zip(la, lb):
+        assert torch.equal(x, y)
+    assert torch.equal(a_u, b_u) and torch.equal(a_i, b_i)
