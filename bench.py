@@ -220,7 +220,8 @@ def main():
     from sml_amd.period import Hyper, run_period, synth_plan
     hp = Hyper(multi_num=a.multi_num)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("SML_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ   # exercise the exchange path at N=1
+    if world > 1 or force_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
         from sml_amd import dist as smldist
@@ -229,8 +230,8 @@ def main():
     # `inter` interactions over them; items are replicated
     U_local = a.users
     st = build_state(engine, U_local, a.items, a.d, device, seed=2000 + rank)
-    if world > 1:
-        smldist.attach(engine, st, dist, hp)
+    if dist is not None:
+        dctx = smldist.attach(engine, st, dist, hp)
     n_plans = min(a.steps + a.warmup, 2)
     plans = [synth_plan(100 + 17 * rank + p, a.inter, U_local, a.items, a.neg, hp, device, with_val=not a.no_val)
              for p in range(max(n_plans, 1))]
@@ -263,7 +264,9 @@ def main():
                                   "MF_batch=%d TR_batch=%d val_eval=%s" % (a.users, a.items, a.inter, a.neg, a.d,
                                                                            hp.multi_num, hp.MF_batch_size, hp.TR_batch_size,
                                                                            not a.no_val),
-                      "parallelism": "users row-sharded x%d, items replicated" % world if world > 1 else "single GPU"}}
+                      "parallelism": ("users row-sharded x%d, items replicated, %s exchange" %
+                                      (world, "native RCCL" if dctx.native else "torch.distributed"))
+                      if dist is not None else "single GPU"}}
 
     if not a.no_roofline:
         engine.profile(True)

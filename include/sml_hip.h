@@ -64,6 +64,21 @@ int64_t sml_theta_offset(int d, int which);
  * (construction, load_state_dict).  The TR-stage Adam keeps them current itself. */
 int sml_theta_pack(sml_ctx* ctx, const float* theta, void* stream);
 
+/* ---- native RCCL exchange (multi-GPU) ------------------------------------------------ */
+/* The library can issue the two exchange collectives itself, on the compute stream: no host
+ * callback per batch.  It binds the RCCL that is ALREADY loaded in the process (the host passes
+ * the path of that librccl.so; no link-time dependency), creates its own communicator from a
+ * 128-byte unique id the host broadcasts (rank 0: sml_comm_unique_id), and then
+ *   - sml_tr_stage_epoch with grad_hook == NULL all-reduces the flat theta gradient,
+ *   - sml_mf_stage_epoch with xchg->hook == NULL all-gathers the item-gradient rows.
+ * sml_comm_allreduce / sml_comm_allgather are exported for the host's start-up self-check. */
+int sml_comm_load(const char* librccl_path);
+int sml_comm_unique_id(void* out128);
+int sml_comm_init(sml_ctx* ctx, int world, int rank, const void* id128);
+int sml_comm_destroy(sml_ctx* ctx);
+int sml_comm_allreduce(sml_ctx* ctx, float* buf, int64_t n, void* stream);
+int sml_comm_allgather(sml_ctx* ctx, const float* src, float* dst, int64_t n_per_rank, void* stream);
+
 /* ---- a5/a6/a10: transfer net forward ------------------------------------------- */
 /* ConvTransfer_com.forward (model/conv_transfer.py:92-110) for `net` (0 = user
  * transfer, 1 = item transfer): out[n,:] = net(x_t[n,:], x_hat[n,:]).  Rows are
@@ -92,7 +107,8 @@ typedef struct {
  * (dx_local[item_off .. item_off + 2*batch) -> dx_items_all[world][2*batch][d]); the item
  * update then runs over the GLOBAL occurrence list (key_items/val_items: every batch's
  * world*2*B_b occurrences sorted by (batch << 32 | item row), value = slot in dx_items_all),
- * so all replicas apply the identical summed update.  loss_scale = B_local / B_global. */
+ * so all replicas apply the identical summed update.  loss_scale = B_local / B_global.
+ * hook == NULL: the library's own RCCL communicator (sml_comm_init) does the all-gather. */
 typedef int (*sml_mf_hook)(void* user, int64_t batch_index);
 typedef struct {
     int world;

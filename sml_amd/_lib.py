@@ -65,6 +65,12 @@ SIGNATURES = {
                                       c_void, c_void, c_void]),
     "sml_eval_ranks": (ctypes.c_int, [c_void, c_void, c_void, c_void, ctypes.c_int64, ctypes.c_int, c_void, c_void]),
     "sml_eval_metrics": (ctypes.c_int, [c_void, c_void, ctypes.c_int64, ctypes.c_int, c_void, c_void]),
+    "sml_comm_load": (ctypes.c_int, [ctypes.c_char_p]),
+    "sml_comm_unique_id": (ctypes.c_int, [c_void]),
+    "sml_comm_init": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void]),
+    "sml_comm_destroy": (ctypes.c_int, [c_void]),
+    "sml_comm_allreduce": (ctypes.c_int, [c_void, c_void, ctypes.c_int64, c_void]),
+    "sml_comm_allgather": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int64, c_void]),
     "sml_prof_enable": (ctypes.c_int, [c_void, ctypes.c_int]),
     "sml_prof_reset": (ctypes.c_int, [c_void]),
     "sml_prof_classes": (ctypes.c_int, []),

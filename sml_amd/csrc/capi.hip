@@ -1,6 +1,8 @@
 // C ABI of libsml_hip.so (see include/sml_hip.h): context, scratch, per-epoch launch loops.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <rccl/rccl.h>      // types only: the functions are bound at run time from the loaded librccl
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdio>
@@ -52,6 +54,23 @@ struct Buf {
 };
 
 bool d_ok(int d) { return d == 32 || d == 64 || d == 128; }
+
+// RCCL entry points, resolved from the librccl.so the process already uses (torch's)
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok() const { return handle != nullptr; }
+} g_rccl;
+#define NCCLCHK(expr)                                                                                       \
+    do {                                                                                                    \
+        ncclResult_t _r = (expr);                                                                           \
+        if (_r != ncclSuccess) return fail(SML_EHIP, #expr, g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "rccl error"); \
+    } while (0)
 
 // ---- optional per-kernel-class timing with HIP events on the caller's stream -------------
 enum ProfClass { PC_FWD = 0, PC_BWD, PC_WGRAD, PC_THETA_ADAM, PC_PAIR_LOSS, PC_SEG_ADAM, PC_SEG_SGD, PC_BARE_GRAD,
@@ -121,6 +140,8 @@ struct sml_ctx {
     int sched_len = 0;
     float sched_lr = -1.0f;
     Buf<int32_t> dummy;
+    ncclComm_t comm = nullptr;
+    int comm_world = 1, comm_rank = 0;
     Buf<uint32_t> hot_list;
     Buf<int> hot_count, hot_first;
     Buf<float> hot_part;
@@ -254,6 +275,7 @@ int sml_ctx_create(sml_ctx** out, int device, int d, int max_batch) {
 
 int sml_ctx_destroy(sml_ctx* ctx) {
     if (!ctx) return SML_OK;
+    (void)sml_comm_destroy(ctx);
     { DevGuard g(ctx->device); ctx->release_all(); }
     delete ctx;
     return SML_OK;
@@ -298,8 +320,10 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
     if (batch > ctx->max_batch) return fail(SML_EINVAL, "sml_mf_stage_epoch", "batch exceeds ctx max_batch");
     if (n > 0x3fffffff) return fail(SML_EINVAL, "sml_mf_stage_epoch", "epoch too long");
     if (loss_kind < 0 || loss_kind > 2) return fail(SML_EINVAL, "sml_mf_stage_epoch", "loss_kind");
-    if (xchg && (xchg->world < 1 || !xchg->key_items || !xchg->val_items || !xchg->dx_local || !xchg->dx_items_all || !xchg->hook))
+    if (xchg && (xchg->world < 1 || !xchg->key_items || !xchg->val_items || !xchg->dx_local || !xchg->dx_items_all))
         return fail(SML_EINVAL, "sml_mf_stage_epoch", "incomplete exchange descriptor");
+    if (xchg && !xchg->hook && (!ctx->comm || ctx->comm_world != xchg->world))
+        return fail(SML_ESTATE, "sml_mf_stage_epoch", "exchange without a hook needs sml_comm_init with the same world size");
     DevGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     const int d = ctx->d;
@@ -356,7 +380,12 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
         u.dx = dx_buf; u.dx_i = dx_buf; u.w_user = t->w_user; u.w_item = t->w_item;
         if (xchg) {
             // every rank contributes 2*B item occurrences of this batch (equal B on all ranks)
-            if (xchg->hook(xchg->hook_user, b) != 0) return fail(SML_ESTATE, "sml_mf_stage_epoch", "exchange hook failed");
+            if (xchg->hook) {
+                if (xchg->hook(xchg->hook_user, b) != 0) return fail(SML_ESTATE, "sml_mf_stage_epoch", "exchange hook failed");
+            } else {
+                const int64_t ioff = (int64_t)SML_R * tiles_of(B);
+                NCCLCHK(g_rccl.AllGather(dx_buf + ioff * d, xchg->dx_items_all, (size_t)2 * batch * d, ncclFloat, ctx->comm, st));
+            }
             u.key_i = xchg->key_items + (int64_t)xchg->world * 2 * b * batch;
             u.val_i = xchg->val_items + (int64_t)xchg->world * 2 * b * batch;
             u.n_i = xchg->world * 2 * B;
@@ -442,7 +471,8 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
         w.scale = loss_scale; w.loss_part = ctx->loss_part.p + b * lstride;
         ctx->prof.begin(PC_BWD, st); HIPCHK(sml_launch_bwd(d, 1, w, tiles, st)); ctx->prof.end(st);
         const SmlSched sc = sched_entry((double)lr, *step + 1 + b);
-        if (!grad_hook) {
+        const bool native = !grad_hook && ctx->comm != nullptr;     // a communicator exists: exchange natively
+        if (!grad_hook && !native) {
             // one GPU: the weight-gradient workgroups take the Adam step for the tiles they own
             wg.theta = theta; wg.m = adam_m; wg.v = adam_v; wg.pk = ctx->pk.p;
             wg.convg_part = ctx->convg.p; wg.tiles0 = f.tiles0; wg.tiles_total = tiles;
@@ -457,8 +487,12 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
             ad.weight_decay = weight_decay; ad.step_size = sc.step_size; ad.bc2_sqrt = sc.bc2_sqrt;
             ad.grad_only = 1;                  // finish the flat gradient (conv partials), all-reduce, then step
             ctx->prof.begin(PC_THETA_ADAM, st); HIPCHK(sml_launch_theta_adam(d, ad, st)); ctx->prof.end(st);
-            const int hr = grad_hook(hook_user, grad, 2 * ns, b);
-            if (hr != 0) return fail(SML_ESTATE, "sml_tr_stage_epoch", "grad_hook failed");
+            if (native) {
+                NCCLCHK(g_rccl.AllReduce(grad, grad, (size_t)(2 * ns), ncclFloat, ncclSum, ctx->comm, st));
+            } else {
+                const int hr = grad_hook(hook_user, grad, 2 * ns, b);
+                if (hr != 0) return fail(SML_ESTATE, "sml_tr_stage_epoch", "grad_hook failed");
+            }
             ad.grad_only = 0; ad.convg_part = nullptr;
             ctx->prof.begin(PC_THETA_ADAM, st); HIPCHK(sml_launch_theta_adam(d, ad, st)); ctx->prof.end(st);
         }
@@ -600,6 +634,64 @@ int sml_eval_metrics(sml_ctx* ctx, const int32_t* rank, int64_t n, int topk, flo
     DevGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     ctx->prof.begin(PC_MISC, st); HIPCHK(sml_launch_eval_metrics(rank, n, topk, out, st)); ctx->prof.end(st);
+    return SML_OK;
+}
+
+int sml_comm_load(const char* path) {
+    if (g_rccl.ok()) return SML_OK;
+    if (!path) return fail(SML_EINVAL, "sml_comm_load", "null path");
+    void* h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(SML_EINVAL, "sml_comm_load", dlerror());
+    RcclApi a;
+    a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+    a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
+    a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.AllGather)
+        return fail(SML_EINVAL, "sml_comm_load", "librccl lacks a required symbol");
+    a.handle = h;
+    g_rccl = a;
+    return SML_OK;
+}
+int sml_comm_unique_id(void* out128) {
+    if (!g_rccl.ok() || !out128) return fail(SML_ESTATE, "sml_comm_unique_id", "call sml_comm_load first");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    NCCLCHK(g_rccl.GetUniqueId(&id));
+    memcpy(out128, &id, sizeof(id));
+    return SML_OK;
+}
+int sml_comm_init(sml_ctx* ctx, int world, int rank, const void* id128) {
+    if (!ctx || !id128 || world < 1 || rank < 0 || rank >= world) return fail(SML_EINVAL, "sml_comm_init", "bad argument");
+    if (!g_rccl.ok()) return fail(SML_ESTATE, "sml_comm_init", "call sml_comm_load first");
+    DevGuard g(ctx->device);
+    if (ctx->comm) { (void)g_rccl.CommDestroy(ctx->comm); ctx->comm = nullptr; }
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    NCCLCHK(g_rccl.CommInitRank(&ctx->comm, world, id, rank));
+    ctx->comm_world = world; ctx->comm_rank = rank;
+    return SML_OK;
+}
+int sml_comm_destroy(sml_ctx* ctx) {
+    if (!ctx) return SML_OK;
+    if (ctx->comm && g_rccl.ok()) { DevGuard g(ctx->device); (void)g_rccl.CommDestroy(ctx->comm); }
+    ctx->comm = nullptr; ctx->comm_world = 1; ctx->comm_rank = 0;
+    return SML_OK;
+}
+int sml_comm_allreduce(sml_ctx* ctx, float* buf, int64_t n, void* stream) {
+    if (!ctx || !buf || n <= 0) return fail(SML_EINVAL, "sml_comm_allreduce", "bad argument");
+    if (!ctx->comm) return fail(SML_ESTATE, "sml_comm_allreduce", "no communicator");
+    DevGuard g(ctx->device);
+    NCCLCHK(g_rccl.AllReduce(buf, buf, (size_t)n, ncclFloat, ncclSum, ctx->comm, (hipStream_t)stream));
+    return SML_OK;
+}
+int sml_comm_allgather(sml_ctx* ctx, const float* src, float* dst, int64_t n_per_rank, void* stream) {
+    if (!ctx || !src || !dst || n_per_rank <= 0) return fail(SML_EINVAL, "sml_comm_allgather", "bad argument");
+    if (!ctx->comm) return fail(SML_ESTATE, "sml_comm_allgather", "no communicator");
+    DevGuard g(ctx->device);
+    NCCLCHK(g_rccl.AllGather(src, dst, (size_t)n_per_rank, ncclFloat, ctx->comm, (hipStream_t)stream));
     return SML_OK;
 }
 

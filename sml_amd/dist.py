@@ -60,6 +60,7 @@ class DistContext(object):
         self.device = torch.device(device)
         self._buf = {}
         self.native_gather = dist.get_backend(group) == "nccl"
+        self.native = False          # True: libsml_hip's own RCCL communicator does the per-batch exchange
 
     # ---- TR stage: all-reduce of the flat theta gradient
     def tr_loss_scale(self):
@@ -91,8 +92,8 @@ class DistContext(object):
             else:
                 self.dist.all_gather(list(dx_all.view(self.world, -1).unbind(0)), src, group=self.group)
 
-        return dict(world=self.world, keys=keys, vals=vals, dx_local=dx_local, dx_all=dx_all, hook=hook,
-                    loss_scale=1.0 / self.world)
+        return dict(world=self.world, keys=keys, vals=vals, dx_local=dx_local, dx_all=dx_all,
+                    hook=None if self.native else hook, loss_scale=1.0 / self.world)
 
     # ---- replicas start identical
     def sync_replicas(self, tensors):
@@ -106,6 +107,22 @@ def attach(engine, state, dist, hp=None, group=None):
     ctx = DistContext(dist, engine.device if hasattr(engine, "device") else "cpu", group)
     engine.dist = ctx
     engine.grad_hook = ctx.tr_grad_hook
+    # Prefer the native exchange (RCCL issued by the library on the compute stream, no host callback per
+    # batch); fall back to the torch.distributed hooks unless EVERY rank's communicator passed its check.
+    import os
+    if hasattr(engine, "comm_init") and os.environ.get("SML_COMM", "rccl") == "rccl":
+        try:
+            ok = engine.comm_init(dist, group)
+        except Exception as e:   # noqa: BLE001 -- any failure means: use the hook path
+            print("[sml_amd.dist] native RCCL exchange unavailable on rank %d: %s" % (ctx.rank, e))
+            ok = False
+        flag = torch.tensor([1.0 if ok else 0.0], device=ctx.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        ctx.native = bool(flag.item() > 0.5)
+        if ctx.native:
+            engine.grad_hook = None
+        elif ok:
+            engine.comm_destroy()
     if state is not None:
         theta = engine.adopt(state.transfer) if hasattr(engine, "adopt") else None
         reps = [state.MFbase.item_laten.weight.data, state.last_item, state.hat_item, state.prev_hat_item]

@@ -169,7 +169,7 @@ class HipEngine(object):
             x.world = ex["world"]
             x.key_items, x.val_items = ex["keys"].data_ptr(), ex["vals"].data_ptr()
             x.dx_local, x.dx_items_all = ex["dx_local"].data_ptr(), ex["dx_all"].data_ptr()
-            x.hook = _lib.MF_HOOK(_cb)
+            x.hook = _lib.MF_HOOK(_cb) if hook_fn is not None else ctypes.cast(None, _lib.MF_HOOK)
             x.hook_user = None
             x.loss_scale = ex["loss_scale"]
             xp = ctypes.byref(x)
@@ -323,6 +323,36 @@ class HipEngine(object):
               "sml_eval_metrics")
         h = out.cpu()
         return float(h[0]), float(h[1])
+
+    # ------------------------------------------------------------------ native RCCL exchange
+    def comm_init(self, dist, group=None):
+        """Create the library's own RCCL communicator over the ranks of `group` (the unique id travels
+        through torch.distributed) and verify it with a small all-reduce and all-gather.
+        Returns True when the native exchange is usable on this rank."""
+        import os
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if not os.path.exists(path):
+            path = "librccl.so"
+        if self.lib.sml_comm_load(path.encode()) != 0:
+            return False
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        buf = ctypes.create_string_buffer(128)
+        if rank == 0:
+            check(self.lib.sml_comm_unique_id(buf), "sml_comm_unique_id")
+        box = [bytes(buf.raw)]
+        dist.broadcast_object_list(box, src=0, group=group)
+        idb = ctypes.create_string_buffer(box[0], 128)
+        check(self.lib.sml_comm_init(self._ctx, world, rank, idb), "sml_comm_init")
+        t = torch.full((8,), float(rank + 1), device=self.device)
+        check(self.lib.sml_comm_allreduce(self._ctx, _ptr(t), 8, self._stream()), "sml_comm_allreduce")
+        src = torch.tensor([float(rank), rank + 0.5], device=self.device)
+        dst = torch.empty(2 * world, device=self.device)
+        check(self.lib.sml_comm_allgather(self._ctx, _ptr(src), _ptr(dst), 2, self._stream()), "sml_comm_allgather")
+        want = torch.tensor([v for r in range(world) for v in (float(r), r + 0.5)], device=self.device)
+        return bool(torch.all(t == world * (world + 1) / 2.0)) and bool(torch.equal(dst, want))
+
+    def comm_destroy(self):
+        self.lib.sml_comm_destroy(self._ctx)
 
     # ------------------------------------------------------------------ measurement
     def profile(self, on):

@@ -358,7 +358,7 @@ def test_g7_end_to_end_on_gpu(tmp_path, monkeypatch):
 
 
 # ----------------------------------------------------------------------------- multi-GPU plumbing on one GPU
-def test_exchange_path_on_one_rank_rccl_group_equals_plain_path():
+def test_exchange_path_on_one_rank_rccl_group_equals_plain_path(monkeypatch):
     """A 1-rank RCCL group drives the real exchange code (global item lists, all-gather of
     item-gradient rows into the gathered buffer, theta-gradient all-reduce hook): results
     must equal the plain single-GPU path (bit for bit in the MF stage)."""
@@ -372,14 +372,16 @@ def test_exchange_path_on_one_rank_rccl_group_equals_plain_path():
                             device_id=torch.device(DEV))
     try:
         outs = []
-        for use_dist in (False, True):
+        for use_dist in (False, "rccl", "torch"):
+            monkeypatch.setenv("SML_COMM", use_dist or "rccl")
             eng = engine(32)
             lr, l2, B, _ = z["hp_mf"]
             U, d = z["W_user0"].shape
             mf = make_mf(U, z["W_item0"].shape[0], d, z["W_user0"], z["W_item0"], device=DEV)
             net = make_transfer(d, z, prefix="theta0.", device=DEV)
             if use_dist:
-                SD.attach(eng, PeriodState(mf, net), dist)
+                ctx = SD.attach(eng, PeriodState(mf, net), dist)
+                assert ctx.native == (use_dist == "rccl")      # the library's own communicator passed its self-check
             tri = torch.from_numpy(z["mf_triples"][:200])
             lu, li = T(z["Wlast_user"], DEV), T(z["Wlast_item"], DEV)
             l1 = eng.mf_stage_epoch(mf, net, lu, li, tri, int(B), lr, l2)
@@ -388,7 +390,9 @@ def test_exchange_path_on_one_rank_rccl_group_equals_plain_path():
             l2_ = eng.tr_stage_epoch(net, lu, li, hu, hi, tri[:, [0, 1, 2]], 16, 1e-3, 1e-4)
             outs.append((l1.cpu(), l2_.cpu(), hu.cpu(), hi.cpu(), eng.adopt(net).cpu().clone()))
         names = ("mf losses", "tr losses", "user table", "item table", "theta")
-        for name, a, b in zip(names, *outs):
+        for name, a, b in zip(names, outs[1], outs[2]):
+            assert torch.equal(a, b), name                     # native RCCL == torch.distributed hooks, bit for bit
+        for name, a, b in zip(names, outs[0], outs[1]):
             if name in ("tr losses", "theta"):
                 # one GPU fuses the theta Adam step into the weight-gradient kernel, the hooked path runs
                 # it as its own kernel after the all-reduce: same arithmetic, different instruction
