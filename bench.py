@@ -31,6 +31,23 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak
 
 
+class _StdoutToStderr(object):
+    """fd-level redirect: RCCL prints a version banner to stdout when a communicator is created; the
+    bench contract is ONE JSON line on stdout."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -219,6 +236,8 @@ def main():
     from sml_amd.engine import HipEngine
     from sml_amd.period import Hyper, run_period, synth_plan
     hp = Hyper(multi_num=a.multi_num)
+    quiet = _StdoutToStderr()
+    quiet.__enter__()          # until the warm-up is done (communicators are created lazily)
     dist = None
     force_dist = os.environ.get("SML_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ   # exercise the exchange path at N=1
     if world > 1 or force_dist:
@@ -244,6 +263,7 @@ def main():
     for w in range(a.warmup):
         run_period(engine, st, plans[w % len(plans)], hp)
     barrier()
+    quiet.__exit__()
     t0 = time.perf_counter()
     for s in range(a.steps):
         run_period(engine, st, plans[(a.warmup + s) % len(plans)], hp)

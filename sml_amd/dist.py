@@ -114,7 +114,8 @@ def attach(engine, state, dist, hp=None, group=None):
         try:
             ok = engine.comm_init(dist, group)
         except Exception as e:   # noqa: BLE001 -- any failure means: use the hook path
-            print("[sml_amd.dist] native RCCL exchange unavailable on rank %d: %s" % (ctx.rank, e))
+            import sys
+            print("[sml_amd.dist] native RCCL exchange unavailable on rank %d: %s" % (ctx.rank, e), file=sys.stderr)
             ok = False
         flag = torch.tensor([1.0 if ok else 0.0], device=ctx.device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
