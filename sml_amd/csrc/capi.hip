@@ -76,7 +76,7 @@ struct RcclApi {
 enum ProfClass { PC_FWD = 0, PC_BWD, PC_WGRAD, PC_THETA_ADAM, PC_PAIR_LOSS, PC_SEG_ADAM, PC_SEG_SGD, PC_BARE_GRAD,
                  PC_EVAL_RANKS, PC_FLUSH, PC_PACK, PC_SORT, PC_MISC, PC_COUNT };
 const char* const kProfNames[PC_COUNT] = {"k_transfer_fwd", "k_transfer_bwd", "k_transfer_wgrad", "k_theta_adam",
-                                          "k_pair_loss", "k_seg_update_adam", "k_seg_update_sgd", "k_bare_grad",
+                                          "(unused)", "k_seg_update_adam", "k_seg_update_sgd", "k_bare_grad",
                                           "k_eval_ranks", "k_adam_flush", "k_theta_pack", "sort_epoch", "misc"};
 struct Prof {
     bool on = false;

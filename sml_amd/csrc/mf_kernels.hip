@@ -58,65 +58,6 @@ __device__ __forceinline__ float block_sum256(float v, float* sh4) {
     return sh4[0] + sh4[1] + sh4[2] + sh4[3];
 }
 
-// ------------------------------------------------------------------------------------
-// pair loss on transferred rows: out = [u' | i' | n'] -> dout, loss partials (+ l2 term)
-// ------------------------------------------------------------------------------------
-template <int D>
-__global__ __launch_bounds__(256) void k_pair_loss(SmlLossArgs a) {
-    constexpr int LPR = D / 4;
-    __shared__ float sh4[4];
-    const int gid = blockIdx.x * 256 + threadIdx.x;
-    const int t = gid / LPR, sub = gid % LPR;
-    float contrib = 0.0f;
-    if (t < a.B) {
-        float u[4], it[4], ng[4];
-        RowVec<float>::load(a.out + (int64_t)t * D + sub * 4, u);
-        RowVec<float>::load(a.out + (int64_t)(a.ioff + t) * D + sub * 4, it);
-        RowVec<float>::load(a.out + (int64_t)(a.ioff + a.B + t) * D + sub * 4, ng);
-        float sp = 0.f, sn = 0.f, uu = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { sp += u[k] * it[k]; sn += u[k] * ng[k]; uu += u[k] * u[k]; }
-        sp = group_sum<LPR>(sp); sn = group_sum<LPR>(sn);
-        float lt, dsp, dsn;
-        float du[4], di[4], dn[4];
-        if (a.kind == SML_LOSS_BPR_NORM) {
-            uu = group_sum<LPR>(uu);
-            const float nu = sqrtf(uu);
-            float d0, d1;
-            pair_terms(SML_LOSS_BPR, (sp - sn) / nu, 0.0f, 1.0f, lt, d0, d1);
-            const float c = (sp - sn) / (nu * nu * nu);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                du[k] = a.scale * d0 * ((it[k] - ng[k]) / nu - c * u[k]);
-                di[k] = a.scale * d0 * u[k] / nu;
-                dn[k] = -di[k];
-            }
-        } else {
-            pair_terms(a.kind, sp, sn, 1.0f / (float)a.B, lt, dsp, dsn);
-            dsp *= a.scale; dsn *= a.scale;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { du[k] = dsp * it[k] + dsn * ng[k]; di[k] = dsp * u[k]; dn[k] = dsn * u[k]; }
-        }
-        RowVec<float>::store(a.dout + (int64_t)t * D + sub * 4, du);
-        RowVec<float>::store(a.dout + (int64_t)(a.ioff + t) * D + sub * 4, di);
-        RowVec<float>::store(a.dout + (int64_t)(a.ioff + a.B + t) * D + sub * 4, dn);
-        if (sub == 0) contrib = lt * a.scale;
-        if (a.xin != nullptr) {   // + l2 * 0.5 * sum(u_hat^2 + i_hat^2 + n_hat^2)   (model/transfer.py:486-488)
-            float x[4], s = 0.f;
-#pragma unroll
-            for (int w = 0; w < 3; ++w) {
-                const int slot = (w == 0) ? t : a.ioff + (w - 1) * a.B + t;
-                RowVec<float>::load(a.xin + ((int64_t)slot * 3 + 1) * D + sub * 4, x);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) s += x[k] * x[k];
-            }
-            contrib += 0.5f * a.l2 * s;   // a sum over rows, not a batch mean: never rescaled
-        }
-    }
-    const float tot = block_sum256(contrib, sh4);
-    if (threadIdx.x == 0) a.loss_part[blockIdx.x] = tot;
-}
-
 // one wavefront per batch: lanes stride over the batch's partials, fixed-order tree (deterministic)
 __global__ __launch_bounds__(64) void k_loss_finalize(const float* __restrict__ part, int n_batches, int stride,
                                                      float* __restrict__ out) {
@@ -653,13 +594,6 @@ __global__ __launch_bounds__(1024) void k_eval_metrics(const int32_t* __restrict
         default: return hipErrorInvalidValue; \
     }
 
-hipError_t sml_launch_pair_loss(int d, const SmlLossArgs& a, int* n_blocks, hipStream_t st) {
-    const int lpr = d / 4;
-    const int nb = (a.B * lpr + 255) / 256;
-    if (n_blocks) *n_blocks = nb;
-    SML_DISPATCH_D(d, k_pair_loss<DD><<<dim3(nb), dim3(256), 0, st>>>(a));
-    return hipGetLastError();
-}
 hipError_t sml_launch_loss_finalize(const float* part, int n_batches, int stride, const int*, float* out, hipStream_t st) {
     k_loss_finalize<<<dim3(n_batches), dim3(64), 0, st>>>(part, n_batches, stride, out);
     return hipGetLastError();

@@ -81,18 +81,6 @@ hipError_t sml_launch_theta_pack(int d, const float* theta, float* pk, hipStream
 hipError_t sml_launch_selftest(const float* A, const float* W, float* pk, float* out, hipStream_t st);
 
 // ---- mf_kernels.hip ------------------------------------------------------------------
-struct SmlLossArgs {
-    const float* out;        // [3B, d]: u' rows, i' rows, n' rows
-    const float* xin;        // [3B, 3, d] or null (no l2 term)
-    float* dout;             // [3B, d]
-    float* loss_part;        // [gridDim.x] partial sums of this batch
-    int B;
-    int ioff;                // first item slot (B rounded up to a whole tile): i' at ioff+t, n' at ioff+B+t
-    int kind;                // SML_LOSS_*
-    float l2;
-    float scale;             // multiplies loss and gradients (multi-GPU: B_local / B_global)
-};
-hipError_t sml_launch_pair_loss(int d, const SmlLossArgs& a, int* n_blocks, hipStream_t st);
 hipError_t sml_launch_loss_finalize(const float* part, int n_batches, int stride, const int* counts,
                                     float* out, hipStream_t st);
 

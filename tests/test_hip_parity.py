@@ -187,10 +187,10 @@ def test_g4_tr_stage_vs_golden_and_oracle():
     assert net.user_transfer.fc1.weight.data_ptr() == flat.data_ptr() + 4 * eng.offsets[4]
 
 
-def test_tr_stage_theta_gradient_vs_autograd():
-    """One batch, lr -> tiny: the flat gradient buffer equals autograd's theta gradient."""
-    z = golden("g2_run_mf_d32.npz")
-    d = 32
+@pytest.mark.parametrize("d", [32, 64])
+def test_tr_stage_theta_gradient_vs_autograd(d):
+    """One batch, lr -> tiny: the flat gradient buffer equals the reference's autograd theta gradient (G2)."""
+    z = golden("g2_run_mf_d%d.npz" % d)
     eng = engine(d)
     net = make_transfer(d, z, device=DEV)
     B = z["ul"].shape[0]
@@ -514,3 +514,36 @@ def test_bare_epoch_prepared_on_side_stream_equals_inline():
     for x, y in zip(la, lb):
         assert torch.equal(x, y)
     assert torch.equal(a_u, b_u) and torch.equal(a_i, b_i)
+
+
+@pytest.mark.parametrize("d", [64, 128])
+def test_stages_at_wider_tables_vs_oracle(d):
+    """MF and TR stage at d = 64 / 128 (BASELINE configs 4 and 5 widths) against the oracle."""
+    torch.manual_seed(d)
+    U, I, B, n = 120, 90, 48, 130
+    wu, wi = torch.randn(U, d) * 0.3, torch.randn(I, d) * 0.3
+    tri = torch.stack([torch.randint(0, U, (n,)), torch.randint(0, I, (n,)), torch.randint(0, I, (n,))], 1)
+    tri[:9, 0] = 4
+    sd = None
+    res = []
+    for eng, dev in ((engine(d, 64), DEV), (O.OracleEngine(d), "cpu")):
+        mf = make_mf(U, I, d, wu.numpy(), wi.numpy(), device=dev)
+        net = make_transfer(d, device=dev)
+        if sd is None:
+            sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+        else:
+            net.load_state_dict(sd)
+        lu, li = (wu * 0.9).to(dev), (wi * 0.9).to(dev)
+        l_mf = eng.mf_stage_epoch(mf, net, lu, li, tri, B, 0.01, 1e-6)
+        eng.mf_flush(mf)
+        hu, hi = mf.user_laten.weight.detach().clone(), mf.item_laten.weight.detach().clone()
+        l_tr = eng.tr_stage_epoch(net, lu, li, hu, hi, tri, B, 1e-3, 1e-4)
+        tonp = lambda x: x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+        res.append((tonp(l_mf), tonp(l_tr), tonp(hu), tonp(hi), {k: tonp(v) for k, v in net.state_dict().items()}))
+    g, o = res
+    np.testing.assert_allclose(g[0], o[0], rtol=1e-4)
+    np.testing.assert_allclose(g[1], o[1], rtol=1e-4)
+    adam_close(g[2], o[2], 0.01, 3)
+    adam_close(g[3], o[3], 0.01, 3)
+    for k in o[4]:
+        adam_close(g[4][k], o[4][k], 1e-3, 3)

@@ -54,7 +54,8 @@ def adam_close(a, b, lr, steps, frac=0.999):
     none is further apart than a small fraction of the distance Adam can move it."""
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     tight = np.abs(a - b) <= 2e-4 * np.abs(b) + 2e-5 * lr * steps
-    assert tight.mean() >= frac, "only %.5f of elements agree tightly" % tight.mean()
+    # (small tensors: a couple of noise-level elements must not fail the fraction test)
+    assert tight.mean() >= frac or (~tight).sum() <= 2, "only %.5f of elements agree tightly" % tight.mean()
     assert np.abs(a - b).max() <= 0.05 * lr * steps, "max abs diff %.3e" % np.abs(a - b).max()
 
 
