@@ -562,6 +562,96 @@ __global__ __launch_bounds__(256) void k_eval_ranks(const float* __restrict__ wu
     if (lane == 0) rank[r] = tot;
 }
 
+// ------------------------------------------------------------------------------------
+// L2-blocked evaluation.  The item table (15.7 MB at Yelp scale) does not fit one XCD's 4 MB L2, so
+// the plain kernel's gathers mostly miss to Infinity Cache.  Once per test set, every row's
+// candidates are grouped into SML_EVB item ranges (k_eval_bucketize); the rank kernel then gives
+// range x to the workgroups that run on XCD x (workgroup b is dispatched to XCD b % 8 -- observed
+// placement, used for cache affinity only: any other placement is merely slower), so each XCD
+// gathers from a 1/8 slice of the table that stays in its own L2.  Partial counts meet in an integer
+// atomicAdd (exact, order-independent).
+// ------------------------------------------------------------------------------------
+#define SML_EVB 8
+__global__ __launch_bounds__(256) void k_eval_bucketize(const int64_t* __restrict__ rows, int64_t n, int n_cols,
+                                                        int64_t n_item, int64_t* __restrict__ rows_out,
+                                                        int32_t* __restrict__ bucket_off) {
+    __shared__ int hist[4][SML_EVB], cursor[4][SML_EVB];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wv;
+    if (lane < SML_EVB) hist[wv][lane] = 0;
+    __syncthreads();
+    const int64_t per = (n_item + SML_EVB - 1) / SML_EVB;
+    const bool ok = r < n;
+    const int64_t* R = rows + (ok ? r : 0) * n_cols;
+    if (ok) for (int c = 2 + lane; c < n_cols; c += 64) atomicAdd(&hist[wv][(int)min((int64_t)SML_EVB - 1, R[c] / per)], 1);
+    __syncthreads();
+    if (ok && lane == 0) {
+        int run = 0;
+        int32_t* off = bucket_off + r * (SML_EVB + 1);
+        for (int b = 0; b < SML_EVB; ++b) { off[b] = run; cursor[wv][b] = run; run += hist[wv][b]; }
+        off[SML_EVB] = run;
+    }
+    __syncthreads();
+    if (!ok) return;
+    int64_t* O = rows_out + r * n_cols;
+    if (lane < 2) O[lane] = R[lane];
+    for (int c = 2 + lane; c < n_cols; c += 64) {
+        const int64_t it = R[c];
+        const int slot = atomicAdd(&cursor[wv][(int)min((int64_t)SML_EVB - 1, it / per)], 1);
+        O[2 + slot] = it;          // order inside a bucket is irrelevant: the rank is a count
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_eval_ranks_bucketed(const float* __restrict__ wu, const float* __restrict__ wi,
+                                                             const int64_t* __restrict__ rows, const int32_t* __restrict__ bucket_off,
+                                                             int64_t n, int n_cols, int32_t* __restrict__ rank) {
+    constexpr int LPR = D / 4;
+    constexpr int G = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int x = blockIdx.x % SML_EVB;                          // this workgroup's item range (= its XCD)
+    const int64_t r = ((int64_t)blockIdx.x / SML_EVB) * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int grp = lane / LPR, sub = lane % LPR;
+    const int64_t* R = rows + r * n_cols;
+    const int c0 = 2 + bucket_off[r * (SML_EVB + 1) + x], c1 = 2 + bucket_off[r * (SML_EVB + 1) + x + 1];
+    if (c0 == c1) return;
+    float u[4], xr[4];
+    RowVec<float>::load(wu + R[0] * D + sub * 4, u);
+    RowVec<float>::load(wi + R[1] * D + sub * 4, xr);
+    float s0 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s0 += u[k] * xr[k];
+    s0 = group_sum<LPR>(s0);
+    int cnt = 0;
+    int c = c0 + grp;
+    for (; c + 3 * G < c1; c += 4 * G) {
+        float y[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) RowVec<float>::load(wi + R[c + j * G] * D + sub * 4, y[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += u[k] * y[j][k];
+            s = group_sum<LPR>(s);
+            cnt += (s > s0) ? 1 : 0;
+        }
+    }
+    for (; c < c1; c += G) {
+        RowVec<float>::load(wi + R[c] * D + sub * 4, xr);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s += u[k] * xr[k];
+        s = group_sum<LPR>(s);
+        cnt += (s > s0) ? 1 : 0;
+    }
+    int tot = (sub == 0) ? cnt : 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off, 64);
+    if (lane == 0 && tot) atomicAdd(&rank[r], tot);
+}
+
 // hits and NDCG sum over ranks (model/MF.py:60-78): hit iff rank < topk, NDCG = 1/log2(rank+2).
 // One 1024-thread block; fixed reduction tree (deterministic).
 __global__ __launch_bounds__(1024) void k_eval_metrics(const int32_t* __restrict__ rank, int64_t n, int topk,
@@ -671,6 +761,19 @@ hipError_t sml_launch_eval_ranks(int d, const float* wu, const float* wi, const 
                                  int32_t* rank, hipStream_t st) {
     const int64_t nb = (n + 3) / 4;
     SML_DISPATCH_D(d, k_eval_ranks<DD><<<dim3((unsigned)nb), dim3(256), 0, st>>>(wu, wi, rows, n, n_cols, rank));
+    return hipGetLastError();
+}
+hipError_t sml_launch_eval_bucketize(const int64_t* rows, int64_t n, int n_cols, int64_t n_item, int64_t* rows_out,
+                                     int32_t* bucket_off, hipStream_t st) {
+    k_eval_bucketize<<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st>>>(rows, n, n_cols, n_item, rows_out, bucket_off);
+    return hipGetLastError();
+}
+hipError_t sml_launch_eval_ranks_bucketed(int d, const float* wu, const float* wi, const int64_t* rows_b,
+                                          const int32_t* bucket_off, int64_t n, int n_cols, int32_t* rank, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(rank, 0, (size_t)n * sizeof(int32_t), st);
+    if (e != hipSuccess) return e;
+    const int64_t nb = ((n + 3) / 4) * SML_EVB;
+    SML_DISPATCH_D(d, k_eval_ranks_bucketed<DD><<<dim3((unsigned)nb), dim3(256), 0, st>>>(wu, wi, rows_b, bucket_off, n, n_cols, rank));
     return hipGetLastError();
 }
 hipError_t sml_launch_eval_metrics(const int32_t* rank, int64_t n, int topk, float* out, hipStream_t st) {

@@ -283,13 +283,37 @@ class HipEngine(object):
         return ue, ie, sc
 
     # ------------------------------------------------------------------ a13
-    def eval_ranks(self, user_tab, item_tab, rows):
+    BLOCKED_EVAL_MIN_ITEM_BYTES = 6 << 20   # L2-block the evaluation once the item table outgrows an XCD's 4 MB L2
+
+    def _blocked_rows(self, rows, n_item):
+        """Candidates of `rows` grouped by item range (built once per test set, kept while the tensor lives)."""
+        key = (rows.data_ptr(), tuple(rows.shape), int(n_item))
+        cache = self.__dict__.setdefault("_eval_blocked", {})
+        hit = cache.get(key)
+        if hit is None:
+            if len(cache) >= 3:
+                cache.pop(next(iter(cache)))
+            rows_b = torch.empty_like(rows)
+            off = torch.empty((rows.shape[0], 9), device=self.device, dtype=torch.int32)
+            check(self.lib.sml_eval_prepare(self._ctx, _ptr(rows), rows.shape[0], rows.shape[1], int(n_item), _ptr(rows_b),
+                                            _ptr(off), self._stream()), "sml_eval_prepare")
+            hit = cache[key] = (rows_b, off, rows)     # keeps `rows` alive: the key is its address
+        return hit[0], hit[1]
+
+    def eval_ranks(self, user_tab, item_tab, rows, blocked=None):
         wu, wi = self._table(user_tab), self._table(item_tab)
         rows = self._dev(rows, torch.int64)
         n, c = rows.shape
         rank = torch.empty(n, device=self.device, dtype=torch.int32)
-        check(self.lib.sml_eval_ranks(self._ctx, _ptr(wu), _ptr(wi), _ptr(rows), n, c, _ptr(rank), self._stream()),
-              "sml_eval_ranks")
+        if blocked is None:
+            blocked = wi.numel() * 4 >= self.BLOCKED_EVAL_MIN_ITEM_BYTES and n * c >= (1 << 22)
+        if blocked:
+            rows_b, off = self._blocked_rows(rows, wi.shape[0])
+            check(self.lib.sml_eval_ranks_blocked(self._ctx, _ptr(wu), _ptr(wi), _ptr(rows_b), _ptr(off), n, c,
+                                                  _ptr(rank), self._stream()), "sml_eval_ranks_blocked")
+        else:
+            check(self.lib.sml_eval_ranks(self._ctx, _ptr(wu), _ptr(wi), _ptr(rows), n, c, _ptr(rank), self._stream()),
+                  "sml_eval_ranks")
         return rank
 
     def eval_async(self, user_tab, item_tab, rows, topk):

@@ -547,3 +547,18 @@ def test_stages_at_wider_tables_vs_oracle(d):
     adam_close(g[3], o[3], 0.01, 3)
     for k in o[4]:
         adam_close(g[4][k], o[4][k], 1e-3, 3)
+
+
+@pytest.mark.parametrize("d,neg,I", [(32, 999, 123000), (64, 99, 50000), (32, 7, 5)])
+def test_blocked_eval_equals_plain_eval(d, neg, I):
+    """The L2-blocked evaluation (candidates bucketed by item range, one range per XCD) returns exactly
+    the ranks of the plain kernel."""
+    torch.manual_seed(d + neg)
+    U, n = 700, 1031
+    wu, wi = torch.randn(U, d).to(DEV), torch.randn(I, d).to(DEV)
+    rows = torch.cat([torch.randint(0, U, (n, 1)), torch.randint(0, I, (n, 1 + neg))], 1).to(DEV)
+    eng = engine(d)
+    plain = eng.eval_ranks(wu, wi, rows, blocked=False)
+    blk = eng.eval_ranks(wu, wi, rows, blocked=True)
+    assert torch.equal(plain, blk)
+    assert torch.equal(blk, eng.eval_ranks(wu, wi, rows, blocked=True))       # cached buckets, repeatable
