@@ -95,7 +95,7 @@ typedef struct {
     const float* last_item;/* last_item_weight  W_{t-1} [I,d] */
     float* m_user; float* v_user;   /* Adam exp_avg / exp_avg_sq, same shape as the tables */
     float* m_item; float* v_item;
-    int32_t* step_user;    /* [U] last Adam step applied to each row (lazy replay) */
+    int32_t* step_user;    /* [U] last Adam step applied to each row (lazy replay); -1 = never touched (m = v = 0) */
     int32_t* step_item;    /* [I] */
     int64_t n_user, n_item;
 } sml_mf_tables;

@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256) void k_adam_flush(float* __restrict__ w, float
     const int sub = (int)(gid % LPR);
     if (row >= rows) return;
     const int from = last[row];
-    if (from >= cur_step) return;
+    if (from < 0 || from >= cur_step) return;          // never touched (state is zero), or already current
     float p[4], m[4], v[4];
     RowVec<float>::load(w + row * D + sub * 4, p);
     RowVec<float>::load(mt + row * D + sub * 4, m);

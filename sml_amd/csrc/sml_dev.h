@@ -127,6 +127,7 @@ __device__ __forceinline__ void adam_zero_step(float& p, float& m, float& v, Sml
 // replay the zero-gradient steps (from+1 .. to) a dense Adam would have applied
 __device__ __forceinline__ void adam_replay(float& p, float& m, float& v, int from, int to,
                                             const SmlSched* __restrict__ sched) {
+    if (from < 0 || (m == 0.0f && v == 0.0f)) return;
     for (int k = from + 1; k <= to; ++k) adam_zero_step(p, m, v, sched[k]);
 }
 // the same with the most recent SML_SW schedule entries staged in LDS (win[i] = sched[wbase + i]):
@@ -139,6 +140,9 @@ __device__ __forceinline__ void sched_window_load(SmlSched* win, const SmlSched*
 }
 __device__ __forceinline__ void adam_replay_w(float& p, float& m, float& v, int from, int to,
                                               const SmlSched* __restrict__ sched, const SmlSched* win, int upto) {
+    // from < 0: the row was never touched.  m = v = 0: every zero-gradient step leaves p, m, v exactly
+    // unchanged (m - 0.1*0 = 0, 0.999*0 = 0, p - c*0 = p), so there is nothing to replay.
+    if (from < 0 || (m == 0.0f && v == 0.0f)) return;
     const int wbase = upto - SML_SW + 1;
     for (int k = from + 1; k <= to; ++k) adam_zero_step(p, m, v, k >= wbase ? win[k - wbase] : sched[k]);
 }

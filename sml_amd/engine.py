@@ -124,8 +124,9 @@ class HipEngine(object):
         if self.mf_state is None or self.mf_state["m_u"].shape != wu.shape or self.mf_state["m_i"].shape != wi.shape:
             z = lambda t: torch.zeros_like(t)
             self.mf_state = dict(m_u=z(wu), v_u=z(wu), m_i=z(wi), v_i=z(wi),
-                                 s_u=torch.full((wu.shape[0],), self.mf_step, device=self.device, dtype=torch.int32),
-                                 s_i=torch.full((wi.shape[0],), self.mf_step, device=self.device, dtype=torch.int32))
+                                 # -1: never touched (m = v = 0: nothing to replay, nothing to flush)
+                                 s_u=torch.full((wu.shape[0],), -1, device=self.device, dtype=torch.int32),
+                                 s_i=torch.full((wi.shape[0],), -1, device=self.device, dtype=torch.int32))
         s = self.mf_state
         t = _lib.MFTables()
         t.w_user, t.w_item = wu.data_ptr(), wi.data_ptr()
