@@ -49,20 +49,23 @@ __device__ __forceinline__ int64_t seg_row_index(const SmlSeg& s, int r) {
 }
 
 // acc[mt][t] += A(MT x 16 rows x 16*NK, LDS) * B(image tiles).  B operand images are prefetched
-// PFD k-steps ahead in a register ring; the loop is fully unrolled so ring indices are static.
+// PFD k-steps ahead in a register ring.  The k loop runs in chunks of PFD steps: the chunk body is
+// unrolled (static ring indices), the chunk loop is NOT, which bounds the live weight registers to the
+// ring (a fully unrolled loop lets the compiler hoist every load of a 32-step reduction to the top).
 //   arow : this lane's LDS pointer (row l&15, column 4*(l>>4)); M-tile mt is a_mt floats further
 //   bimg : tile t, k-step ks at bimg[(tile_of(t) * ksteps_total + ks0 + ks) * 64 + lane]
 template <int MT, int NT, int NK, int PFD, typename TileOf>
 __device__ __forceinline__ void mma16_rows(f32x4 (&acc)[MT][NT], const float* arow, int a_mt,
                                            const f32x4* __restrict__ bimg, int ksteps_total, int ks0, int lane,
                                            TileOf tile_of) {
+    static_assert(PFD >= 1 && PFD <= NK, "ring depth");
+    constexpr int NCH = NK / PFD, REM = NK % PFD;
     f32x4 ring[PFD][NT];
 #pragma unroll
-    for (int i = 0; i < PFD && i < NK; ++i)
+    for (int i = 0; i < PFD; ++i)
 #pragma unroll
         for (int t = 0; t < NT; ++t) ring[i][t] = bimg[(tile_of(t) * ksteps_total + ks0 + i) * 64 + lane];
-#pragma unroll
-    for (int ks = 0; ks < NK; ++ks) {
+    auto step = [&](int ks, int slot, bool refill) {
         f32x4 av[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(arow + mt * a_mt + (ks0 + ks) * 16);
@@ -71,13 +74,20 @@ __device__ __forceinline__ void mma16_rows(f32x4 (&acc)[MT][NT], const float* ar
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[mt][t] = mfma16(av[mt][e], ring[ks % PFD][t][e], acc[mt][t]);
-        if (ks + PFD < NK) {
+                for (int e = 0; e < 4; ++e) acc[mt][t] = mfma16(av[mt][e], ring[slot][t][e], acc[mt][t]);
+        if (refill) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                ring[ks % PFD][t] = bimg[(tile_of(t) * ksteps_total + ks0 + ks + PFD) * 64 + lane];
+                ring[slot][t] = bimg[(tile_of(t) * ksteps_total + ks0 + ks + PFD) * 64 + lane];
         }
+    };
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll
+        for (int j = 0; j < PFD; ++j) step(ch * PFD + j, j, ch * PFD + j + PFD < NK);
     }
+#pragma unroll
+    for (int j = 0; j < REM; ++j) step(NCH * PFD + j, j, false);
 }
 
 template <int MT, int NT>
@@ -204,7 +214,7 @@ __global__ __launch_bounds__(512) void k_transfer_fwd(SmlFwdArgs a) {
     {
         f32x4 acc[MT][4];
         zero_acc(acc);
-        mma16_rows<MT, 4, KS1, 2>(acc, A1s + l15 * S1 + 4 * g4, SML_TM * S1,
+        mma16_rows<MT, 4, KS1, (MT == 1 ? 5 : 2)>(acc, A1s + l15 * S1 + 4 * g4, SML_TM * S1,
                                   reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p1(D)), KS1, 0, lane,
                                   [wv](int t) { return wv * 4 + t; });
         // + bias, save z1, Gelu -> a2 tile.  (xts/nrm are dead: every wave passed the barrier above)
@@ -419,7 +429,7 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
         const int kq = wv % KSPL, tq = wv / KSPL;
         f32x4 acc[MT][5];
         zero_acc(acc);
-        mma16_rows<MT, 5, KPER, 2>(acc, dZs + l15 * S2 + 4 * g4, SML_TM * S2,
+        mma16_rows<MT, 5, KPER, 4>(acc, dZs + l15 * S2 + 4 * g4, SML_TM * S2,
                                    reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p1b(D)), 32, kq * KPER, lane,
                                    [tq](int t) { return tq * 5 + t; });
         __syncthreads();                        // every wave is done reading dZs
