@@ -214,11 +214,13 @@ int sml_prof_get(sml_ctx* ctx, int cls, int64_t* count, double* total_ms);
  * data/dataset.py:63-71) over a pre-drawn candidate stream, on the HOST (no GPU involved):
  * element e takes candidates cand[ptr], cand[ptr+1], ... until one is not an item of user[e]
  * ((user,item) pairs given sorted as user*stride+item), exactly as the per-item loop consumes the
- * random stream.  *consumed = candidates used.  Returns SML_ESTATE if the stream runs out
- * (the caller draws a longer one and retries). */
+ * random stream.  *consumed = candidates used, *resolved = elements that got their negative; when
+ * the stream runs out first (*resolved < n, *consumed == m) the caller continues from element
+ * *resolved with the next draws.  Drawing exactly as many candidates as there are unresolved
+ * elements per call therefore consumes the generator exactly as the per-item loop does. */
 int sml_host_resolve_negatives(const int64_t* users, int64_t n, const int64_t* cand, int64_t m,
                                const int64_t* pairs_sorted, int64_t n_pairs, int64_t stride,
-                               int64_t* negs, int64_t* consumed);
+                               int64_t* negs, int64_t* consumed, int64_t* resolved);
 
 /* ---- self test ------------------------------------------------------------------ */
 /* Checks the MFMA operand/accumulator lane maps this library assumes against a

@@ -79,7 +79,8 @@ SIGNATURES = {
     "sml_prof_name": (ctypes.c_char_p, [ctypes.c_int]),
     "sml_prof_get": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]),
     "sml_host_resolve_negatives": (ctypes.c_int, [c_void, ctypes.c_int64, c_void, ctypes.c_int64, c_void, ctypes.c_int64,
-                                                  ctypes.c_int64, c_void, ctypes.POINTER(ctypes.c_int64)]),
+                                                  ctypes.c_int64, c_void, ctypes.POINTER(ctypes.c_int64),
+                                                  ctypes.POINTER(ctypes.c_int64)]),
     "sml_selftest": (ctypes.c_int, [ctypes.c_int]),
 }
 

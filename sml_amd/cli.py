@@ -93,6 +93,10 @@ def main(which, argv=None):
     args = get_parse(which).parse_args(argv)
     if which == "yelp" and "LOCAL_RANK" not in os.environ:
         os.environ["CUDA_VISIBLE_DEVICES"] = str(args.cuda)      # reference main_yelp.py:125
+    # The host side of this process only draws random numbers and slices index arrays; torch's CPU
+    # thread pool costs tens of ms per randperm(n > 32768) to wake (it splits the arange fill), so keep
+    # host torch ops on the calling thread.  Results do not depend on the thread count.
+    torch.set_num_threads(int(os.environ.get("SML_HOST_THREADS", "1")))
     if which == "yelp":
         print("###(multi num,l2)", 10, 1e-06)                     # the reference's (unused) sweep banner
     # seeding order of the reference (main_yelp.py:137-139)

@@ -746,22 +746,23 @@ int sml_prof_get(sml_ctx* ctx, int cls, int64_t* count, double* total_ms) {
 
 int sml_host_resolve_negatives(const int64_t* users, int64_t n, const int64_t* cand, int64_t m,
                                const int64_t* pairs, int64_t n_pairs, int64_t stride, int64_t* negs,
-                               int64_t* consumed) {
-    if (!users || !cand || !pairs || !negs || !consumed || n < 0 || m < 0 || n_pairs < 0 || stride <= 0)
+                               int64_t* consumed, int64_t* resolved) {
+    if (!users || !cand || !pairs || !negs || !consumed || !resolved || n < 0 || m < 0 || n_pairs < 0 || stride <= 0)
         return fail(SML_EINVAL, "sml_host_resolve_negatives", "bad argument");
-    int64_t ptr = 0;
-    for (int64_t e = 0; e < n; ++e) {
-        for (;;) {
-            if (ptr >= m) { *consumed = ptr; return fail(SML_ESTATE, "sml_host_resolve_negatives", "candidate stream exhausted"); }
-            const int64_t code = users[e] * stride + cand[ptr];
+    int64_t ptr = 0, e = 0;
+    for (; e < n; ++e) {
+        bool placed = false;
+        while (ptr < m) {
+            const int64_t c = cand[ptr++];
+            const int64_t code = users[e] * stride + c;
             int64_t lo = 0, hi = n_pairs;                      // is (user, candidate) one of the user's own pairs?
             while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (pairs[mid] < code) lo = mid + 1; else hi = mid; }
-            const bool own = lo < n_pairs && pairs[lo] == code;
-            ++ptr;
-            if (!own) { negs[e] = cand[ptr - 1]; break; }
+            if (!(lo < n_pairs && pairs[lo] == code)) { negs[e] = c; placed = true; break; }
         }
+        if (!placed) break;                                    // stream ran out inside element e
     }
     *consumed = ptr;
+    *resolved = e;
     return SML_OK;
 }
 

@@ -127,10 +127,10 @@ class offlineDataset_withsample(Dataset):
     def epoch_triples(self, order):
         """Same triples, and same numpy global-RNG end state, as calling __getitem__ for every
         index of `order` in turn.  np.random.choice(a, 1) is one legacy randint(0, len(a)) draw and a
-        block of such draws is the same stream, so the candidates are drawn in one block and the
-        sequential accept/reject walk over them runs in compiled code (sml_host_resolve_negatives,
-        a host-side helper of libsml_hip.so); the generator is then re-positioned to exactly the
-        number of draws the walk consumed."""
+        block of such draws is the same stream, so candidates are drawn in blocks and the sequential
+        accept/reject walk over them runs in compiled code (sml_host_resolve_negatives, a host-side
+        helper of libsml_hip.so).  Each block holds exactly one candidate per still-unresolved element
+        -- every one of which the per-item loop would draw too -- so the generator ends where it would."""
         import ctypes
         from . import _lib
         lib = _lib.load()
@@ -140,21 +140,20 @@ class offlineDataset_withsample(Dataset):
         pop = self.item_all.shape[0]
         items_all = np.ascontiguousarray(self.item_all, dtype=np.int64)
         pairs = np.ascontiguousarray(self._pairs, dtype=np.int64)
-        state0 = np.random.get_state()
-        m = n + 64 + n // 4
         negs = np.empty(n, dtype=np.int64)
-        used = ctypes.c_int64(0)
-        while True:
-            cand = np.ascontiguousarray(items_all[np.random.randint(0, pop, size=m)])
-            rc = lib.sml_host_resolve_negatives(users.ctypes.data, n, cand.ctypes.data, m, pairs.ctypes.data,
-                                                pairs.shape[0], self._stride, negs.ctypes.data, ctypes.byref(used))
-            np.random.set_state(state0)
-            if rc == 0:
-                break
-            if m > 64 * (n + 64):
+        used, got = ctypes.c_int64(0), ctypes.c_int64(0)
+        done, drawn = 0, 0
+        while done < n:
+            k = n - done
+            cand = np.ascontiguousarray(items_all[np.random.randint(0, pop, size=k)])
+            rc = lib.sml_host_resolve_negatives(users.ctypes.data + 8 * done, k, cand.ctypes.data, k,
+                                                pairs.ctypes.data, pairs.shape[0], self._stride,
+                                                negs.ctypes.data + 8 * done, ctypes.byref(used), ctypes.byref(got))
+            _lib.check(rc, "sml_host_resolve_negatives")
+            done += got.value
+            drawn += k
+            if drawn > 64 * (n + 64):
                 raise RuntimeError("negative sampling does not terminate: a user owns (almost) every item")
-            m *= 4
-        np.random.randint(0, pop, size=used.value)      # leave the generator where the per-item loop would
         return np.stack([users, self.item[order].astype(np.int64), negs], axis=1)
 
 

@@ -41,6 +41,22 @@ def _np(x):
     return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
 
 
+class _Lazy(object):
+    """A number that is still being computed on the device; resolved when a line is printed."""
+
+    def __init__(self, fn):
+        self._fn, self._done, self._v = fn, False, None
+
+    def get(self):
+        if not self._done:
+            self._v, self._done, self._fn = self._fn(), True, None
+        return self._v
+
+
+def _val(x):
+    return x.get() if isinstance(x, _Lazy) else x
+
+
 class _OptimizerInfo(object):
     """What the reference exposes as MF_optimizer / transfer_optimizer, reduced to the
     hyper-parameters; the Adam state itself lives in the engine."""
@@ -143,9 +159,41 @@ class meta_train(object):
             self._rank_cache = hit = (key, ranks)
         return hit[1]
 
-    def _metrics(self, ranks, n, topK):
-        hits, ndcg = self.engine.eval_metrics(ranks, topK)
+    # -- deferred output.  Inside train_one_stage3 nothing the host does (random draws, batch building,
+    # launches) depends on device results, so lines are queued with lazy numbers and printed, in the
+    # reference's order, when the stage ends: the host never waits for the device mid-stage.
+    def _emit(self, fn, *args):
+        if getattr(self, "_defer", False):
+            self._queue.append((fn, args))
+        else:
+            fn(*[_val(a) for a in args])
+
+    def _flush_output(self):
+        q, self._queue = getattr(self, "_queue", []), []
+        for fn, args in q:
+            fn(*[_val(a) for a in args])
+
+    def _pair(self, resolve, n):
+        """(recall, ndcg) from a (hits, ndcg_sum) resolver; lazy while output is deferred."""
+        if getattr(self, "_defer", False):
+            box = _Lazy(resolve)
+            return (_Lazy(lambda: box.get()[0] / n), _Lazy(lambda: torch.tensor(np.float32(box.get()[1] / n))))
+        hits, ndcg = resolve()
         return hits / n, torch.tensor(np.float32(ndcg / n))
+
+    def _metrics(self, ranks, n, topK):
+        if hasattr(self.engine, "eval_metrics_device"):
+            out = self.engine.eval_metrics_device(ranks, topK)
+
+            def resolve():
+                h = out.cpu()
+                return float(h[0]), float(h[1])
+        else:
+            res = self.engine.eval_metrics(ranks, topK)
+
+            def resolve():
+                return res
+        return self._pair(resolve, n)
 
     def _test(self, rows, topK):
         """recall@K, ndcg@K of the current tables on `rows` (reference evalution/evaluation2.py:8-26)."""
@@ -154,6 +202,31 @@ class meta_train(object):
         out = self._metrics(self._ranks(rows), rows.rows.shape[0], topK)
         self.timing["eval"] += time.time() - t0
         return out
+
+    def _sample_dataset(self, arr):
+        """SampleDaset(arr), built once per array (it holds no state that changes between epochs; the
+        reference rebuilds it every phase).  Its constructor's "user max:" lines are replayed on every
+        call, in order with the rest of the (possibly deferred) output."""
+        import contextlib
+        import io
+        hit = getattr(self, "_sample_cache", None)
+        if hit is None or hit[0] is not arr:
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                obj = SampleDaset(arr)
+            hit = self._sample_cache = (arr, obj, buf.getvalue())
+        text = hit[2]
+        self._emit(lambda: print(text, end=""))
+        return hit[1]
+
+    @staticmethod
+    def _epoch_loss(losses):
+        """mean of the batch losses, accumulated in fp32 like the reference's `loss_all += loss.data`."""
+        acc = np.float32(0)
+        arr = _np(losses).astype(np.float32)
+        for l in arr:
+            acc = np.float32(acc + l)
+        return float(np.float32(acc / np.float32(len(arr))))
 
     # ------------------------------------------------------------------ hot loop 1
     def MF_train_onestage(self, args, set_t, stage_id, val=None):
@@ -164,11 +237,11 @@ class meta_train(object):
         self.transfer.eval()
         if val is not None:
             val = self._rows(val)
-        print("******MF (inner) training ******")
+        self._emit(lambda: print("******MF (inner) training ******"))
         train_set = self.MF_TrainDataset(set_t)
         if val is not None:
             recall, ndcg = self._test(val, args.topK)
-            print("before train MF test:recall:{:.4f} ndcg:{:.4f}".format(recall, ndcg))
+            self._emit(lambda r, n: print("before train MF test:recall:{:.4f} ndcg:{:.4f}".format(r, n)), recall, ndcg)
             self._log_mf(args, recall, ndcg, None)
         for epoch in range(args.MF_epochs):
             self.MFbase.train()
@@ -181,24 +254,23 @@ class meta_train(object):
                                                 args.MF_lr, args.l2, norm=args.norm, bce=True)
             self.engine.mf_flush(self.MFbase)
             self._touch_tables()
-            losses = _np(losses)
             self.timing["mf"] += time.time() - t0
             self.timing["mf_triples"] += triples.shape[0]
-            loss_all = np.float32(0)
-            for l in losses.astype(np.float32):
-                loss_all = np.float32(loss_all + l)
-            loss_all = float(np.float32(loss_all / np.float32(len(losses)))) / args.MF_batch_size
+            bs = args.MF_batch_size
+            loss_all = _Lazy(lambda losses=losses, bs=bs: self._epoch_loss(losses) / bs)
             if val is not None:
                 recall, ndcg = self._test(val, args.topK)
-                print("MF-stage:", stage_id, "epoch:", epoch, "loss:{:.5f}".format(loss_all),
-                      "recall:{:.4f}".format(recall), "ndcg:{:.4f}".format(ndcg))
+                self._emit(lambda l, r, n, epoch=epoch: print("MF-stage:", stage_id, "epoch:", epoch, "loss:{:.5f}".format(l),
+                                                              "recall:{:.4f}".format(r), "ndcg:{:.4f}".format(n)),
+                           loss_all, recall, ndcg)
                 self._log_mf(args, recall, ndcg, loss_all)
             else:
-                print("MF-stage:", stage_id, "epoch:", epoch, "loss:", loss_all)
+                self._emit(lambda l, epoch=epoch: print("MF-stage:", stage_id, "epoch:", epoch, "loss:", l), loss_all)
 
     def _log_mf(self, args, recall, ndcg, loss):
         if self.writer is None:
             return
+        recall, ndcg, loss = _val(recall), _val(ndcg), _val(loss)
         self.writer.add_scalar("Acc/MF-recall" + str(args.topK), recall, self.MF_itr)
         self.writer.add_scalar("Acc/MF-ndcg" + str(args.topK), float(ndcg), self.MF_itr)
         if loss is not None:
@@ -213,11 +285,11 @@ class meta_train(object):
         if args.clip_grad:
             raise NotImplementedError("--clip_grad is marked 'not used in the final version' by the reference "
                                       "and is outside this build's scope")
-        print("********* this is Transfer model training stage ***********")
+        self._emit(lambda: print("********* this is Transfer model training stage ***********"))
         self.MFbase.eval()
         now_test = None
         if self.TR_train_sampleTYpe == "alone":
-            train_set = SampleDaset(set_tt)
+            train_set = self._sample_dataset(set_tt)
             compute_performance = False
             if val is not None:
                 now_test = self._rows(val)
@@ -229,10 +301,10 @@ class meta_train(object):
         else:
             raise TypeError("no such TR sample type")
         def report_before(recall, ndcg):
-            print("before train transfer test:recall:{:.4f} ndcg:{:.4f}".format(recall, ndcg))
+            self._emit(lambda r, n: print("before train transfer test:recall:{:.4f} ndcg:{:.4f}".format(r, n)), recall, ndcg)
             if self.writer is not None:
-                self.writer.add_scalar("Acc/tr-TR-recall@" + str(args.topK), recall, self.TR_itr)
-                self.writer.add_scalar("Acc/tr-TR-ndcg@" + str(args.topK), float(ndcg), self.TR_itr)
+                self.writer.add_scalar("Acc/tr-TR-recall@" + str(args.topK), _val(recall), self.TR_itr)
+                self.writer.add_scalar("Acc/tr-TR-ndcg@" + str(args.topK), float(_val(ndcg)), self.TR_itr)
                 self.TR_itr += 1
 
         pending = None
@@ -257,33 +329,31 @@ class meta_train(object):
                                                 self.user_weight_hat, self.item_weight_hat, triples,
                                                 args.TR_batch_size, args.TR_lr, args.TR_l2, bce=True)
             if pending is not None:
-                hits, ndcg = self.engine.eval_result(pending)
-                self._rank_cache = ((id(now_test), getattr(self, "_version", 0)), pending[2])
-                pending = None
-                n_rows = now_test.rows.shape[0]
-                report_before(hits / n_rows, torch.tensor(np.float32(ndcg / n_rows)))
-            losses = _np(losses)
+                handle, pending = pending, None
+                self.engine.eval_join(handle)
+                self._rank_cache = ((id(now_test), getattr(self, "_version", 0)), handle[2])
+                report_before(*self._pair(lambda h=handle: self.engine.eval_result(h), now_test.rows.shape[0]))
             self.timing["tr"] += time.time() - t0
             self.timing["tr_triples"] += triples.shape[0]
-            loss_all = np.float32(0)
-            for l in losses.astype(np.float32):
-                loss_all = np.float32(loss_all + l)
-            loss_all = float(np.float32(loss_all / np.float32(len(losses))))
-            print("one epcohs TR time cost:", time.time() - s_time)
+            bs = args.TR_batch_size
+            loss_all = _Lazy(lambda losses=losses: self._epoch_loss(losses))
+            self._emit(lambda dt: print("one epcohs TR time cost:", dt), time.time() - s_time)
             if self.writer is not None:
-                self.writer.add_scalar("Loss/TR-loss", loss_all / args.TR_batch_size, self.TR_itr)
+                self.writer.add_scalar("Loss/TR-loss", _val(loss_all) / bs, self.TR_itr)
             if compute_performance:
                 self.updata()
                 recall, ndcg = self._test(now_test, args.topK)
                 # (the full-width punctuation is the reference's, model/transfer.py:741)
-                print("stage:{}, epcoh：{}，loss:{:.4f},*****val result  reacll:{:.4f}  ndcg:{:.4f}".format(
-                    stage_id, epoch, loss_all / args.TR_batch_size, recall, ndcg))
+                self._emit(lambda l, r, n, epoch=epoch: print(
+                    "stage:{}, epcoh：{}，loss:{:.4f},*****val result  reacll:{:.4f}  ndcg:{:.4f}".format(
+                        stage_id, epoch, l / bs, r, n)), loss_all, recall, ndcg)
                 if self.writer is not None:
-                    self.writer.add_scalar("Acc/tr-TR-recall@" + str(args.topK), recall, self.TR_itr)
-                    self.writer.add_scalar("Acc/tr-TR-ndcg@" + str(args.topK), float(ndcg), self.TR_itr)
+                    self.writer.add_scalar("Acc/tr-TR-recall@" + str(args.topK), _val(recall), self.TR_itr)
+                    self.writer.add_scalar("Acc/tr-TR-ndcg@" + str(args.topK), float(_val(ndcg)), self.TR_itr)
             else:
-                print("stage:", stage_id, "epoch:", epoch, "transfer train loss:", loss_all / args.TR_batch_size)
-        print("stage ", stage_id, " transfer trained finished!!!!")
+                self._emit(lambda l, epoch=epoch: print("stage:", stage_id, "epoch:", epoch, "transfer train loss:", l / bs),
+                           loss_all)
+        self._emit(lambda: print("stage ", stage_id, " transfer trained finished!!!!"))
 
     # ------------------------------------------------------------------ one period
     def _real_test(self, now_test):
@@ -293,9 +363,12 @@ class meta_train(object):
         for k, tag, rl, nl in ((20, "", self.recall, self.ndcg), (10, "@10 ", self.recall_10, self.ndcg_10),
                                (5, "@5 ", self.recall_5, self.ndcg_5)):
             recall, ndcg = self._test(rows, k)
-            print("test result --------- {}reacll:{:.4f}  ndcg:{:.4f}".format(tag, recall, ndcg))
-            rl.append(recall)
-            nl.append(ndcg.cpu().numpy())
+
+            def show(r, n, tag=tag, rl=rl, nl=nl):
+                print("test result --------- {}reacll:{:.4f}  ndcg:{:.4f}".format(tag, r, n))
+                rl.append(r)
+                nl.append(n.cpu().numpy())
+            self._emit(show, recall, ndcg)
 
     def train_one_stage3(self, args, stage_id):
         """One period of SML (reference model/transfer.py:753-881).  False when no data is left."""
@@ -303,18 +376,26 @@ class meta_train(object):
         set_t, set_tt, now_test, val = self.get_next_data(stage_id)
         if set_t is None:
             return False
+        self._defer, self._queue = self.writer is None, []
+        try:
+            return self._stage_body(args, stage_id, set_t, set_tt, now_test, val)
+        finally:
+            self._defer = False
+            self._flush_output()
+
+    def _stage_body(self, args, stage_id, set_t, set_tt, now_test, val):
         if now_test is not None and set_tt is None:
             # --TR_stop_: theta frozen during the test periods
             s_time = time.time()
-            print("stop train transfer while test###!!!!!")
+            self._emit(lambda: print("stop train transfer while test###!!!!!"))
             args.MF_epochs = 2
             self.MF_train_onestage(args, set_t, stage_id, val=val)
             self.MFbase.eval()
             self.save_MF_weight(save_as='hat')
             self.updata()
-            print("only traning time cost:", time.time() - s_time)
+            self._emit(lambda dt: print("only traning time cost:", dt), time.time() - s_time)
             self._real_test(now_test)
-            print("include test time cost:", time.time() - s_time)
+            self._emit(lambda dt: print("include test time cost:", dt), time.time() - s_time)
             return True
         for phase in range(args.multi_num):
             self.MF_train_onestage(args, set_t, stage_id, val=val)

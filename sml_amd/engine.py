@@ -63,7 +63,12 @@ class HipEngine(object):
 
     def _dev(self, t, dtype):
         if isinstance(t, np.ndarray):
+            # pinned staging (torch's caching host allocator) + an asynchronous copy: a pageable upload
+            # would make the host wait for everything already queued on the stream
             t = torch.from_numpy(np.ascontiguousarray(t))
+            if t.dtype != dtype:
+                t = t.to(dtype)
+            return t.pin_memory().to(device=self.device, non_blocking=True)
         t = t.to(device=self.device, dtype=dtype)
         return t if t.is_contiguous() else t.contiguous()
 
@@ -336,17 +341,26 @@ class HipEngine(object):
             t.record_stream(self._side)
         return (out, ev, ranks)
 
+    def eval_join(self, handle):
+        """Order the current stream after a queued evaluation (device-side wait, the host does not block):
+        call it before queueing anything that writes the tables the evaluation reads."""
+        torch.cuda.current_stream(self.device).wait_event(handle[1])
+
     def eval_result(self, handle):
         out, ev, _ = handle
         ev.synchronize()
         h = out.cpu()
         return float(h[0]), float(h[1])
 
-    def eval_metrics(self, ranks, topk):
+    def eval_metrics_device(self, ranks, topk):
+        """(hits, ndcg_sum) as a 2-float DEVICE tensor: no synchronisation."""
         out = torch.empty(2, device=self.device, dtype=torch.float32)
         check(self.lib.sml_eval_metrics(self._ctx, _ptr(ranks), ranks.shape[0], int(topk), _ptr(out), self._stream()),
               "sml_eval_metrics")
-        h = out.cpu()
+        return out
+
+    def eval_metrics(self, ranks, topk):
+        h = self.eval_metrics_device(ranks, topk).cpu()
         return float(h[0]), float(h[1])
 
     # ------------------------------------------------------------------ native RCCL exchange

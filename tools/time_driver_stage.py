@@ -36,8 +36,10 @@ class Periods(object):
 
 def main():
     n_stage = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    profile = len(sys.argv) > 2 and sys.argv[2] == "--profile"
     U, I, n, neg, d = 60000, 123000, 75000, 999, 32
     args = cli.get_parse("yelp").parse_args(["--laten", str(d), "--numworkers", "0"])
+    torch.set_num_threads(1)          # as cli.main does
     torch.manual_seed(0)
     np.random.seed(1)
     mf = MFbasemode(U, I, d)
@@ -49,7 +51,13 @@ def main():
     data = Periods(n_stage, n, U, I, neg)
     with contextlib.redirect_stdout(io.StringIO()):
         meta = meta_train(args, data, U, I, d)
+    prof = None
+    if profile:
+        import cProfile
+        prof = cProfile.Profile()
     for s in range(n_stage):
+        if prof is not None and s == n_stage - 1:
+            prof.enable()
         torch.cuda.synchronize()
         t0 = time.time()
         with contextlib.redirect_stdout(io.StringIO()):
@@ -58,6 +66,11 @@ def main():
         dt = time.time() - t0
         print("stage %d: %.3f s wall; engine calls mf %.3f tr %.3f updata %.3f eval %.3f (cumulative, host view)"
               % (s, dt, meta.timing["mf"], meta.timing["tr"], meta.timing["updata"], meta.timing["eval"]))
+
+    if prof is not None:
+        import pstats
+        prof.disable()
+        pstats.Stats(prof).sort_stats("cumulative").print_stats(28)
 
 
 if __name__ == "__main__":
