@@ -189,18 +189,35 @@ int ensure_sched(sml_ctx* c, float lr, int64_t upto) {
 int tiles_of(int rows) { return (rows + SML_R - 1) / SML_R; }          // 32-row padding units
 int wg_tiles(int rows, int mt) { const int r = SML_TM * mt; return (rows + r - 1) / r; }   // workgroups
 
+// Geometry policy of the training kernels.  A batch whose row tiles cannot fill the 256 CUs is
+// latency-bound on the per-tile chain: split the hidden dimension of the forward over 4 (or 2)
+// workgroups per row tile and the backward over d/16 coordinate slices.  Once the row tiles alone
+// fill the chip the splits only repeat the gather/prologue work, so large batches keep one
+// workgroup per tile.  (SML_FWD_NS / SML_BWD_SPLIT override the policy for measurements.)
+int env_int(const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; }
+int fwd_split(int row_tiles) {
+    const int forced = env_int("SML_FWD_NS", 0);
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
+    return row_tiles <= 64 ? 4 : row_tiles <= 128 ? 2 : 1;
+}
+int bwd_split(int row_tiles) {
+    const int forced = env_int("SML_BWD_SPLIT", -1);
+    if (forced == 0 || forced == 1) return forced;
+    return row_tiles <= 128 ? 1 : 0;
+}
+
 // slot layout of a batch: users at [0, B), items at [ioff, ioff + 2B), ioff = B rounded up to a
 // tile; both runs padded to whole tiles so the kernels store tile rows unconditionally
 int ensure_transfer_ws(sml_ctx* c, int B, bool tr_stage) {
     const size_t slots = (size_t)SML_R * (tiles_of(B) + tiles_of(2 * B)), d = (size_t)c->d;
-    HIPCHK(c->out.ensure(slots * d));
+    HIPCHK(c->out.ensure(slots * d * SML_FWD_NS));     // the training forward writes SML_FWD_NS partial planes
     HIPCHK(c->dout.ensure(slots * d));
     HIPCHK(c->xin.ensure(slots * 3 * d));
     HIPCHK(c->z1.ensure(slots * SML_HID));
     if (tr_stage) {
         HIPCHK(c->a1.ensure(slots * SML_C2 * d));
         HIPCHK(c->dz1.ensure(slots * SML_HID));
-        HIPCHK(c->convg.ensure((slots / SML_TM + 4) * SML_CG));
+        HIPCHK(c->convg.ensure((slots / SML_TM + 4) * (d / 16) * SML_CG));   // one partial per backward workgroup
         HIPCHK(c->grad.ensure((size_t)2 * sml_net_size(c->d)));
     } else {
         HIPCHK(c->dx.ensure(slots * d));
@@ -308,7 +325,7 @@ int sml_transfer_forward(sml_ctx* ctx, const float* theta, int net, const float*
     const int mt = n_rows > 8192 ? 2 : 1;     // table-sized calls: 32 rows per workgroup halve the weight traffic
     a.tiles0 = wg_tiles((int)n_rows, mt);
     a.seg[1] = s; a.seg[1].n_rows = 0;
-    ctx->prof.begin(PC_FWD, st); HIPCHK(sml_launch_fwd(ctx->d, mt, a, a.tiles0, st)); ctx->prof.end(st);
+    ctx->prof.begin(PC_FWD, st); HIPCHK(sml_launch_fwd(ctx->d, mt, 1, a, a.tiles0, st)); ctx->prof.end(st);
     return SML_OK;
 }
 
@@ -332,7 +349,9 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
     if ((rc = ensure_pk(ctx))) return rc;
     if ((rc = ensure_transfer_ws(ctx, batch, false))) return rc;
     if ((rc = ensure_sched(ctx, lr, *step + nb + 1))) return rc;
-    const int lstride = wg_tiles(batch, 1) + wg_tiles(2 * batch, 1);     // one loss partial per backward workgroup
+    const int lstride = (wg_tiles(batch, 1) + wg_tiles(2 * batch, 1)) * (d / 16);     // one loss partial per backward workgroup
+    const int64_t out_pstride = (int64_t)SML_R * (tiles_of(batch) + tiles_of(2 * batch)) * d;
+    const int fns = fwd_split(wg_tiles(batch, 1) + wg_tiles(2 * batch, 1)), bsplit = bwd_split(wg_tiles(batch, 1) + wg_tiles(2 * batch, 1));
     HIPCHK(ctx->loss_part.ensure((size_t)nb * lstride));
     ctx->prof.begin(PC_PACK, st); HIPCHK(sml_launch_theta_pack(d, theta, ctx->pk.p, st)); ctx->prof.end(st);
     ctx->prof.begin(PC_SORT, st); rc = sort_epoch(&ctx->ix[0], triples, n, batch, 1, st); ctx->prof.end(st); if (rc) return rc;
@@ -357,9 +376,9 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
             sg.out = ctx->out.p + slot0 * d; sg.z1 = ctx->z1.p + slot0 * SML_HID; sg.xin = ctx->xin.p + slot0 * 3 * d;
             sg.a1 = nullptr;
         }
-        f.tiles0 = wg_tiles(B, 1); f.cur_step = cur; f.sched = ctx->sched.p;
+        f.tiles0 = wg_tiles(B, 1); f.cur_step = cur; f.sched = ctx->sched.p; f.out_pstride = out_pstride;
         const int tiles = f.tiles0 + wg_tiles(2 * B, 1);
-        ctx->prof.begin(PC_FWD, st); HIPCHK(sml_launch_fwd(d, 1, f, tiles, st)); ctx->prof.end(st);
+        ctx->prof.begin(PC_FWD, st); HIPCHK(sml_launch_fwd(d, 1, fns, f, tiles, st)); ctx->prof.end(st);
         SmlBwdArgs w;
         memset(&w, 0, sizeof(w));
         for (int s = 0; s < 2; ++s) {
@@ -372,7 +391,8 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
         w.tiles0 = f.tiles0; w.l2 = l2; w.convg_part = nullptr;
         w.out_all = ctx->out.p; w.B = B; w.ioff = SML_R * tiles_of(B); w.kind = loss_kind;
         w.scale = xchg ? xchg->loss_scale : 1.0f; w.loss_part = ctx->loss_part.p + b * lstride;
-        ctx->prof.begin(PC_BWD, st); HIPCHK(sml_launch_bwd(d, 1, w, tiles, st)); ctx->prof.end(st);
+        w.out_np = fns; w.out_pstride = out_pstride;
+        ctx->prof.begin(PC_BWD, st); HIPCHK(sml_launch_bwd(d, bsplit, w, tiles, st)); ctx->prof.end(st);
         SmlSegUpdArgs u;
         memset(&u, 0, sizeof(u));
         u.key_u = ctx->ix[0].key_u2.p + b * batch; u.val_u = ctx->ix[0].val_u2.p + b * batch; u.n_u = B;
@@ -428,7 +448,10 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
     if ((rc = ensure_pk(ctx))) return rc;
     if ((rc = ensure_transfer_ws(ctx, batch, true))) return rc;
     float* grad = theta_grad ? theta_grad : ctx->grad.p;
-    const int lstride = wg_tiles(batch, 1) + wg_tiles(2 * batch, 1);
+    const int fns = fwd_split(wg_tiles(batch, 1) + wg_tiles(2 * batch, 1)), bsplit = bwd_split(wg_tiles(batch, 1) + wg_tiles(2 * batch, 1));
+    const int cs = bsplit ? d / 16 : 1;                                 // backward workgroups per row tile
+    const int lstride = (wg_tiles(batch, 1) + wg_tiles(2 * batch, 1)) * (d / 16);
+    const int64_t out_pstride = (int64_t)SML_R * (tiles_of(batch) + tiles_of(2 * batch)) * d;
     HIPCHK(ctx->loss_part.ensure((size_t)nb * lstride));
     ctx->prof.begin(PC_PACK, st); HIPCHK(sml_launch_theta_pack(d, theta, ctx->pk.p, st)); ctx->prof.end(st);
     HIPCHK(hipMemsetAsync(ctx->loss_part.p, 0, (size_t)nb * lstride * sizeof(float), st));
@@ -449,9 +472,9 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
             sg.out = ctx->out.p + slot0 * d; sg.z1 = ctx->z1.p + slot0 * SML_HID; sg.xin = ctx->xin.p + slot0 * 3 * d;
             sg.a1 = ctx->a1.p + slot0 * SML_C2 * d;
         }
-        f.tiles0 = wg_tiles(B, 1); f.cur_step = 0; f.sched = nullptr;
+        f.tiles0 = wg_tiles(B, 1); f.cur_step = 0; f.sched = nullptr; f.out_pstride = out_pstride;
         const int tiles = f.tiles0 + wg_tiles(2 * B, 1);
-        ctx->prof.begin(PC_FWD, st); HIPCHK(sml_launch_fwd(d, 1, f, tiles, st)); ctx->prof.end(st);
+        ctx->prof.begin(PC_FWD, st); HIPCHK(sml_launch_fwd(d, 1, fns, f, tiles, st)); ctx->prof.end(st);
         SmlBwdArgs w;
         memset(&w, 0, sizeof(w));
         SmlWgArgs wg;
@@ -469,13 +492,14 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
         w.tiles0 = f.tiles0; w.l2 = 0.0f; w.convg_part = ctx->convg.p;
         w.out_all = ctx->out.p; w.B = B; w.ioff = SML_R * tiles_of(B); w.kind = loss_kind;
         w.scale = loss_scale; w.loss_part = ctx->loss_part.p + b * lstride;
-        ctx->prof.begin(PC_BWD, st); HIPCHK(sml_launch_bwd(d, 1, w, tiles, st)); ctx->prof.end(st);
+        w.out_np = fns; w.out_pstride = out_pstride;
+        ctx->prof.begin(PC_BWD, st); HIPCHK(sml_launch_bwd(d, bsplit, w, tiles, st)); ctx->prof.end(st);
         const SmlSched sc = sched_entry((double)lr, *step + 1 + b);
         const bool native = !grad_hook && ctx->comm != nullptr;     // a communicator exists: exchange natively
         if (!grad_hook && !native) {
             // one GPU: the weight-gradient workgroups take the Adam step for the tiles they own
             wg.theta = theta; wg.m = adam_m; wg.v = adam_v; wg.pk = ctx->pk.p;
-            wg.convg_part = ctx->convg.p; wg.tiles0 = f.tiles0; wg.tiles_total = tiles;
+            wg.convg_part = ctx->convg.p; wg.tiles0 = f.tiles0 * cs; wg.tiles_total = tiles * cs;
             wg.weight_decay = weight_decay; wg.step_size = sc.step_size; wg.bc2_sqrt = sc.bc2_sqrt;
             ctx->prof.begin(PC_WGRAD, st); HIPCHK(sml_launch_wgrad(d, wg, st)); ctx->prof.end(st);
         } else {
@@ -483,7 +507,7 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
             SmlThetaAdamArgs ad;
             memset(&ad, 0, sizeof(ad));
             ad.theta = theta; ad.m = adam_m; ad.v = adam_v; ad.grad = grad; ad.pk = ctx->pk.p;
-            ad.convg_part = ctx->convg.p; ad.tiles0 = f.tiles0; ad.tiles_total = tiles;
+            ad.convg_part = ctx->convg.p; ad.tiles0 = f.tiles0 * cs; ad.tiles_total = tiles * cs;
             ad.weight_decay = weight_decay; ad.step_size = sc.step_size; ad.bc2_sqrt = sc.bc2_sqrt;
             ad.grad_only = 1;                  // finish the flat gradient (conv partials), all-reduce, then step
             ctx->prof.begin(PC_THETA_ADAM, st); HIPCHK(sml_launch_theta_adam(d, ad, st)); ctx->prof.end(st);

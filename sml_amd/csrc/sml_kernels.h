@@ -27,7 +27,9 @@ struct SmlFwdArgs {
     int tiles0;              // tiles of seg[0]; the rest belong to seg[1]
     int cur_step;            // Adam step about to be applied (replay runs to cur_step-1)
     const SmlSched* sched;
+    int64_t out_pstride;     // hidden-split forward (NS > 1): floats between the NS partial planes of `out`
 };
+#define SML_FWD_NS 4         // largest hidden-dimension split of the training-batch forward (planes of `out`)
 
 struct SmlBwdSeg {
     const float* theta;
@@ -46,6 +48,7 @@ struct SmlBwdArgs {
     float l2;
     // the pair loss is evaluated here: out rows of the whole batch (u' at t, i' at ioff+t, n' at ioff+B+t)
     const float* out_all; int B; int ioff; int kind; float scale;
+    int out_np; int64_t out_pstride;   // `out_all` is the sum of out_np planes, out_pstride floats apart
     float* loss_part;        // [tiles] this batch's per-workgroup loss partials
     float* convg_part;       // TR stage: [tiles, SML_CG] per-tile compact conv1/conv2 gradient partials; else null
 };
@@ -73,8 +76,10 @@ struct SmlThetaAdamArgs {
     float weight_decay, step_size, bc2_sqrt;
 };
 
-hipError_t sml_launch_fwd(int d, int mt, const SmlFwdArgs& a, int tiles_total, hipStream_t st);   // mt row-tiles of 16 per workgroup
-hipError_t sml_launch_bwd(int d, int mt, const SmlBwdArgs& a, int tiles_total, hipStream_t st);
+// mt row-tiles of 16 per workgroup; ns workgroups share a row tile (1, or SML_FWD_NS with mt = 1)
+hipError_t sml_launch_fwd(int d, int mt, int ns, const SmlFwdArgs& a, int tiles_total, hipStream_t st);
+// split != 0: d/16 workgroups per row tile (coordinate split); 0: one workgroup per row tile
+hipError_t sml_launch_bwd(int d, int split, const SmlBwdArgs& a, int tiles_total, hipStream_t st);
 hipError_t sml_launch_wgrad(int d, const SmlWgArgs& a, hipStream_t st);
 hipError_t sml_launch_theta_adam(int d, const SmlThetaAdamArgs& a, hipStream_t st);
 hipError_t sml_launch_theta_pack(int d, const float* theta, float* pk, hipStream_t st);

@@ -53,32 +53,38 @@ __device__ __forceinline__ int64_t seg_row_index(const SmlSeg& s, int r) {
 // unrolled (static ring indices), the chunk loop is NOT, which bounds the live weight registers to the
 // ring (a fully unrolled loop lets the compiler hoist every load of a 32-step reduction to the top).
 //   arow : this lane's LDS pointer (row l&15, column 4*(l>>4)); M-tile mt is a_mt floats further
-//   bimg : tile t, k-step ks at bimg[(tile_of(t) * ksteps_total + ks0 + ks) * 64 + lane]
-template <int MT, int NT, int NK, int PFD, typename TileOf>
-__device__ __forceinline__ void mma16_rows(f32x4 (&acc)[MT][NT], const float* arow, int a_mt,
-                                           const f32x4* __restrict__ bimg, int ksteps_total, int ks0, int lane,
-                                           TileOf tile_of) {
+//   bimg : tile t, k-step ks at bimg[(tile_of(t) * ksteps_total + ks0 + kofs(t) + ks) * 64 + lane]
+//   SPLITK: the NT "tiles" are k-ranges of ONE column tile (kofs(t) differs): independent accumulator
+//   chains for a wave that owns a single column tile; the caller adds the NT accumulators at the end.
+template <int MT, int NT, int NK, int PFD, bool SPLITK, typename TileOf, typename KOfs>
+__device__ __forceinline__ void mma16_rows_k(f32x4 (&acc)[MT][NT], const float* arow, int a_mt,
+                                             const f32x4* __restrict__ bimg, int ksteps_total, int ks0, int lane,
+                                             TileOf tile_of, KOfs kofs) {
     static_assert(PFD >= 1 && PFD <= NK, "ring depth");
     constexpr int NCH = NK / PFD, REM = NK % PFD;
+    constexpr int NA = SPLITK ? NT : 1;
     f32x4 ring[PFD][NT];
 #pragma unroll
     for (int i = 0; i < PFD; ++i)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) ring[i][t] = bimg[(tile_of(t) * ksteps_total + ks0 + i) * 64 + lane];
+        for (int t = 0; t < NT; ++t) ring[i][t] = bimg[(tile_of(t) * ksteps_total + ks0 + kofs(t) + i) * 64 + lane];
     auto step = [&](int ks, int slot, bool refill) {
-        f32x4 av[MT];
+        f32x4 av[NA][MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(arow + mt * a_mt + (ks0 + ks) * 16);
+        for (int u = 0; u < NA; ++u)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                av[u][mt] = *reinterpret_cast<const f32x4*>(arow + mt * a_mt + (ks0 + (SPLITK ? kofs(u) : 0) + ks) * 16);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[mt][t] = mfma16(av[mt][e], ring[slot][t][e], acc[mt][t]);
+                for (int e = 0; e < 4; ++e) acc[mt][t] = mfma16(av[SPLITK ? t : 0][mt][e], ring[slot][t][e], acc[mt][t]);
         if (refill) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                ring[slot][t] = bimg[(tile_of(t) * ksteps_total + ks0 + ks + PFD) * 64 + lane];
+                ring[slot][t] = bimg[(tile_of(t) * ksteps_total + ks0 + kofs(t) + ks + PFD) * 64 + lane];
         }
     };
 #pragma unroll 1
@@ -88,6 +94,12 @@ __device__ __forceinline__ void mma16_rows(f32x4 (&acc)[MT][NT], const float* ar
     }
 #pragma unroll
     for (int j = 0; j < REM; ++j) step(NCH * PFD + j, j, false);
+}
+template <int MT, int NT, int NK, int PFD, typename TileOf>
+__device__ __forceinline__ void mma16_rows(f32x4 (&acc)[MT][NT], const float* arow, int a_mt,
+                                           const f32x4* __restrict__ bimg, int ksteps_total, int ks0, int lane,
+                                           TileOf tile_of) {
+    mma16_rows_k<MT, NT, NK, PFD, false>(acc, arow, a_mt, bimg, ksteps_total, ks0, lane, tile_of, [](int) { return 0; });
 }
 
 template <int MT, int NT>
@@ -106,38 +118,51 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // forward: rows -> out, optionally saving z1 / (x_t, x_hat, x_com) / a1 for backward.
 // The z1 / xin / a1 scratch is padded to whole tiles by the caller, so those stores are
 // unconditional; `out` may be a table (updata) and is bounds-checked.
+//
+// NS > 1 (training batches): the 512 hidden units are split over NS workgroups per row tile, so a
+// 768-row TR batch becomes 192 workgroups instead of 48 and the fc1 chain per workgroup is NS
+// times shorter.  Workgroup (tile, h) repeats the cheap gather + conv prologue, computes
+// z1[:, h*HL .. (h+1)*HL), and writes the fc2 PARTIAL sum over its hidden slice to plane h of
+// `out` (planes out_pstride floats apart; the bias rides in plane 0).  The consumer (the pair loss
+// at the head of k_transfer_bwd) adds the NS planes in index order: deterministic, no atomics.
 // ------------------------------------------------------------------------------------
-template <int D, int MT>
+template <int D, int MT, int NS>
 __global__ __launch_bounds__(512) void k_transfer_fwd(SmlFwdArgs a) {
     constexpr int R = SML_TM * MT;
     constexpr int K1 = SML_C2 * D;       // fc1 reduction length
+    constexpr int HL = SML_HID / NS;     // hidden units of this workgroup
     constexpr int S1 = K1 + 4;           // LDS row strides (multiples of 4 floats: 16-byte aligned b128 reads)
-    constexpr int S2 = SML_HID + 4;
+    constexpr int S2 = HL + 4;
     constexpr int KS1 = K1 / 16;
     constexpr int EPT = R * D / 512;
     constexpr int JT = D / 16;                                    // fc2 column tiles
+    constexpr int CT = HL / 16 / 8;                               // fc1 column tiles per wave
+    constexpr int KL = HL / 16;                                   // fc2 k-steps of this workgroup
     constexpr int KSPL = (D == 32) ? 8 : (D == 64 ? 4 : 2);       // fc2: waves along K ...
     constexpr int JSPL = 8 / KSPL;                                // ... x waves along the columns
     constexpr int JTW = JT / JSPL;
-    constexpr int KPW = 32 / KSPL;                                // fc2 k-steps per wave
+    constexpr int KPW = KL / KSPL;                                // fc2 k-steps per wave
+    static_assert(CT >= 1 && KPW >= 1 && MT * NS <= 4, "tiling");
     constexpr int REG0 = cmax(R * S1, KSPL * R * (D + 1));
-    __shared__ __attribute__((aligned(16))) float smem[REG0 + R * S2 + 104];
+    __shared__ __attribute__((aligned(16))) float smem[REG0 + cmax(R * S2, R * (D + 1) + R) + 104];
     __shared__ SmlSched swin[SML_SW];
     float* A1s = smem;
     float* a2s = smem + REG0;
-    float* cws = smem + REG0 + R * S2;
+    float* cws = smem + REG0 + cmax(R * S2, R * (D + 1) + R);
     float* xts = a2s;                    // [R][D+1], dead before a2s is written
     float* nrm = a2s + R * (D + 1);
     float* part = smem;                  // [KSPL][R][D+1], aliases A1s after fc1
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
-    const int sidx = (int)blockIdx.x >= a.tiles0;
+    const int tile = (int)blockIdx.x / NS, h = (int)blockIdx.x % NS;
+    const int sidx = tile >= a.tiles0;
     const SmlSeg& sg = a.seg[sidx];
-    const int row0 = ((int)blockIdx.x - (sidx ? a.tiles0 : 0)) * R;
+    const int row0 = (tile - (sidx ? a.tiles0 : 0)) * R;
     const float* __restrict__ theta = sg.theta;
     if (tid < 104) cws[tid] = theta[tid];
     const bool lazy = sg.last_tab != nullptr;
     if (lazy) sched_window_load(swin, a.sched, a.cur_step - 1, tid);
+    const bool saver = (h == 0);         // one workgroup of the NS writes the shared saves
 
     // ---- P1: gather x_t and x_hat; all index loads, then all row loads, are in flight together
     float xt[EPT], xh[EPT];
@@ -187,6 +212,10 @@ __global__ __launch_bounds__(512) void k_transfer_fwd(SmlFwdArgs a) {
         nrm[tid] = sqrtf(s);
     }
     __syncthreads();
+    // fc1 bias of this wave's columns: issued now, used after the first GEMM
+    float bias1[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) bias1[t] = theta[sml_off_f1b(D) + h * HL + (wv * CT + t) * 16 + l15];
     // ---- P2: x_com, conv1, Gelu, conv2, Gelu -> A1 tile (channel-major flatten c*D + w)
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
@@ -199,9 +228,9 @@ __global__ __launch_bounds__(512) void k_transfer_fwd(SmlFwdArgs a) {
         for (int c = 0; c < SML_C2; ++c) {
             const float v = sml_gelu(p.h2p[c]);
             A1s[r * S1 + c * D + w] = v;
-            if (sg.a1 != nullptr) sg.a1[(int64_t)row * K1 + c * D + w] = v;
+            if (saver && sg.a1 != nullptr) sg.a1[(int64_t)row * K1 + c * D + w] = v;
         }
-        if (sg.xin != nullptr) {
+        if (saver && sg.xin != nullptr) {
             float* x = sg.xin + (int64_t)row * 3 * D;
             x[w] = xt[q];
             x[D + w] = xh[q];
@@ -210,40 +239,66 @@ __global__ __launch_bounds__(512) void k_transfer_fwd(SmlFwdArgs a) {
     }
     __syncthreads();
 
-    // ---- fc1: Z1[R x 512] = A1[R x K1] * W1^T ; wave wv owns column tiles 4wv..4wv+3 (of 32)
+    // ---- fc1: Z1[R x HL] = A1[R x K1] * W1^T[:, slice h] ; wave wv owns CT column tiles of the slice
     {
-        f32x4 acc[MT][4];
-        zero_acc(acc);
-        mma16_rows<MT, 4, KS1, (MT == 1 ? 5 : 2)>(acc, A1s + l15 * S1 + 4 * g4, SML_TM * S1,
-                                  reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p1(D)), KS1, 0, lane,
-                                  [wv](int t) { return wv * 4 + t; });
+        const f32x4* img = reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p1(D));
+        const int tile0 = h * (HL / 16) + wv * CT;
+        float zt[MT][CT][4];
+        if constexpr (CT >= 2) {
+            f32x4 acc[MT][CT];
+            zero_acc(acc);
+            mma16_rows<MT, CT, KS1, (MT == 1 ? 5 : 2)>(acc, A1s + l15 * S1 + 4 * g4, SML_TM * S1, img, KS1, 0, lane,
+                                                      [tile0](int t) { return tile0 + t; });
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < CT; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) zt[mt][t][q] = acc[mt][t][q];
+        } else {
+            // one column tile per wave: two independent accumulator chains over the two halves of K
+            static_assert(KS1 % 2 == 0, "even k-steps");
+            f32x4 acc[MT][2];
+            zero_acc(acc);
+            mma16_rows_k<MT, 2, KS1 / 2, 5, true>(acc, A1s + l15 * S1 + 4 * g4, SML_TM * S1, img, KS1, 0, lane,
+                                                  [tile0](int) { return tile0; }, [](int t) { return t * (KS1 / 2); });
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) zt[mt][0][q] = acc[mt][0][q] + acc[mt][1][q];
+        }
         // + bias, save z1, Gelu -> a2 tile.  (xts/nrm are dead: every wave passed the barrier above)
         float* z1 = sg.z1;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int n = (wv * 4 + t) * 16 + l15;
-            const float bias = theta[sml_off_f1b(D) + n];
+        for (int t = 0; t < CT; ++t) {
+            const int nl = (wv * CT + t) * 16 + l15;       // column inside the slice
+            const int n = h * HL + nl;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int r = mt * SML_TM + 4 * g4 + q;
-                    const float z = acc[mt][t][q] + bias;
+                    const float z = zt[mt][t][q] + bias1[t];
                     if (z1 != nullptr) z1[(int64_t)(row0 + r) * SML_HID + n] = z;
-                    a2s[r * S2 + n] = sml_gelu(z);
+                    a2s[r * S2 + nl] = sml_gelu(z);
                 }
         }
     }
+    // fc2 bias for the final pass (plane 0 carries it)
+    float bias2[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) bias2[q] = (h == 0) ? theta[sml_off_f2b(D) + (q * 512 + tid) % D] : 0.0f;
     __syncthreads();
 
-    // ---- fc2: Out[R x D] = a2[R x 512] * W2^T ; waves = KSPL (along K = 512) x JSPL (column tiles)
+    // ---- fc2: Out[R x D] (+)= a2[R x HL] * W2^T[slice h, :] ; waves = KSPL (along K) x JSPL (column tiles)
     {
         const int kq = wv % KSPL, jq = wv / KSPL;
         f32x4 acc[MT][JTW];
         zero_acc(acc);
-        mma16_rows<MT, JTW, KPW, (KPW < 4 ? KPW : 4)>(acc, a2s + l15 * S2 + 4 * g4, SML_TM * S2,
+        // the operand image is indexed by the global k-step, the LDS tile by the local one
+        mma16_rows<MT, JTW, KPW, (KPW < 4 ? KPW : 4)>(acc, a2s + l15 * S2 + 4 * g4 - h * HL, SML_TM * S2,
                                                       reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p2(D)), 32,
-                                                      kq * KPW, lane, [jq](int t) { return jq * JTW + t; });
+                                                      h * KL + kq * KPW, lane, [jq](int t) { return jq * JTW + t; });
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -253,13 +308,14 @@ __global__ __launch_bounds__(512) void k_transfer_fwd(SmlFwdArgs a) {
                     part[(kq * R + mt * SML_TM + 4 * g4 + q) * (D + 1) + (jq * JTW + t) * 16 + l15] = acc[mt][t][q];
     }
     __syncthreads();
+    float* __restrict__ outp = sg.out + (int64_t)h * a.out_pstride;
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
         const int e = q * 512 + tid, r = e / D, j = e % D;
-        float s = theta[sml_off_f2b(D) + j];
+        float s = bias2[q];
 #pragma unroll
         for (int k = 0; k < KSPL; ++k) s += part[(k * R + r) * (D + 1) + j];
-        if (row0 + r < sg.n_rows) sg.out[(int64_t)(row0 + r) * D + j] = s;
+        if (row0 + r < sg.n_rows) outp[(int64_t)(row0 + r) * D + j] = s;
     }
 }
 
@@ -289,11 +345,12 @@ __device__ __forceinline__ int wave_sum96_base(int lane) {
 }
 
 // ------------------------------------------------------------------------------------
-// backward: dOut -> (MF stage) dx_hat + l2*x_hat, or (TR stage) dZ1 rows + conv-grad partials.
-// dx / dz1 scratch is padded to whole tiles (unconditional stores).
+// backward, one workgroup per row tile (batches large enough to fill the chip without the
+// coordinate split below): dOut -> (MF stage) dx_hat + l2*x_hat, or (TR stage) dZ1 rows +
+// conv-grad partials.  dx / dz1 scratch is padded to whole tiles (unconditional stores).
 // ------------------------------------------------------------------------------------
 template <int D, int MT, bool TR>
-__global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
+__global__ __launch_bounds__(512) void k_transfer_bwd_full(SmlBwdArgs a) {
     constexpr int R = SML_TM * MT;
     constexpr int K1 = SML_C2 * D;
     constexpr int S2 = SML_HID + 4;
@@ -333,9 +390,14 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
         ou[q] = oi[q] = on[q] = 0.0f;
         if (row < sg.n_rows) {
             const int t = (sg.is_item && row >= a.B) ? row - a.B : row;
-            ou[q] = a.out_all[(int64_t)t * D + w];
-            oi[q] = a.out_all[(int64_t)(a.ioff + t) * D + w];
-            on[q] = a.out_all[(int64_t)(a.ioff + a.B + t) * D + w];
+            const float* pu = a.out_all + (int64_t)t * D + w;
+            const float* pi = a.out_all + (int64_t)(a.ioff + t) * D + w;
+            const float* pn = a.out_all + (int64_t)(a.ioff + a.B + t) * D + w;
+            for (int p = 0; p < a.out_np; ++p) {
+                ou[q] += pu[p * a.out_pstride];
+                oi[q] += pi[p * a.out_pstride];
+                on[q] += pn[p * a.out_pstride];
+            }
         }
         O3[(0 * R + r) * (D + 1) + w] = ou[q];
         O3[(1 * R + r) * (D + 1) + w] = oi[q];
@@ -529,6 +591,261 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------
+// backward: dOut -> (MF stage) dx_hat + l2*x_hat, or (TR stage) dZ1 rows + conv-grad partials.
+// dx / dz1 scratch is padded to whole tiles (unconditional stores).
+//
+// CS = D/16 workgroups share a 16-row tile: workgroup (tile, cs) owns the 16 coordinates
+// w in [16cs, 16cs+16) of every conv channel.  The flatten is channel-major (column c*D + w), so
+// those are the five dA1 column tiles {c*D/16 + cs}: the big GEMM dA1 = dZ1 * W1 splits over the
+// CS workgroups by OUTPUT columns -- no cross-workgroup sum -- while the small one (dA2 = dOut * W2,
+// K = D) and the pair loss are simply repeated.  A 768-row TR batch is 96 workgroups at d = 32.
+// ------------------------------------------------------------------------------------
+template <int D, bool TR>
+__global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
+    constexpr int R = SML_TM;
+    constexpr int CS = D / 16;
+    constexpr int S2 = SML_HID + 4;
+    constexpr int SD = D + 4;
+    constexpr int KSD = D / 16;
+    constexpr int EPT = R * D / 512;
+    constexpr int PSTR = SML_C2 * 16 + 1;
+    constexpr int CGS = 20;                                        // conv-grad operand row stride (16-byte aligned)
+    constexpr int SZ = cmax(cmax(R * S2 + R * SD, 8 * R * PSTR), 2 * 256 * CGS);
+    static_assert(3 * R * (D + 1) <= SZ, "pair-loss staging fits");
+    __shared__ __attribute__((aligned(16))) float smem[SZ + 104];
+    __shared__ float red[TR ? 8 : 1][256];
+    __shared__ float cf[4][SML_TM];
+    __shared__ float lred[8];
+    float* dZs = smem;                    // [R][516]
+    float* dOs = smem + R * S2;           // [R][D+4]
+    float* part = smem;                   // [8][R][81], aliases dZs after the second GEMM
+    float* cws = smem + SZ;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+    const int tile = (int)blockIdx.x / CS, cs = (int)blockIdx.x % CS;
+    const int sidx = tile >= a.tiles0;
+    const SmlBwdSeg& sg = a.seg[sidx];
+    const int row0 = (tile - (sidx ? a.tiles0 : 0)) * R;
+    if (tid < 104) cws[tid] = sg.theta[tid];
+
+    // ---- pair loss (model/conv_transfer.py:120-134) for this tile's rows: every row fetches the three
+    // transferred rows of its triple (each the sum of the forward's out_np hidden-slice planes, added in
+    // plane order), one thread per row forms the two scores and the loss terms, then dOut is written
+    // element-wise.  User tiles own the loss value (each triple once, coordinate slice 0).
+    float* O3 = smem;                     // [3][R][D+1], aliases dZs (not yet live)
+    float ou[EPT], oi[EPT], on[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int e = q * 512 + tid, r = e / D, w = e % D;
+        const int row = row0 + r;
+        ou[q] = oi[q] = on[q] = 0.0f;
+        if (row < sg.n_rows) {
+            const int t = (sg.is_item && row >= a.B) ? row - a.B : row;
+            const float* pu = a.out_all + (int64_t)t * D + w;
+            const float* pi = a.out_all + (int64_t)(a.ioff + t) * D + w;
+            const float* pn = a.out_all + (int64_t)(a.ioff + a.B + t) * D + w;
+            for (int p = 0; p < a.out_np; ++p) {
+                ou[q] += pu[p * a.out_pstride];
+                oi[q] += pi[p * a.out_pstride];
+                on[q] += pn[p * a.out_pstride];
+            }
+        }
+        O3[(0 * R + r) * (D + 1) + w] = ou[q];
+        O3[(1 * R + r) * (D + 1) + w] = oi[q];
+        O3[(2 * R + r) * (D + 1) + w] = on[q];
+    }
+    // the tail's (x_t, x_hat, x_com) and this wave's z1 fragment: issue the loads now, use them later
+    const int tr_ = tid >> 4, twl = tid & 15, tw = cs * 16 + twl;       // tail element of threads 0..255
+    float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+    if (tid < 256) {
+        const float* x = sg.xin + (int64_t)(row0 + tr_) * 3 * D;
+        x0 = x[tw]; x1 = x[D + tw]; x2 = x[2 * D + tw];
+    }
+    float z[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            z[t][q] = sg.z1[(int64_t)(row0 + 4 * g4 + q) * SML_HID + (wv * 4 + t) * 16 + l15];
+    __syncthreads();
+    float lsum = 0.0f;
+    if (tid < R) {
+        float sp = 0.f, sn = 0.f, uu = 0.f;
+#pragma unroll 8
+        for (int w = 0; w < D; ++w) {
+            const float u = O3[(0 * R + tid) * (D + 1) + w];
+            sp += u * O3[(1 * R + tid) * (D + 1) + w];
+            sn += u * O3[(2 * R + tid) * (D + 1) + w];
+            uu += u * u;
+        }
+        float lt, d0, d1, inv_nu = 1.0f, cc = 0.0f;
+        if (a.kind == SML_LOSS_BPR_NORM) {
+            const float nu = sqrtf(uu);
+            inv_nu = 1.0f / nu;
+            cc = (sp - sn) / (nu * nu * nu);
+            pair_terms(SML_LOSS_BPR, (sp - sn) * inv_nu, 0.0f, 1.0f, lt, d0, d1);
+            d1 = -d0;
+        } else {
+            pair_terms(a.kind, sp, sn, 1.0f / (float)a.B, lt, d0, d1);
+        }
+        cf[0][tid] = d0 * a.scale; cf[1][tid] = d1 * a.scale; cf[2][tid] = inv_nu; cf[3][tid] = cc;
+        if (!sg.is_item && cs == 0 && row0 + tid < sg.n_rows) lsum = lt * a.scale;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int e = q * 512 + tid, r = e / D, w = e % D;
+        const int row = row0 + r;
+        const float d0 = cf[0][r], d1 = cf[1][r];
+        float g;
+        if (a.kind == SML_LOSS_BPR_NORM) {
+            const float inv_nu = cf[2][r], cc = cf[3][r];
+            if (!sg.is_item) g = d0 * ((oi[q] - on[q]) * inv_nu - cc * ou[q]);
+            else g = ((row < a.B) ? d0 : d1) * ou[q] * inv_nu;
+        } else {
+            if (!sg.is_item) g = d0 * oi[q] + d1 * on[q];
+            else g = ((row < a.B) ? d0 : d1) * ou[q];
+        }
+        if (row >= sg.n_rows) g = 0.0f;
+        dOs[r * SD + w] = g;
+        if (TR && cs == 0) sg.dout[(int64_t)row * D + w] = g;
+    }
+    __syncthreads();
+    // ---- dA2[R x 512] = dOut[R x D] * W2 ; dZ1 = dA2 * Gelu'(z1) ; wave wv owns column tiles 4wv..4wv+3
+    {
+        f32x4 acc[1][4];
+        zero_acc(acc);
+        mma16_rows<1, 4, KSD, KSD>(acc, dOs + l15 * SD + 4 * g4, 0,
+                                   reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p2b(D)), KSD, 0, lane,
+                                   [wv](int t) { return wv * 4 + t; });
+        float* dz1 = sg.dz1;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int n = (wv * 4 + t) * 16 + l15;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 4 * g4 + q;
+                const float dz = acc[0][t][q] * sml_gelu_grad(z[t][q]);
+                dZs[r * S2 + n] = dz;
+                if (TR && (t % CS) == cs) dz1[(int64_t)(row0 + r) * SML_HID + n] = dz;   // the CS workgroups share the save
+            }
+        }
+    }
+    __syncthreads();
+    // ---- dA1[R x 5*16] = dZ1[R x 512] * W1[:, this slice] ; every wave takes 4 of the 32 k-steps, all 5 channels
+    {
+        f32x4 acc[1][5];
+        zero_acc(acc);
+        mma16_rows<1, 5, 4, 4>(acc, dZs + l15 * S2 + 4 * g4, 0,
+                               reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p1b(D)), 32, wv * 4, lane,
+                               [cs](int t) { return t * (D / 16) + cs; });
+        __syncthreads();                        // every wave is done reading dZs
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) part[(wv * R + 4 * g4 + q) * PSTR + t * 16 + l15] = acc[0][t][q];
+    }
+    __syncthreads();
+    // ---- per-coordinate tail (threads 0..255, one element each): Gelu'(h2) -> conv2^T -> Gelu'(h1) -> conv1^T (row 1 = x_hat)
+    float cga[16], cgb[16];
+    if (tid < 256) {
+        const int row = row0 + tr_;
+        const bool ok = row < sg.n_rows;
+        Pro p;
+        conv_prologue(cws, x0, x1, x2, p);
+        float dh2p[SML_C2];
+#pragma unroll
+        for (int c = 0; c < SML_C2; ++c) {
+            float s = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += part[(k * R + tr_) * PSTR + c * 16 + twl];
+            dh2p[c] = s * sml_gelu_grad(p.h2p[c]);
+        }
+        float dxh = 0.0f;
+        float dh1p[SML_C1];
+#pragma unroll
+        for (int c = 0; c < SML_C1; ++c) {
+            float s = 0.0f;
+#pragma unroll
+            for (int o = 0; o < SML_C2; ++o) s += dh2p[o] * cws[SML_OFF_C2W + o * SML_C1 + c];
+            dh1p[c] = s * sml_gelu_grad(p.h1p[c]);
+            dxh += dh1p[c] * cws[SML_OFF_C1W + c * 3 + 1];
+        }
+        if (!TR) {
+            sg.dx[(int64_t)row * D + tw] = dxh + a.l2 * x1;
+            if (ok) lsum += 0.5f * a.l2 * x1 * x1;      // + l2 * 0.5 * sum(x_hat^2), model/transfer.py:486-488
+        }
+        if constexpr (TR) {
+            // conv1/conv2 parameter gradients are one small matrix product over the tile's elements e:
+            //   G[i][j] = sum_e A[e][i] * B[e][j],  A[e] = (dh1p[0..9], dh2p[0..4], 0),  B[e] = (x0, x1, x2, 1, h1[0..9], 0, 0)
+            // G[c][0..2] = dW_conv1[c], G[c][3] = db_conv1[c], G[10+o][4+c] = dW_conv2[o][c], G[10+o][3] = db_conv2[o]
+#pragma unroll
+            for (int c = 0; c < SML_C1; ++c) { cga[c] = ok ? dh1p[c] : 0.0f; cgb[4 + c] = p.h1[c]; }
+#pragma unroll
+            for (int o = 0; o < SML_C2; ++o) cga[10 + o] = ok ? dh2p[o] : 0.0f;
+            cga[15] = 0.0f;
+            cgb[0] = x0; cgb[1] = x1; cgb[2] = x2; cgb[3] = 1.0f; cgb[14] = 0.0f; cgb[15] = 0.0f;
+        }
+    }
+    {   // this workgroup's share of the batch loss: lanes, then waves in index order (deterministic)
+        float v = lsum;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) lred[wv] = v;
+    }
+    if constexpr (TR) {
+        float* cgA = smem;                 // [256][CGS]  (the dA1 partials are in registers by now)
+        float* cgB = smem + 256 * CGS;
+        __syncthreads();
+        if (tid < 256) {
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                f32x4 va, vb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { va[e] = cga[i4 * 4 + e]; vb[e] = cgb[i4 * 4 + e]; }
+                *reinterpret_cast<f32x4*>(cgA + tid * CGS + i4 * 4) = va;
+                *reinterpret_cast<f32x4*>(cgB + tid * CGS + i4 * 4) = vb;
+            }
+        }
+        __syncthreads();
+        {   // wave wv: elements 64*(wv&3) .. +63, k-steps 8*(wv>>2) .. +7 (4 elements per MFMA)
+            const int e0 = 64 * (wv & 3) + 32 * (wv >> 2);
+            float av[8], bv[8];
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) {
+                av[s8] = cgA[(e0 + 4 * s8 + g4) * CGS + l15];
+                bv[s8] = cgB[(e0 + 4 * s8 + g4) * CGS + l15];
+            }
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) acc = mfma16(av[s8], bv[s8], acc);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[wv][(4 * g4 + q) * 16 + l15] = acc[q];
+        }
+        __syncthreads();
+        if (tid < 95) {
+            int i, j;
+            if (tid < 30) { i = tid / 3; j = tid % 3; }
+            else if (tid < 40) { i = tid - 30; j = 3; }
+            else if (tid < 90) { i = 10 + (tid - 40) / 10; j = 4 + (tid - 40) % 10; }
+            else { i = 10 + (tid - 90); j = 3; }
+            float sacc = 0.0f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) sacc += red[w8][i * 16 + j];
+            a.convg_part[(int64_t)blockIdx.x * SML_CG + tid] = sacc;
+        }
+    } else {
+        __syncthreads();
+    }
+    if (tid == 0) {
+        float sacc = 0.0f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) sacc += lred[w8];
+        a.loss_part[blockIdx.x] = sacc;
+    }
+}
+
 template <int D>
 __device__ __forceinline__ void pack_store(float* __restrict__ pk, int off, float p) {
     constexpr int K1 = SML_C2 * D;
@@ -545,31 +862,42 @@ __device__ __forceinline__ void pack_store(float* __restrict__ pk, int off, floa
 
 // ------------------------------------------------------------------------------------
 // weight gradients (TR stage): dW1 = dZ1^T A1, db1, dW2 = dOut^T Gelu(z1), db2
-// one workgroup per 32x32 output tile (v_mfma_f32_32x32x2_f32); the four waves split the batch rows
+// one workgroup per 32x32 output tile (v_mfma_f32_32x32x2_f32); the eight waves split the batch
+// rows, each with up to 64 rows of operands (64 loads) in flight before its MFMAs.  The Adam state
+// of the tile's weights does not depend on the reduction, so it is fetched first and is in
+// registers by the time the gradient is complete.
 // ------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(256) void k_transfer_wgrad(SmlWgArgs a) {
+__global__ __launch_bounds__(512) void k_transfer_wgrad(SmlWgArgs a) {
     constexpr int K1 = SML_C2 * D;
     constexpr int KT = K1 / 32;
     constexpr int JT = D / 32;
     constexpr int T1 = 16 * KT, T2 = JT * 16, TN = T1 + T2;
-    __shared__ float part[4][32][33];
-    __shared__ float csum[4][32];
+    __shared__ float part[8][32][33];
+    __shared__ float csum[8][32];
     constexpr int NS = sml_net_size(D);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const bool fuse = a.theta != nullptr;
     SmlSched sc; sc.step_size = a.step_size; sc.bc2_sqrt = a.bc2_sqrt;
     if ((int)blockIdx.x >= 2 * TN) {
-        // conv1/conv2 parameters of one net: sum the backward tiles' partials in order, then Adam
+        // conv1/conv2 parameters of one net: sum the backward workgroups' partials in order, then Adam
         const int net = (int)blockIdx.x - 2 * TN;
         if (tid < 95) {
             const int off = tid < 30 ? tid : tid < 40 ? tid + 2 : tid < 90 ? tid + 4 : tid + 6;
             const int t0 = net ? a.tiles0 : 0, t1 = net ? a.tiles_total : a.tiles0;
-            float g = 0.0f;
-            for (int t = t0; t < t1; ++t) g += a.convg_part[(int64_t)t * SML_CG + tid];
             const int64_t i = (int64_t)net * NS + off;
-            a.seg[net].grad[off] = g;
             float p = a.theta[i], m = a.m[i], v = a.v[i];
+            float g = 0.0f;
+            int t = t0;
+            for (; t + 8 <= t1; t += 8) {
+                float x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = a.convg_part[(int64_t)(t + u) * SML_CG + tid];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) g += x[u];
+            }
+            for (; t < t1; ++t) g += a.convg_part[(int64_t)t * SML_CG + tid];
+            a.seg[net].grad[off] = g;
             adam_apply(p, m, v, g + a.weight_decay * p, sc);
             a.theta[i] = p; a.m[i] = m; a.v[i] = v;
         }
@@ -585,19 +913,40 @@ __global__ __launch_bounds__(256) void k_transfer_wgrad(SmlWgArgs a) {
     const int lda = is_w1 ? SML_HID : D;
     const float* __restrict__ Bsrc = is_w1 ? sg.a1 : sg.z1;      // B[r][j] = Bsrc[r][tj*32 + j]
     const int ldb = is_w1 ? K1 : SML_HID;
+    // this thread's two weights of the tile (+ a bias for 32 threads of the tj = 0 workgroups)
+    int woff[2];
+    float wp[2] = {0.f, 0.f}, wm[2] = {0.f, 0.f}, wvv[2] = {0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = q * 512 + tid, i = e >> 5, j = e & 31;
+        woff[q] = is_w1 ? SML_OFF_F1W + (ti * 32 + i) * K1 + tj * 32 + j
+                        : sml_off_f2w(D) + (ti * 32 + i) * SML_HID + tj * 32 + j;
+    }
+    const bool has_bias = (tj == 0 && tid < 32);
+    const int boff = is_w1 ? sml_off_f1b(D) + ti * 32 + tid : sml_off_f2b(D) + ti * 32 + tid;
+    float bp = 0.f, bm = 0.f, bv2 = 0.f;
+    if (fuse) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int64_t i = (int64_t)net * NS + woff[q];
+            wp[q] = a.theta[i]; wm[q] = a.m[i]; wvv[q] = a.v[i];
+        }
+        if (has_bias) { const int64_t i = (int64_t)net * NS + boff; bp = a.theta[i]; bm = a.m[i]; bv2 = a.v[i]; }
+    }
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
     float colsum = 0.0f;
-    // each wave takes a contiguous quarter of the batch rows, 32 rows (4 k-steps) per trip with all
-    // 32 operand loads of the trip in flight before its 16 MFMAs
-    const int rows_per_wave = ((sg.n_rows + 127) / 128) * 32;
+    // each wave takes a contiguous eighth of the batch rows, 64 rows (8 k-steps of 2x4 rows) per trip
+    const int rows_per_wave = ((sg.n_rows + 255) / 256) * 32;
     const int r_begin = wv * rows_per_wave;
     const int r_end = min(sg.n_rows, r_begin + rows_per_wave);
-    for (int rb = r_begin; rb < r_end; rb += 32) {
-        float av[4][4], bv[4][4];
+    for (int rb = r_begin; rb < r_end; rb += 64) {
+        float av[8][4], bv[8][4];
+        const bool two = rb + 32 < r_end;          // wave-uniform
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
+        for (int s4 = 0; s4 < 8; ++s4) {
+            if (s4 >= 4 && !two) break;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = rb + s4 * 8 + 4 * hi + e;
@@ -605,8 +954,10 @@ __global__ __launch_bounds__(256) void k_transfer_wgrad(SmlWgArgs a) {
                 av[s4][e] = ok ? Asrc[(int64_t)r * lda + ti * 32 + l31] : 0.0f;
                 bv[s4][e] = ok ? Bsrc[(int64_t)r * ldb + tj * 32 + l31] : 0.0f;
             }
+        }
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
+        for (int s4 = 0; s4 < 8; ++s4) {
+            if (s4 >= 4 && !two) break;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = rb + s4 * 8 + 4 * hi + e;
@@ -615,6 +966,7 @@ __global__ __launch_bounds__(256) void k_transfer_wgrad(SmlWgArgs a) {
                 colsum += av[s4][e];
                 acc = mfma32(av[s4][e], b, acc);
             }
+        }
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) part[wv][mfma32_row(q, lane)][l31] = acc[q];
@@ -622,26 +974,28 @@ __global__ __launch_bounds__(256) void k_transfer_wgrad(SmlWgArgs a) {
     if (lane < 32) csum[wv][lane] = colsum;
     __syncthreads();
     float* __restrict__ g = sg.grad;
-    auto finish = [&](int off, float gsum) {
+    auto finish = [&](int off, float gsum, float p, float m, float v) {
         g[off] = gsum;
         if (fuse) {
             const int64_t i = (int64_t)net * NS + off;
-            float p = a.theta[i], m = a.m[i], v = a.v[i];
             adam_apply(p, m, v, gsum + a.weight_decay * p, sc);
             a.theta[i] = p; a.m[i] = m; a.v[i] = v;
             pack_store<D>(a.pk + (int64_t)net * sml_pk_size(D), off, p);
         }
     };
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e = q * 256 + tid, i = e >> 5, j = e & 31;
-        const float s = part[0][i][j] + part[1][i][j] + part[2][i][j] + part[3][i][j];
-        finish(is_w1 ? SML_OFF_F1W + (ti * 32 + i) * K1 + tj * 32 + j
-                     : sml_off_f2w(D) + (ti * 32 + i) * SML_HID + tj * 32 + j, s);
+    for (int q = 0; q < 2; ++q) {
+        const int e = q * 512 + tid, i = e >> 5, j = e & 31;
+        float s = 0.0f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) s += part[w8][i][j];
+        finish(woff[q], s, wp[q], wm[q], wvv[q]);
     }
-    if (tj == 0 && tid < 32) {
-        const float s = csum[0][tid] + csum[1][tid] + csum[2][tid] + csum[3][tid];
-        finish(is_w1 ? sml_off_f1b(D) + ti * 32 + tid : sml_off_f2b(D) + ti * 32 + tid, s);
+    if (has_bias) {
+        float s = 0.0f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) s += csum[w8][tid];
+        finish(boff, s, bp, bm, bv2);
     }
 }
 
@@ -718,24 +1072,30 @@ __global__ void k_selftest(const float* __restrict__ A, const float* __restrict_
         default: return hipErrorInvalidValue; \
     }
 
-hipError_t sml_launch_fwd(int d, int mt, const SmlFwdArgs& a, int tiles_total, hipStream_t st) {
+hipError_t sml_launch_fwd(int d, int mt, int ns, const SmlFwdArgs& a, int tiles_total, hipStream_t st) {
     if (tiles_total <= 0) return hipSuccess;
-    if (mt == 1) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 1><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }
-    else if (mt == 2) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 2><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }
+    if (mt == 1 && ns == 1) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 1, 1><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }
+    else if (mt == 1 && ns == 4) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 1, 4><<<dim3(tiles_total * 4), dim3(512), 0, st>>>(a)); }
+    else if (mt == 1 && ns == 2) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 1, 2><<<dim3(tiles_total * 2), dim3(512), 0, st>>>(a)); }
+    else if (mt == 2 && ns == 1) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 2, 1><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
-hipError_t sml_launch_bwd(int d, int mt, const SmlBwdArgs& a, int tiles_total, hipStream_t st) {
+hipError_t sml_launch_bwd(int d, int split, const SmlBwdArgs& a, int tiles_total, hipStream_t st) {
     if (tiles_total <= 0) return hipSuccess;
-    if (mt != 1) return hipErrorInvalidValue;      // backward only ever sees training batches
-    if (a.convg_part != nullptr) { SML_DISPATCH_D(d, k_transfer_bwd<DD, 1, true><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }
-    else { SML_DISPATCH_D(d, k_transfer_bwd<DD, 1, false><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }
+    if (split) {      // d/16 workgroups per row tile
+        if (a.convg_part != nullptr) { SML_DISPATCH_D(d, k_transfer_bwd<DD, true><<<dim3(tiles_total * (DD / 16)), dim3(512), 0, st>>>(a)); }
+        else { SML_DISPATCH_D(d, k_transfer_bwd<DD, false><<<dim3(tiles_total * (DD / 16)), dim3(512), 0, st>>>(a)); }
+    } else {
+        if (a.convg_part != nullptr) { SML_DISPATCH_D(d, k_transfer_bwd_full<DD, 1, true><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }
+        else { SML_DISPATCH_D(d, k_transfer_bwd_full<DD, 1, false><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }
+    }
     return hipGetLastError();
 }
 hipError_t sml_launch_wgrad(int d, const SmlWgArgs& a, hipStream_t st) {
     const int tn = 16 * (SML_C2 * d / 32) + (d / 32) * 16;
     const int extra = a.theta != nullptr ? 2 : 0;        // fused Adam: + one conv-parameter workgroup per net
-    SML_DISPATCH_D(d, k_transfer_wgrad<DD><<<dim3(2 * tn + extra), dim3(256), 0, st>>>(a));
+    SML_DISPATCH_D(d, k_transfer_wgrad<DD><<<dim3(2 * tn + extra), dim3(512), 0, st>>>(a));
     return hipGetLastError();
 }
 hipError_t sml_launch_theta_adam(int d, const SmlThetaAdamArgs& a, hipStream_t st) {

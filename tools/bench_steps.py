@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Per-batch cost of the two SML training stages in isolation (Yelp-shaped tables, d=32 by default).
+
+    python tools/bench_steps.py [--d 32] [--inter 75000] [--reps 5]
+
+Prints one JSON line: wall microseconds per batch of a TR epoch (B=256) and of an MF epoch (B=1024)
+without any profiling events in the stream, then the HIP-event average of every kernel class.  This is
+the iteration harness for the transfer-net kernels; the headline number stays bench.py's.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--d", type=int, default=32)
+    ap.add_argument("--users", type=int, default=60000)
+    ap.add_argument("--items", type=int, default=123000)
+    ap.add_argument("--inter", type=int, default=75000)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--tr-batch", type=int, default=256)
+    ap.add_argument("--mf-batch", type=int, default=1024)
+    a = ap.parse_args()
+    import contextlib
+    import io
+    from sml_amd import synth
+    from sml_amd.conv_transfer import ConvTransfer_com
+    from sml_amd.engine import HipEngine
+    from sml_amd.mf import MFbasemode
+    dev = torch.device("cuda", 0)
+    eng = HipEngine(dev, a.d, max(a.tr_batch, a.mf_batch))
+    torch.manual_seed(2000)
+    mf = MFbasemode(a.users, a.items, a.d)
+    with torch.no_grad():
+        mf.user_laten.weight.mul_(0.3)
+        mf.item_laten.weight.mul_(0.3)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = ConvTransfer_com(a.d, a.d)
+    mf, net = mf.to(dev), net.to(dev)
+    eng.adopt(net)
+    lu = (mf.user_laten.weight.detach() * 0.9).contiguous()
+    li = (mf.item_laten.weight.detach() * 0.9).contiguous()
+    hu, hi = mf.user_laten.weight.detach().clone(), mf.item_laten.weight.detach().clone()
+    rng = np.random.RandomState(7)
+    u, i, j = synth.synth_triples(rng, a.inter, a.users, a.items, a_user=1.1, a_item=1.0)
+    tri = torch.from_numpy(np.stack([u, i, j], 1)).to(dev)
+
+    def tr():
+        eng.tr_stage_epoch(net, lu, li, hu, hi, tri, a.tr_batch, 1e-3, 1e-4)
+
+    def mfe():
+        eng.mf_stage_epoch(mf, net, lu, li, tri, a.mf_batch, 0.01, 1e-6)
+
+    out = {"d": a.d, "inter": a.inter}
+    for name, fn, B in (("tr", tr, a.tr_batch), ("mf", mfe, a.mf_batch)):
+        nb = -(-a.inter // B)
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        out[name + "_us_per_batch"] = round(1000.0 * e0.elapsed_time(e1) / a.reps / nb, 2)
+        eng.profile(True)
+        fn()
+        torch.cuda.synchronize()
+        prof = eng.profile_read()
+        eng.profile(False)
+        out[name + "_kernels_us"] = {k: round(1000.0 * ms / c, 2) for k, (c, ms) in prof.items() if c >= nb // 2}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
