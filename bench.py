@@ -87,11 +87,11 @@ def bench_bare(a, device):
     # the index lists of epoch e+1 (sort, unique marks, compaction) are built on a side stream while epoch e runs
     for _ in range(a.warmup):
         eng.bare_epoch(wu, wi, tri, a.bare_batch, 0.05, 1e-6, 1e-6, bce=True)
-    nxt = eng.bare_prepare(tri, a.bare_batch)
+    nxt = eng.bare_prepare(tri, a.bare_batch, a.users, a.items)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        cur, nxt = nxt, eng.bare_prepare(tri, a.bare_batch)
+        cur, nxt = nxt, eng.bare_prepare(tri, a.bare_batch, a.users, a.items)
         eng.bare_epoch(wu, wi, tri, a.bare_batch, 0.05, 1e-6, 1e-6, bce=True, prepared=cur)
     torch.cuda.synchronize(device)
     dtm = time.perf_counter() - t0

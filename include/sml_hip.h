@@ -166,12 +166,13 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
  * SGD: W -= lr * dL/dW with duplicate rows' gradients summed before the write.
  * dtype_bytes: 4 (fp32 tables) or 2 (fp16 tables, fp32 arithmetic).
  * batch_loss[n_batches] as above.
- * prepared_slot: -1 builds the epoch's index lists (sort by (batch,row), unique marks,
- * duplicates-only compaction) inline on `stream`; 0/1 uses the lists a previous
+ * prepared_slot: -1 builds the epoch's index lists (sort by (batch,row) -- 32-bit keys when the
+ * batch count and n_user / n_item allow -- unique marks, compacted run records of the duplicated
+ * rows) inline on `stream`; 0/1 uses the lists a previous
  * sml_embed_loss_sgd_prepare call built for the SAME triples/n/batch -- so a caller can
  * prepare epoch e+1 on a side stream while epoch e runs. */
-int sml_embed_loss_sgd_prepare(sml_ctx* ctx, const int64_t* triples, int64_t n, int batch, int slot,
-                               void* stream);
+int sml_embed_loss_sgd_prepare(sml_ctx* ctx, const int64_t* triples, int64_t n, int batch,
+                               int64_t n_user, int64_t n_item, int slot, void* stream);
 int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n_user,
                              int64_t n_item, int dtype_bytes, const int64_t* triples, int64_t n,
                              int batch, float lr, float lam_user, float lam_item, int loss_kind,

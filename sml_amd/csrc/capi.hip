@@ -112,19 +112,25 @@ struct Prof {
 
 }  // namespace
 
-// sorted / compacted occurrence lists of one epoch (two sets: one may be prepared on a side
-// stream while the other is in use)
+// sorted occurrence lists and run records of one epoch (two sets: one may be prepared on a side
+// stream while the other is in use).  Keys are uint32 ((batch << row_bits) | row) when that fits,
+// else uint64 ((batch << 32) | row); the key buffers are sized for the wider form.
 struct IndexSet {
     Buf<uint64_t> key_u, key_u2, key_i, key_i2;
     Buf<uint32_t> val_u, val_u2, val_i, val_i2;
-    Buf<uint8_t> uniq, dup_u, dup_i;
+    Buf<SmlRun> rec_u, rec_i;          // one record per sorted position
+    Buf<SmlRun> runs_u, runs_i;        // compacted: duplicated runs only (bare step)
+    Buf<uint32_t> heads_u, heads_i;    // sorted positions of the duplicated-run heads
+    Buf<uint8_t> uniq;
     Buf<int> off_u, off_i, n_sel;
     Buf<char> cub_tmp;
+    int key_bytes = 8, row_bits_u = 32, row_bits_i = 32;
     int64_t n = -1; int batch = 0; const void* triples = nullptr;   // what was prepared here
     void release() {
         key_u.release(); key_u2.release(); key_i.release(); key_i2.release();
         val_u.release(); val_u2.release(); val_i.release(); val_i2.release();
-        uniq.release(); dup_u.release(); dup_i.release(); off_u.release(); off_i.release(); n_sel.release();
+        rec_u.release(); rec_i.release(); runs_u.release(); runs_i.release();
+        uniq.release(); heads_u.release(); heads_i.release(); off_u.release(); off_i.release(); n_sel.release();
         cub_tmp.release();
     }
 };
@@ -140,6 +146,7 @@ struct sml_ctx {
     int sched_len = 0;
     float sched_lr = -1.0f;
     Buf<int32_t> dummy;
+    Buf<SmlRun> rec_x;       // run records of the multi-GPU global item list
     ncclComm_t comm = nullptr;
     int comm_world = 1, comm_rank = 0;
     Buf<uint32_t> hot_list;
@@ -152,7 +159,7 @@ struct sml_ctx {
         out.release(); dout.release(); dx.release(); xin.release(); z1.release(); a1.release(); dz1.release();
         pk.release(); grad.release(); convg.release(); loss_part.release();
         ix[0].release(); ix[1].release();
-        sched.release(); dummy.release();
+        sched.release(); dummy.release(); rec_x.release();
         hot_list.release(); hot_count.release(); hot_first.release(); hot_part.release();
     }
 };
@@ -232,26 +239,87 @@ int ensure_pk(sml_ctx* c) {
 
 int ceil_log2(int64_t x) { int b = 0; while (((int64_t)1 << b) < x) ++b; return b; }
 
-// sort every batch's occurrences by row (stable): users [n], items [2n]
-int sort_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_tiles, hipStream_t st) {
+// selection predicate over sorted positions: q starts a run of at least two equal keys
+template <typename K>
+struct DupHead {
+    const K* keys; int64_t n;
+    __host__ __device__ bool operator()(const uint32_t& q) const {
+        const K k = keys[q];
+        return (q == 0 || keys[q - 1] != k) && ((int64_t)q + 1 < n && keys[q + 1] == k);
+    }
+};
+template <typename K>
+int select_dup_heads(IndexSet* c, const void* keys, int64_t n, uint32_t* heads, int* n_sel, hipStream_t st) {
+    hipcub::CountingInputIterator<uint32_t> pos(0u);
+    DupHead<K> pred{reinterpret_cast<const K*>(keys), n};
+    size_t tmp = 0;
+    HIPCHK(hipcub::DeviceSelect::If(nullptr, tmp, pos, heads, n_sel, (int)n, pred, st));
+    HIPCHK(c->cub_tmp.ensure(tmp + 256));
+    HIPCHK(hipcub::DeviceSelect::If(c->cub_tmp.p, tmp, pos, heads, n_sel, (int)n, pred, st));
+    return SML_OK;
+}
+
+template <typename K>
+int sort_pairs(IndexSet* c, int64_t n, int end_u, int end_i, hipStream_t st) {
+    K* ku = reinterpret_cast<K*>(c->key_u.p); K* ku2 = reinterpret_cast<K*>(c->key_u2.p);
+    K* ki = reinterpret_cast<K*>(c->key_i.p); K* ki2 = reinterpret_cast<K*>(c->key_i2.p);
+    size_t tmp1 = 0, tmp2 = 0;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp1, ku, ku2, c->val_u.p, c->val_u2.p, (int)n, 0, end_u, st));
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, ki, ki2, c->val_i.p, c->val_i2.p, (int)(2 * n), 0, end_i, st));
+    size_t tmp = tmp1 > tmp2 ? tmp1 : tmp2;
+    HIPCHK(c->cub_tmp.ensure(tmp + 256));
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tmp, ku, ku2, c->val_u.p, c->val_u2.p, (int)n, 0, end_u, st));
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tmp, ki, ki2, c->val_i.p, c->val_i2.p, (int)(2 * n), 0, end_i, st));
+    return SML_OK;
+}
+
+// sort every batch's occurrences by row (stable): users [n], items [2n]; then one run record per
+// sorted position.  n_user / n_item (0: unknown) bound the row index so the keys can be 32-bit.
+// With `dups` the duplicated runs are also compacted (stable) with their per-batch ranges, and every
+// occurrence gets its "row occurs once in this batch" mark -- all on the device, no host round trip.
+int sort_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_tiles, int64_t n_user, int64_t n_item,
+               bool dups, hipStream_t st) {
     HIPCHK(c->key_u.ensure((size_t)n)); HIPCHK(c->key_u2.ensure((size_t)n));
     HIPCHK(c->val_u.ensure((size_t)n)); HIPCHK(c->val_u2.ensure((size_t)n));
     HIPCHK(c->key_i.ensure((size_t)2 * n)); HIPCHK(c->key_i2.ensure((size_t)2 * n));
     HIPCHK(c->val_i.ensure((size_t)2 * n)); HIPCHK(c->val_i2.ensure((size_t)2 * n));
-    HIPCHK(sml_launch_build_keys(tri, n, batch, pad_tiles, c->key_u.p, c->val_u.p, c->key_i.p, c->val_i.p, st));
     const int64_t nb = (n + batch - 1) / batch;
-    const int end_bit = 32 + ceil_log2(nb + 1);
-    size_t tmp1 = 0, tmp2 = 0;
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp1, c->key_u.p, c->key_u2.p, c->val_u.p, c->val_u2.p, (int)n, 0,
-                                              end_bit, st));
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, c->key_i.p, c->key_i2.p, c->val_i.p, c->val_i2.p,
-                                              (int)(2 * n), 0, end_bit, st));
-    size_t tmp = tmp1 > tmp2 ? tmp1 : tmp2;
-    HIPCHK(c->cub_tmp.ensure(tmp + 256));
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tmp, c->key_u.p, c->key_u2.p, c->val_u.p, c->val_u2.p, (int)n,
-                                              0, end_bit, st));
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tmp, c->key_i.p, c->key_i2.p, c->val_i.p, c->val_i2.p,
-                                              (int)(2 * n), 0, end_bit, st));
+    const int bb = ceil_log2(nb + 1);
+    const int rbu = n_user > 0 ? ceil_log2(n_user) : 32, rbi = n_item > 0 ? ceil_log2(n_item) : 32;
+    const bool narrow = bb + rbu <= 32 && bb + rbi <= 32;
+    c->key_bytes = narrow ? 4 : 8;
+    c->row_bits_u = narrow ? rbu : 32; c->row_bits_i = narrow ? rbi : 32;
+    HIPCHK(sml_launch_build_keys(c->key_bytes, tri, n, batch, pad_tiles, c->row_bits_u, c->row_bits_i, c->key_u.p, c->val_u.p,
+                                 c->key_i.p, c->val_i.p, st));
+    int rc = narrow ? sort_pairs<uint32_t>(c, n, c->row_bits_u + bb, c->row_bits_i + bb, st)
+                    : sort_pairs<uint64_t>(c, n, 32 + bb, 32 + bb, st);
+    if (rc) return rc;
+    if (!dups) {
+        // one record per sorted position (the MF stage's batches are small: no compaction)
+        HIPCHK(c->rec_u.ensure((size_t)n)); HIPCHK(c->rec_i.ensure((size_t)2 * n));
+        HIPCHK(sml_launch_mark_runs(c->key_bytes, c->key_u2.p, c->val_u2.p, n, c->row_bits_u, c->rec_u.p, nullptr, nullptr, 0, 0, st));
+        HIPCHK(sml_launch_mark_runs(c->key_bytes, c->key_i2.p, c->val_i2.p, 2 * n, c->row_bits_i, c->rec_i.p, nullptr, nullptr, 0, 0, st));
+    } else {
+        // unique marks for the in-place pass; duplicated-run heads selected by position (no per-position
+        // records: the predicate reads the sorted keys), then one record per selected head
+        HIPCHK(c->uniq.ensure((size_t)3 * nb * batch));
+        HIPCHK(c->heads_u.ensure((size_t)n / 2 + 8)); HIPCHK(c->heads_i.ensure((size_t)n + 8));
+        HIPCHK(c->runs_u.ensure((size_t)n / 2 + 8)); HIPCHK(c->runs_i.ensure((size_t)n + 8));
+        HIPCHK(c->off_u.ensure((size_t)nb + 1)); HIPCHK(c->off_i.ensure((size_t)nb + 1)); HIPCHK(c->n_sel.ensure(4));
+        HIPCHK(sml_launch_mark_unique(c->key_bytes, c->key_u2.p, c->val_u2.p, n, c->row_bits_u, c->uniq.p, (int64_t)3 * batch, st));
+        HIPCHK(sml_launch_mark_unique(c->key_bytes, c->key_i2.p, c->val_i2.p, 2 * n, c->row_bits_i, c->uniq.p, (int64_t)3 * batch, st));
+        rc = narrow ? select_dup_heads<uint32_t>(c, c->key_u2.p, n, c->heads_u.p, c->n_sel.p, st)
+                    : select_dup_heads<uint64_t>(c, c->key_u2.p, n, c->heads_u.p, c->n_sel.p, st);
+        if (rc) return rc;
+        rc = narrow ? select_dup_heads<uint32_t>(c, c->key_i2.p, 2 * n, c->heads_i.p, c->n_sel.p + 1, st)
+                    : select_dup_heads<uint64_t>(c, c->key_i2.p, 2 * n, c->heads_i.p, c->n_sel.p + 1, st);
+        if (rc) return rc;
+        HIPCHK(sml_launch_make_runs(c->key_bytes, c->key_u2.p, n, c->row_bits_u, c->heads_u.p, c->n_sel.p, n / 2, c->runs_u.p, st));
+        HIPCHK(sml_launch_make_runs(c->key_bytes, c->key_i2.p, 2 * n, c->row_bits_i, c->heads_i.p, c->n_sel.p + 1, n, c->runs_i.p, st));
+        HIPCHK(sml_launch_batch_offsets(c->runs_u.p, c->n_sel.p, (int)nb, (int64_t)batch, c->off_u.p, st));
+        HIPCHK(sml_launch_batch_offsets(c->runs_i.p, c->n_sel.p + 1, (int)nb, (int64_t)2 * batch, c->off_i.p, st));
+    }
+    c->n = n; c->batch = batch; c->triples = tri;
     return SML_OK;
 }
 
@@ -354,7 +422,12 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
     const int fns = fwd_split(wg_tiles(batch, 1) + wg_tiles(2 * batch, 1)), bsplit = bwd_split(wg_tiles(batch, 1) + wg_tiles(2 * batch, 1));
     HIPCHK(ctx->loss_part.ensure((size_t)nb * lstride));
     ctx->prof.begin(PC_PACK, st); HIPCHK(sml_launch_theta_pack(d, theta, ctx->pk.p, st)); ctx->prof.end(st);
-    ctx->prof.begin(PC_SORT, st); rc = sort_epoch(&ctx->ix[0], triples, n, batch, 1, st); ctx->prof.end(st); if (rc) return rc;
+    ctx->prof.begin(PC_SORT, st); rc = sort_epoch(&ctx->ix[0], triples, n, batch, 1, t->n_user, t->n_item, false, st);
+    if (!rc && xchg) {   // the global item occurrence list of the job: run records over the caller's sorted keys
+        HIPCHK(ctx->rec_x.ensure((size_t)xchg->world * 2 * n));
+        HIPCHK(sml_launch_mark_runs(8, xchg->key_items, xchg->val_items, (int64_t)xchg->world * 2 * n, 32, ctx->rec_x.p, nullptr, nullptr, 0, 0, st));
+    }
+    ctx->prof.end(st); if (rc) return rc;
     HIPCHK(hipMemsetAsync(ctx->loss_part.p, 0, (size_t)nb * lstride * sizeof(float), st));
     const int64_t ns = sml_net_size(d), ps = sml_pk_size(d);
     float* dx_buf = xchg ? xchg->dx_local : ctx->dx.p;
@@ -393,10 +466,10 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
         w.scale = xchg ? xchg->loss_scale : 1.0f; w.loss_part = ctx->loss_part.p + b * lstride;
         w.out_np = fns; w.out_pstride = out_pstride;
         ctx->prof.begin(PC_BWD, st); HIPCHK(sml_launch_bwd(d, bsplit, w, tiles, st)); ctx->prof.end(st);
-        SmlSegUpdArgs u;
+        SmlRunArgs u;
         memset(&u, 0, sizeof(u));
-        u.key_u = ctx->ix[0].key_u2.p + b * batch; u.val_u = ctx->ix[0].val_u2.p + b * batch; u.n_u = B;
-        u.key_i = ctx->ix[0].key_i2.p + 2 * b * batch; u.val_i = ctx->ix[0].val_i2.p + 2 * b * batch; u.n_i = 2 * B;
+        u.run_u = ctx->ix[0].rec_u.p + b * batch; u.n_u = B; u.val_u = ctx->ix[0].val_u2.p;
+        u.run_i = ctx->ix[0].rec_i.p + 2 * b * batch; u.n_i = 2 * B; u.val_i = ctx->ix[0].val_i2.p;
         u.dx = dx_buf; u.dx_i = dx_buf; u.w_user = t->w_user; u.w_item = t->w_item;
         if (xchg) {
             // every rank contributes 2*B item occurrences of this batch (equal B on all ranks)
@@ -406,14 +479,14 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
                 const int64_t ioff = (int64_t)SML_R * tiles_of(B);
                 NCCLCHK(g_rccl.AllGather(dx_buf + ioff * d, xchg->dx_items_all, (size_t)2 * batch * d, ncclFloat, ctx->comm, st));
             }
-            u.key_i = xchg->key_items + (int64_t)xchg->world * 2 * b * batch;
-            u.val_i = xchg->val_items + (int64_t)xchg->world * 2 * b * batch;
+            u.run_i = ctx->rec_x.p + (int64_t)xchg->world * 2 * b * batch;
+            u.val_i = xchg->val_items;
             u.n_i = xchg->world * 2 * B;
             u.dx_i = xchg->dx_items_all;
         }
         u.m_user = t->m_user; u.v_user = t->v_user; u.m_item = t->m_item; u.v_item = t->v_item;
         u.last_user = t->step_user; u.last_item = t->step_item; u.sched = ctx->sched.p; u.cur_step = cur; u.lr = lr;
-        ctx->prof.begin(PC_SEG_ADAM, st); HIPCHK(sml_launch_seg_adam(d, u, st)); ctx->prof.end(st);
+        ctx->prof.begin(PC_SEG_ADAM, st); HIPCHK(sml_launch_run_adam(d, u, (int64_t)u.n_u + u.n_i, st)); ctx->prof.end(st);
     }
     ctx->prof.begin(PC_MISC, st); HIPCHK(sml_launch_loss_finalize(ctx->loss_part.p, (int)nb, lstride, nullptr, batch_loss, st)); ctx->prof.end(st);
     *step += nb;
@@ -526,46 +599,14 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
     return SML_OK;
 }
 
-namespace {
-// sort + unique marks + duplicates-only compaction + per-batch offsets of one epoch, into index set X
-int bare_prepare(sml_ctx* ctx, IndexSet* X, const int64_t* triples, int64_t n, int batch, hipStream_t st) {
-    const int64_t nb = (n + batch - 1) / batch;
-    int rc;
-    if ((rc = sort_epoch(X, triples, n, batch, 0, st))) return rc;
-    // occurrences whose row is unique in its batch are updated in place by the gradient pass; the
-    // segmented update then only sees the duplicated occurrences: compact the sorted lists (stable
-    // select, so slot order inside a run is kept) and find every batch's range in them -- all on
-    // the device, no host round trip
-    HIPCHK(X->uniq.ensure((size_t)3 * nb * batch));
-    HIPCHK(X->dup_u.ensure((size_t)n)); HIPCHK(X->dup_i.ensure((size_t)2 * n));
-    HIPCHK(X->off_u.ensure((size_t)nb + 1)); HIPCHK(X->off_i.ensure((size_t)nb + 1)); HIPCHK(X->n_sel.ensure(4));
-    HIPCHK(sml_launch_mark_unique(X->key_u2.p, X->val_u2.p, X->key_i2.p, X->val_i2.p, n, batch, X->uniq.p, X->dup_u.p,
-                                  X->dup_i.p, st));
-    size_t t1 = 0, t2 = 0, t3 = 0, t4 = 0;
-    HIPCHK(hipcub::DeviceSelect::Flagged(nullptr, t1, X->key_u2.p, X->dup_u.p, X->key_u.p, X->n_sel.p, (int)n, st));
-    HIPCHK(hipcub::DeviceSelect::Flagged(nullptr, t2, X->val_u2.p, X->dup_u.p, X->val_u.p, X->n_sel.p + 1, (int)n, st));
-    HIPCHK(hipcub::DeviceSelect::Flagged(nullptr, t3, X->key_i2.p, X->dup_i.p, X->key_i.p, X->n_sel.p + 2, (int)(2 * n), st));
-    HIPCHK(hipcub::DeviceSelect::Flagged(nullptr, t4, X->val_i2.p, X->dup_i.p, X->val_i.p, X->n_sel.p + 3, (int)(2 * n), st));
-    size_t tmp = t1 > t2 ? t1 : t2; tmp = tmp > t3 ? tmp : t3; tmp = tmp > t4 ? tmp : t4;
-    HIPCHK(X->cub_tmp.ensure(tmp + 256));
-    HIPCHK(hipcub::DeviceSelect::Flagged(X->cub_tmp.p, tmp, X->key_u2.p, X->dup_u.p, X->key_u.p, X->n_sel.p, (int)n, st));
-    HIPCHK(hipcub::DeviceSelect::Flagged(X->cub_tmp.p, tmp, X->val_u2.p, X->dup_u.p, X->val_u.p, X->n_sel.p + 1, (int)n, st));
-    HIPCHK(hipcub::DeviceSelect::Flagged(X->cub_tmp.p, tmp, X->key_i2.p, X->dup_i.p, X->key_i.p, X->n_sel.p + 2, (int)(2 * n), st));
-    HIPCHK(hipcub::DeviceSelect::Flagged(X->cub_tmp.p, tmp, X->val_i2.p, X->dup_i.p, X->val_i.p, X->n_sel.p + 3, (int)(2 * n), st));
-    HIPCHK(sml_launch_batch_offsets(X->key_u.p, X->n_sel.p, (int)nb, X->off_u.p, st));
-    HIPCHK(sml_launch_batch_offsets(X->key_i.p, X->n_sel.p + 2, (int)nb, X->off_i.p, st));
-    X->n = n; X->batch = batch; X->triples = triples;
-    return SML_OK;
-}
-}  // namespace
-
-int sml_embed_loss_sgd_prepare(sml_ctx* ctx, const int64_t* triples, int64_t n, int batch, int slot, void* stream) {
+int sml_embed_loss_sgd_prepare(sml_ctx* ctx, const int64_t* triples, int64_t n, int batch, int64_t n_user,
+                               int64_t n_item, int slot, void* stream) {
     if (!ctx || !triples || n <= 0 || batch <= 0 || (slot != 0 && slot != 1))
         return fail(SML_EINVAL, "sml_embed_loss_sgd_prepare", "bad argument");
     if (batch > ctx->max_batch) return fail(SML_EINVAL, "sml_embed_loss_sgd_prepare", "batch exceeds ctx max_batch");
     if (n > 0x3fffffff) return fail(SML_EINVAL, "sml_embed_loss_sgd_prepare", "epoch too long");
     DevGuard g(ctx->device);
-    return bare_prepare(ctx, &ctx->ix[slot], triples, n, batch, (hipStream_t)stream);
+    return sort_epoch(&ctx->ix[slot], triples, n, batch, 0, n_user, n_item, true, (hipStream_t)stream);
 }
 
 int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n_user, int64_t n_item, int dtype_bytes,
@@ -589,7 +630,7 @@ int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n
     HIPCHK(ctx->loss_part.ensure((size_t)nb * lstride));
     IndexSet* X = &ctx->ix[prepared_slot < 0 ? 0 : prepared_slot];
     if (prepared_slot < 0) {
-        ctx->prof.begin(PC_SORT, st); rc = bare_prepare(ctx, X, triples, n, batch, st); ctx->prof.end(st);
+        ctx->prof.begin(PC_SORT, st); rc = sort_epoch(X, triples, n, batch, 0, n_user, n_item, true, st); ctx->prof.end(st);
         if (rc) return rc;
     } else if (X->n != n || X->batch != batch || X->triples != triples) {
         return fail(SML_ESTATE, "sml_embed_loss_sgd_epoch", "index set was prepared for other triples");
@@ -600,7 +641,7 @@ int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n
     const bool hot = batch >= 4096 && hot_cap <= SML_HOT_MAXCAP;
     const int hot_chunks = 3 * batch / SML_HOT_CHUNK + hot_cap;
     if (hot) {
-        HIPCHK(ctx->hot_list.ensure((size_t)2 * hot_cap));
+        HIPCHK(ctx->hot_list.ensure((size_t)3 * hot_cap));
         HIPCHK(ctx->hot_first.ensure((size_t)hot_cap));
         HIPCHK(ctx->hot_count.ensure((size_t)nb));
         HIPCHK(ctx->hot_part.ensure((size_t)hot_chunks * d));
@@ -613,19 +654,18 @@ int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n
         a.loss_part = ctx->loss_part.p + b * lstride; a.kind = loss_kind; a.lam_user = lam_user; a.lam_item = lam_item;
         a.uniq = X->uniq.p + (size_t)3 * b * batch; a.lr = lr;
         ctx->prof.begin(PC_BARE_GRAD, st); HIPCHK(sml_launch_bare_grad(d, dtype_bytes, a, nullptr, st)); ctx->prof.end(st);
-        SmlSegUpdArgs u;
+        SmlRunArgs u;
         memset(&u, 0, sizeof(u));
-        // compacted (duplicates-only) lists of the whole epoch; the kernels slice out batch b themselves.
-        // The grid still covers the worst case (every occurrence duplicated); surplus groups exit at once.
-        u.key_u = X->key_u.p; u.val_u = X->val_u.p; u.n_u = B;
-        u.key_i = X->key_i.p; u.val_i = X->val_i.p; u.n_i = 2 * B;
-        u.off_u = X->off_u.p; u.off_i = X->off_i.p; u.batch_index = (int)b;
-        u.dx = ctx->dx.p; u.dx_i = ctx->dx.p; u.w_user = w_user; u.w_item = w_item; u.lr = lr; u.skip_single = 0;
+        // compacted duplicated-run lists of the whole epoch; the kernels slice out batch b themselves and
+        // stride over it (how many runs a batch has is only known on the device)
+        u.run_u = X->runs_u.p; u.run_i = X->runs_i.p; u.off_u = X->off_u.p; u.off_i = X->off_i.p; u.batch_index = (int)b;
+        u.val_u = X->val_u2.p; u.val_i = X->val_i2.p;
+        u.dx = ctx->dx.p; u.dx_i = ctx->dx.p; u.w_user = w_user; u.w_item = w_item; u.lr = lr;
         if (hot) {
             u.hot_list = ctx->hot_list.p; u.hot_count = ctx->hot_count.p + b; u.hot_first = ctx->hot_first.p;
             u.hot_part = ctx->hot_part.p; u.hot_cap = hot_cap;
         }
-        ctx->prof.begin(PC_SEG_SGD, st); HIPCHK(sml_launch_seg_sgd(d, dtype_bytes, u, st)); ctx->prof.end(st);
+        ctx->prof.begin(PC_SEG_SGD, st); HIPCHK(sml_launch_run_sgd(d, dtype_bytes, u, (int64_t)3 * B / 2, st)); ctx->prof.end(st);
         if (hot) { ctx->prof.begin(PC_SEG_SGD, st); HIPCHK(sml_launch_hot_rows(d, dtype_bytes, u, hot_chunks, st)); ctx->prof.end(st); }
     }
     ctx->prof.begin(PC_MISC, st); HIPCHK(sml_launch_loss_finalize(ctx->loss_part.p, (int)nb, lstride, nullptr, batch_loss, st)); ctx->prof.end(st);

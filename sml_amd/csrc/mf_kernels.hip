@@ -132,10 +132,14 @@ __global__ __launch_bounds__(256) void k_bare_grad(SmlBareArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
-// sort keys: (batch << 32) | row, value = slot of the occurrence inside its batch
+// sort keys: (batch << row_bits) | row, value = slot of the occurrence inside its batch.
+// K = uint32_t whenever batch and row fit 32 bits together (4 radix passes over 8-byte pairs
+// instead of 5 over 12-byte pairs), else uint64_t with row_bits = 32.
 // ------------------------------------------------------------------------------------
-__global__ void k_build_keys(const int64_t* __restrict__ tri, int64_t n, int batch, int pad_tiles, uint64_t* __restrict__ key_u,
-                             uint32_t* __restrict__ val_u, uint64_t* __restrict__ key_i, uint32_t* __restrict__ val_i) {
+template <typename K>
+__global__ void k_build_keys(const int64_t* __restrict__ tri, int64_t n, int batch, int pad_tiles, int row_bits_u,
+                             int row_bits_i, K* __restrict__ key_u, uint32_t* __restrict__ val_u,
+                             K* __restrict__ key_i, uint32_t* __restrict__ val_i) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     const int64_t b = e / batch;
@@ -143,216 +147,282 @@ __global__ void k_build_keys(const int64_t* __restrict__ tri, int64_t n, int bat
     const uint32_t Bb = (uint32_t)(rem < batch ? rem : batch);
     const uint32_t t = (uint32_t)(e - b * batch);
     const uint32_t ioff = pad_tiles ? ((Bb + SML_R - 1) / SML_R) * SML_R : Bb;   // first item slot of the batch
-    const uint64_t hi = (uint64_t)b << 32;
-    key_u[e] = hi | (uint32_t)tri[e * 3];
+    key_u[e] = ((K)b << row_bits_u) | (K)(uint32_t)tri[e * 3];
     val_u[e] = t;
-    key_i[e] = hi | (uint32_t)tri[e * 3 + 1];
-    val_i[e] = ioff + t;
-    key_i[n + e] = hi | (uint32_t)tri[e * 3 + 2];
-    val_i[n + e] = ioff + Bb + t;
+    // items: batch b's positives then negatives occupy [2*b*batch, 2*b*batch + 2*Bb) -- contiguous per
+    // batch, so after the (stable) sort batch b's item occurrences are exactly that range again
+    const int64_t base = 2 * b * batch;
+    key_i[base + t] = ((K)b << row_bits_i) | (K)(uint32_t)tri[e * 3 + 1];
+    val_i[base + t] = ioff + t;
+    key_i[base + Bb + t] = ((K)b << row_bits_i) | (K)(uint32_t)tri[e * 3 + 2];
+    val_i[base + Bb + t] = ioff + Bb + t;
 }
 
-// per epoch: occurrence (batch b, slot s) is "unique" iff its sorted neighbours carry other keys
-__global__ void k_mark_unique(const uint64_t* __restrict__ key_u, const uint32_t* __restrict__ val_u,
-                              const uint64_t* __restrict__ key_i, const uint32_t* __restrict__ val_i, int64_t n,
-                              int batch, uint8_t* __restrict__ uniq, uint8_t* __restrict__ dup_u,
-                              uint8_t* __restrict__ dup_i) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= 3 * n) return;
-    const bool item = p >= n;
-    const uint64_t* keys = item ? key_i : key_u;
-    const uint32_t* vals = item ? val_i : val_u;
-    const int64_t q = item ? p - n : p, m = item ? 2 * n : n;
-    const uint64_t k = keys[q];
-    const bool one = (q == 0 || keys[q - 1] != k) && (q + 1 >= m || keys[q + 1] != k);
-    const int64_t b = (int64_t)(k >> 32);
-    uniq[b * 3 * batch + vals[q]] = one ? 1 : 0;
-    (item ? dup_i : dup_u)[q] = one ? 0 : 1;       // selection flags of the compacted (duplicates-only) lists
+// per epoch, over one sorted list: a record for every position (len = 0 unless the position
+// starts a run of equal keys); optionally the selection flag of duplicated runs (len >= 2) and
+// the "row occurs once in its batch" mark of every occurrence (indexed by batch and slot).
+template <typename K>
+__global__ void k_mark_runs(const K* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t n, int row_bits,
+                            SmlRun* __restrict__ rec, uint8_t* __restrict__ flag_dup, uint8_t* __restrict__ uniq,
+                            int64_t uniq_stride, int64_t uniq_item_base) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    constexpr int PROBE = 8;
+    const K k = keys[q];
+    K nb[PROBE + 1];
+    nb[0] = q > 0 ? keys[q - 1] : (K)~k;
+#pragma unroll
+    for (int j = 1; j <= PROBE; ++j) nb[j] = q + j < n ? keys[q + j] : (K)~k;
+    const bool head = nb[0] != k;
+    int len = 0;
+    if (head) {
+        len = 1;
+#pragma unroll
+        for (int j = 1; j <= PROBE; ++j) len += (len == j && nb[j] == k) ? 1 : 0;
+        if (len > PROBE) {   // upper bound of `k` in (q+PROBE, n) by bisection
+            int64_t lo = q + PROBE + 1, hi = n;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (keys[mid] == k) lo = mid + 1; else hi = mid;
+            }
+            len = (int)(lo - q);
+        }
+    }
+    SmlRun r;
+    r.row = row_bits >= 32 ? (uint32_t)k : (uint32_t)(k & (((K)1 << (row_bits & 31)) - 1));
+    r.pos = (uint32_t)q; r.len = (uint32_t)len; r.pad = 0;
+    rec[q] = r;
+    if (flag_dup != nullptr) flag_dup[q] = (head && len >= 2) ? 1 : 0;
+    if (uniq != nullptr) {
+        const int64_t b = row_bits >= 32 ? (int64_t)((uint64_t)k >> 32) : (int64_t)(k >> (row_bits & 31));
+        const bool one = head && len == 1;      // (a non-head position belongs to a longer run)
+        uniq[b * uniq_stride + uniq_item_base + vals[q]] = one ? 1 : 0;
+    }
 }
 
-// off[b] = first compacted position whose batch field is >= b  (off[nb] = number selected)
-__global__ void k_batch_offsets(const uint64_t* __restrict__ keys, const int* __restrict__ n_sel, int nb,
+// bare step: "row occurs once in its batch" mark of every occurrence (indexed by batch and slot)
+template <typename K>
+__global__ void k_mark_unique(const K* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t n, int row_bits,
+                              uint8_t* __restrict__ uniq, int64_t uniq_stride) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const K k = keys[q];
+    const bool one = (q == 0 || keys[q - 1] != k) && (q + 1 >= n || keys[q + 1] != k);
+    const int64_t b = row_bits >= 32 ? (int64_t)((uint64_t)k >> 32) : (int64_t)(k >> (row_bits & 31));
+    uniq[b * uniq_stride + vals[q]] = one ? 1 : 0;
+}
+
+// bare step: run records of the compacted duplicated-run heads (positions selected on the device)
+template <typename K>
+__global__ void k_make_runs(const K* __restrict__ keys, int64_t n, int row_bits, const uint32_t* __restrict__ heads,
+                            const int* __restrict__ n_heads, SmlRun* __restrict__ runs) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= *n_heads) return;
+    constexpr int PROBE = 8;
+    const int64_t q = heads[h];
+    const K k = keys[q];
+    K nb[PROBE + 1];
+#pragma unroll
+    for (int j = 1; j <= PROBE; ++j) nb[j] = q + j < n ? keys[q + j] : (K)~k;
+    int len = 1;
+#pragma unroll
+    for (int j = 1; j <= PROBE; ++j) len += (len == j && nb[j] == k) ? 1 : 0;
+    if (len > PROBE) {
+        int64_t lo = q + PROBE + 1, hi = n;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (keys[mid] == k) lo = mid + 1; else hi = mid;
+        }
+        len = (int)(lo - q);
+    }
+    SmlRun r;
+    r.row = row_bits >= 32 ? (uint32_t)k : (uint32_t)(k & (((K)1 << (row_bits & 31)) - 1));
+    r.pos = (uint32_t)q; r.len = (uint32_t)len; r.pad = 0;
+    runs[h] = r;
+}
+
+// off[b] = first compacted run whose position is >= b * seg  (off[nb] = number of runs)
+__global__ void k_batch_offsets(const SmlRun* __restrict__ runs, const int* __restrict__ n_sel, int nb, int64_t seg,
                                 int* __restrict__ off) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b > nb) return;
     const int n = *n_sel;
     int lo = 0, hi = n;
-    const uint64_t want = (uint64_t)b << 32;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < want) lo = mid + 1; else hi = mid; }
+    const int64_t want = (int64_t)b * seg;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int64_t)runs[mid].pos < want) lo = mid + 1; else hi = mid; }
     off[b] = lo;
 }
 
-// this batch's slice of the (possibly compacted) sorted lists
-struct SegLists { const uint64_t* key_u; const uint32_t* val_u; int n_u; const uint64_t* key_i; const uint32_t* val_i; int n_i; };
-__device__ __forceinline__ SegLists seg_lists(const SmlSegUpdArgs& a) {
-    SegLists L{a.key_u, a.val_u, a.n_u, a.key_i, a.val_i, a.n_i};
+// this batch's slice of the run lists
+struct RunLists { const SmlRun* run_u; int n_u; const SmlRun* run_i; int n_i; };
+__device__ __forceinline__ RunLists run_lists(const SmlRunArgs& a) {
+    RunLists L{a.run_u, a.n_u, a.run_i, a.n_i};
     if (a.off_u != nullptr) {
         const int u0 = a.off_u[a.batch_index], i0 = a.off_i[a.batch_index];
-        L.key_u += u0; L.val_u += u0; L.n_u = a.off_u[a.batch_index + 1] - u0;
-        L.key_i += i0; L.val_i += i0; L.n_i = a.off_i[a.batch_index + 1] - i0;
+        L.run_u += u0; L.n_u = a.off_u[a.batch_index + 1] - u0;
+        L.run_i += i0; L.n_i = a.off_i[a.batch_index + 1] - i0;
     }
     return L;
 }
 
 // ------------------------------------------------------------------------------------
-// segmented row update: one lane group per sorted occurrence; the group at the head of
-// a run of equal keys sums the run's gradient rows in order (deterministic) and writes
-// the row once.  OPT 0: SGD.  OPT 1: Adam with the skipped zero-gradient steps replayed.
+// segmented row update over run records: one lane group per record (grid-stride).  The group
+// sums the run's per-occurrence gradient rows in slot order (deterministic) and writes the row
+// once; the row (and its Adam state) is fetched before the sum, so the two latencies overlap.
+// Runs longer than LONG are summed by the whole wavefront; runs longer than SML_HOT (SGD, large
+// batches) go to the workgroup-level reducers.  OPT 0: SGD.  OPT 1: Adam with the skipped
+// zero-gradient steps replayed.
 // ------------------------------------------------------------------------------------
 template <int D, typename T, int OPT>
-__global__ __launch_bounds__(256) void k_seg_update(SmlSegUpdArgs a) {
+__global__ __launch_bounds__(256) void k_run_update(SmlRunArgs a) {
     constexpr int VEC = RowVec<T>::VEC;
     constexpr int LPR = D / VEC;
-    constexpr int G = 64 / LPR;             // lane groups (sorted positions) per wavefront
+    constexpr int G = 64 / LPR;             // lane groups (records) per wavefront
     constexpr int LONG = 8;                 // runs longer than this are summed by the whole wavefront
+    constexpr int LD = VEC == 4 ? 8 : 4;    // ... with LD rows per lane group in flight
     __shared__ SmlSched swin[OPT == 1 ? SML_SW : 1];
     if (OPT == 1) {                       // the Adam schedule of the last SML_SW steps, staged once per block
         sched_window_load(swin, a.sched, a.cur_step, threadIdx.x);
         __syncthreads();
     }
-    const int gid = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int grp = lane / LPR, sub = lane % LPR;
-    int pos = gid / LPR;
-    // which table this position belongs to (a wavefront may straddle the user/item boundary)
-    const SegLists L = seg_lists(a);
-    int is_item = 0, n = L.n_u;
-    if (pos >= L.n_u) { pos -= L.n_u; is_item = 1; n = L.n_i; }
-    const bool valid = pos < n;
-    const uint64_t* keys = is_item ? L.key_i : L.key_u;
-    uint64_t key = 0;
-    bool head = false;
-    int len = 0;
-    if (valid) {
-        key = keys[pos];
-        // the neighbourhood in one batch of independent loads: most runs are 1-8 long
-        uint64_t nb[LONG + 1];
-        nb[0] = pos > 0 ? keys[pos - 1] : ~key;
-#pragma unroll
-        for (int j = 1; j <= LONG; ++j) nb[j] = pos + j < n ? keys[pos + j] : ~key;
-        head = nb[0] != key;
-        if (head) {
-            len = 1;
-#pragma unroll
-            for (int j = 1; j <= LONG; ++j) len += (len == j && nb[j] == key) ? 1 : 0;
-            if (len > LONG) {   // a hot row: upper bound of `key` in (pos+LONG, n) by bisection
-                int lo = pos + LONG + 1, hi2 = n;
-                while (lo < hi2) {
-                    const int mid = (lo + hi2) >> 1;
-                    if (keys[mid] == key) lo = mid + 1; else hi2 = mid;
+    const RunLists L = run_lists(a);
+    const int total = L.n_u + L.n_i;
+    const int wave_id = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int n_waves = (gridDim.x * 256) >> 6;
+    // Compacted run lists (bare step): record k = (trip * G + grp) * n_waves + wave -- neighbouring records
+    // (hot rows are neighbours in a sorted list when popular rows have neighbouring ids) go to different
+    // wavefronts, so their long sums run side by side instead of one after the other in one wave.
+    // Per-position records (MF stage): a run of length L is followed by L-1 empty records, which spaces
+    // the heads out already; consecutive records per wave keep the record loads coalesced.
+    const bool strided = a.off_u != nullptr;
+    for (int base = 0; base < total; base += n_waves * G) {                 // wave-uniform trip count
+        const int k = strided ? base + grp * n_waves + wave_id : base + wave_id * G + grp;
+        const bool valid = k < total;
+        const int is_item = (valid && k >= L.n_u) ? 1 : 0;
+        SmlRun run; run.row = 0; run.pos = 0; run.len = 0; run.pad = 0;
+        if (valid) run = is_item ? L.run_i[k - L.n_u] : L.run_u[k];
+        int len = (int)run.len;
+        bool head = len > 0;
+        if (OPT == 0 && a.hot_list != nullptr && head && len > SML_HOT) {
+            // a hot row: hand the run to the workgroup-level reducers (k_hot_partial / k_hot_apply)
+            if (sub == 0) {
+                const int slot = atomicAdd(a.hot_count, 1);
+                if (slot < a.hot_cap) {
+                    a.hot_list[3 * slot] = run.pos | ((uint32_t)is_item << 31);
+                    a.hot_list[3 * slot + 1] = run.len;
+                    a.hot_list[3 * slot + 2] = run.row;
                 }
-                len = lo - pos;
+            }
+            head = false;
+        }
+        // the row and its optimiser state do not depend on the gradient sum: fetch them first
+        T* w = reinterpret_cast<T*>(is_item ? a.w_item : a.w_user);
+        const int64_t row = run.row;
+        float p[VEC];
+        float m[4] = {0.f, 0.f, 0.f, 0.f}, v[4] = {0.f, 0.f, 0.f, 0.f};
+        int from = 0;
+        if (head) {
+            RowVec<T>::load(w + row * D + sub * VEC, p);
+            if constexpr (OPT == 1) {
+                RowVec<float>::load((is_item ? a.m_item : a.m_user) + row * D + sub * 4, m);
+                RowVec<float>::load((is_item ? a.v_item : a.v_user) + row * D + sub * 4, v);
+                from = (is_item ? a.last_item : a.last_user)[row];
             }
         }
-    }
-    if (OPT == 0 && a.skip_single && len == 1) head = false;     // applied in place by k_bare_grad
-    if (OPT == 0 && a.hot_list != nullptr && head && len > SML_HOT) {
-        // a hot row: hand the run to the workgroup-level reducers (k_hot_partial / k_hot_apply)
-        if (sub == 0) {
-            const int slot = atomicAdd(a.hot_count, 1);
-            if (slot < a.hot_cap) {
-                a.hot_list[2 * slot] = (uint32_t)pos | ((uint32_t)is_item << 31);
-                a.hot_list[2 * slot + 1] = (uint32_t)len;
-            }
-        }
-        head = false;
-    }
-    float g[VEC];
+        float g[VEC];
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) g[k] = 0.0f;
-    // ---- short runs: the head's own lane group sums them, up to LONG rows in flight, in slot order
-    if (head && len <= LONG) {
-        const uint32_t* vals = is_item ? L.val_i : L.val_u;
-        const float* dx = is_item ? a.dx_i : a.dx;
-        float x[LONG][VEC];
+        for (int q = 0; q < VEC; ++q) g[q] = 0.0f;
+        // ---- short runs: the record's own lane group sums them, up to LONG rows in flight, in slot order
+        if (head && len <= LONG) {
+            const uint32_t* vals = (is_item ? a.val_i : a.val_u) + run.pos;
+            const float* dx = is_item ? a.dx_i : a.dx;
+            uint32_t sl[LONG];
 #pragma unroll
-        for (int j = 0; j < LONG; ++j)
-            if (j < len) {
-                const float* src = dx + (int64_t)vals[pos + j] * D + sub * VEC;
+            for (int j = 0; j < LONG; ++j) sl[j] = j < len ? vals[j] : 0u;
+            float x[LONG][VEC];
 #pragma unroll
-                for (int h = 0; h < VEC / 4; ++h) RowVec<float>::load(src + h * 4, reinterpret_cast<float(&)[4]>(x[j][h * 4]));
-            }
-#pragma unroll
-        for (int j = 0; j < LONG; ++j)
-            if (j < len) {
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) g[k] += x[j][k];
-            }
-    }
-    // ---- long runs (hot rows): the wavefront's G lane groups each sum a strided share, then the
-    // shares are added across groups in a fixed xor order (deterministic)
-    unsigned long long todo = __ballot(head && len > LONG && sub == 0);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const int l_pos = __shfl(pos, leader, 64), l_len = __shfl(len, leader, 64), l_item = __shfl(is_item, leader, 64);
-        const uint32_t* vals = l_item ? L.val_i : L.val_u;
-        const float* dx = l_item ? a.dx_i : a.dx;
-        float acc[VEC];
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
-        for (int q0 = grp; q0 < l_len; q0 += 4 * G) {
-            float x[4][VEC];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (q0 + j * G < l_len) {
-                    const float* src = dx + (int64_t)vals[l_pos + q0 + j * G] * D + sub * VEC;
+            for (int j = 0; j < LONG; ++j)
+                if (j < len) {
+                    const float* src = dx + (int64_t)sl[j] * D + sub * VEC;
 #pragma unroll
                     for (int h = 0; h < VEC / 4; ++h) RowVec<float>::load(src + h * 4, reinterpret_cast<float(&)[4]>(x[j][h * 4]));
                 }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (q0 + j * G < l_len) {
+            for (int j = 0; j < LONG; ++j)
+                if (j < len) {
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) acc[k] += x[j][k];
+                    for (int q = 0; q < VEC; ++q) g[q] += x[j][q];
                 }
         }
+        // ---- long runs: the wavefront's G lane groups each sum a strided share, then the shares are
+        // added across groups in a fixed xor order (deterministic)
+        unsigned long long todo = __ballot(head && len > LONG && sub == 0);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int l_pos = __shfl((int)run.pos, leader, 64), l_len = __shfl(len, leader, 64), l_item = __shfl(is_item, leader, 64);
+            const uint32_t* vals = (l_item ? a.val_i : a.val_u) + l_pos;
+            const float* dx = l_item ? a.dx_i : a.dx;
+            float acc[VEC];
 #pragma unroll
-        for (int off = LPR; off < 64; off <<= 1)
+            for (int q = 0; q < VEC; ++q) acc[q] = 0.0f;
+            for (int q0 = grp; q0 < l_len; q0 += LD * G) {
+                float x[LD][VEC];
+                uint32_t sl[LD];
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[k] += __shfl_xor(acc[k], off, 64);
-        if (lane / LPR == leader / LPR) {
+                for (int j = 0; j < LD; ++j) sl[j] = q0 + j * G < l_len ? vals[q0 + j * G] : 0u;
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) g[k] = acc[k];
+                for (int j = 0; j < LD; ++j)
+                    if (q0 + j * G < l_len) {
+                        const float* src = dx + (int64_t)sl[j] * D + sub * VEC;
+#pragma unroll
+                        for (int h = 0; h < VEC / 4; ++h) RowVec<float>::load(src + h * 4, reinterpret_cast<float(&)[4]>(x[j][h * 4]));
+                    }
+#pragma unroll
+                for (int j = 0; j < LD; ++j)
+                    if (q0 + j * G < l_len) {
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) acc[q] += x[j][q];
+                    }
+            }
+#pragma unroll
+            for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) acc[q] += __shfl_xor(acc[q], off, 64);
+            if (lane / LPR == leader / LPR) {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) g[q] = acc[q];
+            }
         }
-    }
-    if (!head) return;
-    T* w = reinterpret_cast<T*>(is_item ? a.w_item : a.w_user);
-    const int64_t row = (uint32_t)key;
-    float p[VEC];
-    RowVec<T>::load(w + row * D + sub * VEC, p);
-    if constexpr (OPT == 0) {
+        if (!head) continue;
+        if constexpr (OPT == 0) {
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) p[k] -= a.lr * g[k];
-        RowVec<T>::store(w + row * D + sub * VEC, p);
-    } else {
-        float* mt = is_item ? a.m_item : a.m_user;
-        float* vt = is_item ? a.v_item : a.v_user;
-        int32_t* last = is_item ? a.last_item : a.last_user;
-        float m[4], v[4];
-        RowVec<float>::load(mt + row * D + sub * 4, m);
-        RowVec<float>::load(vt + row * D + sub * 4, v);
-        const int from = last[row];
-        const SmlSched sc = swin[SML_SW - 1];      // = sched[cur_step]
+            for (int q = 0; q < VEC; ++q) p[q] -= a.lr * g[q];
+            RowVec<T>::store(w + row * D + sub * VEC, p);
+        } else {
+            const SmlSched sc = swin[SML_SW - 1];      // = sched[cur_step]
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            adam_replay_w(p[k], m[k], v[k], from, a.cur_step - 1, a.sched, swin, a.cur_step);
-            adam_apply(p[k], m[k], v[k], g[k], sc);
+            for (int q = 0; q < 4; ++q) {
+                adam_replay_w(p[q], m[q], v[q], from, a.cur_step - 1, a.sched, swin, a.cur_step);
+                adam_apply(p[q], m[q], v[q], g[q], sc);
+            }
+            RowVec<T>::store(w + row * D + sub * VEC, p);
+            RowVec<float>::store((is_item ? a.m_item : a.m_user) + row * D + sub * 4, m);
+            RowVec<float>::store((is_item ? a.v_item : a.v_user) + row * D + sub * 4, v);
+            if (sub == 0) (is_item ? a.last_item : a.last_user)[row] = a.cur_step;
         }
-        RowVec<T>::store(w + row * D + sub * VEC, p);
-        RowVec<float>::store(mt + row * D + sub * 4, m);
-        RowVec<float>::store(vt + row * D + sub * 4, v);
-        if (sub == 0) last[row] = a.cur_step;
     }
 }
 
 // ------------------------------------------------------------------------------------
-// hot rows: chunk partial sums.  One workgroup per (hot run, chunk of SML_HOT_CHUNK occurrences);
-// the flattened chunk index -> (run, chunk) map is a prefix sum over the hot list, recomputed per
-// workgroup in LDS (the list has at most a few thousand entries).  Fixed summation order.
+// hot rows: chunk partial sums.  One workgroup per (hot run, chunk of SML_HOT_CHUNK occurrences),
+// grid-stride; the flattened chunk index -> (run, chunk) map is a prefix sum over the hot list,
+// recomputed per workgroup in LDS (the list has at most a few thousand entries).  Fixed order.
 // ------------------------------------------------------------------------------------
 template <int D, typename T>
-__global__ __launch_bounds__(256) void k_hot_partial(SmlSegUpdArgs a) {
+__global__ __launch_bounds__(256) void k_hot_partial(SmlRunArgs a) {
     constexpr int VEC = 4;
     constexpr int LPR = D / VEC;
     constexpr int GB = 256 / LPR;            // lane groups per workgroup
@@ -366,7 +436,7 @@ __global__ __launch_bounds__(256) void k_hot_partial(SmlSegUpdArgs a) {
     const int per = (nh + 255) / 256;
     int local = 0;
     for (int e = tid * per; e < min(nh, (tid + 1) * per); ++e)
-        local += ((int)a.hot_list[2 * e + 1] + SML_HOT_CHUNK - 1) / SML_HOT_CHUNK;
+        local += ((int)a.hot_list[3 * e + 1] + SML_HOT_CHUNK - 1) / SML_HOT_CHUNK;
     tsum[tid + 1] = local;
     __syncthreads();
     if (tid == 0) { tsum[0] = 0; for (int i = 1; i <= 256; ++i) tsum[i] += tsum[i - 1]; }
@@ -375,58 +445,61 @@ __global__ __launch_bounds__(256) void k_hot_partial(SmlSegUpdArgs a) {
         int run = tsum[tid];
         for (int e = tid * per; e < min(nh, (tid + 1) * per); ++e) {
             pre[e] = run;
-            run += ((int)a.hot_list[2 * e + 1] + SML_HOT_CHUNK - 1) / SML_HOT_CHUNK;
+            run += ((int)a.hot_list[3 * e + 1] + SML_HOT_CHUNK - 1) / SML_HOT_CHUNK;
         }
         if (tid == 255) pre[nh] = tsum[256];
     }
     __syncthreads();
-    const int w = blockIdx.x;
-    if (w >= pre[nh]) return;
-    int lo = 0, hi2 = nh - 1;                 // largest h with pre[h] <= w
-    while (lo < hi2) { const int mid = (lo + hi2 + 1) >> 1; if (pre[mid] <= w) lo = mid; else hi2 = mid - 1; }
-    const int h = lo, c = w - pre[h];
-    if (c == 0 && tid == 0) a.hot_first[h] = w;
-    const uint32_t packed = a.hot_list[2 * h];
-    const int is_item = packed >> 31, pos0 = (int)(packed & 0x7fffffffu), len = (int)a.hot_list[2 * h + 1];
-    const SegLists L = seg_lists(a);
-    const uint32_t* vals = is_item ? L.val_i : L.val_u;
-    const float* dx = is_item ? a.dx_i : a.dx;
-    const int q_begin = c * SML_HOT_CHUNK, q_end = min(len, q_begin + SML_HOT_CHUNK);
     const int grp = tid / LPR, sub = tid % LPR;
-    float acc[VEC] = {0.f, 0.f, 0.f, 0.f};
-    for (int q0 = q_begin + grp; q0 < q_end; q0 += 8 * GB) {
-        float x[8][VEC];
+    for (int w = blockIdx.x; w < pre[nh]; w += gridDim.x) {
+        int lo = 0, hi2 = nh - 1;                 // largest h with pre[h] <= w
+        while (lo < hi2) { const int mid = (lo + hi2 + 1) >> 1; if (pre[mid] <= w) lo = mid; else hi2 = mid - 1; }
+        const int h = lo, c = w - pre[h];
+        if (c == 0 && tid == 0) a.hot_first[h] = w;
+        const uint32_t packed = a.hot_list[3 * h];
+        const int is_item = packed >> 31, pos0 = (int)(packed & 0x7fffffffu), len = (int)a.hot_list[3 * h + 1];
+        const uint32_t* vals = (is_item ? a.val_i : a.val_u) + pos0;
+        const float* dx = is_item ? a.dx_i : a.dx;
+        const int q_begin = c * SML_HOT_CHUNK, q_end = min(len, q_begin + SML_HOT_CHUNK);
+        float acc[VEC] = {0.f, 0.f, 0.f, 0.f};
+        for (int q0 = q_begin + grp; q0 < q_end; q0 += 8 * GB) {
+            float x[8][VEC];
+            uint32_t sl[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (q0 + j * GB < q_end) RowVec<float>::load(dx + (int64_t)vals[pos0 + q0 + j * GB] * D + sub * VEC, x[j]);
+            for (int j = 0; j < 8; ++j) sl[j] = q0 + j * GB < q_end ? vals[q0 + j * GB] : 0u;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (q0 + j * GB < q_end) {
+            for (int j = 0; j < 8; ++j)
+                if (q0 + j * GB < q_end) RowVec<float>::load(dx + (int64_t)sl[j] * D + sub * VEC, x[j]);
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) acc[k] += x[j][k];
-            }
-    }
-    RowVec<float>::store(&rows[grp][sub * VEC], acc);
-    __syncthreads();
-    if (tid < D) {
-        float s2 = 0.0f;
+            for (int j = 0; j < 8; ++j)
+                if (q0 + j * GB < q_end) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] += x[j][k];
+                }
+        }
+        __syncthreads();                          // the previous trip's readers of rows[] are done
+        RowVec<float>::store(&rows[grp][sub * VEC], acc);
+        __syncthreads();
+        if (tid < D) {
+            float s2 = 0.0f;
 #pragma unroll 8
-        for (int g2 = 0; g2 < GB; ++g2) s2 += rows[g2][tid];
-        a.hot_part[(int64_t)w * D + tid] = s2;
+            for (int g2 = 0; g2 < GB; ++g2) s2 += rows[g2][tid];
+            a.hot_part[(int64_t)w * D + tid] = s2;
+        }
     }
 }
 
 // hot rows: sum each run's chunk partials in order and take the SGD step
 template <int D, typename T>
-__global__ __launch_bounds__(256) void k_hot_apply(SmlSegUpdArgs a) {
+__global__ __launch_bounds__(256) void k_hot_apply(SmlRunArgs a) {
     constexpr int VEC = RowVec<T>::VEC;
     constexpr int LPR = D / VEC;
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const int h = gid / LPR, sub = gid % LPR;
     const int nh = min(*a.hot_count, a.hot_cap);
     if (h >= nh) return;
-    const uint32_t packed = a.hot_list[2 * h];
-    const int is_item = packed >> 31, pos0 = (int)(packed & 0x7fffffffu), len = (int)a.hot_list[2 * h + 1];
+    const uint32_t packed = a.hot_list[3 * h];
+    const int is_item = packed >> 31, len = (int)a.hot_list[3 * h + 1];
     const int first = a.hot_first[h], nchunks = (len + SML_HOT_CHUNK - 1) / SML_HOT_CHUNK;
     float g[VEC];
 #pragma unroll
@@ -447,9 +520,7 @@ __global__ __launch_bounds__(256) void k_hot_apply(SmlSegUpdArgs a) {
                 for (int k = 0; k < VEC; ++k) g[k] += x[j][k];
             }
     }
-    const SegLists L = seg_lists(a);
-    const uint64_t* keys = is_item ? L.key_i : L.key_u;
-    const int64_t row = (uint32_t)keys[pos0];
+    const int64_t row = a.hot_list[3 * h + 2];
     T* w = reinterpret_cast<T*>(is_item ? a.w_item : a.w_user);
     float p[VEC];
     RowVec<T>::load(w + row * D + sub * VEC, p);
@@ -699,46 +770,70 @@ hipError_t sml_launch_bare_grad(int d, int dtype_bytes, const SmlBareArgs& a, in
     } else return hipErrorInvalidValue;
     return hipGetLastError();
 }
-hipError_t sml_launch_mark_unique(const uint64_t* key_u, const uint32_t* val_u, const uint64_t* key_i,
-                                  const uint32_t* val_i, int64_t n, int batch, uint8_t* uniq, uint8_t* dup_u,
-                                  uint8_t* dup_i, hipStream_t st) {
-    k_mark_unique<<<dim3((unsigned)((3 * n + 255) / 256)), dim3(256), 0, st>>>(key_u, val_u, key_i, val_i, n, batch, uniq,
-                                                                                 dup_u, dup_i);
+hipError_t sml_launch_mark_runs(int key_bytes, const void* keys, const uint32_t* vals, int64_t n, int row_bits, SmlRun* rec,
+                                uint8_t* flag_dup, uint8_t* uniq, int64_t uniq_stride, int64_t uniq_item_base, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (key_bytes == 4) k_mark_runs<uint32_t><<<grid, dim3(256), 0, st>>>((const uint32_t*)keys, vals, n, row_bits, rec, flag_dup, uniq, uniq_stride, uniq_item_base);
+    else k_mark_runs<uint64_t><<<grid, dim3(256), 0, st>>>((const uint64_t*)keys, vals, n, row_bits, rec, flag_dup, uniq, uniq_stride, uniq_item_base);
     return hipGetLastError();
 }
-hipError_t sml_launch_batch_offsets(const uint64_t* keys, const int* n_sel, int nb, int* off, hipStream_t st) {
-    k_batch_offsets<<<dim3((nb + 1 + 63) / 64), dim3(64), 0, st>>>(keys, n_sel, nb, off);
+hipError_t sml_launch_mark_unique(int key_bytes, const void* keys, const uint32_t* vals, int64_t n, int row_bits, uint8_t* uniq,
+                                  int64_t uniq_stride, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (key_bytes == 4) k_mark_unique<uint32_t><<<grid, dim3(256), 0, st>>>((const uint32_t*)keys, vals, n, row_bits, uniq, uniq_stride);
+    else k_mark_unique<uint64_t><<<grid, dim3(256), 0, st>>>((const uint64_t*)keys, vals, n, row_bits, uniq, uniq_stride);
     return hipGetLastError();
 }
-hipError_t sml_launch_build_keys(const int64_t* tri, int64_t n, int batch, int pad_tiles, uint64_t* key_u,
-                                 uint32_t* val_u, uint64_t* key_i, uint32_t* val_i, hipStream_t st) {
-    k_build_keys<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(tri, n, batch, pad_tiles, key_u, val_u, key_i, val_i);
+hipError_t sml_launch_make_runs(int key_bytes, const void* keys, int64_t n, int row_bits, const uint32_t* heads, const int* n_heads,
+                                int64_t max_heads, SmlRun* runs, hipStream_t st) {
+    if (max_heads <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((max_heads + 255) / 256));
+    if (key_bytes == 4) k_make_runs<uint32_t><<<grid, dim3(256), 0, st>>>((const uint32_t*)keys, n, row_bits, heads, n_heads, runs);
+    else k_make_runs<uint64_t><<<grid, dim3(256), 0, st>>>((const uint64_t*)keys, n, row_bits, heads, n_heads, runs);
     return hipGetLastError();
 }
-hipError_t sml_launch_seg_adam(int d, const SmlSegUpdArgs& a, hipStream_t st) {
-    const int lpr = d / 4;
-    const int nb = (int)(((int64_t)(a.n_u + a.n_i) * lpr + 255) / 256);
-    SML_DISPATCH_D(d, k_seg_update<DD, float, 1><<<dim3(nb), dim3(256), 0, st>>>(a));
+hipError_t sml_launch_batch_offsets(const SmlRun* runs, const int* n_sel, int nb, int64_t seg, int* off, hipStream_t st) {
+    k_batch_offsets<<<dim3((nb + 1 + 63) / 64), dim3(64), 0, st>>>(runs, n_sel, nb, seg, off);
     return hipGetLastError();
 }
-hipError_t sml_launch_seg_sgd(int d, int dtype_bytes, const SmlSegUpdArgs& a, hipStream_t st) {
-    const int lpr = d * dtype_bytes / 16;
-    const int nb = (int)(((int64_t)(a.n_u + a.n_i) * lpr + 255) / 256);
+hipError_t sml_launch_build_keys(int key_bytes, const int64_t* tri, int64_t n, int batch, int pad_tiles, int row_bits_u,
+                                 int row_bits_i, void* key_u, uint32_t* val_u, void* key_i, uint32_t* val_i, hipStream_t st) {
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (key_bytes == 4) k_build_keys<uint32_t><<<grid, dim3(256), 0, st>>>(tri, n, batch, pad_tiles, row_bits_u, row_bits_i, (uint32_t*)key_u, val_u, (uint32_t*)key_i, val_i);
+    else k_build_keys<uint64_t><<<grid, dim3(256), 0, st>>>(tri, n, batch, pad_tiles, row_bits_u, row_bits_i, (uint64_t*)key_u, val_u, (uint64_t*)key_i, val_i);
+    return hipGetLastError();
+}
+// grid for a run kernel: one lane group per record, capped (the kernels stride)
+static int run_grid(int64_t records, int lpr, int cap_blocks) {
+    int64_t nb = (records * lpr + 255) / 256;
+    if (nb < 1) nb = 1;
+    return (int)(nb > cap_blocks ? cap_blocks : nb);
+}
+hipError_t sml_launch_run_adam(int d, const SmlRunArgs& a, int64_t max_records, hipStream_t st) {
+    const int nb = run_grid(max_records, d / 4, 4096);
+    SML_DISPATCH_D(d, k_run_update<DD, float, 1><<<dim3(nb), dim3(256), 0, st>>>(a));
+    return hipGetLastError();
+}
+hipError_t sml_launch_run_sgd(int d, int dtype_bytes, const SmlRunArgs& a, int64_t max_records, hipStream_t st) {
+    const int nb = run_grid(max_records, d * dtype_bytes / 16, 4096);
     if (dtype_bytes == 4) {
-        SML_DISPATCH_D(d, k_seg_update<DD, float, 0><<<dim3(nb), dim3(256), 0, st>>>(a));
+        SML_DISPATCH_D(d, k_run_update<DD, float, 0><<<dim3(nb), dim3(256), 0, st>>>(a));
     } else if (dtype_bytes == 2) {
-        SML_DISPATCH_D(d, k_seg_update<DD, __half, 0><<<dim3(nb), dim3(256), 0, st>>>(a));
+        SML_DISPATCH_D(d, k_run_update<DD, __half, 0><<<dim3(nb), dim3(256), 0, st>>>(a));
     } else return hipErrorInvalidValue;
     return hipGetLastError();
 }
-hipError_t sml_launch_hot_rows(int d, int dtype_bytes, const SmlSegUpdArgs& a, int max_chunks, hipStream_t st) {
+hipError_t sml_launch_hot_rows(int d, int dtype_bytes, const SmlRunArgs& a, int max_chunks, hipStream_t st) {
     const int lpr = d * dtype_bytes / 16;
     const int nb_apply = (a.hot_cap * lpr + 255) / 256;
+    const int nb_part = max_chunks < 512 ? max_chunks : 512;
     if (dtype_bytes == 4) {
-        SML_DISPATCH_D(d, k_hot_partial<DD, float><<<dim3(max_chunks), dim3(256), 0, st>>>(a));
+        SML_DISPATCH_D(d, k_hot_partial<DD, float><<<dim3(nb_part), dim3(256), 0, st>>>(a));
         SML_DISPATCH_D(d, k_hot_apply<DD, float><<<dim3(nb_apply), dim3(256), 0, st>>>(a));
     } else if (dtype_bytes == 2) {
-        SML_DISPATCH_D(d, k_hot_partial<DD, __half><<<dim3(max_chunks), dim3(256), 0, st>>>(a));
+        SML_DISPATCH_D(d, k_hot_partial<DD, __half><<<dim3(nb_part), dim3(256), 0, st>>>(a));
         SML_DISPATCH_D(d, k_hot_apply<DD, __half><<<dim3(nb_apply), dim3(256), 0, st>>>(a));
     } else return hipErrorInvalidValue;
     return hipGetLastError();

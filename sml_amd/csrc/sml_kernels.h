@@ -89,10 +89,17 @@ hipError_t sml_launch_selftest(const float* A, const float* W, float* pk, float*
 hipError_t sml_launch_loss_finalize(const float* part, int n_batches, int stride, const int* counts,
                                     float* out, hipStream_t st);
 
-struct SmlSegUpdArgs {
-    // sorted occurrences of this batch: key = (batch << 32) | row, val = slot in [0, 3B)
-    const uint64_t* key_u; const uint32_t* val_u; int n_u;     // user occurrences (B)
-    const uint64_t* key_i; const uint32_t* val_i; int n_i;     // item occurrences (2B)
+// One run of equal keys in a sorted occurrence list: `len` occurrences of table row `row` at
+// sorted positions pos .. pos+len-1 (len = 0: this position does not start a run).
+struct SmlRun { uint32_t row, pos, len, pad; };
+
+struct SmlRunArgs {
+    // run records of this batch.  off_* == null: one record per sorted position (n_* of them, len 0 =
+    // not a head).  off_* != null: compacted whole-epoch lists; this batch's range is off[b]..off[b+1].
+    const SmlRun* run_u; int n_u;
+    const SmlRun* run_i; int n_i;
+    const int* off_u; const int* off_i; int batch_index;
+    const uint32_t* val_u; const uint32_t* val_i;   // whole sorted value lists (SmlRun.pos indexes them): slot of each occurrence
     const float* dx;         // per-occurrence gradient rows the user values index
     const float* dx_i;       // ... and the item values index (the all-gathered buffer on several GPUs)
     void* w_user; void* w_item;
@@ -100,12 +107,9 @@ struct SmlSegUpdArgs {
     int32_t* last_user; int32_t* last_item;                       // Adam only
     const SmlSched* sched; int cur_step;                          // Adam only
     float lr;                                                     // SGD only
-    int skip_single;         // SGD: runs of length 1 were already applied in place by k_bare_grad
-    // compacted lists (duplicated occurrences only, whole epoch): this batch's range is off[b]..off[b+1]
-    const int* off_u; const int* off_i; int batch_index;
     // hot rows (SGD, large batches): runs longer than SML_HOT are appended here instead of being summed by
     // one wavefront; k_hot_partial / k_hot_apply reduce them with whole workgroups.  null: off.
-    uint32_t* hot_list;      // [hot_cap][2]: (pos | is_item << 31), len
+    uint32_t* hot_list;      // [hot_cap][3]: (pos | is_item << 31), len, row
     int* hot_count;          // this batch's counter (zeroed by the caller)
     int* hot_first;          // [hot_cap] first chunk index of each hot run
     float* hot_part;         // [hot_chunks][d] chunk partial sums
@@ -114,17 +118,21 @@ struct SmlSegUpdArgs {
 #define SML_HOT 512          // runs longer than this take the hot path
 #define SML_HOT_CHUNK 1024   // occurrences per workgroup in k_hot_partial
 #define SML_HOT_MAXCAP 8192
-hipError_t sml_launch_hot_rows(int d, int dtype_bytes, const SmlSegUpdArgs& a, int max_chunks, hipStream_t st);
-hipError_t sml_launch_seg_adam(int d, const SmlSegUpdArgs& a, hipStream_t st);
-hipError_t sml_launch_seg_sgd(int d, int dtype_bytes, const SmlSegUpdArgs& a, hipStream_t st);
+hipError_t sml_launch_hot_rows(int d, int dtype_bytes, const SmlRunArgs& a, int max_chunks, hipStream_t st);
+hipError_t sml_launch_run_adam(int d, const SmlRunArgs& a, int64_t max_records, hipStream_t st);
+hipError_t sml_launch_run_sgd(int d, int dtype_bytes, const SmlRunArgs& a, int64_t max_records, hipStream_t st);
 hipError_t sml_launch_adam_flush(int d, float* w, float* m, float* v, int32_t* last, int64_t rows,
                                  const SmlSched* sched, int cur_step, hipStream_t st);
-hipError_t sml_launch_mark_unique(const uint64_t* key_u, const uint32_t* val_u, const uint64_t* key_i,
-                                  const uint32_t* val_i, int64_t n, int batch, uint8_t* uniq, uint8_t* dup_u,
-                                  uint8_t* dup_i, hipStream_t st);
-hipError_t sml_launch_batch_offsets(const uint64_t* keys, const int* n_sel, int nb, int* off, hipStream_t st);
-hipError_t sml_launch_build_keys(const int64_t* tri, int64_t n, int batch, int pad_tiles, uint64_t* key_u,
-                                 uint32_t* val_u, uint64_t* key_i, uint32_t* val_i, hipStream_t st);
+// key_bytes 4: keys (batch << row_bits) | row in 32 bits; 8: (batch << 32) | row
+hipError_t sml_launch_mark_runs(int key_bytes, const void* keys, const uint32_t* vals, int64_t n, int row_bits, SmlRun* rec,
+                                uint8_t* flag_dup, uint8_t* uniq, int64_t uniq_stride, int64_t uniq_item_base, hipStream_t st);
+hipError_t sml_launch_mark_unique(int key_bytes, const void* keys, const uint32_t* vals, int64_t n, int row_bits, uint8_t* uniq,
+                                  int64_t uniq_stride, hipStream_t st);
+hipError_t sml_launch_make_runs(int key_bytes, const void* keys, int64_t n, int row_bits, const uint32_t* heads, const int* n_heads,
+                                int64_t max_heads, SmlRun* runs, hipStream_t st);
+hipError_t sml_launch_batch_offsets(const SmlRun* runs, const int* n_sel, int nb, int64_t seg, int* off, hipStream_t st);
+hipError_t sml_launch_build_keys(int key_bytes, const int64_t* tri, int64_t n, int batch, int pad_tiles, int row_bits_u,
+                                 int row_bits_i, void* key_u, uint32_t* val_u, void* key_i, uint32_t* val_i, hipStream_t st);
 
 struct SmlBareArgs {
     void* w_user; void* w_item;

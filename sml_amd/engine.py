@@ -233,9 +233,10 @@ class HipEngine(object):
         return losses
 
     # ------------------------------------------------------------------ a3
-    def bare_prepare(self, triples, batch_size):
+    def bare_prepare(self, triples, batch_size, n_user=0, n_item=0):
         """Build the index lists of a coming bare epoch on the engine's side stream (sort by (batch,row),
         unique marks, duplicates-only compaction) while earlier work keeps the main stream busy.
+        n_user / n_item (the table heights; 0 = unknown) let the sort use 32-bit keys.
         Returns a handle for bare_epoch(prepared=...)."""
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.device)
@@ -244,8 +245,8 @@ class HipEngine(object):
         cur = torch.cuda.current_stream(self.device)
         self._side.wait_stream(cur)          # the slot's previous user (two epochs back) has been queued before this
         with torch.cuda.stream(self._side):
-            check(self.lib.sml_embed_loss_sgd_prepare(self._ctx, _ptr(tri), tri.shape[0], int(batch_size), slot,
-                                                      self._stream()), "sml_embed_loss_sgd_prepare")
+            check(self.lib.sml_embed_loss_sgd_prepare(self._ctx, _ptr(tri), tri.shape[0], int(batch_size), int(n_user),
+                                                      int(n_item), slot, self._stream()), "sml_embed_loss_sgd_prepare")
             ev = torch.cuda.Event()
             ev.record(self._side)
         tri.record_stream(self._side)

@@ -57,6 +57,7 @@ def main():
 
     def mfe():
         eng.mf_stage_epoch(mf, net, lu, li, tri, a.mf_batch, 0.01, 1e-6)
+        eng.mf_flush(mf)       # as the period does after every MF epoch (bounds the lazy-Adam replay windows)
 
     out = {"d": a.d, "inter": a.inter}
     for name, fn, B in (("tr", tr, a.tr_batch), ("mf", mfe, a.mf_batch)):
