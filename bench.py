@@ -104,13 +104,14 @@ def bench_bare(a, device):
     a_sgd = 24 + 6 * a.d * s                       # int64 (u,i,j) + 3 rows read + 3 rows written
     n = a.bare_triples
     t_grad, t_seg = prof["k_bare_grad"][1] / 1e3, prof["k_seg_update_sgd"][1] / 1e3
-    ach = n * a_sgd / (t_grad + t_seg) / 1e9
+    t_hot = prof.get("k_hot_rows", (0, 0.0))[1] / 1e3
+    ach = n * a_sgd / (t_grad + t_seg + t_hot) / 1e9
     out = {"metric": "bare embed+loss+SGD step triples/s (a3), synthetic uniform users / Zipf(%g) items, d=%d %s" % (a.item_zipf, a.d, a.bare_dtype),
            "value": a.steps * n / dtm, "unit": "triples/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": 1000.0 * dtm / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": a.bare_dtype, "data": "synthetic",
            "config": {"workload": "bare: users=%d items=%d triples/epoch=%d batch=%d" % (a.users, a.items, n, a.bare_batch)},
-           "roofline": {"kernel": "k_bare_grad + k_seg_update_sgd (one a3 step)", "bound": "hbm", "achieved": ach,
+           "roofline": {"kernel": "k_bare_grad + k_seg_update_sgd + k_hot_rows (one a3 step)", "bound": "hbm", "achieved": ach,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                         "algorithmic_bytes_per_triple": a_sgd},
            "kernels": {k: {"launches": c, "total_ms": round(m, 3), "avg_us": round(1000.0 * m / c, 2)} for k, (c, m) in prof.items()}}

@@ -170,7 +170,10 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
  * batch count and n_user / n_item allow -- unique marks, compacted run records of the duplicated
  * rows) inline on `stream`; 0/1 uses the lists a previous
  * sml_embed_loss_sgd_prepare call built for the SAME triples/n/batch -- so a caller can
- * prepare epoch e+1 on a side stream while epoch e runs. */
+ * prepare epoch e+1 on a side stream while epoch e runs.  sml_embed_loss_sgd_epoch waits on the HOST
+ * for the index lists it uses to be complete (it reads their longest run to decide whether the
+ * hot-row kernels are needed at all): free when they were prepared ahead, one host wait per epoch
+ * when built inline. */
 int sml_embed_loss_sgd_prepare(sml_ctx* ctx, const int64_t* triples, int64_t n, int batch,
                                int64_t n_user, int64_t n_item, int slot, void* stream);
 int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n_user,

@@ -73,10 +73,10 @@ struct RcclApi {
     } while (0)
 
 // ---- optional per-kernel-class timing with HIP events on the caller's stream -------------
-enum ProfClass { PC_FWD = 0, PC_BWD, PC_WGRAD, PC_THETA_ADAM, PC_PAIR_LOSS, PC_SEG_ADAM, PC_SEG_SGD, PC_BARE_GRAD,
+enum ProfClass { PC_FWD = 0, PC_BWD, PC_WGRAD, PC_THETA_ADAM, PC_PAIR_LOSS /* hot-row kernels */, PC_SEG_ADAM, PC_SEG_SGD, PC_BARE_GRAD,
                  PC_EVAL_RANKS, PC_FLUSH, PC_PACK, PC_SORT, PC_MISC, PC_COUNT };
 const char* const kProfNames[PC_COUNT] = {"k_transfer_fwd", "k_transfer_bwd", "k_transfer_wgrad", "k_theta_adam",
-                                          "(unused)", "k_seg_update_adam", "k_seg_update_sgd", "k_bare_grad",
+                                          "k_hot_rows", "k_seg_update_adam", "k_seg_update_sgd", "k_bare_grad",
                                           "k_eval_ranks", "k_adam_flush", "k_theta_pack", "sort_epoch", "misc"};
 struct Prof {
     bool on = false;
@@ -121,17 +121,24 @@ struct IndexSet {
     Buf<SmlRun> rec_u, rec_i;          // one record per sorted position
     Buf<SmlRun> runs_u, runs_i;        // compacted: duplicated runs only (bare step)
     Buf<uint32_t> heads_u, heads_i;    // sorted positions of the duplicated-run heads
+    Buf<uint32_t> hot_list;            // [nb][hot_cap][3] hot runs of every batch (bare step, large batches)
+    Buf<int> hot_count;                // [nb]
+    int hot_cap = 0;                   // 0: the hot-row path is off for this epoch's batch size
     Buf<uint8_t> uniq;
     Buf<int> off_u, off_i, n_sel;
     Buf<char> cub_tmp;
     int key_bytes = 8, row_bits_u = 32, row_bits_i = 32;
+    int* max_len_host = nullptr;       // pinned: longest duplicated run of the prepared epoch (0 if none exceeds SML_HOT)
+    hipEvent_t ready = nullptr;        // recorded after the copy into max_len_host
     int64_t n = -1; int batch = 0; const void* triples = nullptr;   // what was prepared here
     void release() {
         key_u.release(); key_u2.release(); key_i.release(); key_i2.release();
         val_u.release(); val_u2.release(); val_i.release(); val_i2.release();
         rec_u.release(); rec_i.release(); runs_u.release(); runs_i.release();
-        uniq.release(); heads_u.release(); heads_i.release(); off_u.release(); off_i.release(); n_sel.release();
+        uniq.release(); heads_u.release(); heads_i.release(); hot_list.release(); hot_count.release(); off_u.release(); off_i.release(); n_sel.release();
         cub_tmp.release();
+        if (max_len_host) { (void)hipHostFree(max_len_host); max_len_host = nullptr; }
+        if (ready) { (void)hipEventDestroy(ready); ready = nullptr; }
     }
 };
 
@@ -149,8 +156,7 @@ struct sml_ctx {
     Buf<SmlRun> rec_x;       // run records of the multi-GPU global item list
     ncclComm_t comm = nullptr;
     int comm_world = 1, comm_rank = 0;
-    Buf<uint32_t> hot_list;
-    Buf<int> hot_count, hot_first;
+    Buf<int> hot_first;
     Buf<float> hot_part;
     Prof prof;
 
@@ -160,7 +166,7 @@ struct sml_ctx {
         pk.release(); grad.release(); convg.release(); loss_part.release();
         ix[0].release(); ix[1].release();
         sched.release(); dummy.release(); rec_x.release();
-        hot_list.release(); hot_count.release(); hot_first.release(); hot_part.release();
+        hot_first.release(); hot_part.release();
     }
 };
 
@@ -306,6 +312,7 @@ int sort_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
         HIPCHK(c->heads_u.ensure((size_t)n / 2 + 8)); HIPCHK(c->heads_i.ensure((size_t)n + 8));
         HIPCHK(c->runs_u.ensure((size_t)n / 2 + 8)); HIPCHK(c->runs_i.ensure((size_t)n + 8));
         HIPCHK(c->off_u.ensure((size_t)nb + 1)); HIPCHK(c->off_i.ensure((size_t)nb + 1)); HIPCHK(c->n_sel.ensure(4));
+        HIPCHK(hipMemsetAsync(c->uniq.p, 1, (size_t)3 * nb * batch, st));
         HIPCHK(sml_launch_mark_unique(c->key_bytes, c->key_u2.p, c->val_u2.p, n, c->row_bits_u, c->uniq.p, (int64_t)3 * batch, st));
         HIPCHK(sml_launch_mark_unique(c->key_bytes, c->key_i2.p, c->val_i2.p, 2 * n, c->row_bits_i, c->uniq.p, (int64_t)3 * batch, st));
         rc = narrow ? select_dup_heads<uint32_t>(c, c->key_u2.p, n, c->heads_u.p, c->n_sel.p, st)
@@ -314,8 +321,27 @@ int sort_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
         rc = narrow ? select_dup_heads<uint32_t>(c, c->key_i2.p, 2 * n, c->heads_i.p, c->n_sel.p + 1, st)
                     : select_dup_heads<uint64_t>(c, c->key_i2.p, 2 * n, c->heads_i.p, c->n_sel.p + 1, st);
         if (rc) return rc;
-        HIPCHK(sml_launch_make_runs(c->key_bytes, c->key_u2.p, n, c->row_bits_u, c->heads_u.p, c->n_sel.p, n / 2, c->runs_u.p, st));
-        HIPCHK(sml_launch_make_runs(c->key_bytes, c->key_i2.p, 2 * n, c->row_bits_i, c->heads_i.p, c->n_sel.p + 1, n, c->runs_i.p, st));
+        HIPCHK(hipMemsetAsync(c->n_sel.p + 2, 0, sizeof(int), st));
+        // hot rows: with large batches a popular item collects thousands of occurrences per batch; such runs
+        // are listed per batch here and reduced by whole workgroups
+        const int hot_cap = 3 * batch / SML_HOT + 8;
+        c->hot_cap = (batch >= 4096 && hot_cap <= SML_HOT_MAXCAP) ? hot_cap : 0;
+        if (c->hot_cap) {
+            HIPCHK(c->hot_list.ensure((size_t)nb * c->hot_cap * 3)); HIPCHK(c->hot_count.ensure((size_t)nb));
+            HIPCHK(hipMemsetAsync(c->hot_count.p, 0, (size_t)nb * sizeof(int), st));
+        }
+        uint32_t* hl = c->hot_cap ? c->hot_list.p : nullptr;
+        HIPCHK(sml_launch_make_runs(c->key_bytes, c->key_u2.p, c->val_u2.p, n, c->row_bits_u, c->heads_u.p, c->n_sel.p, n / 2, c->runs_u.p,
+                                    c->n_sel.p + 2, (int64_t)batch, 0, hl, c->hot_count.p, c->hot_cap, st));
+        HIPCHK(sml_launch_make_runs(c->key_bytes, c->key_i2.p, c->val_i2.p, 2 * n, c->row_bits_i, c->heads_i.p, c->n_sel.p + 1, n, c->runs_i.p,
+                                    c->n_sel.p + 2, (int64_t)2 * batch, 1, hl, c->hot_count.p, c->hot_cap, st));
+        // the longest run of the epoch travels to the host: an epoch without hot rows skips the hot-row
+        // kernels altogether (the epoch call waits for this event -- long past when the lists were
+        // prepared an epoch ahead on a side stream)
+        if (!c->max_len_host) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->max_len_host), sizeof(int), hipHostMallocDefault));
+        if (!c->ready) HIPCHK(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
+        HIPCHK(hipMemcpyAsync(c->max_len_host, c->n_sel.p + 2, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipEventRecord(c->ready, st));
         HIPCHK(sml_launch_batch_offsets(c->runs_u.p, c->n_sel.p, (int)nb, (int64_t)batch, c->off_u.p, st));
         HIPCHK(sml_launch_batch_offsets(c->runs_i.p, c->n_sel.p + 1, (int)nb, (int64_t)2 * batch, c->off_i.p, st));
     }
@@ -636,16 +662,13 @@ int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n
         return fail(SML_ESTATE, "sml_embed_loss_sgd_epoch", "index set was prepared for other triples");
     }
     HIPCHK(hipMemsetAsync(ctx->loss_part.p, 0, (size_t)nb * lstride * sizeof(float), st));
-    // hot rows: with large batches a popular item collects thousands of occurrences per batch
-    const int hot_cap = 3 * batch / SML_HOT + 8;
-    const bool hot = batch >= 4096 && hot_cap <= SML_HOT_MAXCAP;
+    HIPCHK(hipEventSynchronize(X->ready));       // host-side: the index lists (and their longest run) are final
+    const int hot_cap = X->hot_cap;
+    const bool hot = hot_cap > 0 && *X->max_len_host > SML_HOT;     // no hot run in the whole epoch: skip that path
     const int hot_chunks = 3 * batch / SML_HOT_CHUNK + hot_cap;
     if (hot) {
-        HIPCHK(ctx->hot_list.ensure((size_t)3 * hot_cap));
         HIPCHK(ctx->hot_first.ensure((size_t)hot_cap));
-        HIPCHK(ctx->hot_count.ensure((size_t)nb));
         HIPCHK(ctx->hot_part.ensure((size_t)hot_chunks * d));
-        HIPCHK(hipMemsetAsync(ctx->hot_count.p, 0, (size_t)nb * sizeof(int), st));
     }
     for (int64_t b = 0; b < nb; ++b) {
         const int B = (int)((n - b * batch) < batch ? (n - b * batch) : batch);
@@ -662,11 +685,11 @@ int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n
         u.val_u = X->val_u2.p; u.val_i = X->val_i2.p;
         u.dx = ctx->dx.p; u.dx_i = ctx->dx.p; u.w_user = w_user; u.w_item = w_item; u.lr = lr;
         if (hot) {
-            u.hot_list = ctx->hot_list.p; u.hot_count = ctx->hot_count.p + b; u.hot_first = ctx->hot_first.p;
-            u.hot_part = ctx->hot_part.p; u.hot_cap = hot_cap;
+            u.hot_list = X->hot_list.p + (size_t)b * hot_cap * 3; u.hot_count = X->hot_count.p + b; u.hot_first = ctx->hot_first.p;
+            u.hot_part = ctx->hot_part.p; u.hot_cap = hot_cap; u.hot_blocks = hot_chunks < 512 ? hot_chunks : 512;
         }
         ctx->prof.begin(PC_SEG_SGD, st); HIPCHK(sml_launch_run_sgd(d, dtype_bytes, u, (int64_t)3 * B / 2, st)); ctx->prof.end(st);
-        if (hot) { ctx->prof.begin(PC_SEG_SGD, st); HIPCHK(sml_launch_hot_rows(d, dtype_bytes, u, hot_chunks, st)); ctx->prof.end(st); }
+        if (hot) { ctx->prof.begin(PC_PAIR_LOSS, st); HIPCHK(sml_launch_hot_apply(d, dtype_bytes, u, st)); ctx->prof.end(st); }
     }
     ctx->prof.begin(PC_MISC, st); HIPCHK(sml_launch_loss_finalize(ctx->loss_part.p, (int)nb, lstride, nullptr, batch_loss, st)); ctx->prof.end(st);
     return SML_OK;

@@ -191,6 +191,8 @@ __global__ void k_mark_runs(const K* __restrict__ keys, const uint32_t* __restri
     SmlRun r;
     r.row = row_bits >= 32 ? (uint32_t)k : (uint32_t)(k & (((K)1 << (row_bits & 31)) - 1));
     r.pos = (uint32_t)q; r.len = (uint32_t)len; r.pad = 0;
+#pragma unroll
+    for (int j = 0; j < SML_RUN_INL; ++j) r.slot[j] = j < len ? vals[q + j] : 0u;
     rec[q] = r;
     if (flag_dup != nullptr) flag_dup[q] = (head && len >= 2) ? 1 : 0;
     if (uniq != nullptr) {
@@ -209,13 +211,15 @@ __global__ void k_mark_unique(const K* __restrict__ keys, const uint32_t* __rest
     const K k = keys[q];
     const bool one = (q == 0 || keys[q - 1] != k) && (q + 1 >= n || keys[q + 1] != k);
     const int64_t b = row_bits >= 32 ? (int64_t)((uint64_t)k >> 32) : (int64_t)(k >> (row_bits & 31));
-    uniq[b * uniq_stride + vals[q]] = one ? 1 : 0;
+    if (!one) uniq[b * uniq_stride + vals[q]] = 0;       // the array is preset to 1: only duplicated occurrences scatter
 }
 
 // bare step: run records of the compacted duplicated-run heads (positions selected on the device)
 template <typename K>
-__global__ void k_make_runs(const K* __restrict__ keys, int64_t n, int row_bits, const uint32_t* __restrict__ heads,
-                            const int* __restrict__ n_heads, SmlRun* __restrict__ runs) {
+__global__ void k_make_runs(const K* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t n, int row_bits,
+                            const uint32_t* __restrict__ heads, const int* __restrict__ n_heads, SmlRun* __restrict__ runs,
+                            int* __restrict__ max_len, int64_t seg, int is_item, uint32_t* __restrict__ hot_list,
+                            int* __restrict__ hot_count, int hot_cap) {
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= *n_heads) return;
     constexpr int PROBE = 8;
@@ -238,7 +242,20 @@ __global__ void k_make_runs(const K* __restrict__ keys, int64_t n, int row_bits,
     SmlRun r;
     r.row = row_bits >= 32 ? (uint32_t)k : (uint32_t)(k & (((K)1 << (row_bits & 31)) - 1));
     r.pos = (uint32_t)q; r.len = (uint32_t)len; r.pad = 0;
+#pragma unroll
+    for (int j = 0; j < SML_RUN_INL; ++j) r.slot[j] = j < len ? vals[q + j] : 0u;
     runs[h] = r;
+    if (len > SML_HOT) {
+        atomicMax(max_len, len);      // rare: tells the host whether any batch needs the hot-row path
+        if (hot_list != nullptr) {    // the batch's hot-run list (entry order is arbitrary; every row's sum order is not)
+            const int64_t b = q / seg;
+            const int slot = atomicAdd(hot_count + b, 1);
+            if (slot < hot_cap) {
+                uint32_t* e = hot_list + (b * hot_cap + slot) * 3;
+                e[0] = (uint32_t)q | ((uint32_t)is_item << 31); e[1] = (uint32_t)len; e[2] = r.row;
+            }
+        }
+    }
 }
 
 // off[b] = first compacted run whose position is >= b * seg  (off[nb] = number of runs)
@@ -266,6 +283,88 @@ __device__ __forceinline__ RunLists run_lists(const SmlRunArgs& a) {
 }
 
 // ------------------------------------------------------------------------------------
+// hot rows: chunk partial sums.  One workgroup per (hot run, chunk of SML_HOT_CHUNK occurrences),
+// grid-stride; the flattened chunk index -> (run, chunk) map is a prefix sum over the hot list,
+// recomputed per workgroup in LDS (the list has at most a few thousand entries).  Fixed order.
+// ------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ void hot_partial_body(const SmlRunArgs& a, int block, int n_blocks, int* pre, int* tsum,
+                                                 float (*rows)[D]) {
+    constexpr int VEC = 4;
+    constexpr int LPR = D / VEC;
+    constexpr int GB = 256 / LPR;            // lane groups per workgroup
+    const int tid = threadIdx.x;
+    const int nh = min(*a.hot_count, a.hot_cap);
+    if (nh == 0) return;
+    // exclusive prefix of chunk counts: each thread owns a contiguous slice, then a serial pass over 256 sums
+    const int per = (nh + 255) / 256;
+    int local = 0;
+    for (int e = tid * per; e < min(nh, (tid + 1) * per); ++e)
+        local += ((int)a.hot_list[3 * e + 1] + SML_HOT_CHUNK - 1) / SML_HOT_CHUNK;
+    {   // block-wide inclusive scan of `local`: shuffles inside each wavefront, then the four wave totals
+        const int ln = tid & 63, wvi = tid >> 6;
+        int inc = local;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off, 64); if (ln >= off) inc += t; }
+        if (ln == 63) tsum[wvi] = inc;           // tsum[0..3]: wave totals (scratch use of the first entries)
+        __syncthreads();
+        int before = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) before += (w2 < wvi) ? tsum[w2] : 0;
+        __syncthreads();
+        tsum[tid + 1] = before + inc;
+        if (tid == 0) tsum[0] = 0;
+        __syncthreads();
+    }
+    {
+        int run = tsum[tid];
+        for (int e = tid * per; e < min(nh, (tid + 1) * per); ++e) {
+            pre[e] = run;
+            run += ((int)a.hot_list[3 * e + 1] + SML_HOT_CHUNK - 1) / SML_HOT_CHUNK;
+        }
+        if (tid == 255) pre[nh] = tsum[256];
+    }
+    __syncthreads();
+    const int grp = tid / LPR, sub = tid % LPR;
+    for (int w = block; w < pre[nh]; w += n_blocks) {
+        int lo = 0, hi2 = nh - 1;                 // largest h with pre[h] <= w
+        while (lo < hi2) { const int mid = (lo + hi2 + 1) >> 1; if (pre[mid] <= w) lo = mid; else hi2 = mid - 1; }
+        const int h = lo, c = w - pre[h];
+        if (c == 0 && tid == 0) a.hot_first[h] = w;
+        const uint32_t packed = a.hot_list[3 * h];
+        const int is_item = packed >> 31, pos0 = (int)(packed & 0x7fffffffu), len = (int)a.hot_list[3 * h + 1];
+        const uint32_t* vals = (is_item ? a.val_i : a.val_u) + pos0;
+        const float* dx = is_item ? a.dx_i : a.dx;
+        const int q_begin = c * SML_HOT_CHUNK, q_end = min(len, q_begin + SML_HOT_CHUNK);
+        float acc[VEC] = {0.f, 0.f, 0.f, 0.f};
+        for (int q0 = q_begin + grp; q0 < q_end; q0 += 16 * GB) {
+            float x[16][VEC];
+            uint32_t sl[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) sl[j] = q0 + j * GB < q_end ? vals[q0 + j * GB] : 0u;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (q0 + j * GB < q_end) RowVec<float>::load(dx + (int64_t)sl[j] * D + sub * VEC, x[j]);
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (q0 + j * GB < q_end) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] += x[j][k];
+                }
+        }
+        __syncthreads();                          // the previous trip's readers of rows[] are done
+        RowVec<float>::store(&rows[grp][sub * VEC], acc);
+        __syncthreads();
+        if (tid < D) {
+            float s2 = 0.0f;
+#pragma unroll 8
+            for (int g2 = 0; g2 < GB; ++g2) s2 += rows[g2][tid];
+            a.hot_part[(int64_t)w * D + tid] = s2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // segmented row update over run records: one lane group per record (grid-stride).  The group
 // sums the run's per-occurrence gradient rows in slot order (deterministic) and writes the row
 // once; the row (and its Adam state) is fetched before the sum, so the two latencies overlap.
@@ -285,12 +384,22 @@ __global__ __launch_bounds__(256) void k_run_update(SmlRunArgs a) {
         sched_window_load(swin, a.sched, a.cur_step, threadIdx.x);
         __syncthreads();
     }
+    int run_blocks = gridDim.x;
+    if constexpr (OPT == 0) {
+        // the first hot_blocks workgroups reduce the hot rows' chunks (independent of the runs below; theirs is
+        // the longest chain of the launch, so they are dispatched first)
+        __shared__ int pre[SML_HOT_MAXCAP + 1];
+        __shared__ int tsum[257];
+        __shared__ __attribute__((aligned(16))) float hrows[256 / (D / 4)][D];
+        run_blocks -= a.hot_blocks;
+        if ((int)blockIdx.x < a.hot_blocks) { hot_partial_body<D>(a, (int)blockIdx.x, a.hot_blocks, pre, tsum, hrows); return; }
+    }
     const int lane = threadIdx.x & 63;
     const int grp = lane / LPR, sub = lane % LPR;
     const RunLists L = run_lists(a);
     const int total = L.n_u + L.n_i;
-    const int wave_id = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    const int n_waves = (gridDim.x * 256) >> 6;
+    const int wave_id = (((int)blockIdx.x - (OPT == 0 ? a.hot_blocks : 0)) * 256 + threadIdx.x) >> 6;
+    const int n_waves = (run_blocks * 256) >> 6;
     // Compacted run lists (bare step): record k = (trip * G + grp) * n_waves + wave -- neighbouring records
     // (hot rows are neighbours in a sorted list when popular rows have neighbouring ids) go to different
     // wavefronts, so their long sums run side by side instead of one after the other in one wave.
@@ -301,22 +410,18 @@ __global__ __launch_bounds__(256) void k_run_update(SmlRunArgs a) {
         const int k = strided ? base + grp * n_waves + wave_id : base + wave_id * G + grp;
         const bool valid = k < total;
         const int is_item = (valid && k >= L.n_u) ? 1 : 0;
-        SmlRun run; run.row = 0; run.pos = 0; run.len = 0; run.pad = 0;
-        if (valid) run = is_item ? L.run_i[k - L.n_u] : L.run_u[k];
+        SmlRun run;
+        {   // two 16-byte loads; an out-of-range group gets an empty record
+            const uint4* src = reinterpret_cast<const uint4*>(is_item ? L.run_i + (k - L.n_u) : L.run_u + k);
+            uint4 r0 = make_uint4(0u, 0u, 0u, 0u), r1 = r0;
+            if (valid) { r0 = src[0]; r1 = src[1]; }
+            run.row = r0.x; run.pos = r0.y; run.len = r0.z; run.pad = r0.w;
+            run.slot[0] = r1.x; run.slot[1] = r1.y; run.slot[2] = r1.z; run.slot[3] = r1.w;
+        }
         int len = (int)run.len;
         bool head = len > 0;
-        if (OPT == 0 && a.hot_list != nullptr && head && len > SML_HOT) {
-            // a hot row: hand the run to the workgroup-level reducers (k_hot_partial / k_hot_apply)
-            if (sub == 0) {
-                const int slot = atomicAdd(a.hot_count, 1);
-                if (slot < a.hot_cap) {
-                    a.hot_list[3 * slot] = run.pos | ((uint32_t)is_item << 31);
-                    a.hot_list[3 * slot + 1] = run.len;
-                    a.hot_list[3 * slot + 2] = run.row;
-                }
-            }
-            head = false;
-        }
+        // a hot row is in the batch's hot list (built with the index lists): the workgroup-level reducers own it
+        if (OPT == 0 && a.hot_list != nullptr && len > SML_HOT) head = false;
         // the row and its optimiser state do not depend on the gradient sum: fetch them first
         T* w = reinterpret_cast<T*>(is_item ? a.w_item : a.w_user);
         const int64_t row = run.row;
@@ -340,7 +445,7 @@ __global__ __launch_bounds__(256) void k_run_update(SmlRunArgs a) {
             const float* dx = is_item ? a.dx_i : a.dx;
             uint32_t sl[LONG];
 #pragma unroll
-            for (int j = 0; j < LONG; ++j) sl[j] = j < len ? vals[j] : 0u;
+            for (int j = 0; j < LONG; ++j) sl[j] = j < SML_RUN_INL ? run.slot[j] : (j < len ? vals[j] : 0u);
             float x[LONG][VEC];
 #pragma unroll
             for (int j = 0; j < LONG; ++j)
@@ -416,114 +521,48 @@ __global__ __launch_bounds__(256) void k_run_update(SmlRunArgs a) {
     }
 }
 
-// ------------------------------------------------------------------------------------
-// hot rows: chunk partial sums.  One workgroup per (hot run, chunk of SML_HOT_CHUNK occurrences),
-// grid-stride; the flattened chunk index -> (run, chunk) map is a prefix sum over the hot list,
-// recomputed per workgroup in LDS (the list has at most a few thousand entries).  Fixed order.
-// ------------------------------------------------------------------------------------
-template <int D, typename T>
-__global__ __launch_bounds__(256) void k_hot_partial(SmlRunArgs a) {
-    constexpr int VEC = 4;
-    constexpr int LPR = D / VEC;
-    constexpr int GB = 256 / LPR;            // lane groups per workgroup
-    __shared__ int pre[SML_HOT_MAXCAP + 1];
-    __shared__ int tsum[257];
-    __shared__ __attribute__((aligned(16))) float rows[GB][D];
-    const int tid = threadIdx.x;
-    const int nh = min(*a.hot_count, a.hot_cap);
-    if (nh == 0) return;
-    // exclusive prefix of chunk counts: each thread owns a contiguous slice, then a serial pass over 256 sums
-    const int per = (nh + 255) / 256;
-    int local = 0;
-    for (int e = tid * per; e < min(nh, (tid + 1) * per); ++e)
-        local += ((int)a.hot_list[3 * e + 1] + SML_HOT_CHUNK - 1) / SML_HOT_CHUNK;
-    tsum[tid + 1] = local;
-    __syncthreads();
-    if (tid == 0) { tsum[0] = 0; for (int i = 1; i <= 256; ++i) tsum[i] += tsum[i - 1]; }
-    __syncthreads();
-    {
-        int run = tsum[tid];
-        for (int e = tid * per; e < min(nh, (tid + 1) * per); ++e) {
-            pre[e] = run;
-            run += ((int)a.hot_list[3 * e + 1] + SML_HOT_CHUNK - 1) / SML_HOT_CHUNK;
-        }
-        if (tid == 255) pre[nh] = tsum[256];
-    }
-    __syncthreads();
-    const int grp = tid / LPR, sub = tid % LPR;
-    for (int w = blockIdx.x; w < pre[nh]; w += gridDim.x) {
-        int lo = 0, hi2 = nh - 1;                 // largest h with pre[h] <= w
-        while (lo < hi2) { const int mid = (lo + hi2 + 1) >> 1; if (pre[mid] <= w) lo = mid; else hi2 = mid - 1; }
-        const int h = lo, c = w - pre[h];
-        if (c == 0 && tid == 0) a.hot_first[h] = w;
-        const uint32_t packed = a.hot_list[3 * h];
-        const int is_item = packed >> 31, pos0 = (int)(packed & 0x7fffffffu), len = (int)a.hot_list[3 * h + 1];
-        const uint32_t* vals = (is_item ? a.val_i : a.val_u) + pos0;
-        const float* dx = is_item ? a.dx_i : a.dx;
-        const int q_begin = c * SML_HOT_CHUNK, q_end = min(len, q_begin + SML_HOT_CHUNK);
-        float acc[VEC] = {0.f, 0.f, 0.f, 0.f};
-        for (int q0 = q_begin + grp; q0 < q_end; q0 += 8 * GB) {
-            float x[8][VEC];
-            uint32_t sl[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) sl[j] = q0 + j * GB < q_end ? vals[q0 + j * GB] : 0u;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (q0 + j * GB < q_end) RowVec<float>::load(dx + (int64_t)sl[j] * D + sub * VEC, x[j]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (q0 + j * GB < q_end) {
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) acc[k] += x[j][k];
-                }
-        }
-        __syncthreads();                          // the previous trip's readers of rows[] are done
-        RowVec<float>::store(&rows[grp][sub * VEC], acc);
-        __syncthreads();
-        if (tid < D) {
-            float s2 = 0.0f;
-#pragma unroll 8
-            for (int g2 = 0; g2 < GB; ++g2) s2 += rows[g2][tid];
-            a.hot_part[(int64_t)w * D + tid] = s2;
-        }
-    }
-}
-
-// hot rows: sum each run's chunk partials in order and take the SGD step
+// hot rows: sum each run's chunk partials and take the SGD step.  One wavefront per hot row: its lane
+// groups sum strided shares of the partials, then the shares meet in a fixed xor order (deterministic).
 template <int D, typename T>
 __global__ __launch_bounds__(256) void k_hot_apply(SmlRunArgs a) {
     constexpr int VEC = RowVec<T>::VEC;
     constexpr int LPR = D / VEC;
-    const int gid = blockIdx.x * 256 + threadIdx.x;
-    const int h = gid / LPR, sub = gid % LPR;
+    constexpr int G = 64 / LPR;
+    const int lane = threadIdx.x & 63, grp = lane / LPR, sub = lane % LPR;
+    const int h = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const int nh = min(*a.hot_count, a.hot_cap);
     if (h >= nh) return;
     const uint32_t packed = a.hot_list[3 * h];
     const int is_item = packed >> 31, len = (int)a.hot_list[3 * h + 1];
     const int first = a.hot_first[h], nchunks = (len + SML_HOT_CHUNK - 1) / SML_HOT_CHUNK;
+    const int64_t row = a.hot_list[3 * h + 2];
+    T* w = reinterpret_cast<T*>(is_item ? a.w_item : a.w_user);
+    float p[VEC];
+    if (grp == 0) RowVec<T>::load(w + row * D + sub * VEC, p);
     float g[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) g[k] = 0.0f;
-    for (int c0 = 0; c0 < nchunks; c0 += 8) {
+    for (int c0 = grp; c0 < nchunks; c0 += 8 * G) {
         float x[8][VEC];
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            if (c0 + j < nchunks) {
-                const float* src = a.hot_part + (int64_t)(first + c0 + j) * D + sub * VEC;
+            if (c0 + j * G < nchunks) {
+                const float* src = a.hot_part + (int64_t)(first + c0 + j * G) * D + sub * VEC;
 #pragma unroll
                 for (int hh = 0; hh < VEC / 4; ++hh) RowVec<float>::load(src + hh * 4, reinterpret_cast<float(&)[4]>(x[j][hh * 4]));
             }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            if (c0 + j < nchunks) {
+            if (c0 + j * G < nchunks) {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) g[k] += x[j][k];
             }
     }
-    const int64_t row = a.hot_list[3 * h + 2];
-    T* w = reinterpret_cast<T*>(is_item ? a.w_item : a.w_user);
-    float p[VEC];
-    RowVec<T>::load(w + row * D + sub * VEC, p);
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) g[k] += __shfl_xor(g[k], off, 64);
+    if (grp != 0) return;
 #pragma unroll
     for (int k = 0; k < VEC; ++k) p[k] -= a.lr * g[k];
     RowVec<T>::store(w + row * D + sub * VEC, p);
@@ -786,12 +825,13 @@ hipError_t sml_launch_mark_unique(int key_bytes, const void* keys, const uint32_
     else k_mark_unique<uint64_t><<<grid, dim3(256), 0, st>>>((const uint64_t*)keys, vals, n, row_bits, uniq, uniq_stride);
     return hipGetLastError();
 }
-hipError_t sml_launch_make_runs(int key_bytes, const void* keys, int64_t n, int row_bits, const uint32_t* heads, const int* n_heads,
-                                int64_t max_heads, SmlRun* runs, hipStream_t st) {
+hipError_t sml_launch_make_runs(int key_bytes, const void* keys, const uint32_t* vals, int64_t n, int row_bits, const uint32_t* heads,
+                                const int* n_heads, int64_t max_heads, SmlRun* runs, int* max_len, int64_t seg, int is_item,
+                                uint32_t* hot_list, int* hot_count, int hot_cap, hipStream_t st) {
     if (max_heads <= 0) return hipSuccess;
     const dim3 grid((unsigned)((max_heads + 255) / 256));
-    if (key_bytes == 4) k_make_runs<uint32_t><<<grid, dim3(256), 0, st>>>((const uint32_t*)keys, n, row_bits, heads, n_heads, runs);
-    else k_make_runs<uint64_t><<<grid, dim3(256), 0, st>>>((const uint64_t*)keys, n, row_bits, heads, n_heads, runs);
+    if (key_bytes == 4) k_make_runs<uint32_t><<<grid, dim3(256), 0, st>>>((const uint32_t*)keys, vals, n, row_bits, heads, n_heads, runs, max_len, seg, is_item, hot_list, hot_count, hot_cap);
+    else k_make_runs<uint64_t><<<grid, dim3(256), 0, st>>>((const uint64_t*)keys, vals, n, row_bits, heads, n_heads, runs, max_len, seg, is_item, hot_list, hot_count, hot_cap);
     return hipGetLastError();
 }
 hipError_t sml_launch_batch_offsets(const SmlRun* runs, const int* n_sel, int nb, int64_t seg, int* off, hipStream_t st) {
@@ -817,7 +857,7 @@ hipError_t sml_launch_run_adam(int d, const SmlRunArgs& a, int64_t max_records, 
     return hipGetLastError();
 }
 hipError_t sml_launch_run_sgd(int d, int dtype_bytes, const SmlRunArgs& a, int64_t max_records, hipStream_t st) {
-    const int nb = run_grid(max_records, d * dtype_bytes / 16, 4096);
+    const int nb = run_grid(max_records, d * dtype_bytes / 16, 4096) + a.hot_blocks;
     if (dtype_bytes == 4) {
         SML_DISPATCH_D(d, k_run_update<DD, float, 0><<<dim3(nb), dim3(256), 0, st>>>(a));
     } else if (dtype_bytes == 2) {
@@ -825,15 +865,11 @@ hipError_t sml_launch_run_sgd(int d, int dtype_bytes, const SmlRunArgs& a, int64
     } else return hipErrorInvalidValue;
     return hipGetLastError();
 }
-hipError_t sml_launch_hot_rows(int d, int dtype_bytes, const SmlRunArgs& a, int max_chunks, hipStream_t st) {
-    const int lpr = d * dtype_bytes / 16;
-    const int nb_apply = (a.hot_cap * lpr + 255) / 256;
-    const int nb_part = max_chunks < 512 ? max_chunks : 512;
+hipError_t sml_launch_hot_apply(int d, int dtype_bytes, const SmlRunArgs& a, hipStream_t st) {
+    const int nb_apply = (a.hot_cap + 3) / 4;              // one wavefront per hot row
     if (dtype_bytes == 4) {
-        SML_DISPATCH_D(d, k_hot_partial<DD, float><<<dim3(nb_part), dim3(256), 0, st>>>(a));
         SML_DISPATCH_D(d, k_hot_apply<DD, float><<<dim3(nb_apply), dim3(256), 0, st>>>(a));
     } else if (dtype_bytes == 2) {
-        SML_DISPATCH_D(d, k_hot_partial<DD, __half><<<dim3(nb_part), dim3(256), 0, st>>>(a));
         SML_DISPATCH_D(d, k_hot_apply<DD, __half><<<dim3(nb_apply), dim3(256), 0, st>>>(a));
     } else return hipErrorInvalidValue;
     return hipGetLastError();

@@ -90,8 +90,11 @@ hipError_t sml_launch_loss_finalize(const float* part, int n_batches, int stride
                                     float* out, hipStream_t st);
 
 // One run of equal keys in a sorted occurrence list: `len` occurrences of table row `row` at
-// sorted positions pos .. pos+len-1 (len = 0: this position does not start a run).
-struct SmlRun { uint32_t row, pos, len, pad; };
+// sorted positions pos .. pos+len-1 (len = 0: this position does not start a run).  The slots
+// (gradient-row indices) of the first SML_RUN_INL occurrences ride in the record, so the common
+// short run needs no second index load.
+#define SML_RUN_INL 4
+struct __attribute__((aligned(16))) SmlRun { uint32_t row, pos, len, pad; uint32_t slot[SML_RUN_INL]; };
 
 struct SmlRunArgs {
     // run records of this batch.  off_* == null: one record per sorted position (n_* of them, len 0 =
@@ -107,18 +110,20 @@ struct SmlRunArgs {
     int32_t* last_user; int32_t* last_item;                       // Adam only
     const SmlSched* sched; int cur_step;                          // Adam only
     float lr;                                                     // SGD only
-    // hot rows (SGD, large batches): runs longer than SML_HOT are appended here instead of being summed by
-    // one wavefront; k_hot_partial / k_hot_apply reduce them with whole workgroups.  null: off.
-    uint32_t* hot_list;      // [hot_cap][3]: (pos | is_item << 31), len, row
-    int* hot_count;          // this batch's counter (zeroed by the caller)
+    // hot rows (SGD, large batches): runs longer than SML_HOT are listed here (by the index preparation)
+    // instead of being summed by one wavefront; the first hot_blocks workgroups of the run kernel reduce
+    // their chunks and k_hot_apply finishes them.  null: off.
+    const uint32_t* hot_list;// this batch's [hot_cap][3]: (pos | is_item << 31), len, row
+    const int* hot_count;    // this batch's number of hot runs
+    int hot_blocks;
     int* hot_first;          // [hot_cap] first chunk index of each hot run
     float* hot_part;         // [hot_chunks][d] chunk partial sums
     int hot_cap;
 };
-#define SML_HOT 512          // runs longer than this take the hot path
-#define SML_HOT_CHUNK 1024   // occurrences per workgroup in k_hot_partial
+#define SML_HOT 128          // runs longer than this take the hot path
+#define SML_HOT_CHUNK 512    // occurrences per workgroup in the hot-row partial sums
 #define SML_HOT_MAXCAP 8192
-hipError_t sml_launch_hot_rows(int d, int dtype_bytes, const SmlRunArgs& a, int max_chunks, hipStream_t st);
+hipError_t sml_launch_hot_apply(int d, int dtype_bytes, const SmlRunArgs& a, hipStream_t st);
 hipError_t sml_launch_run_adam(int d, const SmlRunArgs& a, int64_t max_records, hipStream_t st);
 hipError_t sml_launch_run_sgd(int d, int dtype_bytes, const SmlRunArgs& a, int64_t max_records, hipStream_t st);
 hipError_t sml_launch_adam_flush(int d, float* w, float* m, float* v, int32_t* last, int64_t rows,
@@ -128,8 +133,9 @@ hipError_t sml_launch_mark_runs(int key_bytes, const void* keys, const uint32_t*
                                 uint8_t* flag_dup, uint8_t* uniq, int64_t uniq_stride, int64_t uniq_item_base, hipStream_t st);
 hipError_t sml_launch_mark_unique(int key_bytes, const void* keys, const uint32_t* vals, int64_t n, int row_bits, uint8_t* uniq,
                                   int64_t uniq_stride, hipStream_t st);
-hipError_t sml_launch_make_runs(int key_bytes, const void* keys, int64_t n, int row_bits, const uint32_t* heads, const int* n_heads,
-                                int64_t max_heads, SmlRun* runs, hipStream_t st);
+hipError_t sml_launch_make_runs(int key_bytes, const void* keys, const uint32_t* vals, int64_t n, int row_bits, const uint32_t* heads,
+                                const int* n_heads, int64_t max_heads, SmlRun* runs, int* max_len, int64_t seg, int is_item,
+                                uint32_t* hot_list, int* hot_count, int hot_cap, hipStream_t st);
 hipError_t sml_launch_batch_offsets(const SmlRun* runs, const int* n_sel, int nb, int64_t seg, int* off, hipStream_t st);
 hipError_t sml_launch_build_keys(int key_bytes, const int64_t* tri, int64_t n, int batch, int pad_tiles, int row_bits_u,
                                  int row_bits_i, void* key_u, uint32_t* val_u, void* key_i, uint32_t* val_i, hipStream_t st);
