@@ -11,6 +11,9 @@
 #include "sml_kernels.h"
 #include "../../include/sml_hip.h"
 
+#ifndef SML_NT
+#define SML_NT 7    // bit 0: user-row loads, bit 1: user-row stores, bit 2: item-row stores of the in-place pass are nontemporal
+#endif
 namespace {
 
 template <typename T> struct RowVec;
@@ -23,6 +26,15 @@ template <> struct RowVec<float> {
     __device__ static void store(float* p, const float (&x)[4]) {
         f32x4 v; v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
         *reinterpret_cast<f32x4*>(p) = v;
+    }
+    // streaming forms: a row that is touched once per batch should not displace re-used lines
+    __device__ static void load_nt(const float* p, float (&x)[4]) {
+        const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+        x[0] = v[0]; x[1] = v[1]; x[2] = v[2]; x[3] = v[3];
+    }
+    __device__ static void store_nt(float* p, const float (&x)[4]) {
+        f32x4 v; v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
     }
 };
 template <> struct RowVec<__half> {
@@ -40,6 +52,8 @@ template <> struct RowVec<__half> {
         for (int i = 0; i < 4; ++i) h[i] = __floats2half2_rn(x[2 * i], x[2 * i + 1]);
         *reinterpret_cast<uint4*>(p) = raw;
     }
+    __device__ static void load_nt(const __half* p, float (&x)[8]) { load(p, x); }
+    __device__ static void store_nt(__half* p, const float (&x)[8]) { store(p, x); }
 };
 
 template <int LPR>
@@ -86,7 +100,8 @@ __global__ __launch_bounds__(256) void k_bare_grad(SmlBareArgs a) {
     if (t < a.B) {
         const int64_t iu = a.tri[(int64_t)t * 3], ii = a.tri[(int64_t)t * 3 + 1], in = a.tri[(int64_t)t * 3 + 2];
         float u[VEC], it[VEC], ng[VEC];
-        RowVec<T>::load(reinterpret_cast<const T*>(a.w_user) + iu * D + sub * VEC, u);
+        if (SML_NT & 1) RowVec<T>::load_nt(reinterpret_cast<const T*>(a.w_user) + iu * D + sub * VEC, u);
+        else RowVec<T>::load(reinterpret_cast<const T*>(a.w_user) + iu * D + sub * VEC, u);
         RowVec<T>::load(reinterpret_cast<const T*>(a.w_item) + ii * D + sub * VEC, it);
         RowVec<T>::load(reinterpret_cast<const T*>(a.w_item) + in * D + sub * VEC, ng);
         float sp = 0.f, sn = 0.f, sq_u = 0.f, sq_i = 0.f;
@@ -110,21 +125,21 @@ __global__ __launch_bounds__(256) void k_bare_grad(SmlBareArgs a) {
         }
         const bool one_u = a.uniq != nullptr && a.uniq[t], one_i = a.uniq != nullptr && a.uniq[a.B + t],
                    one_n = a.uniq != nullptr && a.uniq[2 * a.B + t];
-        auto emit = [&](bool in_place, T* wrow, const float (&row)[VEC], const float (&g)[VEC], float* dxrow) {
+        auto emit = [&](bool in_place, T* wrow, const float (&row)[VEC], const float (&g)[VEC], float* dxrow, bool nt) {
             if (in_place) {
                 float nw[VEC];
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) nw[e] = row[e] - a.lr * g[e];
-                RowVec<T>::store(wrow, nw);
+                if (nt) RowVec<T>::store_nt(wrow, nw); else RowVec<T>::store(wrow, nw);
             } else {
 #pragma unroll
                 for (int h = 0; h < VEC / 4; ++h)
                     RowVec<float>::store(dxrow + h * 4, reinterpret_cast<const float(&)[4]>(g[h * 4]));
             }
         };
-        emit(one_u, reinterpret_cast<T*>(a.w_user) + iu * D + sub * VEC, u, gx, a.dx + (int64_t)t * D + sub * VEC);
-        emit(one_i, reinterpret_cast<T*>(a.w_item) + ii * D + sub * VEC, it, gy, a.dx + (int64_t)(a.B + t) * D + sub * VEC);
-        emit(one_n, reinterpret_cast<T*>(a.w_item) + in * D + sub * VEC, ng, gz, a.dx + (int64_t)(2 * a.B + t) * D + sub * VEC);
+        emit(one_u, reinterpret_cast<T*>(a.w_user) + iu * D + sub * VEC, u, gx, a.dx + (int64_t)t * D + sub * VEC, (SML_NT & 2) != 0);
+        emit(one_i, reinterpret_cast<T*>(a.w_item) + ii * D + sub * VEC, it, gy, a.dx + (int64_t)(a.B + t) * D + sub * VEC, (SML_NT & 4) != 0);
+        emit(one_n, reinterpret_cast<T*>(a.w_item) + in * D + sub * VEC, ng, gz, a.dx + (int64_t)(2 * a.B + t) * D + sub * VEC, (SML_NT & 4) != 0);
         contrib = (sub == 0 ? lt : 0.0f) + 0.5f * (a.lam_user * sq_u + a.lam_item * sq_i);
     }
     const float tot = block_sum256(contrib, sh4);
