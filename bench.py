@@ -149,7 +149,7 @@ def kernel_work(name, a, hp, U_local):
     f_row = 6304.0 * d                      # conv prologue + fc1 + fc2 forward, FLOP per row
     b_row = (2.0 * d * 512 + 2.0 * 512 * 5 * d) + 160.0 * d   # dA2 + dA1 GEMMs + per-coordinate tail
     if name == "k_eval_ranks":
-        per = n * ((2 + a.neg) * d * 4 + (2 + a.neg) * 8 + 4)
+        per = n * ((2 + a.neg) * d * 4 + (2 + a.neg) * 4 + 4)     # candidate rows + int32 candidate ids + the rank
         return "hbm", per * evals, evals
     if name == "k_transfer_fwd":
         return "mfma", rows_fwd * f_row, hp.multi_num * (hp.MF_epochs * nb_mf + hp.TR_epochs * nb_tr) + 2 * n_updata
@@ -296,7 +296,10 @@ def main():
         prof = engine.profile_read()
         engine.profile(False)
         if prof and rank == 0:
-            dom = max(prof.items(), key=lambda kv: kv[1][1])
+            # the evaluations run throttled (256 workgroups) on a low-priority side stream underneath the
+            # training kernels: their span is not on the critical path, so the roofline object describes
+            # the kernel class that dominates the TRAINING stream
+            dom = max(((k, v) for k, v in prof.items() if k != "k_eval_ranks"), key=lambda kv: kv[1][1])
             name, (cnt, ms) = dom
             bound, work, _ = kernel_work(name, a, hp, U_local)
             kern = {k: {"launches": c, "total_ms": round(m, 3), "avg_us": round(1000.0 * m / c, 2)} for k, (c, m) in prof.items()}

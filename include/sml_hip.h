@@ -193,13 +193,16 @@ int sml_mf_forward(sml_ctx* ctx, const float* w_user, const float* w_item, const
 int sml_eval_ranks(sml_ctx* ctx, const float* w_user, const float* w_item, const int64_t* rows,
                    int64_t n, int n_cols, int32_t* rank, void* stream);
 /* L2-blocked form for test sets that are evaluated repeatedly (the validation rows of a period):
- * sml_eval_prepare groups each row's candidates by item range ONCE into rows_b [n, n_cols] and
- * bucket_off int32 [n, 9]; sml_eval_ranks_blocked then yields the same ranks as sml_eval_ranks with
- * every XCD gathering from its own eighth of the item table. */
+ * sml_eval_prepare groups each row's candidates by item range ONCE into rows_b int32 [n, n_cols]
+ * (half the index bytes of the int64 input; n_item < 2^31) and bucket_off int32 [n, 9];
+ * sml_eval_ranks_blocked then yields the same ranks as sml_eval_ranks with every XCD gathering from
+ * its own eighth of the item table.  max_workgroups > 0 caps the (persistent) grid: an evaluation
+ * queued on a side stream underneath training kernels leaves them most of each CU's wave slots. */
 int sml_eval_prepare(sml_ctx* ctx, const int64_t* rows, int64_t n, int n_cols, int64_t n_item,
-                     int64_t* rows_b, int32_t* bucket_off, void* stream);
-int sml_eval_ranks_blocked(sml_ctx* ctx, const float* w_user, const float* w_item, const int64_t* rows_b,
-                           const int32_t* bucket_off, int64_t n, int n_cols, int32_t* rank, void* stream);
+                     int32_t* rows_b, int32_t* bucket_off, void* stream);
+int sml_eval_ranks_blocked(sml_ctx* ctx, const float* w_user, const float* w_item, const int32_t* rows_b,
+                           const int32_t* bucket_off, int64_t n, int n_cols, int32_t* rank,
+                           int max_workgroups, void* stream);
 /* hits = #{rank < topk}, ndcg = sum 1/log2(rank+2) over hits; out[0]=hits, out[1]=ndcg (device). */
 int sml_eval_metrics(sml_ctx* ctx, const int32_t* rank, int64_t n, int topk, float* out, void* stream);
 

@@ -67,7 +67,8 @@ SIGNATURES = {
     "sml_eval_ranks": (ctypes.c_int, [c_void, c_void, c_void, c_void, ctypes.c_int64, ctypes.c_int, c_void, c_void]),
     "sml_eval_metrics": (ctypes.c_int, [c_void, c_void, ctypes.c_int64, ctypes.c_int, c_void, c_void]),
     "sml_eval_prepare": (ctypes.c_int, [c_void, c_void, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, c_void, c_void, c_void]),
-    "sml_eval_ranks_blocked": (ctypes.c_int, [c_void, c_void, c_void, c_void, c_void, ctypes.c_int64, ctypes.c_int, c_void, c_void]),
+    "sml_eval_ranks_blocked": (ctypes.c_int, [c_void, c_void, c_void, c_void, c_void, ctypes.c_int64, ctypes.c_int, c_void, ctypes.c_int,
+                                              c_void]),
     "sml_comm_load": (ctypes.c_int, [ctypes.c_char_p]),
     "sml_comm_unique_id": (ctypes.c_int, [c_void]),
     "sml_comm_init": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void]),

@@ -716,9 +716,9 @@ int sml_eval_ranks(sml_ctx* ctx, const float* w_user, const float* w_item, const
     return SML_OK;
 }
 
-int sml_eval_prepare(sml_ctx* ctx, const int64_t* rows, int64_t n, int n_cols, int64_t n_item, int64_t* rows_b,
+int sml_eval_prepare(sml_ctx* ctx, const int64_t* rows, int64_t n, int n_cols, int64_t n_item, int32_t* rows_b,
                      int32_t* bucket_off, void* stream) {
-    if (!ctx || !rows || !rows_b || !bucket_off || n < 0 || n_cols < 2 || n_item <= 0)
+    if (!ctx || !rows || !rows_b || !bucket_off || n < 0 || n_cols < 2 || n_item <= 0 || n_item > 0x7fffffff)
         return fail(SML_EINVAL, "sml_eval_prepare", "bad argument");
     if (n == 0) return SML_OK;
     DevGuard g(ctx->device);
@@ -727,15 +727,16 @@ int sml_eval_prepare(sml_ctx* ctx, const int64_t* rows, int64_t n, int n_cols, i
     return SML_OK;
 }
 
-int sml_eval_ranks_blocked(sml_ctx* ctx, const float* w_user, const float* w_item, const int64_t* rows_b,
-                           const int32_t* bucket_off, int64_t n, int n_cols, int32_t* rank, void* stream) {
+int sml_eval_ranks_blocked(sml_ctx* ctx, const float* w_user, const float* w_item, const int32_t* rows_b,
+                           const int32_t* bucket_off, int64_t n, int n_cols, int32_t* rank, int max_workgroups,
+                           void* stream) {
     if (!ctx || !w_user || !w_item || !rows_b || !bucket_off || !rank || n < 0 || n_cols < 2)
         return fail(SML_EINVAL, "sml_eval_ranks_blocked", "bad argument");
     if (n == 0) return SML_OK;
     DevGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     ctx->prof.begin(PC_EVAL_RANKS, st);
-    HIPCHK(sml_launch_eval_ranks_bucketed(ctx->d, w_user, w_item, rows_b, bucket_off, n, n_cols, rank, st));
+    HIPCHK(sml_launch_eval_ranks_bucketed(ctx->d, w_user, w_item, rows_b, bucket_off, n, n_cols, rank, max_workgroups, st));
     ctx->prof.end(st);
     return SML_OK;
 }

@@ -63,6 +63,12 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+// 4-element partial dot product with a pinned operation order (one multiply, three fused multiply-adds):
+// the evaluation compares scores exactly, so every kernel variant must round them identically
+__device__ __forceinline__ float dot4(const float (&a)[4], const float (&b)[4]) {
+    return __fmaf_rn(a[3], b[3], __fmaf_rn(a[2], b[2], __fmaf_rn(a[1], b[1], __fmul_rn(a[0], b[0]))));
+}
+
 // deterministic 256-thread block sum; result valid in thread 0
 __device__ __forceinline__ float block_sum256(float v, float* sh4) {
 #pragma unroll
@@ -654,10 +660,7 @@ __global__ __launch_bounds__(256) void k_eval_ranks(const float* __restrict__ wu
     float u[4], x[4];
     RowVec<float>::load(wu + R[0] * D + sub * 4, u);
     RowVec<float>::load(wi + R[1] * D + sub * 4, x);
-    float s0 = 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) s0 += u[k] * x[k];
-    s0 = group_sum<LPR>(s0);
+    const float s0 = group_sum<LPR>(dot4(u, x));
     int cnt = 0;
     int c = 2 + grp;
     for (; c + 3 * G < n_cols; c += 4 * G) {
@@ -666,19 +669,13 @@ __global__ __launch_bounds__(256) void k_eval_ranks(const float* __restrict__ wu
         for (int j = 0; j < 4; ++j) RowVec<float>::load(wi + R[c + j * G] * D + sub * 4, y[j]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float s = 0.f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) s += u[k] * y[j][k];
-            s = group_sum<LPR>(s);
+            const float s = group_sum<LPR>(dot4(u, y[j]));
             cnt += (s > s0) ? 1 : 0;
         }
     }
     for (; c < n_cols; c += G) {
         RowVec<float>::load(wi + R[c] * D + sub * 4, x);
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) s += u[k] * x[k];
-        s = group_sum<LPR>(s);
+        const float s = group_sum<LPR>(dot4(u, x));
         cnt += (s > s0) ? 1 : 0;
     }
     int tot = (sub == 0) ? cnt : 0;
@@ -697,8 +694,10 @@ __global__ __launch_bounds__(256) void k_eval_ranks(const float* __restrict__ wu
 // atomicAdd (exact, order-independent).
 // ------------------------------------------------------------------------------------
 #define SML_EVB 8
+// rows_out: int32 [n, n_cols] (user, positive, then the candidates grouped by item range): half the
+// index stream of the int64 input, and that stream is the evaluation's only HBM traffic of note
 __global__ __launch_bounds__(256) void k_eval_bucketize(const int64_t* __restrict__ rows, int64_t n, int n_cols,
-                                                        int64_t n_item, int64_t* __restrict__ rows_out,
+                                                        int64_t n_item, int32_t* __restrict__ rows_out,
                                                         int32_t* __restrict__ bucket_off) {
     __shared__ int hist[4][SML_EVB], cursor[4][SML_EVB];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -718,63 +717,62 @@ __global__ __launch_bounds__(256) void k_eval_bucketize(const int64_t* __restric
     }
     __syncthreads();
     if (!ok) return;
-    int64_t* O = rows_out + r * n_cols;
-    if (lane < 2) O[lane] = R[lane];
+    int32_t* O = rows_out + r * n_cols;
+    if (lane < 2) O[lane] = (int32_t)R[lane];
     for (int c = 2 + lane; c < n_cols; c += 64) {
         const int64_t it = R[c];
         const int slot = atomicAdd(&cursor[wv][(int)min((int64_t)SML_EVB - 1, it / per)], 1);
-        O[2 + slot] = it;          // order inside a bucket is irrelevant: the rank is a count
+        O[2 + slot] = (int32_t)it;          // order inside a bucket is irrelevant: the rank is a count
     }
 }
 
+// Persistent form: workgroup b serves item range b % 8 (= its XCD) and strides over the groups of four
+// test rows, so the grid can be capped (an evaluation that runs underneath training kernels on a side
+// stream should not flood every CU's wave slots).  The candidate indices are read once: nontemporal,
+// so the stream does not push the item slice (and the neighbours' weights) out of L2.
 template <int D>
 __global__ __launch_bounds__(256) void k_eval_ranks_bucketed(const float* __restrict__ wu, const float* __restrict__ wi,
-                                                             const int64_t* __restrict__ rows, const int32_t* __restrict__ bucket_off,
+                                                             const int32_t* __restrict__ rows, const int32_t* __restrict__ bucket_off,
                                                              int64_t n, int n_cols, int32_t* __restrict__ rank) {
     constexpr int LPR = D / 4;
     constexpr int G = 64 / LPR;
     const int lane = threadIdx.x & 63;
     const int x = blockIdx.x % SML_EVB;                          // this workgroup's item range (= its XCD)
-    const int64_t r = ((int64_t)blockIdx.x / SML_EVB) * 4 + (threadIdx.x >> 6);
-    if (r >= n) return;
     const int grp = lane / LPR, sub = lane % LPR;
-    const int64_t* R = rows + r * n_cols;
-    const int c0 = 2 + bucket_off[r * (SML_EVB + 1) + x], c1 = 2 + bucket_off[r * (SML_EVB + 1) + x + 1];
-    if (c0 == c1) return;
-    float u[4], xr[4];
-    RowVec<float>::load(wu + R[0] * D + sub * 4, u);
-    RowVec<float>::load(wi + R[1] * D + sub * 4, xr);
-    float s0 = 0.f;
+    const int64_t n_groups = (n + 3) / 4;
+    for (int64_t gi = blockIdx.x / SML_EVB; gi < n_groups; gi += gridDim.x / SML_EVB) {
+        const int64_t r = gi * 4 + (threadIdx.x >> 6);
+        if (r >= n) continue;
+        const int32_t* R = rows + r * n_cols;
+        const int c0 = 2 + bucket_off[r * (SML_EVB + 1) + x], c1 = 2 + bucket_off[r * (SML_EVB + 1) + x + 1];
+        if (c0 == c1) continue;
+        float u[4], xr[4];
+        const int32_t pos_item = R[1];
+        RowVec<float>::load(wu + (int64_t)R[0] * D + sub * 4, u);
+        RowVec<float>::load(wi + (int64_t)pos_item * D + sub * 4, xr);
+        const float s0 = group_sum<LPR>(dot4(u, xr));
+        int cnt = 0;
+        constexpr int UD = 4;                  // candidate rows in flight per lane group
+        // predicated full-depth trips (a bucket holds ~n_cols/8 candidates, a lane group ~n_cols/64 of them):
+        // a slot past the bucket's end re-reads the positive's row (cached) and is not counted
+        for (int c = c0 + grp; c < c1; c += UD * G) {
+            float y[UD][4];
+            int32_t id[UD];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) s0 += u[k] * xr[k];
-    s0 = group_sum<LPR>(s0);
-    int cnt = 0;
-    int c = c0 + grp;
-    for (; c + 3 * G < c1; c += 4 * G) {
-        float y[4][4];
+            for (int j = 0; j < UD; ++j) id[j] = (c + j * G < c1) ? __builtin_nontemporal_load(R + c + j * G) : pos_item;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) RowVec<float>::load(wi + R[c + j * G] * D + sub * 4, y[j]);
+            for (int j = 0; j < UD; ++j) RowVec<float>::load(wi + (int64_t)id[j] * D + sub * 4, y[j]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float s = 0.f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) s += u[k] * y[j][k];
-            s = group_sum<LPR>(s);
-            cnt += (s > s0) ? 1 : 0;
+            for (int j = 0; j < UD; ++j) {
+                const float sc = group_sum<LPR>(dot4(u, y[j]));
+                cnt += (c + j * G < c1 && sc > s0) ? 1 : 0;
+            }
         }
-    }
-    for (; c < c1; c += G) {
-        RowVec<float>::load(wi + R[c] * D + sub * 4, xr);
-        float s = 0.f;
+        int tot = (sub == 0) ? cnt : 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s += u[k] * xr[k];
-        s = group_sum<LPR>(s);
-        cnt += (s > s0) ? 1 : 0;
+        for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off, 64);
+        if (lane == 0 && tot) atomicAdd(&rank[r], tot);
     }
-    int tot = (sub == 0) ? cnt : 0;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off, 64);
-    if (lane == 0 && tot) atomicAdd(&rank[r], tot);
 }
 
 // hits and NDCG sum over ranks (model/MF.py:60-78): hit iff rank < topk, NDCG = 1/log2(rank+2).
@@ -909,16 +907,19 @@ hipError_t sml_launch_eval_ranks(int d, const float* wu, const float* wi, const 
     SML_DISPATCH_D(d, k_eval_ranks<DD><<<dim3((unsigned)nb), dim3(256), 0, st>>>(wu, wi, rows, n, n_cols, rank));
     return hipGetLastError();
 }
-hipError_t sml_launch_eval_bucketize(const int64_t* rows, int64_t n, int n_cols, int64_t n_item, int64_t* rows_out,
+hipError_t sml_launch_eval_bucketize(const int64_t* rows, int64_t n, int n_cols, int64_t n_item, int32_t* rows_out,
                                      int32_t* bucket_off, hipStream_t st) {
     k_eval_bucketize<<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st>>>(rows, n, n_cols, n_item, rows_out, bucket_off);
     return hipGetLastError();
 }
-hipError_t sml_launch_eval_ranks_bucketed(int d, const float* wu, const float* wi, const int64_t* rows_b,
-                                          const int32_t* bucket_off, int64_t n, int n_cols, int32_t* rank, hipStream_t st) {
+hipError_t sml_launch_eval_ranks_bucketed(int d, const float* wu, const float* wi, const int32_t* rows_b,
+                                          const int32_t* bucket_off, int64_t n, int n_cols, int32_t* rank, int max_blocks,
+                                          hipStream_t st) {
     hipError_t e = hipMemsetAsync(rank, 0, (size_t)n * sizeof(int32_t), st);
     if (e != hipSuccess) return e;
-    const int64_t nb = ((n + 3) / 4) * SML_EVB;
+    int64_t nb = ((n + 3) / 4) * SML_EVB;
+    if (max_blocks > 0 && nb > max_blocks) nb = (max_blocks / SML_EVB > 0 ? max_blocks / SML_EVB : 1) * SML_EVB;
+    if (nb > 0x7fffffff) nb = 0x7fffff00;
     SML_DISPATCH_D(d, k_eval_ranks_bucketed<DD><<<dim3((unsigned)nb), dim3(256), 0, st>>>(wu, wi, rows_b, bucket_off, n, n_cols, rank));
     return hipGetLastError();
 }

@@ -154,8 +154,9 @@ hipError_t sml_launch_mf_forward(int d, const float* wu, const float* wi, const 
                                  int64_t n, int norm, float* uemb, float* iemb, float* score, hipStream_t st);
 hipError_t sml_launch_eval_ranks(int d, const float* wu, const float* wi, const int64_t* rows, int64_t n,
                                  int n_cols, int32_t* rank, hipStream_t st);
-hipError_t sml_launch_eval_bucketize(const int64_t* rows, int64_t n, int n_cols, int64_t n_item, int64_t* rows_out,
+hipError_t sml_launch_eval_bucketize(const int64_t* rows, int64_t n, int n_cols, int64_t n_item, int32_t* rows_out,
                                      int32_t* bucket_off, hipStream_t st);
-hipError_t sml_launch_eval_ranks_bucketed(int d, const float* wu, const float* wi, const int64_t* rows_b,
-                                          const int32_t* bucket_off, int64_t n, int n_cols, int32_t* rank, hipStream_t st);
+hipError_t sml_launch_eval_ranks_bucketed(int d, const float* wu, const float* wi, const int32_t* rows_b,
+                                          const int32_t* bucket_off, int64_t n, int n_cols, int32_t* rank, int max_blocks,
+                                          hipStream_t st);
 hipError_t sml_launch_eval_metrics(const int32_t* rank, int64_t n, int topk, float* out, hipStream_t st);

@@ -150,12 +150,17 @@ class meta_train(object):
 
     def _ranks(self, rows):
         """Rank of every row's positive under the current tables; reused while the tables are unchanged
-        (the reference re-evaluates identical tables several times per phase, and @20/@10/@5 share ranks)."""
+        (the reference re-evaluates identical tables several times per phase, and @20/@10/@5 share ranks).
+        On the GPU engine this is a handle of an evaluation queued on a snapshot of the tables
+        (engine.eval_submit): the training stream does not wait for it."""
         key = (id(rows), getattr(self, "_version", 0))
         hit = getattr(self, "_rank_cache", None)
         if hit is None or hit[0] != key:
-            ranks = self.engine.eval_ranks(self.MFbase.user_laten.weight.data, self.MFbase.item_laten.weight.data,
-                                           rows.rows)
+            wu, wi = self.MFbase.user_laten.weight.data, self.MFbase.item_laten.weight.data
+            if hasattr(self.engine, "eval_submit"):
+                ranks = self.engine.eval_submit(wu, wi, rows.rows)
+            else:
+                ranks = self.engine.eval_ranks(wu, wi, rows.rows)
             self._rank_cache = hit = (key, ranks)
         return hit[1]
 
@@ -182,7 +187,12 @@ class meta_train(object):
         return hits / n, torch.tensor(np.float32(ndcg / n))
 
     def _metrics(self, ranks, n, topK):
-        if hasattr(self.engine, "eval_metrics_device"):
+        if isinstance(ranks, dict):               # a submitted evaluation (engine.eval_submit)
+            pending = self.engine.eval_metrics_submit(ranks, topK)
+
+            def resolve():
+                return self.engine.eval_result(pending)
+        elif hasattr(self.engine, "eval_metrics_device"):
             out = self.engine.eval_metrics_device(ranks, topK)
 
             def resolve():
@@ -307,18 +317,9 @@ class meta_train(object):
                 self.writer.add_scalar("Acc/tr-TR-ndcg@" + str(args.topK), float(_val(ndcg)), self.TR_itr)
                 self.TR_itr += 1
 
-        pending = None
         if compute_performance:
-            # this evaluation only READS the MF tables and the TR epoch never writes them: queue it on the
-            # engine's side stream, let it run underneath the first TR epoch, print it in its place
-            cached = getattr(self, "_rank_cache", None)
-            fresh = cached is not None and cached[0] == (id(now_test), getattr(self, "_version", 0))
-            if hasattr(self.engine, "eval_async") and args.TR_epochs > 0 and not fresh:
-                D.loader_base_seed_draw()
-                pending = self.engine.eval_async(self.MFbase.user_laten.weight.data,
-                                                 self.MFbase.item_laten.weight.data, now_test.rows, args.topK)
-            else:
-                report_before(*self._test(now_test, args.topK))
+            # (queued on a snapshot of the tables: it runs underneath the TR epoch that follows)
+            report_before(*self._test(now_test, args.topK))
         s_time = time.time()
         for epoch in range(args.TR_epochs):
             self.transfer.train()
@@ -328,11 +329,6 @@ class meta_train(object):
             losses = self.engine.tr_stage_epoch(self.transfer, self.last_user_weight, self.last_item_weight,
                                                 self.user_weight_hat, self.item_weight_hat, triples,
                                                 args.TR_batch_size, args.TR_lr, args.TR_l2, bce=True)
-            if pending is not None:
-                handle, pending = pending, None
-                self.engine.eval_join(handle)
-                self._rank_cache = ((id(now_test), getattr(self, "_version", 0)), handle[2])
-                report_before(*self._pair(lambda h=handle: self.engine.eval_result(h), now_test.rows.shape[0]))
             self.timing["tr"] += time.time() - t0
             self.timing["tr_triples"] += triples.shape[0]
             bs = args.TR_batch_size

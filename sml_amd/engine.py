@@ -238,18 +238,18 @@ class HipEngine(object):
         unique marks, duplicates-only compaction) while earlier work keeps the main stream busy.
         n_user / n_item (the table heights; 0 = unknown) let the sort use 32-bit keys.
         Returns a handle for bare_epoch(prepared=...)."""
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
+        if getattr(self, "_prep", None) is None:
+            self._prep = torch.cuda.Stream(device=self.device)
         tri = self._dev(triples, torch.int64)
         slot = self._prep_slot = 1 - getattr(self, "_prep_slot", 1)
         cur = torch.cuda.current_stream(self.device)
-        self._side.wait_stream(cur)          # the slot's previous user (two epochs back) has been queued before this
-        with torch.cuda.stream(self._side):
+        self._prep.wait_stream(cur)          # the slot's previous user (two epochs back) has been queued before this
+        with torch.cuda.stream(self._prep):
             check(self.lib.sml_embed_loss_sgd_prepare(self._ctx, _ptr(tri), tri.shape[0], int(batch_size), int(n_user),
                                                       int(n_item), slot, self._stream()), "sml_embed_loss_sgd_prepare")
             ev = torch.cuda.Event()
-            ev.record(self._side)
-        tri.record_stream(self._side)
+            ev.record(self._prep)
+        tri.record_stream(self._prep)
         return dict(slot=slot, event=ev, tri=tri, batch=int(batch_size))
 
     def bare_epoch(self, w_user, w_item, triples, batch_size, lr, lam_user, lam_item, bce=True, prepared=None):
@@ -300,14 +300,18 @@ class HipEngine(object):
         if hit is None:
             if len(cache) >= 3:
                 cache.pop(next(iter(cache)))
-            rows_b = torch.empty_like(rows)
+            rows_b = torch.empty(rows.shape, device=self.device, dtype=torch.int32)
             off = torch.empty((rows.shape[0], 9), device=self.device, dtype=torch.int32)
             check(self.lib.sml_eval_prepare(self._ctx, _ptr(rows), rows.shape[0], rows.shape[1], int(n_item), _ptr(rows_b),
                                             _ptr(off), self._stream()), "sml_eval_prepare")
-            hit = cache[key] = (rows_b, off, rows)     # keeps `rows` alive: the key is its address
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            hit = cache[key] = (rows_b, off, rows, ev)     # keeps `rows` alive: the key is its address
+        else:
+            torch.cuda.current_stream(self.device).wait_event(hit[3])   # built on another stream, perhaps
         return hit[0], hit[1]
 
-    def eval_ranks(self, user_tab, item_tab, rows, blocked=None):
+    def eval_ranks(self, user_tab, item_tab, rows, blocked=None, max_workgroups=0):
         wu, wi = self._table(user_tab), self._table(item_tab)
         rows = self._dev(rows, torch.int64)
         n, c = rows.shape
@@ -317,38 +321,78 @@ class HipEngine(object):
         if blocked:
             rows_b, off = self._blocked_rows(rows, wi.shape[0])
             check(self.lib.sml_eval_ranks_blocked(self._ctx, _ptr(wu), _ptr(wi), _ptr(rows_b), _ptr(off), n, c,
-                                                  _ptr(rank), self._stream()), "sml_eval_ranks_blocked")
+                                                  _ptr(rank), int(max_workgroups), self._stream()), "sml_eval_ranks_blocked")
         else:
             check(self.lib.sml_eval_ranks(self._ctx, _ptr(wu), _ptr(wi), _ptr(rows), n, c, _ptr(rank), self._stream()),
                   "sml_eval_ranks")
         return rank
 
-    def eval_async(self, user_tab, item_tab, rows, topk):
-        """Queue ranks + metrics on the engine's side stream (ordered after everything already queued on the
-        current stream) and return a handle; `eval_result(handle)` waits for it.  Lets an evaluation that
-        only READS the tables run underneath kernels that do not write them (e.g. the TR epoch)."""
+    # Evaluations never sit on the training stream.  eval_submit copies the two tables into a snapshot
+    # (a device copy of a few tens of MB, microseconds) on the CURRENT stream and queues the rank pass
+    # over the snapshot on the engine's low-priority side stream, so the training kernels that follow on
+    # the current stream -- which may overwrite the tables at once -- run on top of it: the latency-bound
+    # training kernels leave most of the chip idle, the evaluation fills it.
+    SNAPSHOTS = 3
+    SIDE_EVAL_WORKGROUPS = int(__import__("os").environ.get("SML_SIDE_EVAL_WGS", "256"))   # grid cap of a side-stream evaluation
+
+    def _side_stream(self):
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            prio = 0
+            try:
+                lo, _hi = torch.cuda.Stream.priority_range()
+                prio = int(lo)                      # least urgent
+            except Exception:
+                prio = 0
+            try:
+                self._side = torch.cuda.Stream(device=self.device, priority=prio)
+            except Exception:
+                self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
+    def eval_submit(self, user_tab, item_tab, rows):
+        """Queue the ranks of `rows` under the tables AS THEY ARE NOW (at this point of the current stream)
+        and return a handle; the caller may modify the tables right away."""
+        wu, wi = self._table(user_tab), self._table(item_tab)
+        rows = self._dev(rows, torch.int64)
+        side = self._side_stream()
         cur = torch.cuda.current_stream(self.device)
-        self._side.wait_stream(cur)
-        with torch.cuda.stream(self._side):
-            ranks = self.eval_ranks(user_tab, item_tab, rows)
+        ring = self.__dict__.setdefault("_snap", [])
+        k = self.__dict__.get("_snap_next", 0) % self.SNAPSHOTS
+        self._snap_next = k + 1
+        while len(ring) <= k:
+            ring.append(dict(u=None, i=None, ev=None))
+        slot = ring[k]
+        if slot["ev"] is not None:
+            cur.wait_event(slot["ev"])          # the evaluation that last read this snapshot is done (device-side wait)
+        if slot["u"] is None or slot["u"].shape != wu.shape:
+            slot["u"] = torch.empty_like(wu)
+        if slot["i"] is None or slot["i"].shape != wi.shape:
+            slot["i"] = torch.empty_like(wi)
+        slot["u"].copy_(wu)
+        slot["i"].copy_(wi)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            ranks = self.eval_ranks(slot["u"], slot["i"], rows, max_workgroups=self.SIDE_EVAL_WORKGROUPS)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        slot["ev"] = ev
+        rows.record_stream(side)
+        return dict(ranks=ranks, event=ev, n=rows.shape[0])
+
+    def eval_metrics_submit(self, handle, topk):
+        """(hits, ndcg_sum) of a submitted evaluation at `topk`, on the side stream; returns (out, event)."""
+        side = self._side_stream()
+        with torch.cuda.stream(side):
             out = torch.empty(2, device=self.device, dtype=torch.float32)
-            check(self.lib.sml_eval_metrics(self._ctx, _ptr(ranks), ranks.shape[0], int(topk), _ptr(out),
+            check(self.lib.sml_eval_metrics(self._ctx, _ptr(handle["ranks"]), handle["n"], int(topk), _ptr(out),
                                             self._stream()), "sml_eval_metrics")
             ev = torch.cuda.Event()
-            ev.record(self._side)
-        for t in (user_tab, item_tab, rows):
-            t.record_stream(self._side)
-        return (out, ev, ranks)
+            ev.record(side)
+        return (out, ev)
 
-    def eval_join(self, handle):
-        """Order the current stream after a queued evaluation (device-side wait, the host does not block):
-        call it before queueing anything that writes the tables the evaluation reads."""
-        torch.cuda.current_stream(self.device).wait_event(handle[1])
-
-    def eval_result(self, handle):
-        out, ev, _ = handle
+    def eval_result(self, pending):
+        """Wait (host) for an eval_metrics_submit result: (hits, ndcg_sum)."""
+        out, ev = pending[0], pending[1]
         ev.synchronize()
         h = out.cpu()
         return float(h[0]), float(h[1])

@@ -98,27 +98,33 @@ def run_period(engine, st, plan, hp, record=None, overlap=True):
       * an evaluation of tables that were not modified since the previous evaluation of the same rows
         returns the previous result (the reference's "before train MF" numbers always repeat the
         preceding "val result" line);
-      * the "before train transfer" evaluation only reads W, which the TR epoch never writes, so it is
-        queued on a side stream and runs underneath the TR epoch."""
+      * every other evaluation is queued on a snapshot of the tables (engine.eval_submit) and runs on the
+        engine's low-priority side stream underneath the training kernels that follow; the numbers are
+        collected when the period ends.  overlap=False evaluates in place on the training stream."""
     mf, net = st.MFbase, st.transfer
     wu, wi = mf.user_laten.weight.data, mf.item_laten.weight.data
     state = {"version": 0, "cached": None}
-
-    def note(tag, hits, ndcg):
-        if record is not None:
-            n = plan.val_rows.shape[0]
-            record.append((tag, hits / n, ndcg / n))
+    notes = []          # (tag, resolver)
 
     def evaluate(tag):
         if plan.val_rows is None:
             return
-        if state["cached"] is not None and state["cached"][0] == state["version"]:
-            note(tag, *state["cached"][1])
-            return
-        ranks = engine.eval_ranks(wu, wi, plan.val_rows)
-        res = engine.eval_metrics(ranks, hp.topK)
-        state["cached"] = (state["version"], res)
-        note(tag, *res)
+        if state["cached"] is None or state["cached"][0] != state["version"]:
+            if overlap and hasattr(engine, "eval_submit"):
+                pending = engine.eval_metrics_submit(engine.eval_submit(wu, wi, plan.val_rows), hp.topK)
+                box = {}
+
+                def res(pending=pending, box=box):
+                    if "v" not in box:
+                        box["v"] = engine.eval_result(pending)
+                    return box["v"]
+            else:
+                val = engine.eval_metrics(engine.eval_ranks(wu, wi, plan.val_rows), hp.topK)
+
+                def res(val=val):
+                    return val
+            state["cached"] = (state["version"], res)
+        notes.append((tag, state["cached"][1]))
 
     def updata():
         engine.updata(net, st.last_user, st.hat_user, st.last_item, st.hat_item, wu, wi)
@@ -142,21 +148,17 @@ def run_period(engine, st, plan, hp, record=None, overlap=True):
         st.hat_user.copy_(wu)
         st.hat_item.copy_(wi)
         updata()
-        pending = None
-        if plan.val_rows is not None and overlap and hasattr(engine, "eval_async") and plan.tr_triples[ph]:
-            pending = engine.eval_async(wu, wi, plan.val_rows, hp.topK)      # "before TR", under the first TR epoch
-        else:
-            evaluate("before TR")
+        evaluate("before TR")
         for tri in plan.tr_triples[ph]:
             tr_loss = engine.tr_stage_epoch(net, st.last_user, st.last_item, st.hat_user, st.hat_item, tri,
                                             hp.TR_batch_size, hp.TR_lr, hp.TR_l2, bce=True)
-            if pending is not None:
-                res = engine.eval_result(pending)
-                pending = None
-                state["cached"] = (state["version"], res)
-                note("before TR", *res)
             if plan.val_rows is not None:
                 updata()
                 evaluate("TR epoch")
     updata()
+    if record is not None and plan.val_rows is not None:
+        n = plan.val_rows.shape[0]
+        for tag, res in notes:
+            hits, ndcg = res()
+            record.append((tag, hits / n, ndcg / n))
     return mf_loss, tr_loss
