@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--no-val", action="store_true", help="skip the validation evaluations (not the reference default)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="evaluate in place on the training stream instead of on the side stream (single-queue runs for "
+                         "rocprofv3 --pmc, which does not survive this workload's two queues)")
     ap.add_argument("--workload", default="yelp_period", choices=["yelp_period", "bare"],
                     help="yelp_period: the headline SML retrain period (default).  bare: the a3 fused embed+loss+SGD "
                          "step alone on large synthetic tables (HBM roofline study; not the headline metric)")
@@ -106,14 +109,24 @@ def bench_bare(a, device):
     t_grad, t_seg = prof["k_bare_grad"][1] / 1e3, prof["k_seg_update_sgd"][1] / 1e3
     t_hot = prof.get("k_hot_rows", (0, 0.0))[1] / 1e3
     ach = n * a_sgd / (t_grad + t_seg + t_hot) / 1e9
+    # fabric bytes of one a3 step (one batch: gradient pass + run update + hot apply) from the committed PMC
+    # passes of this command at its profiled shape (tools/profile_round.sh); null for any other shape
+    traffic = None
+    if (a.users, a.items, a.bare_batch, a.d, a.bare_dtype) == (10000000, 1000000, 262144, 32, "f32") and a.item_zipf in (0.0, 1.0):
+        try:
+            run = json.load(open(os.path.join(REPO, "profiles", "r01b_pmc_per_launch.json")))["bare_z%d" % int(a.item_zipf)]
+            traffic = sum((2.0 * c["FETCH_SIZE"]["avg_counter_per_launch"] + c["WRITE_SIZE"]["avg_counter_per_launch"]) * 1024.0
+                          for k, c in run.items() if k.startswith(("k_bare_grad", "k_run_update", "k_hot_apply")))
+        except Exception:
+            traffic = None
     out = {"metric": "bare embed+loss+SGD step triples/s (a3), synthetic uniform users / Zipf(%g) items, d=%d %s" % (a.item_zipf, a.d, a.bare_dtype),
            "value": a.steps * n / dtm, "unit": "triples/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": 1000.0 * dtm / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": a.bare_dtype, "data": "synthetic",
            "config": {"workload": "bare: users=%d items=%d triples/epoch=%d batch=%d" % (a.users, a.items, n, a.bare_batch)},
            "roofline": {"kernel": "k_bare_grad + k_seg_update_sgd + k_hot_rows (one a3 step)", "bound": "hbm", "achieved": ach,
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                        "algorithmic_bytes_per_triple": a_sgd},
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                        "algorithmic_bytes_per_step": a_sgd * min(a.bare_batch, n), "algorithmic_bytes_per_triple": a_sgd},
            "kernels": {k: {"launches": c, "total_ms": round(m, 3), "avg_us": round(1000.0 * m / c, 2)} for k, (c, m) in prof.items()}}
     print(json.dumps(out))
 
@@ -166,14 +179,22 @@ def kernel_work(name, a, hp, U_local):
 
 
 def pmc_traffic(kernel):
-    """Fabric bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r01_final_pmc_fetch_write_per_launch.json: FETCH_SIZE and WRITE_SIZE in separate passes;
-    units KB; FETCH doubled per the gfx950 correction in MI355X_MICROARCH.md).  PMC cannot be read from
-    inside the process, so this is null whenever no committed summary covers the kernel."""
-    path = os.path.join(REPO, "profiles", "r01_final_pmc_fetch_write_per_launch.json")
+    """Fabric bytes per launch of kernel class `kernel` from the committed rocprofv3 --pmc passes of this same
+    command (profiles/r01b_pmc_per_launch.json, made by tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE in
+    separate passes; units KB; FETCH doubled per the gfx950 correction in MI355X_MICROARCH.md), averaged
+    over the class's template instances by launch count.  PMC cannot be read from inside the process, so
+    this is null whenever no committed summary covers the kernel."""
+    path = os.path.join(REPO, "profiles", "r01b_pmc_per_launch.json")
     try:
-        d = json.load(open(path)).get(kernel)
-        return (2.0 * d["FETCH_SIZE"]["avg_counter_per_launch"] + d["WRITE_SIZE"]["avg_counter_per_launch"]) * 1024.0
+        runs = json.load(open(path))["period"]
+        tot, n = 0.0, 0
+        for name, c in runs.items():
+            if not name.startswith(kernel):
+                continue
+            k = c["FETCH_SIZE"]["launches"]
+            tot += k * (2.0 * c["FETCH_SIZE"]["avg_counter_per_launch"] + c["WRITE_SIZE"]["avg_counter_per_launch"]) * 1024.0
+            n += k
+        return tot / n if n else None
     except Exception:
         return None
 
@@ -262,12 +283,12 @@ def main():
         torch.cuda.synchronize(device)
 
     for w in range(a.warmup):
-        run_period(engine, st, plans[w % len(plans)], hp)
+        run_period(engine, st, plans[w % len(plans)], hp, overlap=not a.no_overlap)
     barrier()
     quiet.__exit__()
     t0 = time.perf_counter()
     for s in range(a.steps):
-        run_period(engine, st, plans[(a.warmup + s) % len(plans)], hp)
+        run_period(engine, st, plans[(a.warmup + s) % len(plans)], hp, overlap=not a.no_overlap)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -291,7 +312,7 @@ def main():
 
     if not a.no_roofline:
         engine.profile(True)
-        run_period(engine, st, plans[0], hp)
+        run_period(engine, st, plans[0], hp, overlap=not a.no_overlap)
         torch.cuda.synchronize(device)
         prof = engine.profile_read()
         engine.profile(False)
