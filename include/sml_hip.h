@@ -181,6 +181,14 @@ int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n
                              int batch, float lr, float lam_user, float lam_item, int loss_kind,
                              float* batch_loss, int prepared_slot, void* stream);
 
+/* The same step as the reference's baselines run it (model/baseline.py:188-201 in base_train, :343-361 in
+ * run_one_stage2: fine-tune / full-retrain MF): BCE + L2 loss and torch.optim.Adam(lr, wd 0) over the DENSE
+ * tables, reproduced lazily per row exactly as in sml_mf_stage_epoch (same sml_mf_tables; last_* are not
+ * read).  Flush with sml_mf_adam_flush before the tables are read out.  fp32 tables. */
+int sml_embed_loss_adam_epoch(sml_ctx* ctx, const sml_mf_tables* t, const int64_t* triples, int64_t n,
+                              int batch, float lr, float lam_user, float lam_item, int loss_kind,
+                              int64_t* step, float* batch_loss, void* stream);
+
 /* ---- a2: MFbasemode.forward (model/MF.py:34-43) --------------------------------- */
 int sml_mf_forward(sml_ctx* ctx, const float* w_user, const float* w_item, const int64_t* user,
                    const int64_t* item, int64_t n, int norm, float* uemb, float* iemb, float* score,

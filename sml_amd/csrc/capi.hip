@@ -673,6 +673,7 @@ int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n
     for (int64_t b = 0; b < nb; ++b) {
         const int B = (int)((n - b * batch) < batch ? (n - b * batch) : batch);
         SmlBareArgs a;
+        memset(&a, 0, sizeof(a));
         a.w_user = w_user; a.w_item = w_item; a.tri = triples + b * batch * 3; a.B = B; a.dx = ctx->dx.p;
         a.loss_part = ctx->loss_part.p + b * lstride; a.kind = loss_kind; a.lam_user = lam_user; a.lam_item = lam_item;
         a.uniq = X->uniq.p + (size_t)3 * b * batch; a.lr = lr;
@@ -692,6 +693,50 @@ int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n
         if (hot) { ctx->prof.begin(PC_PAIR_LOSS, st); HIPCHK(sml_launch_hot_apply(d, dtype_bytes, u, st)); ctx->prof.end(st); }
     }
     ctx->prof.begin(PC_MISC, st); HIPCHK(sml_launch_loss_finalize(ctx->loss_part.p, (int)nb, lstride, nullptr, batch_loss, st)); ctx->prof.end(st);
+    return SML_OK;
+}
+
+int sml_embed_loss_adam_epoch(sml_ctx* ctx, const sml_mf_tables* t, const int64_t* triples, int64_t n, int batch, float lr,
+                              float lam_user, float lam_item, int loss_kind, int64_t* step, float* batch_loss, void* stream) {
+    if (!ctx || !t || !t->w_user || !t->w_item || !t->m_user || !t->v_user || !t->m_item || !t->v_item || !t->step_user ||
+        !t->step_item || !triples || !step || !batch_loss || n <= 0 || batch <= 0)
+        return fail(SML_EINVAL, "sml_embed_loss_adam_epoch", "bad argument");
+    if (loss_kind != SML_LOSS_BCE && loss_kind != SML_LOSS_BPR) return fail(SML_EINVAL, "sml_embed_loss_adam_epoch", "loss_kind");
+    if (batch > ctx->max_batch) return fail(SML_EINVAL, "sml_embed_loss_adam_epoch", "batch exceeds ctx max_batch");
+    if (n > 0x3fffffff) return fail(SML_EINVAL, "sml_embed_loss_adam_epoch", "epoch too long");
+    DevGuard g(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    const int d = ctx->d;
+    const int64_t nb = (n + batch - 1) / batch;
+    int rc;
+    if ((rc = ensure_sched(ctx, lr, *step + nb + 1))) return rc;
+    HIPCHK(ctx->dx.ensure((size_t)3 * batch * d));
+    const int lstride = (int)(((int64_t)batch * (d / 4) + 255) / 256);
+    HIPCHK(ctx->loss_part.ensure((size_t)nb * lstride));
+    ctx->prof.begin(PC_SORT, st); rc = sort_epoch(&ctx->ix[0], triples, n, batch, 0, t->n_user, t->n_item, false, st); ctx->prof.end(st);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(ctx->loss_part.p, 0, (size_t)nb * lstride * sizeof(float), st));
+    for (int64_t b = 0; b < nb; ++b) {
+        const int B = (int)((n - b * batch) < batch ? (n - b * batch) : batch);
+        const int cur = (int)(*step + 1 + b);
+        SmlBareArgs a;
+        memset(&a, 0, sizeof(a));
+        a.w_user = t->w_user; a.w_item = t->w_item; a.tri = triples + b * batch * 3; a.B = B; a.dx = ctx->dx.p;
+        a.loss_part = ctx->loss_part.p + b * lstride; a.kind = loss_kind; a.lam_user = lam_user; a.lam_item = lam_item;
+        a.m_user = t->m_user; a.v_user = t->v_user; a.m_item = t->m_item; a.v_item = t->v_item;
+        a.last_user = t->step_user; a.last_item = t->step_item; a.sched = ctx->sched.p; a.cur_step = cur;
+        ctx->prof.begin(PC_BARE_GRAD, st); HIPCHK(sml_launch_bare_grad(d, 4, a, nullptr, st)); ctx->prof.end(st);
+        SmlRunArgs u;
+        memset(&u, 0, sizeof(u));
+        u.run_u = ctx->ix[0].rec_u.p + b * batch; u.n_u = B; u.val_u = ctx->ix[0].val_u2.p;
+        u.run_i = ctx->ix[0].rec_i.p + 2 * b * batch; u.n_i = 2 * B; u.val_i = ctx->ix[0].val_i2.p;
+        u.dx = ctx->dx.p; u.dx_i = ctx->dx.p; u.w_user = t->w_user; u.w_item = t->w_item;
+        u.m_user = t->m_user; u.v_user = t->v_user; u.m_item = t->m_item; u.v_item = t->v_item;
+        u.last_user = t->step_user; u.last_item = t->step_item; u.sched = ctx->sched.p; u.cur_step = cur; u.lr = lr;
+        ctx->prof.begin(PC_SEG_ADAM, st); HIPCHK(sml_launch_run_adam(d, u, (int64_t)3 * B, st)); ctx->prof.end(st);
+    }
+    ctx->prof.begin(PC_MISC, st); HIPCHK(sml_launch_loss_finalize(ctx->loss_part.p, (int)nb, lstride, nullptr, batch_loss, st)); ctx->prof.end(st);
+    *step += nb;
     return SML_OK;
 }
 

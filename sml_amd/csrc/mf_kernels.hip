@@ -95,11 +95,20 @@ __global__ __launch_bounds__(64) void k_loss_finalize(const float* __restrict__ 
 // products, loss, per-occurrence gradient rows.  model/baseline.py:188-201 (BCE),
 // model/MF.py:139-144 without biases (BPR).
 // ------------------------------------------------------------------------------------
-template <int D, typename T>
+// LAZY (the baselines' dense-Adam form, model/baseline.py:343-361): the three rows first take the
+// zero-gradient Adam steps a dense optimiser would have applied since they were last touched (replayed
+// in registers, nothing written here), every occurrence emits its gradient row, and k_run_update<Adam>
+// finishes the step.
+template <int D, typename T, bool LAZY>
 __global__ __launch_bounds__(256) void k_bare_grad(SmlBareArgs a) {
     constexpr int VEC = RowVec<T>::VEC;
     constexpr int LPR = D / VEC;
     __shared__ float sh4[4];
+    __shared__ SmlSched swin[LAZY ? SML_SW : 1];
+    if constexpr (LAZY) {
+        sched_window_load(swin, a.sched, a.cur_step - 1, threadIdx.x);
+        __syncthreads();
+    }
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const int t = gid / LPR, sub = gid % LPR;
     float contrib = 0.0f;
@@ -110,6 +119,20 @@ __global__ __launch_bounds__(256) void k_bare_grad(SmlBareArgs a) {
         else RowVec<T>::load(reinterpret_cast<const T*>(a.w_user) + iu * D + sub * VEC, u);
         RowVec<T>::load(reinterpret_cast<const T*>(a.w_item) + ii * D + sub * VEC, it);
         RowVec<T>::load(reinterpret_cast<const T*>(a.w_item) + in * D + sub * VEC, ng);
+        if constexpr (LAZY) {
+            static_assert(!LAZY || VEC == 4, "lazy Adam runs on fp32 tables");
+            float m[3][4], v[3][4];
+            RowVec<float>::load(a.m_user + iu * D + sub * 4, m[0]); RowVec<float>::load(a.v_user + iu * D + sub * 4, v[0]);
+            RowVec<float>::load(a.m_item + ii * D + sub * 4, m[1]); RowVec<float>::load(a.v_item + ii * D + sub * 4, v[1]);
+            RowVec<float>::load(a.m_item + in * D + sub * 4, m[2]); RowVec<float>::load(a.v_item + in * D + sub * 4, v[2]);
+            const int fu = a.last_user[iu], fi = a.last_item[ii], fn = a.last_item[in];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                adam_replay_w(u[k], m[0][k], v[0][k], fu, a.cur_step - 1, a.sched, swin, a.cur_step - 1);
+                adam_replay_w(it[k], m[1][k], v[1][k], fi, a.cur_step - 1, a.sched, swin, a.cur_step - 1);
+                adam_replay_w(ng[k], m[2][k], v[2][k], fn, a.cur_step - 1, a.sched, swin, a.cur_step - 1);
+            }
+        }
         float sp = 0.f, sn = 0.f, sq_u = 0.f, sq_i = 0.f;
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
@@ -129,8 +152,8 @@ __global__ __launch_bounds__(256) void k_bare_grad(SmlBareArgs a) {
             gy[e] = dsp * u[e] + a.lam_item * it[e];
             gz[e] = dsn * u[e] + a.lam_item * ng[e];
         }
-        const bool one_u = a.uniq != nullptr && a.uniq[t], one_i = a.uniq != nullptr && a.uniq[a.B + t],
-                   one_n = a.uniq != nullptr && a.uniq[2 * a.B + t];
+        const bool one_u = !LAZY && a.uniq != nullptr && a.uniq[t], one_i = !LAZY && a.uniq != nullptr && a.uniq[a.B + t],
+                   one_n = !LAZY && a.uniq != nullptr && a.uniq[2 * a.B + t];
         auto emit = [&](bool in_place, T* wrow, const float (&row)[VEC], const float (&g)[VEC], float* dxrow, bool nt) {
             if (in_place) {
                 float nw[VEC];
@@ -815,10 +838,13 @@ hipError_t sml_launch_bare_grad(int d, int dtype_bytes, const SmlBareArgs& a, in
     const int lpr = d * dtype_bytes / 16;
     const int nb = (int)(((int64_t)a.B * lpr + 255) / 256);
     if (n_blocks) *n_blocks = nb;
-    if (dtype_bytes == 4) {
-        SML_DISPATCH_D(d, k_bare_grad<DD, float><<<dim3(nb), dim3(256), 0, st>>>(a));
+    if (a.sched != nullptr) {            // lazy dense-Adam form (fp32 tables)
+        if (dtype_bytes != 4) return hipErrorInvalidValue;
+        SML_DISPATCH_D(d, k_bare_grad<DD, float, true><<<dim3(nb), dim3(256), 0, st>>>(a));
+    } else if (dtype_bytes == 4) {
+        SML_DISPATCH_D(d, k_bare_grad<DD, float, false><<<dim3(nb), dim3(256), 0, st>>>(a));
     } else if (dtype_bytes == 2) {
-        SML_DISPATCH_D(d, k_bare_grad<DD, __half><<<dim3(nb), dim3(256), 0, st>>>(a));
+        SML_DISPATCH_D(d, k_bare_grad<DD, __half, false><<<dim3(nb), dim3(256), 0, st>>>(a));
     } else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -148,6 +148,11 @@ struct SmlBareArgs {
     float* dx;               // [3B, d] per-occurrence gradients (fp32)
     float* loss_part;
     int kind; float lam_user, lam_item;
+    // lazy dense-Adam form (sched != null; fp32 tables): the rows' pending zero-gradient steps are replayed
+    // before use; uniq is ignored (every occurrence emits its gradient row)
+    const float* m_user; const float* v_user; const float* m_item; const float* v_item;
+    const int32_t* last_user; const int32_t* last_item;
+    const SmlSched* sched; int cur_step;
 };
 hipError_t sml_launch_bare_grad(int d, int dtype_bytes, const SmlBareArgs& a, int* n_blocks, hipStream_t st);
 hipError_t sml_launch_mf_forward(int d, const float* wu, const float* wi, const int64_t* user, const int64_t* item,

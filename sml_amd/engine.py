@@ -277,6 +277,24 @@ class HipEngine(object):
               "sml_embed_loss_sgd_epoch")
         return losses
 
+    def bare_adam_epoch(self, mfbase, triples, batch_size, lr, lam_user, lam_item, bce=True):
+        """One epoch of the baselines' bare-MF step (reference model/baseline.py:343-361): BCE (or BPR) + L2 with
+        the dense-Adam semantics of torch.optim.Adam over MFbase, replayed lazily per row.  Shares the MF
+        optimiser state (m, v, step) with mf_stage_epoch; call mf_flush before reading the tables."""
+        tri = self._dev(triples, torch.int64)
+        n = tri.shape[0]
+        nb = (n + batch_size - 1) // batch_size
+        t = self._mf_tables(mfbase, None, None)
+        self._mf_lr = float(lr)
+        losses = torch.empty(nb, device=self.device, dtype=torch.float32)
+        step = ctypes.c_int64(self.mf_step)
+        check(self.lib.sml_embed_loss_adam_epoch(self._ctx, ctypes.byref(t), _ptr(tri), n, int(batch_size), float(lr),
+                                                 float(lam_user), float(lam_item),
+                                                 _lib.LOSS_BCE if bce else _lib.LOSS_BPR, ctypes.byref(step),
+                                                 _ptr(losses), self._stream()), "sml_embed_loss_adam_epoch")
+        self.mf_step = step.value
+        return losses
+
     # ------------------------------------------------------------------ a2
     def mf_forward(self, w_user, w_item, user, item, norm=False):
         wu, wi = self._table(w_user), self._table(w_item)

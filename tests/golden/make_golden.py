@@ -16,7 +16,8 @@ Harness-side shims (the reference is untouched):
 Fixtures:  G1 transfer forward, G2 run_MF loss and
 gradients, G3 MF-stage steps, G4 TR-stage steps, G5 updata, G6 evaluation,
 G7 end-to-end main_yelp.py log on a tiny 40-period dataset, G8 batch supply,
-G9 parameter initialisation.
+G9 parameter initialisation, G10 the baselines' bare-MF fine-tune loop (model/baseline.py
+SPMF.run_one_stage2: BCE + L2 + dense Adam on recorded batches).
 
 usage: python tests/golden/make_golden.py [--ref /root/reference]
 """
@@ -64,9 +65,25 @@ def install_shims(ref):
         return _orig_load(f, *a, **k)
 
     torch.load = _load
+    # The build ships drop-in packages with the SAME names (model/, data/, evalution/ at the repo root, with
+    # __init__.py -- a regular package beats the reference's __init__-less directories wherever both are on
+    # sys.path).  So: only the reference is on the path while its modules are imported, every module's
+    # origin is checked, and the repo root is appended afterwards, for sml_amd.synth alone.
+    for name in [m for m in sys.modules if m.split(".")[0] in ("model", "data", "evalution")]:
+        del sys.modules[name]
+    sys.path[:] = [p for p in sys.path if os.path.realpath(p or os.getcwd()) != os.path.realpath(REPO)]
     sys.path.insert(0, ref)
-    sys.path.insert(1, REPO)  # for sml_amd.synth (the build's own generator)
+    if not hasattr(np, "long"):
+        np.long = np.int64              # model/baseline.py predates numpy 2
     import model.transfer as T
+    import model.MF, model.conv_transfer, model.baseline            # noqa: F401,E401
+    import data.dataset2, data.dataset, evalution.evaluation2       # noqa: F401,E401
+    root = os.path.realpath(ref) + os.sep
+    for name in ("model.transfer", "model.MF", "model.conv_transfer", "model.baseline", "data.dataset2", "data.dataset",
+                 "evalution.evaluation2"):
+        origin = os.path.realpath(sys.modules[name].__file__)
+        assert origin.startswith(root), "%s was imported from %s, not from the reference" % (name, origin)
+    sys.path.append(REPO)  # for sml_amd.synth (the build's own generator)
 
     _orig_tm = T.test_model
 
@@ -82,8 +99,11 @@ def sd_np(module, prefix=""):
     return {prefix + k: v.detach().cpu().numpy().copy() for k, v in module.state_dict().items()}
 
 
+OUT_DIR = [HERE]
+
+
 def save(name, **arrs):
-    path = os.path.join(HERE, name)
+    path = os.path.join(OUT_DIR[0], name)
     np.savez_compressed(path, **arrs)
     print("wrote", name, "%.1f KB" % (os.path.getsize(path) / 1024.0))
 
@@ -403,15 +423,94 @@ def gen_g7(T, ref, tmp):
     out["dataset_zipf"] = np.array([0.8, 0.8])
     save("g7_end_to_end.npz", **out)
     # a reference-pickled whole-module checkpoint: the on-disk contract for --pre_model
-    shutil.copy(ck, os.path.join(HERE, "ref_BCE_init_tiny.pkl"))
+    shutil.copy(ck, os.path.join(OUT_DIR[0], "ref_BCE_init_tiny.pkl"))
     print("log lines:", len(log.splitlines()))
+
+
+# --------------------------------------------------------------------------- G10 baseline bare-MF loop
+def gen_g10(ref):
+    """Drive the reference's SPMF.run_one_stage2 (model/baseline.py:306-386: the fine-tune / full-retrain
+    baseline = bare MF with BCE + L2 and torch.optim.Adam) on a tiny stream.  Harness shims only: np.long
+    (removed from numpy 2), and the DataLoader the method builds is forced to num_workers=0 and its batches
+    are recorded -- those recorded (user, item, neg) batches are the fixture's inputs."""
+    import model.baseline as B
+    assert os.path.realpath(B.__file__).startswith(os.path.realpath(ref))
+
+    U, I, d, n_train, n_test, neg = 80, 60, 32, 700, 90, 49
+    rng = np.random.RandomState(31)
+    train = np.stack([rng.randint(0, U, n_train), rng.randint(0, I, n_train)], 1).astype(np.int64)
+    test = np.zeros((n_test, 2 + neg), dtype=np.int64)
+    for r in range(n_test):
+        test[r, 0] = rng.randint(0, U)
+        test[r, 1] = rng.randint(0, I)
+        test[r, 2:] = rng.choice(np.setdiff1d(np.arange(I), [test[r, 1]]), size=neg, replace=False)
+
+    class Stream(object):                      # the surface of baseline.StreamingData that SPMF touches
+        test_new_user = np.zeros(0, dtype=np.int64)
+        test_new_item = np.zeros(0, dtype=np.int64)
+
+        def get_next(self, stage_id, types="not_only_new"):
+            return train, test
+
+    args = types.SimpleNamespace(lr=0.01, pool_size=0, neg_num=1, batch_size=128, l2_u=1e-5, l2_i=1e-5,
+                                 epochs=3, pool_init_type=0)
+    recorded = []
+    real_loader = torch.utils.data.DataLoader
+
+    class RecLoader(object):
+        def __init__(self, ds, batch_size=1, shuffle=False, num_workers=0, **k):
+            self.inner = real_loader(ds, batch_size=batch_size, shuffle=shuffle, num_workers=0)
+
+        def __iter__(self):
+            for (u, i, j) in self.inner:
+                recorded.append(np.stack([np.asarray(u), np.asarray(i), np.asarray(j)], 1).astype(np.int64))
+                yield (u, i, j)
+
+    torch.manual_seed(41)
+    np.random.seed(42)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        sp = B.SPMF(args, Stream(), U, I, d)
+        with torch.no_grad():                  # pretrained-like scale (scores not saturated)
+            sp.MFbase.user_laten.weight.mul_(0.3)
+            sp.MFbase.item_laten.weight.mul_(0.3)
+        init = {k: v.detach().numpy().copy() for k, v in sp.MFbase.state_dict().items()}
+        torch.utils.data.DataLoader = RecLoader
+        try:
+            ok = sp.run_one_stage2(1, read_data_type="only_new")
+        finally:
+            torch.utils.data.DataLoader = real_loader
+    assert ok
+    log = buf.getvalue()
+    losses = [float(l.split("loss:")[1]) for l in log.splitlines() if l.startswith("epoch:")]
+    nb = -(-n_train // args.batch_size)
+    assert len(recorded) == args.epochs * nb and len(losses) == args.epochs, (len(recorded), losses)
+    out = {"init." + k: v for k, v in init.items()}
+    for e in range(args.epochs):
+        out["triples_%d" % e] = np.concatenate(recorded[e * nb:(e + 1) * nb], 0)
+    out["epoch_loss"] = np.array(losses, dtype=np.float64)          # as printed: 4 decimals
+    st = sp.optimizer.state
+    Wu, Wi = sp.MFbase.user_laten.weight, sp.MFbase.item_laten.weight
+    out["final.user"], out["final.item"] = Wu.detach().numpy().copy(), Wi.detach().numpy().copy()
+    out["adam.m_user"], out["adam.v_user"] = st[Wu]["exp_avg"].numpy().copy(), st[Wu]["exp_avg_sq"].numpy().copy()
+    out["adam.m_item"], out["adam.v_item"] = st[Wi]["exp_avg"].numpy().copy(), st[Wi]["exp_avg_sq"].numpy().copy()
+    out["adam.step"] = np.array(int(st[Wu]["step"]))
+    out["test_rows"] = test
+    out["recall_5_10_20"] = np.asarray(sp.recall[-1], dtype=np.float64)
+    out["ndcg_5_10_20"] = np.asarray(sp.ndcg[-1], dtype=np.float64)
+    out["hyper"] = np.array([args.lr, args.l2_u, args.l2_i, args.batch_size, args.epochs], dtype=np.float64)
+    save("g10_baseline_adam.npz", **out)
+    print("G10 losses:", losses, "recall:", out["recall_5_10_20"])
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--only", default="")
+    ap.add_argument("--out", default=HERE, help="where to write the fixtures (default: next to this script)")
     a = ap.parse_args()
+    OUT_DIR[0] = a.out
+    os.makedirs(a.out, exist_ok=True)
     T = install_shims(a.ref)
     tmp = tempfile.mkdtemp(prefix="sml_golden_")
     try:
@@ -426,6 +525,8 @@ def main():
             gen_g8(T)
         if not only or "g7" in only:
             gen_g7(T, a.ref, tmp)
+        if not only or "g10" in only:
+            gen_g10(a.ref)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

@@ -563,3 +563,75 @@ def test_blocked_eval_equals_plain_eval(d, neg, I):
     blk = eng.eval_ranks(wu, wi, rows, blocked=True)
     assert torch.equal(plain, blk)
     assert torch.equal(blk, eng.eval_ranks(wu, wi, rows, blocked=True))       # cached buckets, repeatable
+
+
+# ----------------------------------------------------------------------------- G10 / bare Adam (baselines' loop)
+def test_g10_bare_adam_epochs_match_reference_and_oracle():
+    """The baselines' bare-MF fine-tune loop (reference model/baseline.py SPMF.run_one_stage2, recorded as G10):
+    HIP lazy dense-Adam path vs the reference's printed losses, final tables, Adam state and final test."""
+    g = golden("g10_baseline_adam.npz")
+    lr, l2u, l2i, B, epochs = (float(x) for x in g["hyper"])
+    B, epochs = int(B), int(epochs)
+    U, d = g["init.user_laten.weight"].shape
+    I = g["init.item_laten.weight"].shape[0]
+    mf = make_mf(U, I, d, g["init.user_laten.weight"], g["init.item_laten.weight"], device=DEV)
+    eng = engine(d)
+    for e in range(epochs):
+        losses = eng.bare_adam_epoch(mf, T(g["triples_%d" % e], DEV), B, lr, l2u, l2i, bce=True).cpu().numpy()
+        assert abs(float(np.mean(losses.astype(np.float64))) - float(g["epoch_loss"][e])) < 1e-4
+    eng.mf_flush(mf)
+    steps = int(g["adam.step"])
+    assert eng.mf_step == steps
+    adam_close(mf.user_laten.weight.detach().cpu().numpy(), g["final.user"], lr, steps)
+    adam_close(mf.item_laten.weight.detach().cpu().numpy(), g["final.item"], lr, steps)
+    close(eng.mf_state["m_u"].cpu().numpy(), g["adam.m_user"], 2e-4)
+    close(eng.mf_state["v_i"].cpu().numpy(), g["adam.v_item"], 2e-4)
+    rows = T(g["test_rows"], DEV)
+    ranks = eng.eval_ranks(mf.user_laten.weight.data, mf.item_laten.weight.data, rows)
+    n = rows.shape[0]
+    for k, topk in enumerate((5, 10, 20)):
+        hits, ndcg = eng.eval_metrics(ranks, topk)
+        assert abs(hits / n - g["recall_5_10_20"][k]) <= 1.0 / n + 1e-9      # one rank flip at most
+        assert abs(ndcg / n - g["ndcg_5_10_20"][k]) <= 1.0 / n
+
+
+@pytest.mark.parametrize("d,B", [(32, 1024), (64, 300), (128, 64)])
+def test_bare_adam_epoch_vs_oracle_with_duplicates_and_untouched_rows(d, B):
+    """Zipf-like duplicates inside batches, rows never touched, a second epoch on the same optimiser state:
+    lazy replay in the gradient pass and in the row update equals dense Adam."""
+    torch.manual_seed(3 * d + B)
+    rng = np.random.RandomState(d + B)
+    U, I, n = 500, 300, 3 * B + 17
+    u = np.minimum((rng.pareto(1.2, n) * 3).astype(np.int64), U - 1)
+    i = np.minimum((rng.pareto(1.0, n) * 2).astype(np.int64), I - 1)
+    j = rng.randint(0, I, n)
+    tri = np.stack([u, i, j], 1)
+    mf_cpu = make_mf(U, I, d)
+    with torch.no_grad():
+        mf_cpu.user_laten.weight.mul_(0.3)
+        mf_cpu.item_laten.weight.mul_(0.3)
+    mf = make_mf(U, I, d, mf_cpu.user_laten.weight.detach().numpy(), mf_cpu.item_laten.weight.detach().numpy(), device=DEV)
+    eng, oeng = engine(d), O.OracleEngine(d)
+    for e in range(2):
+        got = eng.bare_adam_epoch(mf, T(tri, DEV), B, 0.01, 1e-5, 2e-5, bce=(e == 0)).cpu().numpy()
+        want = oeng.bare_adam_epoch(mf_cpu, torch.from_numpy(tri), B, 0.01, 1e-5, 2e-5, bce=(e == 0))
+        np.testing.assert_allclose(got, want, rtol=1e-4)
+    eng.mf_flush(mf)
+    steps = oeng.mf_step
+    adam_close(mf.user_laten.weight.detach().cpu().numpy(), mf_cpu.user_laten.weight.detach().numpy(), 0.01, steps)
+    adam_close(mf.item_laten.weight.detach().cpu().numpy(), mf_cpu.item_laten.weight.detach().numpy(), 0.01, steps)
+
+
+def test_g10_baseline_spmf_finetune_stage_on_hip():
+    """model.baseline.SPMF.run_one_stage2 end to end on the HIP engine: same batches as the reference drew,
+    its printed losses, its final recall/ndcg (a rank flip moves recall by 1/90)."""
+    from test_host_logic import run_g10_finetune
+    g, sp, log, seen = run_g10_finetune(engine(32), DEV)
+    for e in range(3):
+        assert np.array_equal(seen[e], g["triples_%d" % e])
+    losses = [float(l.split("loss:")[1]) for l in log.splitlines() if l.startswith("epoch:")]
+    np.testing.assert_allclose(losses, g["epoch_loss"], atol=2.01e-4)
+    n = g["test_rows"].shape[0]
+    assert np.all(np.abs(sp.recall[-1] - g["recall_5_10_20"]) <= 1.0 / n + 1e-9)
+    assert np.all(np.abs(sp.ndcg[-1] - g["ndcg_5_10_20"]) <= 1.0 / n)
+    adam_close(sp.MFbase.user_laten.weight.detach().cpu().numpy(), g["final.user"], 0.01, int(g["adam.step"]))

@@ -230,3 +230,71 @@ def test_g7_driver_control_flow_on_cpu(tmp_path, monkeypatch):
     got, want = run_g7(tmp_path, monkeypatch)
     # identical data and RNG tape: the first three periods print identically
     check_g7(got, want, exact_lines=90)
+
+
+def _g10_stream(g):
+    """The tiny stream G10 was recorded on (tests/golden/make_golden.py: gen_g10)."""
+    U, I, n_train, n_test, neg = 80, 60, 700, 90, 49
+    rng = np.random.RandomState(31)
+    train = np.stack([rng.randint(0, U, n_train), rng.randint(0, I, n_train)], 1).astype(np.int64)
+    test = np.zeros((n_test, 2 + neg), dtype=np.int64)
+    for r in range(n_test):
+        test[r, 0] = rng.randint(0, U)
+        test[r, 1] = rng.randint(0, I)
+        test[r, 2:] = rng.choice(np.setdiff1d(np.arange(I), [test[r, 1]]), size=neg, replace=False)
+    assert np.array_equal(test, g["test_rows"])
+
+    class Stream(object):
+        test_new_user = np.zeros(0, dtype=np.int64)
+        test_new_item = np.zeros(0, dtype=np.int64)
+
+        def get_next(self, stage_id, types="not_only_new"):
+            return train, test
+    return Stream(), U, I
+
+
+def run_g10_finetune(engine, device):
+    """model.baseline.SPMF.run_one_stage2 under the seeds G10 was recorded with; returns (spmf, log, batches)."""
+    import contextlib
+    import io
+    import types
+    from model.baseline import SPMF
+    g = golden("g10_baseline_adam.npz")
+    stream, U, I = _g10_stream(g)
+    args = types.SimpleNamespace(lr=0.01, pool_size=0, neg_num=1, batch_size=128, l2_u=1e-5, l2_i=1e-5, epochs=3,
+                                 pool_init_type=0)
+    seen = []
+    real = engine.bare_adam_epoch
+
+    def spy(mf, triples, *a, **k):
+        seen.append(np.asarray(triples).copy())
+        return real(mf, triples, *a, **k)
+    engine.bare_adam_epoch = spy
+    torch.manual_seed(41)
+    np.random.seed(42)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        sp = SPMF(args, stream, U, I, 32, device=device, engine=engine)
+        with torch.no_grad():
+            sp.MFbase.user_laten.weight.mul_(0.3)
+            sp.MFbase.item_laten.weight.mul_(0.3)
+        assert sp.run_one_stage2(1, read_data_type="only_new")
+    return g, sp, buf.getvalue(), seen
+
+
+def test_baseline_finetune_loop_replays_reference_batches_and_log():
+    """G10 through the product's model.baseline.SPMF with the oracle injected as the engine: the batches
+    (DataLoader shuffle + per-item negative sampling streams), the printed epoch losses and the final
+    recall/ndcg are the reference's."""
+    from _cpu_engine import CpuEngine
+    eng = CpuEngine(d=32)
+    eng.mf_forward = lambda wu, wi, u, i, norm=False: O.mf_forward(wu, wi, u, i, norm)
+    g, sp, log, seen = run_g10_finetune(eng, "cpu")
+    assert len(seen) == 3
+    for e in range(3):
+        assert np.array_equal(seen[e], g["triples_%d" % e])
+    losses = [float(l.split("loss:")[1]) for l in log.splitlines() if l.startswith("epoch:")]
+    np.testing.assert_allclose(losses, g["epoch_loss"], atol=1.01e-4)
+    np.testing.assert_allclose(sp.recall[-1], g["recall_5_10_20"], atol=1e-9)
+    np.testing.assert_allclose(sp.ndcg[-1], g["ndcg_5_10_20"], atol=1e-5)
+    assert "before train test---" in log and "FInal test---" in log and "max result " in log

@@ -161,3 +161,33 @@ def test_bare_step_matches_autograd_sgd():
         np.testing.assert_allclose(loss, float(l), rtol=1e-6)
         np.testing.assert_allclose(a.numpy(), pu.detach().numpy(), rtol=1e-6, atol=1e-7)
         np.testing.assert_allclose(b.numpy(), pi.detach().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_g10_baseline_bare_adam_loop():
+    """G10: the baselines' bare-MF loop (reference model/baseline.py SPMF.run_one_stage2 on its own recorded
+    batches): per-epoch losses as printed, final tables, Adam state, and the final test's recall/ndcg."""
+    g = golden("g10_baseline_adam.npz")
+    lr, l2u, l2i, B, epochs = (float(x) for x in g["hyper"])
+    B, epochs = int(B), int(epochs)
+    from sml_amd.mf import MFbasemode
+    U, d = g["init.user_laten.weight"].shape
+    I = g["init.item_laten.weight"].shape[0]
+    mf = MFbasemode(U, I, d)
+    mf.load_state_dict({k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("init.")})
+    eng = O.OracleEngine(d)
+    for e in range(epochs):
+        losses = eng.bare_adam_epoch(mf, torch.from_numpy(g["triples_%d" % e]), B, lr, l2u, l2i, bce=True)
+        # reference prints loss_all / n_batches with 4 decimals (model/baseline.py:363-364)
+        assert abs(float(np.mean(losses)) - float(g["epoch_loss"][e])) < 6e-5
+    assert eng.mf_step == int(g["adam.step"])
+    np.testing.assert_allclose(mf.user_laten.weight.detach().numpy(), g["final.user"], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(mf.item_laten.weight.detach().numpy(), g["final.item"], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(eng.mf_state[0].m.numpy(), g["adam.m_user"], rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(eng.mf_state[1].v.numpy(), g["adam.v_item"], rtol=2e-4, atol=1e-9)
+    rows = torch.from_numpy(g["test_rows"])
+    ranks = O.eval_ranks(mf.user_laten.weight.detach(), mf.item_laten.weight.detach(), rows)
+    n = rows.shape[0]
+    for k, topk in enumerate((5, 10, 20)):
+        hits, ndcg = O.eval_metrics(ranks, topk)
+        assert abs(hits / n - g["recall_5_10_20"][k]) < 1e-9
+        assert abs(ndcg / n - g["ndcg_5_10_20"][k]) < 1e-5
