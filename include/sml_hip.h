@@ -44,6 +44,7 @@ extern "C" {
 #define SML_LOSS_BCE 0
 #define SML_LOSS_BPR 1
 #define SML_LOSS_BPR_NORM 2   /* BPR with score / ||u'|| (norm=True, :130-132) */
+#define SML_LOSS_BPR_UNIT 3   /* ConvTransfer.run_MF (:71-85): BPR over u' / ||u'||.detach() */
 
 typedef struct sml_ctx sml_ctx;
 
@@ -54,6 +55,13 @@ int sml_version(void);
 /* Scratch for batches of up to max_batch triples at width d on `device`. */
 int sml_ctx_create(sml_ctx** out, int device, int d, int max_batch);
 int sml_ctx_destroy(sml_ctx* ctx);
+/* Which of the reference's two convolutional transfers the following calls run
+ * (model/transfer.py:377-382, --transfer_type):
+ *   0  ConvTransfer_com (conv_com, the default; model/conv_transfer.py:87-135)
+ *   1  ConvTransfer     (conv; :52-85): conv1 kernel (2,1) over (x_t, x_hat) -- theta keeps the [10][3]
+ *      conv1 block with a zero third column -- no x_com row, user-net output divided by its detached norm
+ *      (sml_transfer_forward with net 0 returns the normalised rows), loss SML_LOSS_BPR_UNIT. */
+int sml_ctx_set_variant(sml_ctx* ctx, int variant);
 
 /* ---- theta layout ------------------------------------------------------------- */
 /* Floats in one net's flat block / offset of tensor `which` (0..7 in state_dict

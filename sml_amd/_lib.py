@@ -20,7 +20,7 @@ c_void = ctypes.c_void_p
 GRAD_HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64)
 MF_HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64)
 
-LOSS_BCE, LOSS_BPR, LOSS_BPR_NORM = 0, 1, 2
+LOSS_BCE, LOSS_BPR, LOSS_BPR_NORM, LOSS_BPR_UNIT = 0, 1, 2, 3
 
 
 class MFTables(ctypes.Structure):
@@ -44,6 +44,7 @@ SIGNATURES = {
     "sml_last_error": (ctypes.c_char_p, []),
     "sml_version": (ctypes.c_int, []),
     "sml_ctx_create": (ctypes.c_int, [ctypes.POINTER(c_void), ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "sml_ctx_set_variant": (ctypes.c_int, [c_void, ctypes.c_int]),
     "sml_ctx_destroy": (ctypes.c_int, [c_void]),
     "sml_theta_net_size": (ctypes.c_int64, [ctypes.c_int]),
     "sml_theta_offset": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int]),

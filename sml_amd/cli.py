@@ -30,7 +30,7 @@ _COMMON = [
     ("--TR_sample_type", dict(default="alone", help='negatives of the transfer step: all or alone')),
     ("--TR_with_MF_bias", dict(type=bool, default=False, help='feed the MF bias to the transfer net')),
     ("--TR_stop_", dict(type=bool, default=False, help='freeze the transfer net during the test periods')),
-    ("--transfer_type", dict(default="conv_com", help='transfer architecture (conv_com)')),
+    ("--transfer_type", dict(default="conv_com", help='transfer architecture: conv_com (the paper\'s) or conv')),
     ("--seed", dict(type=int, default=2000, help='random seed')),
     ("--numworkers", dict(type=int, default=4, help='accepted for compatibility; batches are built in-process')),
     ("--cuda", dict(type=int, default=0, help='which GPU')),

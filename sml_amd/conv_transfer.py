@@ -83,6 +83,33 @@ class ConvTransfer_com(nn.Module):
         return -torch.sum(torch.nn.functional.logsigmoid(score))
 
 
+class ConvTransfer(ConvTransfer_com):
+    """The reference's first convolutional transfer (model/conv_transfer.py:52-85; `--transfer_type conv`):
+    nets with a (2,1) first kernel over the stack (x_t, x_hat) -- no x_com row -- the USER output divided by
+    its detached norm, and a BPR sum loss.  Same engine, same kernels: the x_com row is fed as zeros against
+    a zero third kernel column (whose gradient is then exactly zero), the normalisation sits in the pair-loss
+    stage of the backward kernel and in the epilogue of the table-sized forward."""
+
+    def __init__(self, in_dim, out_dim):
+        nn.Module.__init__(self)
+        if in_dim != out_dim:
+            raise ValueError("ConvTransfer: in_dim must equal out_dim (the reference always passes the same)")
+        self.user_transfer = one_transfer(in_dim, out_dim, kernel=2)
+        self.item_transfer = one_transfer(in_dim, out_dim, kernel=2)
+        self.dim = in_dim
+
+    def run_MF(self, user_weight_last, user_weight_hat, item_weight_last, item_weight_hat, negitem_weight_last,
+               negitem_weight_hat, norm=False):
+        """BPR loss value of one batch (model/conv_transfer.py:71-85); no graph."""
+        un = self.forward(user_weight_last, user_weight_hat, "user")        # already unit norm
+        im = self.forward(item_weight_last, item_weight_hat, "item")
+        nn_ = self.forward(negitem_weight_last, negitem_weight_hat, "item")
+        score = (un * im).sum(-1) - (un * nn_).sum(-1)
+        if norm:
+            score = score / (un ** 2).sum(-1).sqrt()
+        return -torch.sum(torch.nn.functional.logsigmoid(score))
+
+
 def _out_of_scope(name):
     class _Stub(nn.Module):
         def __init__(self, *a, **k):
@@ -93,7 +120,6 @@ def _out_of_scope(name):
     return _Stub
 
 
-ConvTransfer = _out_of_scope("ConvTransfer")
 ConvTransfer_com2 = _out_of_scope("ConvTransfer_com2")
 ConvTransfer_com3 = _out_of_scope("ConvTransfer_com3")
 one_transfer_com = _out_of_scope("one_transfer_com")

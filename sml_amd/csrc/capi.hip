@@ -144,6 +144,7 @@ struct IndexSet {
 
 struct sml_ctx {
     int device = 0, d = 32, max_batch = 0;
+    int variant = 0;         // 0: ConvTransfer_com, 1: ConvTransfer (sml_ctx_set_variant)
     IndexSet ix[2];
     // transfer-net workspaces, 3*B slots each
     Buf<float> out, dout, dx, xin, z1, a1, dz1;
@@ -384,6 +385,12 @@ int sml_ctx_create(sml_ctx** out, int device, int d, int max_batch) {
     return SML_OK;
 }
 
+int sml_ctx_set_variant(sml_ctx* ctx, int variant) {
+    if (!ctx || (variant != 0 && variant != 1)) return fail(SML_EINVAL, "sml_ctx_set_variant", "variant must be 0 or 1");
+    ctx->variant = variant;
+    return SML_OK;
+}
+
 int sml_ctx_destroy(sml_ctx* ctx) {
     if (!ctx) return SML_OK;
     (void)sml_comm_destroy(ctx);
@@ -416,6 +423,7 @@ int sml_transfer_forward(sml_ctx* ctx, const float* theta, int net, const float*
     s.theta = theta + (int64_t)net * sml_net_size(ctx->d);
     s.pk = ctx->pk.p + (int64_t)net * sml_pk_size(ctx->d);
     s.xt_tab = x_t; s.xh_tab = x_hat; s.n_rows = (int)n_rows; s.out = out;
+    a.k2 = ctx->variant == 1; a.unit_rows = (ctx->variant == 1 && net == 0);
     const int mt = n_rows > 8192 ? 2 : 1;     // table-sized calls: 32 rows per workgroup halve the weight traffic
     a.tiles0 = wg_tiles((int)n_rows, mt);
     a.seg[1] = s; a.seg[1].n_rows = 0;
@@ -430,7 +438,8 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
         return fail(SML_EINVAL, "sml_mf_stage_epoch", "bad argument");
     if (batch > ctx->max_batch) return fail(SML_EINVAL, "sml_mf_stage_epoch", "batch exceeds ctx max_batch");
     if (n > 0x3fffffff) return fail(SML_EINVAL, "sml_mf_stage_epoch", "epoch too long");
-    if (loss_kind < 0 || loss_kind > 2) return fail(SML_EINVAL, "sml_mf_stage_epoch", "loss_kind");
+    if (loss_kind < 0 || loss_kind > 3 || ((loss_kind == SML_LOSS_BPR_UNIT) != (ctx->variant == 1)))
+        return fail(SML_EINVAL, "sml_mf_stage_epoch", "loss_kind (SML_LOSS_BPR_UNIT goes with variant 1, and only it)");
     if (xchg && (xchg->world < 1 || !xchg->key_items || !xchg->val_items || !xchg->dx_local || !xchg->dx_items_all))
         return fail(SML_EINVAL, "sml_mf_stage_epoch", "incomplete exchange descriptor");
     if (xchg && !xchg->hook && (!ctx->comm || ctx->comm_world != xchg->world))
@@ -475,7 +484,7 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
             sg.out = ctx->out.p + slot0 * d; sg.z1 = ctx->z1.p + slot0 * SML_HID; sg.xin = ctx->xin.p + slot0 * 3 * d;
             sg.a1 = nullptr;
         }
-        f.tiles0 = wg_tiles(B, 1); f.cur_step = cur; f.sched = ctx->sched.p; f.out_pstride = out_pstride;
+        f.tiles0 = wg_tiles(B, 1); f.cur_step = cur; f.sched = ctx->sched.p; f.out_pstride = out_pstride; f.k2 = ctx->variant == 1;
         const int tiles = f.tiles0 + wg_tiles(2 * B, 1);
         ctx->prof.begin(PC_FWD, st); HIPCHK(sml_launch_fwd(d, 1, fns, f, tiles, st)); ctx->prof.end(st);
         SmlBwdArgs w;
@@ -538,7 +547,8 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
     if (!ctx || !theta || !adam_m || !adam_v || !t || !triples || !step || !batch_loss || n <= 0 || batch <= 0)
         return fail(SML_EINVAL, "sml_tr_stage_epoch", "bad argument");
     if (batch > ctx->max_batch) return fail(SML_EINVAL, "sml_tr_stage_epoch", "batch exceeds ctx max_batch");
-    if (loss_kind < 0 || loss_kind > 2) return fail(SML_EINVAL, "sml_tr_stage_epoch", "loss_kind");
+    if (loss_kind < 0 || loss_kind > 3 || ((loss_kind == SML_LOSS_BPR_UNIT) != (ctx->variant == 1)))
+        return fail(SML_EINVAL, "sml_tr_stage_epoch", "loss_kind (SML_LOSS_BPR_UNIT goes with variant 1, and only it)");
     DevGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     const int d = ctx->d;
@@ -571,7 +581,7 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
             sg.out = ctx->out.p + slot0 * d; sg.z1 = ctx->z1.p + slot0 * SML_HID; sg.xin = ctx->xin.p + slot0 * 3 * d;
             sg.a1 = ctx->a1.p + slot0 * SML_C2 * d;
         }
-        f.tiles0 = wg_tiles(B, 1); f.cur_step = 0; f.sched = nullptr; f.out_pstride = out_pstride;
+        f.tiles0 = wg_tiles(B, 1); f.cur_step = 0; f.sched = nullptr; f.out_pstride = out_pstride; f.k2 = ctx->variant == 1;
         const int tiles = f.tiles0 + wg_tiles(2 * B, 1);
         ctx->prof.begin(PC_FWD, st); HIPCHK(sml_launch_fwd(d, 1, fns, f, tiles, st)); ctx->prof.end(st);
         SmlBwdArgs w;

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(512) void k_transfer_fwd(SmlFwdArgs a) {
     for (int q = 0; q < EPT; ++q) {
         const int e = q * 512 + tid, r = e / D, w = e % D;
         const int row = row0 + r;
-        const float xc = (xt[q] * xh[q]) / nrm[r];     // no epsilon, as model/conv_transfer.py:99
+        const float xc = a.k2 ? 0.0f : (xt[q] * xh[q]) / nrm[r];     // no epsilon, as model/conv_transfer.py:99
         Pro p;
         conv_prologue(cws, xt[q], xh[q], xc, p);
 #pragma unroll
@@ -309,13 +309,34 @@ __global__ __launch_bounds__(512) void k_transfer_fwd(SmlFwdArgs a) {
     }
     __syncthreads();
     float* __restrict__ outp = sg.out + (int64_t)h * a.out_pstride;
+    float sres[EPT];
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
         const int e = q * 512 + tid, r = e / D, j = e % D;
         float s = bias2[q];
 #pragma unroll
         for (int k = 0; k < KSPL; ++k) s += part[(k * R + r) * (D + 1) + j];
-        if (row0 + r < sg.n_rows) outp[(int64_t)(row0 + r) * D + j] = s;
+        sres[q] = s;
+    }
+    if (NS == 1 && a.unit_rows && sidx == 0) {
+        // ConvTransfer.forward(type='user'): x / ||x|| (model/conv_transfer.py:62-64).  Every thread parks its
+        // element in its own k = 0 slot of `part` (nobody else reads that slot), then reads its row back.
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) { const int e = q * 512 + tid; part[(e / D) * (D + 1) + (e % D)] = sres[q]; }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int r = (q * 512 + tid) / D;
+            float n2 = 0.0f;
+#pragma unroll 8
+            for (int w = 0; w < D; ++w) { const float t = part[r * (D + 1) + w]; n2 += t * t; }
+            sres[q] = sres[q] / sqrtf(n2);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int e = q * 512 + tid, r = e / D, j = e % D;
+        if (row0 + r < sg.n_rows) outp[(int64_t)(row0 + r) * D + j] = sres[q];
     }
 }
 
@@ -415,10 +436,11 @@ __global__ __launch_bounds__(512) void k_transfer_bwd_full(SmlBwdArgs a) {
             uu += u * u;
         }
         float lt, d0, d1, inv_nu = 1.0f, cc = 0.0f;
-        if (a.kind == SML_LOSS_BPR_NORM) {
+        if (a.kind == SML_LOSS_BPR_NORM || a.kind == SML_LOSS_BPR_UNIT) {
             const float nu = sqrtf(uu);
             inv_nu = 1.0f / nu;
-            cc = (sp - sn) / (nu * nu * nu);
+            // BPR_NORM differentiates through the norm; BPR_UNIT's norm is detached (ConvTransfer.forward)
+            cc = a.kind == SML_LOSS_BPR_NORM ? (sp - sn) / (nu * nu * nu) : 0.0f;
             pair_terms(SML_LOSS_BPR, (sp - sn) * inv_nu, 0.0f, 1.0f, lt, d0, d1);
             d1 = -d0;
         } else {
@@ -434,7 +456,7 @@ __global__ __launch_bounds__(512) void k_transfer_bwd_full(SmlBwdArgs a) {
         const int row = row0 + r;
         const float d0 = cf[0][r], d1 = cf[1][r];
         float g;
-        if (a.kind == SML_LOSS_BPR_NORM) {
+        if (a.kind == SML_LOSS_BPR_NORM || a.kind == SML_LOSS_BPR_UNIT) {
             const float inv_nu = cf[2][r], cc = cf[3][r];
             if (!sg.is_item) g = d0 * ((oi[q] - on[q]) * inv_nu - cc * ou[q]);
             else g = ((row < a.B) ? d0 : d1) * ou[q] * inv_nu;
@@ -680,10 +702,11 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
             uu += u * u;
         }
         float lt, d0, d1, inv_nu = 1.0f, cc = 0.0f;
-        if (a.kind == SML_LOSS_BPR_NORM) {
+        if (a.kind == SML_LOSS_BPR_NORM || a.kind == SML_LOSS_BPR_UNIT) {
             const float nu = sqrtf(uu);
             inv_nu = 1.0f / nu;
-            cc = (sp - sn) / (nu * nu * nu);
+            // BPR_NORM differentiates through the norm; BPR_UNIT's norm is detached (ConvTransfer.forward)
+            cc = a.kind == SML_LOSS_BPR_NORM ? (sp - sn) / (nu * nu * nu) : 0.0f;
             pair_terms(SML_LOSS_BPR, (sp - sn) * inv_nu, 0.0f, 1.0f, lt, d0, d1);
             d1 = -d0;
         } else {
@@ -699,7 +722,7 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
         const int row = row0 + r;
         const float d0 = cf[0][r], d1 = cf[1][r];
         float g;
-        if (a.kind == SML_LOSS_BPR_NORM) {
+        if (a.kind == SML_LOSS_BPR_NORM || a.kind == SML_LOSS_BPR_UNIT) {
             const float inv_nu = cf[2][r], cc = cf[3][r];
             if (!sg.is_item) g = d0 * ((oi[q] - on[q]) * inv_nu - cc * ou[q]);
             else g = ((row < a.B) ? d0 : d1) * ou[q] * inv_nu;

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import datasets as D
-from .conv_transfer import ConvTransfer_com
+from .conv_transfer import ConvTransfer, ConvTransfer_com
 from .evaluation import DeviceRows, test_model
 from .mf import MFbasemode
 
@@ -108,9 +108,12 @@ class meta_train(object):
         if self.transfer_type == "conv_com":
             self.transfer = ConvTransfer_com(laten_dim, laten_dim).to(self.device)
             self.transfer_type = "transfer2"
-        elif self.transfer_type in ("transfer", "transfer2", "GRU", "transfer3", "conv", "conv_com2"):
+        elif self.transfer_type == "conv":
+            self.transfer = ConvTransfer(laten_dim, laten_dim).to(self.device)
+            self.transfer_type = "transfer2"
+        elif self.transfer_type in ("transfer", "transfer2", "GRU", "transfer3", "conv_com2"):
             raise NotImplementedError("transfer type %r is one of the reference's unused variants "
-                                      "(model/transfer.py:1-4); only conv_com is built" % self.transfer_type)
+                                      "(model/transfer.py:1-4); only conv_com and conv are built" % self.transfer_type)
         else:
             raise TypeError("No such type transfer!!!")
 

@@ -95,18 +95,35 @@ class HipEngine(object):
                 p = named[name]
                 off = ni * self.net_size + self.offsets[w]
                 n = p.numel()
+                if name == "conv1.weight" and p.shape[2] == 2:
+                    # ConvTransfer's (2,1) kernel lives in the first two columns of the [10][3] block; the third
+                    # column multiplies the zero x_com row and stays zero (its gradient is exactly zero)
+                    block = flat[off:off + 30].view(10, 3)
+                    block[:, :2].copy_(p.data.reshape(10, 2).to(self.device, torch.float32))
+                    p.data = block[:, :2].view(10, 1, 2, 1)
+                    views.append((p, off, n))
+                    continue
                 flat[off:off + n].copy_(p.data.reshape(-1).to(self.device, torch.float32))
                 p.data = flat[off:off + n].view(p.shape)
                 views.append((p, off, n))
         self._flat[key] = (flat, views)
         return flat
 
+    def _select(self, transfer):
+        """Tell the library which transfer architecture the next calls are for (0: ConvTransfer_com,
+        1: ConvTransfer -- kernel-2 nets, unit-norm user output, BPR) and return the flat theta."""
+        variant = 1 if int(getattr(transfer.user_transfer, "kernel", 3)) == 2 else 0
+        if variant != getattr(self, "_variant", 0):
+            check(self.lib.sml_ctx_set_variant(self._ctx, variant), "sml_ctx_set_variant")
+            self._variant = variant
+        return self.adopt(transfer)
+
     # ------------------------------------------------------------------ a5/a6/a10
     def transfer_forward(self, transfer, x_t, x_hat, which):
         net = {"user": 0, "item": 1}.get(which)
         if net is None:
             raise TypeError("convtransfer has not this type")
-        theta = self.adopt(transfer)
+        theta = self._select(transfer)
         x_t = self._table(self._dev(x_t, torch.float32))
         x_hat = self._table(self._dev(x_hat.detach(), torch.float32))
         out = torch.empty_like(x_t)
@@ -115,7 +132,7 @@ class HipEngine(object):
         return out
 
     def updata(self, transfer, last_user, hat_user, last_item, hat_item, out_user, out_item):
-        theta = self.adopt(transfer)
+        theta = self._select(transfer)
         for net, (xt, xh, out) in enumerate(((last_user, hat_user, out_user), (last_item, hat_item, out_item))):
             xt, xh, out = self._table(xt), self._table(xh), self._table(out)
             if out.data_ptr() in (xt.data_ptr(), xh.data_ptr()):
@@ -143,14 +160,18 @@ class HipEngine(object):
         t.n_user, t.n_item = wu.shape[0], wi.shape[0]
         return t
 
-    @staticmethod
-    def _loss_kind(bce, norm):
+    def _loss_kind(self, bce, norm):
+        if getattr(self, "_variant", 0) == 1:
+            # ConvTransfer.run_MF has one loss: BPR over the unit-norm user output (model/conv_transfer.py:71-85)
+            if norm:
+                raise NotImplementedError("ConvTransfer with norm=True (the reference's unused --norm flag)")
+            return _lib.LOSS_BPR_UNIT
         if bce:
             return _lib.LOSS_BCE
         return _lib.LOSS_BPR_NORM if norm else _lib.LOSS_BPR
 
     def mf_stage_epoch(self, mfbase, transfer, last_user, last_item, triples, batch_size, lr, l2, norm=False, bce=True):
-        theta = self.adopt(transfer)
+        theta = self._select(transfer)
         tri = self._dev(triples, torch.int64)
         n = tri.shape[0]
         nb = (n + batch_size - 1) // batch_size
@@ -196,7 +217,7 @@ class HipEngine(object):
     # ------------------------------------------------------------------ a9
     def tr_stage_epoch(self, transfer, last_user, last_item, hat_user, hat_item, triples, batch_size, lr,
                        weight_decay, bce=True, loss_scale=None):
-        theta = self.adopt(transfer)
+        theta = self._select(transfer)
         if loss_scale is None:
             loss_scale = self.dist.tr_loss_scale() if self.dist is not None else 1.0
         if self.tr_state is None or self.tr_state[0].shape != theta.shape:

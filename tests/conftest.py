@@ -29,9 +29,12 @@ def quiet():
 
 def make_transfer(d, z=None, prefix="theta.", device="cpu"):
     """The product's ConvTransfer_com module (a parameter container) filled from a fixture."""
-    from sml_amd.conv_transfer import ConvTransfer_com
+    from sml_amd.conv_transfer import ConvTransfer, ConvTransfer_com
+    cls = ConvTransfer_com
+    if z is not None and np.asarray(z[prefix + "user_transfer.conv1.weight"]).shape[2] == 2:
+        cls = ConvTransfer          # fixtures of --transfer_type conv (kernel (2,1) nets)
     with quiet():
-        net = ConvTransfer_com(d, d)
+        net = cls(d, d)
     if z is not None:
         sd = {k[len(prefix):]: torch.from_numpy(np.asarray(z[k])) for k in z.files if k.startswith(prefix)}
         net.load_state_dict(sd)

@@ -16,7 +16,7 @@ Harness-side shims (the reference is untouched):
 Fixtures:  G1 transfer forward, G2 run_MF loss and
 gradients, G3 MF-stage steps, G4 TR-stage steps, G5 updata, G6 evaluation,
 G7 end-to-end main_yelp.py log on a tiny 40-period dataset, G8 batch supply,
-G9 parameter initialisation, G10 the baselines' bare-MF fine-tune loop (model/baseline.py
+G9 parameter initialisation, G11 the ConvTransfer variant (--transfer_type conv), G10 the baselines' bare-MF fine-tune loop (model/baseline.py
 SPMF.run_one_stage2: BCE + L2 + dense Adam on recorded batches).
 
 usage: python tests/golden/make_golden.py [--ref /root/reference]
@@ -198,12 +198,12 @@ def build_meta(T, tmp, U, I, d, args, seed):
     return meta
 
 
-def gen_g3_g4_g5(T, tmp):
+def gen_g3_g4_g5(T, tmp, ttype="conv_com", suffix=""):
     from data.dataset2 import trainDataset_withPreSample
     from data.dataset import offlineDataset_withsample
 
     U, I, d = 50, 40, 32
-    args = Args(MF_batch_size=32, TR_batch_size=16, MF_epochs=2, TR_epochs=2)
+    args = Args(MF_batch_size=32, TR_batch_size=16, MF_epochs=2, TR_epochs=2, transfer_type=ttype)
     meta = build_meta(T, tmp, U, I, d, args, seed=31)
     rng = np.random.RandomState(5)
     # the transfer net only sees non-trivial x_t after a 'last' save; make W_{t-1} != W_hat
@@ -266,7 +266,7 @@ def gen_g3_g4_g5(T, tmp):
     out["adam_v_item"] = st[pi]["exp_avg_sq"].numpy().copy()
     out["adam_step"] = np.array(float(st[pu]["step"]))
     out["hp_mf"] = np.array([args.MF_lr, args.l2, args.MF_batch_size, args.MF_epochs], dtype=np.float64)
-    save("g3_mf_stage.npz", **out)
+    save("g3_mf_stage%s.npz" % suffix, **out)
 
     # ---- G5 updata (after save 'hat'), then G4 TR-stage steps on the same state
     meta.MFbase.eval()
@@ -280,7 +280,7 @@ def gen_g3_g4_g5(T, tmp):
     meta.updata()
     g5["Wnew_user"] = meta.MFbase.user_laten.weight.detach().numpy().copy()
     g5["Wnew_item"] = meta.MFbase.item_laten.weight.detach().numpy().copy()
-    save("g5_updata.npz", **g5)
+    save("g5_updata%s.npz" % suffix, **g5)
 
     g4 = {}
     g4.update(sd_np(meta.transfer, "theta0."))
@@ -317,7 +317,43 @@ def gen_g3_g4_g5(T, tmp):
         g4["adam_v." + k] = ost[p]["exp_avg_sq"].numpy().copy()
     g4["adam_step"] = np.array(float(ost[next(meta.transfer.parameters())]["step"]))
     g4["hp_tr"] = np.array([args.TR_lr, args.TR_l2, args.TR_batch_size, args.TR_epochs], dtype=np.float64)
-    save("g4_tr_stage.npz", **g4)
+    save("g4_tr_stage%s.npz" % suffix, **g4)
+
+
+# --------------------------------------------------------------------------- G11 ConvTransfer (--transfer_type conv)
+def gen_g11(T, tmp):
+    """The reference's other convolutional transfer (model/conv_transfer.py:52-85: kernel (2,1), no x_com row,
+    user output divided by its detached norm, BPR sum loss): forward, run_MF loss and gradients, then the
+    same recorded MF-stage / updata / TR-stage runs as G3-G5 through meta_train(transfer_type='conv')."""
+    from model.conv_transfer import ConvTransfer
+    d = 32
+    torch.manual_seed(300 + d)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = ConvTransfer(d, d)
+    g = torch.Generator().manual_seed(9 + d)
+    x_t = torch.randn(64, d, generator=g)
+    x_hat = torch.randn(64, d, generator=g)
+    with torch.no_grad():
+        yu = net(x_t, x_hat, "user")
+        yi = net(x_t, x_hat, "item")
+    out = sd_np(net, "theta.")
+    out.update(x_t=x_t.numpy(), x_hat=x_hat.numpy(), y_user=yu.numpy(), y_item=yi.numpy())
+    B = 48
+    ten = [torch.randn(B, d, generator=g) * 0.7 for _ in range(6)]
+    ins = [t.clone() for t in ten]
+    for k in (1, 3, 5):
+        ins[k].requires_grad_(True)
+    net.zero_grad()
+    loss = net.run_MF(*ins, norm=False)
+    loss.backward()
+    out["loss_bpr"] = loss.detach().numpy()
+    out["gu_bpr"], out["gi_bpr"], out["gn_bpr"] = ins[1].grad.numpy().copy(), ins[3].grad.numpy().copy(), ins[5].grad.numpy().copy()
+    for k, p in net.named_parameters():
+        out["gtheta_bpr.%s" % k] = p.grad.detach().numpy().copy()
+    for k, nm in enumerate(("ul", "uh", "il", "ih", "nl", "nh")):
+        out[nm] = ten[k].numpy()
+    save("g11_convtransfer_d32.npz", **out)
+    gen_g3_g4_g5(T, tmp, ttype="conv", suffix="_conv")
 
 
 # --------------------------------------------------------------------------- G6 eval
@@ -390,7 +426,7 @@ def gen_g8(T):
 
 
 # --------------------------------------------------------------------------- G7 end to end
-def gen_g7(T, ref, tmp):
+def gen_g7(T, ref, tmp, extra=(), suffix=""):
     from sml_amd import synth
     from model.MF import MFbasemode
 
@@ -406,7 +442,7 @@ def gen_g7(T, ref, tmp):
     ck = os.path.join(tmp, "BCE_init.pkl")
     torch.save(mf, ck)
     argv = ["main_yelp.py", "--data_path", root, "--pre_model", ck, "--laten", str(d), "--multi_num", "2",
-            "--numworkers", "0", "--MF_batch_size", "64", "--TR_batch_size", "32"]
+            "--numworkers", "0", "--MF_batch_size", "64", "--TR_batch_size", "32"] + list(extra)
     buf = io.StringIO()
     old = sys.argv
     sys.argv = argv
@@ -421,9 +457,10 @@ def gen_g7(T, ref, tmp):
     out["argv"] = np.array(argv[5:])
     out["dataset"] = np.array([40, 160, U, I, 49, 2000], dtype=np.int64)
     out["dataset_zipf"] = np.array([0.8, 0.8])
-    save("g7_end_to_end.npz", **out)
-    # a reference-pickled whole-module checkpoint: the on-disk contract for --pre_model
-    shutil.copy(ck, os.path.join(OUT_DIR[0], "ref_BCE_init_tiny.pkl"))
+    save("g7_end_to_end%s.npz" % suffix, **out)
+    if not suffix:
+        # a reference-pickled whole-module checkpoint: the on-disk contract for --pre_model
+        shutil.copy(ck, os.path.join(OUT_DIR[0], "ref_BCE_init_tiny.pkl"))
     print("log lines:", len(log.splitlines()))
 
 
@@ -527,6 +564,9 @@ def main():
             gen_g7(T, a.ref, tmp)
         if not only or "g10" in only:
             gen_g10(a.ref)
+        if not only or "g11" in only:
+            gen_g11(T, tmp)
+            gen_g7(T, a.ref, tmp, extra=("--transfer_type", "conv"), suffix="_conv")
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

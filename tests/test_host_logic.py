@@ -202,10 +202,10 @@ def check_g7(got, want, exact_lines):
         assert abs(fin(got, key) - fin(want, key)) <= 0.02, key
 
 
-def run_g7(tmp_path, monkeypatch, device_patch=True):
+def run_g7(tmp_path, monkeypatch, device_patch=True, variant=""):
     from sml_amd import cli, driver, synth
     from sml_amd.mf import MFbasemode
-    z = golden("g7_end_to_end.npz")
+    z = golden("g7_end_to_end%s.npz" % variant)      # "_conv": the same run with --transfer_type conv
     P, n_inter, U, I, neg, seed = [int(v) for v in z["dataset"]]
     root = str(tmp_path) + "/"
     synth.write_dataset(root, "yelp", n_periods=P, n_inter=n_inter, n_user=U, n_item=I, neg=neg,
@@ -220,14 +220,15 @@ def run_g7(tmp_path, monkeypatch, device_patch=True):
     return buf.getvalue(), str(z["log"])
 
 
-def test_g7_driver_control_flow_on_cpu(tmp_path, monkeypatch):
+@pytest.mark.parametrize("variant", ["", "_conv"])
+def test_g7_driver_control_flow_on_cpu(tmp_path, monkeypatch, variant):
     from sml_amd import driver
     from sml_amd.mf import MFbasemode
     monkeypatch.setattr(driver, "_default_device", lambda: torch.device("cpu"))
     monkeypatch.setattr(driver, "_make_engine", lambda dev, d, mb: _CpuEngine(dev, d, mb))
     monkeypatch.setattr(MFbasemode, "test", _cpu_mf_test)
     monkeypatch.delenv("CUDA_VISIBLE_DEVICES", raising=False)
-    got, want = run_g7(tmp_path, monkeypatch)
+    got, want = run_g7(tmp_path, monkeypatch, variant=variant)
     # identical data and RNG tape: the first three periods print identically
     check_g7(got, want, exact_lines=90)
 

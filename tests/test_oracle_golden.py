@@ -59,10 +59,11 @@ def adam_close(a, b, lr, steps, frac=0.999):
     assert np.abs(a - b).max() <= 0.05 * lr * steps, "max abs diff %.3e" % np.abs(a - b).max()
 
 
-def test_g3_mf_stage_steps():
+@pytest.mark.parametrize("variant", ["", "_conv"])
+def test_g3_mf_stage_steps(variant):
     """K batches of MF_train_onestage incl. duplicate rows: per-batch loss, touched and
     untouched rows (dense-Adam drift), Adam moments and step count."""
-    z = golden("g3_mf_stage.npz")
+    z = golden("g3_mf_stage%s.npz" % variant)      # "_conv": the same run through --transfer_type conv
     lr, l2, B, epochs = z["hp_mf"]
     B, epochs = int(B), int(epochs)
     U, d = z["W_user0"].shape
@@ -95,8 +96,9 @@ def test_g3_mf_stage_steps():
     np.testing.assert_allclose(mine, printed, rtol=1e-5)
 
 
-def test_g4_tr_stage_steps():
-    z = golden("g4_tr_stage.npz")
+@pytest.mark.parametrize("variant", ["", "_conv"])
+def test_g4_tr_stage_steps(variant):
+    z = golden("g4_tr_stage%s.npz" % variant)
     lr, wd, B, epochs = z["hp_tr"]
     B, epochs = int(B), int(epochs)
     d = z["Wlast_user"].shape[1]
@@ -116,8 +118,9 @@ def test_g4_tr_stage_steps():
         adam_close(p.detach().numpy(), ref, lr, eng.tr_step)
 
 
-def test_g5_updata():
-    z = golden("g5_updata.npz")
+@pytest.mark.parametrize("variant", ["", "_conv"])
+def test_g5_updata(variant):
+    z = golden("g5_updata%s.npz" % variant)
     d = z["Wlast_user"].shape[1]
     net = make_transfer(d, z)
     eng = O.OracleEngine(d)
@@ -191,3 +194,28 @@ def test_g10_baseline_bare_adam_loop():
         hits, ndcg = O.eval_metrics(ranks, topk)
         assert abs(hits / n - g["recall_5_10_20"][k]) < 1e-9
         assert abs(ndcg / n - g["ndcg_5_10_20"][k]) < 1e-5
+
+
+def test_g11_convtransfer_forward_loss_and_gradients():
+    """ConvTransfer (--transfer_type conv; reference model/conv_transfer.py:52-85): forward of both nets (user
+    output unit-norm), run_MF's BPR loss, gradients w.r.t. the x_hat inputs and theta."""
+    z = golden("g11_convtransfer_d32.npz")
+    theta = O.split_theta(z, "theta.")
+    assert O.net_kernel(theta["user"]) == 2
+    x_t, x_hat = T(z["x_t"]), T(z["x_hat"])
+    np.testing.assert_allclose(O.transfer_forward(theta["user"], x_t, x_hat, unit_norm=True).numpy(), z["y_user"],
+                               rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(O.transfer_forward(theta["item"], x_t, x_hat).numpy(), z["y_item"], rtol=2e-5, atol=2e-6)
+    theta = {n: {k: v.clone().requires_grad_(True) for k, v in t.items()} for n, t in theta.items()}
+    ins = [T(z[k]).clone() for k in ("ul", "uh", "il", "ih", "nl", "nh")]
+    for k in (1, 3, 5):
+        ins[k].requires_grad_(True)
+    loss = O.run_mf(theta, *ins, norm=False, bce=True)      # bce is ignored for kernel-2 nets: BPR only
+    loss.backward()
+    np.testing.assert_allclose(float(loss), float(z["loss_bpr"]), rtol=1e-5)
+    close(ins[1].grad.numpy(), z["gu_bpr"], 3e-5)
+    close(ins[3].grad.numpy(), z["gi_bpr"], 3e-5)
+    close(ins[5].grad.numpy(), z["gn_bpr"], 3e-5)
+    for net, mod in (("user", "user_transfer"), ("item", "item_transfer")):
+        for k, p in theta[net].items():
+            close(p.grad.numpy(), z["gtheta_bpr.%s.%s" % (mod, k)], 3e-4 if k.endswith("bias") else 3e-5)
