@@ -56,18 +56,24 @@ __device__ __forceinline__ int64_t seg_row_index(const SmlSeg& s, int r) {
 //   bimg : tile t, k-step ks at bimg[(tile_of(t) * ksteps_total + ks0 + kofs(t) + ks) * 64 + lane]
 //   SPLITK: the NT "tiles" are k-ranges of ONE column tile (kofs(t) differs): independent accumulator
 //   chains for a wave that owns a single column tile; the caller adds the NT accumulators at the end.
-template <int MT, int NT, int NK, int PFD, bool SPLITK, typename TileOf, typename KOfs>
-__device__ __forceinline__ void mma16_rows_k(f32x4 (&acc)[MT][NT], const float* arow, int a_mt,
-                                             const f32x4* __restrict__ bimg, int ksteps_total, int ks0, int lane,
-                                             TileOf tile_of, KOfs kofs) {
-    static_assert(PFD >= 1 && PFD <= NK, "ring depth");
-    constexpr int NCH = NK / PFD, REM = NK % PFD;
-    constexpr int NA = SPLITK ? NT : 1;
-    f32x4 ring[PFD][NT];
+// first PFD k-steps of every tile's operand image into the ring.  Separate from the product so a kernel can
+// issue these loads (they depend on nothing but theta) at its very top, under its gather / pair-loss stage
+template <int NT, int PFD, typename TileOf, typename KOfs>
+__device__ __forceinline__ void ring_preload(f32x4 (&ring)[PFD][NT], const f32x4* __restrict__ bimg, int ksteps_total, int ks0,
+                                             int lane, TileOf tile_of, KOfs kofs) {
 #pragma unroll
     for (int i = 0; i < PFD; ++i)
 #pragma unroll
         for (int t = 0; t < NT; ++t) ring[i][t] = bimg[(tile_of(t) * ksteps_total + ks0 + kofs(t) + i) * 64 + lane];
+}
+
+template <int MT, int NT, int NK, int PFD, bool SPLITK, typename TileOf, typename KOfs>
+__device__ __forceinline__ void mma16_ring(f32x4 (&acc)[MT][NT], f32x4 (&ring)[PFD][NT], const float* arow, int a_mt,
+                                           const f32x4* __restrict__ bimg, int ksteps_total, int ks0, int lane,
+                                           TileOf tile_of, KOfs kofs) {
+    static_assert(PFD >= 1 && PFD <= NK, "ring depth");
+    constexpr int NCH = NK / PFD, REM = NK % PFD;
+    constexpr int NA = SPLITK ? NT : 1;
     auto step = [&](int ks, int slot, bool refill) {
         f32x4 av[NA][MT];
 #pragma unroll
@@ -94,6 +100,15 @@ __device__ __forceinline__ void mma16_rows_k(f32x4 (&acc)[MT][NT], const float* 
     }
 #pragma unroll
     for (int j = 0; j < REM; ++j) step(NCH * PFD + j, j, false);
+}
+
+template <int MT, int NT, int NK, int PFD, bool SPLITK, typename TileOf, typename KOfs>
+__device__ __forceinline__ void mma16_rows_k(f32x4 (&acc)[MT][NT], const float* arow, int a_mt,
+                                             const f32x4* __restrict__ bimg, int ksteps_total, int ks0, int lane,
+                                             TileOf tile_of, KOfs kofs) {
+    f32x4 ring[PFD][NT];
+    ring_preload<NT, PFD>(ring, bimg, ksteps_total, ks0, lane, tile_of, kofs);
+    mma16_ring<MT, NT, NK, PFD, SPLITK>(acc, ring, arow, a_mt, bimg, ksteps_total, ks0, lane, tile_of, kofs);
 }
 template <int MT, int NT, int NK, int PFD, typename TileOf>
 __device__ __forceinline__ void mma16_rows(f32x4 (&acc)[MT][NT], const float* arow, int a_mt,
@@ -414,11 +429,17 @@ __global__ __launch_bounds__(512) void k_transfer_bwd_full(SmlBwdArgs a) {
             const float* pu = a.out_all + (int64_t)t * D + w;
             const float* pi = a.out_all + (int64_t)(a.ioff + t) * D + w;
             const float* pn = a.out_all + (int64_t)(a.ioff + a.B + t) * D + w;
-            for (int p = 0; p < a.out_np; ++p) {
-                ou[q] += pu[p * a.out_pstride];
-                oi[q] += pi[p * a.out_pstride];
-                on[q] += pn[p * a.out_pstride];
+            // (all planes' loads in flight together; a runtime-bounded loop would take them one round trip at a time)
+            float vu[SML_FWD_NS], vi[SML_FWD_NS], vn[SML_FWD_NS];
+#pragma unroll
+            for (int p = 0; p < SML_FWD_NS; ++p) {
+                const bool live = p < a.out_np;
+                vu[p] = live ? pu[p * a.out_pstride] : 0.0f;
+                vi[p] = live ? pi[p * a.out_pstride] : 0.0f;
+                vn[p] = live ? pn[p * a.out_pstride] : 0.0f;
             }
+#pragma unroll
+            for (int p = 0; p < SML_FWD_NS; ++p) { ou[q] += vu[p]; oi[q] += vi[p]; on[q] += vn[p]; }
         }
         O3[(0 * R + r) * (D + 1) + w] = ou[q];
         O3[(1 * R + r) * (D + 1) + w] = oi[q];
@@ -650,6 +671,16 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
     const SmlBwdSeg& sg = a.seg[sidx];
     const int row0 = (tile - (sidx ? a.tiles0 : 0)) * R;
     if (tid < 104) cws[tid] = sg.theta[tid];
+    // Both GEMMs' operand images fit a register ring whole at d <= 64 (dA2: D/16 k-steps x 4 tiles, dA1: 4 k-steps
+    // x 5 tiles per wave): they are fetched right after the pair-loss inputs below (loads return in issue order,
+    // so the loss stage does not wait for them) and neither GEMM starts with an L2 round trip
+    constexpr bool PRE = D <= 64;
+    const f32x4* __restrict__ p2b = reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p2b(D));
+    const f32x4* __restrict__ p1b = reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p1b(D));
+    auto tile2 = [wv](int t) { return wv * 4 + t; };
+    auto tile1 = [cs](int t) { return t * (D / 16) + cs; };
+    auto nokofs = [](int) { return 0; };
+    f32x4 ring2[PRE ? KSD : 1][4], ring1[PRE ? 4 : 1][5];
 
     // ---- pair loss (model/conv_transfer.py:120-134) for this tile's rows: every row fetches the three
     // transferred rows of its triple (each the sum of the forward's out_np hidden-slice planes, added in
@@ -667,15 +698,23 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
             const float* pu = a.out_all + (int64_t)t * D + w;
             const float* pi = a.out_all + (int64_t)(a.ioff + t) * D + w;
             const float* pn = a.out_all + (int64_t)(a.ioff + a.B + t) * D + w;
-            for (int p = 0; p < a.out_np; ++p) {
-                ou[q] += pu[p * a.out_pstride];
-                oi[q] += pi[p * a.out_pstride];
-                on[q] += pn[p * a.out_pstride];
+            // (all planes' loads in flight together; a runtime-bounded loop would take them one round trip at a time)
+            float vu[SML_FWD_NS], vi[SML_FWD_NS], vn[SML_FWD_NS];
+#pragma unroll
+            for (int p = 0; p < SML_FWD_NS; ++p) {
+                const bool live = p < a.out_np;
+                vu[p] = live ? pu[p * a.out_pstride] : 0.0f;
+                vi[p] = live ? pi[p * a.out_pstride] : 0.0f;
+                vn[p] = live ? pn[p * a.out_pstride] : 0.0f;
             }
+#pragma unroll
+            for (int p = 0; p < SML_FWD_NS; ++p) { ou[q] += vu[p]; oi[q] += vi[p]; on[q] += vn[p]; }
         }
-        O3[(0 * R + r) * (D + 1) + w] = ou[q];
-        O3[(1 * R + r) * (D + 1) + w] = oi[q];
-        O3[(2 * R + r) * (D + 1) + w] = on[q];
+        if constexpr (D > 64) {           // a row spans two wavefronts: the scores go through LDS
+            O3[(0 * R + r) * (D + 1) + w] = ou[q];
+            O3[(1 * R + r) * (D + 1) + w] = oi[q];
+            O3[(2 * R + r) * (D + 1) + w] = on[q];
+        }
     }
     // the tail's (x_t, x_hat, x_com) and this wave's z1 fragment: issue the loads now, use them later
     const int tr_ = tid >> 4, twl = tid & 15, tw = cs * 16 + twl;       // tail element of threads 0..255
@@ -690,58 +729,101 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             z[t][q] = sg.z1[(int64_t)(row0 + 4 * g4 + q) * SML_HID + (wv * 4 + t) * 16 + l15];
-    __syncthreads();
-    float lsum = 0.0f;
-    if (tid < R) {
-        float sp = 0.f, sn = 0.f, uu = 0.f;
-#pragma unroll 8
-        for (int w = 0; w < D; ++w) {
-            const float u = O3[(0 * R + tid) * (D + 1) + w];
-            sp += u * O3[(1 * R + tid) * (D + 1) + w];
-            sn += u * O3[(2 * R + tid) * (D + 1) + w];
-            uu += u * u;
-        }
-        float lt, d0, d1, inv_nu = 1.0f, cc = 0.0f;
-        if (a.kind == SML_LOSS_BPR_NORM || a.kind == SML_LOSS_BPR_UNIT) {
-            const float nu = sqrtf(uu);
-            inv_nu = 1.0f / nu;
-            // BPR_NORM differentiates through the norm; BPR_UNIT's norm is detached (ConvTransfer.forward)
-            cc = a.kind == SML_LOSS_BPR_NORM ? (sp - sn) / (nu * nu * nu) : 0.0f;
-            pair_terms(SML_LOSS_BPR, (sp - sn) * inv_nu, 0.0f, 1.0f, lt, d0, d1);
-            d1 = -d0;
-        } else {
-            pair_terms(a.kind, sp, sn, 1.0f / (float)a.B, lt, d0, d1);
-        }
-        cf[0][tid] = d0 * a.scale; cf[1][tid] = d1 * a.scale; cf[2][tid] = inv_nu; cf[3][tid] = cc;
-        if (!sg.is_item && cs == 0 && row0 + tid < sg.n_rows) lsum = lt * a.scale;
+    if constexpr (PRE) {
+        ring_preload<4, KSD>(ring2, p2b, KSD, 0, lane, tile2, nokofs);
+        ring_preload<5, 4>(ring1, p1b, 32, wv * 4, lane, tile1, nokofs);
     }
-    __syncthreads();
+    float lsum = 0.0f;
+    if constexpr (D <= 64) {
+        // a row's D elements sit in D adjacent lanes of one wavefront (d = 32: half a wave, d = 64: a wave):
+        // the three dot products are xor-shuffle sums, every lane of the row forms the loss terms itself --
+        // no LDS round trip, no barrier before dOut
 #pragma unroll
-    for (int q = 0; q < EPT; ++q) {
-        const int e = q * 512 + tid, r = e / D, w = e % D;
-        const int row = row0 + r;
-        const float d0 = cf[0][r], d1 = cf[1][r];
-        float g;
-        if (a.kind == SML_LOSS_BPR_NORM || a.kind == SML_LOSS_BPR_UNIT) {
-            const float inv_nu = cf[2][r], cc = cf[3][r];
-            if (!sg.is_item) g = d0 * ((oi[q] - on[q]) * inv_nu - cc * ou[q]);
-            else g = ((row < a.B) ? d0 : d1) * ou[q] * inv_nu;
-        } else {
-            if (!sg.is_item) g = d0 * oi[q] + d1 * on[q];
-            else g = ((row < a.B) ? d0 : d1) * ou[q];
+        for (int q = 0; q < EPT; ++q) {
+            const int e = q * 512 + tid, r = e / D, w = e % D;
+            const int row = row0 + r;
+            float sp = ou[q] * oi[q], sn = ou[q] * on[q], uu = ou[q] * ou[q];
+#pragma unroll
+            for (int off = D / 2; off >= 1; off >>= 1) {
+                sp += __shfl_xor(sp, off, 64); sn += __shfl_xor(sn, off, 64); uu += __shfl_xor(uu, off, 64);
+            }
+            float lt, d0, d1, inv_nu = 1.0f, cc = 0.0f;
+            if (a.kind == SML_LOSS_BPR_NORM || a.kind == SML_LOSS_BPR_UNIT) {
+                const float nu = sqrtf(uu);
+                inv_nu = 1.0f / nu;
+                // BPR_NORM differentiates through the norm; BPR_UNIT's norm is detached (ConvTransfer.forward)
+                cc = a.kind == SML_LOSS_BPR_NORM ? (sp - sn) / (nu * nu * nu) : 0.0f;
+                pair_terms(SML_LOSS_BPR, (sp - sn) * inv_nu, 0.0f, 1.0f, lt, d0, d1);
+                d1 = -d0;
+            } else {
+                pair_terms(a.kind, sp, sn, 1.0f / (float)a.B, lt, d0, d1);
+            }
+            d0 *= a.scale; d1 *= a.scale;
+            if (!sg.is_item && cs == 0 && w == 0 && row < sg.n_rows) lsum += lt * a.scale;
+            float g;
+            if (a.kind == SML_LOSS_BPR_NORM || a.kind == SML_LOSS_BPR_UNIT) {
+                if (!sg.is_item) g = d0 * ((oi[q] - on[q]) * inv_nu - cc * ou[q]);
+                else g = ((row < a.B) ? d0 : d1) * ou[q] * inv_nu;
+            } else {
+                if (!sg.is_item) g = d0 * oi[q] + d1 * on[q];
+                else g = ((row < a.B) ? d0 : d1) * ou[q];
+            }
+            if (row >= sg.n_rows) g = 0.0f;
+            dOs[r * SD + w] = g;
+            if (TR && cs == 0) sg.dout[(int64_t)row * D + w] = g;
         }
-        if (row >= sg.n_rows) g = 0.0f;
-        dOs[r * SD + w] = g;
-        if (TR && cs == 0) sg.dout[(int64_t)row * D + w] = g;
+    } else {
+        __syncthreads();
+        if (tid < R) {
+            float sp = 0.f, sn = 0.f, uu = 0.f;
+    #pragma unroll 8
+            for (int w = 0; w < D; ++w) {
+                const float u = O3[(0 * R + tid) * (D + 1) + w];
+                sp += u * O3[(1 * R + tid) * (D + 1) + w];
+                sn += u * O3[(2 * R + tid) * (D + 1) + w];
+                uu += u * u;
+            }
+            float lt, d0, d1, inv_nu = 1.0f, cc = 0.0f;
+            if (a.kind == SML_LOSS_BPR_NORM || a.kind == SML_LOSS_BPR_UNIT) {
+                const float nu = sqrtf(uu);
+                inv_nu = 1.0f / nu;
+                // BPR_NORM differentiates through the norm; BPR_UNIT's norm is detached (ConvTransfer.forward)
+                cc = a.kind == SML_LOSS_BPR_NORM ? (sp - sn) / (nu * nu * nu) : 0.0f;
+                pair_terms(SML_LOSS_BPR, (sp - sn) * inv_nu, 0.0f, 1.0f, lt, d0, d1);
+                d1 = -d0;
+            } else {
+                pair_terms(a.kind, sp, sn, 1.0f / (float)a.B, lt, d0, d1);
+            }
+            cf[0][tid] = d0 * a.scale; cf[1][tid] = d1 * a.scale; cf[2][tid] = inv_nu; cf[3][tid] = cc;
+            if (!sg.is_item && cs == 0 && row0 + tid < sg.n_rows) lsum = lt * a.scale;
+        }
+        __syncthreads();
+    #pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int e = q * 512 + tid, r = e / D, w = e % D;
+            const int row = row0 + r;
+            const float d0 = cf[0][r], d1 = cf[1][r];
+            float g;
+            if (a.kind == SML_LOSS_BPR_NORM || a.kind == SML_LOSS_BPR_UNIT) {
+                const float inv_nu = cf[2][r], cc = cf[3][r];
+                if (!sg.is_item) g = d0 * ((oi[q] - on[q]) * inv_nu - cc * ou[q]);
+                else g = ((row < a.B) ? d0 : d1) * ou[q] * inv_nu;
+            } else {
+                if (!sg.is_item) g = d0 * oi[q] + d1 * on[q];
+                else g = ((row < a.B) ? d0 : d1) * ou[q];
+            }
+            if (row >= sg.n_rows) g = 0.0f;
+            dOs[r * SD + w] = g;
+            if (TR && cs == 0) sg.dout[(int64_t)row * D + w] = g;
+        }
     }
     __syncthreads();
     // ---- dA2[R x 512] = dOut[R x D] * W2 ; dZ1 = dA2 * Gelu'(z1) ; wave wv owns column tiles 4wv..4wv+3
     {
         f32x4 acc[1][4];
         zero_acc(acc);
-        mma16_rows<1, 4, KSD, KSD>(acc, dOs + l15 * SD + 4 * g4, 0,
-                                   reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p2b(D)), KSD, 0, lane,
-                                   [wv](int t) { return wv * 4 + t; });
+        if constexpr (PRE) mma16_ring<1, 4, KSD, KSD, false>(acc, ring2, dOs + l15 * SD + 4 * g4, 0, p2b, KSD, 0, lane, tile2, nokofs);
+        else mma16_rows<1, 4, KSD, KSD>(acc, dOs + l15 * SD + 4 * g4, 0, p2b, KSD, 0, lane, tile2);
         float* dz1 = sg.dz1;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -760,9 +842,8 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
     {
         f32x4 acc[1][5];
         zero_acc(acc);
-        mma16_rows<1, 5, 4, 4>(acc, dZs + l15 * S2 + 4 * g4, 0,
-                               reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p1b(D)), 32, wv * 4, lane,
-                               [cs](int t) { return t * (D / 16) + cs; });
+        if constexpr (PRE) mma16_ring<1, 5, 4, 4, false>(acc, ring1, dZs + l15 * S2 + 4 * g4, 0, p1b, 32, wv * 4, lane, tile1, nokofs);
+        else mma16_rows<1, 5, 4, 4>(acc, dZs + l15 * S2 + 4 * g4, 0, p1b, 32, wv * 4, lane, tile1);
         __syncthreads();                        // every wave is done reading dZs
 #pragma unroll
         for (int t = 0; t < 5; ++t)
