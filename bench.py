@@ -41,11 +41,28 @@ class _StdoutToStderr(object):
         os.dup2(2, 1)
         return self
 
+    @staticmethod
+    def _flush_c():
+        # RCCL printf()s into C stdio's buffer (fully buffered on a pipe): push it out while fd 1 still points at
+        # stderr, or it surfaces on the real stdout when the process exits
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+
     def __exit__(self, *exc):
         sys.stdout.flush()
+        self._flush_c()
         os.dup2(self._saved, 1)
         os.close(self._saved)
         return False
+
+    def emit(self, text):
+        """Write to the REAL stdout while the redirect stays in place."""
+        sys.stdout.flush()
+        self._flush_c()
+        os.write(self._saved, (text + "\n").encode())
 
 
 def parse():
@@ -259,7 +276,8 @@ def main():
     from sml_amd.period import Hyper, run_period, synth_plan
     hp = Hyper(multi_num=a.multi_num)
     quiet = _StdoutToStderr()
-    quiet.__enter__()          # until the warm-up is done (communicators are created lazily)
+    quiet.__enter__()          # for the whole run: RCCL prints its banner whenever a communicator is first used --
+    #                            the one JSON line goes to the real stdout through quiet.emit()
     dist = None
     force_dist = os.environ.get("SML_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ   # exercise the exchange path at N=1
     if world > 1 or force_dist:
@@ -285,7 +303,6 @@ def main():
     for w in range(a.warmup):
         run_period(engine, st, plans[w % len(plans)], hp, overlap=not a.no_overlap)
     barrier()
-    quiet.__exit__()
     t0 = time.perf_counter()
     for s in range(a.steps):
         run_period(engine, st, plans[(a.warmup + s) % len(plans)], hp, overlap=not a.no_overlap)
@@ -338,10 +355,11 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(a, hp)
     if rank == 0:
-        print(json.dumps(out))
+        quiet.emit(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    quiet.__exit__()
 
 
 if __name__ == "__main__":

@@ -612,21 +612,21 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
             wg.weight_decay = weight_decay; wg.step_size = sc.step_size; wg.bc2_sqrt = sc.bc2_sqrt;
             ctx->prof.begin(PC_WGRAD, st); HIPCHK(sml_launch_wgrad(d, wg, st)); ctx->prof.end(st);
         } else {
+            // the weight-gradient launch leaves the flat gradient complete (its conv workgroups sum the backward's
+            // partials): all-reduce it, then one Adam launch
+            wg.convg_part = ctx->convg.p; wg.tiles0 = f.tiles0 * cs; wg.tiles_total = tiles * cs;
             ctx->prof.begin(PC_WGRAD, st); HIPCHK(sml_launch_wgrad(d, wg, st)); ctx->prof.end(st);
             SmlThetaAdamArgs ad;
             memset(&ad, 0, sizeof(ad));
             ad.theta = theta; ad.m = adam_m; ad.v = adam_v; ad.grad = grad; ad.pk = ctx->pk.p;
-            ad.convg_part = ctx->convg.p; ad.tiles0 = f.tiles0 * cs; ad.tiles_total = tiles * cs;
             ad.weight_decay = weight_decay; ad.step_size = sc.step_size; ad.bc2_sqrt = sc.bc2_sqrt;
-            ad.grad_only = 1;                  // finish the flat gradient (conv partials), all-reduce, then step
-            ctx->prof.begin(PC_THETA_ADAM, st); HIPCHK(sml_launch_theta_adam(d, ad, st)); ctx->prof.end(st);
             if (native) {
                 NCCLCHK(g_rccl.AllReduce(grad, grad, (size_t)(2 * ns), ncclFloat, ncclSum, ctx->comm, st));
             } else {
                 const int hr = grad_hook(hook_user, grad, 2 * ns, b);
                 if (hr != 0) return fail(SML_ESTATE, "sml_tr_stage_epoch", "grad_hook failed");
             }
-            ad.grad_only = 0; ad.convg_part = nullptr;
+            ad.grad_only = 0; ad.convg_part = nullptr;   // conv gradients are already in `grad`
             ctx->prof.begin(PC_THETA_ADAM, st); HIPCHK(sml_launch_theta_adam(d, ad, st)); ctx->prof.end(st);
         }
     }

@@ -990,7 +990,8 @@ __global__ __launch_bounds__(512) void k_transfer_wgrad(SmlWgArgs a) {
             const int off = tid < 30 ? tid : tid < 40 ? tid + 2 : tid < 90 ? tid + 4 : tid + 6;
             const int t0 = net ? a.tiles0 : 0, t1 = net ? a.tiles_total : a.tiles0;
             const int64_t i = (int64_t)net * NS + off;
-            float p = a.theta[i], m = a.m[i], v = a.v[i];
+            float p = 0.f, m = 0.f, v = 0.f;
+            if (fuse) { p = a.theta[i]; m = a.m[i]; v = a.v[i]; }
             float g = 0.0f;
             int t = t0;
             for (; t + 8 <= t1; t += 8) {
@@ -1001,9 +1002,11 @@ __global__ __launch_bounds__(512) void k_transfer_wgrad(SmlWgArgs a) {
                 for (int u = 0; u < 8; ++u) g += x[u];
             }
             for (; t < t1; ++t) g += a.convg_part[(int64_t)t * SML_CG + tid];
-            a.seg[net].grad[off] = g;
-            adam_apply(p, m, v, g + a.weight_decay * p, sc);
-            a.theta[i] = p; a.m[i] = m; a.v[i] = v;
+            a.seg[net].grad[off] = g;                 // the flat gradient is complete after this launch
+            if (fuse) {
+                adam_apply(p, m, v, g + a.weight_decay * p, sc);
+                a.theta[i] = p; a.m[i] = m; a.v[i] = v;
+            }
         }
         return;
     }
@@ -1198,7 +1201,7 @@ hipError_t sml_launch_bwd(int d, int split, const SmlBwdArgs& a, int tiles_total
 }
 hipError_t sml_launch_wgrad(int d, const SmlWgArgs& a, hipStream_t st) {
     const int tn = 16 * (SML_C2 * d / 32) + (d / 32) * 16;
-    const int extra = a.theta != nullptr ? 2 : 0;        // fused Adam: + one conv-parameter workgroup per net
+    const int extra = 2;        // + one conv-parameter workgroup per net (sums the backward's partials; Adam when fused)
     SML_DISPATCH_D(d, k_transfer_wgrad<DD><<<dim3(2 * tn + extra), dim3(512), 0, st>>>(a));
     return hipGetLastError();
 }
