@@ -416,20 +416,22 @@ __device__ __forceinline__ void hot_partial_body(const SmlRunArgs& a, int block,
 // batches) go to the workgroup-level reducers.  OPT 0: SGD.  OPT 1: Adam with the skipped
 // zero-gradient steps replayed.
 // ------------------------------------------------------------------------------------
-template <int D, typename T, int OPT>
+template <int D, typename T, int OPT, bool HOTB>
 __global__ __launch_bounds__(256) void k_run_update(SmlRunArgs a) {
     constexpr int VEC = RowVec<T>::VEC;
     constexpr int LPR = D / VEC;
     constexpr int G = 64 / LPR;             // lane groups (records) per wavefront
-    constexpr int LONG = 8;                 // runs longer than this are summed by the whole wavefront
-    constexpr int LD = VEC == 4 ? 8 : 4;    // ... with LD rows per lane group in flight
+    // (an SGD epoch without hot runs is light-tailed: shallower unrolls, 71 instead of 112 VGPRs, 7 waves per SIMD)
+    constexpr bool LIGHT = OPT == 0 && !HOTB;
+    constexpr int LONG = LIGHT ? 4 : 8;     // runs longer than this are summed by the whole wavefront
+    constexpr int LD = (VEC == 4 && !LIGHT) ? 8 : 4;    // ... with LD rows per lane group in flight
     __shared__ SmlSched swin[OPT == 1 ? SML_SW : 1];
     if (OPT == 1) {                       // the Adam schedule of the last SML_SW steps, staged once per block
         sched_window_load(swin, a.sched, a.cur_step, threadIdx.x);
         __syncthreads();
     }
     int run_blocks = gridDim.x;
-    if constexpr (OPT == 0) {
+    if constexpr (OPT == 0 && HOTB) {
         // the first hot_blocks workgroups reduce the hot rows' chunks (independent of the runs below; theirs is
         // the longest chain of the launch, so they are dispatched first)
         __shared__ int pre[SML_HOT_MAXCAP + 1];
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(256) void k_run_update(SmlRunArgs a) {
     const int grp = lane / LPR, sub = lane % LPR;
     const RunLists L = run_lists(a);
     const int total = L.n_u + L.n_i;
-    const int wave_id = (((int)blockIdx.x - (OPT == 0 ? a.hot_blocks : 0)) * 256 + threadIdx.x) >> 6;
+    const int wave_id = (((int)blockIdx.x - ((OPT == 0 && HOTB) ? a.hot_blocks : 0)) * 256 + threadIdx.x) >> 6;
     const int n_waves = (run_blocks * 256) >> 6;
     // Compacted run lists (bare step): record k = (trip * G + grp) * n_waves + wave -- neighbouring records
     // (hot rows are neighbours in a sorted list when popular rows have neighbouring ids) go to different
@@ -892,15 +894,21 @@ static int run_grid(int64_t records, int lpr, int cap_blocks) {
 }
 hipError_t sml_launch_run_adam(int d, const SmlRunArgs& a, int64_t max_records, hipStream_t st) {
     const int nb = run_grid(max_records, d / 4, 4096);
-    SML_DISPATCH_D(d, k_run_update<DD, float, 1><<<dim3(nb), dim3(256), 0, st>>>(a));
+    SML_DISPATCH_D(d, k_run_update<DD, float, 1, false><<<dim3(nb), dim3(256), 0, st>>>(a));
     return hipGetLastError();
 }
 hipError_t sml_launch_run_sgd(int d, int dtype_bytes, const SmlRunArgs& a, int64_t max_records, hipStream_t st) {
     const int nb = run_grid(max_records, d * dtype_bytes / 16, 4096) + a.hot_blocks;
+    // the hot-chunk reducer rides in the launch only when the epoch has hot runs (tried as its own launch on a
+    // second stream beside this one: the fork/join cost more than the overlap gave, 2.45 -> 2.17 G triples/s).
+    // Without it the epoch is light-tailed: shallower unrolls, half the registers, no LDS to speak of.
+    const bool hotb = a.hot_blocks > 0;
     if (dtype_bytes == 4) {
-        SML_DISPATCH_D(d, k_run_update<DD, float, 0><<<dim3(nb), dim3(256), 0, st>>>(a));
+        if (hotb) { SML_DISPATCH_D(d, k_run_update<DD, float, 0, true><<<dim3(nb), dim3(256), 0, st>>>(a)); }
+        else { SML_DISPATCH_D(d, k_run_update<DD, float, 0, false><<<dim3(nb), dim3(256), 0, st>>>(a)); }
     } else if (dtype_bytes == 2) {
-        SML_DISPATCH_D(d, k_run_update<DD, __half, 0><<<dim3(nb), dim3(256), 0, st>>>(a));
+        if (hotb) { SML_DISPATCH_D(d, k_run_update<DD, __half, 0, true><<<dim3(nb), dim3(256), 0, st>>>(a)); }
+        else { SML_DISPATCH_D(d, k_run_update<DD, __half, 0, false><<<dim3(nb), dim3(256), 0, st>>>(a)); }
     } else return hipErrorInvalidValue;
     return hipGetLastError();
 }
