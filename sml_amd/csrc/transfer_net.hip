@@ -668,9 +668,12 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
     const int tile = (int)blockIdx.x / CS, cs = (int)blockIdx.x % CS;
     const int sidx = tile >= a.tiles0;
-    const SmlBwdSeg& sg = a.seg[sidx];
+    // (both segments' fields come in with the kernel arguments in one scalar-load burst and are selected here: a
+    // dynamically indexed a.seg[sidx] is a chain of dependent scalar loads at the very start of the kernel)
+    const SmlBwdSeg sg = sidx ? a.seg[1] : a.seg[0];
     const int row0 = (tile - (sidx ? a.tiles0 : 0)) * R;
-    if (tid < 104) cws[tid] = sg.theta[tid];
+    float cw_reg = 0.0f;
+    if (tid < 104) cw_reg = sg.theta[tid];      // parked in LDS below, once the other loads are on their way
     // Both GEMMs' operand images fit a register ring whole at d <= 64 (dA2: D/16 k-steps x 4 tiles, dA1: 4 k-steps
     // x 5 tiles per wave): they are fetched right after the pair-loss inputs below (loads return in issue order,
     // so the loss stage does not wait for them) and neither GEMM starts with an L2 round trip
@@ -688,32 +691,23 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
     // element-wise.  User tiles own the loss value (each triple once, coordinate slice 0).
     float* O3 = smem;                     // [3][R][D+1], aliases dZs (not yet live)
     float ou[EPT], oi[EPT], on[EPT];
+    // every global load of this kernel is issued before the first value is consumed (one memory round trip, not
+    // three): the planes of the three out rows here, then the tail's inputs, z1 and the operand rings
+    float vu[EPT][SML_FWD_NS], vi[EPT][SML_FWD_NS], vn[EPT][SML_FWD_NS];
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
         const int e = q * 512 + tid, r = e / D, w = e % D;
         const int row = row0 + r;
-        ou[q] = oi[q] = on[q] = 0.0f;
-        if (row < sg.n_rows) {
-            const int t = (sg.is_item && row >= a.B) ? row - a.B : row;
-            const float* pu = a.out_all + (int64_t)t * D + w;
-            const float* pi = a.out_all + (int64_t)(a.ioff + t) * D + w;
-            const float* pn = a.out_all + (int64_t)(a.ioff + a.B + t) * D + w;
-            // (all planes' loads in flight together; a runtime-bounded loop would take them one round trip at a time)
-            float vu[SML_FWD_NS], vi[SML_FWD_NS], vn[SML_FWD_NS];
+        const bool inr = row < sg.n_rows;
+        const int t = !inr ? 0 : ((sg.is_item && row >= a.B) ? row - a.B : row);
+        const float* pu = a.out_all + (int64_t)t * D + w;
+        const float* pi = a.out_all + (int64_t)(a.ioff + t) * D + w;
+        const float* pn = a.out_all + (int64_t)(a.ioff + a.B + t) * D + w;
 #pragma unroll
-            for (int p = 0; p < SML_FWD_NS; ++p) {
-                const bool live = p < a.out_np;
-                vu[p] = live ? pu[p * a.out_pstride] : 0.0f;
-                vi[p] = live ? pi[p * a.out_pstride] : 0.0f;
-                vn[p] = live ? pn[p * a.out_pstride] : 0.0f;
-            }
-#pragma unroll
-            for (int p = 0; p < SML_FWD_NS; ++p) { ou[q] += vu[p]; oi[q] += vi[p]; on[q] += vn[p]; }
-        }
-        if constexpr (D > 64) {           // a row spans two wavefronts: the scores go through LDS
-            O3[(0 * R + r) * (D + 1) + w] = ou[q];
-            O3[(1 * R + r) * (D + 1) + w] = oi[q];
-            O3[(2 * R + r) * (D + 1) + w] = on[q];
+        for (int p = 0; p < SML_FWD_NS; ++p) {
+            // unconditional loads (a dead plane or an out-of-range row re-reads a live address and is weighted by zero)
+            const int64_t po = (int64_t)min(p, a.out_np - 1) * a.out_pstride;
+            vu[q][p] = pu[po]; vi[q][p] = pi[po]; vn[q][p] = pn[po];
         }
     }
     // the tail's (x_t, x_hat, x_com) and this wave's z1 fragment: issue the loads now, use them later
@@ -732,6 +726,23 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
     if constexpr (PRE) {
         ring_preload<4, KSD>(ring2, p2b, KSD, 0, lane, tile2, nokofs);
         ring_preload<5, 4>(ring1, p1b, 32, wv * 4, lane, tile1, nokofs);
+    }
+    if (tid < 104) cws[tid] = cw_reg;
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int e = q * 512 + tid, r = e / D, w = e % D;
+        const float inr = (row0 + r < sg.n_rows) ? 1.0f : 0.0f;
+        ou[q] = oi[q] = on[q] = 0.0f;
+#pragma unroll
+        for (int p = 0; p < SML_FWD_NS; ++p) {      // planes added in index order
+            const float live = p < a.out_np ? inr : 0.0f;
+            ou[q] += live * vu[q][p]; oi[q] += live * vi[q][p]; on[q] += live * vn[q][p];
+        }
+        if constexpr (D > 64) {           // a row spans two wavefronts: the scores go through LDS
+            O3[(0 * R + r) * (D + 1) + w] = ou[q];
+            O3[(1 * R + r) * (D + 1) + w] = oi[q];
+            O3[(2 * R + r) * (D + 1) + w] = on[q];
+        }
     }
     float lsum = 0.0f;
     if constexpr (D <= 64) {
