@@ -429,17 +429,12 @@ __global__ __launch_bounds__(512) void k_transfer_bwd_full(SmlBwdArgs a) {
             const float* pu = a.out_all + (int64_t)t * D + w;
             const float* pi = a.out_all + (int64_t)(a.ioff + t) * D + w;
             const float* pn = a.out_all + (int64_t)(a.ioff + a.B + t) * D + w;
-            // (all planes' loads in flight together; a runtime-bounded loop would take them one round trip at a time)
-            float vu[SML_FWD_NS], vi[SML_FWD_NS], vn[SML_FWD_NS];
-#pragma unroll
-            for (int p = 0; p < SML_FWD_NS; ++p) {
-                const bool live = p < a.out_np;
-                vu[p] = live ? pu[p * a.out_pstride] : 0.0f;
-                vi[p] = live ? pi[p * a.out_pstride] : 0.0f;
-                vn[p] = live ? pn[p * a.out_pstride] : 0.0f;
+            // (this kernel runs behind the unsplit forward: one plane, as a rule)
+            for (int p = 0; p < a.out_np; ++p) {
+                ou[q] += pu[p * a.out_pstride];
+                oi[q] += pi[p * a.out_pstride];
+                on[q] += pn[p * a.out_pstride];
             }
-#pragma unroll
-            for (int p = 0; p < SML_FWD_NS; ++p) { ou[q] += vu[p]; oi[q] += vi[p]; on[q] += vn[p]; }
         }
         O3[(0 * R + r) * (D + 1) + w] = ou[q];
         O3[(1 * R + r) * (D + 1) + w] = oi[q];
