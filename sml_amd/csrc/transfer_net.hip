@@ -171,16 +171,43 @@ __global__ __launch_bounds__(512) void k_transfer_fwd(SmlFwdArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
     const int tile = (int)blockIdx.x / NS, h = (int)blockIdx.x % NS;
     const int sidx = tile >= a.tiles0;
-    const SmlSeg& sg = a.seg[sidx];
+    const SmlSeg sg = sidx ? a.seg[1] : a.seg[0];     // (static select: no dependent scalar loads at the kernel's start)
     const int row0 = (tile - (sidx ? a.tiles0 : 0)) * R;
     const float* __restrict__ theta = sg.theta;
-    if (tid < 104) cws[tid] = theta[tid];
+    float cw_reg = 0.0f;
+    if (tid < 104) cw_reg = theta[tid];               // parked in LDS once the other loads are on their way
     const bool lazy = sg.last_tab != nullptr;
     if (lazy) sched_window_load(swin, a.sched, a.cur_step - 1, tid);
     const bool saver = (h == 0);         // one workgroup of the NS writes the shared saves
 
+    // Hidden-split form: this wave's whole fc1 operand set (one column tile: 2 x KS1/2 k-steps) and its fc2 share fit a
+    // register ring at d = 32 -- fetched now, with the biases, so neither GEMM waits for the fabric (the images
+    // were rewritten by the previous batch's Adam step on other XCDs: their first read is a fabric round trip)
+    constexpr bool PRE = (CT == 1) && (KS1 / 2 <= 5);
+    constexpr int PF2 = KPW < 4 ? KPW : 4;
+    const f32x4* __restrict__ img1 = reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p1(D));
+    const f32x4* __restrict__ img2 = reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p2(D));
+    const int tile0 = h * (HL / 16) + wv * CT;
+    const int kq = wv % KSPL, jq = wv / KSPL;
+    auto t1 = [tile0](int) { return tile0; };
+    auto k1 = [](int t) { return t * (KS1 / 2); };
+    auto t2 = [jq](int t) { return jq * JTW + t; };
+    auto nokofs = [](int) { return 0; };
+    f32x4 ringf1[PRE ? 5 : 1][2], ringf2[PRE ? PF2 : 1][JTW];
+    if constexpr (PRE) {
+        ring_preload<2, 5>(ringf1, img1, KS1, 0, lane, t1, k1);
+        ring_preload<JTW, PF2>(ringf2, img2, 32, h * KL + kq * KPW, lane, t2, nokofs);
+    }
+    float bias1[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) bias1[t] = theta[sml_off_f1b(D) + h * HL + (wv * CT + t) * 16 + l15];
+    float bias2[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) bias2[q] = (h == 0) ? theta[sml_off_f2b(D) + (q * 512 + tid) % D] : 0.0f;
+
     // ---- P1: gather x_t and x_hat; all index loads, then all row loads, are in flight together
     float xt[EPT], xh[EPT];
+    float nr2[EPT];
     {
         int64_t idx[EPT];
         bool ok[EPT];
@@ -211,8 +238,16 @@ __global__ __launch_bounds__(512) void k_transfer_fwd(SmlFwdArgs a) {
         for (int q = 0; q < EPT; ++q) {
             const int e = q * 512 + tid;
             if (!ok[q]) { xt[q] = 1.0f; xh[q] = 0.0f; }
-            xts[(e / D) * (D + 1) + (e % D)] = xt[q];
+            if constexpr (D > 64) xts[(e / D) * (D + 1) + (e % D)] = xt[q];
+            else {
+                // ||x_t||^2: a row's D elements are D adjacent lanes of one wavefront
+                float s2 = xt[q] * xt[q];
+#pragma unroll
+                for (int off = D / 2; off >= 1; off >>= 1) s2 += __shfl_xor(s2, off, 64);
+                nr2[q] = s2;
+            }
         }
+        if (tid < 104) cws[tid] = cw_reg;
         __syncthreads();                   // xts, cws and the schedule window are in LDS
         if (lazy) {                        // replay the rows' pending zero-gradient Adam steps
 #pragma unroll
@@ -220,23 +255,22 @@ __global__ __launch_bounds__(512) void k_transfer_fwd(SmlFwdArgs a) {
                 if (ok[q]) adam_replay_w(xh[q], m[q], v[q], from[q], a.cur_step - 1, a.sched, swin, a.cur_step - 1);
         }
     }
-    if (tid < R) {
-        float s = 0.0f;
+    if constexpr (D > 64) {
+        if (tid < R) {
+            float s = 0.0f;
 #pragma unroll 8
-        for (int w = 0; w < D; ++w) { const float t = xts[tid * (D + 1) + w]; s += t * t; }
-        nrm[tid] = sqrtf(s);
+            for (int w = 0; w < D; ++w) { const float t = xts[tid * (D + 1) + w]; s += t * t; }
+            nrm[tid] = sqrtf(s);
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    // fc1 bias of this wave's columns: issued now, used after the first GEMM
-    float bias1[CT];
-#pragma unroll
-    for (int t = 0; t < CT; ++t) bias1[t] = theta[sml_off_f1b(D) + h * HL + (wv * CT + t) * 16 + l15];
     // ---- P2: x_com, conv1, Gelu, conv2, Gelu -> A1 tile (channel-major flatten c*D + w)
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
         const int e = q * 512 + tid, r = e / D, w = e % D;
         const int row = row0 + r;
-        const float xc = a.k2 ? 0.0f : (xt[q] * xh[q]) / nrm[r];     // no epsilon, as model/conv_transfer.py:99
+        const float nrow = D > 64 ? nrm[r] : sqrtf(nr2[q]);
+        const float xc = a.k2 ? 0.0f : (xt[q] * xh[q]) / nrow;     // no epsilon, as model/conv_transfer.py:99
         Pro p;
         conv_prologue(cws, xt[q], xh[q], xc, p);
 #pragma unroll
@@ -256,8 +290,7 @@ __global__ __launch_bounds__(512) void k_transfer_fwd(SmlFwdArgs a) {
 
     // ---- fc1: Z1[R x HL] = A1[R x K1] * W1^T[:, slice h] ; wave wv owns CT column tiles of the slice
     {
-        const f32x4* img = reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p1(D));
-        const int tile0 = h * (HL / 16) + wv * CT;
+        const f32x4* img = img1;
         float zt[MT][CT][4];
         if constexpr (CT >= 2) {
             f32x4 acc[MT][CT];
@@ -275,8 +308,8 @@ __global__ __launch_bounds__(512) void k_transfer_fwd(SmlFwdArgs a) {
             static_assert(KS1 % 2 == 0, "even k-steps");
             f32x4 acc[MT][2];
             zero_acc(acc);
-            mma16_rows_k<MT, 2, KS1 / 2, 5, true>(acc, A1s + l15 * S1 + 4 * g4, SML_TM * S1, img, KS1, 0, lane,
-                                                  [tile0](int) { return tile0; }, [](int t) { return t * (KS1 / 2); });
+            if constexpr (PRE) mma16_ring<MT, 2, KS1 / 2, 5, true>(acc, ringf1, A1s + l15 * S1 + 4 * g4, SML_TM * S1, img, KS1, 0, lane, t1, k1);
+            else mma16_rows_k<MT, 2, KS1 / 2, 5, true>(acc, A1s + l15 * S1 + 4 * g4, SML_TM * S1, img, KS1, 0, lane, t1, k1);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -299,21 +332,16 @@ __global__ __launch_bounds__(512) void k_transfer_fwd(SmlFwdArgs a) {
                 }
         }
     }
-    // fc2 bias for the final pass (plane 0 carries it)
-    float bias2[EPT];
-#pragma unroll
-    for (int q = 0; q < EPT; ++q) bias2[q] = (h == 0) ? theta[sml_off_f2b(D) + (q * 512 + tid) % D] : 0.0f;
     __syncthreads();
 
     // ---- fc2: Out[R x D] (+)= a2[R x HL] * W2^T[slice h, :] ; waves = KSPL (along K) x JSPL (column tiles)
     {
-        const int kq = wv % KSPL, jq = wv / KSPL;
         f32x4 acc[MT][JTW];
         zero_acc(acc);
         // the operand image is indexed by the global k-step, the LDS tile by the local one
-        mma16_rows<MT, JTW, KPW, (KPW < 4 ? KPW : 4)>(acc, a2s + l15 * S2 + 4 * g4 - h * HL, SML_TM * S2,
-                                                      reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p2(D)), 32,
-                                                      h * KL + kq * KPW, lane, [jq](int t) { return jq * JTW + t; });
+        if constexpr (PRE) mma16_ring<MT, JTW, KPW, PF2, false>(acc, ringf2, a2s + l15 * S2 + 4 * g4 - h * HL, SML_TM * S2, img2, 32,
+                                                                h * KL + kq * KPW, lane, t2, nokofs);
+        else mma16_rows<MT, JTW, KPW, PF2>(acc, a2s + l15 * S2 + 4 * g4 - h * HL, SML_TM * S2, img2, 32, h * KL + kq * KPW, lane, t2);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
