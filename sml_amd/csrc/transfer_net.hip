@@ -1044,12 +1044,19 @@ __global__ __launch_bounds__(512) void k_transfer_wgrad(SmlWgArgs a) {
         }
         return;
     }
-    const int net = (int)blockIdx.x / TN;
-    const int tl = (int)blockIdx.x % TN;
+    // XCD-aware tile map.  Every operand of this kernel was written by the previous launches on OTHER XCDs, so a
+    // tile's first read of each operand line crosses the fabric; workgroup b runs on XCD b % 8 (observed
+    // dispatch order: affinity only), so XCD x takes, for both nets, the dW1 tiles of hidden blocks {2x, 2x+1}
+    // (one eighth of dZ1's columns, all of A1) and the dW2 tiles of the same hidden blocks (one eighth of z1):
+    // each XCD pulls an eighth of the two big operands instead of nearly all of them
+    static_assert(TN % 8 == 0 && T2 == 16 * JT, "tile map");
+    constexpr int PER = 2 * (KT + JT);                 // tiles per XCD per net
+    const int xcd = (int)blockIdx.x % 8, kk = (int)blockIdx.x / 8;
+    const int net = kk / PER, rr = kk % PER;
     const SmlWgSeg& sg = a.seg[net];
-    const bool is_w1 = tl < T1;
+    const bool is_w1 = rr < 2 * KT;
     int ti, tj;                       // tile along output rows / cols
-    if (is_w1) { ti = tl / KT; tj = tl % KT; } else { ti = (tl - T1) / 16; tj = (tl - T1) % 16; }
+    if (is_w1) { ti = 2 * xcd + rr / KT; tj = rr % KT; } else { tj = 2 * xcd + (rr - 2 * KT) / JT; ti = (rr - 2 * KT) % JT; }
     const float* __restrict__ Asrc = is_w1 ? sg.dz1 : sg.dout;   // A[i][r] = Asrc[r][ti*32 + i]
     const int lda = is_w1 ? SML_HID : D;
     const float* __restrict__ Bsrc = is_w1 ? sg.a1 : sg.z1;      // B[r][j] = Bsrc[r][tj*32 + j]
