@@ -696,3 +696,39 @@ def test_g11_convtransfer_theta_gradient_via_one_tr_step_vs_oracle():
             assert np.abs(gt[k] - ot[k]).max() <= 2.0 * 1e-3 * 1.001
             continue
         adam_close(gt[k], ot[k], 1e-3, 1)
+
+
+@pytest.mark.parametrize("B,n", [(1, 3), (17, 40), (100, 250)])
+def test_ragged_batches_through_the_split_kernels_vs_oracle(B, n):
+    """Batch sizes that are no multiple of the 16-row tile (and a last batch shorter still): the hidden-split
+    forward, coordinate-split backward and the XCD-mapped weight-gradient kernel pad rows, never mix them."""
+    torch.manual_seed(B)
+    rng = np.random.RandomState(B + n)
+    U, I, d = 90, 70, 32
+    tri = np.stack([rng.randint(0, U, n), rng.randint(0, I, n), rng.randint(0, I, n)], 1)
+    base = make_mf(U, I, d)
+    with torch.no_grad():
+        base.user_laten.weight.mul_(0.3)
+        base.item_laten.weight.mul_(0.3)
+    net0 = make_transfer(d)
+    res = []
+    for eng, dev in ((engine(d), DEV), (O.OracleEngine(d), "cpu")):
+        mf = make_mf(U, I, d, base.user_laten.weight.detach().numpy(), base.item_laten.weight.detach().numpy(), device=dev)
+        net = make_transfer(d, device=dev)
+        net.load_state_dict({k: v.to(dev) for k, v in net0.state_dict().items()})
+        lu = (mf.user_laten.weight.detach() * 0.9).contiguous()
+        li = (mf.item_laten.weight.detach() * 0.9).contiguous()
+        l1 = eng.mf_stage_epoch(mf, net, lu, li, torch.from_numpy(tri), B, 0.01, 1e-6)
+        eng.mf_flush(mf)
+        hu, hi = mf.user_laten.weight.detach().clone(), mf.item_laten.weight.detach().clone()
+        l2 = eng.tr_stage_epoch(net, lu, li, hu, hi, torch.from_numpy(tri), B, 1e-3, 1e-4)
+        tonp = lambda x: x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+        res.append((tonp(l1), tonp(l2), tonp(hu), tonp(hi), {k: tonp(v) for k, v in net.state_dict().items()}))
+    g, o = res
+    np.testing.assert_allclose(g[0], o[0], rtol=1e-4)
+    np.testing.assert_allclose(g[1], o[1], rtol=1e-4)
+    steps = len(g[0])
+    adam_close(g[2], o[2], 0.01, steps)
+    adam_close(g[3], o[3], 0.01, steps)
+    for k in o[4]:
+        adam_close(g[4][k], o[4][k], 1e-3, steps)
