@@ -486,6 +486,7 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
         }
         f.tiles0 = wg_tiles(B, 1); f.cur_step = cur; f.sched = ctx->sched.p; f.out_pstride = out_pstride; f.k2 = ctx->variant == 1;
         const int tiles = f.tiles0 + wg_tiles(2 * B, 1);
+        f.tiles_total = tiles;
         ctx->prof.begin(PC_FWD, st); HIPCHK(sml_launch_fwd(d, 1, fns, f, tiles, st)); ctx->prof.end(st);
         SmlBwdArgs w;
         memset(&w, 0, sizeof(w));
@@ -583,6 +584,7 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
         }
         f.tiles0 = wg_tiles(B, 1); f.cur_step = 0; f.sched = nullptr; f.out_pstride = out_pstride; f.k2 = ctx->variant == 1;
         const int tiles = f.tiles0 + wg_tiles(2 * B, 1);
+        f.tiles_total = tiles;
         ctx->prof.begin(PC_FWD, st); HIPCHK(sml_launch_fwd(d, 1, fns, f, tiles, st)); ctx->prof.end(st);
         SmlBwdArgs w;
         memset(&w, 0, sizeof(w));

@@ -28,6 +28,7 @@ struct SmlFwdArgs {
     int cur_step;            // Adam step about to be applied (replay runs to cur_step-1)
     const SmlSched* sched;
     int64_t out_pstride;     // hidden-split forward (NS > 1): floats between the NS partial planes of `out`
+    int tiles_total;
     int k2;                  // ConvTransfer nets: kernel (2,1), the x_com row is zero
     int unit_rows;           // NS = 1 only: rows of seg[0] leave divided by their norm (ConvTransfer's user output)
 };

@@ -169,7 +169,15 @@ __global__ __launch_bounds__(512) void k_transfer_fwd(SmlFwdArgs a) {
     float* part = smem;                  // [KSPL][R][D+1], aliases A1s after fc1
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
-    const int tile = (int)blockIdx.x / NS, h = (int)blockIdx.x % NS;
+    // Workgroup b runs on XCD b % 8 (observed dispatch order; affinity only).  In the four-way hidden split, slice h
+    // goes to XCDs {2h, 2h+1} -- the XCDs whose weight-gradient workgroups rewrote exactly that slice of the
+    // operand images in the previous batch's Adam step (k_transfer_wgrad's tile map) -- and to no other.
+    int tile, h;
+    if constexpr (NS == 4) {
+        const int x = (int)blockIdx.x % 8;
+        h = x / 2; tile = 2 * ((int)blockIdx.x / 8) + (x % 2);
+        if (tile >= a.tiles_total) return;
+    } else { tile = (int)blockIdx.x / NS; h = (int)blockIdx.x % NS; }
     const int sidx = tile >= a.tiles0;
     const SmlSeg sg = sidx ? a.seg[1] : a.seg[0];     // (static select: no dependent scalar loads at the kernel's start)
     const int row0 = (tile - (sidx ? a.tiles0 : 0)) * R;
@@ -1223,7 +1231,7 @@ __global__ void k_selftest(const float* __restrict__ A, const float* __restrict_
 hipError_t sml_launch_fwd(int d, int mt, int ns, const SmlFwdArgs& a, int tiles_total, hipStream_t st) {
     if (tiles_total <= 0) return hipSuccess;
     if (mt == 1 && ns == 1) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 1, 1><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }
-    else if (mt == 1 && ns == 4) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 1, 4><<<dim3(tiles_total * 4), dim3(512), 0, st>>>(a)); }
+    else if (mt == 1 && ns == 4) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 1, 4><<<dim3(((tiles_total + 1) / 2) * 8), dim3(512), 0, st>>>(a)); }
     else if (mt == 1 && ns == 2) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 1, 2><<<dim3(tiles_total * 2), dim3(512), 0, st>>>(a)); }
     else if (mt == 2 && ns == 1) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 2, 1><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }
     else return hipErrorInvalidValue;
