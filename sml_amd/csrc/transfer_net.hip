@@ -157,7 +157,7 @@ __global__ __launch_bounds__(512) void k_transfer_fwd(SmlFwdArgs a) {
     constexpr int JSPL = 8 / KSPL;                                // ... x waves along the columns
     constexpr int JTW = JT / JSPL;
     constexpr int KPW = KL / KSPL;                                // fc2 k-steps per wave
-    static_assert(CT >= 1 && KPW >= 1 && MT * NS <= 4, "tiling");
+    static_assert(CT >= 1 && KPW >= 1 && MT * NS <= 4 && (R * D) % 512 == 0, "tiling");
     constexpr int REG0 = cmax(R * S1, KSPL * R * (D + 1));
     __shared__ __attribute__((aligned(16))) float smem[REG0 + cmax(R * S2, R * (D + 1) + R) + 104];
     __shared__ SmlSched swin[SML_SW];
@@ -1234,6 +1234,7 @@ hipError_t sml_launch_fwd(int d, int mt, int ns, const SmlFwdArgs& a, int tiles_
     else if (mt == 1 && ns == 4) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 1, 4><<<dim3(((tiles_total + 1) / 2) * 8), dim3(512), 0, st>>>(a)); }
     else if (mt == 1 && ns == 2) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 1, 2><<<dim3(tiles_total * 2), dim3(512), 0, st>>>(a)); }
     else if (mt == 2 && ns == 1) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 2, 1><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }
+    else if (mt == 3 && ns == 1 && d == 32) { k_transfer_fwd<32, 3, 1><<<dim3(tiles_total), dim3(512), 0, st>>>(a); }
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
