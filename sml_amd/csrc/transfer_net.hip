@@ -1130,14 +1130,15 @@ __global__ __launch_bounds__(512) void k_transfer_wgrad(SmlWgArgs a) {
     if (lane < 32) csum[wv][lane] = colsum;
     __syncthreads();
     float* __restrict__ g = sg.grad;
-    auto finish = [&](int off, float gsum, float p, float m, float v) {
+    __shared__ float wt[32][33];          // the tile's updated weights, for the operand-image refresh
+    auto finish = [&](int off, float gsum, float p, float m, float v) -> float {
         g[off] = gsum;
         if (fuse) {
             const int64_t i = (int64_t)net * NS + off;
             adam_apply(p, m, v, gsum + a.weight_decay * p, sc);
             a.theta[i] = p; a.m[i] = m; a.v[i] = v;
-            pack_store<D>(a.pk + (int64_t)net * sml_pk_size(D), off, p);
         }
+        return p;
     };
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -1145,13 +1146,39 @@ __global__ __launch_bounds__(512) void k_transfer_wgrad(SmlWgArgs a) {
         float s = 0.0f;
 #pragma unroll
         for (int w8 = 0; w8 < 8; ++w8) s += part[w8][i][j];
-        finish(woff[q], s, wp[q], wm[q], wvv[q]);
+        wt[i][j] = finish(woff[q], s, wp[q], wm[q], wvv[q]);
     }
     if (has_bias) {
         float s = 0.0f;
 #pragma unroll
         for (int w8 = 0; w8 < 8; ++w8) s += csum[w8][tid];
         finish(boff, s, bp, bm, bv2);
+    }
+    if (!fuse) return;
+    // Operand-image refresh.  A 32x32 weight tile is four whole (column tile, k-step) blocks of 64 lanes x 4 floats
+    // in EACH of its two images (forward and backward GEMM), i.e. eight contiguous 1 KB runs: one coalesced
+    // 16-byte store per thread instead of four scattered 4-byte ones.
+    __syncthreads();
+    {
+        const int img = tid >> 8, blk = (tid >> 6) & 3, ct = blk >> 1, ks = blk & 1, l = tid & 63;
+        const int r0 = ti * 32, c0 = tj * 32;          // the tile's first weight row / column
+        float* __restrict__ pkn = a.pk + (int64_t)net * sml_pk_size(D);
+        f32x4 v;
+        int64_t base;
+        if (img == 0) {
+            // forward image: columns = weight rows, reduction = weight columns
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = wt[ct * 16 + (l & 15)][ks * 16 + 4 * (l >> 4) + e];
+            const int ksteps = is_w1 ? K1 / 16 : SML_HID / 16;
+            base = (is_w1 ? sml_pk_p1(D) : sml_pk_p2(D)) + ((int64_t)((r0 >> 4) + ct) * ksteps + ((c0 >> 4) + ks)) * 256;
+        } else {
+            // backward image: columns = weight columns, reduction = weight rows
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = wt[ks * 16 + 4 * (l >> 4) + e][ct * 16 + (l & 15)];
+            const int ksteps = is_w1 ? SML_HID / 16 : D / 16;
+            base = (is_w1 ? sml_pk_p1b(D) : sml_pk_p2b(D)) + ((int64_t)((c0 >> 4) + ct) * ksteps + ((r0 >> 4) + ks)) * 256;
+        }
+        *reinterpret_cast<f32x4*>(pkn + base + l * 4) = v;
     }
 }
 
