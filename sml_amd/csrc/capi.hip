@@ -913,6 +913,35 @@ int sml_host_resolve_negatives(const int64_t* users, int64_t n, const int64_t* c
     return SML_OK;
 }
 
+int sml_host_resolve_negatives_csr(const int64_t* users, int64_t n, const int64_t* cand, int64_t m,
+                                   const int64_t* user_ptr, int64_t n_users, const int64_t* user_items, int64_t* negs,
+                                   int64_t* consumed, int64_t* resolved) {
+    if (!users || !cand || !user_ptr || !user_items || !negs || !consumed || !resolved || n < 0 || m < 0 || n_users < 0)
+        return fail(SML_EINVAL, "sml_host_resolve_negatives_csr", "bad argument");
+    int64_t ptr = 0, e = 0;
+    for (; e < n; ++e) {
+        const int64_t u = users[e];
+        int64_t b = 0, t = 0;
+        if (u >= 0 && u < n_users) { b = user_ptr[u]; t = user_ptr[u + 1]; }     // the user's own items, ascending
+        bool placed = false;
+        while (ptr < m) {
+            const int64_t c = cand[ptr++];
+            bool own = false;
+            if (t - b <= 8) { for (int64_t q = b; q < t; ++q) own |= (user_items[q] == c); }
+            else {
+                int64_t lo = b, hi = t;
+                while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (user_items[mid] < c) lo = mid + 1; else hi = mid; }
+                own = lo < t && user_items[lo] == c;
+            }
+            if (!own) { negs[e] = c; placed = true; break; }
+        }
+        if (!placed) break;                                    // stream ran out inside element e
+    }
+    *consumed = ptr;
+    *resolved = e;
+    return SML_OK;
+}
+
 int sml_selftest(int device) {
     DevGuard g(device);
     const int M = 16, K = 32;

@@ -104,6 +104,11 @@ class offlineDataset_withsample(Dataset):
         self._user_list = None                  # per-item access only: built on first use
         self._stride = int(self.item_all.max()) + 1
         self._pairs = np.unique(self.user.astype(np.int64) * self._stride + self.item.astype(np.int64))
+        # the same pairs in CSR form (user -> its items, ascending) for the compiled sequential resolver
+        pu = self._pairs // self._stride
+        self._n_users = int(pu.max()) + 1 if pu.size else 0
+        self._uptr = np.ascontiguousarray(np.searchsorted(pu, np.arange(self._n_users + 1)), dtype=np.int64)
+        self._uitems = np.ascontiguousarray(self._pairs % self._stride, dtype=np.int64)
 
     @property
     def user_list(self):
@@ -128,7 +133,7 @@ class offlineDataset_withsample(Dataset):
         """Same triples, and same numpy global-RNG end state, as calling __getitem__ for every
         index of `order` in turn.  np.random.choice(a, 1) is one legacy randint(0, len(a)) draw and a
         block of such draws is the same stream, so candidates are drawn in blocks and the sequential
-        accept/reject walk over them runs in compiled code (sml_host_resolve_negatives, a host-side
+        accept/reject walk over them runs in compiled code (sml_host_resolve_negatives_csr, a host-side
         helper of libsml_hip.so).  Each block holds exactly one candidate per still-unresolved element
         -- every one of which the per-item loop would draw too -- so the generator ends where it would."""
         import ctypes
@@ -139,17 +144,16 @@ class offlineDataset_withsample(Dataset):
         users = np.ascontiguousarray(self.user[order], dtype=np.int64)
         pop = self.item_all.shape[0]
         items_all = np.ascontiguousarray(self.item_all, dtype=np.int64)
-        pairs = np.ascontiguousarray(self._pairs, dtype=np.int64)
         negs = np.empty(n, dtype=np.int64)
         used, got = ctypes.c_int64(0), ctypes.c_int64(0)
         done, drawn = 0, 0
         while done < n:
             k = n - done
             cand = np.ascontiguousarray(items_all[np.random.randint(0, pop, size=k)])
-            rc = lib.sml_host_resolve_negatives(users.ctypes.data + 8 * done, k, cand.ctypes.data, k,
-                                                pairs.ctypes.data, pairs.shape[0], self._stride,
-                                                negs.ctypes.data + 8 * done, ctypes.byref(used), ctypes.byref(got))
-            _lib.check(rc, "sml_host_resolve_negatives")
+            rc = lib.sml_host_resolve_negatives_csr(users.ctypes.data + 8 * done, k, cand.ctypes.data, k,
+                                                    self._uptr.ctypes.data, self._n_users, self._uitems.ctypes.data,
+                                                    negs.ctypes.data + 8 * done, ctypes.byref(used), ctypes.byref(got))
+            _lib.check(rc, "sml_host_resolve_negatives_csr")
             done += got.value
             drawn += k
             if drawn > 64 * (n + 64):
