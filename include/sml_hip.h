@@ -232,6 +232,18 @@ int sml_prof_classes(void);
 const char* sml_prof_name(int cls);
 int sml_prof_get(sml_ctx* ctx, int cls, int64_t* count, double* total_ms);
 
+/* ---- device batch supply (fast mode) --------------------------------------------------- */
+/* offlineDataset_withsample's negatives (reference data/dataset.py:63-71) drawn ON THE DEVICE: for every
+ * element e, candidates uniform over item_all[0..pop) are redrawn while they are one of users[e]'s own
+ * items (CSR: user_ptr [n_users+1] into ascending user_items; all device pointers).  Same distribution as
+ * the reference's loop, NOT its numpy random stream: the driver uses it only when asked
+ * (--device_batches); the stream-exact host path (sml_host_resolve_negatives_csr) is the default.
+ * Counter-based generator keyed by (seed, e): reproducible for a given seed.  *failed (device int32) counts
+ * elements left at -1 after 4096 rejected draws. */
+int sml_sample_negatives(sml_ctx* ctx, const int64_t* users, int64_t n, const int64_t* item_all, int64_t pop,
+                         const int64_t* user_ptr, int64_t n_users, const int64_t* user_items, uint64_t seed,
+                         int64_t* negs, int32_t* failed, void* stream);
+
 /* ---- host helper: batch supply ------------------------------------------------------- */
 /* Sequential rejection sampling of offlineDataset_withsample.__getitem__ (reference
  * data/dataset.py:63-71) over a pre-drawn candidate stream, on the HOST (no GPU involved):

@@ -83,6 +83,8 @@ SIGNATURES = {
     "sml_prof_classes": (ctypes.c_int, []),
     "sml_prof_name": (ctypes.c_char_p, [ctypes.c_int]),
     "sml_prof_get": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]),
+    "sml_sample_negatives": (ctypes.c_int, [c_void, c_void, ctypes.c_int64, c_void, ctypes.c_int64, c_void, ctypes.c_int64, c_void,
+                                            ctypes.c_uint64, c_void, c_void, c_void]),
     "sml_host_resolve_negatives": (ctypes.c_int, [c_void, ctypes.c_int64, c_void, ctypes.c_int64, c_void, ctypes.c_int64,
                                                   ctypes.c_int64, c_void, ctypes.POINTER(ctypes.c_int64),
                                                   ctypes.POINTER(ctypes.c_int64)]),

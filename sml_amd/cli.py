@@ -43,6 +43,9 @@ _COMMON = [
     ("--tqdm", dict(type=bool, default=False, help='(unused)')),
     ("--need_writer", dict(type=bool, default=False, help='tensorboard summaries')),
     ("--test_in_TR_Train", dict(type=bool, default=False, help='(unused)')),
+    # extension (not a reference flag): draw the transfer stage's shuffles and negatives on the GPU -- the same
+    # distribution, not the reference's numpy/torch random streams (default: stream-exact host path)
+    ("--device_batches", dict(type=int, default=0, help='1: build the transfer stage batches on the device (not stream-exact)')),
 ]
 
 _PER_DATASET = {

@@ -913,6 +913,21 @@ int sml_host_resolve_negatives(const int64_t* users, int64_t n, const int64_t* c
     return SML_OK;
 }
 
+int sml_sample_negatives(sml_ctx* ctx, const int64_t* users, int64_t n, const int64_t* item_all, int64_t pop,
+                         const int64_t* user_ptr, int64_t n_users, const int64_t* user_items, uint64_t seed, int64_t* negs,
+                         int32_t* failed, void* stream) {
+    if (!ctx || !users || !item_all || !user_ptr || !user_items || !negs || !failed || n < 0 || pop <= 0 || n_users < 0)
+        return fail(SML_EINVAL, "sml_sample_negatives", "bad argument");
+    if (n == 0) return SML_OK;
+    DevGuard g(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(failed, 0, sizeof(int32_t), st));
+    ctx->prof.begin(PC_MISC, st);
+    HIPCHK(sml_launch_sample_negatives(users, n, item_all, pop, user_ptr, n_users, user_items, seed, negs, failed, st));
+    ctx->prof.end(st);
+    return SML_OK;
+}
+
 int sml_host_resolve_negatives_csr(const int64_t* users, int64_t n, const int64_t* cand, int64_t m,
                                    const int64_t* user_ptr, int64_t n_users, const int64_t* user_items, int64_t* negs,
                                    int64_t* consumed, int64_t* resolved) {

@@ -800,6 +800,41 @@ __global__ __launch_bounds__(256) void k_eval_ranks_bucketed(const float* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------
+// On-device batch supply (fast mode; the reference-exact numpy stream stays on the host): for every
+// (user, item) pair of an epoch, a negative drawn uniformly from the period's item set, redrawn while it is
+// one of the user's own items (data/dataset.py:63-71 as a distribution, not as a random-number stream).
+// Counter-based generator: element e of epoch `seed` always gets the same draws, whatever the launch shape.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t& s) {
+    uint64_t z = (s += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void k_sample_negatives(const int64_t* __restrict__ users, int64_t n,
+                                                          const int64_t* __restrict__ item_all, int64_t pop,
+                                                          const int64_t* __restrict__ user_ptr, int64_t n_users,
+                                                          const int64_t* __restrict__ user_items, uint64_t seed,
+                                                          int64_t* __restrict__ negs, int* __restrict__ failed) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const int64_t u = users[e];
+    int64_t b = 0, t = 0;
+    if (u >= 0 && u < n_users) { b = user_ptr[u]; t = user_ptr[u + 1]; }
+    uint64_t st = seed ^ ((uint64_t)e * 0xd1342543de82ef95ull + 0x632be59bd9b4e019ull);
+    int64_t c = -1;
+    for (int tries = 0; tries < 4096; ++tries) {
+        const uint64_t r = splitmix64(st);
+        const int64_t cand = item_all[(int64_t)__umul64hi(r, (uint64_t)pop)];      // uniform over [0, pop)
+        int64_t lo = b, hi = t;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (user_items[mid] < cand) lo = mid + 1; else hi = mid; }
+        if (!(lo < t && user_items[lo] == cand)) { c = cand; break; }
+    }
+    if (c < 0) atomicAdd(failed, 1);            // a user who owns (almost) every item of the period
+    negs[e] = c;
+}
+
 // hits and NDCG sum over ranks (model/MF.py:60-78): hit iff rank < topk, NDCG = 1/log2(rank+2).
 // One 1024-thread block; fixed reduction tree (deterministic).
 __global__ __launch_bounds__(1024) void k_eval_metrics(const int32_t* __restrict__ rank, int64_t n, int topk,
@@ -955,6 +990,14 @@ hipError_t sml_launch_eval_ranks_bucketed(int d, const float* wu, const float* w
     if (max_blocks > 0 && nb > max_blocks) nb = (max_blocks / SML_EVB > 0 ? max_blocks / SML_EVB : 1) * SML_EVB;
     if (nb > 0x7fffffff) nb = 0x7fffff00;
     SML_DISPATCH_D(d, k_eval_ranks_bucketed<DD><<<dim3((unsigned)nb), dim3(256), 0, st>>>(wu, wi, rows_b, bucket_off, n, n_cols, rank));
+    return hipGetLastError();
+}
+hipError_t sml_launch_sample_negatives(const int64_t* users, int64_t n, const int64_t* item_all, int64_t pop, const int64_t* user_ptr,
+                                       int64_t n_users, const int64_t* user_items, uint64_t seed, int64_t* negs, int* failed,
+                                       hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    k_sample_negatives<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(users, n, item_all, pop, user_ptr, n_users, user_items,
+                                                                              seed, negs, failed);
     return hipGetLastError();
 }
 hipError_t sml_launch_eval_metrics(const int32_t* rank, int64_t n, int topk, float* out, hipStream_t st) {

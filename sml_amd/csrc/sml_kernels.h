@@ -167,4 +167,7 @@ hipError_t sml_launch_eval_bucketize(const int64_t* rows, int64_t n, int n_cols,
 hipError_t sml_launch_eval_ranks_bucketed(int d, const float* wu, const float* wi, const int32_t* rows_b,
                                           const int32_t* bucket_off, int64_t n, int n_cols, int32_t* rank, int max_blocks,
                                           hipStream_t st);
+hipError_t sml_launch_sample_negatives(const int64_t* users, int64_t n, const int64_t* item_all, int64_t pop, const int64_t* user_ptr,
+                                       int64_t n_users, const int64_t* user_items, uint64_t seed, int64_t* negs, int* failed,
+                                       hipStream_t st);
 hipError_t sml_launch_eval_metrics(const int32_t* rank, int64_t n, int topk, float* out, hipStream_t st);

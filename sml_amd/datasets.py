@@ -161,6 +161,26 @@ class offlineDataset_withsample(Dataset):
         return np.stack([users, self.item[order].astype(np.int64), negs], axis=1)
 
 
+    def epoch_triples_device(self, engine, seed):
+        """One shuffled pass with fresh negatives, built ON THE DEVICE (fast mode: the same distribution as
+        epoch_triples, not the reference's random streams): a device permutation, two gathers and
+        engine.sample_negatives.  Returns an int64 [n,3] device tensor; nothing crosses PCIe per epoch."""
+        import torch
+        dev = engine.device
+        cache = self.__dict__.setdefault("_dev_cache", {})
+        c = cache.get(str(dev))
+        if c is None:
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(dev)
+            c = cache[str(dev)] = dict(user=t(self.user), item=t(self.item), item_all=t(self.item_all), uptr=t(self._uptr),
+                                       uitems=t(self._uitems), gen=torch.Generator(device=dev))
+        c["gen"].manual_seed(int(seed) & (2 ** 62 - 1))
+        perm = torch.randperm(len(self), device=dev, generator=c["gen"])
+        users, items = c["user"][perm], c["item"][perm]
+        negs, failed = engine.sample_negatives(users, c["item_all"], c["uptr"], c["uitems"], int(seed) + 1)
+        self._last_failed = failed            # device counter; checked lazily by the caller if it cares
+        return torch.stack([users, items, negs], dim=1).contiguous()
+
+
 class transfer_data(object):
     """Per-stage period data (reference data/dataset2.py:203-351).
 

@@ -326,8 +326,13 @@ class meta_train(object):
         s_time = time.time()
         for epoch in range(args.TR_epochs):
             self.transfer.train()
-            order = D.loader_order(len(train_set), shuffle=True)
-            triples = train_set.epoch_triples(order)
+            if getattr(args, "device_batches", 0) and hasattr(train_set, "epoch_triples_device") \
+                    and hasattr(self.engine, "sample_negatives"):
+                # fast mode: permutation and rejection-sampled negatives on the device (same distribution, other streams)
+                triples = train_set.epoch_triples_device(self.engine, int(torch.randint(0, 2 ** 62, (1,))))
+            else:
+                order = D.loader_order(len(train_set), shuffle=True)
+                triples = train_set.epoch_triples(order)
             t0 = time.time()
             losses = self.engine.tr_stage_epoch(self.transfer, self.last_user_weight, self.last_item_weight,
                                                 self.user_weight_hat, self.item_weight_hat, triples,

@@ -316,6 +316,19 @@ class HipEngine(object):
         self.mf_step = step.value
         return losses
 
+    # ------------------------------------------------------------------ device batch supply (fast mode)
+    def sample_negatives(self, users, item_all, user_ptr, user_items, seed):
+        """A negative per element of `users` (device int64), uniform over item_all, never one of the user's own items
+        (CSR user_ptr / user_items, device int64).  Distribution of the reference's sampler, not its numpy stream."""
+        users = self._dev(users, torch.int64)
+        n = users.shape[0]
+        negs = torch.empty(n, device=self.device, dtype=torch.int64)
+        failed = torch.zeros(1, device=self.device, dtype=torch.int32)
+        check(self.lib.sml_sample_negatives(self._ctx, _ptr(users), n, _ptr(item_all), item_all.shape[0], _ptr(user_ptr),
+                                            user_ptr.shape[0] - 1, _ptr(user_items), ctypes.c_uint64(int(seed) & (2 ** 64 - 1)),
+                                            _ptr(negs), _ptr(failed), self._stream()), "sml_sample_negatives")
+        return negs, failed
+
     # ------------------------------------------------------------------ a2
     def mf_forward(self, w_user, w_item, user, item, norm=False):
         wu, wi = self._table(w_user), self._table(w_item)

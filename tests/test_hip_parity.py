@@ -732,3 +732,58 @@ def test_ragged_batches_through_the_split_kernels_vs_oracle(B, n):
     adam_close(g[3], o[3], 0.01, steps)
     for k in o[4]:
         adam_close(g[4][k], o[4][k], 1e-3, steps)
+
+
+# ----------------------------------------------------------------------------- device batch supply (fast mode)
+def test_device_sampler_distribution_and_constraints():
+    """engine.sample_negatives / offlineDataset_withsample.epoch_triples_device: every negative belongs to the period's
+    item set and is never one of the user's own items; the draw is uniform over the allowed items (chi-square on a user
+    with few forbidden items); reproducible for a seed; a pass is a permutation of the pairs."""
+    from sml_amd.datasets import offlineDataset_withsample
+    rng = np.random.RandomState(3)
+    U, I, n = 50, 40, 400                 # ~8 of the 20 occurring items per user
+    pairs = np.stack([rng.randint(0, U, n), rng.randint(0, I // 2, n) * 2], 1).astype(np.int64)   # only even items occur
+    with quiet():
+        ds = offlineDataset_withsample(pairs)
+    eng = engine(32)
+    t1 = ds.epoch_triples_device(eng, 123).cpu().numpy()
+    t2 = ds.epoch_triples_device(eng, 123).cpu().numpy()
+    t3 = ds.epoch_triples_device(eng, 124).cpu().numpy()
+    assert int(ds._last_failed.cpu()) == 0
+    assert np.array_equal(t1, t2) and not np.array_equal(t1, t3)
+    # a pass is a permutation of the (user, item) pairs
+    key = lambda a: np.sort(a[:, 0] * 1000 + a[:, 1])
+    assert np.array_equal(key(t1), key(pairs))
+    assert not np.array_equal(t1[:, :2], pairs)                      # ... and a shuffled one
+    own = {}
+    for u, i in pairs:
+        own.setdefault(int(u), set()).add(int(i))
+    assert all(int(j) % 2 == 0 for j in t1[:, 2])                    # drawn from the items of the set
+    assert all(int(j) not in own[int(u)] for u, _, j in t1)          # never the user's own
+    # uniformity: pool the negatives of many epochs for one user and compare with the allowed items
+    u0 = int(np.bincount(pairs[:, 0]).argmax())
+    allowed = sorted(set(range(0, I, 2)) - own[u0])
+    cnt = np.zeros(I)
+    for s in range(200):
+        t = ds.epoch_triples_device(eng, 1000 + s).cpu().numpy()
+        np.add.at(cnt, t[t[:, 0] == u0, 2], 1)
+    obs = cnt[allowed]
+    if len(allowed) > 1:
+        exp = obs.sum() / len(allowed)
+        chi2 = ((obs - exp) ** 2 / exp).sum()
+        assert chi2 < 3.0 * len(allowed) + 30, (chi2, len(allowed))
+    assert cnt.sum() == obs.sum()
+
+
+def test_driver_runs_with_device_batches(tmp_path, monkeypatch):
+    """--device_batches 1: the driver's control flow with the TR batches drawn on the device (statistically, not
+    stream-wise, the reference): it runs the tiny 29-stage sequence and lands on comparable final averages."""
+    from test_host_logic import run_g7
+    from sml_amd import cli
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    real_main = cli.main
+    monkeypatch.setattr(cli, "main", lambda which, argv: real_main(which, list(argv) + ["--device_batches", "1"]))
+    got, want = run_g7(tmp_path, monkeypatch)
+    fin = lambda log, key: float([l for l in log.splitlines() if l.startswith(key)][0].split(":")[1])
+    for key in ("test average recall@20", "val average recall@20"):
+        assert abs(fin(got, key) - fin(want, key)) <= 0.05, key
