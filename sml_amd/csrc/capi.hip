@@ -630,7 +630,6 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
                 const int hr = grad_hook(hook_user, grad, 2 * ns, b);
                 if (hr != 0) return fail(SML_ESTATE, "sml_tr_stage_epoch", "grad_hook failed");
             }
-            ad.grad_only = 0; ad.convg_part = nullptr;   // conv gradients are already in `grad`
             ctx->prof.begin(PC_THETA_ADAM, st); HIPCHK(sml_launch_theta_adam(d, ad, st)); ctx->prof.end(st);
         }
     }

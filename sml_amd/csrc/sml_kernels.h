@@ -73,9 +73,6 @@ struct SmlWgArgs {
 
 struct SmlThetaAdamArgs {
     float* theta; float* m; float* v; float* grad; float* pk;
-    const float* convg_part; // null: conv gradients already in grad (after an all-reduce)
-    int tiles0, tiles_total;
-    int grad_only;           // 1: only finish the flat gradient (sum the conv partials), no update
     float weight_decay, step_size, bc2_sqrt;
 };
 

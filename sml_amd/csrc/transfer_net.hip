@@ -1201,22 +1201,8 @@ __global__ __launch_bounds__(256) void k_theta_adam(SmlThetaAdamArgs a) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= 2 * NS) return;
     const int net = i / NS, off = i % NS;
-    float g;
-    if (off < SML_OFF_F1W) {
-        if (!conv_slot_used_host(off)) return;
-        if (a.convg_part != nullptr) {
-            g = 0.0f;
-            const int t0 = net ? a.tiles0 : 0, t1 = net ? a.tiles_total : a.tiles0;
-            const int c = conv_compact(off);
-            for (int t = t0; t < t1; ++t) g += a.convg_part[(int64_t)t * SML_CG + c];
-            a.grad[i] = g;                           // keep the flat gradient complete (all-reduce input)
-        } else {
-            g = a.grad[i];
-        }
-    } else {
-        g = a.grad[i];
-    }
-    if (a.grad_only) return;
+    if (off < SML_OFF_F1W && !conv_slot_used_host(off)) return;       // alignment padding of the conv block
+    float g = a.grad[i];                                              // complete (and all-reduced) flat gradient
     float p = a.theta[i], m = a.m[i], v = a.v[i];
     g = g + a.weight_decay * p;
     SmlSched s; s.step_size = a.step_size; s.bc2_sqrt = a.bc2_sqrt;
