@@ -299,3 +299,32 @@ def test_baseline_finetune_loop_replays_reference_batches_and_log():
     np.testing.assert_allclose(sp.recall[-1], g["recall_5_10_20"], atol=1e-9)
     np.testing.assert_allclose(sp.ndcg[-1], g["ndcg_5_10_20"], atol=1e-5)
     assert "before train test---" in log and "FInal test---" in log and "max result " in log
+
+
+def test_csr_resolver_equals_pair_list_resolver():
+    """sml_host_resolve_negatives_csr (two memory touches per candidate) walks the candidate stream exactly as
+    sml_host_resolve_negatives (bisection of the sorted pair list) does: same negatives, same consumption, also
+    when the stream runs out mid-element and for users with long item lists."""
+    from sml_amd import _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(9)
+    U, I, n_pairs = 40, 30, 500
+    pairs = np.unique(rng.randint(0, U, n_pairs).astype(np.int64) * I + rng.randint(0, I, n_pairs))
+    pu = pairs // I
+    uptr = np.ascontiguousarray(np.searchsorted(pu, np.arange(U + 1)), dtype=np.int64)
+    uitems = np.ascontiguousarray(pairs % I, dtype=np.int64)
+    for n, m in ((200, 200), (200, 120), (1, 1), (64, 1000)):
+        users = np.ascontiguousarray(rng.randint(0, U, n), dtype=np.int64)
+        cand = np.ascontiguousarray(rng.randint(0, I, m), dtype=np.int64)
+        out = []
+        for fn, extra in ((lib.sml_host_resolve_negatives, (pairs.ctypes.data, pairs.shape[0], I)),
+                          (lib.sml_host_resolve_negatives_csr, (uptr.ctypes.data, U, uitems.ctypes.data))):
+            negs = np.full(n, -7, dtype=np.int64)
+            used, got = ctypes.c_int64(0), ctypes.c_int64(0)
+            rc = fn(users.ctypes.data, n, cand.ctypes.data, m, *extra, negs.ctypes.data, ctypes.byref(used), ctypes.byref(got))
+            assert rc == 0
+            out.append((negs[:got.value].copy(), used.value, got.value))
+        assert out[0][1:] == out[1][1:]
+        assert np.array_equal(out[0][0], out[1][0])
+        own = set(pairs.tolist())
+        assert all(int(u) * I + int(c) not in own for u, c in zip(users[:out[1][2]], out[1][0]))
