@@ -147,7 +147,7 @@ struct sml_ctx {
     int variant = 0;         // 0: ConvTransfer_com, 1: ConvTransfer (sml_ctx_set_variant)
     IndexSet ix[2];
     // transfer-net workspaces, 3*B slots each
-    Buf<float> out, dout, dx, xin, z1, a1, dz1;
+    Buf<float> out, dout, dx, xin, z1, a1, dz1, mrep, vrep;
     Buf<float> pk, grad, convg, loss_part;
     // Adam schedule of the MF optimiser
     Buf<SmlSched> sched;
@@ -164,6 +164,7 @@ struct sml_ctx {
     void release_all() {
         prof.release();
         out.release(); dout.release(); dx.release(); xin.release(); z1.release(); a1.release(); dz1.release();
+        mrep.release(); vrep.release();
         pk.release(); grad.release(); convg.release(); loss_part.release();
         ix[0].release(); ix[1].release();
         sched.release(); dummy.release(); rec_x.release();
@@ -235,6 +236,7 @@ int ensure_transfer_ws(sml_ctx* c, int B, bool tr_stage) {
         HIPCHK(c->grad.ensure((size_t)2 * sml_net_size(c->d)));
     } else {
         HIPCHK(c->dx.ensure(slots * d));
+        HIPCHK(c->mrep.ensure(slots * d)); HIPCHK(c->vrep.ensure(slots * d));
     }
     return SML_OK;
 }
@@ -485,6 +487,7 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
             const int64_t slot0 = s ? (int64_t)SML_R * tiles_of(B) : 0;
             sg.out = ctx->out.p + slot0 * d; sg.z1 = ctx->z1.p + slot0 * SML_HID; sg.xin = ctx->xin.p + slot0 * 3 * d;
             sg.a1 = nullptr;
+            sg.mrep = ctx->mrep.p + slot0 * d; sg.vrep = ctx->vrep.p + slot0 * d;
         }
         f.tiles0 = wg_tiles(B, 1); f.cur_step = cur; f.sched = ctx->sched.p; f.out_pstride = out_pstride; f.k2 = ctx->variant == 1;
         const int tiles = f.tiles0 + wg_tiles(2 * B, 1);
@@ -524,6 +527,9 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
         }
         u.m_user = t->m_user; u.v_user = t->v_user; u.m_item = t->m_item; u.v_item = t->v_item;
         u.last_user = t->step_user; u.last_item = t->step_item; u.sched = ctx->sched.p; u.cur_step = cur; u.lr = lr;
+        // rows continue from the forward's replayed copies (local scratch; the multi-GPU item list's slots index the
+        // all-gathered buffer instead, so item rows are replayed from the table there)
+        u.rep_x = ctx->xin.p; u.rep_m = ctx->mrep.p; u.rep_v = ctx->vrep.p; u.rep_u = 1; u.rep_i = xchg ? 0 : 1;
         ctx->prof.begin(PC_SEG_ADAM, st); HIPCHK(sml_launch_run_adam(d, u, (int64_t)u.n_u + u.n_i, st)); ctx->prof.end(st);
     }
     ctx->prof.begin(PC_MISC, st); HIPCHK(sml_launch_loss_finalize(ctx->loss_part.p, (int)nb, lstride, nullptr, batch_loss, st)); ctx->prof.end(st);

@@ -475,11 +475,24 @@ __global__ __launch_bounds__(256) void k_run_update(SmlRunArgs a) {
         float m[4] = {0.f, 0.f, 0.f, 0.f}, v[4] = {0.f, 0.f, 0.f, 0.f};
         int from = 0;
         if (head) {
-            RowVec<T>::load(w + row * D + sub * VEC, p);
+            bool from_scratch = false;
+            if constexpr (OPT == 1) from_scratch = a.rep_x != nullptr && (is_item ? a.rep_i : a.rep_u);
             if constexpr (OPT == 1) {
-                RowVec<float>::load((is_item ? a.m_item : a.m_user) + row * D + sub * 4, m);
-                RowVec<float>::load((is_item ? a.v_item : a.v_user) + row * D + sub * 4, v);
-                from = (is_item ? a.last_item : a.last_user)[row];
+                if (from_scratch) {
+                    // the forward's replayed copy of this row (any occurrence holds the same values: the first one)
+                    const int64_t s0 = run.slot[0];
+                    RowVec<float>::load(a.rep_x + (s0 * 3 + 1) * D + sub * 4, reinterpret_cast<float(&)[4]>(p[0]));
+                    RowVec<float>::load(a.rep_m + s0 * D + sub * 4, m);
+                    RowVec<float>::load(a.rep_v + s0 * D + sub * 4, v);
+                    from = a.cur_step - 1;
+                } else {
+                    RowVec<T>::load(w + row * D + sub * VEC, p);
+                    RowVec<float>::load((is_item ? a.m_item : a.m_user) + row * D + sub * 4, m);
+                    RowVec<float>::load((is_item ? a.v_item : a.v_user) + row * D + sub * 4, v);
+                    from = (is_item ? a.last_item : a.last_user)[row];
+                }
+            } else {
+                RowVec<T>::load(w + row * D + sub * VEC, p);
             }
         }
         float g[VEC];

@@ -21,6 +21,7 @@ struct SmlSeg {
     float* z1;               // optional saves for backward
     float* xin;              // [n_rows, 3, d]  (x_t, x_hat, x_com)
     float* a1;               // [n_rows, 5d]
+    float* mrep; float* vrep;   // lazy gather: [n_rows, d] the rows' Adam moments after the replay (for the row update)
 };
 struct SmlFwdArgs {
     SmlSeg seg[2];
@@ -109,6 +110,10 @@ struct SmlRunArgs {
     float* m_user; float* v_user; float* m_item; float* v_item;   // Adam only
     int32_t* last_user; int32_t* last_item;                       // Adam only
     const SmlSched* sched; int cur_step;                          // Adam only
+    // Adam, MF stage: the forward already replayed every gathered row's pending zero-gradient steps; it left the
+    // replayed row in xin[slot][1] and the moments in rep_m / rep_v [slot]: the update starts from those (no second
+    // replay, no table read).  rep_u / rep_i: which of the two lists' slots index that local scratch.
+    const float* rep_x; const float* rep_m; const float* rep_v; int rep_u, rep_i;
     float lr;                                                     // SGD only
     // hot rows (SGD, large batches): runs longer than SML_HOT are listed here (by the index preparation)
     // instead of being summed by one wavefront; the first hot_blocks workgroups of the run kernel reduce

@@ -261,6 +261,15 @@ __global__ __launch_bounds__(512) void k_transfer_fwd(SmlFwdArgs a) {
 #pragma unroll
             for (int q = 0; q < EPT; ++q)
                 if (ok[q]) adam_replay_w(xh[q], m[q], v[q], from[q], a.cur_step - 1, a.sched, swin, a.cur_step - 1);
+            if (saver && sg.mrep != nullptr) {     // the row update continues from here: it need not replay again
+#pragma unroll
+                for (int q = 0; q < EPT; ++q) {
+                    const int e = q * 512 + tid;
+                    const int64_t o = (int64_t)(row0 + e / D) * D + (e % D);
+                    sg.mrep[o] = ok[q] ? m[q] : 0.0f;
+                    sg.vrep[o] = ok[q] ? v[q] : 0.0f;
+                }
+            }
         }
     }
     if constexpr (D > 64) {
