@@ -530,6 +530,7 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
         // rows continue from the forward's replayed copies (local scratch; the multi-GPU item list's slots index the
         // all-gathered buffer instead, so item rows are replayed from the table there)
         u.rep_x = ctx->xin.p; u.rep_m = ctx->mrep.p; u.rep_v = ctx->vrep.p; u.rep_u = 1; u.rep_i = xchg ? 0 : 1;
+        u.rep_x_stride = 3 * d; u.rep_x_off = d;
         ctx->prof.begin(PC_SEG_ADAM, st); HIPCHK(sml_launch_run_adam(d, u, (int64_t)u.n_u + u.n_i, st)); ctx->prof.end(st);
     }
     ctx->prof.begin(PC_MISC, st); HIPCHK(sml_launch_loss_finalize(ctx->loss_part.p, (int)nb, lstride, nullptr, batch_loss, st)); ctx->prof.end(st);
@@ -730,6 +731,7 @@ int sml_embed_loss_adam_epoch(sml_ctx* ctx, const sml_mf_tables* t, const int64_
     int rc;
     if ((rc = ensure_sched(ctx, lr, *step + nb + 1))) return rc;
     HIPCHK(ctx->dx.ensure((size_t)3 * batch * d));
+    HIPCHK(ctx->xin.ensure((size_t)3 * batch * d)); HIPCHK(ctx->mrep.ensure((size_t)3 * batch * d)); HIPCHK(ctx->vrep.ensure((size_t)3 * batch * d));
     const int lstride = (int)(((int64_t)batch * (d / 4) + 255) / 256);
     HIPCHK(ctx->loss_part.ensure((size_t)nb * lstride));
     ctx->prof.begin(PC_SORT, st); rc = sort_epoch(&ctx->ix[0], triples, n, batch, 0, t->n_user, t->n_item, false, st); ctx->prof.end(st);
@@ -744,6 +746,7 @@ int sml_embed_loss_adam_epoch(sml_ctx* ctx, const sml_mf_tables* t, const int64_
         a.loss_part = ctx->loss_part.p + b * lstride; a.kind = loss_kind; a.lam_user = lam_user; a.lam_item = lam_item;
         a.m_user = t->m_user; a.v_user = t->v_user; a.m_item = t->m_item; a.v_item = t->v_item;
         a.last_user = t->step_user; a.last_item = t->step_item; a.sched = ctx->sched.p; a.cur_step = cur;
+        a.xrep = ctx->xin.p; a.mrep = ctx->mrep.p; a.vrep = ctx->vrep.p;
         ctx->prof.begin(PC_BARE_GRAD, st); HIPCHK(sml_launch_bare_grad(d, 4, a, nullptr, st)); ctx->prof.end(st);
         SmlRunArgs u;
         memset(&u, 0, sizeof(u));
@@ -752,6 +755,7 @@ int sml_embed_loss_adam_epoch(sml_ctx* ctx, const sml_mf_tables* t, const int64_
         u.dx = ctx->dx.p; u.dx_i = ctx->dx.p; u.w_user = t->w_user; u.w_item = t->w_item;
         u.m_user = t->m_user; u.v_user = t->v_user; u.m_item = t->m_item; u.v_item = t->v_item;
         u.last_user = t->step_user; u.last_item = t->step_item; u.sched = ctx->sched.p; u.cur_step = cur; u.lr = lr;
+        u.rep_x = ctx->xin.p; u.rep_m = ctx->mrep.p; u.rep_v = ctx->vrep.p; u.rep_u = 1; u.rep_i = 1; u.rep_x_stride = d; u.rep_x_off = 0;
         ctx->prof.begin(PC_SEG_ADAM, st); HIPCHK(sml_launch_run_adam(d, u, (int64_t)3 * B, st)); ctx->prof.end(st);
     }
     ctx->prof.begin(PC_MISC, st); HIPCHK(sml_launch_loss_finalize(ctx->loss_part.p, (int)nb, lstride, nullptr, batch_loss, st)); ctx->prof.end(st);

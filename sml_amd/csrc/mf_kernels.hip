@@ -132,6 +132,14 @@ __global__ __launch_bounds__(256) void k_bare_grad(SmlBareArgs a) {
                 adam_replay_w(it[k], m[1][k], v[1][k], fi, a.cur_step - 1, a.sched, swin, a.cur_step - 1);
                 adam_replay_w(ng[k], m[2][k], v[2][k], fn, a.cur_step - 1, a.sched, swin, a.cur_step - 1);
             }
+            if (a.xrep != nullptr) {          // the row update continues from these copies: no second replay
+                const int64_t o[3] = {(int64_t)t * D + sub * 4, (int64_t)(a.B + t) * D + sub * 4, (int64_t)(2 * a.B + t) * D + sub * 4};
+                RowVec<float>::store(a.xrep + o[0], reinterpret_cast<const float(&)[4]>(u[0]));
+                RowVec<float>::store(a.xrep + o[1], reinterpret_cast<const float(&)[4]>(it[0]));
+                RowVec<float>::store(a.xrep + o[2], reinterpret_cast<const float(&)[4]>(ng[0]));
+#pragma unroll
+                for (int r3 = 0; r3 < 3; ++r3) { RowVec<float>::store(a.mrep + o[r3], m[r3]); RowVec<float>::store(a.vrep + o[r3], v[r3]); }
+            }
         }
         float sp = 0.f, sn = 0.f, sq_u = 0.f, sq_i = 0.f;
 #pragma unroll
@@ -481,7 +489,7 @@ __global__ __launch_bounds__(256) void k_run_update(SmlRunArgs a) {
                 if (from_scratch) {
                     // the forward's replayed copy of this row (any occurrence holds the same values: the first one)
                     const int64_t s0 = run.slot[0];
-                    RowVec<float>::load(a.rep_x + (s0 * 3 + 1) * D + sub * 4, reinterpret_cast<float(&)[4]>(p[0]));
+                    RowVec<float>::load(a.rep_x + s0 * a.rep_x_stride + a.rep_x_off + sub * 4, reinterpret_cast<float(&)[4]>(p[0]));
                     RowVec<float>::load(a.rep_m + s0 * D + sub * 4, m);
                     RowVec<float>::load(a.rep_v + s0 * D + sub * 4, v);
                     from = a.cur_step - 1;

@@ -114,6 +114,7 @@ struct SmlRunArgs {
     // replayed row in xin[slot][1] and the moments in rep_m / rep_v [slot]: the update starts from those (no second
     // replay, no table read).  rep_u / rep_i: which of the two lists' slots index that local scratch.
     const float* rep_x; const float* rep_m; const float* rep_v; int rep_u, rep_i;
+    int rep_x_stride, rep_x_off;   // the replayed row of slot s starts at rep_x[s * rep_x_stride + rep_x_off]
     float lr;                                                     // SGD only
     // hot rows (SGD, large batches): runs longer than SML_HOT are listed here (by the index preparation)
     // instead of being summed by one wavefront; the first hot_blocks workgroups of the run kernel reduce
@@ -158,6 +159,7 @@ struct SmlBareArgs {
     const float* m_user; const float* v_user; const float* m_item; const float* v_item;
     const int32_t* last_user; const int32_t* last_item;
     const SmlSched* sched; int cur_step;
+    float* xrep; float* mrep; float* vrep;   // lazy form: [3B, d] replayed rows / moments per occurrence, for the row update
 };
 hipError_t sml_launch_bare_grad(int d, int dtype_bytes, const SmlBareArgs& a, int* n_blocks, hipStream_t st);
 hipError_t sml_launch_mf_forward(int d, const float* wu, const float* wi, const int64_t* user, const int64_t* item,
