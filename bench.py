@@ -131,7 +131,7 @@ def bench_bare(a, device):
     traffic = None
     if (a.users, a.items, a.bare_batch, a.d, a.bare_dtype) == (10000000, 1000000, 262144, 32, "f32") and a.item_zipf in (0.0, 1.0):
         try:
-            run = json.load(open(os.path.join(REPO, "profiles", "r01d_pmc_per_launch.json")))["bare_z%d" % int(a.item_zipf)]
+            run = json.load(open(os.path.join(REPO, "profiles", "r01e_pmc_per_launch.json")))["bare_z%d" % int(a.item_zipf)]
             traffic = sum((2.0 * c["FETCH_SIZE"]["avg_counter_per_launch"] + c["WRITE_SIZE"]["avg_counter_per_launch"]) * 1024.0
                           for k, c in run.items() if k.startswith(("k_bare_grad", "k_run_update", "k_hot_apply")))
         except Exception:
@@ -197,11 +197,11 @@ def kernel_work(name, a, hp, U_local):
 
 def pmc_traffic(kernel):
     """Fabric bytes per launch of kernel class `kernel` from the committed rocprofv3 --pmc passes of this same
-    command (profiles/r01d_pmc_per_launch.json, made by tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE in
+    command (profiles/r01e_pmc_per_launch.json, made by tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE in
     separate passes; units KB; FETCH doubled per the gfx950 correction in MI355X_MICROARCH.md), averaged
     over the class's template instances by launch count.  PMC cannot be read from inside the process, so
     this is null whenever no committed summary covers the kernel."""
-    path = os.path.join(REPO, "profiles", "r01d_pmc_per_launch.json")
+    path = os.path.join(REPO, "profiles", "r01e_pmc_per_launch.json")
     try:
         runs = json.load(open(path))["period"]
         tot, n = 0.0, 0
