@@ -119,6 +119,5 @@ def main(which, argv=None):
         print("@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@TR:L2:", 1e-06)
     print("##")
     print("##")
-    if which == "yelp":
-        print("\n")
+    print("\n")            # both mains end this way (main_yelp.py:172, main_news.py:232)
     return meta

@@ -86,12 +86,16 @@ struct Prof {
     double total_ms[PC_COUNT] = {0};
     int64_t count[PC_COUNT] = {0};
     static constexpr size_t kPairs = 4096;
+    int64_t lost = 0;               // pairs whose elapsed time could not be read (reported by sml_prof_get's caller as missing)
     void drain() {
         if (!used) return;
-        (void)hipEventSynchronize(ev[2 * used - 1]);
+        // the ring is shared by every stream the context is used on (training stream, side-stream evaluations):
+        // wait for EACH pair's end event, not just the newest one
         for (size_t i = 0; i < used; ++i) {
             float ms = 0.f;
+            (void)hipEventSynchronize(ev[2 * i + 1]);
             if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) == hipSuccess) { total_ms[cls[i]] += ms; count[cls[i]]++; }
+            else ++lost;
         }
         used = 0;
     }

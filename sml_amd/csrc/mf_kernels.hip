@@ -844,15 +844,17 @@ __global__ __launch_bounds__(256) void k_sample_negatives(const int64_t* __restr
     int64_t b = 0, t = 0;
     if (u >= 0 && u < n_users) { b = user_ptr[u]; t = user_ptr[u + 1]; }
     uint64_t st = seed ^ ((uint64_t)e * 0xd1342543de82ef95ull + 0x632be59bd9b4e019ull);
-    int64_t c = -1;
+    int64_t c = -1, cand = item_all[0];
     for (int tries = 0; tries < 4096; ++tries) {
         const uint64_t r = splitmix64(st);
-        const int64_t cand = item_all[(int64_t)__umul64hi(r, (uint64_t)pop)];      // uniform over [0, pop)
+        cand = item_all[(int64_t)__umul64hi(r, (uint64_t)pop)];                    // uniform over [0, pop)
         int64_t lo = b, hi = t;
         while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (user_items[mid] < cand) lo = mid + 1; else hi = mid; }
         if (!(lo < t && user_items[lo] == cand)) { c = cand; break; }
     }
-    if (c < 0) atomicAdd(failed, 1);            // a user who owns (almost) every item of the period
+    // a user who owns (almost) every item of the period: counted (the driver raises when it reads the counter), and
+    // the element still carries a VALID item index -- the last candidate -- so nothing downstream gathers row -1
+    if (c < 0) { atomicAdd(failed, 1); c = cand; }
     negs[e] = c;
 }
 

@@ -143,6 +143,7 @@ class meta_train(object):
         if hit is None or hit[0] is not arr:
             if len(self._rows_cache) > 4:
                 self._rows_cache.clear()
+                self._rank_cache = None        # its rows object went with the entries above
             hit = (arr, DeviceRows(arr, self.device))
             self._rows_cache[key] = hit
         return hit[1]
@@ -156,9 +157,9 @@ class meta_train(object):
         (the reference re-evaluates identical tables several times per phase, and @20/@10/@5 share ranks).
         On the GPU engine this is a handle of an evaluation queued on a snapshot of the tables
         (engine.eval_submit): the training stream does not wait for it."""
-        key = (id(rows), getattr(self, "_version", 0))
+        key = (rows, getattr(self, "_version", 0))          # holds the rows object itself: an id() can be recycled
         hit = getattr(self, "_rank_cache", None)
-        if hit is None or hit[0] != key:
+        if hit is None or hit[0][0] is not rows or hit[0][1] != key[1]:
             wu, wi = self.MFbase.user_laten.weight.data, self.MFbase.item_laten.weight.data
             if hasattr(self.engine, "eval_submit"):
                 ranks = self.engine.eval_submit(wu, wi, rows.rows)
@@ -251,7 +252,9 @@ class meta_train(object):
         if val is not None:
             val = self._rows(val)
         self._emit(lambda: print("******MF (inner) training ******"))
-        train_set = self.MF_TrainDataset(set_t)
+        # (SampleDaset's constructor prints: built once per array, its lines replayed in order with the deferred
+        # output; PreSampleDatast draws np.random.shuffle when constructed, so it is built here every time)
+        train_set = self._sample_dataset(set_t) if self.MF_TrainDataset is SampleDaset else self.MF_TrainDataset(set_t)
         if val is not None:
             recall, ndcg = self._test(val, args.topK)
             self._emit(lambda r, n: print("before train MF test:recall:{:.4f} ndcg:{:.4f}".format(r, n)), recall, ndcg)
@@ -330,6 +333,12 @@ class meta_train(object):
                     and hasattr(self.engine, "sample_negatives"):
                 # fast mode: permutation and rejection-sampled negatives on the device (same distribution, other streams)
                 triples = train_set.epoch_triples_device(self.engine, int(torch.randint(0, 2 ** 62, (1,))))
+                failed = train_set._last_failed
+
+                def check_failed(failed=failed):
+                    if int(failed.item()) != 0:
+                        raise RuntimeError("negative sampling does not terminate: a user owns (almost) every item")
+                self._emit(check_failed)       # read when the stage's output is flushed: no mid-stage host wait
             else:
                 order = D.loader_order(len(train_set), shuffle=True)
                 triples = train_set.epoch_triples(order)

@@ -38,7 +38,7 @@ class HipEngine(object):
         self._ctx = h
         self.net_size = int(self.lib.sml_theta_net_size(self.d))
         self.offsets = [int(self.lib.sml_theta_offset(self.d, w)) for w in range(8)]
-        self._flat = {}       # id(transfer) -> (flat theta, [(param, off, numel)])
+        self._flat = {}       # id(transfer) -> (flat theta, [(param, off, numel)], transfer): the entry keeps the module alive
         self.mf_state = None  # lazy-Adam state of the MF tables
         self.mf_step = 0      # torch.optim.Adam's step counter; never resets (reference model/transfer.py:392)
         self.tr_state = None  # (m, v) flat, theta layout
@@ -83,8 +83,8 @@ class HipEngine(object):
         (user net then item net, layout sml_theta_offset) and return that buffer."""
         key = id(transfer)
         ent = self._flat.get(key)
-        if ent is not None:
-            flat, views = ent
+        if ent is not None and ent[2] is transfer:
+            flat, views = ent[0], ent[1]
             if all(p.data_ptr() == flat.data_ptr() + 4 * off for (p, off, _) in views):
                 return flat
         flat = torch.zeros(2 * self.net_size, device=self.device, dtype=torch.float32)
@@ -106,8 +106,39 @@ class HipEngine(object):
                 flat[off:off + n].copy_(p.data.reshape(-1).to(self.device, torch.float32))
                 p.data = flat[off:off + n].view(p.shape)
                 views.append((p, off, n))
-        self._flat[key] = (flat, views)
+        if len(self._flat) >= 8:                 # a long-lived engine does not collect every module it ever saw
+            self._flat.pop(next(iter(self._flat)))
+        self._flat[key] = (flat, views, transfer)
         return flat
+
+    def load_optimizer_state(self, mfbase=None, mf_state=None, transfer=None, tr_state=None):
+        """Resume from saved torch.optim.Adam states (the reference keeps both optimisers alive for the whole run,
+        model/transfer.py:392-393; this is how a run is continued from a checkpoint of them).
+        mf_state: dict(m_user, v_user, m_item, v_item, step) -- exp_avg / exp_avg_sq of the two tables, all rows
+        current as of `step`.  tr_state: dict(m={param name: exp_avg}, v={param name: exp_avg_sq}, step) over
+        transfer.named_parameters()."""
+        if mf_state is not None:
+            self._mf_tables(mfbase, None, None)
+            s = self.mf_state
+            for key, src in (("m_u", "m_user"), ("v_u", "v_user"), ("m_i", "m_item"), ("v_i", "v_item")):
+                s[key].copy_(torch.as_tensor(mf_state[src]).to(self.device, torch.float32))
+            self.mf_step = int(mf_state["step"])
+            s["s_u"].fill_(self.mf_step)
+            s["s_i"].fill_(self.mf_step)
+        if tr_state is not None:
+            theta = self._select(transfer)
+            if self.tr_state is None or self.tr_state[0].shape != theta.shape:
+                self.tr_state = (torch.zeros_like(theta), torch.zeros_like(theta), torch.zeros_like(theta))
+            names = {id(p): n for n, p in transfer.named_parameters()}
+            for flat, src in ((self.tr_state[0], tr_state["m"]), (self.tr_state[1], tr_state["v"])):
+                flat.zero_()
+                for p, off, n in self._flat[id(transfer)][1]:
+                    t = torch.as_tensor(src[names[id(p)]]).to(self.device, torch.float32)
+                    if p.dim() == 4 and p.shape[2] == 2 and p.shape[0] == 10:   # ConvTransfer's (2,1) conv1 kernel: see adopt()
+                        flat[off:off + 30].view(10, 3)[:, :2].copy_(t.reshape(10, 2))
+                    else:
+                        flat[off:off + n].copy_(t.reshape(-1))
+            self.tr_step = int(tr_state["step"])
 
     def _select(self, transfer):
         """Tell the library which transfer architecture the next calls are for (0: ConvTransfer_com,

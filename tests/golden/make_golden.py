@@ -16,7 +16,9 @@ Harness-side shims (the reference is untouched):
 Fixtures:  G1 transfer forward, G2 run_MF loss and
 gradients, G3 MF-stage steps, G4 TR-stage steps, G5 updata, G6 evaluation,
 G7 end-to-end main_yelp.py log on a tiny 40-period dataset, G8 batch supply,
-G9 parameter initialisation, G11 the ConvTransfer variant (--transfer_type conv), G10 the baselines' bare-MF fine-tune loop (model/baseline.py
+G9 parameter initialisation, G7-news the main_news.py (Adressa) path end to end, G12 a mid-size period
+sequence (10,000 test rows per period: Recall@20 resolves 1e-4) with full-precision per-batch losses and
+teacher-forcing state snapshots, G11 the ConvTransfer variant (--transfer_type conv), G10 the baselines' bare-MF fine-tune loop (model/baseline.py
 SPMF.run_one_stage2: BCE + L2 + dense Adam on recorded batches).
 
 usage: python tests/golden/make_golden.py [--ref /root/reference]
@@ -106,6 +108,24 @@ def save(name, **arrs):
     path = os.path.join(OUT_DIR[0], name)
     np.savez_compressed(path, **arrs)
     print("wrote", name, "%.1f KB" % (os.path.getsize(path) / 1024.0))
+
+
+@contextlib.contextmanager
+def record_backward(sink):
+    """Every scalar the reference calls .backward() on (the per-batch training loss, l2 term included) is
+    appended to `sink` at full precision.  A harness-side wrapper: the reference is untouched."""
+    orig = torch.Tensor.backward
+
+    def rec(self, *a, **k):
+        if self.dim() == 0:
+            sink.append(float(self.detach()))
+        return orig(self, *a, **k)
+
+    torch.Tensor.backward = rec
+    try:
+        yield
+    finally:
+        torch.Tensor.backward = orig
 
 
 class Args(object):
@@ -251,8 +271,10 @@ def gen_g3_g4_g5(T, tmp, ttype="conv_com", suffix=""):
     torch.manual_seed(77)
     np.random.seed(78)
     buf = io.StringIO()
-    with contextlib.redirect_stdout(buf):
+    full = []          # loss_batch as the reference backpropagates it: run_MF + l2 * l2loss (model/transfer.py:488, 502)
+    with contextlib.redirect_stdout(buf), record_backward(full):
         meta.MF_train_onestage(args, set_t, 0, val=None)
+    out["mf_batch_loss"] = np.array(full, dtype=np.float64)
     out["mf_log"] = np.array(buf.getvalue())
     out["mf_triples"] = np.array(log, dtype=np.int64)  # [epochs*n_t, 3] in consumption order
     out["mf_runmf_loss"] = np.array(losses, dtype=np.float64)
@@ -304,8 +326,10 @@ def gen_g3_g4_g5(T, tmp, ttype="conv_com", suffix=""):
     torch.manual_seed(177)
     np.random.seed(178)
     buf = io.StringIO()
-    with contextlib.redirect_stdout(buf):
+    full = []
+    with contextlib.redirect_stdout(buf), record_backward(full):
         meta.transfer_train_onestage(args, set_tt, 0, val=None)
+    g4["tr_batch_loss"] = np.array(full, dtype=np.float64)
     T.SampleDaset = offlineDataset_withsample
     g4["tr_log"] = np.array(buf.getvalue())
     g4["tr_triples"] = np.array(log2, dtype=np.int64)
@@ -426,13 +450,17 @@ def gen_g8(T):
 
 
 # --------------------------------------------------------------------------- G7 end to end
-def gen_g7(T, ref, tmp, extra=(), suffix=""):
+def gen_g7(T, ref, tmp, extra=(), suffix="", which="yelp"):
+    """which='yelp': main_yelp.py (40 periods).  which='news': main_news.py (63 periods, train from 21, test from
+    48, multi_num 7, 2 + 2 epochs: main_news.py:22,34,68,221-227) -- the Adressa path, which also makes the
+    discarded-MFbasemode RNG draw of model/transfer.py:314-317 before the transfer net is initialised."""
     from sml_amd import synth
     from model.MF import MFbasemode
 
-    root = os.path.join(tmp, "data") + "/"
+    root = os.path.join(tmp, "data_" + which) + "/"
     U, I, d = 300, 120, 32
-    synth.write_dataset(root, "yelp", n_periods=40, n_inter=160, n_user=U, n_item=I, neg=49,
+    n_periods = 40 if which == "yelp" else 63
+    synth.write_dataset(root, which, n_periods=n_periods, n_inter=160, n_user=U, n_item=I, neg=49,
                         a_user=0.8, a_item=0.8, seed=2000)
     torch.manual_seed(4242)
     mf = MFbasemode(U, I, d)
@@ -441,27 +469,125 @@ def gen_g7(T, ref, tmp, extra=(), suffix=""):
         mf.item_laten.weight.mul_(0.3)
     ck = os.path.join(tmp, "BCE_init.pkl")
     torch.save(mf, ck)
-    argv = ["main_yelp.py", "--data_path", root, "--pre_model", ck, "--laten", str(d), "--multi_num", "2",
-            "--numworkers", "0", "--MF_batch_size", "64", "--TR_batch_size", "32"] + list(extra)
+    script = "main_%s.py" % which
+    argv = [script, "--data_path", root, "--pre_model", ck, "--laten", str(d)] + \
+           (["--multi_num", "2"] if which == "yelp" else []) + \
+           ["--numworkers", "0", "--MF_batch_size", "64", "--TR_batch_size", "32"] + list(extra)
     buf = io.StringIO()
     old = sys.argv
     sys.argv = argv
     try:
         with contextlib.redirect_stdout(buf):
-            runpy.run_path(os.path.join(ref, "main_yelp.py"), run_name="__main__")
+            runpy.run_path(os.path.join(ref, script), run_name="__main__")
     finally:
         sys.argv = old
     log = buf.getvalue()
     out = sd_np(mf, "mf.")
     out["log"] = np.array(log)
     out["argv"] = np.array(argv[5:])
-    out["dataset"] = np.array([40, 160, U, I, 49, 2000], dtype=np.int64)
+    out["dataset"] = np.array([n_periods, 160, U, I, 49, 2000], dtype=np.int64)
     out["dataset_zipf"] = np.array([0.8, 0.8])
     save("g7_end_to_end%s.npz" % suffix, **out)
-    if not suffix:
+    if not suffix and which == "yelp":
         # a reference-pickled whole-module checkpoint: the on-disk contract for --pre_model
         shutil.copy(ck, os.path.join(OUT_DIR[0], "ref_BCE_init_tiny.pkl"))
     print("log lines:", len(log.splitlines()))
+
+
+# --------------------------------------------------------------------------- G12 mid-size period sequence
+G12 = dict(U=1500, I=2500, d=32, n_inter=10000, neg=99, n_periods=6, train_from=1, test_from=3, multi_num=3,
+           seed=2000, data_seed=4100, a_user=0.9, a_item=0.9, ck_seed=4343, snap_stages=(2, 3))
+
+
+def gen_g12(T, ref, tmp):
+    """The reference's period loop at a size where Recall@20 resolves 1e-4: 10,000 validation / test rows per
+    period.  main_yelp.py's __main__ body (seeding order main_yelp.py:137-139, transfer_data, meta_train,
+    run: :159-168) is driven here with SIX periods instead of forty (train from period 1, test from period 3
+    -> one pure-training stage and three test stages), main_yelp.py's defaults otherwise (MF batch 1024, TR
+    batch 256, lr / l2) except multi_num 3.  Recorded: the whole printed log; every per-batch training loss at
+    full precision (the scalar the reference backpropagates); and -- for the teacher-forced test -- the complete
+    numerical state (tables, theta, both Adam states) at the START of stages 2 and 3, so a re-implementation can
+    be set onto the reference's trajectory there and must then reproduce that stage's printed numbers."""
+    from sml_amd import synth
+    from model.MF import MFbasemode
+    import data.dataset2 as dataset2
+
+    c = G12
+    root = os.path.join(tmp, "data_g12") + "/"
+    synth.write_dataset(root, "yelp", n_periods=c["n_periods"], n_inter=c["n_inter"], n_user=c["U"], n_item=c["I"],
+                        neg=c["neg"], a_user=c["a_user"], a_item=c["a_item"], seed=c["data_seed"])
+    torch.manual_seed(c["ck_seed"])
+    mf = MFbasemode(c["U"], c["I"], c["d"])
+    with torch.no_grad():
+        mf.user_laten.weight.mul_(0.3)
+        mf.item_laten.weight.mul_(0.3)
+    ck = os.path.join(tmp, "g12_init.pkl")
+    torch.save(mf, ck)
+    args = Args(data_path=root, pre_model=ck, laten=c["d"], multi_num=c["multi_num"], MF_batch_size=1024,
+                TR_batch_size=256, numworkers=0, seed=c["seed"])
+    # main_yelp.py:137-139
+    torch.manual_seed(args.seed)
+    torch.cuda.manual_seed(args.seed + 1)
+    np.random.seed(args.seed + 2)
+    file_list = [str(i) for i in range(c["n_periods"])]
+    test_list = [str(j) for j in range(c["test_from"], c["n_periods"])]
+    buf = io.StringIO()
+    losses, tags, snaps = [], [], {}
+    with contextlib.redirect_stdout(buf):
+        sets = dataset2.transfer_data(args, path=root, datasetname="yelp", file_path_list=file_list, test_list=test_list,
+                                      validation_list=None, online_train_time=c["train_from"], online_test_time=c["test_from"])
+        meta = T.meta_train(args, sets, sets.user_number, sets.item_number, args.laten)
+        theta0 = sd_np(meta.transfer, "theta0.")
+        stage_now = [0]
+        for name, tag in (("MF_train_onestage", 0), ("transfer_train_onestage", 1)):
+            def wrap(fn, tag=tag):
+                def inner(*a, **k):
+                    n0 = len(losses)
+                    r = fn(*a, **k)
+                    tags.extend([(stage_now[0], tag)] * (len(losses) - n0))
+                    return r
+                return inner
+            setattr(meta, name, wrap(getattr(meta, name)))
+        real_stage = meta.train_one_stage3
+
+        def stage(a, stage_id):
+            stage_now[0] = stage_id
+            if stage_id in c["snap_stages"]:
+                sn = {}
+                sn["W_user"] = meta.MFbase.user_laten.weight.detach().numpy().copy()
+                sn["W_item"] = meta.MFbase.item_laten.weight.detach().numpy().copy()
+                sn.update(sd_np(meta.transfer, "theta."))
+                st = meta.MF_optimizer.state
+                for nm, p in (("user", meta.MFbase.user_laten.weight), ("item", meta.MFbase.item_laten.weight)):
+                    sn["mf_m_" + nm] = st[p]["exp_avg"].numpy().copy()
+                    sn["mf_v_" + nm] = st[p]["exp_avg_sq"].numpy().copy()
+                    sn["mf_step"] = np.array(int(st[p]["step"]))
+                ost = meta.transfer_optimizer.state
+                for k, p in meta.transfer.named_parameters():
+                    sn["tr_m." + k] = ost[p]["exp_avg"].numpy().copy()
+                    sn["tr_v." + k] = ost[p]["exp_avg_sq"].numpy().copy()
+                    sn["tr_step"] = np.array(int(ost[p]["step"]))
+                snaps[stage_id] = sn
+            return real_stage(a, stage_id)
+
+        meta.train_one_stage3 = stage
+        with record_backward(losses):
+            meta.run(args)
+    log = buf.getvalue()
+    out = {"log": np.array(log), "batch_loss": np.array(losses, dtype=np.float64),
+           "batch_tag": np.array(tags, dtype=np.int64),           # [n, 2]: (stage, 0 = MF batch / 1 = TR batch)
+           "config": np.array([c[k] for k in ("U", "I", "d", "n_inter", "neg", "n_periods", "train_from", "test_from",
+                                              "multi_num", "seed", "data_seed", "ck_seed")], dtype=np.int64),
+           "zipf": np.array([c["a_user"], c["a_item"]]),
+           "final_sum": np.array([float(meta.MFbase.user_laten.weight.double().sum()), float(meta.MFbase.item_laten.weight.double().sum()),
+                                  float(meta.MFbase.user_laten.weight.double().abs().sum()), float(meta.MFbase.item_laten.weight.double().abs().sum())]),
+           "recall": np.array(meta.recall, dtype=np.float64), "ndcg": np.array([float(x) for x in meta.ndcg], dtype=np.float64),
+           "test_num": np.array(meta.test_num, dtype=np.int64)}
+    out.update(theta0)
+    save("g12_midsize.npz", **out)
+    for sid, sn in snaps.items():
+        save("g12_midsize_state_s%d.npz" % sid, **sn)
+    print("G12 log lines:", len(log.splitlines()), "batches:", len(losses), "recall:", meta.recall)
 
 
 # --------------------------------------------------------------------------- G10 baseline bare-MF loop
@@ -562,6 +688,10 @@ def main():
             gen_g8(T)
         if not only or "g7" in only:
             gen_g7(T, a.ref, tmp)
+        if not only or "g7news" in only:
+            gen_g7(T, a.ref, tmp, suffix="_news", which="news")
+        if not only or "g12" in only:
+            gen_g12(T, a.ref, tmp)
         if not only or "g10" in only:
             gen_g10(a.ref)
         if not only or "g11" in only:

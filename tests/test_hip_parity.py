@@ -112,9 +112,10 @@ def test_g3_mf_stage_vs_golden_and_oracle(variant):
     eng = engine(32)
     mf, losses, lr = _run_g3(eng, z)
     omf, olosses, _ = _run_g3(O.OracleEngine(32), z)
-    # per-batch loss (with the l2 term): HIP vs oracle 1e-4 relative; vs the reference's run_MF value
+    # per-batch loss, l2 term included: HIP vs the scalar the REFERENCE backpropagated (model/transfer.py:488, 502)
+    # at north_star's 1e-4 relative, and vs the oracle
+    np.testing.assert_allclose(losses, z["mf_batch_loss"], rtol=1e-4)
     np.testing.assert_allclose(losses, olosses, rtol=1e-4)
-    np.testing.assert_allclose(losses, z["mf_runmf_loss"], rtol=0, atol=3e-3)
     assert eng.mf_step == int(z["adam_step"])
     # every row -- touched, duplicated within a batch, and never touched (dense-Adam drift)
     adam_close(mf.user_laten.weight.detach().cpu().numpy(), z["W_user1"], lr, eng.mf_step)
@@ -183,6 +184,7 @@ def test_g4_tr_stage_vs_golden_and_oracle(variant):
                                          T(z["What_item"], DEV), tri, B, lr, wd).cpu().numpy())
     losses = np.concatenate(losses)
     np.testing.assert_allclose(losses, z["tr_runmf_loss"], rtol=1e-4)
+    np.testing.assert_allclose(losses, z["tr_batch_loss"], rtol=1e-4)      # the scalar the reference backpropagated
     assert eng.tr_step == int(z["adam_step"])
     for name, p in net.named_parameters():
         got, ref = p.detach().cpu().numpy(), z["theta1." + name]
@@ -358,15 +360,68 @@ def test_yelp_scale_properties():
 
 
 # ----------------------------------------------------------------------------- G7 end to end
-@pytest.mark.parametrize("variant", ["", "_conv"])
+@pytest.mark.parametrize("variant", ["", "_conv", "_news"])
 def test_g7_end_to_end_on_gpu(tmp_path, monkeypatch, variant):
-    """main_yelp.py's full 29-stage sequence on the tiny dataset, HIP path, against the
-    reference's recorded log: identical text, first periods identical numbers, final
-    Recall@20 / NDCG@20 averages within the free-running tolerance (see test_host_logic)."""
+    """main_yelp.py's full 29-stage sequence (and, "_news", main_news.py's 41-stage Adressa-shaped one: multi_num 7,
+    2 + 2 epochs, the discarded-MFbasemode RNG draw of model/transfer.py:314-317) on the tiny dataset, HIP path,
+    against the reference's recorded log: identical text, first periods identical numbers, final Recall@20 /
+    NDCG@20 averages within the free-running tolerance of a 160-row test set (see test_host_logic; the 1e-4 pin
+    is G12 below)."""
     from test_host_logic import check_g7, run_g7
     monkeypatch.setenv("LOCAL_RANK", "0")          # keep main from rewriting CUDA_VISIBLE_DEVICES
     got, want = run_g7(tmp_path, monkeypatch, variant=variant)      # "_conv": --transfer_type conv
     check_g7(got, want, exact_lines=40)
+
+
+def _report(name, obj):
+    """Parity numbers the suite measured on the GPU box (merged back from gpurun_out/, committed under profiles/)."""
+    import json
+    import os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, name), "w") as f:
+            json.dump(obj, f, indent=1)
+    except OSError:
+        pass
+
+
+def test_g12_midsize_teacher_forced_on_gpu(tmp_path, monkeypatch):
+    """north_star's bar, at a size that resolves it: the reference's period loop with 10,000 test rows per period
+    (one rank flip = 1e-4 of Recall@20), recorded as G12.  With the state set to the reference's at the start of
+    stages 2 and 3 (and stage 0 starting identically by seed), the HIP path must reproduce EVERY per-batch training
+    loss of those stages to 1e-4 relative and every printed Recall@20 / NDCG@20 (validation lines and the
+    real-test @20/@10/@5 lines) within 2 rank flips."""
+    from test_host_logic import g12_compare, run_g12
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    meta, log, flat, z = run_g12(tmp_path, teacher_forced=True)
+    want = str(z["log"])
+    r = g12_compare(log, want, flat, z, stages=(0, 2, 3), loss_rtol=1e-4, flips=2)
+    free = g12_compare(log, want, flat, z, stages=(1,), loss_rtol=1.0, flips=10000)
+    _report("parity_g12_teacher_forced.json",
+            {"stages_forced_or_seeded": [0, 2, 3], "max_loss_rel_err": r[0], "max_recall_abs_diff": r[1],
+             "max_ndcg_abs_diff": r[2], "stage1_free_running": {"max_loss_rel_err": free[0], "max_recall_abs_diff": free[1],
+                                                                "max_ndcg_abs_diff": free[2]}})
+
+
+def test_g12_midsize_free_running_on_gpu(tmp_path, monkeypatch):
+    """The same sequence free-running from the seeds (no state is ever reset): the gap to the reference is REPORTED
+    per stage (gpurun_out/parity_g12_free_running.json) and bounded -- per-batch losses 1e-3 relative, Recall@20
+    within 15 rank flips of 10,000 by the last stage (Adam divides rounding noise by sqrt(v); three stages x
+    three phases of it) -- with the final weighted Recall@20 averages within 5e-4."""
+    from test_host_logic import g12_compare, run_g12
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    meta, log, flat, z = run_g12(tmp_path, teacher_forced=False)
+    want = str(z["log"])
+    rep = {}
+    for st in range(4):
+        r = g12_compare(log, want, flat, z, stages=(st,), loss_rtol=1.0, flips=10000)
+        rep["stage%d" % st] = {"max_loss_rel_err": r[0], "max_recall_abs_diff": r[1], "max_ndcg_abs_diff": r[2]}
+    rep["real_test_recall20"] = {"got": [float(x) for x in meta.recall], "reference": [float(x) for x in z["recall"]]}
+    _report("parity_g12_free_running.json", rep)
+    g12_compare(log, want, flat, z, stages=(0,), loss_rtol=1e-4, flips=2)
+    g12_compare(log, want, flat, z, stages=(0, 1, 2, 3), loss_rtol=1e-3, flips=15)
+    assert np.abs(np.array(meta.recall) - z["recall"]).max() <= 5e-4 + 1e-9
 
 
 # ----------------------------------------------------------------------------- multi-GPU plumbing on one GPU
@@ -418,8 +473,9 @@ def test_exchange_path_on_one_rank_rccl_group_equals_plain_path(monkeypatch):
 
 def test_main_news_path_end_to_end(tmp_path, monkeypatch):
     """main_news.py (Adressa shape: 63 periods, train from 21, test from 48, multi_num 7,
-    2+2 epochs) on a tiny synthetic dataset: runs to the final report and produces 15 test
-    results; determinism: two runs print the same metrics."""
+    2+2 epochs) on another tiny synthetic dataset: runs to the final report and produces 15 test
+    results; determinism: two runs print the same metrics.  (The reference-recorded pin of this path is
+    test_g7_end_to_end_on_gpu[_news].)"""
     from sml_amd import cli, synth
     from sml_amd.mf import MFbasemode
     monkeypatch.setenv("LOCAL_RANK", "0")

@@ -205,10 +205,12 @@ def check_g7(got, want, exact_lines):
 def run_g7(tmp_path, monkeypatch, device_patch=True, variant=""):
     from sml_amd import cli, driver, synth
     from sml_amd.mf import MFbasemode
-    z = golden("g7_end_to_end%s.npz" % variant)      # "_conv": the same run with --transfer_type conv
+    # "_conv": the same run with --transfer_type conv; "_news": main_news.py (63 periods, multi_num 7, 2 + 2 epochs)
+    z = golden("g7_end_to_end%s.npz" % variant)
+    which = "news" if variant == "_news" else "yelp"
     P, n_inter, U, I, neg, seed = [int(v) for v in z["dataset"]]
     root = str(tmp_path) + "/"
-    synth.write_dataset(root, "yelp", n_periods=P, n_inter=n_inter, n_user=U, n_item=I, neg=neg,
+    synth.write_dataset(root, which, n_periods=P, n_inter=n_inter, n_user=U, n_item=I, neg=neg,
                         a_user=float(z["dataset_zipf"][0]), a_item=float(z["dataset_zipf"][1]), seed=seed)
     mf = MFbasemode(U, I, 32)
     mf.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("mf.")})
@@ -216,11 +218,11 @@ def run_g7(tmp_path, monkeypatch, device_patch=True, variant=""):
     torch.save(mf, ck)
     argv = ["--data_path", root, "--pre_model", ck] + [str(a) for a in z["argv"]]
     with quiet() as buf:
-        cli.main("yelp", argv)
+        cli.main(which, argv)
     return buf.getvalue(), str(z["log"])
 
 
-@pytest.mark.parametrize("variant", ["", "_conv"])
+@pytest.mark.parametrize("variant", ["", "_conv", "_news"])
 def test_g7_driver_control_flow_on_cpu(tmp_path, monkeypatch, variant):
     from sml_amd import driver
     from sml_amd.mf import MFbasemode
@@ -231,6 +233,154 @@ def test_g7_driver_control_flow_on_cpu(tmp_path, monkeypatch, variant):
     got, want = run_g7(tmp_path, monkeypatch, variant=variant)
     # identical data and RNG tape: the first three periods print identically
     check_g7(got, want, exact_lines=90)
+
+
+# ----------------------------------------------------------------------------- G12 mid-size sequence
+def g12_losses_from_log(log):
+    """(kind, value) of every printed training loss / metric line, in order."""
+    out = []
+    for l in log.splitlines():
+        if "time cost" in l:
+            continue
+        for m in re.finditer(r"(recall|reacll|ndcg|loss):\s*(-?\d+\.\d+)", l):
+            out.append((m.group(1).replace("reacll", "recall"), float(m.group(2)), l))
+    return out
+
+
+def run_g12(tmp_path, teacher_forced, spy=None):
+    """The product's period loop on G12's dataset, seeded and configured as tests/golden/make_golden.py: gen_g12 drove
+    the reference (main_yelp.py's __main__ body with six periods).  teacher_forced: at the start of every stage
+    the fixture holds a state for (2 and 3), tables, theta and both Adam states are set to the reference's.
+    Returns (meta, log, per-batch losses [(stage, kind, value)...])."""
+    from sml_amd import cli, datasets, driver, synth
+    from sml_amd.mf import MFbasemode
+    z = golden("g12_midsize.npz")
+    U, I, d, n_inter, neg, P, train_from, test_from, multi_num, seed, data_seed, ck_seed = [int(v) for v in z["config"]]
+    root = str(tmp_path) + "/"
+    synth.write_dataset(root, "yelp", n_periods=P, n_inter=n_inter, n_user=U, n_item=I, neg=neg,
+                        a_user=float(z["zipf"][0]), a_item=float(z["zipf"][1]), seed=data_seed)
+    torch.manual_seed(ck_seed)
+    mf = MFbasemode(U, I, d)
+    with torch.no_grad():
+        mf.user_laten.weight.mul_(0.3)
+        mf.item_laten.weight.mul_(0.3)
+    ck = os.path.join(root, "g12_init.pkl")
+    torch.save(mf, ck)
+    args = cli.get_parse("yelp").parse_args(["--data_path", root, "--pre_model", ck, "--laten", str(d), "--multi_num",
+                                            str(multi_num), "--numworkers", "0", "--seed", str(seed)])
+    torch.set_num_threads(int(os.environ.get("SML_HOST_THREADS", "1")) if torch.cuda.is_available() else torch.get_num_threads())
+    torch.manual_seed(args.seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(args.seed + 1)
+    np.random.seed(args.seed + 2)
+    batch_losses = []
+    with quiet() as buf:
+        sets = datasets.transfer_data(args, path=root, datasetname="yelp", file_path_list=[str(i) for i in range(P)],
+                                      test_list=[str(j) for j in range(test_from, P)], validation_list=None,
+                                      online_train_time=train_from, online_test_time=test_from)
+        meta = driver.meta_train(args, sets, sets.user_number, sets.item_number, args.laten)
+        for k in z.files:       # the transfer net's initial parameters are the reference's (seeded identically: G9)
+            if k.startswith("theta0."):
+                np.testing.assert_array_equal(meta.transfer.state_dict()[k[7:]].cpu().numpy(), z[k])
+        eng = meta.engine
+        stage_now = [0]
+        for name, kind in (("mf_stage_epoch", 0), ("tr_stage_epoch", 1)):
+            def wrap(fn, kind=kind):
+                def inner(*a, **k):
+                    l = fn(*a, **k)
+                    batch_losses.append((stage_now[0], kind, l))
+                    return l
+                return inner
+            setattr(eng, name, wrap(getattr(eng, name)))
+        real_stage = meta.train_one_stage3
+
+        def stage(a, stage_id):
+            stage_now[0] = stage_id
+            path = os.path.join(GOLDEN, "g12_midsize_state_s%d.npz" % stage_id)
+            if teacher_forced and os.path.exists(path):
+                sn = np.load(path)
+                dev = meta.MFbase.user_laten.weight.device
+                meta.MFbase.user_laten.weight.data.copy_(torch.from_numpy(sn["W_user"]).to(dev))
+                meta.MFbase.item_laten.weight.data.copy_(torch.from_numpy(sn["W_item"]).to(dev))
+                meta.transfer.load_state_dict({k[6:]: torch.from_numpy(sn[k]) for k in sn.files if k.startswith("theta.")})
+                names = [n for n, _ in meta.transfer.named_parameters()]
+                eng.load_optimizer_state(
+                    mfbase=meta.MFbase, transfer=meta.transfer,
+                    mf_state=dict(m_user=sn["mf_m_user"], v_user=sn["mf_v_user"], m_item=sn["mf_m_item"],
+                                  v_item=sn["mf_v_item"], step=int(sn["mf_step"])),
+                    tr_state=dict(m={n: sn["tr_m." + n] for n in names}, v={n: sn["tr_v." + n] for n in names},
+                                  step=int(sn["tr_step"])))
+                meta._touch_tables()
+            return real_stage(a, stage_id)
+        meta.train_one_stage3 = stage
+        meta.run(args)
+    flat = []
+    for st, kind, l in batch_losses:
+        arr = l.detach().cpu().numpy() if isinstance(l, torch.Tensor) else np.asarray(l)
+        flat += [(st, kind, float(v)) for v in arr]
+    return meta, buf.getvalue(), flat, z
+
+
+def g12_compare(log, want_log, flat, z, stages, loss_rtol, flips):
+    """Inside `stages`: every per-batch loss within loss_rtol of the reference's backpropagated scalar, every
+    printed recall within `flips` rank flips (n = 10,000 rows: one flip = 1e-4), ndcg within flips / n too.
+    Returns (max loss rel err, max |recall diff|, max |ndcg diff|) over those stages."""
+    tags, ref = z["batch_tag"], z["batch_loss"]
+    assert len(flat) == len(ref) and all((a[0], a[1]) == (int(t[0]), int(t[1])) for a, t in zip(flat, tags))
+    sel = np.isin(tags[:, 0], list(stages))
+    got = np.array([a[2] for a in flat])
+    rel = np.abs(got[sel] - ref[sel]) / np.abs(ref[sel])
+    # printed metrics, stage by stage ("now time:" opens a stage's block of lines)
+    def blocks(text):
+        out, cur = [], None
+        for l in text.splitlines():
+            if l.startswith("now time:") and (cur is None or not cur[-1].startswith("now time:")) \
+                    and (cur is None or not cur[-1].startswith("will be test")):
+                if cur is not None and any("MF (inner)" in x for x in cur):
+                    out.append(cur)
+                    cur = []
+                elif cur is None:
+                    cur = []
+            if cur is not None:
+                cur.append(l)
+        out.append(cur)
+        return out
+    gb, wb = blocks(log), blocks(want_log)
+    assert len(gb) == len(wb) == 4, (len(gb), len(wb))
+    dr, dn = [0.0], [0.0]
+    for st in stages:
+        g, w = g12_losses_from_log("\n".join(gb[st])), g12_losses_from_log("\n".join(wb[st]))
+        assert [x[0] for x in g] == [x[0] for x in w]
+        for (k, a, _), (_, b, _) in zip(g, w):
+            if k == "recall":
+                dr.append(abs(a - b))
+            elif k == "ndcg":
+                dn.append(abs(a - b))
+    n = 10000.0
+    assert rel.max() <= loss_rtol, "per-batch loss: max rel err %.3e" % rel.max()
+    assert max(dr) <= flips / n + 1e-9, "recall: max diff %.4f" % max(dr)
+    assert max(dn) <= flips / n + 0.5e-4 + 1e-9, "ndcg: max diff %.4f" % max(dn)      # (+ the print's own rounding)
+    return rel.max(), max(dr), max(dn)
+
+
+def test_g12_midsize_sequence_on_cpu_oracle(tmp_path, monkeypatch):
+    """G12 through the product's driver with the oracle injected: control flow, RNG tape and the oracle's
+    arithmetic against the reference at a size where Recall@20 resolves 1e-4.  Teacher-forced at stages 2 and 3
+    (state set to the reference's at the stage start): per-batch losses to 2e-5 relative, Recall@20 within 2 rank
+    flips; stage 0 (identical start by seed) to the same bar; the free-running gap is reported."""
+    from sml_amd import driver
+    from sml_amd.mf import MFbasemode
+    monkeypatch.setattr(driver, "_default_device", lambda: torch.device("cpu"))
+    monkeypatch.setattr(driver, "_make_engine", lambda dev, d, mb: _CpuEngine(dev, d, mb))
+    monkeypatch.setattr(MFbasemode, "test", _cpu_mf_test)
+    meta, log, flat, z = run_g12(tmp_path, teacher_forced=True)
+    want = str(z["log"])
+    norm = lambda t: [" ".join(l.split()) for l in t.splitlines() if "time cost" not in l and "is:" not in l]
+    assert [_NUM.sub("#", l) for l in norm(log)] == [_NUM.sub("#", l) for l in norm(want)]      # same text, line by line
+    r = g12_compare(log, want, flat, z, stages=(0, 2, 3), loss_rtol=1e-4, flips=2)
+    free = g12_compare(log, want, flat, z, stages=(1,), loss_rtol=1.0, flips=10000)
+    print("G12 oracle: teacher-forced/seeded stages: loss rel %.2e recall %.4f ndcg %.4f | free-running stage 1: "
+          "loss rel %.2e recall %.4f ndcg %.4f" % (r + free))
 
 
 def _g10_stream(g):

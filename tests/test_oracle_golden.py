@@ -78,10 +78,10 @@ def test_g3_mf_stage_steps(variant):
         losses.append(eng.mf_stage_epoch(mf, net, T(z["Wlast_user"]), T(z["Wlast_item"]), tri[ep * n:(ep + 1) * n],
                                          B, lr, l2))
     losses = np.concatenate(losses)
-    # the fixture recorded run_MF's value (before the l2 term); the l2 term is ~1e-6 * 0.5 * sum x^2
-    assert losses.shape == z["mf_runmf_loss"].shape
+    # mf_batch_loss: the scalar the reference backpropagates per batch (run_MF + l2 * l2loss, model/transfer.py:488);
+    # mf_runmf_loss: run_MF's own value before the l2 term
+    np.testing.assert_allclose(losses, z["mf_batch_loss"], rtol=2e-5)
     assert np.all(losses >= z["mf_runmf_loss"] - 1e-6)
-    np.testing.assert_allclose(losses, z["mf_runmf_loss"], rtol=0, atol=3e-3)
     assert eng.mf_step == int(z["adam_step"])
     adam_close(mf.user_laten.weight.detach().numpy(), z["W_user1"], lr, eng.mf_step)
     adam_close(mf.item_laten.weight.detach().numpy(), z["W_item1"], lr, eng.mf_step)
@@ -112,6 +112,7 @@ def test_g4_tr_stage_steps(variant):
                                          T(z["What_item"]), tri[ep * n:(ep + 1) * n], B, lr, wd))
     losses = np.concatenate(losses)
     np.testing.assert_allclose(losses, z["tr_runmf_loss"], rtol=2e-5)
+    np.testing.assert_allclose(losses, z["tr_batch_loss"], rtol=2e-5)      # the backpropagated scalar (no l2 term here)
     assert eng.tr_step == int(z["adam_step"])
     for name, p in net.named_parameters():
         ref = z["theta1." + name]
