@@ -1,6 +1,2 @@
-"""reference model/baseline.py surface (full-retrain / fine-tune / SPMF MF baselines) -> sml_amd.baseline."""
-from sml_amd.baseline import (SPMF, Reservious, StreamingData, get_parse, main, offlineDataset_withsample,  # noqa: F401
-                              test_hit_new)
-
-if __name__ == "__main__":
-    main()
+"""reference model/baseline.py: only SPMF.run_one_stage2 (the bare-MF fine-tune / full-retrain step) is hosted -> sml_amd.baseline."""
+from sml_amd.baseline import SPMF, offlineDataset_withsample  # noqa: F401

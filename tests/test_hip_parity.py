@@ -406,9 +406,10 @@ def test_g12_midsize_teacher_forced_on_gpu(tmp_path, monkeypatch):
 
 def test_g12_midsize_free_running_on_gpu(tmp_path, monkeypatch):
     """The same sequence free-running from the seeds (no state is ever reset): the gap to the reference is REPORTED
-    per stage (gpurun_out/parity_g12_free_running.json) and bounded -- per-batch losses 1e-3 relative, Recall@20
-    within 15 rank flips of 10,000 by the last stage (Adam divides rounding noise by sqrt(v); three stages x
-    three phases of it) -- with the final weighted Recall@20 averages within 5e-4."""
+    per stage (gpurun_out/parity_g12_free_running.json; committed as profiles/r02_parity_g12_free_running.json:
+    per-batch losses within 3.3e-5 relative, every printed Recall@20 within ONE rank flip of 10,000 over all four
+    stages, the three real-test Recall@20 values identical) and held to north_star's bar without teacher forcing:
+    losses 1e-4 relative, Recall@20 / NDCG@20 within 3 rank flips, real-test Recall@20 within 2e-4."""
     from test_host_logic import g12_compare, run_g12
     monkeypatch.setenv("LOCAL_RANK", "0")
     meta, log, flat, z = run_g12(tmp_path, teacher_forced=False)
@@ -420,8 +421,8 @@ def test_g12_midsize_free_running_on_gpu(tmp_path, monkeypatch):
     rep["real_test_recall20"] = {"got": [float(x) for x in meta.recall], "reference": [float(x) for x in z["recall"]]}
     _report("parity_g12_free_running.json", rep)
     g12_compare(log, want, flat, z, stages=(0,), loss_rtol=1e-4, flips=2)
-    g12_compare(log, want, flat, z, stages=(0, 1, 2, 3), loss_rtol=1e-3, flips=15)
-    assert np.abs(np.array(meta.recall) - z["recall"]).max() <= 5e-4 + 1e-9
+    g12_compare(log, want, flat, z, stages=(0, 1, 2, 3), loss_rtol=1e-4, flips=3)
+    assert np.abs(np.array(meta.recall) - z["recall"]).max() <= 2e-4 + 1e-9
 
 
 # ----------------------------------------------------------------------------- multi-GPU plumbing on one GPU
