@@ -79,6 +79,7 @@ def parse():
     ap.add_argument("--no-val", action="store_true", help="skip the validation evaluations (not the reference default)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-a3", action="store_true", help="skip the a3 (bare fused embed+loss+SGD) table-scale leg")
     ap.add_argument("--no-overlap", action="store_true",
                     help="evaluate in place on the training stream instead of on the side stream (single-queue runs for "
                          "rocprofv3 --pmc, which does not survive this workload's two queues)")
@@ -93,7 +94,7 @@ def parse():
 
 
 def bench_bare(a, device):
-    """a3 alone: synchronous minibatch SGD on (user, pos, neg) triples over large tables."""
+    """a3 alone: synchronous minibatch SGD on (user, pos, neg) triples over large tables.  Returns the result dict."""
     from sml_amd import synth
     from sml_amd.engine import HipEngine
     eng = HipEngine(device, a.d, a.bare_batch)
@@ -115,37 +116,69 @@ def bench_bare(a, device):
         eng.bare_epoch(wu, wi, tri, a.bare_batch, 0.05, 1e-6, 1e-6, bce=True, prepared=cur)
     torch.cuda.synchronize(device)
     dtm = time.perf_counter() - t0
+    cur = eng.bare_prepare(tri, a.bare_batch, a.users, a.items)      # (prepared ahead, as in the timed loop)
+    torch.cuda.synchronize(device)
     eng.profile(True)
-    eng.bare_epoch(wu, wi, tri, a.bare_batch, 0.05, 1e-6, 1e-6, bce=True)
+    eng.bare_epoch(wu, wi, tri, a.bare_batch, 0.05, 1e-6, 1e-6, bce=True, prepared=cur)
     torch.cuda.synchronize(device)
     prof = eng.profile_read()
     eng.profile(False)
     s = wu.element_size()
     a_sgd = 24 + 6 * a.d * s                       # int64 (u,i,j) + 3 rows read + 3 rows written
     n = a.bare_triples
-    t_grad, t_seg = prof["k_bare_grad"][1] / 1e3, prof["k_seg_update_sgd"][1] / 1e3
+    # k_bare_grad = the fused pass (unique rows in place, duplicated rows by their last arriver); the other two classes
+    # exist only in epochs with hot runs (chunk partial sums, per-row apply)
+    t_grad, t_seg = prof["k_bare_grad"][1] / 1e3, prof.get("k_seg_update_sgd", (0, 0.0))[1] / 1e3
     t_hot = prof.get("k_hot_rows", (0, 0.0))[1] / 1e3
     ach = n * a_sgd / (t_grad + t_seg + t_hot) / 1e9
-    # fabric bytes of one a3 step (one batch: gradient pass + run update + hot apply) from the committed PMC
-    # passes of this command at its profiled shape (tools/profile_round.sh); null for any other shape
-    traffic = None
-    if (a.users, a.items, a.bare_batch, a.d, a.bare_dtype) == (10000000, 1000000, 262144, 32, "f32") and a.item_zipf in (0.0, 1.0):
-        try:
-            run = json.load(open(os.path.join(REPO, "profiles", "r01e_pmc_per_launch.json")))["bare_z%d" % int(a.item_zipf)]
-            traffic = sum((2.0 * c["FETCH_SIZE"]["avg_counter_per_launch"] + c["WRITE_SIZE"]["avg_counter_per_launch"]) * 1024.0
-                          for k, c in run.items() if k.startswith(("k_bare_grad", "k_run_update", "k_hot_apply")))
-        except Exception:
-            traffic = None
+    e2e = a.steps * n / dtm * a_sgd / 1e9                 # whole step incl. the index preparation on its side stream
     out = {"metric": "bare embed+loss+SGD step triples/s (a3), synthetic uniform users / Zipf(%g) items, d=%d %s" % (a.item_zipf, a.d, a.bare_dtype),
            "value": a.steps * n / dtm, "unit": "triples/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": 1000.0 * dtm / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": a.bare_dtype, "data": "synthetic",
            "config": {"workload": "bare: users=%d items=%d triples/epoch=%d batch=%d" % (a.users, a.items, n, a.bare_batch)},
+           # traffic (PMC bytes) cannot be read from inside the process: null here; the rocprofv3 --pmc passes of this
+           # command are tools/profile_round.sh's, summarised under profiles/
            "roofline": {"kernel": "k_bare_grad + k_seg_update_sgd + k_hot_rows (one a3 step)", "bound": "hbm", "achieved": ach,
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                        "end_to_end_achieved": e2e, "end_to_end_frac": e2e / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_step": a_sgd * min(a.bare_batch, n), "algorithmic_bytes_per_triple": a_sgd},
            "kernels": {k: {"launches": c, "total_ms": round(m, 3), "avg_us": round(1000.0 * m / c, 2)} for k, (c, m) in prof.items()}}
-    print(json.dumps(out))
+    del eng, wu, wi, tri
+    torch.cuda.empty_cache()
+    return out
+
+
+A3_CONFIGS = (   # (tag, users, items, d, dtype, item zipf): BASELINE.json configs 4 / 5 shapes and the d=32 target of north_star
+    ("d32_f32_uniform", 10000000, 1000000, 32, "f32", 0.0),
+    ("d32_f32_zipf", 10000000, 1000000, 32, "f32", 1.0),
+    ("d64_f32_zipf", 10000000, 1000000, 64, "f32", 1.0),
+    ("d128_f16_uniform", 50000000, 5000000, 128, "f16", 0.0),
+)
+
+
+def a3_object(a, device):
+    """The fused embed+loss+SGD kernel pair (north_star's HBM-roofline target) at table scale,
+    measured in this same run: per configuration the kernel-only fraction of the 8 TB/s roofline (HIP events over
+    k_bare_grad + k_run_update + k_hot_apply), the end-to-end fraction (wall clock of whole epochs, index
+    preparation included) and the algorithmic bytes per triple (24 + 6*d*s)."""
+    import copy
+    res = {}
+    for tag, users, items, d, dt, zipf in A3_CONFIGS:
+        b = copy.copy(a)
+        b.users, b.items, b.d, b.bare_dtype, b.item_zipf = users, items, d, dt, zipf
+        b.bare_batch, b.bare_triples, b.steps, b.warmup = 262144, 1 << 22, 3, 1
+        try:
+            r = bench_bare(b, device)
+            res[tag] = {"users": users, "items": items, "d": d, "dtype": dt, "item_zipf": zipf, "batch": b.bare_batch,
+                        "triples_per_s": r["value"], "bytes_per_triple": r["roofline"]["algorithmic_bytes_per_triple"],
+                        "kernel_frac": r["roofline"]["frac"], "end_to_end_frac": r["roofline"]["end_to_end_frac"],
+                        "kernel_GBps": r["roofline"]["achieved"],
+                        "kernels_avg_us": {k: v["avg_us"] for k, v in r["kernels"].items()}}
+        except Exception as e:      # noqa: BLE001 -- e.g. a smaller-memory part: report, do not lose the headline line
+            res[tag] = {"error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.empty_cache()
+    return res
 
 
 def build_state(engine, U, I, d, device, seed):
@@ -196,12 +229,16 @@ def kernel_work(name, a, hp, U_local):
 
 
 def pmc_traffic(kernel):
-    """Fabric bytes per launch of kernel class `kernel` from the committed rocprofv3 --pmc passes of this same
-    command (profiles/r01e_pmc_per_launch.json, made by tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE in
+    """Fabric bytes per launch of kernel class `kernel` from the COMMITTED rocprofv3 --pmc passes of this same
+    command (profiles/*_pmc_per_launch.json, made by tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE in
     separate passes; units KB; FETCH doubled per the gfx950 correction in MI355X_MICROARCH.md), averaged
-    over the class's template instances by launch count.  PMC cannot be read from inside the process, so
-    this is null whenever no committed summary covers the kernel."""
-    path = os.path.join(REPO, "profiles", "r01e_pmc_per_launch.json")
+    over the class's template instances by launch count.  PMC cannot be read from inside the process: the bench
+    line reports this under `traffic_from_profiles` (with the file's name) and leaves `traffic` null."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_per_launch.json")))
+    if not files:
+        return None, None
+    path = files[-1]
     try:
         runs = json.load(open(path))["period"]
         tot, n = 0.0, 0
@@ -211,9 +248,41 @@ def pmc_traffic(kernel):
             k = c["FETCH_SIZE"]["launches"]
             tot += k * (2.0 * c["FETCH_SIZE"]["avg_counter_per_launch"] + c["WRITE_SIZE"]["avg_counter_per_launch"]) * 1024.0
             n += k
-        return tot / n if n else None
+        return (tot / n if n else None), os.path.basename(path)
     except Exception:
-        return None
+        return None, None
+
+
+def rocprof_avg_us(kernel):
+    """Average duration of kernel class `kernel` in the COMMITTED rocprofv3 --kernel-trace --stats summary of this same
+    command (profiles/r*_yelp_period_kernel_stats.csv): a HIP-event pair around one short kernel reads the kernel
+    plus a few microseconds of the pair's own cost, rocprofv3 reads the kernel alone -- both are quoted."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_yelp_period_kernel_stats.csv")))
+    if not files:
+        return None, None
+    try:
+        tot_ms, calls = 0.0, 0        # tools/summarize_prof.py's columns: kernel, calls, total_ms, avg_us
+        for row in csv.DictReader(open(files[-1])):
+            if row["kernel"].startswith(kernel):
+                tot_ms += float(row["total_ms"])
+                calls += int(row["calls"])
+        return (1000.0 * tot_ms / calls if calls else None), os.path.basename(files[-1])
+    except Exception:
+        return None, None
+
+
+def host_cpu():
+    model = "unknown"
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                model = l.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"os_cpu_count": os.cpu_count(), "model": model}
 
 
 def cpu_baseline(a, hp):
@@ -253,7 +322,8 @@ def cpu_baseline(a, hp):
     n_updata = hp.multi_num * (1 + (hp.TR_epochs if not a.no_val else 0)) + 1
     period_s = hp.multi_num * (hp.MF_epochs * t_mf * n / n_mf + hp.TR_epochs * t_tr * n / n_tr) + n_updata * t_up + evals * t_ev
     triples = hp.multi_num * (hp.MF_epochs + hp.TR_epochs) * n
-    return {"value": triples / period_s, "unit": "triples/s", "cores": cores, "kind": "port",
+    return {"value": triples / period_s, "unit": "triples/s", "cores": cores, "kind": "port", "host": host_cpu(),
+            "extrapolated": True,
             "sample": "oracle on full-size tables: %d MF triples, %d TR triples, updata on 1/16 of rows, eval of 2048 rows; "
                       "scaled to one period (est. %.1f s/period: MF %.1f s, TR %.1f s, updata %.1f s, eval %.1f s)"
                       % (n_mf, n_tr, period_s, hp.multi_num * hp.MF_epochs * t_mf * n / n_mf,
@@ -271,7 +341,8 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if a.workload == "bare":
-        return bench_bare(a, device)
+        print(json.dumps(bench_bare(a, device)))
+        return
     from sml_amd.engine import HipEngine
     from sml_amd.period import Hyper, run_period, synth_plan
     hp = Hyper(multi_num=a.multi_num)
@@ -320,9 +391,11 @@ def main():
            "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": "yelp_period: users=%d items=%d interactions/period=%d neg=%d d=%d multi_num=%d "
-                                  "MF_batch=%d TR_batch=%d val_eval=%s" % (a.users, a.items, a.inter, a.neg, a.d,
-                                                                           hp.multi_num, hp.MF_batch_size, hp.TR_batch_size,
-                                                                           not a.no_val),
+                                  "MF_batch=%d TR_batch=%d val_eval=%s (the reference's 40 validation evaluations per period: "
+                                  "31 computed on the GPU, 9 memoised because the tables did not change in between -- identical "
+                                  "numbers); inputs resident in HBM: host batch supply and H2D are outside the timed region"
+                                  % (a.users, a.items, a.inter, a.neg, a.d, hp.multi_num, hp.MF_batch_size, hp.TR_batch_size,
+                                     not a.no_val),
                       "parallelism": ("users row-sharded x%d, items replicated, %s exchange" %
                                       (world, "native RCCL" if dctx.native else "torch.distributed"))
                       if dist is not None else "single GPU"}}
@@ -348,10 +421,19 @@ def main():
                     ach, peak, unit = per_launch / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
                 else:
                     ach, peak, unit = per_launch / avg_s / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+                tp, tfile = pmc_traffic(name)
+                rp_us, rp_file = rocprof_avg_us(name)
                 out["roofline"] = {"kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
-                                   "frac": ach / peak, "traffic": pmc_traffic(name), "launches": cnt,
-                                   "avg_launch_us": 1e6 * avg_s, "algorithmic_per_launch": per_launch}
+                                   "frac": ach / peak, "traffic": None, "traffic_from_profiles": tp, "traffic_profile": tfile,
+                                   "launches": cnt, "avg_launch_us": 1e6 * avg_s, "algorithmic_per_launch": per_launch,
+                                   # in-run HIP events (above) vs the committed rocprofv3 kernel-trace of the same command
+                                   "avg_launch_us_rocprof": rp_us, "rocprof_profile": rp_file,
+                                   "frac_rocprof": ((per_launch / (rp_us * 1e-6) / (1e9 if bound == "hbm" else 1e12)) / peak) if rp_us else None}
             out["kernels"] = kern
+    if rank == 0 and world == 1 and not a.no_a3:
+        del plans, st
+        torch.cuda.empty_cache()
+        out["a3"] = a3_object(a, device)
     if rank == 0 and world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(a, hp)
     if rank == 0:

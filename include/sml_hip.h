@@ -122,12 +122,28 @@ typedef struct {
     int world;
     const uint64_t* key_items;
     const uint32_t* val_items;
-    float* dx_local;        /* caller-owned scratch, >= (3*batch + 64) * d floats */
-    float* dx_items_all;    /* caller-owned, world * 2*batch * d floats */
+    float* dx_local;        /* caller-owned scratch, >= (3*batch + 64 + slot_stride) * d floats */
+    float* dx_items_all;    /* caller-owned, world * slot_stride * d floats */
     sml_mf_hook hook;
     void* hook_user;
-    float loss_scale;
+    float loss_scale;       /* used when no batch plan gives per-batch scales */
+    int64_t slot_stride;    /* rows every rank contributes per batch to dx_items_all (0: 2*batch) */
+    const int64_t* item_off;/* host [n_batches+1]: batch b's global item occurrences are key/val_items[item_off[b] .. item_off[b+1])
+                               (NULL: world*2*batch per full batch, the uniform layout) */
 } sml_mf_exchange;
+
+/* Batches of unequal size.  A global batch split over ranks by user owner leaves every rank a DIFFERENT number of
+ * triples per batch (possibly none).  With a plan, `triples` holds the rank's batches back to back, batch b =
+ * rows [batch_off[b], batch_off[b+1]), each at most `batch` long (the size the scratch was made for), and
+ * loss_scale[b] multiplies batch b's loss and gradients (B_local/B_global for the mean-type BCE, 1 for the
+ * sum-type BPR kinds).  An empty batch still takes part in the exchange and in the optimiser step.
+ * NULL plan: consecutive batches of `batch` triples, the last one ragged. */
+typedef struct {
+    int64_t n_batches;
+    const int64_t* batch_off;       /* host [n_batches + 1] */
+    const int32_t* batch_off_dev;   /* the same offsets as int32 on the device (the index preparation reads them there) */
+    const float* loss_scale;        /* host [n_batches], or NULL for the call's scalar */
+} sml_batch_plan;
 
 /* One epoch over n pre-drawn triples (u,i,j) int64 [n,3], in batches of `batch`:
  * 6 gathers -> run_MF -> + l2*0.5*sum(x_hat^2) -> backward to the W_hat rows ->
@@ -140,7 +156,7 @@ typedef struct {
 int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
                        const int64_t* triples, int64_t n, int batch, float lr, float l2,
                        int loss_kind, int64_t* step, float* batch_loss, const sml_mf_exchange* xchg,
-                       void* stream);
+                       const sml_batch_plan* plan, void* stream);
 /* Replay every pending zero-gradient Adam step so the tables can be read out
  * (before save_MF_weight / updata / evaluation; model/transfer.py:518, 777, 832). */
 int sml_mf_adam_flush(sml_ctx* ctx, const sml_mf_tables* t, float lr, int64_t step, void* stream);
@@ -166,7 +182,7 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
                        const sml_tr_tables* t, const int64_t* triples, int64_t n, int batch,
                        float lr, float weight_decay, int loss_kind, float loss_scale,
                        int64_t* step, float* batch_loss, sml_grad_hook grad_hook, void* hook_user,
-                       void* stream);
+                       const sml_batch_plan* plan, void* stream);
 
 /* ---- a3: bare fused embed + loss + SGD write-back ------------------------------ */
 /* gather 3 rows, 2 dot products, BCE (model/baseline.py:188-201) or BPR
@@ -178,10 +194,10 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
  * batch count and n_user / n_item allow -- unique marks, compacted run records of the duplicated
  * rows) inline on `stream`; 0/1 uses the lists a previous
  * sml_embed_loss_sgd_prepare call built for the SAME triples/n/batch -- so a caller can
- * prepare epoch e+1 on a side stream while epoch e runs.  sml_embed_loss_sgd_epoch waits on the HOST
- * for the index lists it uses to be complete (it reads their longest run to decide whether the
- * hot-row kernels are needed at all): free when they were prepared ahead, one host wait per epoch
- * when built inline. */
+ * prepare epoch e+1 on a side stream while epoch e runs.  No host wait either way: the call QUERIES whether
+ * the lists it uses are complete; if they are (prepared ahead) and hold no hot run, the hot-row kernels are
+ * skipped; if they are still in flight the hot-row kernels are launched and find their lists empty on the device.
+ * (The caller orders `stream` behind the preparation stream, as for any two streams.) */
 int sml_embed_loss_sgd_prepare(sml_ctx* ctx, const int64_t* triples, int64_t n, int batch,
                                int64_t n_user, int64_t n_item, int slot, void* stream);
 int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n_user,

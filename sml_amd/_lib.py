@@ -31,7 +31,12 @@ class MFTables(ctypes.Structure):
 
 class MFExchange(ctypes.Structure):
     _fields_ = [("world", ctypes.c_int), ("key_items", c_void), ("val_items", c_void), ("dx_local", c_void),
-                ("dx_items_all", c_void), ("hook", MF_HOOK), ("hook_user", c_void), ("loss_scale", ctypes.c_float)]
+                ("dx_items_all", c_void), ("hook", MF_HOOK), ("hook_user", c_void), ("loss_scale", ctypes.c_float),
+                ("slot_stride", ctypes.c_int64), ("item_off", c_void)]
+
+
+class BatchPlan(ctypes.Structure):
+    _fields_ = [("n_batches", ctypes.c_int64), ("batch_off", c_void), ("batch_off_dev", c_void), ("loss_scale", c_void)]
 
 
 class TRTables(ctypes.Structure):
@@ -52,12 +57,12 @@ SIGNATURES = {
     "sml_transfer_forward": (ctypes.c_int, [c_void, c_void, ctypes.c_int, c_void, c_void, c_void, ctypes.c_int64, c_void]),
     "sml_mf_stage_epoch": (ctypes.c_int, [c_void, c_void, ctypes.POINTER(MFTables), c_void, ctypes.c_int64, ctypes.c_int,
                                           ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.POINTER(ctypes.c_int64),
-                                          c_void, ctypes.POINTER(MFExchange), c_void]),
+                                          c_void, ctypes.POINTER(MFExchange), ctypes.POINTER(BatchPlan), c_void]),
     "sml_mf_adam_flush": (ctypes.c_int, [c_void, ctypes.POINTER(MFTables), ctypes.c_float, ctypes.c_int64, c_void]),
     "sml_tr_stage_epoch": (ctypes.c_int, [c_void, c_void, c_void, c_void, c_void, ctypes.POINTER(TRTables), c_void,
                                           ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int,
                                           ctypes.c_float, ctypes.POINTER(ctypes.c_int64), c_void, GRAD_HOOK, c_void,
-                                          c_void]),
+                                          ctypes.POINTER(BatchPlan), c_void]),
     "sml_embed_loss_sgd_epoch": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                                                 c_void, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                                 ctypes.c_float, ctypes.c_int, c_void, ctypes.c_int, c_void]),

@@ -96,6 +96,19 @@ def main(which, argv=None):
     args = get_parse(which).parse_args(argv)
     if which == "yelp" and "LOCAL_RANK" not in os.environ:
         os.environ["CUDA_VISIBLE_DEVICES"] = str(args.cuda)      # reference main_yelp.py:125
+    # `torchrun --nproc-per-node N main_yelp.py ...`: one process per GPU.  Every rank runs this same program on the
+    # same seeds and files; users are sharded by owner inside meta_train (sml_amd/dist.py), rank 0 prints.
+    dist = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch.distributed as dist
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
+        if not dist.is_initialized():
+            dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+        if dist.get_rank() != 0:
+            import sys
+            sys.stdout = open(os.devnull, "w")
     # The host side of this process only draws random numbers and slices index arrays; torch's CPU
     # thread pool costs tens of ms per randperm(n > 32768) to wake (it splits the arange fill), so keep
     # host torch ops on the calling thread.  Results do not depend on the thread count.
@@ -113,7 +126,8 @@ def main(which, argv=None):
     sets = dataset2.transfer_data(args, path=args.data_path, datasetname=args.data_name, file_path_list=file_list,
                                   test_list=test_list, validation_list=None,
                                   online_train_time=round(cfg["train_from"]), online_test_time=round(cfg["test_from"]))
-    meta = transfer.meta_train(args, sets, sets.user_number, sets.item_number, args.laten)
+    meta = transfer.meta_train(args, sets, sets.user_number, sets.item_number, args.laten) if dist is None else \
+        transfer.meta_train(args, sets, sets.user_number, sets.item_number, args.laten, dist=dist)
     meta.run(args)
     if which == "yelp":
         print("@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@TR:L2:", 1e-06)

@@ -291,19 +291,21 @@ int sort_pairs(IndexSet* c, int64_t n, int end_u, int end_i, hipStream_t st) {
 // With `dups` the duplicated runs are also compacted (stable) with their per-batch ranges, and every
 // occurrence gets its "row occurs once in this batch" mark -- all on the device, no host round trip.
 int sort_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_tiles, int64_t n_user, int64_t n_item,
-               bool dups, hipStream_t st) {
-    HIPCHK(c->key_u.ensure((size_t)n)); HIPCHK(c->key_u2.ensure((size_t)n));
-    HIPCHK(c->val_u.ensure((size_t)n)); HIPCHK(c->val_u2.ensure((size_t)n));
-    HIPCHK(c->key_i.ensure((size_t)2 * n)); HIPCHK(c->key_i2.ensure((size_t)2 * n));
-    HIPCHK(c->val_i.ensure((size_t)2 * n)); HIPCHK(c->val_i2.ensure((size_t)2 * n));
-    const int64_t nb = (n + batch - 1) / batch;
+               bool dups, hipStream_t st, const sml_batch_plan* plan = nullptr) {
+    HIPCHK(c->key_u.ensure((size_t)n + 1)); HIPCHK(c->key_u2.ensure((size_t)n + 1));
+    HIPCHK(c->val_u.ensure((size_t)n + 1)); HIPCHK(c->val_u2.ensure((size_t)n + 1));
+    HIPCHK(c->key_i.ensure((size_t)2 * n + 1)); HIPCHK(c->key_i2.ensure((size_t)2 * n + 1));
+    HIPCHK(c->val_i.ensure((size_t)2 * n + 1)); HIPCHK(c->val_i2.ensure((size_t)2 * n + 1));
+    const int64_t nb = plan ? plan->n_batches : (n + batch - 1) / batch;
+    const int* boff = plan ? plan->batch_off_dev : nullptr;
+    if (n == 0) { c->n = 0; c->batch = batch; c->triples = tri; return SML_OK; }
     const int bb = ceil_log2(nb + 1);
     const int rbu = n_user > 0 ? ceil_log2(n_user) : 32, rbi = n_item > 0 ? ceil_log2(n_item) : 32;
     const bool narrow = bb + rbu <= 32 && bb + rbi <= 32;
     c->key_bytes = narrow ? 4 : 8;
     c->row_bits_u = narrow ? rbu : 32; c->row_bits_i = narrow ? rbi : 32;
     HIPCHK(sml_launch_build_keys(c->key_bytes, tri, n, batch, pad_tiles, c->row_bits_u, c->row_bits_i, c->key_u.p, c->val_u.p,
-                                 c->key_i.p, c->val_i.p, st));
+                                 c->key_i.p, c->val_i.p, boff, (int)nb, st));
     int rc = narrow ? sort_pairs<uint32_t>(c, n, c->row_bits_u + bb, c->row_bits_i + bb, st)
                     : sort_pairs<uint64_t>(c, n, 32 + bb, 32 + bb, st);
     if (rc) return rc;
@@ -342,9 +344,8 @@ int sort_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
                                     c->n_sel.p + 2, (int64_t)batch, 0, hl, c->hot_count.p, c->hot_cap, st));
         HIPCHK(sml_launch_make_runs(c->key_bytes, c->key_i2.p, c->val_i2.p, 2 * n, c->row_bits_i, c->heads_i.p, c->n_sel.p + 1, n, c->runs_i.p,
                                     c->n_sel.p + 2, (int64_t)2 * batch, 1, hl, c->hot_count.p, c->hot_cap, st));
-        // the longest run of the epoch travels to the host: an epoch without hot rows skips the hot-row
-        // kernels altogether (the epoch call waits for this event -- long past when the lists were
-        // prepared an epoch ahead on a side stream)
+        // the longest run of the epoch travels to the host: an epoch KNOWN to have no hot rows skips the hot-row
+        // kernels altogether (the epoch call queries this event, it never waits for it)
         if (!c->max_len_host) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->max_len_host), sizeof(int), hipHostMallocDefault));
         if (!c->ready) HIPCHK(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
         HIPCHK(hipMemcpyAsync(c->max_len_host, c->n_sel.p + 2, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -441,9 +442,11 @@ int sml_transfer_forward(sml_ctx* ctx, const float* theta, int net, const float*
 
 int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t, const int64_t* triples, int64_t n,
                        int batch, float lr, float l2, int loss_kind, int64_t* step, float* batch_loss,
-                       const sml_mf_exchange* xchg, void* stream) {
-    if (!ctx || !theta || !t || !triples || !step || !batch_loss || n <= 0 || batch <= 0)
+                       const sml_mf_exchange* xchg, const sml_batch_plan* plan, void* stream) {
+    if (!ctx || !theta || !t || !step || !batch_loss || batch <= 0 || (plan ? n < 0 : n <= 0) || (n > 0 && !triples))
         return fail(SML_EINVAL, "sml_mf_stage_epoch", "bad argument");
+    if (plan && (plan->n_batches <= 0 || !plan->batch_off || !plan->batch_off_dev || plan->batch_off[0] != 0 || plan->batch_off[plan->n_batches] != n))
+        return fail(SML_EINVAL, "sml_mf_stage_epoch", "batch plan does not cover the triples");
     if (batch > ctx->max_batch) return fail(SML_EINVAL, "sml_mf_stage_epoch", "batch exceeds ctx max_batch");
     if (n > 0x3fffffff) return fail(SML_EINVAL, "sml_mf_stage_epoch", "epoch too long");
     if (loss_kind < 0 || loss_kind > 3 || ((loss_kind == SML_LOSS_BPR_UNIT) != (ctx->variant == 1)))
@@ -455,7 +458,10 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
     DevGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     const int d = ctx->d;
-    const int64_t nb = (n + batch - 1) / batch;
+    const int64_t nb = plan ? plan->n_batches : (n + batch - 1) / batch;
+    if (plan) for (int64_t b = 0; b < nb; ++b)
+        if (plan->batch_off[b + 1] < plan->batch_off[b] || plan->batch_off[b + 1] - plan->batch_off[b] > batch)
+            return fail(SML_EINVAL, "sml_mf_stage_epoch", "a planned batch is longer than `batch`");
     int rc;
     if ((rc = ensure_pk(ctx))) return rc;
     if ((rc = ensure_transfer_ws(ctx, batch, false))) return rc;
@@ -465,18 +471,21 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
     const int fns = fwd_split(wg_tiles(batch, 1) + wg_tiles(2 * batch, 1)), bsplit = bwd_split(wg_tiles(batch, 1) + wg_tiles(2 * batch, 1));
     HIPCHK(ctx->loss_part.ensure((size_t)nb * lstride));
     ctx->prof.begin(PC_PACK, st); HIPCHK(sml_launch_theta_pack(d, theta, ctx->pk.p, st)); ctx->prof.end(st);
-    ctx->prof.begin(PC_SORT, st); rc = sort_epoch(&ctx->ix[0], triples, n, batch, 1, t->n_user, t->n_item, false, st);
-    if (!rc && xchg) {   // the global item occurrence list of the job: run records over the caller's sorted keys
-        HIPCHK(ctx->rec_x.ensure((size_t)xchg->world * 2 * n));
-        HIPCHK(sml_launch_mark_runs(8, xchg->key_items, xchg->val_items, (int64_t)xchg->world * 2 * n, 32, ctx->rec_x.p, nullptr, nullptr, 0, 0, st));
+    ctx->prof.begin(PC_SORT, st); rc = sort_epoch(&ctx->ix[0], triples, n, batch, 1, t->n_user, t->n_item, false, st, plan);
+    const int64_t x_total = !xchg ? 0 : xchg->item_off ? xchg->item_off[nb] : (int64_t)xchg->world * 2 * n;
+    const int64_t x_stride = !xchg ? 0 : xchg->slot_stride > 0 ? xchg->slot_stride : (int64_t)2 * batch;
+    if (!rc && xchg && x_total > 0) {   // the global item occurrence list of the job: run records over the caller's sorted keys
+        HIPCHK(ctx->rec_x.ensure((size_t)x_total));
+        HIPCHK(sml_launch_mark_runs(8, xchg->key_items, xchg->val_items, x_total, 32, ctx->rec_x.p, nullptr, nullptr, 0, 0, st));
     }
     ctx->prof.end(st); if (rc) return rc;
     HIPCHK(hipMemsetAsync(ctx->loss_part.p, 0, (size_t)nb * lstride * sizeof(float), st));
     const int64_t ns = sml_net_size(d), ps = sml_pk_size(d);
     float* dx_buf = xchg ? xchg->dx_local : ctx->dx.p;
     for (int64_t b = 0; b < nb; ++b) {
-        const int B = (int)((n - b * batch) < batch ? (n - b * batch) : batch);
-        const int64_t* tri = triples + b * batch * 3;
+        const int64_t off0 = plan ? plan->batch_off[b] : b * batch;
+        const int B = plan ? (int)(plan->batch_off[b + 1] - off0) : (int)((n - off0) < batch ? (n - off0) : batch);
+        const int64_t* tri = triples + off0 * 3;
         const int cur = (int)(*step + 1 + b);
         SmlFwdArgs f;
         memset(&f, 0, sizeof(f));
@@ -508,25 +517,28 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
         }
         w.tiles0 = f.tiles0; w.l2 = l2; w.convg_part = nullptr;
         w.out_all = ctx->out.p; w.B = B; w.ioff = SML_R * tiles_of(B); w.kind = loss_kind;
-        w.scale = xchg ? xchg->loss_scale : 1.0f; w.loss_part = ctx->loss_part.p + b * lstride;
+        w.scale = (plan && plan->loss_scale) ? plan->loss_scale[b] : xchg ? xchg->loss_scale : 1.0f;
+        w.loss_part = ctx->loss_part.p + b * lstride;
         w.out_np = fns; w.out_pstride = out_pstride;
         ctx->prof.begin(PC_BWD, st); HIPCHK(sml_launch_bwd(d, bsplit, w, tiles, st)); ctx->prof.end(st);
         SmlRunArgs u;
         memset(&u, 0, sizeof(u));
-        u.run_u = ctx->ix[0].rec_u.p + b * batch; u.n_u = B; u.val_u = ctx->ix[0].val_u2.p;
-        u.run_i = ctx->ix[0].rec_i.p + 2 * b * batch; u.n_i = 2 * B; u.val_i = ctx->ix[0].val_i2.p;
+        u.run_u = ctx->ix[0].rec_u.p + off0; u.n_u = B; u.val_u = ctx->ix[0].val_u2.p;
+        u.run_i = ctx->ix[0].rec_i.p + 2 * off0; u.n_i = 2 * B; u.val_i = ctx->ix[0].val_i2.p;
         u.dx = dx_buf; u.dx_i = dx_buf; u.w_user = t->w_user; u.w_item = t->w_item;
         if (xchg) {
-            // every rank contributes 2*B item occurrences of this batch (equal B on all ranks)
+            // every rank contributes x_stride rows per batch (its 2*B item-gradient rows first: B may differ from rank
+            // to rank and be zero); an empty local batch still joins the collective
             if (xchg->hook) {
                 if (xchg->hook(xchg->hook_user, b) != 0) return fail(SML_ESTATE, "sml_mf_stage_epoch", "exchange hook failed");
             } else {
                 const int64_t ioff = (int64_t)SML_R * tiles_of(B);
-                NCCLCHK(g_rccl.AllGather(dx_buf + ioff * d, xchg->dx_items_all, (size_t)2 * batch * d, ncclFloat, ctx->comm, st));
+                NCCLCHK(g_rccl.AllGather(dx_buf + ioff * d, xchg->dx_items_all, (size_t)x_stride * d, ncclFloat, ctx->comm, st));
             }
-            u.run_i = ctx->rec_x.p + (int64_t)xchg->world * 2 * b * batch;
+            const int64_t x0 = xchg->item_off ? xchg->item_off[b] : (int64_t)xchg->world * 2 * b * batch;
+            u.run_i = ctx->rec_x.p + x0;
             u.val_i = xchg->val_items;
-            u.n_i = xchg->world * 2 * B;
+            u.n_i = xchg->item_off ? (int)(xchg->item_off[b + 1] - x0) : xchg->world * 2 * B;
             u.dx_i = xchg->dx_items_all;
         }
         u.m_user = t->m_user; u.v_user = t->v_user; u.m_item = t->m_item; u.v_item = t->v_item;
@@ -557,16 +569,21 @@ int sml_mf_adam_flush(sml_ctx* ctx, const sml_mf_tables* t, float lr, int64_t st
 int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v, float* theta_grad,
                        const sml_tr_tables* t, const int64_t* triples, int64_t n, int batch, float lr,
                        float weight_decay, int loss_kind, float loss_scale, int64_t* step, float* batch_loss,
-                       sml_grad_hook grad_hook, void* hook_user, void* stream) {
-    if (!ctx || !theta || !adam_m || !adam_v || !t || !triples || !step || !batch_loss || n <= 0 || batch <= 0)
+                       sml_grad_hook grad_hook, void* hook_user, const sml_batch_plan* plan, void* stream) {
+    if (!ctx || !theta || !adam_m || !adam_v || !t || !step || !batch_loss || batch <= 0 || (plan ? n < 0 : n <= 0) || (n > 0 && !triples))
         return fail(SML_EINVAL, "sml_tr_stage_epoch", "bad argument");
+    if (plan && (plan->n_batches <= 0 || !plan->batch_off || plan->batch_off[0] != 0 || plan->batch_off[plan->n_batches] != n))
+        return fail(SML_EINVAL, "sml_tr_stage_epoch", "batch plan does not cover the triples");
     if (batch > ctx->max_batch) return fail(SML_EINVAL, "sml_tr_stage_epoch", "batch exceeds ctx max_batch");
     if (loss_kind < 0 || loss_kind > 3 || ((loss_kind == SML_LOSS_BPR_UNIT) != (ctx->variant == 1)))
         return fail(SML_EINVAL, "sml_tr_stage_epoch", "loss_kind (SML_LOSS_BPR_UNIT goes with variant 1, and only it)");
     DevGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     const int d = ctx->d;
-    const int64_t nb = (n + batch - 1) / batch;
+    const int64_t nb = plan ? plan->n_batches : (n + batch - 1) / batch;
+    if (plan) for (int64_t b = 0; b < nb; ++b)
+        if (plan->batch_off[b + 1] < plan->batch_off[b] || plan->batch_off[b + 1] - plan->batch_off[b] > batch)
+            return fail(SML_EINVAL, "sml_tr_stage_epoch", "a planned batch is longer than `batch`");
     int rc;
     if ((rc = ensure_pk(ctx))) return rc;
     if ((rc = ensure_transfer_ws(ctx, batch, true))) return rc;
@@ -581,8 +598,9 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
     HIPCHK(hipMemsetAsync(grad, 0, (size_t)2 * sml_net_size(d) * sizeof(float), st));
     const int64_t ns = sml_net_size(d), ps = sml_pk_size(d);
     for (int64_t b = 0; b < nb; ++b) {
-        const int B = (int)((n - b * batch) < batch ? (n - b * batch) : batch);
-        const int64_t* tri = triples + b * batch * 3;
+        const int64_t off0 = plan ? plan->batch_off[b] : b * batch;
+        const int B = plan ? (int)(plan->batch_off[b + 1] - off0) : (int)((n - off0) < batch ? (n - off0) : batch);
+        const int64_t* tri = triples + off0 * 3;
         SmlFwdArgs f;
         memset(&f, 0, sizeof(f));
         for (int s = 0; s < 2; ++s) {
@@ -615,7 +633,7 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
         }
         w.tiles0 = f.tiles0; w.l2 = 0.0f; w.convg_part = ctx->convg.p;
         w.out_all = ctx->out.p; w.B = B; w.ioff = SML_R * tiles_of(B); w.kind = loss_kind;
-        w.scale = loss_scale; w.loss_part = ctx->loss_part.p + b * lstride;
+        w.scale = (plan && plan->loss_scale) ? plan->loss_scale[b] : loss_scale; w.loss_part = ctx->loss_part.p + b * lstride;
         w.out_np = fns; w.out_pstride = out_pstride;
         ctx->prof.begin(PC_BWD, st); HIPCHK(sml_launch_bwd(d, bsplit, w, tiles, st)); ctx->prof.end(st);
         const SmlSched sc = sched_entry((double)lr, *step + 1 + b);
@@ -686,9 +704,13 @@ int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n
         return fail(SML_ESTATE, "sml_embed_loss_sgd_epoch", "index set was prepared for other triples");
     }
     HIPCHK(hipMemsetAsync(ctx->loss_part.p, 0, (size_t)nb * lstride * sizeof(float), st));
-    HIPCHK(hipEventSynchronize(X->ready));       // host-side: the index lists (and their longest run) are final
+    // NO host wait: the event is only queried.  Lists prepared an epoch ahead on a side stream are long complete and
+    // their longest run is known: an epoch without hot rows skips the hot-row kernels and runs the light-tailed run
+    // kernel.  Lists still in flight (built inline just above, or prepared a moment ago): assume hot rows -- the hot
+    // reducers then find, on the device, that their lists are empty.
     const int hot_cap = X->hot_cap;
-    const bool hot = hot_cap > 0 && *X->max_len_host > SML_HOT;     // no hot run in the whole epoch: skip that path
+    const bool known = hipEventQuery(X->ready) == hipSuccess;
+    const bool hot = hot_cap > 0 && (!known || *X->max_len_host > SML_HOT);
     const int hot_chunks = 3 * batch / SML_HOT_CHUNK + hot_cap;
     if (hot) {
         HIPCHK(ctx->hot_first.ensure((size_t)hot_cap));

@@ -191,19 +191,27 @@ __global__ __launch_bounds__(256) void k_bare_grad(SmlBareArgs a) {
 template <typename K>
 __global__ void k_build_keys(const int64_t* __restrict__ tri, int64_t n, int batch, int pad_tiles, int row_bits_u,
                              int row_bits_i, K* __restrict__ key_u, uint32_t* __restrict__ val_u,
-                             K* __restrict__ key_i, uint32_t* __restrict__ val_i) {
+                             K* __restrict__ key_i, uint32_t* __restrict__ val_i, const int* __restrict__ boff, int nb) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
-    const int64_t b = e / batch;
-    const int64_t rem = n - b * batch;
-    const uint32_t Bb = (uint32_t)(rem < batch ? rem : batch);
-    const uint32_t t = (uint32_t)(e - b * batch);
+    int64_t b, start;
+    uint32_t Bb;
+    if (boff == nullptr) {
+        b = e / batch; start = b * batch;
+        const int64_t rem = n - start;
+        Bb = (uint32_t)(rem < batch ? rem : batch);
+    } else {                                   // planned batches of unequal size: the last b with boff[b] <= e
+        int lo = 0, hi = nb - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int64_t)boff[mid] <= e) lo = mid; else hi = mid - 1; }
+        b = lo; start = boff[lo]; Bb = (uint32_t)(boff[lo + 1] - boff[lo]);
+    }
+    const uint32_t t = (uint32_t)(e - start);
     const uint32_t ioff = pad_tiles ? ((Bb + SML_R - 1) / SML_R) * SML_R : Bb;   // first item slot of the batch
     key_u[e] = ((K)b << row_bits_u) | (K)(uint32_t)tri[e * 3];
     val_u[e] = t;
-    // items: batch b's positives then negatives occupy [2*b*batch, 2*b*batch + 2*Bb) -- contiguous per
+    // items: batch b's positives then negatives occupy [2*start, 2*start + 2*Bb) -- contiguous per
     // batch, so after the (stable) sort batch b's item occurrences are exactly that range again
-    const int64_t base = 2 * b * batch;
+    const int64_t base = 2 * start;
     key_i[base + t] = ((K)b << row_bits_i) | (K)(uint32_t)tri[e * 3 + 1];
     val_i[base + t] = ioff + t;
     key_i[base + Bb + t] = ((K)b << row_bits_i) | (K)(uint32_t)tri[e * 3 + 2];
@@ -431,7 +439,9 @@ __global__ __launch_bounds__(256) void k_run_update(SmlRunArgs a) {
     constexpr int G = 64 / LPR;             // lane groups (records) per wavefront
     // (an SGD epoch without hot runs is light-tailed: shallower unrolls, 71 instead of 112 VGPRs, 7 waves per SIMD)
     constexpr bool LIGHT = OPT == 0 && !HOTB;
-    constexpr int LONG = LIGHT ? 4 : 8;     // runs longer than this are summed by the whole wavefront
+    // runs longer than this are summed by the whole wavefront.  (ONE value for both SGD variants: which of them runs
+    // depends on whether the epoch's longest run is known yet, and the two must round identically)
+    constexpr int LONG = OPT == 0 ? 4 : 8;
     constexpr int LD = (VEC == 4 && !LIGHT) ? 8 : 4;    // ... with LD rows per lane group in flight
     __shared__ SmlSched swin[OPT == 1 ? SML_SW : 1];
     if (OPT == 1) {                       // the Adam schedule of the last SML_SW steps, staged once per block
@@ -938,10 +948,12 @@ hipError_t sml_launch_batch_offsets(const SmlRun* runs, const int* n_sel, int nb
     return hipGetLastError();
 }
 hipError_t sml_launch_build_keys(int key_bytes, const int64_t* tri, int64_t n, int batch, int pad_tiles, int row_bits_u,
-                                 int row_bits_i, void* key_u, uint32_t* val_u, void* key_i, uint32_t* val_i, hipStream_t st) {
+                                 int row_bits_i, void* key_u, uint32_t* val_u, void* key_i, uint32_t* val_i, const int* boff,
+                                 int nb, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (key_bytes == 4) k_build_keys<uint32_t><<<grid, dim3(256), 0, st>>>(tri, n, batch, pad_tiles, row_bits_u, row_bits_i, (uint32_t*)key_u, val_u, (uint32_t*)key_i, val_i);
-    else k_build_keys<uint64_t><<<grid, dim3(256), 0, st>>>(tri, n, batch, pad_tiles, row_bits_u, row_bits_i, (uint64_t*)key_u, val_u, (uint64_t*)key_i, val_i);
+    if (key_bytes == 4) k_build_keys<uint32_t><<<grid, dim3(256), 0, st>>>(tri, n, batch, pad_tiles, row_bits_u, row_bits_i, (uint32_t*)key_u, val_u, (uint32_t*)key_i, val_i, boff, nb);
+    else k_build_keys<uint64_t><<<grid, dim3(256), 0, st>>>(tri, n, batch, pad_tiles, row_bits_u, row_bits_i, (uint64_t*)key_u, val_u, (uint64_t*)key_i, val_i, boff, nb);
     return hipGetLastError();
 }
 // grid for a run kernel: one lane group per record, capped (the kernels stride)

@@ -143,8 +143,10 @@ hipError_t sml_launch_make_runs(int key_bytes, const void* keys, const uint32_t*
                                 const int* n_heads, int64_t max_heads, SmlRun* runs, int* max_len, int64_t seg, int is_item,
                                 uint32_t* hot_list, int* hot_count, int hot_cap, hipStream_t st);
 hipError_t sml_launch_batch_offsets(const SmlRun* runs, const int* n_sel, int nb, int64_t seg, int* off, hipStream_t st);
+// boff: device [nb+1] offsets of the batches inside tri (null: batches of `batch`, the last one ragged)
 hipError_t sml_launch_build_keys(int key_bytes, const int64_t* tri, int64_t n, int batch, int pad_tiles, int row_bits_u,
-                                 int row_bits_i, void* key_u, uint32_t* val_u, void* key_i, uint32_t* val_i, hipStream_t st);
+                                 int row_bits_i, void* key_u, uint32_t* val_u, void* key_i, uint32_t* val_i, const int* boff,
+                                 int nb, hipStream_t st);
 
 struct SmlBareArgs {
     void* w_user; void* w_item;

@@ -10,6 +10,7 @@
 // a small register ring.  MT = 1 for a training batch (a TR batch is only 768 rows: more,
 // shorter tiles keep more CUs busy and halve the serial chain); MT = 2 for table-sized calls
 // (updata), where reusing each weight fragment for 32 rows halves the L2 traffic.
+#include <cstdlib>
 #include "sml_dev.h"
 #include "sml_kernels.h"
 
@@ -400,31 +401,6 @@ __global__ __launch_bounds__(512) void k_transfer_fwd(SmlFwdArgs a) {
     }
 }
 
-// sum 96 per-lane values over the wavefront with 96 shuffles instead of 6 x 96: at each step
-// the two halves of the lane pair split the remaining vector (a transposed butterfly), so after
-// masks 32..2 each lane holds 3 complete-but-for-one-bit sums; a last plain step finishes them.
-// Lane l (even) ends with v[0..2] = totals of compact indices base(l) + 0..2.  Deterministic.
-__device__ __forceinline__ void wave_sum96(float (&v)[SML_CG], int lane) {
-#pragma unroll
-    for (int s = 0; s < 5; ++s) {
-        const int mask = 32 >> s;
-        const int half = (SML_CG / 2) >> s;
-        const bool up = (lane & mask) != 0;
-#pragma unroll
-        for (int i = 0; i < half; ++i) {
-            const float send = up ? v[i] : v[i + half];
-            const float keep = up ? v[i + half] : v[i];
-            v[i] = keep + __shfl_xor(send, mask, 64);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) v[i] += __shfl_xor(v[i], 1, 64);
-}
-__device__ __forceinline__ int wave_sum96_base(int lane) {
-    return ((lane >> 5) & 1) * 48 + ((lane >> 4) & 1) * 24 + ((lane >> 3) & 1) * 12 + ((lane >> 2) & 1) * 6 +
-           ((lane >> 1) & 1) * 3;
-}
-
 // ------------------------------------------------------------------------------------
 // backward, one workgroup per row tile (batches large enough to fill the chip without the
 // coordinate split below): dOut -> (MF stage) dx_hat + l2*x_hat, or (TR stage) dZ1 rows +
@@ -444,8 +420,10 @@ __global__ __launch_bounds__(512) void k_transfer_bwd_full(SmlBwdArgs a) {
     constexpr int PSTR = K1 + 1;
     constexpr int SZ = cmax(R * S2 + R * SD, KSPL * R * PSTR);
     static_assert((K1 / 16) == 5 * TSPL, "5 column tiles per wave");
+    constexpr int CGS = 20;               // conv-grad operand row stride (16-byte aligned)
     __shared__ __attribute__((aligned(16))) float smem[SZ + 104];
-    __shared__ float red[8][SML_CG];
+    __shared__ __attribute__((aligned(16))) float cgst[TR ? 2 * 256 * CGS : 4];   // conv-gradient operands of 256 elements (A, B)
+    __shared__ float red[TR ? 8 : 1][256];
     __shared__ float cf[4][SML_TM * MT];
     __shared__ float lred[8];
     float* dZs = smem;                    // [R][516]
@@ -588,11 +566,10 @@ __global__ __launch_bounds__(512) void k_transfer_bwd_full(SmlBwdArgs a) {
     }
     __syncthreads();
     // ---- per-coordinate tail: Gelu'(h2) -> conv2^T -> Gelu'(h1) -> conv1^T (row 1 = x_hat)
-    float cg[TR ? SML_CG : 1];
-    if constexpr (TR) {
-#pragma unroll
-        for (int i = 0; i < SML_CG; ++i) cg[i] = 0.0f;
-    }
+    // TR: the conv1/conv2 parameter gradients are ONE small matrix product over the tile's elements (see
+    // k_transfer_bwd): G = sum_e A[e]^T B[e], accumulated on MFMA across the EPT passes in four registers per
+    // wave -- not 96 per-thread accumulators (which spilled at d = 64 / 128)
+    f32x4 cgacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int q = 0; q < EPT; ++q) {
         const int e = q * 512 + tid, r = e / D, w = e % D;
@@ -627,19 +604,42 @@ __global__ __launch_bounds__(512) void k_transfer_bwd_full(SmlBwdArgs a) {
             sg.dx[(int64_t)row * D + w] = dxh + a.l2 * x1;
             if (ok) lsum += 0.5f * a.l2 * x1 * x1;      // + l2 * 0.5 * sum(x_hat^2), model/transfer.py:486-488
         }
-        if constexpr (TR) if (ok) {
+        if constexpr (TR) {
+            // A[e] = (dh1p[0..9], dh2p[0..4], 0), B[e] = (x0, x1, x2, 1, h1[0..9], 0, 0); 256 elements per round
+            float* cgA = cgst;
+            float* cgB = cgst + 256 * CGS;
+#pragma unroll 1
+            for (int half = 0; half < 2; ++half) {
+                __syncthreads();               // the previous round's MFMA operands have been read
+                if ((tid >> 8) == half) {
+                    const int t8 = tid & 255;
+                    float cga[16], cgb[16];
 #pragma unroll
-            for (int c = 0; c < SML_C1; ++c) {
-                cg[conv_compact(SML_OFF_C1W + c * 3 + 0)] += dh1p[c] * x0;
-                cg[conv_compact(SML_OFF_C1W + c * 3 + 1)] += dh1p[c] * x1;
-                cg[conv_compact(SML_OFF_C1W + c * 3 + 2)] += dh1p[c] * x2;
-                cg[conv_compact(SML_OFF_C1B + c)] += dh1p[c];
-            }
+                    for (int c = 0; c < SML_C1; ++c) { cga[c] = ok ? dh1p[c] : 0.0f; cgb[4 + c] = p.h1[c]; }
 #pragma unroll
-            for (int o = 0; o < SML_C2; ++o) {
+                    for (int o = 0; o < SML_C2; ++o) cga[10 + o] = ok ? dh2p[o] : 0.0f;
+                    cga[15] = 0.0f;
+                    cgb[0] = x0; cgb[1] = x1; cgb[2] = x2; cgb[3] = 1.0f; cgb[14] = 0.0f; cgb[15] = 0.0f;
 #pragma unroll
-                for (int c = 0; c < SML_C1; ++c) cg[conv_compact(SML_OFF_C2W + o * SML_C1 + c)] += dh2p[o] * p.h1[c];
-                cg[conv_compact(SML_OFF_C2B + o)] += dh2p[o];
+                    for (int i4 = 0; i4 < 4; ++i4) {
+                        f32x4 va, vb;
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) { va[e4] = cga[i4 * 4 + e4]; vb[e4] = cgb[i4 * 4 + e4]; }
+                        *reinterpret_cast<f32x4*>(cgA + t8 * CGS + i4 * 4) = va;
+                        *reinterpret_cast<f32x4*>(cgB + t8 * CGS + i4 * 4) = vb;
+                    }
+                }
+                __syncthreads();
+                // wave wv: elements 64*(wv&3) + 32*(wv>>2) .. +31, 4 elements per MFMA
+                const int e0 = 64 * (wv & 3) + 32 * (wv >> 2);
+                float av8[8], bv8[8];
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8) {
+                    av8[s8] = cgA[(e0 + 4 * s8 + g4) * CGS + l15];
+                    bv8[s8] = cgB[(e0 + 4 * s8 + g4) * CGS + l15];
+                }
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8) cgacc = mfma16(av8[s8], bv8[s8], cgacc);
             }
         }
     }
@@ -650,18 +650,20 @@ __global__ __launch_bounds__(512) void k_transfer_bwd_full(SmlBwdArgs a) {
         if (lane == 0) lred[wv] = v;
     }
     if constexpr (TR) {
-        wave_sum96(cg, lane);
-        if ((lane & 1) == 0) {
-            const int base = wave_sum96_base(lane);
+        // G[c][0..2] = dW_conv1[c], G[c][3] = db_conv1[c], G[10+o][4+c] = dW_conv2[o][c], G[10+o][3] = db_conv2[o]
 #pragma unroll
-            for (int i = 0; i < 3; ++i) red[wv][base + i] = cg[i];
-        }
+        for (int q4 = 0; q4 < 4; ++q4) red[wv][(4 * g4 + q4) * 16 + l15] = cgacc[q4];
         __syncthreads();
-        if (tid < SML_CG) {
-            float s = 0.0f;
+        if (tid < 95) {
+            int i, j;
+            if (tid < 30) { i = tid / 3; j = tid % 3; }
+            else if (tid < 40) { i = tid - 30; j = 3; }
+            else if (tid < 90) { i = 10 + (tid - 40) / 10; j = 4 + (tid - 40) % 10; }
+            else { i = 10 + (tid - 90); j = 3; }
+            float sacc = 0.0f;
 #pragma unroll
-            for (int w8 = 0; w8 < 8; ++w8) s += red[w8][tid];
-            a.convg_part[(int64_t)blockIdx.x * SML_CG + tid] = s;
+            for (int w8 = 0; w8 < 8; ++w8) sacc += red[w8][i * 16 + j];
+            a.convg_part[(int64_t)blockIdx.x * SML_CG + tid] = sacc;
         }
     } else {
         __syncthreads();
@@ -684,7 +686,7 @@ __global__ __launch_bounds__(512) void k_transfer_bwd_full(SmlBwdArgs a) {
 // CS workgroups by OUTPUT columns -- no cross-workgroup sum -- while the small one (dA2 = dOut * W2,
 // K = D) and the pair loss are simply repeated.  A 768-row TR batch is 96 workgroups at d = 32.
 // ------------------------------------------------------------------------------------
-template <int D, bool TR>
+template <int D, bool TR, bool PRE>
 __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
     constexpr int R = SML_TM;
     constexpr int CS = D / 16;
@@ -717,7 +719,10 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
     // Both GEMMs' operand images fit a register ring whole at d <= 64 (dA2: D/16 k-steps x 4 tiles, dA1: 4 k-steps
     // x 5 tiles per wave): they are fetched right after the pair-loss inputs below (loads return in issue order,
     // so the loss stage does not wait for them) and neither GEMM starts with an L2 round trip
-    constexpr bool PRE = D <= 64;
+    // (PRE is the launcher's choice: d = 32 always; d = 64 by default -- 220 registers, one workgroup per CU, which is
+    // all a small batch's grid asks for -- with the on-demand form (<= 128 registers, two workgroups per CU) kept
+    // for grids larger than the chip; d = 128: the rings do not fit)
+    static_assert(!PRE || D <= 64, "operand rings fit the register file at d <= 64 only");
     const f32x4* __restrict__ p2b = reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p2b(D));
     const f32x4* __restrict__ p1b = reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p1b(D));
     auto tile2 = [wv](int t) { return wv * 4 + t; };
@@ -1263,8 +1268,21 @@ hipError_t sml_launch_fwd(int d, int mt, int ns, const SmlFwdArgs& a, int tiles_
 hipError_t sml_launch_bwd(int d, int split, const SmlBwdArgs& a, int tiles_total, hipStream_t st) {
     if (tiles_total <= 0) return hipSuccess;
     if (split) {      // d/16 workgroups per row tile
-        if (a.convg_part != nullptr) { SML_DISPATCH_D(d, k_transfer_bwd<DD, true><<<dim3(tiles_total * (DD / 16)), dim3(512), 0, st>>>(a)); }
-        else { SML_DISPATCH_D(d, k_transfer_bwd<DD, false><<<dim3(tiles_total * (DD / 16)), dim3(512), 0, st>>>(a)); }
+        // operand rings preloaded at d = 32 (one memory round trip for the whole kernel); fetched on demand at d >= 64
+        const char* fp = d == 64 ? getenv("SML_BWD_PRE") : nullptr;           // (measurement / test override, d = 64 only)
+        const int force_pre = fp && *fp ? atoi(fp) : -1;
+        const int grid = tiles_total * (d / 16);
+        // (d = 64 measured both ways on MI355X, TR batch 256: 39.09 us/batch preloaded vs 39.12 on demand -- no
+        // difference, so the form with 124 registers instead of 224 is the default)
+        const bool pre = d == 32 || (d == 64 && force_pre > 0);
+        const bool tr = a.convg_part != nullptr;
+#define SML_BWD_LAUNCH(DD, TRV, PREV) k_transfer_bwd<DD, TRV, PREV><<<dim3(grid), dim3(512), 0, st>>>(a)
+        if (d == 32) { if (tr) SML_BWD_LAUNCH(32, true, true); else SML_BWD_LAUNCH(32, false, true); }
+        else if (d == 64 && pre) { if (tr) SML_BWD_LAUNCH(64, true, true); else SML_BWD_LAUNCH(64, false, true); }
+        else if (d == 64) { if (tr) SML_BWD_LAUNCH(64, true, false); else SML_BWD_LAUNCH(64, false, false); }
+        else if (d == 128) { if (tr) SML_BWD_LAUNCH(128, true, false); else SML_BWD_LAUNCH(128, false, false); }
+        else return hipErrorInvalidValue;
+#undef SML_BWD_LAUNCH
     } else {
         if (a.convg_part != nullptr) { SML_DISPATCH_D(d, k_transfer_bwd_full<DD, 1, true><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }
         else { SML_DISPATCH_D(d, k_transfer_bwd_full<DD, 1, false><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }

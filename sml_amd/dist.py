@@ -1,20 +1,36 @@
 """Multi-GPU layout of the SML period: one process per GPU, RCCL over xGMI via
 torch.distributed (backend "nccl"); CPU tests drive the same code over gloo.
 
-  users   row-sharded by owner: rank r owns users [lo_r, hi_r); a period's triples and
-          test rows are routed to the owner of their user, so user gathers, the user-row
-          Adam, updata over users and evaluation need no communication at all;
-  items   replicated (the item table is the small one; a replica is 16 MB at Yelp scale,
-          0.26 GB for 1M x 64 -- nothing next to 288 GB of HBM): every MF batch the ranks
-          all-gather their per-occurrence item-gradient rows and each applies the update
-          over the global, row-sorted occurrence list -> bit-identical replicas and exact
-          global-batch semantics (the reference's dense gradient sums duplicates the same way);
-  theta   replicated: every TR batch the flat theta-gradient (0.79 MB at d=32) is
-          all-reduced, then every rank takes the identical Adam step.
+  users   row-sharded by owner: rank r owns the contiguous range [lo_r, hi_r) and holds ONLY those rows (local row =
+          user - lo_r).  A period's triples and test rows are routed to the owner of their user, so user gathers,
+          the user-row Adam, updata over users and evaluation need no communication at all;
+  items   replicated (the item table is the small one: 16 MB at Yelp scale, 0.26 GB for 1M x 64 -- nothing next to
+          288 GB of HBM; see DESIGN.md for where that stops being the right call): every MF batch the ranks
+          all-gather their per-occurrence item-gradient rows and each applies the update over the global,
+          row-sorted occurrence list -> bit-identical replicas and exact global-batch semantics (the reference's
+          dense gradient sums duplicates the same way);
+  theta   replicated: every TR batch the flat theta-gradient (0.79 MB at d=32) is all-reduced, then every rank
+          takes the identical Adam step.
 
-BCE is a MEAN over the global batch: local terms are scaled by B_local / B_global.
+Two ways to get a rank its share of an epoch:
+
+  EpochRoute (the real driver, `torchrun ... main_yelp.py`): every rank runs the SAME host program with the same
+          seeds, so every rank holds the same GLOBAL epoch (the reference's batches, in the reference's order) and
+          simply keeps the triples whose user it owns.  Nothing about indices is ever communicated: each rank
+          derives every rank's per-batch counts and the job's global item-occurrence list from data it already has.
+          The local batch sizes differ from rank to rank and batch to batch (a rank may own no triple of a batch):
+          the C ABI's `sml_batch_plan` carries the offsets and the per-batch loss scales.  Results equal the
+          single-GPU run of the same command up to floating-point summation order.
+  independent shards (bench.py weak scaling; period.py): every rank draws its own period over its own users, all
+          with the same n and batch size; the item indices of the other ranks are all-gathered once per epoch.
+
+Loss scaling: BCE is a MEAN over the global batch -> local terms are scaled by B_local / B_global; the BPR kinds are
+SUMS -> scale 1.
 """
+import numpy as np
 import torch
+
+LOSS_BCE = 0       # sml_hip.h: the only mean-type loss kind
 
 
 def user_range(n_user, world, rank):
@@ -29,11 +45,17 @@ def owner_of(users, n_user, world):
     return users // per
 
 
+def _sort_occurrences(keys, vals):
+    """(keys, vals) stably sorted by key, on the keys' device."""
+    order = torch.sort(keys, stable=True).indices
+    return keys[order].contiguous(), vals[order].to(torch.int32).contiguous()
+
+
 def global_item_lists(all_triples, batch):
-    """all_triples int64 [world, n, 3] (same n on every rank) -> (keys uint64-as-int64 [nb-major],
-    vals int32): for every batch b the world*2*B_b item occurrences sorted (stably) by
-    (b << 32 | item row); value = slot in the gathered gradient buffer
-    [world][2*batch][d]: rank q's positives at q*2*batch + t, negatives at q*2*batch + B_b + t."""
+    """Independent-shards mode.  all_triples int64 [world, n, 3] (same n on every rank) -> (keys uint64-as-int64
+    [nb-major], vals int32): for every batch b the world*2*B_b item occurrences sorted (stably) by
+    (b << 32 | item row); value = slot in the gathered gradient buffer [world][2*batch][d]: rank q's positives at
+    q*2*batch + t, negatives at q*2*batch + B_b + t."""
     world, n, _ = all_triples.shape
     dev = all_triples.device
     e = torch.arange(n, device=dev)
@@ -45,10 +67,75 @@ def global_item_lists(all_triples, batch):
         base = q * 2 * batch
         keys += [(b << 32) | all_triples[q, :, 1], (b << 32) | all_triples[q, :, 2]]
         vals += [base + t, base + Bb + t]
-    keys = torch.cat(keys)
-    vals = torch.cat(vals)
-    order = torch.sort(keys, stable=True).indices
-    return keys[order].contiguous(), vals[order].to(torch.int32).contiguous()
+    return _sort_occurrences(torch.cat(keys), torch.cat(vals))
+
+
+class EpochRoute(object):
+    """One epoch of GLOBAL batches split over the ranks by user owner (see the module docstring).
+
+    local_tri   int64 [n_local, 3]: this rank's triples in global order, users re-indexed into the rank's shard
+    plan        {batch_off, loss_scale}: the sml_batch_plan of the local triples (empty batches included)
+    cap         the longest local batch of ANY rank (>= 1): the `batch` the scratch is sized for, and half the rows
+                every rank contributes per batch to the gathered item-gradient buffer
+    counts      int64 [world, nb]: every rank's local batch sizes"""
+
+    def __init__(self, ctx, global_tri, batch, n_user, mean_loss):
+        tri = np.ascontiguousarray(global_tri, dtype=np.int64)
+        n = tri.shape[0]
+        world, rank = ctx.world, ctx.rank
+        nb = max(1, -(-n // batch))
+        owner = owner_of(tri[:, 0], n_user, world)
+        b_of = np.arange(n, dtype=np.int64) // batch
+        group = owner * nb + b_of
+        self.counts = np.bincount(group, minlength=world * nb).reshape(world, nb).astype(np.int64)
+        Bg = self.counts.sum(0)
+        lo, _hi = user_range(n_user, world, rank)
+        mine = owner == rank
+        self.local_tri = tri[mine].copy()
+        self.local_tri[:, 0] -= lo
+        off = np.zeros(nb + 1, dtype=np.int64)
+        np.cumsum(self.counts[rank], out=off[1:])
+        scale = (self.counts[rank] / np.maximum(Bg, 1)).astype(np.float32) if mean_loss else np.ones(nb, dtype=np.float32)
+        self.plan = dict(batch_off=off, loss_scale=scale)
+        self.cap = int(max(1, self.counts.max()))
+        self.nb, self.n, self.batch, self.ctx = nb, n, batch, ctx
+        self.global_batch_sizes = Bg
+        # position of every element inside its (owner, batch) group, in global order
+        order = np.argsort(group, kind="stable")
+        start = np.zeros(world * nb + 1, dtype=np.int64)
+        np.cumsum(self.counts.reshape(-1), out=start[1:])
+        t_in = np.empty(n, dtype=np.int64)
+        t_in[order] = np.arange(n, dtype=np.int64) - start[group[order]]
+        self._owner, self._b_of, self._t_in, self._items = owner, b_of, t_in, tri[:, 1:3]
+
+    def exchange(self, d):
+        """Exchange descriptor of the MF stage (engine.mf_stage_epoch(exchange=...)): the job's global item-occurrence
+        list -- for batch b every rank's 2*B_{q,b} occurrences sorted (stably) by (b << 32 | item row), value = slot
+        in the gathered buffer [world][2*cap][d]: rank q's positives at q*2*cap + t, negatives at q*2*cap + B_{q,b}
+        + t -- derived locally, plus the scratch and the gather hook."""
+        ctx = self.ctx
+        stride = 2 * self.cap
+        cnt = self.counts[self._owner, self._b_of]
+        base = self._owner * stride + self._t_in
+        dev = ctx.device
+        b = torch.from_numpy(self._b_of).to(dev)
+        keys = torch.cat([(b << 32) | torch.from_numpy(np.ascontiguousarray(self._items[:, 0])).to(dev),
+                          (b << 32) | torch.from_numpy(np.ascontiguousarray(self._items[:, 1])).to(dev)])
+        vals = torch.cat([torch.from_numpy(base).to(dev), torch.from_numpy(base + cnt).to(dev)])
+        keys, vals = _sort_occurrences(keys, vals)
+        item_off = np.zeros(self.nb + 1, dtype=np.int64)
+        np.cumsum(2 * self.global_batch_sizes, out=item_off[1:])
+        dx_local, dx_all = ctx.scratch(self.cap, stride, d)
+        mine = self.counts[ctx.rank]
+        tile = 32
+
+        def hook(bi):
+            ioff = -(-int(mine[bi]) // tile) * tile
+            src = dx_local[ioff * d:(ioff + stride) * d]
+            ctx.all_gather_rows(dx_all[:ctx.world * stride * d], src)
+
+        return dict(world=ctx.world, keys=keys, vals=vals, dx_local=dx_local, dx_all=dx_all,
+                    hook=None if ctx.native else hook, loss_scale=1.0, slot_stride=stride, item_off=item_off)
 
 
 class DistContext(object):
@@ -62,38 +149,90 @@ class DistContext(object):
         self.native_gather = dist.get_backend(group) == "nccl"
         self.native = False          # True: libsml_hip's own RCCL communicator does the per-batch exchange
 
-    # ---- TR stage: all-reduce of the flat theta gradient
-    def tr_loss_scale(self):
-        return 1.0 / self.world
+    # ---- loss scaling
+    def loss_scale(self, loss_kind):
+        """Equal local batches on every rank: B_local / B_global = 1 / world for the mean-type BCE, 1 for the BPR sums."""
+        return 1.0 / self.world if loss_kind == LOSS_BCE else 1.0
 
+    def tr_loss_scale(self, loss_kind=LOSS_BCE):
+        return self.loss_scale(loss_kind)
+
+    # ---- TR stage: all-reduce of the flat theta gradient
     def tr_grad_hook(self, grad, batch_index):
         self.dist.all_reduce(grad, op=self.dist.ReduceOp.SUM, group=self.group)
 
     # ---- MF stage: all-gather of item-gradient rows
-    def mf_exchange(self, triples, batch, d):
-        """Exchange descriptor of one MF epoch over this rank's `triples` [n,3]."""
+    def scratch(self, cap, stride, d):
+        """(dx_local, dx_all) grown on demand: the backward's gradient rows of one local batch and the gathered
+        item-gradient rows of all ranks."""
+        need_l, need_a = (3 * cap + 64 + stride) * d, self.world * stride * d
+        cur = self._buf.get(d)
+        if cur is None or cur[0].numel() < need_l or cur[1].numel() < need_a:
+            cur = (torch.zeros(max(need_l, cur[0].numel() if cur else 0), device=self.device, dtype=torch.float32),
+                   torch.zeros(max(need_a, cur[1].numel() if cur else 0), device=self.device, dtype=torch.float32))
+            self._buf[d] = cur
+        return cur
+
+    def all_gather_rows(self, dst, src):
+        if self.native_gather:
+            self.dist.all_gather_into_tensor(dst, src, group=self.group)
+        else:
+            self.dist.all_gather(list(dst.view(self.world, -1).unbind(0)), src, group=self.group)
+
+    def same_on_all_ranks(self, value, what):
+        """Independent-shards mode needs the same epoch length on every rank: check it, do not hang."""
+        t = torch.tensor([float(value), -float(value)], device=self.device, dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        if t[0].item() != -t[1].item():
+            raise ValueError("%s differs between ranks (max %d, min %d): independent-shard epochs need equal sizes; "
+                             "route a shared epoch with DistContext.route_epoch instead"
+                             % (what, int(t[0].item()), int(-t[1].item())))
+
+    def mf_exchange(self, triples, batch, d, loss_kind=LOSS_BCE):
+        """Independent-shards mode: exchange descriptor of one MF epoch over this rank's `triples` [n,3] (every rank
+        brings the same n).  The other ranks' item indices are all-gathered once per epoch."""
         n = triples.shape[0]
-        allt = torch.empty((self.world,) + tuple(triples.shape), dtype=triples.dtype, device=triples.device)
-        self.dist.all_gather(list(allt.unbind(0)), triples.contiguous(), group=self.group)
+        self.same_on_all_ranks(n, "the epoch length n")
+        items = triples[:, 1:3].contiguous()
+        alli = torch.empty((self.world,) + tuple(items.shape), dtype=items.dtype, device=items.device)
+        self.dist.all_gather(list(alli.unbind(0)), items, group=self.group)
+        allt = torch.cat([torch.zeros((self.world, n, 1), dtype=items.dtype, device=items.device), alli], dim=2)
         keys, vals = global_item_lists(allt, batch)
-        key = (batch, d)
-        if key not in self._buf:
-            self._buf[key] = (torch.zeros((3 * batch + 64) * d, device=self.device, dtype=torch.float32),
-                              torch.zeros(self.world * 2 * batch * d, device=self.device, dtype=torch.float32))
-        dx_local, dx_all = self._buf[key]
+        stride = 2 * batch
+        dx_local, dx_all = self.scratch(batch, stride, d)
         tile = 32
 
         def hook(b):
             Bb = min(batch, n - b * batch)
             ioff = -(-Bb // tile) * tile
-            src = dx_local[ioff * d:(ioff + 2 * batch) * d]
-            if self.native_gather:
-                self.dist.all_gather_into_tensor(dx_all, src, group=self.group)
-            else:
-                self.dist.all_gather(list(dx_all.view(self.world, -1).unbind(0)), src, group=self.group)
+            self.all_gather_rows(dx_all[:self.world * stride * d], dx_local[ioff * d:(ioff + stride) * d])
 
         return dict(world=self.world, keys=keys, vals=vals, dx_local=dx_local, dx_all=dx_all,
-                    hook=None if self.native else hook, loss_scale=1.0 / self.world)
+                    hook=None if self.native else hook, loss_scale=self.loss_scale(loss_kind), slot_stride=stride,
+                    item_off=None)
+
+    # ---- the real driver: a shared global epoch, split by user owner
+    def route_epoch(self, global_tri, batch, n_user, mean_loss):
+        return EpochRoute(self, global_tri, batch, n_user, mean_loss)
+
+    def route_rows(self, rows, n_user):
+        """Test rows [n, 2+neg] (numpy) of the users this rank owns, user column re-indexed into the shard."""
+        rows = np.asarray(rows)
+        lo, hi = user_range(n_user, self.world, self.rank)
+        mine = (rows[:, 0] >= lo) & (rows[:, 0] < hi)
+        out = rows[mine].copy()
+        out[:, 0] -= lo
+        return out
+
+    def sum_scalars(self, values):
+        """Sum a few host numbers over the ranks (evaluation hit counts, ...)."""
+        t = torch.tensor([float(v) for v in values], device=self.device, dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return [float(v) for v in t.cpu()]
+
+    def sum_tensor_(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t
 
     # ---- replicas start identical
     def sync_replicas(self, tensors):

@@ -66,8 +66,13 @@ class _OptimizerInfo(object):
 
 
 class meta_train(object):
-    def __init__(self, args, datasets, user_num, item_num, laten_dim):
+    def __init__(self, args, datasets, user_num, item_num, laten_dim, dist=None):
+        """dist: an initialised torch.distributed module (one process per GPU, `torchrun ... main_yelp.py`), or None.
+        Under dist every rank runs this same program on the same seeds and data; users are row-sharded by owner
+        (this rank keeps rows [lo, hi) of every user-side table), items and theta are replicated, and every global
+        batch is split by user owner (sml_amd.dist.EpochRoute): the printed numbers are the single-GPU run's."""
         self.device = _default_device()
+        self.n_user_global = int(user_num)
         if args.data_name != 'yelp':
             # the reference builds (and then discards) a fresh MF model here, which advances
             # the global RNG before the transfer net is initialised (model/transfer.py:314-317)
@@ -77,6 +82,23 @@ class meta_train(object):
         table_dim = self.MFbase.user_laten.weight.shape[1]
         if table_dim != laten_dim:
             raise ValueError("--laten %d does not match the checkpoint's embedding width %d" % (laten_dim, table_dim))
+        self.dist = None
+        import os
+        use_dist = dist is not None and (dist.get_world_size() > 1 or os.environ.get("SML_FORCE_DIST") == "1")   # (forced: tests drive the exchange path on one GPU)
+        if use_dist:
+            # keep this rank's user rows only (the checkpoint holds the whole table)
+            from . import dist as smldist
+            lo, hi = smldist.user_range(self.n_user_global, dist.get_world_size(), dist.get_rank())
+            full = self.MFbase
+            rng = torch.get_rng_state()        # (the shard's constructor draws initial values: keep the run's random tape)
+            self.MFbase = MFbasemode(num_user=max(hi - lo, 1), num_item=full.item_num, laten_factor=table_dim).to(self.device)
+            torch.set_rng_state(rng)
+            with torch.no_grad():
+                self.MFbase.user_laten.weight[:hi - lo].copy_(full.user_laten.weight.data[lo:hi])
+                self.MFbase.user_bais.weight[:hi - lo].copy_(full.user_bais.weight.data[lo:hi])
+                self.MFbase.item_laten.weight.copy_(full.item_laten.weight.data)
+                self.MFbase.item_bais.weight.copy_(full.item_bais.weight.data)
+            del full
 
         self.transfer_type = args.transfer_type
         self.with_MF_bias = args.TR_with_MF_bias
@@ -121,6 +143,13 @@ class meta_train(object):
         self.engine = _make_engine(self.device, laten_dim, max(args.MF_batch_size, args.TR_batch_size))
         self.MFbase._sml_engine = self.engine
         self.transfer._sml_engine = self.engine
+        if use_dist:
+            from . import dist as smldist
+            self.dist = smldist.attach(self.engine, None, dist)
+            theta = self.engine.adopt(self.transfer) if hasattr(self.engine, "adopt") else None
+            # (every rank built theta and loaded the item table from the same seeds / file: the broadcast is a guard)
+            self.dist.sync_replicas([self.MFbase.item_laten.weight.data] +
+                                    ([theta] if theta is not None else [p.data for p in self.transfer.parameters()]))
         self.MF_optimizer = _OptimizerInfo(args.MF_lr, 0)
         self.transfer_optimizer = _OptimizerInfo(args.TR_lr, args.TR_l2)
 
@@ -144,7 +173,10 @@ class meta_train(object):
             if len(self._rows_cache) > 4:
                 self._rows_cache.clear()
                 self._rank_cache = None        # its rows object went with the entries above
-            hit = (arr, DeviceRows(arr, self.device))
+            local = arr if self.dist is None else self.dist.route_rows(arr, self.n_user_global)
+            rows = DeviceRows(local, self.device)
+            rows.n_global = int(np.asarray(arr).shape[0])      # recall / ndcg are over ALL rows of the set
+            hit = (arr, rows)
             self._rows_cache[key] = hit
         return hit[1]
 
@@ -194,26 +226,32 @@ class meta_train(object):
         if isinstance(ranks, dict):               # a submitted evaluation (engine.eval_submit)
             pending = self.engine.eval_metrics_submit(ranks, topK)
 
-            def resolve():
+            def local():
                 return self.engine.eval_result(pending)
         elif hasattr(self.engine, "eval_metrics_device"):
             out = self.engine.eval_metrics_device(ranks, topK)
 
-            def resolve():
+            def local():
                 h = out.cpu()
                 return float(h[0]), float(h[1])
         else:
             res = self.engine.eval_metrics(ranks, topK)
 
-            def resolve():
+            def local():
                 return res
+        resolve = local
+        if self.dist is not None:
+            # every rank evaluated the rows of ITS users: hits and ndcg sums add up.  (Resolved when the stage's lines
+            # are printed -- in the same order on every rank, which run the same program.)
+            def resolve():
+                return tuple(self.dist.sum_scalars(local()))
         return self._pair(resolve, n)
 
     def _test(self, rows, topK):
         """recall@K, ndcg@K of the current tables on `rows` (reference evalution/evaluation2.py:8-26)."""
         t0 = time.time()
         D.loader_base_seed_draw()          # the draw the reference's DataLoader iteration makes
-        out = self._metrics(self._ranks(rows), rows.rows.shape[0], topK)
+        out = self._metrics(self._ranks(rows), getattr(rows, "n_global", rows.rows.shape[0]), topK)
         self.timing["eval"] += time.time() - t0
         return out
 
@@ -232,6 +270,18 @@ class meta_train(object):
         text = hit[2]
         self._emit(lambda: print(text, end=""))
         return hit[1]
+
+    def transfer_variant_is_bce(self):
+        """ConvTransfer_com.run_MF is called with its BCE default (a MEAN over the batch); ConvTransfer.run_MF has only
+        the BPR SUM (model/conv_transfer.py:71-85, 113-126): decides how a split batch's loss terms are scaled."""
+        return not isinstance(self.transfer, ConvTransfer)
+
+    def _sum_losses(self, losses):
+        """Per-batch losses of a split global batch: the ranks' parts add up (device tensor or numpy array)."""
+        if isinstance(losses, torch.Tensor):
+            return self.dist.sum_tensor_(losses)
+        t = torch.as_tensor(np.asarray(losses, dtype=np.float64)).to(self.dist.device)
+        return self.dist.sum_tensor_(t).cpu().numpy()
 
     @staticmethod
     def _epoch_loss(losses):
@@ -265,9 +315,19 @@ class meta_train(object):
             order = D.loader_order(len(train_set), shuffle=True)
             triples = train_set.epoch_triples(order)
             t0 = time.time()
-            losses = self.engine.mf_stage_epoch(self.MFbase, self.transfer, self.last_user_weight,
-                                                self.last_item_weight, triples, args.MF_batch_size,
-                                                args.MF_lr, args.l2, norm=args.norm, bce=True)
+            if self.dist is None:
+                losses = self.engine.mf_stage_epoch(self.MFbase, self.transfer, self.last_user_weight,
+                                                    self.last_item_weight, triples, args.MF_batch_size,
+                                                    args.MF_lr, args.l2, norm=args.norm, bce=True)
+            else:
+                # the same global batches, this rank's share of each (its users' triples); batch losses add up
+                route = self.dist.route_epoch(triples, args.MF_batch_size, self.n_user_global,
+                                              mean_loss=self.transfer_variant_is_bce())
+                losses = self.engine.mf_stage_epoch(self.MFbase, self.transfer, self.last_user_weight,
+                                                    self.last_item_weight, route.local_tri, route.cap,
+                                                    args.MF_lr, args.l2, norm=args.norm, bce=True,
+                                                    plan=route.plan, exchange=route.exchange(self.MFbase.user_laten.weight.shape[1]))
+                losses = self._sum_losses(losses)
             self.engine.mf_flush(self.MFbase)
             self._touch_tables()
             self.timing["mf"] += time.time() - t0
@@ -343,9 +403,19 @@ class meta_train(object):
                 order = D.loader_order(len(train_set), shuffle=True)
                 triples = train_set.epoch_triples(order)
             t0 = time.time()
-            losses = self.engine.tr_stage_epoch(self.transfer, self.last_user_weight, self.last_item_weight,
-                                                self.user_weight_hat, self.item_weight_hat, triples,
-                                                args.TR_batch_size, args.TR_lr, args.TR_l2, bce=True)
+            if self.dist is None:
+                losses = self.engine.tr_stage_epoch(self.transfer, self.last_user_weight, self.last_item_weight,
+                                                    self.user_weight_hat, self.item_weight_hat, triples,
+                                                    args.TR_batch_size, args.TR_lr, args.TR_l2, bce=True)
+            else:
+                if isinstance(triples, torch.Tensor):
+                    raise NotImplementedError("--device_batches with several GPUs: the ranks must share one epoch")
+                route = self.dist.route_epoch(triples, args.TR_batch_size, self.n_user_global,
+                                              mean_loss=self.transfer_variant_is_bce())
+                losses = self.engine.tr_stage_epoch(self.transfer, self.last_user_weight, self.last_item_weight,
+                                                    self.user_weight_hat, self.item_weight_hat, route.local_tri,
+                                                    route.cap, args.TR_lr, args.TR_l2, bce=True, plan=route.plan)
+                losses = self._sum_losses(losses)
             self.timing["tr"] += time.time() - t0
             self.timing["tr_triples"] += triples.shape[0]
             bs = args.TR_batch_size

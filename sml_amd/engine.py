@@ -201,18 +201,40 @@ class HipEngine(object):
             return _lib.LOSS_BCE
         return _lib.LOSS_BPR_NORM if norm else _lib.LOSS_BPR
 
-    def mf_stage_epoch(self, mfbase, transfer, last_user, last_item, triples, batch_size, lr, l2, norm=False, bce=True):
+    def _plan(self, plan, n):
+        """ctypes view of a batch plan {batch_off: int64 [nb+1] (numpy), loss_scale: float32 [nb] or None}: batches
+        of unequal size (a global batch split over ranks by user owner).  Returns (struct pointer, keep-alive)."""
+        if plan is None:
+            return None, None
+        off = np.ascontiguousarray(plan["batch_off"], dtype=np.int64)
+        if off[0] != 0 or off[-1] != n:
+            raise ValueError("batch plan does not cover the %d triples" % n)
+        off_dev = torch.from_numpy(off.astype(np.int32)).pin_memory().to(self.device, non_blocking=True)
+        sc = plan.get("loss_scale")
+        sc = None if sc is None else np.ascontiguousarray(sc, dtype=np.float32)
+        p = _lib.BatchPlan()
+        p.n_batches = off.shape[0] - 1
+        p.batch_off = off.ctypes.data
+        p.batch_off_dev = off_dev.data_ptr()
+        p.loss_scale = sc.ctypes.data if sc is not None else None
+        return ctypes.byref(p), (p, off, off_dev, sc)
+
+    def mf_stage_epoch(self, mfbase, transfer, last_user, last_item, triples, batch_size, lr, l2, norm=False, bce=True,
+                       plan=None, exchange=None):
+        """plan / exchange: the multi-GPU driver's per-epoch descriptors (sml_amd.dist.EpochRoute): batches of unequal
+        local size, and the global item-occurrence list of the job."""
         theta = self._select(transfer)
         tri = self._dev(triples, torch.int64)
         n = tri.shape[0]
-        nb = (n + batch_size - 1) // batch_size
+        nb = (n + batch_size - 1) // batch_size if plan is None else len(plan["batch_off"]) - 1
         t = self._mf_tables(mfbase, last_user, last_item)
         self._mf_lr = float(lr)
         losses = torch.empty(nb, device=self.device, dtype=torch.float32)
         step = ctypes.c_int64(self.mf_step)
         xp = None
+        pp, keep = self._plan(plan, n)
         if self.dist is not None:
-            ex = self.dist.mf_exchange(tri, int(batch_size), self.d)
+            ex = exchange if exchange is not None else self.dist.mf_exchange(tri, int(batch_size), self.d, self._loss_kind(bce, norm))
             hook_fn = ex["hook"]
 
             def _cb(_user, b):
@@ -230,10 +252,16 @@ class HipEngine(object):
             x.hook = _lib.MF_HOOK(_cb) if hook_fn is not None else ctypes.cast(None, _lib.MF_HOOK)
             x.hook_user = None
             x.loss_scale = ex["loss_scale"]
+            x.slot_stride = int(ex.get("slot_stride", 0))
+            ioff = ex.get("item_off")
+            if ioff is not None:
+                ioff = np.ascontiguousarray(ioff, dtype=np.int64)
+                keep = (keep, ioff)
+            x.item_off = ioff.ctypes.data if ioff is not None else None
             xp = ctypes.byref(x)
         check(self.lib.sml_mf_stage_epoch(self._ctx, _ptr(theta), ctypes.byref(t), _ptr(tri), n, int(batch_size),
                                           float(lr), float(l2), self._loss_kind(bce, norm), ctypes.byref(step),
-                                          _ptr(losses), xp, self._stream()), "sml_mf_stage_epoch")
+                                          _ptr(losses), xp, pp, self._stream()), "sml_mf_stage_epoch")
         self.mf_step = step.value
         return losses
 
@@ -247,16 +275,17 @@ class HipEngine(object):
 
     # ------------------------------------------------------------------ a9
     def tr_stage_epoch(self, transfer, last_user, last_item, hat_user, hat_item, triples, batch_size, lr,
-                       weight_decay, bce=True, loss_scale=None):
+                       weight_decay, bce=True, loss_scale=None, plan=None):
         theta = self._select(transfer)
         if loss_scale is None:
-            loss_scale = self.dist.tr_loss_scale() if self.dist is not None else 1.0
+            loss_scale = self.dist.tr_loss_scale(self._loss_kind(bce, False)) if self.dist is not None else 1.0
         if self.tr_state is None or self.tr_state[0].shape != theta.shape:
             self.tr_state = (torch.zeros_like(theta), torch.zeros_like(theta), torch.zeros_like(theta))
         m, v, grad = self.tr_state
         tri = self._dev(triples, torch.int64)
         n = tri.shape[0]
-        nb = (n + batch_size - 1) // batch_size
+        nb = (n + batch_size - 1) // batch_size if plan is None else len(plan["batch_off"]) - 1
+        pp, keep = self._plan(plan, n)
         t = _lib.TRTables()
         t.last_user, t.last_item = self._table(last_user).data_ptr(), self._table(last_item).data_ptr()
         t.hat_user, t.hat_item = self._table(hat_user).data_ptr(), self._table(hat_item).data_ptr()
@@ -280,7 +309,7 @@ class HipEngine(object):
         check(self.lib.sml_tr_stage_epoch(self._ctx, _ptr(theta), _ptr(m), _ptr(v), _ptr(grad), ctypes.byref(t),
                                           _ptr(tri), n, int(batch_size), float(lr), float(weight_decay),
                                           self._loss_kind(bce, False), float(loss_scale), ctypes.byref(step),
-                                          _ptr(losses), cb, None, self._stream()), "sml_tr_stage_epoch")
+                                          _ptr(losses), cb, None, pp, self._stream()), "sml_tr_stage_epoch")
         self.tr_step = step.value
         return losses
 

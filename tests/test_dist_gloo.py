@@ -134,3 +134,85 @@ def test_user_range_and_item_lists():
             lookup[(b, q * 4 + Bb + t)] = int(tri[q, e, 2])
     for k, v, b in zip(rows, vals.tolist(), bat):
         assert lookup[(b, v)] == k
+
+
+# ----------------------------------------------------------------------------- the real driver under 2 ranks
+def _driver_rank(rank, world, port, root, ck, ttype, out):
+    """main_yelp.py's program (sml_amd.cli: seeds, transfer_data, meta_train.run) on a six-period dataset, under
+    `world` gloo ranks (world 1: the plain single-process driver), with the oracle-based engine doubles."""
+    import contextlib
+    import io
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from sml_amd import cli, datasets, driver
+    from sml_amd.mf import MFbasemode
+    from test_host_logic import _cpu_mf_test
+    driver._default_device = lambda: torch.device("cpu")
+    driver._make_engine = (lambda dev, d, mb: CpuDistEngine(dev, d, mb)) if world > 1 else (lambda dev, d, mb: CpuEngine(dev, d, mb))
+    MFbasemode.test = _cpu_mf_test
+    d = None
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        d = dist
+    try:
+        args = cli.get_parse("yelp").parse_args(["--data_path", root, "--pre_model", ck, "--laten", "32", "--multi_num", "2",
+                                                "--numworkers", "0", "--MF_batch_size", "64", "--TR_batch_size", "32",
+                                                "--transfer_type", ttype])
+        torch.manual_seed(args.seed)
+        np.random.seed(args.seed + 2)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            sets = datasets.transfer_data(args, path=root, datasetname="yelp", file_path_list=[str(i) for i in range(6)],
+                                          test_list=[str(j) for j in range(3, 6)], validation_list=None, online_train_time=1,
+                                          online_test_time=3)
+            meta = driver.meta_train(args, sets, sets.user_number, sets.item_number, args.laten, dist=d)
+            meta.run(args)
+        torch.save(dict(log=buf.getvalue(), recall=[float(r) for r in meta.recall], wi=meta.MFbase.item_laten.weight.detach().clone(),
+                        wu=meta.MFbase.user_laten.weight.detach().clone(),
+                        theta={k: v.clone() for k, v in meta.transfer.state_dict().items()}),
+                   os.path.join(out, "w%d_rank%d.pt" % (world, rank)))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ttype", ["conv_com", "conv"])        # BCE (a mean over the split batch) and BPR (a sum)
+def test_driver_under_two_ranks_prints_the_single_process_run(tmp_path, ttype):
+    """`torchrun --nproc-per-node 2 main_yelp.py` in miniature: users row-sharded by owner (each rank keeps its rows
+    only), every global batch split by owner -- unequal, sometimes empty local batches --, item-gradient exchange,
+    theta all-reduce, routed evaluation.  The two ranks must print what one process prints: same lines, losses to
+    1e-4, recall within 2 rank flips of the 160-row sets; item replicas and theta bit-identical between the ranks."""
+    import re
+    from sml_amd import synth
+    from sml_amd.mf import MFbasemode
+    root = str(tmp_path) + "/"
+    U, I = 300, 120
+    synth.write_dataset(root, "yelp", n_periods=6, n_inter=160, n_user=U, n_item=I, neg=49, a_user=0.8, a_item=0.8, seed=77)
+    torch.manual_seed(9)
+    mf = MFbasemode(U, I, 32)
+    with torch.no_grad():
+        mf.user_laten.weight.mul_(0.3)
+        mf.item_laten.weight.mul_(0.3)
+    ck = root + "init.pkl"
+    torch.save(mf, ck)
+    out = str(tmp_path)
+    mp.spawn(_driver_rank, args=(1, 0, root, ck, ttype, out), nprocs=1, join=True)     # (own process: it patches the engine factory)
+    mp.spawn(_driver_rank, args=(2, _free_port(), root, ck, ttype, out), nprocs=2, join=True)
+    one = torch.load(os.path.join(out, "w1_rank0.pt"), weights_only=False)
+    r0 = torch.load(os.path.join(out, "w2_rank0.pt"), weights_only=False)
+    r1 = torch.load(os.path.join(out, "w2_rank1.pt"), weights_only=False)
+    assert torch.equal(r0["wi"], r1["wi"])
+    for k in r0["theta"]:
+        assert torch.equal(r0["theta"][k], r1["theta"][k]), k
+    assert r0["wu"].shape[0] == 150 and r1["wu"].shape[0] == 150            # each rank holds its own user rows only
+    num = re.compile(r"-?\d+\.\d+(?:e-?\d+)?")
+    strip = lambda t: [re.sub(r"\s+", " ", l).replace("[ ", "[").replace(" ]", "]") for l in t.splitlines() if "time cost" not in l]
+    a, b = strip(one["log"]), strip(r0["log"])
+    assert [num.sub("#", l) for l in a] == [num.sub("#", l) for l in b]
+    for la, lb in zip(a, b):
+        for x, y in zip(num.findall(la), num.findall(lb)):
+            x, y = float(x), float(y)
+            tol = 2.0 / 160 + 1e-4 if ("recall" in la or "reacll" in la or "ndcg" in la) else 1e-4 * max(1.0, abs(x))
+            assert abs(x - y) <= tol, (la, lb)
+    np.testing.assert_allclose(torch.cat([r0["wu"], r1["wu"]]).numpy(), one["wu"].numpy(), rtol=5e-3, atol=5e-4)
+    np.testing.assert_allclose(r0["wi"].numpy(), one["wi"].numpy(), rtol=5e-3, atol=5e-4)
+    assert strip(r1["log"]) == strip(r0["log"])      # every rank holds the job's numbers (cli.main silences all but rank 0)

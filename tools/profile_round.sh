@@ -10,7 +10,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
-PERIOD="bench.py --no-cpu --steps 2 --warmup 1"
+PERIOD="bench.py --no-cpu --no-a3 --steps 2 --warmup 1"
 BARE="bench.py --workload bare --users 10000000 --items 1000000 --bare-batch 262144 --steps 2 --warmup 1"
 run() { # name, rocprof args..., -- cmd
     local name=$1; shift
