@@ -93,30 +93,52 @@ def parse():
     return ap.parse_args()
 
 
-def bench_bare(a, device):
-    """a3 alone: synchronous minibatch SGD on (user, pos, neg) triples over large tables.  Returns the result dict."""
+def bench_bare(a, device, dist=None):
+    """a3 alone: synchronous minibatch SGD on (user, pos, neg) triples over large tables.  Returns the result dict.
+    dist (several GPUs, weak scaling): the `users` rows are sharded over the ranks (each rank holds users/world rows and
+    draws `bare_triples` triples over them), the item table is replicated, every global batch is the union of the ranks'
+    batches: item-gradient rows are all-gathered per batch and every rank applies the identical item update."""
     from sml_amd import synth
     from sml_amd.engine import HipEngine
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
     eng = HipEngine(device, a.d, a.bare_batch)
     dt = torch.float32 if a.bare_dtype == "f32" else torch.float16
+    users_local = -(-a.users // world)
     g = torch.Generator(device=device).manual_seed(4)
-    wu = (torch.randn(a.users, a.d, device=device, generator=g) * 0.1).to(dt)
-    wi = (torch.randn(a.items, a.d, device=device, generator=g) * 0.1).to(dt)
-    rng = np.random.RandomState(4)
-    u, i, j = synth.synth_triples(rng, a.bare_triples, a.users, a.items, a_user=0.0, a_item=a.item_zipf)
+    wi = (torch.randn(a.items, a.d, device=device, generator=g) * 0.1).to(dt)         # the same replica on every rank
+    g.manual_seed(40 + rank)
+    wu = (torch.randn(users_local, a.d, device=device, generator=g) * 0.1).to(dt)
+    rng = np.random.RandomState(4 + 1000 * rank)
+    u, i, j = synth.synth_triples(rng, a.bare_triples, users_local, a.items, a_user=0.0, a_item=a.item_zipf)
     tri = torch.from_numpy(np.stack([u, i, j], 1)).to(device)
+    ex = None
+    if dist is not None:
+        from sml_amd import dist as smldist
+        ctx = smldist.attach(eng, None, dist)
+        ex = ctx.bare_exchange(tri, a.bare_batch, a.d, 0)         # item columns gathered once: the triples are reused every epoch
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
     # the index lists of epoch e+1 (sort, unique marks, compaction) are built on a side stream while epoch e runs
     for _ in range(a.warmup):
-        eng.bare_epoch(wu, wi, tri, a.bare_batch, 0.05, 1e-6, 1e-6, bce=True)
-    nxt = eng.bare_prepare(tri, a.bare_batch, a.users, a.items)
-    torch.cuda.synchronize(device)
+        eng.bare_epoch(wu, wi, tri, a.bare_batch, 0.05, 1e-6, 1e-6, bce=True, exchange=ex)
+    nxt = eng.bare_prepare(tri, a.bare_batch, users_local, a.items, exchange=ex)
+    barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        cur, nxt = nxt, eng.bare_prepare(tri, a.bare_batch, a.users, a.items)
+        cur, nxt = nxt, eng.bare_prepare(tri, a.bare_batch, users_local, a.items, exchange=ex)
         eng.bare_epoch(wu, wi, tri, a.bare_batch, 0.05, 1e-6, 1e-6, bce=True, prepared=cur)
-    torch.cuda.synchronize(device)
+    barrier()
     dtm = time.perf_counter() - t0
-    cur = eng.bare_prepare(tri, a.bare_batch, a.users, a.items)      # (prepared ahead, as in the timed loop)
+    if dist is not None:
+        tt = torch.tensor([dtm], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dtm = float(tt.item())
+    cur = eng.bare_prepare(tri, a.bare_batch, users_local, a.items, exchange=ex)      # (prepared ahead, as in the timed loop)
     torch.cuda.synchronize(device)
     eng.profile(True)
     eng.bare_epoch(wu, wi, tri, a.bare_batch, 0.05, 1e-6, 1e-6, bce=True, prepared=cur)
@@ -131,12 +153,16 @@ def bench_bare(a, device):
     t_grad, t_seg = prof["k_bare_grad"][1] / 1e3, prof.get("k_seg_update_sgd", (0, 0.0))[1] / 1e3
     t_hot = prof.get("k_hot_rows", (0, 0.0))[1] / 1e3
     ach = n * a_sgd / (t_grad + t_seg + t_hot) / 1e9
-    e2e = a.steps * n / dtm * a_sgd / 1e9                 # whole step incl. the index preparation on its side stream
+    e2e = a.steps * n / dtm * a_sgd / 1e9                 # whole step incl. the index preparation on its side stream (per GPU)
     out = {"metric": "bare embed+loss+SGD step triples/s (a3), synthetic uniform users / Zipf(%g) items, d=%d %s" % (a.item_zipf, a.d, a.bare_dtype),
-           "value": a.steps * n / dtm, "unit": "triples/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+           "value": world * a.steps * n / dtm, "unit": "triples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": 1000.0 * dtm / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": a.bare_dtype, "data": "synthetic",
-           "config": {"workload": "bare: users=%d items=%d triples/epoch=%d batch=%d" % (a.users, a.items, n, a.bare_batch)},
+           "config": {"workload": "bare: users=%d (row-sharded over %d GPU(s)) items=%d (replicated) triples/epoch/GPU=%d batch/GPU=%d"
+                                  % (a.users, world, a.items, n, a.bare_batch),
+                      "parallelism": "single GPU" if world == 1 else
+                      "users row-sharded x%d, items replicated, per-batch all-gather of item-gradient rows (%s)"
+                      % (world, "native RCCL" if ctx.native else "torch.distributed")},
            # traffic (PMC bytes) cannot be read from inside the process: null here; the rocprofv3 --pmc passes of this
            # command are tools/profile_round.sh's, summarised under profiles/
            "roofline": {"kernel": "k_bare_grad + k_seg_update_sgd + k_hot_rows (one a3 step)", "bound": "hbm", "achieved": ach,
@@ -341,7 +367,19 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if a.workload == "bare":
-        print(json.dumps(bench_bare(a, device)))
+        quiet = _StdoutToStderr()
+        quiet.__enter__()
+        dist = None
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("nccl", device_id=device)
+        res = bench_bare(a, device, dist)
+        if rank == 0:
+            quiet.emit(json.dumps(res))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        quiet.__exit__()
         return
     from sml_amd.engine import HipEngine
     from sml_amd.period import Hyper, run_period, synth_plan

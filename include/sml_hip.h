@@ -198,12 +198,32 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
  * the lists it uses are complete; if they are (prepared ahead) and hold no hot run, the hot-row kernels are
  * skipped; if they are still in flight the hot-row kernels are launched and find their lists empty on the device.
  * (The caller orders `stream` behind the preparation stream, as for any two streams.) */
+/* Several GPUs (NULL on one): users are row-sharded -- w_user holds this rank's rows, `triples` its users' triples
+ * (local user index), every rank brings the SAME n and batch -- and the item table is replicated.  The ranks'
+ * global batch b is the union of their local batches b.  Item rows are then never updated in place: every item
+ * occurrence emits its gradient row, the ranks all-gather those rows after the gradient pass (dx[B .. B + 2*batch)
+ * -> dx_items_all[world][2*batch][d]; `hook` on the host, or the library's own communicator when hook == NULL),
+ * and every rank applies the identical update over the job's global item-occurrence list, which the index
+ * preparation builds from `items_all` (the item columns of every rank's triples, gathered once per epoch by the
+ * caller): replicas stay bit-identical, the step is the synchronous SGD step of the global batch.  BCE's mean is
+ * over the global batch: loss_scale = B_local / B_global (1 for BPR). */
+typedef struct {
+    int world;
+    const int64_t* items_all;   /* device [world][n][2]: (positive, negative) of every rank's triples, rank-major */
+    float* dx_local;            /* caller-owned, 3*batch * d floats: this rank's per-occurrence gradient rows (what a host-side
+                                   hook gathers from) */
+    float* dx_items_all;        /* caller-owned, world * 2*batch * d floats */
+    sml_mf_hook hook;
+    void* hook_user;
+    float loss_scale;
+} sml_bare_exchange;
+
 int sml_embed_loss_sgd_prepare(sml_ctx* ctx, const int64_t* triples, int64_t n, int batch,
-                               int64_t n_user, int64_t n_item, int slot, void* stream);
+                               int64_t n_user, int64_t n_item, int slot, const sml_bare_exchange* xchg, void* stream);
 int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n_user,
                              int64_t n_item, int dtype_bytes, const int64_t* triples, int64_t n,
                              int batch, float lr, float lam_user, float lam_item, int loss_kind,
-                             float* batch_loss, int prepared_slot, void* stream);
+                             float* batch_loss, int prepared_slot, const sml_bare_exchange* xchg, void* stream);
 
 /* The same step as the reference's baselines run it (model/baseline.py:188-201 in base_train, :343-361 in
  * run_one_stage2: fine-tune / full-retrain MF): BCE + L2 loss and torch.optim.Adam(lr, wd 0) over the DENSE

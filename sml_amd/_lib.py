@@ -35,6 +35,11 @@ class MFExchange(ctypes.Structure):
                 ("slot_stride", ctypes.c_int64), ("item_off", c_void)]
 
 
+class BareExchange(ctypes.Structure):
+    _fields_ = [("world", ctypes.c_int), ("items_all", c_void), ("dx_local", c_void), ("dx_items_all", c_void), ("hook", MF_HOOK),
+                ("hook_user", c_void), ("loss_scale", ctypes.c_float)]
+
+
 class BatchPlan(ctypes.Structure):
     _fields_ = [("n_batches", ctypes.c_int64), ("batch_off", c_void), ("batch_off_dev", c_void), ("loss_scale", c_void)]
 
@@ -65,11 +70,11 @@ SIGNATURES = {
                                           ctypes.POINTER(BatchPlan), c_void]),
     "sml_embed_loss_sgd_epoch": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                                                 c_void, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_float,
-                                                ctypes.c_float, ctypes.c_int, c_void, ctypes.c_int, c_void]),
+                                                ctypes.c_float, ctypes.c_int, c_void, ctypes.c_int, ctypes.POINTER(BareExchange), c_void]),
     "sml_embed_loss_adam_epoch": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                                  ctypes.c_float, ctypes.c_int, c_void, c_void, c_void]),
     "sml_embed_loss_sgd_prepare": (ctypes.c_int, [c_void, c_void, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
-                                                  ctypes.c_int, c_void]),
+                                                  ctypes.c_int, ctypes.POINTER(BareExchange), c_void]),
     "sml_mf_forward": (ctypes.c_int, [c_void, c_void, c_void, c_void, c_void, ctypes.c_int64, ctypes.c_int, c_void,
                                       c_void, c_void, c_void]),
     "sml_eval_ranks": (ctypes.c_int, [c_void, c_void, c_void, c_void, ctypes.c_int64, ctypes.c_int, c_void, c_void]),

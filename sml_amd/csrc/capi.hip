@@ -134,7 +134,7 @@ struct IndexSet {
     int key_bytes = 8, row_bits_u = 32, row_bits_i = 32;
     int* max_len_host = nullptr;       // pinned: longest duplicated run of the prepared epoch (0 if none exceeds SML_HOT)
     hipEvent_t ready = nullptr;        // recorded after the copy into max_len_host
-    int64_t n = -1; int batch = 0; const void* triples = nullptr;   // what was prepared here
+    int64_t n = -1; int batch = 0; const void* triples = nullptr; int world = 1;   // what was prepared here
     void release() {
         key_u.release(); key_u2.release(); key_i.release(); key_i2.release();
         val_u.release(); val_u2.release(); val_i.release(); val_i2.release();
@@ -261,6 +261,23 @@ struct DupHead {
         return (q == 0 || keys[q - 1] != k) && ((int64_t)q + 1 < n && keys[q + 1] == k);
     }
 };
+// ... or any run (several GPUs: every item run of the job's global list is applied by the run kernel, also the
+// single-occurrence ones -- an in-place update on one rank would leave the other replicas behind)
+template <typename K>
+struct AnyHead {
+    const K* keys; int64_t n;
+    __host__ __device__ bool operator()(const uint32_t& q) const { return q == 0 || keys[q - 1] != keys[q]; }
+};
+template <typename K>
+int select_all_heads(IndexSet* c, const void* keys, int64_t n, uint32_t* heads, int* n_sel, hipStream_t st) {
+    hipcub::CountingInputIterator<uint32_t> pos(0u);
+    AnyHead<K> pred{reinterpret_cast<const K*>(keys), n};
+    size_t tmp = 0;
+    HIPCHK(hipcub::DeviceSelect::If(nullptr, tmp, pos, heads, n_sel, (int)n, pred, st));
+    HIPCHK(c->cub_tmp.ensure(tmp + 256));
+    HIPCHK(hipcub::DeviceSelect::If(c->cub_tmp.p, tmp, pos, heads, n_sel, (int)n, pred, st));
+    return SML_OK;
+}
 template <typename K>
 int select_dup_heads(IndexSet* c, const void* keys, int64_t n, uint32_t* heads, int* n_sel, hipStream_t st) {
     hipcub::CountingInputIterator<uint32_t> pos(0u);
@@ -273,16 +290,16 @@ int select_dup_heads(IndexSet* c, const void* keys, int64_t n, uint32_t* heads, 
 }
 
 template <typename K>
-int sort_pairs(IndexSet* c, int64_t n, int end_u, int end_i, hipStream_t st) {
+int sort_pairs(IndexSet* c, int64_t n, int64_t n_items, int end_u, int end_i, hipStream_t st) {
     K* ku = reinterpret_cast<K*>(c->key_u.p); K* ku2 = reinterpret_cast<K*>(c->key_u2.p);
     K* ki = reinterpret_cast<K*>(c->key_i.p); K* ki2 = reinterpret_cast<K*>(c->key_i2.p);
     size_t tmp1 = 0, tmp2 = 0;
     HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp1, ku, ku2, c->val_u.p, c->val_u2.p, (int)n, 0, end_u, st));
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, ki, ki2, c->val_i.p, c->val_i2.p, (int)(2 * n), 0, end_i, st));
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, ki, ki2, c->val_i.p, c->val_i2.p, (int)n_items, 0, end_i, st));
     size_t tmp = tmp1 > tmp2 ? tmp1 : tmp2;
     HIPCHK(c->cub_tmp.ensure(tmp + 256));
     HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tmp, ku, ku2, c->val_u.p, c->val_u2.p, (int)n, 0, end_u, st));
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tmp, ki, ki2, c->val_i.p, c->val_i2.p, (int)(2 * n), 0, end_i, st));
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tmp, ki, ki2, c->val_i.p, c->val_i2.p, (int)n_items, 0, end_i, st));
     return SML_OK;
 }
 
@@ -291,11 +308,15 @@ int sort_pairs(IndexSet* c, int64_t n, int end_u, int end_i, hipStream_t st) {
 // With `dups` the duplicated runs are also compacted (stable) with their per-batch ranges, and every
 // occurrence gets its "row occurs once in this batch" mark -- all on the device, no host round trip.
 int sort_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_tiles, int64_t n_user, int64_t n_item,
-               bool dups, hipStream_t st, const sml_batch_plan* plan = nullptr) {
+               bool dups, hipStream_t st, const sml_batch_plan* plan = nullptr, const sml_bare_exchange* bx = nullptr) {
+    // bx (bare step on several GPUs): the item lists are the JOB's -- every rank's 2n item occurrences
+    const int64_t n_items = bx ? (int64_t)bx->world * 2 * n : 2 * n;
+    const int64_t seg_i = bx ? (int64_t)bx->world * 2 * batch : (int64_t)2 * batch;       // item occurrences of a full batch
+    if (n_items > 0x7fffffff) return fail(SML_EINVAL, "index preparation", "too many item occurrences in one epoch");
     HIPCHK(c->key_u.ensure((size_t)n + 1)); HIPCHK(c->key_u2.ensure((size_t)n + 1));
     HIPCHK(c->val_u.ensure((size_t)n + 1)); HIPCHK(c->val_u2.ensure((size_t)n + 1));
-    HIPCHK(c->key_i.ensure((size_t)2 * n + 1)); HIPCHK(c->key_i2.ensure((size_t)2 * n + 1));
-    HIPCHK(c->val_i.ensure((size_t)2 * n + 1)); HIPCHK(c->val_i2.ensure((size_t)2 * n + 1));
+    HIPCHK(c->key_i.ensure((size_t)n_items + 1)); HIPCHK(c->key_i2.ensure((size_t)n_items + 1));
+    HIPCHK(c->val_i.ensure((size_t)n_items + 1)); HIPCHK(c->val_i2.ensure((size_t)n_items + 1));
     const int64_t nb = plan ? plan->n_batches : (n + batch - 1) / batch;
     const int* boff = plan ? plan->batch_off_dev : nullptr;
     if (n == 0) { c->n = 0; c->batch = batch; c->triples = tri; return SML_OK; }
@@ -306,8 +327,9 @@ int sort_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
     c->row_bits_u = narrow ? rbu : 32; c->row_bits_i = narrow ? rbi : 32;
     HIPCHK(sml_launch_build_keys(c->key_bytes, tri, n, batch, pad_tiles, c->row_bits_u, c->row_bits_i, c->key_u.p, c->val_u.p,
                                  c->key_i.p, c->val_i.p, boff, (int)nb, st));
-    int rc = narrow ? sort_pairs<uint32_t>(c, n, c->row_bits_u + bb, c->row_bits_i + bb, st)
-                    : sort_pairs<uint64_t>(c, n, 32 + bb, 32 + bb, st);
+    if (bx) HIPCHK(sml_launch_build_item_keys_x(c->key_bytes, bx->items_all, bx->world, n, batch, c->row_bits_i, c->key_i.p, c->val_i.p, st));
+    int rc = narrow ? sort_pairs<uint32_t>(c, n, n_items, c->row_bits_u + bb, c->row_bits_i + bb, st)
+                    : sort_pairs<uint64_t>(c, n, n_items, 32 + bb, 32 + bb, st);
     if (rc) return rc;
     if (!dups) {
         // one record per sorted position (the MF stage's batches are small: no compaction)
@@ -318,22 +340,28 @@ int sort_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
         // unique marks for the in-place pass; duplicated-run heads selected by position (no per-position
         // records: the predicate reads the sorted keys), then one record per selected head
         HIPCHK(c->uniq.ensure((size_t)3 * nb * batch));
-        HIPCHK(c->heads_u.ensure((size_t)n / 2 + 8)); HIPCHK(c->heads_i.ensure((size_t)n + 8));
-        HIPCHK(c->runs_u.ensure((size_t)n / 2 + 8)); HIPCHK(c->runs_i.ensure((size_t)n + 8));
+        const int64_t max_heads_i = bx ? n_items : n;      // dup heads: at most every second occurrence; all heads: every one
+        HIPCHK(c->heads_u.ensure((size_t)n / 2 + 8)); HIPCHK(c->heads_i.ensure((size_t)max_heads_i + 8));
+        HIPCHK(c->runs_u.ensure((size_t)n / 2 + 8)); HIPCHK(c->runs_i.ensure((size_t)max_heads_i + 8));
         HIPCHK(c->off_u.ensure((size_t)nb + 1)); HIPCHK(c->off_i.ensure((size_t)nb + 1)); HIPCHK(c->n_sel.ensure(4));
         HIPCHK(hipMemsetAsync(c->uniq.p, 1, (size_t)3 * nb * batch, st));
         HIPCHK(sml_launch_mark_unique(c->key_bytes, c->key_u2.p, c->val_u2.p, n, c->row_bits_u, c->uniq.p, (int64_t)3 * batch, st));
-        HIPCHK(sml_launch_mark_unique(c->key_bytes, c->key_i2.p, c->val_i2.p, 2 * n, c->row_bits_i, c->uniq.p, (int64_t)3 * batch, st));
+        if (bx) HIPCHK(sml_launch_zero_item_marks(c->uniq.p, n, batch, st));     // items: never in place
+        else HIPCHK(sml_launch_mark_unique(c->key_bytes, c->key_i2.p, c->val_i2.p, 2 * n, c->row_bits_i, c->uniq.p, (int64_t)3 * batch, st));
         rc = narrow ? select_dup_heads<uint32_t>(c, c->key_u2.p, n, c->heads_u.p, c->n_sel.p, st)
                     : select_dup_heads<uint64_t>(c, c->key_u2.p, n, c->heads_u.p, c->n_sel.p, st);
         if (rc) return rc;
-        rc = narrow ? select_dup_heads<uint32_t>(c, c->key_i2.p, 2 * n, c->heads_i.p, c->n_sel.p + 1, st)
-                    : select_dup_heads<uint64_t>(c, c->key_i2.p, 2 * n, c->heads_i.p, c->n_sel.p + 1, st);
+        if (bx) rc = narrow ? select_all_heads<uint32_t>(c, c->key_i2.p, n_items, c->heads_i.p, c->n_sel.p + 1, st)
+                            : select_all_heads<uint64_t>(c, c->key_i2.p, n_items, c->heads_i.p, c->n_sel.p + 1, st);
+        else rc = narrow ? select_dup_heads<uint32_t>(c, c->key_i2.p, n_items, c->heads_i.p, c->n_sel.p + 1, st)
+                         : select_dup_heads<uint64_t>(c, c->key_i2.p, n_items, c->heads_i.p, c->n_sel.p + 1, st);
         if (rc) return rc;
         HIPCHK(hipMemsetAsync(c->n_sel.p + 2, 0, sizeof(int), st));
         // hot rows: with large batches a popular item collects thousands of occurrences per batch; such runs
-        // are listed per batch here and reduced by whole workgroups
-        const int hot_cap = 3 * batch / SML_HOT + 8;
+        // are listed per batch here and reduced by whole workgroups.  (The list is sized for the most hot runs a
+        // batch's occurrences can form; beyond SML_HOT_MAXCAP the path is off and wavefronts sum the long runs.)
+        const int64_t hot_cap64 = (batch + seg_i) / SML_HOT + 8;
+        const int hot_cap = (int)(hot_cap64 < 0x7fffffff ? hot_cap64 : 0x7fffffff);
         c->hot_cap = (batch >= 4096 && hot_cap <= SML_HOT_MAXCAP) ? hot_cap : 0;
         if (c->hot_cap) {
             HIPCHK(c->hot_list.ensure((size_t)nb * c->hot_cap * 3)); HIPCHK(c->hot_count.ensure((size_t)nb));
@@ -342,8 +370,8 @@ int sort_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
         uint32_t* hl = c->hot_cap ? c->hot_list.p : nullptr;
         HIPCHK(sml_launch_make_runs(c->key_bytes, c->key_u2.p, c->val_u2.p, n, c->row_bits_u, c->heads_u.p, c->n_sel.p, n / 2, c->runs_u.p,
                                     c->n_sel.p + 2, (int64_t)batch, 0, hl, c->hot_count.p, c->hot_cap, st));
-        HIPCHK(sml_launch_make_runs(c->key_bytes, c->key_i2.p, c->val_i2.p, 2 * n, c->row_bits_i, c->heads_i.p, c->n_sel.p + 1, n, c->runs_i.p,
-                                    c->n_sel.p + 2, (int64_t)2 * batch, 1, hl, c->hot_count.p, c->hot_cap, st));
+        HIPCHK(sml_launch_make_runs(c->key_bytes, c->key_i2.p, c->val_i2.p, n_items, c->row_bits_i, c->heads_i.p, c->n_sel.p + 1, max_heads_i, c->runs_i.p,
+                                    c->n_sel.p + 2, seg_i, 1, hl, c->hot_count.p, c->hot_cap, st));
         // the longest run of the epoch travels to the host: an epoch KNOWN to have no hot rows skips the hot-row
         // kernels altogether (the epoch call queries this event, it never waits for it)
         if (!c->max_len_host) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->max_len_host), sizeof(int), hipHostMallocDefault));
@@ -351,9 +379,9 @@ int sort_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
         HIPCHK(hipMemcpyAsync(c->max_len_host, c->n_sel.p + 2, sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(hipEventRecord(c->ready, st));
         HIPCHK(sml_launch_batch_offsets(c->runs_u.p, c->n_sel.p, (int)nb, (int64_t)batch, c->off_u.p, st));
-        HIPCHK(sml_launch_batch_offsets(c->runs_i.p, c->n_sel.p + 1, (int)nb, (int64_t)2 * batch, c->off_i.p, st));
+        HIPCHK(sml_launch_batch_offsets(c->runs_i.p, c->n_sel.p + 1, (int)nb, seg_i, c->off_i.p, st));
     }
-    c->n = n; c->batch = batch; c->triples = tri;
+    c->n = n; c->batch = batch; c->triples = tri; c->world = bx ? bx->world : 1;
     return SML_OK;
 }
 
@@ -668,20 +696,25 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
 }
 
 int sml_embed_loss_sgd_prepare(sml_ctx* ctx, const int64_t* triples, int64_t n, int batch, int64_t n_user,
-                               int64_t n_item, int slot, void* stream) {
+                               int64_t n_item, int slot, const sml_bare_exchange* xchg, void* stream) {
     if (!ctx || !triples || n <= 0 || batch <= 0 || (slot != 0 && slot != 1))
         return fail(SML_EINVAL, "sml_embed_loss_sgd_prepare", "bad argument");
+    if (xchg && (xchg->world < 1 || !xchg->items_all)) return fail(SML_EINVAL, "sml_embed_loss_sgd_prepare", "incomplete exchange descriptor");
     if (batch > ctx->max_batch) return fail(SML_EINVAL, "sml_embed_loss_sgd_prepare", "batch exceeds ctx max_batch");
     if (n > 0x3fffffff) return fail(SML_EINVAL, "sml_embed_loss_sgd_prepare", "epoch too long");
     DevGuard g(ctx->device);
-    return sort_epoch(&ctx->ix[slot], triples, n, batch, 0, n_user, n_item, true, (hipStream_t)stream);
+    return sort_epoch(&ctx->ix[slot], triples, n, batch, 0, n_user, n_item, true, (hipStream_t)stream, nullptr, xchg);
 }
 
 int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n_user, int64_t n_item, int dtype_bytes,
                              const int64_t* triples, int64_t n, int batch, float lr, float lam_user, float lam_item,
-                             int loss_kind, float* batch_loss, int prepared_slot, void* stream) {
+                             int loss_kind, float* batch_loss, int prepared_slot, const sml_bare_exchange* xchg, void* stream) {
     if (!ctx || !w_user || !w_item || !triples || !batch_loss || n <= 0 || batch <= 0 || n_user <= 0 || n_item <= 0)
         return fail(SML_EINVAL, "sml_embed_loss_sgd_epoch", "bad argument");
+    if (xchg && (xchg->world < 1 || !xchg->items_all || !xchg->dx_items_all || !xchg->dx_local))
+        return fail(SML_EINVAL, "sml_embed_loss_sgd_epoch", "incomplete exchange descriptor");
+    if (xchg && !xchg->hook && (!ctx->comm || ctx->comm_world != xchg->world))
+        return fail(SML_ESTATE, "sml_embed_loss_sgd_epoch", "exchange without a hook needs sml_comm_init with the same world size");
     if (dtype_bytes != 4 && dtype_bytes != 2) return fail(SML_EINVAL, "sml_embed_loss_sgd_epoch", "dtype_bytes must be 4 or 2");
     if (loss_kind != SML_LOSS_BCE && loss_kind != SML_LOSS_BPR) return fail(SML_EINVAL, "sml_embed_loss_sgd_epoch", "loss_kind");
     if (batch > ctx->max_batch) return fail(SML_EINVAL, "sml_embed_loss_sgd_epoch", "batch exceeds ctx max_batch");
@@ -693,14 +726,15 @@ int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n
     const int64_t nb = (n + batch - 1) / batch;
     int rc;
     HIPCHK(ctx->dx.ensure((size_t)3 * batch * d));
+    float* const dxb = xchg ? xchg->dx_local : ctx->dx.p;       // per-occurrence gradient rows of the batch in flight
     const int lpr = d * dtype_bytes / 16;
     const int lstride = (int)(((int64_t)batch * lpr + 255) / 256);
     HIPCHK(ctx->loss_part.ensure((size_t)nb * lstride));
     IndexSet* X = &ctx->ix[prepared_slot < 0 ? 0 : prepared_slot];
     if (prepared_slot < 0) {
-        ctx->prof.begin(PC_SORT, st); rc = sort_epoch(X, triples, n, batch, 0, n_user, n_item, true, st); ctx->prof.end(st);
+        ctx->prof.begin(PC_SORT, st); rc = sort_epoch(X, triples, n, batch, 0, n_user, n_item, true, st, nullptr, xchg); ctx->prof.end(st);
         if (rc) return rc;
-    } else if (X->n != n || X->batch != batch || X->triples != triples) {
+    } else if (X->n != n || X->batch != batch || X->triples != triples || X->world != (xchg ? xchg->world : 1)) {
         return fail(SML_ESTATE, "sml_embed_loss_sgd_epoch", "index set was prepared for other triples");
     }
     HIPCHK(hipMemsetAsync(ctx->loss_part.p, 0, (size_t)nb * lstride * sizeof(float), st));
@@ -711,7 +745,8 @@ int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n
     const int hot_cap = X->hot_cap;
     const bool known = hipEventQuery(X->ready) == hipSuccess;
     const bool hot = hot_cap > 0 && (!known || *X->max_len_host > SML_HOT);
-    const int hot_chunks = 3 * batch / SML_HOT_CHUNK + hot_cap;
+    const int world = xchg ? xchg->world : 1;
+    const int hot_chunks = (int)(((int64_t)batch + (int64_t)world * 2 * batch) / SML_HOT_CHUNK) + hot_cap;
     if (hot) {
         HIPCHK(ctx->hot_first.ensure((size_t)hot_cap));
         HIPCHK(ctx->hot_part.ensure((size_t)hot_chunks * d));
@@ -720,22 +755,32 @@ int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n
         const int B = (int)((n - b * batch) < batch ? (n - b * batch) : batch);
         SmlBareArgs a;
         memset(&a, 0, sizeof(a));
-        a.w_user = w_user; a.w_item = w_item; a.tri = triples + b * batch * 3; a.B = B; a.dx = ctx->dx.p;
+        a.w_user = w_user; a.w_item = w_item; a.tri = triples + b * batch * 3; a.B = B; a.dx = dxb;
         a.loss_part = ctx->loss_part.p + b * lstride; a.kind = loss_kind; a.lam_user = lam_user; a.lam_item = lam_item;
-        a.uniq = X->uniq.p + (size_t)3 * b * batch; a.lr = lr;
+        a.uniq = X->uniq.p + (size_t)3 * b * batch; a.lr = lr; a.scale = xchg ? xchg->loss_scale : 1.0f;
         ctx->prof.begin(PC_BARE_GRAD, st); HIPCHK(sml_launch_bare_grad(d, dtype_bytes, a, nullptr, st)); ctx->prof.end(st);
+        if (xchg) {     // every rank's item-gradient rows (slots [B, B + 2*batch) of dx; a ragged batch sends its tail along)
+            if (xchg->hook) {
+                if (xchg->hook(xchg->hook_user, b) != 0) return fail(SML_ESTATE, "sml_embed_loss_sgd_epoch", "exchange hook failed");
+            } else {
+                NCCLCHK(g_rccl.AllGather(dxb + (size_t)B * d, xchg->dx_items_all, (size_t)2 * batch * d, ncclFloat, ctx->comm, st));
+            }
+        }
         SmlRunArgs u;
         memset(&u, 0, sizeof(u));
         // compacted duplicated-run lists of the whole epoch; the kernels slice out batch b themselves and
         // stride over it (how many runs a batch has is only known on the device)
         u.run_u = X->runs_u.p; u.run_i = X->runs_i.p; u.off_u = X->off_u.p; u.off_i = X->off_i.p; u.batch_index = (int)b;
         u.val_u = X->val_u2.p; u.val_i = X->val_i2.p;
-        u.dx = ctx->dx.p; u.dx_i = ctx->dx.p; u.w_user = w_user; u.w_item = w_item; u.lr = lr;
+        u.dx = dxb; u.dx_i = xchg ? xchg->dx_items_all : dxb; u.w_user = w_user; u.w_item = w_item; u.lr = lr;
         if (hot) {
             u.hot_list = X->hot_list.p + (size_t)b * hot_cap * 3; u.hot_count = X->hot_count.p + b; u.hot_first = ctx->hot_first.p;
             u.hot_part = ctx->hot_part.p; u.hot_cap = hot_cap; u.hot_blocks = hot_chunks < 512 ? hot_chunks : 512;
         }
-        ctx->prof.begin(PC_SEG_SGD, st); HIPCHK(sml_launch_run_sgd(d, dtype_bytes, u, (int64_t)3 * B / 2, st)); ctx->prof.end(st);
+        // (grid: one lane group per possible record -- duplicated runs are at most every second occurrence; on several
+        // GPUs every item run of the job's list is a record)
+        const int64_t max_rec = xchg ? (int64_t)B / 2 + (int64_t)world * 2 * B : (int64_t)3 * B / 2;
+        ctx->prof.begin(PC_SEG_SGD, st); HIPCHK(sml_launch_run_sgd(d, dtype_bytes, u, max_rec, st)); ctx->prof.end(st);
         if (hot) { ctx->prof.begin(PC_PAIR_LOSS, st); HIPCHK(sml_launch_hot_apply(d, dtype_bytes, u, st)); ctx->prof.end(st); }
     }
     ctx->prof.begin(PC_MISC, st); HIPCHK(sml_launch_loss_finalize(ctx->loss_part.p, (int)nb, lstride, nullptr, batch_loss, st)); ctx->prof.end(st);
@@ -772,7 +817,7 @@ int sml_embed_loss_adam_epoch(sml_ctx* ctx, const sml_mf_tables* t, const int64_
         a.loss_part = ctx->loss_part.p + b * lstride; a.kind = loss_kind; a.lam_user = lam_user; a.lam_item = lam_item;
         a.m_user = t->m_user; a.v_user = t->v_user; a.m_item = t->m_item; a.v_item = t->v_item;
         a.last_user = t->step_user; a.last_item = t->step_item; a.sched = ctx->sched.p; a.cur_step = cur;
-        a.xrep = ctx->xin.p; a.mrep = ctx->mrep.p; a.vrep = ctx->vrep.p;
+        a.xrep = ctx->xin.p; a.mrep = ctx->mrep.p; a.vrep = ctx->vrep.p; a.scale = 1.0f;
         ctx->prof.begin(PC_BARE_GRAD, st); HIPCHK(sml_launch_bare_grad(d, 4, a, nullptr, st)); ctx->prof.end(st);
         SmlRunArgs u;
         memset(&u, 0, sizeof(u));

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void k_bare_grad(SmlBareArgs a) {
         }
         sp = group_sum<LPR>(sp); sn = group_sum<LPR>(sn);
         float lt, dsp, dsn;
-        pair_terms(a.kind, sp, sn, 1.0f / (float)a.B, lt, dsp, dsn);
+        pair_terms(a.kind, sp, sn, a.scale / (float)a.B, lt, dsp, dsn);     // (BCE: a mean over the GLOBAL batch; the BPR sum ignores it)
         // gradient rows.  An occurrence whose row appears ONCE in this batch is read by nobody else in
         // the batch, so its synchronous-SGD update is applied in place right here (exact); the others
         // hand their gradient row to the segmented update.
@@ -216,6 +216,33 @@ __global__ void k_build_keys(const int64_t* __restrict__ tri, int64_t n, int bat
     val_i[base + t] = ioff + t;
     key_i[base + Bb + t] = ((K)b << row_bits_i) | (K)(uint32_t)tri[e * 3 + 2];
     val_i[base + Bb + t] = ioff + Bb + t;
+}
+
+template <typename K>
+__global__ void k_build_item_keys_x(const int64_t* __restrict__ items_all, int world, int64_t n, int batch, int row_bits_i,
+                                    K* __restrict__ key_i, uint32_t* __restrict__ val_i) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // (rank q, element e)
+    if (g >= (int64_t)world * n) return;
+    const int64_t q = g / n, e = g - q * n;
+    const int64_t b = e / batch;
+    const int64_t rem = n - b * batch;
+    const uint32_t Bb = (uint32_t)(rem < batch ? rem : batch);
+    const uint32_t t = (uint32_t)(e - b * batch);
+    const uint32_t base = (uint32_t)(q * 2 * batch);
+    key_i[2 * g] = ((K)b << row_bits_i) | (K)(uint32_t)items_all[2 * g];
+    val_i[2 * g] = base + t;
+    key_i[2 * g + 1] = ((K)b << row_bits_i) | (K)(uint32_t)items_all[2 * g + 1];
+    val_i[2 * g + 1] = base + Bb + t;
+}
+
+__global__ void k_zero_item_marks(uint8_t* __restrict__ uniq, int64_t n, int batch) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int64_t b = e / batch;
+    const int64_t rem = n - b * batch;
+    const int64_t Bb = rem < batch ? rem : batch, t = e - b * batch;
+    uint8_t* u = uniq + b * 3 * batch;
+    u[Bb + t] = 0; u[2 * Bb + t] = 0;
 }
 
 // per epoch, over one sorted list: a record for every position (len = 0 unless the position
@@ -941,6 +968,20 @@ hipError_t sml_launch_make_runs(int key_bytes, const void* keys, const uint32_t*
     const dim3 grid((unsigned)((max_heads + 255) / 256));
     if (key_bytes == 4) k_make_runs<uint32_t><<<grid, dim3(256), 0, st>>>((const uint32_t*)keys, vals, n, row_bits, heads, n_heads, runs, max_len, seg, is_item, hot_list, hot_count, hot_cap);
     else k_make_runs<uint64_t><<<grid, dim3(256), 0, st>>>((const uint64_t*)keys, vals, n, row_bits, heads, n_heads, runs, max_len, seg, is_item, hot_list, hot_count, hot_cap);
+    return hipGetLastError();
+}
+hipError_t sml_launch_build_item_keys_x(int key_bytes, const int64_t* items_all, int world, int64_t n, int batch, int row_bits_i,
+                                        void* key_i, uint32_t* val_i, hipStream_t st) {
+    const int64_t tot = (int64_t)world * n;
+    if (tot <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((tot + 255) / 256));
+    if (key_bytes == 4) k_build_item_keys_x<uint32_t><<<grid, dim3(256), 0, st>>>(items_all, world, n, batch, row_bits_i, (uint32_t*)key_i, val_i);
+    else k_build_item_keys_x<uint64_t><<<grid, dim3(256), 0, st>>>(items_all, world, n, batch, row_bits_i, (uint64_t*)key_i, val_i);
+    return hipGetLastError();
+}
+hipError_t sml_launch_zero_item_marks(uint8_t* uniq, int64_t n, int batch, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    k_zero_item_marks<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(uniq, n, batch);
     return hipGetLastError();
 }
 hipError_t sml_launch_batch_offsets(const SmlRun* runs, const int* n_sel, int nb, int64_t seg, int* off, hipStream_t st) {

@@ -143,6 +143,12 @@ hipError_t sml_launch_make_runs(int key_bytes, const void* keys, const uint32_t*
                                 const int* n_heads, int64_t max_heads, SmlRun* runs, int* max_len, int64_t seg, int is_item,
                                 uint32_t* hot_list, int* hot_count, int hot_cap, hipStream_t st);
 hipError_t sml_launch_batch_offsets(const SmlRun* runs, const int* n_sel, int nb, int64_t seg, int* off, hipStream_t st);
+// several GPUs, bare step: keys / slots of the job's item occurrences from the gathered item columns
+// items_all [world][n][2]; slot of rank q's element t of batch b: q*2*batch + t (positive), q*2*batch + B_b + t (negative)
+hipError_t sml_launch_build_item_keys_x(int key_bytes, const int64_t* items_all, int world, int64_t n, int batch, int row_bits_i,
+                                        void* key_i, uint32_t* val_i, hipStream_t st);
+// uniq[b][B_b .. 3*B_b) = 0: item occurrences are never updated in place
+hipError_t sml_launch_zero_item_marks(uint8_t* uniq, int64_t n, int batch, hipStream_t st);
 // boff: device [nb+1] offsets of the batches inside tri (null: batches of `batch`, the last one ragged)
 hipError_t sml_launch_build_keys(int key_bytes, const int64_t* tri, int64_t n, int batch, int pad_tiles, int row_bits_u,
                                  int row_bits_i, void* key_u, uint32_t* val_u, void* key_i, uint32_t* val_i, const int* boff,
@@ -156,6 +162,7 @@ struct SmlBareArgs {
     float* dx;               // [3B, d] per-occurrence gradients (fp32)
     float* loss_part;
     int kind; float lam_user, lam_item;
+    float scale;             // multiplies the pair loss and its gradients (B_local / B_global for a split BCE batch; else 1)
     // lazy dense-Adam form (sched != null; fp32 tables): the rows' pending zero-gradient steps are replayed
     // before use; uniq is ignored (every occurrence emits its gradient row)
     const float* m_user; const float* v_user; const float* m_item; const float* v_item;

@@ -211,6 +211,30 @@ class DistContext(object):
                     hook=None if self.native else hook, loss_scale=self.loss_scale(loss_kind), slot_stride=stride,
                     item_off=None)
 
+    # ---- bare a3 step (SGD): users sharded, items replicated, per-occurrence item-gradient rows all-gathered
+    def bare_exchange(self, triples, batch, d, loss_kind=LOSS_BCE):
+        """Exchange descriptor of the bare step over this rank's `triples` [n,3] (local user index; every rank brings
+        the same n and batch): the item columns of every rank are gathered ONCE here (the library builds the job's
+        item-occurrence list from them on the device), and per batch the ranks' item-gradient rows are gathered (by
+        the library's own communicator, or by the hook)."""
+        n = triples.shape[0]
+        self.same_on_all_ranks(n, "the epoch length n")
+        items = triples[:, 1:3].contiguous()
+        items_all = torch.empty((self.world,) + tuple(items.shape), dtype=items.dtype, device=items.device)
+        self.dist.all_gather(list(items_all.unbind(0)), items, group=self.group)
+        key = ("bare", d, batch)
+        if key not in self._buf:
+            self._buf[key] = (torch.zeros(3 * batch * d, device=self.device, dtype=torch.float32),
+                              torch.zeros(self.world * 2 * batch * d, device=self.device, dtype=torch.float32))
+        dx_local, dx_all = self._buf[key]
+
+        def hook(b):
+            Bb = min(batch, n - b * batch)
+            self.all_gather_rows(dx_all, dx_local[Bb * d:(Bb + 2 * batch) * d])
+
+        return dict(world=self.world, items_all=items_all.contiguous(), dx_local=dx_local, dx_all=dx_all,
+                    hook=None if self.native else hook, loss_scale=self.loss_scale(loss_kind))
+
     # ---- the real driver: a shared global epoch, split by user owner
     def route_epoch(self, global_tri, batch, n_user, mean_loss):
         return EpochRoute(self, global_tri, batch, n_user, mean_loss)

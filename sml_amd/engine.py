@@ -314,10 +314,34 @@ class HipEngine(object):
         return losses
 
     # ------------------------------------------------------------------ a3
-    def bare_prepare(self, triples, batch_size, n_user=0, n_item=0):
+    def _bare_exchange(self, ex):
+        """ctypes view of sml_amd.dist.DistContext.bare_exchange(): (struct pointer or None, keep-alive)."""
+        if ex is None:
+            return None, None
+        hook_fn = ex["hook"]
+
+        def _cb(_user, b):
+            try:
+                hook_fn(int(b))
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+        x = _lib.BareExchange()
+        x.world = ex["world"]
+        x.items_all, x.dx_local, x.dx_items_all = ex["items_all"].data_ptr(), ex["dx_local"].data_ptr(), ex["dx_all"].data_ptr()
+        cb = _lib.MF_HOOK(_cb) if hook_fn is not None else ctypes.cast(None, _lib.MF_HOOK)
+        x.hook = cb
+        x.hook_user = None
+        x.loss_scale = ex["loss_scale"]
+        return ctypes.byref(x), (x, cb, ex)
+
+    def bare_prepare(self, triples, batch_size, n_user=0, n_item=0, exchange=None):
         """Build the index lists of a coming bare epoch on the engine's side stream (sort by (batch,row),
         unique marks, duplicates-only compaction) while earlier work keeps the main stream busy.
         n_user / n_item (the table heights; 0 = unknown) let the sort use 32-bit keys.
+        exchange: several GPUs (DistContext.bare_exchange): the item lists are then the job's.
         Returns a handle for bare_epoch(prepared=...)."""
         if getattr(self, "_prep", None) is None:
             self._prep = torch.cuda.Stream(device=self.device)
@@ -325,15 +349,16 @@ class HipEngine(object):
         slot = self._prep_slot = 1 - getattr(self, "_prep_slot", 1)
         cur = torch.cuda.current_stream(self.device)
         self._prep.wait_stream(cur)          # the slot's previous user (two epochs back) has been queued before this
+        xp, keep = self._bare_exchange(exchange)
         with torch.cuda.stream(self._prep):
             check(self.lib.sml_embed_loss_sgd_prepare(self._ctx, _ptr(tri), tri.shape[0], int(batch_size), int(n_user),
-                                                      int(n_item), slot, self._stream()), "sml_embed_loss_sgd_prepare")
+                                                      int(n_item), slot, xp, self._stream()), "sml_embed_loss_sgd_prepare")
             ev = torch.cuda.Event()
             ev.record(self._prep)
         tri.record_stream(self._prep)
-        return dict(slot=slot, event=ev, tri=tri, batch=int(batch_size))
+        return dict(slot=slot, event=ev, tri=tri, batch=int(batch_size), exchange=exchange)
 
-    def bare_epoch(self, w_user, w_item, triples, batch_size, lr, lam_user, lam_item, bce=True, prepared=None):
+    def bare_epoch(self, w_user, w_item, triples, batch_size, lr, lam_user, lam_item, bce=True, prepared=None, exchange=None):
         if w_user.dtype not in (torch.float32, torch.float16) or w_item.dtype != w_user.dtype:
             raise ValueError("tables must both be fp32 or both fp16")
         for w in (w_user, w_item):
@@ -344,16 +369,18 @@ class HipEngine(object):
             if prepared["batch"] != int(batch_size):
                 raise ValueError("prepared for another batch size")
             tri, slot = prepared["tri"], prepared["slot"]
+            exchange = prepared.get("exchange") if exchange is None else exchange
             torch.cuda.current_stream(self.device).wait_event(prepared["event"])
         else:
             tri = self._dev(triples, torch.int64)
         n = tri.shape[0]
         nb = (n + batch_size - 1) // batch_size
         losses = torch.empty(nb, device=self.device, dtype=torch.float32)
+        xp, keep = self._bare_exchange(exchange)
         check(self.lib.sml_embed_loss_sgd_epoch(self._ctx, _ptr(w_user), _ptr(w_item), w_user.shape[0], w_item.shape[0],
                                                 w_user.element_size(), _ptr(tri), n, int(batch_size), float(lr),
                                                 float(lam_user), float(lam_item),
-                                                _lib.LOSS_BCE if bce else _lib.LOSS_BPR, _ptr(losses), slot,
+                                                _lib.LOSS_BCE if bce else _lib.LOSS_BPR, _ptr(losses), slot, xp,
                                                 self._stream()),
               "sml_embed_loss_sgd_epoch")
         return losses

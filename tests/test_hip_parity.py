@@ -1165,3 +1165,90 @@ def test_two_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run(monkey
     adam_close(r0["wi"].numpy(), hi.cpu().numpy(), 0.01, 5)
     for k in theta1:
         adam_close(r0["theta"][k].numpy(), theta1[k].numpy(), 1e-3, 5)
+
+
+# ----------------------------------------------------------------------------- bare a3 step on several GPUs
+def _bare_world2_inputs(d, dtype, B, n, U_rank, I, seed):
+    torch.manual_seed(seed)
+    wi = (torch.randn(I, d) * 0.3).to(dtype)
+    wus = [(torch.randn(U_rank, d) * 0.3).to(dtype) for _ in range(2)]
+    tris = []
+    for r in range(2):
+        u = torch.randint(0, U_rank, (n,)); u[:7] = 2
+        i = torch.randint(0, I, (n,)); j = torch.randint(0, I, (n,))
+        i[3] = j[3]
+        i[10:14] = 5                       # an item hit from both ranks inside one batch
+        tris.append(torch.stack([u, i, j], 1))
+    return wi, wus, tris
+
+
+@pytest.mark.parametrize("d,dtype,bce", [(32, torch.float32, True), (64, torch.float32, False), (128, torch.float16, False)])
+def test_bare_step_two_ranks_on_one_gpu_equal_the_global_batch_step(d, dtype, bce, monkeypatch):
+    """The bare a3 step under world_size 2 (thread ranks on one GPU, hook exchange): users sharded -- each rank its own
+    user table and triples --, item table replicated, per-occurrence item-gradient rows all-gathered every batch, the
+    job's item-occurrence list built by the library from the gathered item columns.  Equals the oracle's synchronous
+    SGD step over the GLOBAL batches [rank 0's batch b ; rank 1's batch b]; the item replicas are bit-identical."""
+    from _thread_group import run_ranks
+    from sml_amd import dist as SD
+    monkeypatch.setenv("SML_COMM", "torch")
+    B, n, U_rank, I = 96, 96 * 3 - 11, 150, 120
+    wi, wus, tris = _bare_world2_inputs(d, dtype, B, n, U_rank, I, seed=3 * d)
+    lr = 0.05 if bce else 0.01
+
+    def rank_fn(rank, group):
+        e = engine(d, B)
+        ctx = SD.attach(e, None, group)
+        gu, gi = wus[rank].clone().to(DEV), wi.clone().to(DEV)
+        tri = tris[rank].to(DEV)
+        ex = ctx.bare_exchange(tri, B, d, 0 if bce else 1)
+        losses = e.bare_epoch(gu, gi, tri, B, lr, 1e-3, 2e-3, bce=bce, exchange=ex)
+        return dict(l=losses.cpu().numpy(), wu=gu.float().cpu(), wi=gi.cpu())
+
+    r0, r1 = run_ranks(2, rank_fn)
+    assert torch.equal(r0["wi"], r1["wi"])
+    # oracle: one table of 2 * U_rank users, global batch b = the two ranks' batches b
+    ou, oi = torch.cat(wus).float().clone(), wi.float().clone()
+    want = []
+    for b0 in range(0, n, B):
+        t0, t1 = tris[0][b0:b0 + B], tris[1][b0:b0 + B].clone()
+        t1[:, 0] += U_rank
+        t = torch.cat([t0, t1])
+        want.append(O.bare_step(ou, oi, t[:, 0], t[:, 1], t[:, 2], lr, 1e-3, 2e-3, bce=bce))
+        if dtype == torch.float16:
+            ou, oi = ou.half().float(), oi.half().float()
+    tol = 1e-4 if dtype == torch.float32 else 2e-3
+    np.testing.assert_allclose(r0["l"] + r1["l"], want, rtol=tol)
+    close(torch.cat([r0["wu"], r1["wu"]]).numpy(), ou.numpy(), tol)
+    close(r0["wi"].float().numpy(), oi.numpy(), tol)
+
+
+def test_bare_step_exchange_on_a_one_rank_rccl_group_equals_the_plain_step():
+    """The same exchange through the library's OWN RCCL communicator (ncclAllGather issued between its kernels) on a
+    1-rank group, with a batch large enough for the hot-row path: equals the plain single-GPU step (same arithmetic;
+    the item rows go through the run kernel instead of the in-place update)."""
+    import socket
+    import torch.distributed as dist
+    from sml_amd import dist as SD
+    torch.manual_seed(8)
+    U, I, d, B = 4000, 2500, 32, 8192
+    n = 2 * B + 500
+    wu, wi = torch.randn(U, d) * 0.3, torch.randn(I, d) * 0.3
+    u = torch.randint(0, U, (n,)); i = torch.randint(0, I, (n,)); j = torch.randint(0, I, (n,))
+    i[0:B:3] = 7                                   # a hot item: ~2,700 occurrences in batch 0
+    tri = torch.stack([u, i, j], 1)
+    a_u, a_i = wu.clone().to(DEV), wi.clone().to(DEV)
+    la = engine(d, B).bare_epoch(a_u, a_i, tri, B, 0.05, 1e-4, 1e-4).cpu().numpy()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        e = engine(d, B)
+        ctx = SD.attach(e, None, dist)
+        assert ctx.native
+        b_u, b_i = wu.clone().to(DEV), wi.clone().to(DEV)
+        t = tri.to(DEV)
+        lb = e.bare_epoch(b_u, b_i, t, B, 0.05, 1e-4, 1e-4, exchange=ctx.bare_exchange(t, B, d, 0)).cpu().numpy()
+    finally:
+        dist.destroy_process_group()
+    np.testing.assert_allclose(lb, la, rtol=1e-6)
+    close(b_u.cpu().numpy(), a_u.cpu().numpy(), 1e-5)
+    close(b_i.cpu().numpy(), a_i.cpu().numpy(), 1e-5)
