@@ -255,6 +255,12 @@ int sml_eval_prepare(sml_ctx* ctx, const int64_t* rows, int64_t n, int n_cols, i
 int sml_eval_ranks_blocked(sml_ctx* ctx, const float* w_user, const float* w_item, const int32_t* rows_b,
                            const int32_t* bucket_off, int64_t n, int n_cols, int32_t* rank,
                            int max_workgroups, void* stream);
+/* A HIP stream restricted to the compute units [cu_lo, cu_hi) of the device's CU mask (on MI355X mask bit i is a
+ * CU of XCD i % 8, so a contiguous range takes the same number of CUs from every XCD: each range keeps all eight
+ * L2s and an eighth of its CUs on each).  Evaluations queued on such a stream run beside the training kernels on
+ * CUs of their own instead of sharing SIMDs and L2 ports with them.  The caller owns the stream. */
+int sml_stream_create_cu_range(void** stream, int device, int cu_lo, int cu_hi);
+int sml_stream_destroy(void* stream);
 /* hits = #{rank < topk}, ndcg = sum 1/log2(rank+2) over hits; out[0]=hits, out[1]=ndcg (device). */
 int sml_eval_metrics(sml_ctx* ctx, const int32_t* rank, int64_t n, int topk, float* out, void* stream);
 

@@ -82,6 +82,8 @@ SIGNATURES = {
     "sml_eval_prepare": (ctypes.c_int, [c_void, c_void, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, c_void, c_void, c_void]),
     "sml_eval_ranks_blocked": (ctypes.c_int, [c_void, c_void, c_void, c_void, c_void, ctypes.c_int64, ctypes.c_int, c_void, ctypes.c_int,
                                               c_void]),
+    "sml_stream_create_cu_range": (ctypes.c_int, [ctypes.POINTER(c_void), ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "sml_stream_destroy": (ctypes.c_int, [c_void]),
     "sml_comm_load": (ctypes.c_int, [ctypes.c_char_p]),
     "sml_comm_unique_id": (ctypes.c_int, [c_void]),
     "sml_comm_init": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void]),

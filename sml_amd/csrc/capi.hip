@@ -859,6 +859,8 @@ int sml_eval_prepare(sml_ctx* ctx, const int64_t* rows, int64_t n, int n_cols, i
                      int32_t* bucket_off, void* stream) {
     if (!ctx || !rows || !rows_b || !bucket_off || n < 0 || n_cols < 2 || n_item <= 0 || n_item > 0x7fffffff)
         return fail(SML_EINVAL, "sml_eval_prepare", "bad argument");
+    if ((uint64_t)n_item * (uint64_t)ctx->d > 0xffffffffull)      // the blocked rank kernel addresses the table with 32-bit element offsets
+        return fail(SML_EINVAL, "sml_eval_prepare", "item table too large for the blocked evaluation (n_item * d >= 2^32): use sml_eval_ranks");
     if (n == 0) return SML_OK;
     DevGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
@@ -1034,6 +1036,25 @@ int sml_host_resolve_negatives_csr(const int64_t* users, int64_t n, const int64_
     }
     *consumed = ptr;
     *resolved = e;
+    return SML_OK;
+}
+
+int sml_stream_create_cu_range(void** stream, int device, int cu_lo, int cu_hi) {
+    if (!stream) return fail(SML_EINVAL, "sml_stream_create_cu_range", "null stream pointer");
+    DevGuard g(device);
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    const int n_cu = prop.multiProcessorCount;
+    if (cu_lo < 0 || cu_hi > n_cu || cu_lo >= cu_hi) return fail(SML_EINVAL, "sml_stream_create_cu_range", "range outside the device's CUs");
+    std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32, 0u);
+    for (int b = cu_lo; b < cu_hi; ++b) mask[(size_t)b / 32] |= 1u << (b % 32);
+    hipStream_t st = nullptr;
+    HIPCHK(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+    *stream = st;
+    return SML_OK;
+}
+int sml_stream_destroy(void* stream) {
+    if (stream) HIPCHK(hipStreamDestroy((hipStream_t)stream));
     return SML_OK;
 }
 

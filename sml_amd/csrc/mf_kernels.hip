@@ -63,6 +63,76 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+// The evaluation's lane-group sums on DPP (data-parallel primitives: the cross-lane move rides in the VALU
+// instruction) instead of ds_bpermute shuffles.  rocprofv3 counters put the rank kernels at two thirds VALU-bound
+// (293 M vector instructions per 75k x 1001 evaluation, 31 per candidate and lane group): so the candidates are
+// reduced EIGHT AT A TIME in a transposing butterfly -- every lane brings its partial dot product of eight
+// candidates, each exchange step halves the candidates a lane still carries (stride LPR/2, LPR/4, LPR/8), and the
+// lane ends up with the complete score of ONE candidate: 25 cross-lane instructions per eight candidates instead of
+// 40, one compare per wavefront step instead of eight.  The pairing order is the plain xor butterfly's (stride LPR/2
+// down to 1) for every candidate, so these sums equal group_sum<LPR>() bit for bit: the positive's score, the
+// remainder candidates and the eight-at-a-time path all round alike (scores are compared exactly).
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ float dpp_f(float old, float v) {
+    // (full-mask permutations: bound_ctrl set, so `old` is never read and the move folds into the consuming VALU op)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, 0xf, BANK_MASK,
+                                                                 BANK_MASK == 0xf));
+}
+// the value lane ^ S holds (S = 1, 2, 4, 8: inside a 16-lane DPP row)
+template <int S>
+__device__ __forceinline__ float lane_xor(float v) {
+    if constexpr (S == 1) return dpp_f<0xB1, 0xf>(0.0f, v);               // quad_perm [1,0,3,2]
+    else if constexpr (S == 2) return dpp_f<0x4E, 0xf>(0.0f, v);          // quad_perm [2,3,0,1]
+    else if constexpr (S == 8) return dpp_f<0x128, 0xf>(0.0f, v);         // row_ror:8
+    else {
+        static_assert(S == 4, "stride");
+        const float t = dpp_f<0x104, 0x5>(0.0f, v);                       // row_shl:4 -> lanes 0-3, 8-11 of a row take lane + 4
+        return dpp_f<0x114, 0xa>(t, v);                                   // row_shr:4 -> lanes 4-7, 12-15 take lane - 4
+    }
+}
+template <int LPR>
+__device__ __forceinline__ float eval_group_sum(float v) {              // == group_sum<LPR>(v), on DPP
+    if constexpr (LPR >= 32) v += __shfl_xor(v, 16, 64);
+    if constexpr (LPR >= 16) v += lane_xor<8>(v);
+    if constexpr (LPR >= 8) v += lane_xor<4>(v);
+    v += lane_xor<2>(v);
+    v += lane_xor<1>(v);
+    return v;
+}
+// one exchange step of the transposing butterfly: N candidates in, N/2 out; lanes with bit S of `sub` keep the upper half
+template <int S, int N>
+__device__ __forceinline__ void butterfly_split(float (&a)[8], int sub) {
+    const bool hi = (sub & S) != 0;
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) {
+        if constexpr (S == 4) {
+            // partner's share of the candidate THIS lane keeps, in two bank-masked moves; then one add
+            float t = dpp_f<0x104, 0x5>(0.0f, a[i]);                      // low lanes (keep i): partner's a[i]
+            t = dpp_f<0x114, 0xa>(t, a[i + N / 2]);                       // high lanes (keep i + N/2): partner's a[i + N/2]
+            a[i] = (hi ? a[i + N / 2] : a[i]) + t;
+        } else {
+            const float x = a[i] + lane_xor<S>(a[i]), y = a[i + N / 2] + lane_xor<S>(a[i + N / 2]);
+            a[i] = hi ? y : x;
+        }
+    }
+}
+// scores of eight candidates from the lanes' partial dot products a[0..7]; returns the complete score of candidate
+// eval8_index<LPR>(sub) (lanes whose `sub` differ only below LPR/8 hold the same candidate)
+template <int LPR>
+__device__ __forceinline__ float eval8_reduce(float (&a)[8], int sub) {
+    static_assert(LPR == 8 || LPR == 16, "eight-at-a-time path: d = 32 or 64");
+    butterfly_split<LPR / 2, 8>(a, sub);
+    butterfly_split<LPR / 4, 4>(a, sub);
+    butterfly_split<LPR / 8, 2>(a, sub);
+    float v = a[0];
+    if constexpr (LPR == 16) v += lane_xor<1>(v);
+    return v;
+}
+template <int LPR>
+__device__ __forceinline__ int eval8_index(int sub) {
+    return ((sub & (LPR / 2)) ? 4 : 0) + ((sub & (LPR / 4)) ? 2 : 0) + ((sub & (LPR / 8)) ? 1 : 0);
+}
+
 // 4-element partial dot product with a pinned operation order (one multiply, three fused multiply-adds):
 // the evaluation compares scores exactly, so every kernel variant must round them identically
 __device__ __forceinline__ float dot4(const float (&a)[4], const float (&b)[4]) {
@@ -743,28 +813,30 @@ __global__ __launch_bounds__(256) void k_eval_ranks(const float* __restrict__ wu
     float u[4], x[4];
     RowVec<float>::load(wu + R[0] * D + sub * 4, u);
     RowVec<float>::load(wi + R[1] * D + sub * 4, x);
-    const float s0 = group_sum<LPR>(dot4(u, x));
+    const float s0 = eval_group_sum<LPR>(dot4(u, x));
     int cnt = 0;
-    int c = 2 + grp;
-    for (; c + 3 * G < n_cols; c += 4 * G) {
-        float y[4][4];
+    int c = 2;
+    if constexpr (LPR <= 16) {
+        // eight candidates per lane group and trip: 8 * G consecutive candidates per wavefront
+        for (; c + 8 * G <= n_cols; c += 8 * G) {
+            const int cb = c + grp * 8;
+            float y[8][4], a[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) RowVec<float>::load(wi + R[c + j * G] * D + sub * 4, y[j]);
+            for (int e = 0; e < 8; ++e) RowVec<float>::load(wi + R[cb + e] * D + sub * 4, y[e]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float s = group_sum<LPR>(dot4(u, y[j]));
-            cnt += (s > s0) ? 1 : 0;
+            for (int e = 0; e < 8; ++e) a[e] = dot4(u, y[e]);
+            const float sc = eval8_reduce<LPR>(a, sub);
+            cnt += ((sub & (LPR / 8 - 1)) == 0 && sc > s0) ? 1 : 0;
         }
     }
-    for (; c < n_cols; c += G) {
+    for (c += grp; c < n_cols; c += G) {            // the remainder, one candidate per lane group
         RowVec<float>::load(wi + R[c] * D + sub * 4, x);
-        const float s = group_sum<LPR>(dot4(u, x));
-        cnt += (s > s0) ? 1 : 0;
+        const float sc = eval_group_sum<LPR>(dot4(u, x));
+        cnt += (sub == 0 && sc > s0) ? 1 : 0;
     }
-    int tot = (sub == 0) ? cnt : 0;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off, 64);
-    if (lane == 0) rank[r] = tot;
+    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    if (lane == 0) rank[r] = cnt;
 }
 
 // ------------------------------------------------------------------------------------
@@ -809,10 +881,19 @@ __global__ __launch_bounds__(256) void k_eval_bucketize(const int64_t* __restric
     }
 }
 
-// Persistent form: workgroup b serves item range b % 8 (= its XCD) and strides over the groups of four
-// test rows, so the grid can be capped (an evaluation that runs underneath training kernels on a side
-// stream should not flood every CU's wave slots).  The candidate indices are read once: nontemporal,
-// so the stream does not push the item slice (and the neighbours' weights) out of L2.
+// Persistent form: workgroup b serves item range b % 8 (= its XCD); wavefront w of it walks the test rows
+// (b/8 + k * gridDim/8) * 4 + w, k = 0, 1, ...  The grid is capped (an evaluation that runs underneath training
+// kernels on a side stream should not flood every CU's wave slots), so what a wavefront does per row is a chain of
+// dependent memory round trips -- header (bucket bounds, user, positive) -> candidate ids -> item rows -> scores --
+// and with one wavefront per SIMD nothing else hides it.  The loop is therefore software-pipelined on UNITS of 8*G
+// candidates (one trip of the eight-at-a-time reduction):
+//   headers    for 64 rows at a time: lane l fetches the header of row k0 + l, the walk reads them with v_readlane
+//              (scalar control flow; the next 64 headers are in flight while these are consumed);
+//   unit k+2   candidate ids: one coalesced nontemporal load;
+//   unit k+1   ids -> byte offsets through an LDS row of the wavefront -> eight item-row gathers + the user row
+//              (+ the positive's row on a row's first unit) into the idle register buffer;
+//   unit k     scores, exact compare against the positive's score, count by ballot / popcount (scalar).
+// Two register buffers alternate by unrolling the loop twice: no register is copied while its load is in flight.
 template <int D>
 __global__ __launch_bounds__(256) void k_eval_ranks_bucketed(const float* __restrict__ wu, const float* __restrict__ wi,
                                                              const int32_t* __restrict__ rows, const int32_t* __restrict__ bucket_off,
@@ -820,43 +901,146 @@ __global__ __launch_bounds__(256) void k_eval_ranks_bucketed(const float* __rest
     constexpr int LPR = D / 4;
     constexpr int G = 64 / LPR;
     const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int x = blockIdx.x % SML_EVB;                          // this workgroup's item range (= its XCD)
     const int grp = lane / LPR, sub = lane % LPR;
     const int64_t n_groups = (n + 3) / 4;
-    for (int64_t gi = blockIdx.x / SML_EVB; gi < n_groups; gi += gridDim.x / SML_EVB) {
-        const int64_t r = gi * 4 + (threadIdx.x >> 6);
-        if (r >= n) continue;
-        const int32_t* R = rows + r * n_cols;
-        const int c0 = 2 + bucket_off[r * (SML_EVB + 1) + x], c1 = 2 + bucket_off[r * (SML_EVB + 1) + x + 1];
-        if (c0 == c1) continue;
-        float u[4], xr[4];
-        const int32_t pos_item = R[1];
-        RowVec<float>::load(wu + (int64_t)R[0] * D + sub * 4, u);
-        RowVec<float>::load(wi + (int64_t)pos_item * D + sub * 4, xr);
-        const float s0 = group_sum<LPR>(dot4(u, xr));
-        int cnt = 0;
-        constexpr int UD = 4;                  // candidate rows in flight per lane group
-        // predicated full-depth trips (a bucket holds ~n_cols/8 candidates, a lane group ~n_cols/64 of them):
-        // a slot past the bucket's end re-reads the positive's row (cached) and is not counted
-        for (int c = c0 + grp; c < c1; c += UD * G) {
-            float y[UD][4];
-            int32_t id[UD];
-#pragma unroll
-            for (int j = 0; j < UD; ++j) id[j] = (c + j * G < c1) ? __builtin_nontemporal_load(R + c + j * G) : pos_item;
-#pragma unroll
-            for (int j = 0; j < UD; ++j) RowVec<float>::load(wi + (int64_t)id[j] * D + sub * 4, y[j]);
-#pragma unroll
-            for (int j = 0; j < UD; ++j) {
-                const float sc = group_sum<LPR>(dot4(u, y[j]));
-                cnt += (c + j * G < c1 && sc > s0) ? 1 : 0;
+    const int64_t g0 = blockIdx.x / SML_EVB, gstep = gridDim.x / SML_EVB;
+    if constexpr (LPR <= 16) {
+        constexpr int UN = 8 * G;                                // candidates per unit
+        __shared__ uint32_t xch[4][64];
+        const int64_t K = g0 < n_groups ? (n_groups - g0 + gstep - 1) / gstep : 0;     // rows of this wavefront
+        if (K == 0) return;
+        const char* const wib = reinterpret_cast<const char*>(wi);
+        const char* const wub = reinterpret_cast<const char*>(wu);
+
+        struct Hdr { int c0, c1, user, pos; };
+        auto load_headers = [&](int64_t k0) {                    // lane l: row k0 + l of this wavefront's walk
+            const int64_t k = k0 + lane, r = (g0 + k * gstep) * 4 + wv;
+            const bool ok = k < K && r < n;
+            const int64_t rr = ok ? r : 0;
+            Hdr h;
+            h.c0 = 2 + bucket_off[rr * (SML_EVB + 1) + x];
+            h.c1 = 2 + bucket_off[rr * (SML_EVB + 1) + x + 1];
+            h.user = rows[rr * n_cols];
+            h.pos = rows[rr * n_cols + 1];
+            if (!ok) h.c1 = h.c0;
+            return h;
+        };
+        struct Unit { int valid, cb, c1, user, pos, first, last; int64_t r; };
+        // ---- the walk (all scalar): rows in order, each cut into units of UN candidates; empty buckets yield none
+        Hdr hq = load_headers(0), hq_next = load_headers(64);
+        int64_t kb = 0;
+        int j = -1, p = 0, c0 = 0, c1 = 0, user = 0, pos = 0;
+        int64_t r = 0;
+        auto next_unit = [&]() {
+            Unit u;
+            u.valid = 0; u.cb = 0; u.c1 = 0; u.user = 0; u.pos = 0; u.first = 0; u.last = 0; u.r = 0;
+            for (;;) {
+                if (p < c1) {
+                    u.valid = 1; u.cb = p; u.c1 = c1; u.user = user; u.pos = pos; u.first = p == c0; u.r = r;
+                    p += UN;
+                    u.last = p >= c1;
+                    return u;
+                }
+                ++j;
+                if (kb + j >= K) { --j; return u; }
+                if (j == 64) { hq = hq_next; kb += 64; j = 0; hq_next = load_headers(kb + 64); }
+                c0 = __builtin_amdgcn_readlane(hq.c0, j);
+                c1 = __builtin_amdgcn_readlane(hq.c1, j);
+                user = __builtin_amdgcn_readlane(hq.user, j);
+                pos = __builtin_amdgcn_readlane(hq.pos, j);
+                r = (g0 + (kb + j) * gstep) * 4 + wv;
+                p = c0;
             }
-        }
-        int tot = (sub == 0) ? cnt : 0;
+        };
+        auto issue_ids = [&](const Unit& u) -> uint32_t {        // (a slot past the bucket's end re-reads its last candidate)
+            if (!u.valid) return 0u;
+            return (uint32_t)__builtin_nontemporal_load(rows + u.r * n_cols + min(u.cb + lane, u.c1 - 1));
+        };
+        auto issue_rows = [&](const Unit& u, uint32_t id, float (&y)[8][4], float (&uu)[4], float (&xx)[4]) {
+            if (!u.valid) return;
+            xch[wv][lane] = id * (uint32_t)(D * 4);
+            const uint4 o0 = *reinterpret_cast<const uint4*>(&xch[wv][grp * 8]);
+            const uint4 o1 = *reinterpret_cast<const uint4*>(&xch[wv][grp * 8 + 4]);
+            const uint32_t off[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off, 64);
-        if (lane == 0 && tot) atomicAdd(&rank[r], tot);
+            for (int e = 0; e < 8; ++e) RowVec<float>::load(reinterpret_cast<const float*>(wib + (size_t)(off[e] + (uint32_t)(sub * 16))), y[e]);
+            RowVec<float>::load(reinterpret_cast<const float*>(wub + (int64_t)u.user * (D * 4)) + sub * 4, uu);
+            if (u.first) RowVec<float>::load(reinterpret_cast<const float*>(wib + (int64_t)u.pos * (D * 4)) + sub * 4, xx);
+        };
+        float s0 = 0.f;
+        int cnt = 0;
+        auto score = [&](const Unit& u, float (&y)[8][4], float (&uu)[4], float (&xx)[4]) {
+            if (!u.valid) return;
+            if (u.first) s0 = eval_group_sum<LPR>(dot4(uu, xx));
+            float a[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = dot4(uu, y[e]);
+            const float sc = eval8_reduce<LPR>(a, sub);
+            const bool hit = (sub & (LPR / 8 - 1)) == 0 && u.cb + grp * 8 + eval8_index<LPR>(sub) < u.c1 && sc > s0;
+            cnt += __popcll(__ballot(hit));
+            if (u.last) {
+                if (cnt && lane == 0) atomicAdd(&rank[u.r], cnt);
+                cnt = 0;
+            }
+        };
+        float yP[8][4], uP[4], xP[4], yQ[8][4], uQ[4], xQ[4];
+        Unit U0 = next_unit();
+        uint32_t idA = issue_ids(U0);
+        issue_rows(U0, idA, yP, uP, xP);
+        Unit U1 = next_unit();
+        idA = issue_ids(U1);
+        uint32_t idB;
+        while (U0.valid) {
+            // U0's rows are landing in P, U1's ids in idA
+            Unit U2 = next_unit();
+            idB = issue_ids(U2);
+            issue_rows(U1, idA, yQ, uQ, xQ);
+            score(U0, yP, uP, xP);
+            if (!U1.valid) break;
+            // U1's rows are landing in Q, U2's ids in idB
+            Unit U3 = next_unit();
+            idA = issue_ids(U3);
+            issue_rows(U2, idB, yP, uP, xP);
+            score(U1, yQ, uQ, xQ);
+            U0 = U2;
+            U1 = U3;
+        }
+    } else {
+        for (int64_t gi = g0; gi < n_groups; gi += gstep) {
+            const int64_t r = gi * 4 + wv;
+            if (r >= n) continue;
+            const int32_t* R = rows + r * n_cols;
+            const int c0 = 2 + bucket_off[r * (SML_EVB + 1) + x], c1 = 2 + bucket_off[r * (SML_EVB + 1) + x + 1];
+            if (c0 == c1) continue;
+            float u[4], xr[4];
+            const int32_t pos_item = R[1];
+            RowVec<float>::load(wu + (int64_t)R[0] * D + sub * 4, u);
+            RowVec<float>::load(wi + (int64_t)pos_item * D + sub * 4, xr);
+            const float s0 = eval_group_sum<LPR>(dot4(u, xr));
+            int cnt = 0;
+            constexpr int UD = 4;              // candidate rows in flight per lane group
+            for (int c = c0 + grp; c < c1; c += UD * G) {
+                float y[UD][4];
+                int32_t id[UD];
+#pragma unroll
+                for (int j = 0; j < UD; ++j) id[j] = (c + j * G < c1) ? __builtin_nontemporal_load(R + c + j * G) : pos_item;
+#pragma unroll
+                for (int j = 0; j < UD; ++j) RowVec<float>::load(wi + (int64_t)id[j] * D + sub * 4, y[j]);
+#pragma unroll
+                for (int j = 0; j < UD; ++j) {
+                    const float sc = eval_group_sum<LPR>(dot4(u, y[j]));
+                    cnt += (sub == 0 && c + j * G < c1 && sc > s0) ? 1 : 0;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+            if (lane == 0 && cnt) atomicAdd(&rank[r], cnt);
+        }
     }
 }
+
 
 // ------------------------------------------------------------------------------------
 // On-device batch supply (fast mode; the reference-exact numpy stream stays on the host): for every
@@ -1062,9 +1246,10 @@ hipError_t sml_launch_eval_ranks_bucketed(int d, const float* wu, const float* w
                                           hipStream_t st) {
     hipError_t e = hipMemsetAsync(rank, 0, (size_t)n * sizeof(int32_t), st);
     if (e != hipSuccess) return e;
+    // persistent: at most four workgroups per CU (the pipelined walk holds 4 waves per SIMD), fewer on request
     int64_t nb = ((n + 3) / 4) * SML_EVB;
-    if (max_blocks > 0 && nb > max_blocks) nb = (max_blocks / SML_EVB > 0 ? max_blocks / SML_EVB : 1) * SML_EVB;
-    if (nb > 0x7fffffff) nb = 0x7fffff00;
+    const int64_t cap = max_blocks > 0 ? max_blocks : (d <= 64 ? 1024 : 0x7fffff00);
+    if (nb > cap) nb = (cap / SML_EVB > 0 ? cap / SML_EVB : 1) * SML_EVB;
     SML_DISPATCH_D(d, k_eval_ranks_bucketed<DD><<<dim3((unsigned)nb), dim3(256), 0, st>>>(wu, wi, rows_b, bucket_off, n, n_cols, rank));
     return hipGetLastError();
 }

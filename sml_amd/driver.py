@@ -10,6 +10,7 @@ into main_yelp.py / main_news.py; the three hot loops
 are single calls into libsml_hip.so per epoch / per table, with whole-epoch triples
 built by sml_amd.datasets instead of a per-item DataLoader.
 """
+import contextlib
 import copy
 import time
 
@@ -461,7 +462,11 @@ class meta_train(object):
             return False
         self._defer, self._queue = self.writer is None, []
         try:
-            return self._stage_body(args, stage_id, set_t, set_tt, now_test, val)
+            # the training kernels of the stage run on the training partition of the chip, the queued evaluations on
+            # the side stream's own CUs (HipEngine.partition; the CPU test double has no such thing)
+            scope = self.engine.partition() if hasattr(self.engine, "partition") else contextlib.nullcontext()
+            with scope:
+                return self._stage_body(args, stage_id, set_t, set_tt, now_test, val)
         finally:
             self._defer = False
             self._flush_output()

@@ -472,10 +472,73 @@ class HipEngine(object):
     # the current stream -- which may overwrite the tables at once -- run on top of it: the latency-bound
     # training kernels leave most of the chip idle, the evaluation fills it.
     SNAPSHOTS = 3
-    SIDE_EVAL_WORKGROUPS = int(__import__("os").environ.get("SML_SIDE_EVAL_WGS", "256"))   # grid cap of a side-stream evaluation
+    # The chip is PARTITIONED between the two streams: the side stream owns the last SIDE_EVAL_CUS compute units of
+    # the CU mask (mask bit i is a CU of XCD i % 8: a contiguous range takes the same share of every XCD), and the
+    # training loop may run on the rest (`training_stream()`); the evaluation then neither shares SIMD issue slots
+    # nor a CU's L2 port with the latency-bound training kernels.  SML_SIDE_EVAL_CUS=0 falls back to a low-priority
+    # stream over all CUs with a capped grid.
+    SIDE_EVAL_CUS = int(__import__("os").environ.get("SML_SIDE_EVAL_CUS", "-1"))      # -1: a quarter of the chip (64 of 256 CUs)
+    SIDE_EVAL_WORKGROUPS = int(__import__("os").environ.get("SML_SIDE_EVAL_WGS", "0"))   # grid cap of a side-stream evaluation
+
+    def _n_cus(self):
+        return int(torch.cuda.get_device_properties(self.device).multi_processor_count)
+
+    def _side_cus(self):
+        if self.SIDE_EVAL_CUS >= 0:
+            return self.SIDE_EVAL_CUS
+        n = self._n_cus()
+        return (n // 4) // 8 * 8 if n >= 64 else 0       # whole CUs-per-XCD multiples; tiny parts are not partitioned
+
+    _MASKED = {}     # (device index, lo, hi) -> ExternalStream: one pair of hardware queues per process, shared by its engines
+    #                  and never destroyed (torch's allocator and events keep referring to a stream it has seen)
+
+    def _masked_stream(self, lo, hi):
+        key = (self.device.index or 0, int(lo), int(hi))
+        st = HipEngine._MASKED.get(key)
+        if st is None:
+            h = ctypes.c_void_p()
+            check(self.lib.sml_stream_create_cu_range(ctypes.byref(h), key[0], key[1], key[2]), "sml_stream_create_cu_range")
+            st = HipEngine._MASKED[key] = torch.cuda.ExternalStream(h.value, device=self.device)
+        return st
+
+    def training_stream(self):
+        """The stream over the CUs the side stream does NOT own (None when the chip is not partitioned)."""
+        if self._side_cus() <= 0:
+            return None
+        if getattr(self, "_train", None) is None:
+            self._train = self._masked_stream(0, self._n_cus() - self._side_cus())
+        return self._train
+
+    def partition(self):
+        """Context manager: run the enclosed training loop on the training partition (no-op when the chip is not
+        partitioned or SML_TRAIN_PARTITION=0).  The stream is ordered after the current stream on entry and the
+        current stream after it on exit."""
+        import contextlib, os
+
+        @contextlib.contextmanager
+        def scope():
+            ts = self.training_stream() if os.environ.get("SML_TRAIN_PARTITION", "1") != "0" else None
+            if ts is None:
+                yield
+                return
+            outer = torch.cuda.current_stream(self.device)
+            ts.wait_stream(outer)
+            with torch.cuda.stream(ts):
+                yield
+            outer.wait_stream(ts)
+        return scope()
+
+    def _side_eval_cap(self):
+        if self.SIDE_EVAL_WORKGROUPS > 0:
+            return self.SIDE_EVAL_WORKGROUPS
+        return 4 * self._side_cus() if self._side_cus() > 0 else 256
 
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
+            if self._side_cus() > 0:
+                n = self._n_cus()
+                self._side = self._masked_stream(n - self._side_cus(), n)
+                return self._side
             prio = 0
             try:
                 lo, _hi = torch.cuda.Stream.priority_range()
@@ -511,7 +574,7 @@ class HipEngine(object):
         slot["i"].copy_(wi)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            ranks = self.eval_ranks(slot["u"], slot["i"], rows, max_workgroups=self.SIDE_EVAL_WORKGROUPS)
+            ranks = self.eval_ranks(slot["u"], slot["i"], rows, max_workgroups=self._side_eval_cap())
             ev = torch.cuda.Event()
             ev.record(side)
         slot["ev"] = ev

@@ -509,9 +509,11 @@ def test_period_validation_overlap_and_cache_do_not_change_results():
     from sml_amd.period import Hyper, PeriodState, run_period, synth_plan
     hp = Hyper(multi_num=2, MF_batch_size=256, TR_batch_size=64)
     outs = []
-    for overlap in (False, True):
+    for overlap in (False, True, "partitioned"):
         torch.manual_seed(3)
         eng = engine(32, 256)
+        if overlap is True:
+            eng.SIDE_EVAL_CUS = 0                 # one low-priority side stream over all CUs, capped grid
         mf = make_mf(500, 400, 32, device=DEV)
         with torch.no_grad():
             mf.user_laten.weight.mul_(0.3); mf.item_laten.weight.mul_(0.3)
@@ -519,12 +521,19 @@ def test_period_validation_overlap_and_cache_do_not_change_results():
         st = PeriodState(mf, net)
         plan = synth_plan(11, 1500, 500, 400, 49, hp, DEV)
         rec = []
-        run_period(eng, st, plan, hp, record=rec, overlap=overlap)
+        if overlap == "partitioned":              # training kernels on 192 CUs, evaluations on the other 64 (CU-masked streams)
+            assert eng.training_stream() is not None and eng.training_stream().cuda_stream != eng._side_stream().cuda_stream
+            with eng.partition():
+                assert torch.cuda.current_stream().cuda_stream == eng.training_stream().cuda_stream
+                run_period(eng, st, plan, hp, record=rec, overlap=True)
+        else:
+            run_period(eng, st, plan, hp, record=rec, overlap=overlap)
         torch.cuda.synchronize()
         outs.append((rec, mf.user_laten.weight.detach().clone(), eng.adopt(net).clone()))
     assert [r[0] for r in outs[0][0]] == [r[0] for r in outs[1][0]] and len(outs[0][0]) == 8
-    assert outs[0][0] == outs[1][0]
-    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    for o in outs[1:]:
+        assert outs[0][0] == o[0]
+        assert torch.equal(outs[0][1], o[1]) and torch.equal(outs[0][2], o[2])
     # the memoised "before MF" of phase 2 repeats phase 1's "TR epoch" line, as in the reference's log
     assert outs[1][0][4][1:] == outs[1][0][3][1:]
 
@@ -618,7 +627,7 @@ def test_stages_at_wider_tables_vs_oracle(d):
         adam_close(g[4][k], o[4][k], 1e-3, 3)
 
 
-@pytest.mark.parametrize("d,neg,I", [(32, 999, 123000), (64, 99, 50000), (32, 7, 5)])
+@pytest.mark.parametrize("d,neg,I", [(32, 999, 123000), (64, 99, 50000), (32, 7, 5), (128, 333, 3000), (32, 0, 50)])
 def test_blocked_eval_equals_plain_eval(d, neg, I):
     """The L2-blocked evaluation (candidates bucketed by item range, one range per XCD) returns exactly
     the ranks of the plain kernel."""
