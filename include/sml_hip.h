@@ -255,12 +255,25 @@ int sml_eval_prepare(sml_ctx* ctx, const int64_t* rows, int64_t n, int n_cols, i
 int sml_eval_ranks_blocked(sml_ctx* ctx, const float* w_user, const float* w_item, const int32_t* rows_b,
                            const int32_t* bucket_off, int64_t n, int n_cols, int32_t* rank,
                            int max_workgroups, void* stream);
+/* ---- a11: save_MF_weight (model/transfer.py:911-943) and evaluation snapshots ------- */
+/* n <= 4 device-to-device copies (dst[q] <- src[q], bytes[q]; all multiples of 16) in one launch. */
+int sml_copy_tables(int n, void* const* dst, const void* const* src, const int64_t* bytes, void* stream);
+
 /* A HIP stream restricted to the compute units [cu_lo, cu_hi) of the device's CU mask (on MI355X mask bit i is a
  * CU of XCD i % 8, so a contiguous range takes the same number of CUs from every XCD: each range keeps all eight
  * L2s and an eighth of its CUs on each).  Evaluations queued on such a stream run beside the training kernels on
  * CUs of their own instead of sharing SIMDs and L2 ports with them.  The caller owns the stream. */
 int sml_stream_create_cu_range(void** stream, int device, int cu_lo, int cu_hi);
 int sml_stream_destroy(void* stream);
+/* Orders `waiter` after everything queued on `signaler` so far, through a device-scope event (no system fence). */
+int sml_stream_wait_stream(void* waiter, void* signaler);
+/* The same ordering WITHOUT a cross-queue barrier packet: sml_flag_set (a one-thread kernel on the signalling stream,
+ * after the work to be waited for) stores `value` into the device word `flag`; sml_flag_wait (a kernel on the waiting
+ * stream, before the dependent work) polls until *flag >= value.  Values must grow monotonically per flag; the word
+ * starts at 0.  A waiter that is not released within timeout_s stores -1 (which releases every later waiter too) and
+ * returns: the dependent work then runs unordered -- check the word on the host when the results are collected. */
+int sml_flag_set(int32_t* flag, int value, void* stream);
+int sml_flag_wait(int32_t* flag, int value, double timeout_s, void* stream);
 /* hits = #{rank < topk}, ndcg = sum 1/log2(rank+2) over hits; out[0]=hits, out[1]=ndcg (device). */
 int sml_eval_metrics(sml_ctx* ctx, const int32_t* rank, int64_t n, int topk, float* out, void* stream);
 

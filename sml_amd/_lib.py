@@ -84,6 +84,10 @@ SIGNATURES = {
                                               c_void]),
     "sml_stream_create_cu_range": (ctypes.c_int, [ctypes.POINTER(c_void), ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "sml_stream_destroy": (ctypes.c_int, [c_void]),
+    "sml_stream_wait_stream": (ctypes.c_int, [c_void, c_void]),
+    "sml_copy_tables": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(c_void), ctypes.POINTER(c_void), ctypes.POINTER(ctypes.c_int64), c_void]),
+    "sml_flag_set": (ctypes.c_int, [c_void, ctypes.c_int, c_void]),
+    "sml_flag_wait": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_double, c_void]),
     "sml_comm_load": (ctypes.c_int, [ctypes.c_char_p]),
     "sml_comm_unique_id": (ctypes.c_int, [c_void]),
     "sml_comm_init": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void]),

@@ -1053,6 +1053,41 @@ int sml_stream_create_cu_range(void** stream, int device, int cu_lo, int cu_hi) 
     *stream = st;
     return SML_OK;
 }
+int sml_stream_wait_stream(void* waiter, void* signaler) {
+    // work queued on `waiter` after this call starts after everything queued on `signaler` so far.  The event is
+    // device-scope (no system fence: nothing on the host reads what the signaler wrote) -- a default event makes the
+    // signalling stream write back and invalidate the L2s for the host's benefit
+    static const unsigned flags = getenv("SML_EVENT_FLAGS") ? (unsigned)strtoul(getenv("SML_EVENT_FLAGS"), nullptr, 0)
+                                                            : (hipEventDisableTiming | hipEventDisableSystemFence);
+    hipEvent_t ev;
+    HIPCHK(hipEventCreateWithFlags(&ev, flags));
+    hipError_t e = hipEventRecord(ev, (hipStream_t)signaler);
+    if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)waiter, ev, 0);
+    (void)hipEventDestroy(ev);                   // released once it has completed
+    if (e != hipSuccess) return fail(SML_EHIP, "sml_stream_wait_stream", hipGetErrorString(e));
+    return SML_OK;
+}
+int sml_copy_tables(int n, void* const* dst, const void* const* src, const int64_t* bytes, void* stream) {
+    if (n < 0 || n > 4 || (n && (!dst || !src || !bytes))) return fail(SML_EINVAL, "sml_copy_tables", "1..4 copies per call");
+    long long b[4] = {0, 0, 0, 0};
+    for (int q = 0; q < n; ++q) {
+        if (!dst[q] || !src[q] || bytes[q] < 0 || bytes[q] % 16 || ((uintptr_t)dst[q] | (uintptr_t)src[q]) % 16)
+            return fail(SML_EINVAL, "sml_copy_tables", "pointers and sizes must be multiples of 16 bytes");
+        b[q] = bytes[q];
+    }
+    HIPCHK(sml_launch_copy_tables(n, dst, src, b, (hipStream_t)stream));
+    return SML_OK;
+}
+int sml_flag_set(int32_t* flag, int value, void* stream) {
+    if (!flag || value < 0) return fail(SML_EINVAL, "sml_flag_set", "bad argument");
+    HIPCHK(sml_launch_flag_set(flag, value, (hipStream_t)stream));
+    return SML_OK;
+}
+int sml_flag_wait(int32_t* flag, int value, double timeout_s, void* stream) {
+    if (!flag || value < 0 || !(timeout_s > 0)) return fail(SML_EINVAL, "sml_flag_wait", "bad argument");
+    HIPCHK(sml_launch_flag_wait(flag, value, (long long)(timeout_s * 1e8), (hipStream_t)stream));   // wall_clock64: 100 MHz
+    return SML_OK;
+}
 int sml_stream_destroy(void* stream) {
     if (stream) HIPCHK(hipStreamDestroy((hipStream_t)stream));
     return SML_OK;

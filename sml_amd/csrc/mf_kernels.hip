@@ -1241,6 +1241,58 @@ hipError_t sml_launch_eval_bucketize(const int64_t* rows, int64_t n, int n_cols,
     k_eval_bucketize<<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st>>>(rows, n, n_cols, n_item, rows_out, bucket_off);
     return hipGetLastError();
 }
+// a11 save_MF_weight / evaluation snapshots: up to four table copies in ONE launch (a hipMemcpyAsync per table costs
+// a blit launch plus the runtime's bookkeeping around it, ~30 us of stream time each at these sizes)
+struct SmlCopyJobs { f32x4* dst[4]; const f32x4* src[4]; long long n16[4]; int n_jobs; };
+__global__ __launch_bounds__(256) void k_copy_tables(SmlCopyJobs j) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (int q = 0; q < j.n_jobs; ++q) {
+        f32x4* __restrict__ d = j.dst[q];
+        const f32x4* __restrict__ s = j.src[q];
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < j.n16[q]; i += stride)
+            __builtin_nontemporal_store(__builtin_nontemporal_load(s + i), d + i);
+    }
+}
+hipError_t sml_launch_copy_tables(int n_jobs, void* const* dst, const void* const* src, const long long* bytes, hipStream_t st) {
+    SmlCopyJobs j;
+    long long most = 0;
+    j.n_jobs = n_jobs;
+    for (int q = 0; q < 4; ++q) {
+        j.dst[q] = q < n_jobs ? reinterpret_cast<f32x4*>(dst[q]) : nullptr;
+        j.src[q] = q < n_jobs ? reinterpret_cast<const f32x4*>(src[q]) : nullptr;
+        j.n16[q] = q < n_jobs ? bytes[q] / 16 : 0;
+        if (j.n16[q] > most) most = j.n16[q];
+    }
+    if (most == 0) return hipSuccess;
+    long long nb = (most + 1023) / 1024;            // four 16-byte chunks per thread and table
+    if (nb > 4096) nb = 4096;
+    k_copy_tables<<<dim3((unsigned)nb), dim3(256), 0, st>>>(j);
+    return hipGetLastError();
+}
+
+// Device-side ordering between two streams without a cross-queue barrier packet: the signalling stream runs
+// k_flag_set after the work to be waited for (in-order queue: that work is complete and released when the kernel
+// starts), the waiting stream runs k_flag_wait before its dependent kernels (their start-of-kernel acquire then sees
+// the data).  One lane polls a system-scope word; a waiter gives up after `timeout` 100-MHz ticks and poisons the word.
+__global__ void k_flag_set(int* flag, int value) { __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__global__ void k_flag_wait(int* flag, int value, long long timeout) {
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    for (;;) {
+        const int v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (v >= value || v < 0) return;
+        if (wall_clock64() - t0 > timeout) { __hip_atomic_store(flag, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return; }
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+hipError_t sml_launch_flag_set(int* flag, int value, hipStream_t st) {
+    k_flag_set<<<dim3(1), dim3(1), 0, st>>>(flag, value);
+    return hipGetLastError();
+}
+hipError_t sml_launch_flag_wait(int* flag, int value, long long timeout_ticks, hipStream_t st) {
+    k_flag_wait<<<dim3(1), dim3(64), 0, st>>>(flag, value, timeout_ticks);
+    return hipGetLastError();
+}
 hipError_t sml_launch_eval_ranks_bucketed(int d, const float* wu, const float* wi, const int32_t* rows_b,
                                           const int32_t* bucket_off, int64_t n, int n_cols, int32_t* rank, int max_blocks,
                                           hipStream_t st) {

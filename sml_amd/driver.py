@@ -522,14 +522,12 @@ class meta_train(object):
     def save_MF_weight(self, save_as="last"):
         """'last': W_{t-1} <- W.  'hat': previous W_hat <- W_hat; W_hat <- W.  (model/transfer.py:911-943)"""
         wu, wi = self.MFbase.user_laten.weight.data, self.MFbase.item_laten.weight.data
+        copy = getattr(self.engine, "copy_tables", None) or (lambda pairs: [d.copy_(s) for d, s in pairs])
         if save_as == "last":
-            self.last_user_weight.copy_(wu)
-            self.last_item_weight.copy_(wi)
+            copy([(self.last_user_weight, wu), (self.last_item_weight, wi)])
         elif save_as == "hat":
-            self.last_user_weight_hat.copy_(self.user_weight_hat)
-            self.last_item_weight_hat.copy_(self.item_weight_hat)
-            self.user_weight_hat.copy_(wu)
-            self.item_weight_hat.copy_(wi)
+            copy([(self.last_user_weight_hat, self.user_weight_hat), (self.last_item_weight_hat, self.item_weight_hat)])
+            copy([(self.user_weight_hat, wu), (self.item_weight_hat, wi)])       # (own launch: reads what the first wrote from)
         else:
             raise TypeError("save MFbase weight type is wrong")
 

@@ -551,6 +551,24 @@ class HipEngine(object):
                 self._side = torch.cuda.Stream(device=self.device)
         return self._side
 
+    def copy_tables(self, pairs):
+        """dst.copy_(src) for up to four (dst, src) pairs of same-shaped contiguous fp32 device tensors, in ONE launch
+        on the current stream (save_MF_weight, model/transfer.py:911-943; evaluation snapshots).  The copies of one
+        call run concurrently: no dst may be another pair's src."""
+        pairs = list(pairs)
+        for k in range(0, len(pairs), 4):
+            chunk = pairs[k:k + 4]
+            n = len(chunk)
+            dst, src, nbytes = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_int64 * n)()
+            for q, (d, s) in enumerate(chunk):
+                if d.shape != s.shape or d.dtype != s.dtype or not (d.is_contiguous() and s.is_contiguous()) \
+                        or (d.numel() * d.element_size()) % 16 or d.data_ptr() % 16 or s.data_ptr() % 16:
+                    d.copy_(s)                    # odd shapes: torch's copy
+                    dst[q], src[q], nbytes[q] = d.data_ptr(), d.data_ptr(), 0
+                    continue
+                dst[q], src[q], nbytes[q] = d.data_ptr(), s.data_ptr(), d.numel() * d.element_size()
+            check(self.lib.sml_copy_tables(n, dst, src, nbytes, self._stream()), "sml_copy_tables")
+
     def eval_submit(self, user_tab, item_tab, rows):
         """Queue the ranks of `rows` under the tables AS THEY ARE NOW (at this point of the current stream)
         and return a handle; the caller may modify the tables right away."""
@@ -570,9 +588,22 @@ class HipEngine(object):
             slot["u"] = torch.empty_like(wu)
         if slot["i"] is None or slot["i"].shape != wi.shape:
             slot["i"] = torch.empty_like(wi)
-        slot["u"].copy_(wu)
-        slot["i"].copy_(wi)
-        side.wait_stream(cur)
+        self.copy_tables([(slot["u"], wu), (slot["i"], wi)])
+        # the side stream may start on the snapshot once the copies are done.  Device-side ordering (a flag kernel
+        # behind the copies, a polling kernel ahead of the rank kernel) instead of an event: a cross-queue barrier
+        # packet cost the training stream 2-4 ms per period (31 of them), the two tiny kernels cost nothing measurable
+        mode = __import__("os").environ.get("SML_SIDE_SYNC", "flag")
+        if mode == "event":
+            check(self.lib.sml_stream_wait_stream(ctypes.c_void_p(side.cuda_stream), ctypes.c_void_p(cur.cuda_stream)),
+                  "sml_stream_wait_stream")
+        else:
+            if getattr(self, "_sync_flag", None) is None:
+                self._sync_flag = torch.zeros(1, device=self.device, dtype=torch.int32)
+                self._sync_seq = 0
+            self._sync_seq += 1
+            check(self.lib.sml_flag_set(_ptr(self._sync_flag), self._sync_seq, ctypes.c_void_p(cur.cuda_stream)), "sml_flag_set")
+            check(self.lib.sml_flag_wait(_ptr(self._sync_flag), self._sync_seq, 20.0, ctypes.c_void_p(side.cuda_stream)),
+                  "sml_flag_wait")
         with torch.cuda.stream(side):
             ranks = self.eval_ranks(slot["u"], slot["i"], rows, max_workgroups=self._side_eval_cap())
             ev = torch.cuda.Event()
@@ -596,6 +627,9 @@ class HipEngine(object):
         """Wait (host) for an eval_metrics_submit result: (hits, ndcg_sum)."""
         out, ev = pending[0], pending[1]
         ev.synchronize()
+        flag = getattr(self, "_sync_flag", None)
+        if flag is not None and int(flag.item()) < 0:
+            raise RuntimeError("a side-stream evaluation gave up waiting for its table snapshot (sml_flag_wait timeout)")
         h = out.cpu()
         return float(h[0]), float(h[1])
 

@@ -131,8 +131,8 @@ def run_period(engine, st, plan, hp, record=None, overlap=True):
         state["version"] += 1
 
     # save_MF_weight('last')
-    st.last_user.copy_(wu)
-    st.last_item.copy_(wi)
+    copy = engine.copy_tables if hasattr(engine, "copy_tables") else (lambda pairs: [d.copy_(s) for d, s in pairs])
+    copy([(st.last_user, wu), (st.last_item, wi)])
     mf_loss = tr_loss = None
     for ph in range(hp.multi_num):
         evaluate("before MF")
@@ -143,10 +143,8 @@ def run_period(engine, st, plan, hp, record=None, overlap=True):
             state["version"] += 1
             evaluate("MF epoch")
         # save_MF_weight('hat')
-        st.prev_hat_user.copy_(st.hat_user)
-        st.prev_hat_item.copy_(st.hat_item)
-        st.hat_user.copy_(wu)
-        st.hat_item.copy_(wi)
+        copy([(st.prev_hat_user, st.hat_user), (st.prev_hat_item, st.hat_item)])
+        copy([(st.hat_user, wu), (st.hat_item, wi)])
         updata()
         evaluate("before TR")
         for tri in plan.tr_triples[ph]:

@@ -12,12 +12,12 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ
   f=$(find /tmp/pmcout -name "*counter_collection.csv" | head -1)
   [ -z "$f" ] && { echo "no counters for: $grp"; tail -3 /tmp/pmc.log; continue; }
   python3 - "$f" "$K" <<'PY'
-import csv, sys, collections
+import csv, sys, collections, re
 acc = collections.defaultdict(lambda: [0, 0.0])
 for r in csv.DictReader(open(sys.argv[1])):
     if sys.argv[2] in r["Kernel_Name"]:
-        a = acc[r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
-for k, (c, v) in sorted(acc.items()):
-    print("%-26s launches %4d  avg %.4g" % (k, c, v / c))
+        a = acc[((re.search(r"k_\w+(<[^>]*>)?", r["Kernel_Name"]) or re.search(r".{1,40}", r["Kernel_Name"])).group(0), r["Counter_Name"])]; a[0] += 1; a[1] += float(r["Counter_Value"])
+for (kn, k), (c, v) in sorted(acc.items()):
+    print("%-46s %-24s launches %5d  avg %.4g" % (kn, k, c, v / c))
 PY
 done
