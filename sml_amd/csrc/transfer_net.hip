@@ -66,6 +66,10 @@ __device__ __forceinline__ void ring_preload(f32x4 (&ring)[PFD][NT], const f32x4
     for (int i = 0; i < PFD; ++i)
 #pragma unroll
         for (int t = 0; t < NT; ++t) ring[i][t] = bimg[(tile_of(t) * ksteps_total + ks0 + kofs(t) + i) * 64 + lane];
+    // the ring IS the prefetch distance: without this the scheduler sinks most of these loads in between the
+    // products (seen in the ISA: one or two operand loads in flight per wave instead of PFD * NT), and a
+    // workgroup's weight stream runs at a tenth of its CU's L2 port.  (VALU, SALU and LDS may still cross.)
+    __builtin_amdgcn_sched_barrier(0x86);
 }
 
 template <int MT, int NT, int NK, int PFD, bool SPLITK, typename TileOf, typename KOfs>
@@ -93,6 +97,7 @@ __device__ __forceinline__ void mma16_ring(f32x4 (&acc)[MT][NT], f32x4 (&ring)[P
             for (int t = 0; t < NT; ++t)
                 ring[slot][t] = bimg[(tile_of(t) * ksteps_total + ks0 + kofs(t) + ks + PFD) * 64 + lane];
         }
+        __builtin_amdgcn_sched_barrier(0x86);      // refills stay behind their step's products, ahead of the next step's
     };
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
@@ -143,7 +148,7 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // at the head of k_transfer_bwd) adds the NS planes in index order: deterministic, no atomics.
 // ------------------------------------------------------------------------------------
 template <int D, int MT, int NS>
-__global__ __launch_bounds__(512) void k_transfer_fwd(SmlFwdArgs a) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_transfer_fwd(SmlFwdArgs a) {
     constexpr int R = SML_TM * MT;
     constexpr int K1 = SML_C2 * D;       // fc1 reduction length
     constexpr int HL = SML_HID / NS;     // hidden units of this workgroup
@@ -206,6 +211,15 @@ __global__ __launch_bounds__(512) void k_transfer_fwd(SmlFwdArgs a) {
     if constexpr (PRE) {
         ring_preload<2, 5>(ringf1, img1, KS1, 0, lane, t1, k1);
         ring_preload<JTW, PF2>(ringf2, img2, 32, h * KL + kq * KPW, lane, t2, nokofs);
+    }
+    // Unsplit training form (MF stage: one workgroup per row tile, CT column tiles per wave): the first five k-steps of
+    // all CT tiles and the wave's fc2 share are fetched here as well, under the gather / lazy-Adam replay / prologue
+    constexpr bool PREW = false && (MT == 1) && (CT >= 2) && (D <= 64);   // measured: 41.3 -> 42.9 us per MF step with it (the early operand loads compete with the gather that heads the chain)
+    auto tw = [tile0](int t) { return tile0 + t; };
+    f32x4 ringw1[PREW ? 5 : 1][CT], ringw2[PREW ? PF2 : 1][JTW];
+    if constexpr (PREW) {
+        ring_preload<CT, 5>(ringw1, img1, KS1, 0, lane, tw, nokofs);
+        ring_preload<JTW, PF2>(ringw2, img2, 32, h * KL + kq * KPW, lane, t2, nokofs);
     }
     float bias1[CT];
 #pragma unroll
@@ -313,8 +327,9 @@ __global__ __launch_bounds__(512) void k_transfer_fwd(SmlFwdArgs a) {
         if constexpr (CT >= 2) {
             f32x4 acc[MT][CT];
             zero_acc(acc);
-            mma16_rows<MT, CT, KS1, (MT == 1 ? 5 : 2)>(acc, A1s + l15 * S1 + 4 * g4, SML_TM * S1, img, KS1, 0, lane,
-                                                      [tile0](int t) { return tile0 + t; });
+            if constexpr (PREW) mma16_ring<MT, CT, KS1, 5, false>(acc, ringw1, A1s + l15 * S1 + 4 * g4, SML_TM * S1, img, KS1, 0, lane, tw, nokofs);
+            else mma16_rows<MT, CT, KS1, (MT == 1 ? 5 : 2)>(acc, A1s + l15 * S1 + 4 * g4, SML_TM * S1, img, KS1, 0, lane,
+                                                           [tile0](int t) { return tile0 + t; });
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -359,6 +374,8 @@ __global__ __launch_bounds__(512) void k_transfer_fwd(SmlFwdArgs a) {
         // the operand image is indexed by the global k-step, the LDS tile by the local one
         if constexpr (PRE) mma16_ring<MT, JTW, KPW, PF2, false>(acc, ringf2, a2s + l15 * S2 + 4 * g4 - h * HL, SML_TM * S2, img2, 32,
                                                                 h * KL + kq * KPW, lane, t2, nokofs);
+        else if constexpr (PREW) mma16_ring<MT, JTW, KPW, PF2, false>(acc, ringw2, a2s + l15 * S2 + 4 * g4 - h * HL, SML_TM * S2, img2, 32,
+                                                                      h * KL + kq * KPW, lane, t2, nokofs);
         else mma16_rows<MT, JTW, KPW, PF2>(acc, a2s + l15 * S2 + 4 * g4 - h * HL, SML_TM * S2, img2, 32, h * KL + kq * KPW, lane, t2);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -407,7 +424,7 @@ __global__ __launch_bounds__(512) void k_transfer_fwd(SmlFwdArgs a) {
 // conv-grad partials.  dx / dz1 scratch is padded to whole tiles (unconditional stores).
 // ------------------------------------------------------------------------------------
 template <int D, int MT, bool TR>
-__global__ __launch_bounds__(512) void k_transfer_bwd_full(SmlBwdArgs a) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_transfer_bwd_full(SmlBwdArgs a) {
     constexpr int R = SML_TM * MT;
     constexpr int K1 = SML_C2 * D;
     constexpr int S2 = SML_HID + 4;
@@ -436,6 +453,18 @@ __global__ __launch_bounds__(512) void k_transfer_bwd_full(SmlBwdArgs a) {
     const SmlBwdSeg& sg = a.seg[sidx];
     const int row0 = ((int)blockIdx.x - (sidx ? a.tiles0 : 0)) * R;
     if (tid < 104) cws[tid] = sg.theta[tid];
+    // both GEMMs' first operand k-steps are on their way before the pair loss starts (they depend on theta alone)
+    constexpr bool PREB = false && (MT == 1) && (D <= 64);                // (same measurement: no gain)
+    const f32x4* __restrict__ p2b = reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p2b(D));
+    const f32x4* __restrict__ p1b = reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p1b(D));
+    auto tileA2 = [wv](int t) { return wv * 4 + t; };
+    auto tileA1 = [wv](int t) { return (wv / KSPL) * 5 + t; };
+    auto nokofs = [](int) { return 0; };
+    f32x4 ringb2[PREB ? KSD : 1][4], ringb1[PREB ? 4 : 1][5];
+    if constexpr (PREB) {
+        ring_preload<4, KSD>(ringb2, p2b, KSD, 0, lane, tileA2, nokofs);
+        ring_preload<5, 4>(ringb1, p1b, 32, (wv % KSPL) * KPER, lane, tileA1, nokofs);
+    }
 
     // ---- pair loss (model/conv_transfer.py:120-134) for this tile's rows: every row fetches the three
     // transferred rows of its triple, one thread per row forms the two scores and the loss terms,
@@ -528,9 +557,8 @@ __global__ __launch_bounds__(512) void k_transfer_bwd_full(SmlBwdArgs a) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     z[mt][t][q] = sg.z1[(int64_t)(row0 + mt * SML_TM + 4 * g4 + q) * SML_HID + (wv * 4 + t) * 16 + l15];
-        mma16_rows<MT, 4, KSD, KSD>(acc, dOs + l15 * SD + 4 * g4, SML_TM * SD,
-                                    reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p2b(D)), KSD, 0, lane,
-                                    [wv](int t) { return wv * 4 + t; });
+        if constexpr (PREB) mma16_ring<MT, 4, KSD, KSD, false>(acc, ringb2, dOs + l15 * SD + 4 * g4, SML_TM * SD, p2b, KSD, 0, lane, tileA2, nokofs);
+        else mma16_rows<MT, 4, KSD, KSD>(acc, dOs + l15 * SD + 4 * g4, SML_TM * SD, p2b, KSD, 0, lane, tileA2);
         float* dz1 = sg.dz1;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -552,9 +580,9 @@ __global__ __launch_bounds__(512) void k_transfer_bwd_full(SmlBwdArgs a) {
         const int kq = wv % KSPL, tq = wv / KSPL;
         f32x4 acc[MT][5];
         zero_acc(acc);
-        mma16_rows<MT, 5, KPER, 4>(acc, dZs + l15 * S2 + 4 * g4, SML_TM * S2,
-                                   reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p1b(D)), 32, kq * KPER, lane,
-                                   [tq](int t) { return tq * 5 + t; });
+        if constexpr (PREB) mma16_ring<MT, 5, KPER, 4, false>(acc, ringb1, dZs + l15 * S2 + 4 * g4, SML_TM * S2, p1b, 32, kq * KPER, lane, tileA1, nokofs);
+        else mma16_rows<MT, 5, KPER, 4>(acc, dZs + l15 * S2 + 4 * g4, SML_TM * S2, p1b, 32, kq * KPER, lane,
+                                        [tq](int t) { return tq * 5 + t; });
         __syncthreads();                        // every wave is done reading dZs
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
