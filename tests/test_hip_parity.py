@@ -1261,3 +1261,48 @@ def test_bare_step_exchange_on_a_one_rank_rccl_group_equals_the_plain_step():
     np.testing.assert_allclose(lb, la, rtol=1e-6)
     close(b_u.cpu().numpy(), a_u.cpu().numpy(), 1e-5)
     close(b_i.cpu().numpy(), a_i.cpu().numpy(), 1e-5)
+
+
+def test_copy_tables_one_launch_and_odd_shapes():
+    """sml_copy_tables (save_MF_weight / evaluation snapshots): up to four copies per launch, more in several
+    launches, odd sizes through torch's copy; every destination equals its source and nothing else moves."""
+    eng = engine(32, 64)
+    torch.manual_seed(5)
+    shapes = [(60000, 32), (123000, 32), (7, 32), (1000, 64), (3, 5), (1, 4)]
+    src = [torch.randn(s, device=DEV) for s in shapes]
+    dst = [torch.full(s, -1.0, device=DEV) for s in shapes]
+    guard = torch.full((1024,), 7.0, device=DEV)
+    eng.copy_tables(list(zip(dst, src)))
+    torch.cuda.synchronize()
+    for d_, s_ in zip(dst, src):
+        assert torch.equal(d_, s_)
+    assert torch.all(guard == 7.0)
+
+
+def test_stream_partition_runs_on_disjoint_cus_and_flag_ordering_holds():
+    """The two CU-masked streams exist, are distinct, and work queued behind sml_flag_wait on one of them sees what
+    was written before sml_flag_set on the other (the evaluation hand-off); a waiter nobody releases gives up."""
+    import ctypes
+    eng = engine(32, 64)
+    train, side = eng.training_stream(), eng._side_stream()
+    assert train is not None and train.cuda_stream != side.cuda_stream
+    lib = eng.lib
+    flag = torch.zeros(1, device=DEV, dtype=torch.int32)
+    a = torch.zeros(1 << 22, device=DEV)
+    out = torch.empty_like(a)
+    torch.cuda.synchronize()
+    for it in range(1, 6):
+        with torch.cuda.stream(side):                       # the consumer is queued FIRST: it must wait on the device
+            assert lib.sml_flag_wait(ctypes.c_void_p(flag.data_ptr()), it, 10.0, ctypes.c_void_p(side.cuda_stream)) == 0
+            out.copy_(a)
+            got = out.sum()
+        with torch.cuda.stream(train):
+            a.fill_(float(it))
+            assert lib.sml_flag_set(ctypes.c_void_p(flag.data_ptr()), it, ctypes.c_void_p(train.cuda_stream)) == 0
+        torch.cuda.synchronize()
+        assert float(got) == float(it) * a.numel()
+    assert int(flag.item()) == 5
+    with torch.cuda.stream(side):                           # never released: gives up after 0.05 s and poisons the word
+        assert lib.sml_flag_wait(ctypes.c_void_p(flag.data_ptr()), 99, 0.05, ctypes.c_void_p(side.cuda_stream)) == 0
+    torch.cuda.synchronize()
+    assert int(flag.item()) == -1
