@@ -1274,7 +1274,10 @@ hipError_t sml_launch_copy_tables(int n_jobs, void* const* dst, const void* cons
 // k_flag_set after the work to be waited for (in-order queue: that work is complete and released when the kernel
 // starts), the waiting stream runs k_flag_wait before its dependent kernels (their start-of-kernel acquire then sees
 // the data).  One lane polls a system-scope word; a waiter gives up after `timeout` 100-MHz ticks and poisons the word.
-__global__ void k_flag_set(int* flag, int value) { __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__global__ void k_flag_set(int* flag, int value) {          // (a poisoned word stays poisoned: the host finds it when it collects results)
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= 0)
+        __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __global__ void k_flag_wait(int* flag, int value, long long timeout) {
     if (threadIdx.x != 0) return;
     const long long t0 = wall_clock64();

@@ -602,7 +602,7 @@ class HipEngine(object):
                 self._sync_seq = 0
             self._sync_seq += 1
             check(self.lib.sml_flag_set(_ptr(self._sync_flag), self._sync_seq, ctypes.c_void_p(cur.cuda_stream)), "sml_flag_set")
-            check(self.lib.sml_flag_wait(_ptr(self._sync_flag), self._sync_seq, 20.0, ctypes.c_void_p(side.cuda_stream)),
+            check(self.lib.sml_flag_wait(_ptr(self._sync_flag), self._sync_seq, 5.0, ctypes.c_void_p(side.cuda_stream)),
                   "sml_flag_wait")
         with torch.cuda.stream(side):
             ranks = self.eval_ranks(slot["u"], slot["i"], rows, max_workgroups=self._side_eval_cap())
