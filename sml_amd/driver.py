@@ -12,6 +12,8 @@ built by sml_amd.datasets instead of a per-item DataLoader.
 """
 import contextlib
 import copy
+import io
+import sys
 import time
 
 import numpy as np
@@ -164,7 +166,29 @@ class meta_train(object):
 
     # ------------------------------------------------------------------ helpers
     def get_next_data(self, stage_id):
+        pre, self._next_data = getattr(self, "_next_data", None), None
+        if pre is not None and pre[0] == stage_id:
+            sys.stdout.write(pre[1])          # the loader's lines, where the reference prints them
+            return pre[2]
         return self.dataset.next_train(stage_id)
+
+    def _prefetch_next(self, stage_id):
+        """Load period `stage_id` and upload its test rows NOW -- called when a stage's kernels are all queued and
+        the host would otherwise just wait for the device: the next stage then starts with its rows resident
+        (the upload of 0.6 GB of validation rows is 13 ms during which the device used to have nothing queued).
+        The period loader draws no random numbers, so loading early does not move the run's random streams; its
+        prints are captured and replayed by get_next_data at the point the reference prints them."""
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            data = self.dataset.next_train(stage_id)
+        self._next_data = (stage_id, buf.getvalue(), data)
+        self._uploading = True                # (on a stream of its own: the queued kernels keep running meanwhile)
+        try:
+            for arr in (data[3], data[2]):
+                if arr is not None:
+                    self._rows(arr)
+        finally:
+            self._uploading = False
 
     def _rows(self, arr):
         """Device-resident copy of a test array (cached per array object)."""
@@ -175,7 +199,10 @@ class meta_train(object):
                 self._rows_cache.clear()
                 self._rank_cache = None        # its rows object went with the entries above
             local = arr if self.dist is None else self.dist.route_rows(arr, self.n_user_global)
-            rows = DeviceRows(local, self.device)
+            up = None
+            if getattr(self, "_uploading", False) and torch.device(self.device).type == "cuda":
+                up = self.__dict__.get("_upload_stream") or self.__dict__.setdefault("_upload_stream", torch.cuda.Stream(device=self.device))
+            rows = DeviceRows(local, self.device, stream=up)
             rows.n_global = int(np.asarray(arr).shape[0])      # recall / ndcg are over ALL rows of the set
             hit = (arr, rows)
             self._rows_cache[key] = hit
@@ -194,6 +221,8 @@ class meta_train(object):
         hit = getattr(self, "_rank_cache", None)
         if hit is None or hit[0][0] is not rows or hit[0][1] != key[1]:
             wu, wi = self.MFbase.user_laten.weight.data, self.MFbase.item_laten.weight.data
+            if hasattr(rows, "wait_ready"):
+                rows.wait_ready()               # rows uploaded ahead of their stage (_prefetch_next)
             if hasattr(self.engine, "eval_submit"):
                 ranks = self.engine.eval_submit(wu, wi, rows.rows)
             else:
@@ -260,8 +289,6 @@ class meta_train(object):
         """SampleDaset(arr), built once per array (it holds no state that changes between epochs; the
         reference rebuilds it every phase).  Its constructor's "user max:" lines are replayed on every
         call, in order with the rest of the (possibly deferred) output."""
-        import contextlib
-        import io
         hit = getattr(self, "_sample_cache", None)
         if hit is None or hit[0] is not arr:
             buf = io.StringIO()
@@ -466,7 +493,10 @@ class meta_train(object):
             # the side stream's own CUs (HipEngine.partition; the CPU test double has no such thing)
             scope = self.engine.partition() if hasattr(self.engine, "partition") else contextlib.nullcontext()
             with scope:
-                return self._stage_body(args, stage_id, set_t, set_tt, now_test, val)
+                more = self._stage_body(args, stage_id, set_t, set_tt, now_test, val)
+            if more and getattr(self, "_prefetch", False):
+                self._prefetch_next(stage_id + 1)
+            return more
         finally:
             self._defer = False
             self._flush_output()
@@ -542,8 +572,10 @@ class meta_train(object):
     def run(self, args):
         """All periods, then the weighted averages (reference model/transfer.py:965-1029)."""
         pass_num = args.pass_num
+        self._prefetch = True                 # consecutive stages: each one loads its successor's data while it drains
         for pass_id in range(pass_num):
             stage_id = 0
+            self._next_data = None
             self.dataset.reinit()
             while True:
                 if self.train_one_stage3(args, stage_id):

@@ -12,10 +12,25 @@ class DeviceRows(object):
     Iterating it makes the one global-RNG draw a DataLoader iteration makes, so a run's
     random stream stays aligned with the reference's."""
 
-    def __init__(self, rows, device):
+    def __init__(self, rows, device, stream=None):
         if isinstance(rows, np.ndarray):
             rows = torch.from_numpy(np.ascontiguousarray(rows))
-        self.rows = rows.to(device=device, dtype=torch.int64).contiguous()
+        self.ready = None
+        if stream is None:
+            self.rows = rows.to(device=device, dtype=torch.int64).contiguous()
+        else:
+            # upload on a stream of its own (a copy on the default stream would first wait for every queued kernel);
+            # the first consumer orders itself behind `ready` (wait_ready)
+            with torch.cuda.stream(stream):
+                self.rows = rows.to(device=device, dtype=torch.int64).contiguous()
+                self.ready = torch.cuda.Event()
+                self.ready.record(stream)
+
+    def wait_ready(self):
+        """Order the current stream behind the upload (once)."""
+        if self.ready is not None:
+            torch.cuda.current_stream(self.rows.device).wait_event(self.ready)
+            self.ready = None
 
     def __len__(self):
         return 1

@@ -55,6 +55,7 @@ def main():
     if profile:
         import cProfile
         prof = cProfile.Profile()
+    meta._prefetch = os.environ.get("SML_PREFETCH", "1") != "0"      # as meta_train.run does
     for s in range(n_stage):
         if prof is not None and s == n_stage - 1:
             prof.enable()
