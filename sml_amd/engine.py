@@ -466,11 +466,10 @@ class HipEngine(object):
                   "sml_eval_ranks")
         return rank
 
-    # Evaluations never sit on the training stream.  eval_submit copies the two tables into a snapshot
-    # (a device copy of a few tens of MB, microseconds) on the CURRENT stream and queues the rank pass
-    # over the snapshot on the engine's low-priority side stream, so the training kernels that follow on
-    # the current stream -- which may overwrite the tables at once -- run on top of it: the latency-bound
-    # training kernels leave most of the chip idle, the evaluation fills it.
+    # Evaluations never sit on the training stream.  eval_submit copies the two tables into a snapshot (one copy
+    # kernel, a few tens of MB) on the CURRENT stream and queues the rank pass over the snapshot on the engine's side
+    # stream; the training kernels that follow on the current stream -- which may overwrite the tables at once -- do
+    # not wait for it.
     SNAPSHOTS = 3
     # The chip is PARTITIONED between the two streams: the side stream owns the last SIDE_EVAL_CUS compute units of
     # the CU mask (mask bit i is a CU of XCD i % 8: a contiguous range takes the same share of every XCD), and the
