@@ -443,6 +443,7 @@ class HipEngine(object):
             off = torch.empty((rows.shape[0], 9), device=self.device, dtype=torch.int32)
             check(self.lib.sml_eval_prepare(self._ctx, _ptr(rows), rows.shape[0], rows.shape[1], int(n_item), _ptr(rows_b),
                                             _ptr(off), self._stream()), "sml_eval_prepare")
+            rows.record_stream(torch.cuda.current_stream(self.device))      # (it may have been uploaded on another stream)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
             hit = cache[key] = (rows_b, off, rows, ev)     # keeps `rows` alive: the key is its address
@@ -461,6 +462,8 @@ class HipEngine(object):
             rows_b, off = self._blocked_rows(rows, wi.shape[0])
             check(self.lib.sml_eval_ranks_blocked(self._ctx, _ptr(wu), _ptr(wi), _ptr(rows_b), _ptr(off), n, c,
                                                   _ptr(rank), int(max_workgroups), self._stream()), "sml_eval_ranks_blocked")
+            for t in (rows_b, off):            # built on one stream, read here on another: not to be recycled under this launch
+                t.record_stream(torch.cuda.current_stream(self.device))
         else:
             check(self.lib.sml_eval_ranks(self._ctx, _ptr(wu), _ptr(wi), _ptr(rows), n, c, _ptr(rank), self._stream()),
                   "sml_eval_ranks")
