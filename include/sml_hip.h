@@ -170,8 +170,10 @@ typedef struct {
 
 /* One epoch: per batch, run_MF(norm=False) forward, backward to theta, then
  * Adam(lr, weight_decay added to the gradient) on theta (and m, v: flat buffers of
- * the same layout).  theta_grad (2*net_size floats, may be NULL for internal
- * scratch) receives each batch's flat gradient.  With grad_hook == NULL the whole
+ * the same layout).  theta_grad (2*net_size floats) receives each batch's flat
+ * gradient; NULL: internal scratch on the exchange paths, and NOT WRITTEN AT ALL by the
+ * single-GPU step (Adam is fused into the weight-gradient kernel there and nothing
+ * reads the gradient).  With grad_hook == NULL the whole
  * epoch is queued asynchronously.  A non-NULL grad_hook is called on the host after
  * each batch's backward has been queued on `stream` and before its Adam step is
  * queued, with the flat theta-gradient buffer: the multi-GPU path all-reduces it
@@ -282,6 +284,9 @@ int sml_eval_metrics(sml_ctx* ctx, const int32_t* rank, int64_t n, int topk, flo
  * (bench.py's roofline leg).  Off by default; when on, each launch is bracketed by two
  * event records.  sml_prof_get synchronises on the last recorded event. */
 int sml_prof_enable(sml_ctx* ctx, int on);
+/* In-kernel timeline of the training kernels (measurement builds only: -DSML_TIMELINE, see tools/timeline_probe.py;
+ * returns -1 otherwise).  buf: device int64, [0] = record counter (zero it), 16-stamp records from [16]; NULL: off. */
+int sml_debug_timeline(long long* buf);
 int sml_prof_reset(sml_ctx* ctx);
 int sml_prof_classes(void);
 const char* sml_prof_name(int cls);

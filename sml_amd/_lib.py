@@ -95,6 +95,7 @@ SIGNATURES = {
     "sml_comm_allreduce": (ctypes.c_int, [c_void, c_void, ctypes.c_int64, c_void]),
     "sml_comm_allgather": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int64, c_void]),
     "sml_prof_enable": (ctypes.c_int, [c_void, ctypes.c_int]),
+    "sml_debug_timeline": (ctypes.c_int, [c_void]),
     "sml_prof_reset": (ctypes.c_int, [c_void]),
     "sml_prof_classes": (ctypes.c_int, []),
     "sml_prof_name": (ctypes.c_char_p, [ctypes.c_int]),

@@ -178,6 +178,7 @@ hipError_t sml_launch_eval_ranks(int d, const float* wu, const float* wi, const 
 hipError_t sml_launch_eval_bucketize(const int64_t* rows, int64_t n, int n_cols, int64_t n_item, int32_t* rows_out,
                                      int32_t* bucket_off, hipStream_t st);
 hipError_t sml_launch_copy_tables(int n_jobs, void* const* dst, const void* const* src, const long long* bytes, hipStream_t st);
+hipError_t sml_debug_set_timeline(long long* buf);
 hipError_t sml_launch_flag_set(int* flag, int value, hipStream_t st);
 hipError_t sml_launch_flag_wait(int* flag, int value, long long timeout_ticks, hipStream_t st);
 hipError_t sml_launch_eval_ranks_bucketed(int d, const float* wu, const float* wi, const int32_t* rows_b,

@@ -14,6 +14,46 @@
 #include "sml_dev.h"
 #include "sml_kernels.h"
 
+// In-kernel timeline (tools/timeline_probe.py): built only with -DSML_TIMELINE (SML_EXTRA_FLAGS of sml_amd/build.py) --
+// even a null check at every stamp costs the TR step more than a microsecond.  Workgroup 0 and the last workgroup
+// of every instrumented launch take a record of 16 stamps (100 MHz wall clock): [0] = kernel id * 2 + (last block).
+#ifdef SML_TIMELINE
+__device__ long long* g_timeline = nullptr;     // [0] = record counter, records from [16]
+#define TL_BEGIN(KID) long long* tl_rec = nullptr; { long long* tl = g_timeline; if (tl && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) { \
+    const unsigned long long slot = atomicAdd(reinterpret_cast<unsigned long long*>(tl), 1ull); tl_rec = tl + 16 + slot * 16; tl_rec[0] = (KID) * 2 + (blockIdx.x != 0); tl_rec[1] = wall_clock64(); for (int q = 2; q < 16; ++q) tl_rec[q] = 0; } }
+#define TL(i) do { if (tl_rec) tl_rec[(i)] = wall_clock64(); } while (0)
+#else
+#define TL_BEGIN(KID) do { } while (0)
+#define TL(i) do { } while (0)
+#endif
+// How a kernel's outputs leave the CU.  The gap between two dependent launches grows with the bytes the first one
+// leaves DIRTY in the L2s (measured with the timeline: about 1 us + 1 us per MB -- the end-of-kernel release walks and
+// writes back every dirty line before the next dispatch may start).  Outputs that the next launch reads from OTHER
+// XCDs anyway are therefore stored write-through (agent scope, `sc1`): they are on their way to memory while the
+// kernel is still computing, and the release finds little left.  MODE 0 plain, 1 nontemporal (measured: no effect),
+// 2 sc1.  (Per-dword sc1 stores cost more per byte than plain ones: the weight-gradient kernel's theta / m / v stores
+// stay plain -- measured slower with sc1 -- until they are 16-byte vectors.)
+#ifndef SML_WT_FWD
+#define SML_WT_FWD 2
+#endif
+#ifndef SML_WT_BWD
+#define SML_WT_BWD 2
+#endif
+#ifndef SML_WT_MFB
+#define SML_WT_MFB 2
+#endif
+#ifndef SML_WT_FWD_LOCAL
+#define SML_WT_FWD_LOCAL 0
+#endif
+__device__ __forceinline__ void st_out16_wt(float* p, const f32x4& v) {       // one 16-byte write-through store
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+template <int MODE>
+__device__ __forceinline__ void st_out(float* p, float v) {
+    if constexpr (MODE == 1) __builtin_nontemporal_store(v, p);
+    else if constexpr (MODE == 2) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
 namespace {
 
 struct Pro {
@@ -175,6 +215,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float* part = smem;                  // [KSPL][R][D+1], aliases A1s after fc1
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+    TL_BEGIN(NS == 4 ? 1 : 4);
+    // hidden-split form: everything this kernel writes is read next from other XCDs -> write-through.  Unsplit form:
+    // z1 / xin / the replayed moments go to the SAME tile's backward / row update, which runs as the same block index
+    // on the same XCD -> those stay in this XCD's L2 (plain stores); only `out` crosses XCDs (the pair loss reads the
+    // partner rows' tiles)
+    constexpr int WT_LOCAL = (NS == 4) ? SML_WT_FWD : SML_WT_FWD_LOCAL;
     // Workgroup b runs on XCD b % 8 (observed dispatch order; affinity only).  In the four-way hidden split, slice h
     // goes to XCDs {2h, 2h+1} -- the XCDs whose weight-gradient workgroups rewrote exactly that slice of the
     // operand images in the previous batch's Adam step (k_transfer_wgrad's tile map) -- and to no other.
@@ -272,6 +318,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         if (tid < 104) cws[tid] = cw_reg;
         __syncthreads();                   // xts, cws and the schedule window are in LDS
+        TL(2);
         if (lazy) {                        // replay the rows' pending zero-gradient Adam steps
 #pragma unroll
             for (int q = 0; q < EPT; ++q)
@@ -281,8 +328,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int q = 0; q < EPT; ++q) {
                     const int e = q * 512 + tid;
                     const int64_t o = (int64_t)(row0 + e / D) * D + (e % D);
-                    sg.mrep[o] = ok[q] ? m[q] : 0.0f;
-                    sg.vrep[o] = ok[q] ? v[q] : 0.0f;
+                    st_out<WT_LOCAL>(&sg.mrep[o], ok[q] ? m[q] : 0.0f);
+                    st_out<WT_LOCAL>(&sg.vrep[o], ok[q] ? v[q] : 0.0f);
                 }
             }
         }
@@ -309,16 +356,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int c = 0; c < SML_C2; ++c) {
             const float v = sml_gelu(p.h2p[c]);
             A1s[r * S1 + c * D + w] = v;
-            if (saver && sg.a1 != nullptr) sg.a1[(int64_t)row * K1 + c * D + w] = v;
+            if (saver && sg.a1 != nullptr) st_out<WT_LOCAL>(&sg.a1[(int64_t)row * K1 + c * D + w], v);
         }
         if (saver && sg.xin != nullptr) {
             float* x = sg.xin + (int64_t)row * 3 * D;
-            x[w] = xt[q];
-            x[D + w] = xh[q];
-            x[2 * D + w] = xc;
+            st_out<WT_LOCAL>(&x[w], xt[q]);
+            st_out<WT_LOCAL>(&x[D + w], xh[q]);
+            st_out<WT_LOCAL>(&x[2 * D + w], xc);
         }
     }
     __syncthreads();
+    TL(3);
 
     // ---- fc1: Z1[R x HL] = A1[R x K1] * W1^T[:, slice h] ; wave wv owns CT column tiles of the slice
     {
@@ -360,12 +408,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int q = 0; q < 4; ++q) {
                     const int r = mt * SML_TM + 4 * g4 + q;
                     const float z = zt[mt][t][q] + bias1[t];
-                    if (z1 != nullptr) z1[(int64_t)(row0 + r) * SML_HID + n] = z;
+                    if (z1 != nullptr) st_out<WT_LOCAL>(&z1[(int64_t)(row0 + r) * SML_HID + n], z);
                     a2s[r * S2 + nl] = sml_gelu(z);
                 }
         }
     }
+    TL(4);
     __syncthreads();
+    TL(5);
 
     // ---- fc2: Out[R x D] (+)= a2[R x HL] * W2^T[slice h, :] ; waves = KSPL (along K) x JSPL (column tiles)
     {
@@ -386,6 +436,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     part[(kq * R + mt * SML_TM + 4 * g4 + q) * (D + 1) + (jq * JTW + t) * 16 + l15] = acc[mt][t][q];
     }
     __syncthreads();
+    TL(6);
     float* __restrict__ outp = sg.out + (int64_t)h * a.out_pstride;
     float sres[EPT];
 #pragma unroll
@@ -414,8 +465,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
         const int e = q * 512 + tid, r = e / D, j = e % D;
-        if (row0 + r < sg.n_rows) outp[(int64_t)(row0 + r) * D + j] = sres[q];
+        if (row0 + r < sg.n_rows) st_out<SML_WT_FWD>(&outp[(int64_t)(row0 + r) * D + j], sres[q]);
     }
+    TL(7);
 }
 
 // ------------------------------------------------------------------------------------
@@ -629,7 +681,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             dxh += dh1p[c] * cws[SML_OFF_C1W + c * 3 + 1];
         }
         if (!TR) {
-            sg.dx[(int64_t)row * D + w] = dxh + a.l2 * x1;
+            st_out<SML_WT_MFB>(&sg.dx[(int64_t)row * D + w], dxh + a.l2 * x1);
             if (ok) lsum += 0.5f * a.l2 * x1 * x1;      // + l2 * 0.5 * sum(x_hat^2), model/transfer.py:486-488
         }
         if constexpr (TR) {
@@ -736,6 +788,7 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
     float* cws = smem + SZ;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+    TL_BEGIN(2);
     const int tile = (int)blockIdx.x / CS, cs = (int)blockIdx.x % CS;
     const int sidx = tile >= a.tiles0;
     // (both segments' fields come in with the kernel arguments in one scalar-load burst and are selected here: a
@@ -854,7 +907,7 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
             }
             if (row >= sg.n_rows) g = 0.0f;
             dOs[r * SD + w] = g;
-            if (TR && cs == 0) sg.dout[(int64_t)row * D + w] = g;
+            if (TR && cs == 0) st_out<SML_WT_BWD>(&sg.dout[(int64_t)row * D + w], g);
         }
     } else {
         __syncthreads();
@@ -898,10 +951,11 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
             }
             if (row >= sg.n_rows) g = 0.0f;
             dOs[r * SD + w] = g;
-            if (TR && cs == 0) sg.dout[(int64_t)row * D + w] = g;
+            if (TR && cs == 0) st_out<SML_WT_BWD>(&sg.dout[(int64_t)row * D + w], g);
         }
     }
     __syncthreads();
+    TL(2);
     // ---- dA2[R x 512] = dOut[R x D] * W2 ; dZ1 = dA2 * Gelu'(z1) ; wave wv owns column tiles 4wv..4wv+3
     {
         f32x4 acc[1][4];
@@ -917,11 +971,12 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
                 const int r = 4 * g4 + q;
                 const float dz = acc[0][t][q] * sml_gelu_grad(z[t][q]);
                 dZs[r * S2 + n] = dz;
-                if (TR && (t % CS) == cs) dz1[(int64_t)(row0 + r) * SML_HID + n] = dz;   // the CS workgroups share the save
+                if (TR && (t % CS) == cs) st_out<SML_WT_BWD>(&dz1[(int64_t)(row0 + r) * SML_HID + n], dz);   // the CS workgroups share the save
             }
         }
     }
     __syncthreads();
+    TL(3);
     // ---- dA1[R x 5*16] = dZ1[R x 512] * W1[:, this slice] ; every wave takes 4 of the 32 k-steps, all 5 channels
     {
         f32x4 acc[1][5];
@@ -935,6 +990,7 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
             for (int q = 0; q < 4; ++q) part[(wv * R + 4 * g4 + q) * PSTR + t * 16 + l15] = acc[0][t][q];
     }
     __syncthreads();
+    TL(4);
     // ---- per-coordinate tail (threads 0..255, one element each): Gelu'(h2) -> conv2^T -> Gelu'(h1) -> conv1^T (row 1 = x_hat)
     float cga[16], cgb[16];
     if (tid < 256) {
@@ -1031,6 +1087,7 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
 #pragma unroll
         for (int w8 = 0; w8 < 8; ++w8) sacc += lred[w8];
         a.loss_part[blockIdx.x] = sacc;
+        TL(7);
     }
 }
 
@@ -1062,6 +1119,7 @@ __global__ __launch_bounds__(512) void k_transfer_wgrad(SmlWgArgs a) {
     constexpr int JT = D / 32;
     constexpr int T1 = 16 * KT, T2 = JT * 16, TN = T1 + T2;
     __shared__ float part[8][32][33];
+    TL_BEGIN(3);
     __shared__ float csum[8][32];
     constexpr int NS = sml_net_size(D);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -1086,12 +1144,13 @@ __global__ __launch_bounds__(512) void k_transfer_wgrad(SmlWgArgs a) {
                 for (int u = 0; u < 8; ++u) g += x[u];
             }
             for (; t < t1; ++t) g += a.convg_part[(int64_t)t * SML_CG + tid];
-            a.seg[net].grad[off] = g;                 // the flat gradient is complete after this launch
+            if (a.seg[net].grad) a.seg[net].grad[off] = g;    // the flat gradient is complete after this launch (null: nobody reads it)
             if (fuse) {
                 adam_apply(p, m, v, g + a.weight_decay * p, sc);
                 a.theta[i] = p; a.m[i] = m; a.v[i] = v;
             }
         }
+        TL(7);
         return;
     }
     // XCD-aware tile map.  Every operand of this kernel was written by the previous launches on OTHER XCDs, so a
@@ -1166,15 +1225,17 @@ __global__ __launch_bounds__(512) void k_transfer_wgrad(SmlWgArgs a) {
             }
         }
     }
+    TL(2);
 #pragma unroll
     for (int q = 0; q < 16; ++q) part[wv][mfma32_row(q, lane)][l31] = acc[q];
     colsum += __shfl_xor(colsum, 32, 64);
     if (lane < 32) csum[wv][lane] = colsum;
     __syncthreads();
+    TL(3);
     float* __restrict__ g = sg.grad;
     __shared__ float wt[32][33];          // the tile's updated weights, for the operand-image refresh
     auto finish = [&](int off, float gsum, float p, float m, float v) -> float {
-        g[off] = gsum;
+        if (g) g[off] = gsum;
         if (fuse) {
             const int64_t i = (int64_t)net * NS + off;
             adam_apply(p, m, v, gsum + a.weight_decay * p, sc);
@@ -1220,8 +1281,9 @@ __global__ __launch_bounds__(512) void k_transfer_wgrad(SmlWgArgs a) {
             const int ksteps = is_w1 ? SML_HID / 16 : D / 16;
             base = (is_w1 ? sml_pk_p1b(D) : sml_pk_p2b(D)) + ((int64_t)((c0 >> 4) + ct) * ksteps + ((r0 >> 4) + ks)) * 256;
         }
-        *reinterpret_cast<f32x4*>(pkn + base + l * 4) = v;
+        st_out16_wt(pkn + base + l * 4, v);      // (write-through: the next forward reads these from other XCDs)
     }
+    TL(7);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1283,6 +1345,11 @@ __global__ void k_selftest(const float* __restrict__ A, const float* __restrict_
         default: return hipErrorInvalidValue; \
     }
 
+#ifdef SML_TIMELINE
+hipError_t sml_debug_set_timeline(long long* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &buf, sizeof(buf)); }
+#else
+hipError_t sml_debug_set_timeline(long long*) { return hipErrorNotSupported; }
+#endif
 hipError_t sml_launch_fwd(int d, int mt, int ns, const SmlFwdArgs& a, int tiles_total, hipStream_t st) {
     if (tiles_total <= 0) return hipSuccess;
     if (mt == 1 && ns == 1) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 1, 1><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }

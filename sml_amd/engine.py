@@ -306,7 +306,10 @@ class HipEngine(object):
             cb = _lib.GRAD_HOOK(_cb)
         else:
             cb = ctypes.cast(None, _lib.GRAD_HOOK)
-        check(self.lib.sml_tr_stage_epoch(self._ctx, _ptr(theta), _ptr(m), _ptr(v), _ptr(grad), ctypes.byref(t),
+        # the flat theta-gradient is an output only where somebody reads it: the exchange on several GPUs, or a caller
+        # that set keep_theta_grad (the G2 parity test); the fused single-GPU step does not write it otherwise
+        want_grad = self.grad_hook is not None or self.dist is not None or getattr(self, "keep_theta_grad", False)
+        check(self.lib.sml_tr_stage_epoch(self._ctx, _ptr(theta), _ptr(m), _ptr(v), _ptr(grad) if want_grad else None, ctypes.byref(t),
                                           _ptr(tri), n, int(batch_size), float(lr), float(weight_decay),
                                           self._loss_kind(bce, False), float(loss_scale), ctypes.byref(step),
                                           _ptr(losses), cb, None, pp, self._stream()), "sml_tr_stage_epoch")

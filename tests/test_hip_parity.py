@@ -213,6 +213,7 @@ def test_tr_stage_theta_gradient_vs_autograd(d):
     hat_i = torch.cat([T(z["ih"], DEV), T(z["nh"], DEV)])
     ar = torch.arange(B)
     tri = torch.stack([ar, ar, ar + B], 1)
+    eng.keep_theta_grad = True             # (the fused single-GPU step writes the flat gradient only on request)
     eng.tr_stage_epoch(net, last_u, last_i, hat_u, hat_i, tri, B, 1e-12, 0.0)
     grad = eng.tr_state[2].cpu().numpy()
     for ni, mod in enumerate(("user_transfer", "item_transfer")):

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""In-kernel timeline of the TR step: phase durations of workgroup 0 of each kernel and the gaps between consecutive
+kernels, in microseconds (100 MHz wall clock: 10 ns resolution).  Needs a measurement build of the library:
+
+    SML_EXTRA_FLAGS=-DSML_TIMELINE python -m sml_amd.build --force     (and a plain `--force` build afterwards)
+
+fwd stamps: 2 gather done, 3 prologue done, 4 fc1 done, 5 barrier, 6 fc2 + reduce, 7 out stored;
+bwd: 2 pair loss + dOut, 3 dA2 / dZ1, 4 dA1, 7 end;  wgrad: 2 MFMA loop done, 3 partials in LDS, 7 end."""
+import ctypes, json, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import contextlib, io
+from sml_amd import synth
+from sml_amd.conv_transfer import ConvTransfer_com
+from sml_amd.engine import HipEngine
+from sml_amd.mf import MFbasemode
+dev = torch.device("cuda", 0)
+d, U, I, n = 32, 60000, 123000, 256 * 120
+eng = HipEngine(dev, d, 1024)
+torch.manual_seed(2000)
+mf = MFbasemode(U, I, d)
+with contextlib.redirect_stdout(io.StringIO()):
+    net = ConvTransfer_com(d, d)
+mf, net = mf.to(dev), net.to(dev)
+eng.adopt(net)
+lu = (mf.user_laten.weight.detach() * 0.9).contiguous(); li = (mf.item_laten.weight.detach() * 0.9).contiguous()
+hu, hi = mf.user_laten.weight.detach().clone(), mf.item_laten.weight.detach().clone()
+rng = np.random.RandomState(7)
+u, i, j = synth.synth_triples(rng, n, U, I, a_user=1.1, a_item=1.0)
+tri = torch.from_numpy(np.stack([u, i, j], 1)).to(dev)
+eng.tr_stage_epoch(net, lu, li, hu, hi, tri, 256, 1e-3, 1e-4)
+torch.cuda.synchronize()
+buf = torch.zeros(16 + 16 * 4096, dtype=torch.int64, device=dev)
+assert eng.lib.sml_debug_timeline(ctypes.c_void_p(buf.data_ptr())) == 0, "library was not built with -DSML_TIMELINE"
+with eng.partition():
+    eng.tr_stage_epoch(net, lu, li, hu, hi, tri, 256, 1e-3, 1e-4)
+torch.cuda.synchronize()
+eng.lib.sml_debug_timeline(ctypes.c_void_p(0))
+b = buf.cpu().numpy()
+nrec = int(b[0])
+rec = b[16:16 + 16 * nrec].reshape(nrec, 16)
+rec = rec[np.argsort(rec[:, 1])]
+names = {1: "fwd", 2: "bwd", 3: "wgrad", 4: "fwd1"}
+# group per kernel launch: consecutive records with the same kid (first + last block)
+launches = []
+for r in rec:
+    kid, last = int(r[0]) // 2, int(r[0]) % 2
+    if launches and launches[-1]["kid"] == kid and len(launches[-1]["recs"]) < 2 and launches[-1]["recs"][0][0] % 2 != r[0] % 2:
+        launches[-1]["recs"].append(r)
+    else:
+        launches.append({"kid": kid, "recs": [r]})
+out = {}
+def us(x): return x / 100.0
+stats = {}
+prev_end = None
+for L in launches[30:-30]:
+    name = names.get(L["kid"], "?")
+    r0 = [r for r in L["recs"] if r[0] % 2 == 0]
+    rl = [r for r in L["recs"] if r[0] % 2 == 1]
+    if not r0: continue
+    r0 = r0[0]
+    st = stats.setdefault(name, {})
+    stamps = [int(x) for x in r0[1:8]]
+    prev = stamps[0]
+    for k, t in enumerate(stamps[1:], start=2):
+        if t:
+            st.setdefault("T%d-T%d" % (k - 1 if k > 2 else 1, k), []).append(us(t - prev)); prev = t
+    if rl:
+        st.setdefault("entry skew last-first", []).append(us(int(rl[0][1]) - stamps[0]))
+        if rl[0][7]: st.setdefault("last block end - first block end", []).append(us(int(rl[0][7]) - prev))
+    ends = [int(r[7]) for r in L["recs"] if r[7]]
+    if prev_end is not None:
+        st.setdefault("gap from previous kernel's last stamp to entry", []).append(us(stamps[0] - prev_end))
+    prev_end = max(ends) if ends else prev
+for k, v in stats.items():
+    print(k, {kk: round(float(np.median(vv)), 2) for kk, vv in v.items()})
