@@ -151,7 +151,7 @@ struct sml_ctx {
     int variant = 0;         // 0: ConvTransfer_com, 1: ConvTransfer (sml_ctx_set_variant)
     IndexSet ix[2];
     // transfer-net workspaces, 3*B slots each
-    Buf<float> out, dout, dx, xin, z1, a1, dz1, mrep, vrep;
+    Buf<float> out, dout, dx, xin, z1, a1, a2, dz1, mrep, vrep;
     Buf<float> pk, grad, convg, loss_part;
     // Adam schedule of the MF optimiser
     Buf<SmlSched> sched;
@@ -167,7 +167,7 @@ struct sml_ctx {
 
     void release_all() {
         prof.release();
-        out.release(); dout.release(); dx.release(); xin.release(); z1.release(); a1.release(); dz1.release();
+        out.release(); dout.release(); dx.release(); xin.release(); z1.release(); a1.release(); a2.release(); dz1.release();
         mrep.release(); vrep.release();
         pk.release(); grad.release(); convg.release(); loss_part.release();
         ix[0].release(); ix[1].release();
@@ -235,6 +235,7 @@ int ensure_transfer_ws(sml_ctx* c, int B, bool tr_stage) {
     HIPCHK(c->z1.ensure(slots * SML_HID));
     if (tr_stage) {
         HIPCHK(c->a1.ensure(slots * SML_C2 * d));
+        HIPCHK(c->a2.ensure(slots * SML_HID));
         HIPCHK(c->dz1.ensure(slots * SML_HID));
         HIPCHK(c->convg.ensure((slots / SML_TM + 4) * (d / 16) * SML_CG));   // one partial per backward workgroup
         HIPCHK(c->grad.ensure((size_t)2 * sml_net_size(c->d)));
@@ -639,7 +640,7 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
             sg.tri = tri; sg.B = B; sg.is_item = s; sg.n_rows = s ? 2 * B : B;
             const int64_t slot0 = s ? (int64_t)SML_R * tiles_of(B) : 0;
             sg.out = ctx->out.p + slot0 * d; sg.z1 = ctx->z1.p + slot0 * SML_HID; sg.xin = ctx->xin.p + slot0 * 3 * d;
-            sg.a1 = ctx->a1.p + slot0 * SML_C2 * d;
+            sg.a1 = ctx->a1.p + slot0 * SML_C2 * d; sg.a2 = ctx->a2.p + slot0 * SML_HID;
         }
         f.tiles0 = wg_tiles(B, 1); f.cur_step = 0; f.sched = nullptr; f.out_pstride = out_pstride; f.k2 = ctx->variant == 1;
         const int tiles = f.tiles0 + wg_tiles(2 * B, 1);
@@ -656,7 +657,7 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
             sg.dout = ctx->dout.p + slot0 * d; sg.is_item = s; sg.z1 = ctx->z1.p + slot0 * SML_HID; sg.xin = ctx->xin.p + slot0 * 3 * d;
             sg.dx = nullptr; sg.dz1 = ctx->dz1.p + slot0 * SML_HID; sg.n_rows = s ? 2 * B : B;
             SmlWgSeg& q = wg.seg[s];
-            q.dz1 = sg.dz1; q.a1 = ctx->a1.p + slot0 * SML_C2 * d; q.dout = sg.dout; q.z1 = sg.z1;
+            q.dz1 = sg.dz1; q.a1 = ctx->a1.p + slot0 * SML_C2 * d; q.dout = sg.dout; q.a2 = ctx->a2.p + slot0 * SML_HID;
             // (one GPU, Adam fused into the weight-gradient kernel, no gradient buffer asked for: the flat gradient is
             // not written at all -- 0.8 MB less for the launch to leave dirty in L2)
             const bool fused_only = !grad_hook && ctx->comm == nullptr && theta_grad == nullptr;

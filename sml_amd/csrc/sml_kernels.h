@@ -21,6 +21,7 @@ struct SmlSeg {
     float* z1;               // optional saves for backward
     float* xin;              // [n_rows, 3, d]  (x_t, x_hat, x_com)
     float* a1;               // [n_rows, 5d]
+    float* a2;               // TR stage: [n_rows, 512] Gelu(z1), the B operand of dW2 (the weight-gradient kernel then needs no Gelu)
     float* mrep; float* vrep;   // lazy gather: [n_rows, d] the rows' Adam moments after the replay (for the row update)
 };
 struct SmlFwdArgs {
@@ -58,7 +59,7 @@ struct SmlBwdArgs {
 };
 
 struct SmlWgSeg {
-    const float* dz1; const float* a1; const float* dout; const float* z1;
+    const float* dz1; const float* a1; const float* dout; const float* a2;    // a2 = Gelu(z1), saved by the forward
     float* grad;             // this net's flat gradient block
     int n_rows;
 };

@@ -19,12 +19,22 @@
 // of every instrumented launch take a record of 16 stamps (100 MHz wall clock): [0] = kernel id * 2 + (last block).
 #ifdef SML_TIMELINE
 __device__ long long* g_timeline = nullptr;     // [0] = record counter, records from [16]
-#define TL_BEGIN(KID) long long* tl_rec = nullptr; { long long* tl = g_timeline; if (tl && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) { \
+#ifndef SML_TL_SECOND
+#define SML_TL_SECOND (gridDim.x - 1)      // the second workgroup that takes a record (default: the last one)
+#endif
+#define TL_BEGIN(KID) long long* tl_rec = nullptr; const int tl_all = 70000 + (KID) * 1024; { if (g_timeline && threadIdx.x == 0) g_timeline[tl_all + 512 + blockIdx.x] = wall_clock64(); } { long long* tl = g_timeline; if (tl && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == SML_TL_SECOND)) { \
     const unsigned long long slot = atomicAdd(reinterpret_cast<unsigned long long*>(tl), 1ull); tl_rec = tl + 16 + slot * 16; tl_rec[0] = (KID) * 2 + (blockIdx.x != 0); tl_rec[1] = wall_clock64(); for (int q = 2; q < 16; ++q) tl_rec[q] = 0; } }
 #define TL(i) do { if (tl_rec) tl_rec[(i)] = wall_clock64(); } while (0)
+// every workgroup's end joins a running maximum ([2]); workgroup 0 of the next launch copies it into its stamp 8:
+// stamp 1 - stamp 8 = the true gap between the two launches (last workgroup out -> first workgroup in)
+#define TL_DONE() do { long long* tl = g_timeline; if (tl && threadIdx.x == 0) { const long long now_ = wall_clock64(); \
+    atomicMax(reinterpret_cast<unsigned long long*>(tl + 2), (unsigned long long)now_); tl[tl_all + blockIdx.x] = now_; } } while (0)   /* per-workgroup end: the LAST launch of each kernel survives */
+#define TL_PREV() do { if (tl_rec) tl_rec[8] = (long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(g_timeline + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
 #else
-#define TL_BEGIN(KID) do { } while (0)
+#define TL_BEGIN(KID) const int tl_all = 0; (void)tl_all
 #define TL(i) do { } while (0)
+#define TL_DONE() do { } while (0)
+#define TL_PREV() do { } while (0)
 #endif
 // How a kernel's outputs leave the CU.  The gap between two dependent launches grows with the bytes the first one
 // leaves DIRTY in the L2s (measured with the timeline: about 1 us + 1 us per MB -- the end-of-kernel release walks and
@@ -215,7 +225,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float* part = smem;                  // [KSPL][R][D+1], aliases A1s after fc1
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
-    TL_BEGIN(NS == 4 ? 1 : 4);
+    TL_BEGIN(NS == 4 ? 1 : 4); TL_PREV();
     // hidden-split form: everything this kernel writes is read next from other XCDs -> write-through.  Unsplit form:
     // z1 / xin / the replayed moments go to the SAME tile's backward / row update, which runs as the same block index
     // on the same XCD -> those stay in this XCD's L2 (plain stores); only `out` crosses XCDs (the pair loss reads the
@@ -409,7 +419,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const int r = mt * SML_TM + 4 * g4 + q;
                     const float z = zt[mt][t][q] + bias1[t];
                     if (z1 != nullptr) st_out<WT_LOCAL>(&z1[(int64_t)(row0 + r) * SML_HID + n], z);
-                    a2s[r * S2 + nl] = sml_gelu(z);
+                    const float gz = sml_gelu(z);
+                    a2s[r * S2 + nl] = gz;
+                    if (sg.a2 != nullptr) st_out<WT_LOCAL>(&sg.a2[(int64_t)(row0 + r) * SML_HID + n], gz);
                 }
         }
     }
@@ -468,6 +480,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (row0 + r < sg.n_rows) st_out<SML_WT_FWD>(&outp[(int64_t)(row0 + r) * D + j], sres[q]);
     }
     TL(7);
+    TL_DONE();
 }
 
 // ------------------------------------------------------------------------------------
@@ -788,7 +801,7 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
     float* cws = smem + SZ;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
-    TL_BEGIN(2);
+    TL_BEGIN(2); TL_PREV();
     const int tile = (int)blockIdx.x / CS, cs = (int)blockIdx.x % CS;
     const int sidx = tile >= a.tiles0;
     // (both segments' fields come in with the kernel arguments in one scalar-load burst and are selected here: a
@@ -1089,6 +1102,7 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
         a.loss_part[blockIdx.x] = sacc;
         TL(7);
     }
+    TL_DONE();
 }
 
 template <int D>
@@ -1119,15 +1133,19 @@ __global__ __launch_bounds__(512) void k_transfer_wgrad(SmlWgArgs a) {
     constexpr int JT = D / 32;
     constexpr int T1 = 16 * KT, T2 = JT * 16, TN = T1 + T2;
     __shared__ float part[8][32][33];
-    TL_BEGIN(3);
+    TL_BEGIN(3); TL_PREV();
     __shared__ float csum[8][32];
     constexpr int NS = sml_net_size(D);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const bool fuse = a.theta != nullptr;
     SmlSched sc; sc.step_size = a.step_size; sc.bc2_sqrt = a.bc2_sqrt;
-    if ((int)blockIdx.x >= 2 * TN) {
+    // Dispatch order = start order (the 194 workgroups start over ~1.3 us) and the work is uneven: the item net has
+    // twice the user net's rows, so its tiles run ~2 us longer, and the two conv-parameter workgroups are a serial
+    // chain of partial sums.  The long ones take the LOW block indices: conv workgroups first, then the item net's
+    // tiles, the user net's last (per-workgroup end times from the in-kernel timeline: median 6.4, max 8.7 us before).
+    if ((int)blockIdx.x < 2) {
         // conv1/conv2 parameters of one net: sum the backward workgroups' partials in order, then Adam
-        const int net = (int)blockIdx.x - 2 * TN;
+        const int net = (int)blockIdx.x;
         if (tid < 95) {
             const int off = tid < 30 ? tid : tid < 40 ? tid + 2 : tid < 90 ? tid + 4 : tid + 6;
             const int t0 = net ? a.tiles0 : 0, t1 = net ? a.tiles_total : a.tiles0;
@@ -1151,6 +1169,7 @@ __global__ __launch_bounds__(512) void k_transfer_wgrad(SmlWgArgs a) {
             }
         }
         TL(7);
+        TL_DONE();
         return;
     }
     // XCD-aware tile map.  Every operand of this kernel was written by the previous launches on OTHER XCDs, so a
@@ -1160,15 +1179,15 @@ __global__ __launch_bounds__(512) void k_transfer_wgrad(SmlWgArgs a) {
     // each XCD pulls an eighth of the two big operands instead of nearly all of them
     static_assert(TN % 8 == 0 && T2 == 16 * JT, "tile map");
     constexpr int PER = 2 * (KT + JT);                 // tiles per XCD per net
-    const int xcd = (int)blockIdx.x % 8, kk = (int)blockIdx.x / 8;
-    const int net = kk / PER, rr = kk % PER;
+    const int xcd = (int)blockIdx.x % 8, kk = ((int)blockIdx.x - 2) / 8;    // (8 consecutive blocks: one per XCD)
+    const int net = 1 - kk / PER, rr = kk % PER;
     const SmlWgSeg& sg = a.seg[net];
     const bool is_w1 = rr < 2 * KT;
     int ti, tj;                       // tile along output rows / cols
     if (is_w1) { ti = 2 * xcd + rr / KT; tj = rr % KT; } else { tj = 2 * xcd + (rr - 2 * KT) / JT; ti = (rr - 2 * KT) % JT; }
     const float* __restrict__ Asrc = is_w1 ? sg.dz1 : sg.dout;   // A[i][r] = Asrc[r][ti*32 + i]
     const int lda = is_w1 ? SML_HID : D;
-    const float* __restrict__ Bsrc = is_w1 ? sg.a1 : sg.z1;      // B[r][j] = Bsrc[r][tj*32 + j]
+    const float* __restrict__ Bsrc = is_w1 ? sg.a1 : sg.a2;      // B[r][j] = Bsrc[r][tj*32 + j]  (a2 = Gelu(z1), saved by the forward)
     const int ldb = is_w1 ? K1 : SML_HID;
     // this thread's two weights of the tile (+ a bias for 32 threads of the tj = 0 workgroups)
     int woff[2];
@@ -1217,9 +1236,7 @@ __global__ __launch_bounds__(512) void k_transfer_wgrad(SmlWgArgs a) {
             if (s4 >= 4 && !two) break;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int r = rb + s4 * 8 + 4 * hi + e;
-                float b = bv[s4][e];
-                if (!is_w1) b = (r < r_end) ? sml_gelu(b) : 0.0f;
+                const float b = bv[s4][e];
                 colsum += av[s4][e];
                 acc = mfma32(av[s4][e], b, acc);
             }
@@ -1257,7 +1274,7 @@ __global__ __launch_bounds__(512) void k_transfer_wgrad(SmlWgArgs a) {
         for (int w8 = 0; w8 < 8; ++w8) s += csum[w8][tid];
         finish(boff, s, bp, bm, bv2);
     }
-    if (!fuse) return;
+    if (!fuse) { TL_DONE(); return; }
     // Operand-image refresh.  A 32x32 weight tile is four whole (column tile, k-step) blocks of 64 lanes x 4 floats
     // in EACH of its two images (forward and backward GEMM), i.e. eight contiguous 1 KB runs: one coalesced
     // 16-byte store per thread instead of four scattered 4-byte ones.
@@ -1284,6 +1301,7 @@ __global__ __launch_bounds__(512) void k_transfer_wgrad(SmlWgArgs a) {
         st_out16_wt(pkn + base + l * 4, v);      // (write-through: the next forward reads these from other XCDs)
     }
     TL(7);
+    TL_DONE();
 }
 
 // ------------------------------------------------------------------------------------

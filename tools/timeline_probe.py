@@ -30,7 +30,7 @@ u, i, j = synth.synth_triples(rng, n, U, I, a_user=1.1, a_item=1.0)
 tri = torch.from_numpy(np.stack([u, i, j], 1)).to(dev)
 eng.tr_stage_epoch(net, lu, li, hu, hi, tri, 256, 1e-3, 1e-4)
 torch.cuda.synchronize()
-buf = torch.zeros(16 + 16 * 4096, dtype=torch.int64, device=dev)
+buf = torch.zeros(70000 + 8 * 1024, dtype=torch.int64, device=dev)
 assert eng.lib.sml_debug_timeline(ctypes.c_void_p(buf.data_ptr())) == 0, "library was not built with -DSML_TIMELINE"
 with eng.partition():
     eng.tr_stage_epoch(net, lu, li, hu, hi, tri, 256, 1e-3, 1e-4)
@@ -65,6 +65,8 @@ for L in launches[30:-30]:
     for k, t in enumerate(stamps[1:], start=2):
         if t:
             st.setdefault("T%d-T%d" % (k - 1 if k > 2 else 1, k), []).append(us(t - prev)); prev = t
+    if r0[8]:
+        st.setdefault("TRUE gap: last workgroup of the previous launches out -> this launch's first stamp", []).append(us(stamps[0] - int(r0[8])))
     if rl:
         st.setdefault("entry skew last-first", []).append(us(int(rl[0][1]) - stamps[0]))
         if rl[0][7]: st.setdefault("last block end - first block end", []).append(us(int(rl[0][7]) - prev))
@@ -74,3 +76,21 @@ for L in launches[30:-30]:
     prev_end = max(ends) if ends else prev
 for k, v in stats.items():
     print(k, {kk: round(float(np.median(vv)), 2) for kk, vv in v.items()})
+
+# per-workgroup picture of the LAST launch of each kernel: start / end relative to the earliest start
+for kid, name in ((1, "fwd"), (2, "bwd"), (3, "wgrad")):
+    base = 70000 + kid * 1024
+    end, start = b[base:base + 512], b[base + 512:base + 1024]
+    live = start > 0
+    if not live.any(): continue
+    t0 = start[live].min()
+    e = (end[live] - t0) / 100.0; st_ = (start[live] - t0) / 100.0
+    idx = np.nonzero(live)[0]
+    order = np.argsort(-e)[:6]
+    print(name, "workgroups", int(live.sum()), "start spread %.2f us" % st_.max(), "end: median %.2f  max %.2f us" % (np.median(e), e.max()),
+          "slowest blocks", [(int(idx[o]), round(float(e[o]), 2)) for o in order])
+    if name == "wgrad":
+        for lo, hi, what in ((0, 2, "conv"), (2, 98, "first net's tiles"), (98, 194, "second net's tiles")):
+            sel = (idx >= lo) & (idx < hi)
+            if sel.any():
+                print("   ", what, "start median %.2f  end median %.2f  max %.2f" % (np.median(st_[sel]), np.median(e[sel]), e[sel].max()))
