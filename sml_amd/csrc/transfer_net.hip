@@ -969,6 +969,18 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
     }
     __syncthreads();
     TL(2);
+    // The tail's forward recomputation (conv prologue of this thread's element and the Gelu' factors) depends only on
+    // the inputs loaded at the top: done HERE by waves 0..3, on the VALU, while the other waves already feed the MFMA
+    // pipe with dA2 -- not after both GEMMs, where everybody would wait for it
+    Pro pt;
+    float gg2[SML_C2], gg1[SML_C1];
+    if (tid < 256) {
+        conv_prologue(cws, x0, x1, x2, pt);
+#pragma unroll
+        for (int c = 0; c < SML_C2; ++c) gg2[c] = sml_gelu_grad(pt.h2p[c]);
+#pragma unroll
+        for (int c = 0; c < SML_C1; ++c) gg1[c] = sml_gelu_grad(pt.h1p[c]);
+    }
     // ---- dA2[R x 512] = dOut[R x D] * W2 ; dZ1 = dA2 * Gelu'(z1) ; wave wv owns column tiles 4wv..4wv+3
     {
         f32x4 acc[1][4];
@@ -1009,15 +1021,14 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
     if (tid < 256) {
         const int row = row0 + tr_;
         const bool ok = row < sg.n_rows;
-        Pro p;
-        conv_prologue(cws, x0, x1, x2, p);
+        const Pro& p = pt;
         float dh2p[SML_C2];
 #pragma unroll
         for (int c = 0; c < SML_C2; ++c) {
             float s = 0.0f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) s += part[(k * R + tr_) * PSTR + c * 16 + twl];
-            dh2p[c] = s * sml_gelu_grad(p.h2p[c]);
+            dh2p[c] = s * gg2[c];
         }
         float dxh = 0.0f;
         float dh1p[SML_C1];
@@ -1026,7 +1037,7 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
             float s = 0.0f;
 #pragma unroll
             for (int o = 0; o < SML_C2; ++o) s += dh2p[o] * cws[SML_OFF_C2W + o * SML_C1 + c];
-            dh1p[c] = s * sml_gelu_grad(p.h1p[c]);
+            dh1p[c] = s * gg1[c];
             dxh += dh1p[c] * cws[SML_OFF_C1W + c * 3 + 1];
         }
         if (!TR) {
