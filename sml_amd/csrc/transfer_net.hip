@@ -270,13 +270,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     // Unsplit training form (MF stage: one workgroup per row tile, CT column tiles per wave): the first five k-steps of
     // all CT tiles and the wave's fc2 share are fetched here as well, under the gather / lazy-Adam replay / prologue
-    constexpr bool PREW = false && (MT == 1) && (CT >= 2) && (D <= 64);   // measured: 41.3 -> 42.9 us per MF step with it (the early operand loads compete with the gather that heads the chain)
+    // (optional, off: issued BEHIND the gather's loads further down -- loads return in issue order and the gather heads the chain;
+    // at the very top the MF step got slower, 41.3 -> 42.9 us; behind the gather it is neutral, 42.2 vs 42.3 us)
+#ifndef SML_PREW
+#define SML_PREW 0
+#endif
+    constexpr bool PREW = (SML_PREW != 0) && (MT == 1) && (CT >= 2) && (D <= 64);
     auto tw = [tile0](int t) { return tile0 + t; };
     f32x4 ringw1[PREW ? 5 : 1][CT], ringw2[PREW ? PF2 : 1][JTW];
-    if constexpr (PREW) {
-        ring_preload<CT, 5>(ringw1, img1, KS1, 0, lane, tw, nokofs);
-        ring_preload<JTW, PF2>(ringw2, img2, 32, h * KL + kq * KPW, lane, t2, nokofs);
-    }
     float bias1[CT];
 #pragma unroll
     for (int t = 0; t < CT; ++t) bias1[t] = theta[sml_off_f1b(D) + h * HL + (wv * CT + t) * 16 + l15];
@@ -312,6 +313,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 v[q] = sg.v_tab[idx[q] * D + w];
                 from[q] = sg.last_tab[idx[q]];
             }
+        }
+        if constexpr (PREW) {              // the operand rings, behind every load of the gather
+            ring_preload<CT, 5>(ringw1, img1, KS1, 0, lane, tw, nokofs);
+            ring_preload<JTW, PF2>(ringw2, img2, 32, h * KL + kq * KPW, lane, t2, nokofs);
         }
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
@@ -514,6 +519,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float* cws = smem + SZ;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+    TL_BEGIN(5); TL_PREV();
     const int sidx = (int)blockIdx.x >= a.tiles0;
     const SmlBwdSeg& sg = a.seg[sidx];
     const int row0 = ((int)blockIdx.x - (sidx ? a.tiles0 : 0)) * R;
@@ -610,6 +616,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         x0p = x[tid % D]; x1p = x[D + tid % D]; x2p = x[2 * D + tid % D];
     }
     __syncthreads();
+    TL(2);
     // ---- dA2[R x 512] = dOut[R x D] * W2 ; dZ1 = dA2 * Gelu'(z1) ; wave wv owns column tiles 4wv..4wv+3
     {
         f32x4 acc[MT][4];
@@ -640,6 +647,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     }
     __syncthreads();
+    TL(3);
     // ---- dA1[R x 5D] = dZ1[R x 512] * W1 ; waves = KSPL (reduction) x TSPL (5 column tiles each)
     {
         const int kq = wv % KSPL, tq = wv / KSPL;
@@ -658,6 +666,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     part[(kq * R + mt * SML_TM + 4 * g4 + q) * PSTR + (tq * 5 + t) * 16 + l15] = acc[mt][t][q];
     }
     __syncthreads();
+    TL(4);
     // ---- per-coordinate tail: Gelu'(h2) -> conv2^T -> Gelu'(h1) -> conv1^T (row 1 = x_hat)
     // TR: the conv1/conv2 parameter gradients are ONE small matrix product over the tile's elements (see
     // k_transfer_bwd): G = sum_e A[e]^T B[e], accumulated on MFMA across the EPT passes in four registers per
@@ -766,7 +775,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int w8 = 0; w8 < 8; ++w8) s += lred[w8];
         a.loss_part[blockIdx.x] = s;
+        TL(7);
     }
+    TL_DONE();
 }
 
 // ------------------------------------------------------------------------------------

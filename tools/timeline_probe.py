@@ -31,16 +31,21 @@ tri = torch.from_numpy(np.stack([u, i, j], 1)).to(dev)
 eng.tr_stage_epoch(net, lu, li, hu, hi, tri, 256, 1e-3, 1e-4)
 torch.cuda.synchronize()
 buf = torch.zeros(70000 + 8 * 1024, dtype=torch.int64, device=dev)
+mf.user_laten.weight.data.mul_(1.0)
 assert eng.lib.sml_debug_timeline(ctypes.c_void_p(buf.data_ptr())) == 0, "library was not built with -DSML_TIMELINE"
+MODE = os.environ.get("MODE", "tr")
 with eng.partition():
-    eng.tr_stage_epoch(net, lu, li, hu, hi, tri, 256, 1e-3, 1e-4)
+    if MODE == "mf":
+        eng.mf_stage_epoch(mf, net, lu, li, tri, 1024, 0.01, 1e-6)
+    else:
+        eng.tr_stage_epoch(net, lu, li, hu, hi, tri, 256, 1e-3, 1e-4)
 torch.cuda.synchronize()
 eng.lib.sml_debug_timeline(ctypes.c_void_p(0))
 b = buf.cpu().numpy()
 nrec = int(b[0])
 rec = b[16:16 + 16 * nrec].reshape(nrec, 16)
 rec = rec[np.argsort(rec[:, 1])]
-names = {1: "fwd", 2: "bwd", 3: "wgrad", 4: "fwd1"}
+names = {1: "fwd", 2: "bwd", 3: "wgrad", 4: "fwd1", 5: "bwd_full"}
 # group per kernel launch: consecutive records with the same kid (first + last block)
 launches = []
 for r in rec:
@@ -53,7 +58,7 @@ out = {}
 def us(x): return x / 100.0
 stats = {}
 prev_end = None
-for L in launches[30:-30]:
+for L in launches[6:-6]:
     name = names.get(L["kid"], "?")
     r0 = [r for r in L["recs"] if r[0] % 2 == 0]
     rl = [r for r in L["recs"] if r[0] % 2 == 1]
@@ -78,7 +83,7 @@ for k, v in stats.items():
     print(k, {kk: round(float(np.median(vv)), 2) for kk, vv in v.items()})
 
 # per-workgroup picture of the LAST launch of each kernel: start / end relative to the earliest start
-for kid, name in ((1, "fwd"), (2, "bwd"), (3, "wgrad")):
+for kid, name in ((1, "fwd"), (2, "bwd"), (3, "wgrad"), (4, "fwd1"), (5, "bwd_full")):
     base = 70000 + kid * 1024
     end, start = b[base:base + 512], b[base + 512:base + 1024]
     live = start > 0
