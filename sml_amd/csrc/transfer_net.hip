@@ -129,13 +129,21 @@ __device__ __forceinline__ void mma16_ring(f32x4 (&acc)[MT][NT], f32x4 (&ring)[P
     static_assert(PFD >= 1 && PFD <= NK, "ring depth");
     constexpr int NCH = NK / PFD, REM = NK % PFD;
     constexpr int NA = SPLITK ? NT : 1;
-    auto step = [&](int ks, int slot, bool refill) {
-        f32x4 av[NA][MT];
+    // the A fragments (LDS) of step k+1 are fetched BEFORE the products of step k: an LDS round trip per k-step is
+    // otherwise exposed in front of every burst of MFMAs (the ISA had ds_read_b128; s_waitcnt lgkmcnt(0); v_mfma ...)
+    f32x4 av[NA][MT];
+    auto load_a = [&](int ks, f32x4 (&dst)[NA][MT]) {
 #pragma unroll
         for (int u = 0; u < NA; ++u)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                av[u][mt] = *reinterpret_cast<const f32x4*>(arow + mt * a_mt + (ks0 + (SPLITK ? kofs(u) : 0) + ks) * 16);
+                dst[u][mt] = *reinterpret_cast<const f32x4*>(arow + mt * a_mt + (ks0 + (SPLITK ? kofs(u) : 0) + ks) * 16);
+    };
+    load_a(0, av);
+    auto step = [&](int ks, int slot, bool refill) {
+        f32x4 an[NA][MT];
+        const int kn = ks + 1 < NK ? ks + 1 : ks;          // (the last step re-reads its own fragment: no branch)
+        load_a(kn, an);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -148,6 +156,10 @@ __device__ __forceinline__ void mma16_ring(f32x4 (&acc)[MT][NT], f32x4 (&ring)[P
                 ring[slot][t] = bimg[(tile_of(t) * ksteps_total + ks0 + kofs(t) + ks + PFD) * 64 + lane];
         }
         __builtin_amdgcn_sched_barrier(0x86);      // refills stay behind their step's products, ahead of the next step's
+#pragma unroll
+        for (int u = 0; u < NA; ++u)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[u][mt] = an[u][mt];
     };
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
