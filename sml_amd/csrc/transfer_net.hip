@@ -423,6 +423,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int q = 0; q < 4; ++q) zt[mt][0][q] = acc[mt][0][q] + acc[mt][1][q];
         }
+        TL(9);
         // + bias, save z1, Gelu -> a2 tile.  (xts/nrm are dead: every wave passed the barrier above)
         float* z1 = sg.z1;
 #pragma unroll

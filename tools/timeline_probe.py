@@ -70,6 +70,9 @@ for L in launches[6:-6]:
     for k, t in enumerate(stamps[1:], start=2):
         if t:
             st.setdefault("T%d-T%d" % (k - 1 if k > 2 else 1, k), []).append(us(t - prev)); prev = t
+    if r0[9] and r0[3]:
+        st.setdefault("T3-T9 (fc1 products incl. the wait for the first operands)", []).append(us(int(r0[9]) - int(r0[3])))
+        if r0[4]: st.setdefault("T9-T4 (fc1 epilogue: bias, z1 / a2 stores, Gelu, a2 tile)", []).append(us(int(r0[4]) - int(r0[9])))
     if r0[8]:
         st.setdefault("TRUE gap: last workgroup of the previous launches out -> this launch's first stamp", []).append(us(stamps[0] - int(r0[8])))
     if rl:
@@ -80,7 +83,7 @@ for L in launches[6:-6]:
         st.setdefault("gap from previous kernel's last stamp to entry", []).append(us(stamps[0] - prev_end))
     prev_end = max(ends) if ends else prev
 for k, v in stats.items():
-    print(k, {kk: round(float(np.median(vv)), 2) for kk, vv in v.items()})
+    print(k, {kk: (round(float(np.median(vv)), 2) if not isinstance(vv[0], tuple) else [round(float(x), 2) for x in np.median(np.array(vv), axis=0)]) for kk, vv in v.items()})
 
 # per-workgroup picture of the LAST launch of each kernel: start / end relative to the earliest start
 for kid, name in ((1, "fwd"), (2, "bwd"), (3, "wgrad"), (4, "fwd1"), (5, "bwd_full")):
