@@ -420,6 +420,7 @@ def main():
             run_period(engine, st, plans[(a.warmup + s) % len(plans)], hp, overlap=not a.no_overlap)
     barrier()
     dt = time.perf_counter() - t0
+    engine.side_sync_check()          # the periods dropped their evaluation results: an unordered evaluation still fails the run
     if dist is not None:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -270,10 +270,12 @@ int sml_stream_destroy(void* stream);
 /* Orders `waiter` after everything queued on `signaler` so far, through a device-scope event (no system fence). */
 int sml_stream_wait_stream(void* waiter, void* signaler);
 /* The same ordering WITHOUT a cross-queue barrier packet: sml_flag_set (a one-thread kernel on the signalling stream,
- * after the work to be waited for) stores `value` into the device word `flag`; sml_flag_wait (a kernel on the waiting
- * stream, before the dependent work) polls until *flag >= value.  Values must grow monotonically per flag; the word
- * starts at 0.  A waiter that is not released within timeout_s stores -1 (which releases every later waiter too) and
- * returns: the dependent work then runs unordered -- check the word on the host when the results are collected. */
+ * after the work to be waited for) stores `value` into the device word flag[0]; sml_flag_wait (a kernel on the waiting
+ * stream, before the dependent work) polls until flag[0] >= value.  `flag` points at TWO int32 words, both starting at
+ * 0: flag[0] the sequence word (values must grow monotonically), flag[1] a counter of waiters that were not released
+ * within timeout_s and gave up -- their dependent work then ran unordered.  The time-out is a hang guard (make it
+ * long): it never touches the sequence word, so later waiters stay ordered; the host reads flag[1] when it collects
+ * (or drops) results and treats a non-zero count as an error. */
 int sml_flag_set(int32_t* flag, int value, void* stream);
 int sml_flag_wait(int32_t* flag, int value, double timeout_s, void* stream);
 /* hits = #{rank < topk}, ndcg = sum 1/log2(rank+2) over hits; out[0]=hits, out[1]=ndcg (device). */

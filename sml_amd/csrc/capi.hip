@@ -146,6 +146,8 @@ struct IndexSet {
     }
 };
 
+struct SchedRetired { SmlSched* dev; SmlSched* host; hipEvent_t done; };
+
 struct sml_ctx {
     int device = 0, d = 32, max_batch = 0;
     int variant = 0;         // 0: ConvTransfer_com, 1: ConvTransfer (sml_ctx_set_variant)
@@ -157,6 +159,9 @@ struct sml_ctx {
     Buf<SmlSched> sched;
     int sched_len = 0;
     float sched_lr = -1.0f;
+    std::vector<SchedRetired> sched_retired;     // replaced schedule tables / their pinned sources, freed once idle
+    hipEvent_t sched_ready = nullptr;            // behind the newest table's upload
+    hipStream_t sched_stream = nullptr;
     Buf<int32_t> dummy;
     Buf<SmlRun> rec_x;       // run records of the multi-GPU global item list
     ncclComm_t comm = nullptr;
@@ -172,6 +177,9 @@ struct sml_ctx {
         pk.release(); grad.release(); convg.release(); loss_part.release();
         ix[0].release(); ix[1].release();
         sched.release(); dummy.release(); rec_x.release();
+        for (auto& r : sched_retired) { if (r.dev) (void)hipFree(r.dev); if (r.host) (void)hipHostFree(r.host); (void)hipEventDestroy(r.done); }
+        sched_retired.clear();
+        if (sched_ready) { (void)hipEventDestroy(sched_ready); sched_ready = nullptr; }
         hot_first.release(); hot_part.release();
     }
 };
@@ -189,19 +197,55 @@ SmlSched sched_entry(double lr, int64_t k) {
     return s;
 }
 
-int ensure_sched(sml_ctx* c, float lr, int64_t upto) {
-    if (c->sched_lr == lr && upto < c->sched_len) return SML_OK;
+// Grow (or rebuild for another lr) the Adam schedule table WITHOUT a host wait: the new table is filled from a pinned
+// host buffer by an asynchronous copy on the caller's stream; the table it replaces may still be read by kernels in
+// flight, so it is retired with an event behind them and freed by a later call once that event has completed (or with
+// the context).  A call on ANOTHER stream before the copy has landed is ordered behind it by an event wait.
+void sched_reap(sml_ctx* c, bool all) {
+    for (size_t i = 0; i < c->sched_retired.size();) {
+        SchedRetired& r = c->sched_retired[i];
+        if (all || hipEventQuery(r.done) == hipSuccess) {
+            if (r.dev) (void)hipFree(r.dev);
+            if (r.host) (void)hipHostFree(r.host);
+            (void)hipEventDestroy(r.done);
+            c->sched_retired[i] = c->sched_retired.back();
+            c->sched_retired.pop_back();
+        } else ++i;
+    }
+}
+int ensure_sched(sml_ctx* c, float lr, int64_t upto, hipStream_t st) {
+    if (c->sched_lr == lr && upto < c->sched_len) {
+        if (c->sched_ready && st != c->sched_stream && hipEventQuery(c->sched_ready) != hipSuccess)
+            HIPCHK(hipStreamWaitEvent(st, c->sched_ready, 0));
+        return SML_OK;
+    }
     int64_t len = c->sched_len > 0 && c->sched_lr == lr ? c->sched_len : 0;
     while (len <= upto) len = len ? len * 2 : 65536;
     if (len > (int64_t)1 << 30) return fail(SML_EINVAL, "adam schedule", "step counter too large");
-    std::vector<SmlSched> h((size_t)len);
+    sched_reap(c, false);
+    SmlSched* h = nullptr;
+    SmlSched* dnew = nullptr;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h), (size_t)len * sizeof(SmlSched), hipHostMallocDefault));
     for (int64_t k = 0; k < len; ++k) h[(size_t)k] = sched_entry((double)lr, k);
-    // growth is rare; a blocking copy keeps the host buffer's lifetime trivial
-    HIPCHK(hipDeviceSynchronize());
-    HIPCHK(c->sched.ensure((size_t)len));
-    HIPCHK(hipMemcpy(c->sched.p, h.data(), (size_t)len * sizeof(SmlSched), hipMemcpyHostToDevice));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&dnew), (size_t)len * sizeof(SmlSched));
+    if (e == hipSuccess) e = hipMemcpyAsync(dnew, h, (size_t)len * sizeof(SmlSched), hipMemcpyHostToDevice, st);
+    SchedRetired r;
+    r.dev = c->sched.p; r.host = h; r.done = nullptr;
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&r.done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(r.done, st);          // behind the copy and behind every earlier reader on `st`
+    if (e != hipSuccess) {
+        if (dnew) (void)hipFree(dnew);
+        (void)hipHostFree(h);
+        if (r.done) (void)hipEventDestroy(r.done);
+        return fail(SML_EHIP, "adam schedule", hipGetErrorString(e));
+    }
+    c->sched_retired.push_back(r);
+    c->sched.p = dnew; c->sched.cap = (size_t)len;
     c->sched_len = (int)len;
     c->sched_lr = lr;
+    if (!c->sched_ready) HIPCHK(hipEventCreateWithFlags(&c->sched_ready, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(c->sched_ready, st));
+    c->sched_stream = st;
     return SML_OK;
 }
 
@@ -494,7 +538,7 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
     int rc;
     if ((rc = ensure_pk(ctx))) return rc;
     if ((rc = ensure_transfer_ws(ctx, batch, false))) return rc;
-    if ((rc = ensure_sched(ctx, lr, *step + nb + 1))) return rc;
+    if ((rc = ensure_sched(ctx, lr, *step + nb + 1, st))) return rc;
     const int lstride = (wg_tiles(batch, 1) + wg_tiles(2 * batch, 1)) * (d / 16);     // one loss partial per backward workgroup
     const int64_t out_pstride = (int64_t)SML_R * (tiles_of(batch) + tiles_of(2 * batch)) * d;
     const int fns = fwd_split(wg_tiles(batch, 1) + wg_tiles(2 * batch, 1)), bsplit = bwd_split(wg_tiles(batch, 1) + wg_tiles(2 * batch, 1));
@@ -589,7 +633,7 @@ int sml_mf_adam_flush(sml_ctx* ctx, const sml_mf_tables* t, float lr, int64_t st
     DevGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if ((rc = ensure_sched(ctx, lr, step + 1))) return rc;
+    if ((rc = ensure_sched(ctx, lr, step + 1, st))) return rc;
     ctx->prof.begin(PC_FLUSH, st); HIPCHK(sml_launch_adam_flush(ctx->d, t->w_user, t->m_user, t->v_user, t->step_user, t->n_user, ctx->sched.p, (int)step, st));
     HIPCHK(sml_launch_adam_flush(ctx->d, t->w_item, t->m_item, t->v_item, t->step_item, t->n_item, ctx->sched.p, (int)step, st)); ctx->prof.end(st);
     return SML_OK;
@@ -804,7 +848,7 @@ int sml_embed_loss_adam_epoch(sml_ctx* ctx, const sml_mf_tables* t, const int64_
     const int d = ctx->d;
     const int64_t nb = (n + batch - 1) / batch;
     int rc;
-    if ((rc = ensure_sched(ctx, lr, *step + nb + 1))) return rc;
+    if ((rc = ensure_sched(ctx, lr, *step + nb + 1, st))) return rc;
     HIPCHK(ctx->dx.ensure((size_t)3 * batch * d));
     HIPCHK(ctx->xin.ensure((size_t)3 * batch * d)); HIPCHK(ctx->mrep.ensure((size_t)3 * batch * d)); HIPCHK(ctx->vrep.ensure((size_t)3 * batch * d));
     const int lstride = (int)(((int64_t)batch * (d / 4) + 255) / 256);
@@ -850,9 +894,9 @@ int sml_mf_forward(sml_ctx* ctx, const float* w_user, const float* w_item, const
 
 int sml_eval_ranks(sml_ctx* ctx, const float* w_user, const float* w_item, const int64_t* rows, int64_t n, int n_cols,
                    int32_t* rank, void* stream) {
+    if (ctx && n == 0) return SML_OK;        // (a rank that owns no row of a test set passes empty -- null -- tensors)
     if (!ctx || !w_user || !w_item || !rows || !rank || n < 0 || n_cols < 2)
         return fail(SML_EINVAL, "sml_eval_ranks", "bad argument");
-    if (n == 0) return SML_OK;
     DevGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     ctx->prof.begin(PC_EVAL_RANKS, st); HIPCHK(sml_launch_eval_ranks(ctx->d, w_user, w_item, rows, n, n_cols, rank, st)); ctx->prof.end(st);
@@ -861,11 +905,12 @@ int sml_eval_ranks(sml_ctx* ctx, const float* w_user, const float* w_item, const
 
 int sml_eval_prepare(sml_ctx* ctx, const int64_t* rows, int64_t n, int n_cols, int64_t n_item, int32_t* rows_b,
                      int32_t* bucket_off, void* stream) {
+    if (ctx && n == 0 && n_cols >= 2 && n_item > 0) return SML_OK;
     if (!ctx || !rows || !rows_b || !bucket_off || n < 0 || n_cols < 2 || n_item <= 0 || n_item > 0x7fffffff)
         return fail(SML_EINVAL, "sml_eval_prepare", "bad argument");
-    if ((uint64_t)n_item * (uint64_t)ctx->d > 0xffffffffull)      // the blocked rank kernel addresses the table with 32-bit element offsets
-        return fail(SML_EINVAL, "sml_eval_prepare", "item table too large for the blocked evaluation (n_item * d >= 2^32): use sml_eval_ranks");
-    if (n == 0) return SML_OK;
+    // the blocked rank kernel addresses the item table with 32-bit BYTE offsets (row id * d * 4, + 16 per lane)
+    if ((uint64_t)n_item * (uint64_t)ctx->d * 4ull > 0x100000000ull)
+        return fail(SML_EINVAL, "sml_eval_prepare", "item table too large for the blocked evaluation (n_item * d * 4 > 2^32 bytes): use sml_eval_ranks");
     DevGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     ctx->prof.begin(PC_MISC, st); HIPCHK(sml_launch_eval_bucketize(rows, n, n_cols, n_item, rows_b, bucket_off, st)); ctx->prof.end(st);
@@ -875,9 +920,9 @@ int sml_eval_prepare(sml_ctx* ctx, const int64_t* rows, int64_t n, int n_cols, i
 int sml_eval_ranks_blocked(sml_ctx* ctx, const float* w_user, const float* w_item, const int32_t* rows_b,
                            const int32_t* bucket_off, int64_t n, int n_cols, int32_t* rank, int max_workgroups,
                            void* stream) {
+    if (ctx && n == 0) return SML_OK;
     if (!ctx || !w_user || !w_item || !rows_b || !bucket_off || !rank || n < 0 || n_cols < 2)
         return fail(SML_EINVAL, "sml_eval_ranks_blocked", "bad argument");
-    if (n == 0) return SML_OK;
     DevGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     ctx->prof.begin(PC_EVAL_RANKS, st);
@@ -887,9 +932,10 @@ int sml_eval_ranks_blocked(sml_ctx* ctx, const float* w_user, const float* w_ite
 }
 
 int sml_eval_metrics(sml_ctx* ctx, const int32_t* rank, int64_t n, int topk, float* out, void* stream) {
-    if (!ctx || !rank || !out || n < 0) return fail(SML_EINVAL, "sml_eval_metrics", "bad argument");
+    if (!ctx || !out || n < 0 || (n > 0 && !rank)) return fail(SML_EINVAL, "sml_eval_metrics", "bad argument");
     DevGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
+    if (n == 0) { HIPCHK(hipMemsetAsync(out, 0, 2 * sizeof(float), st)); return SML_OK; }    // no rows: (0 hits, 0 ndcg)
     ctx->prof.begin(PC_MISC, st); HIPCHK(sml_launch_eval_metrics(rank, n, topk, out, st)); ctx->prof.end(st);
     return SML_OK;
 }
@@ -1075,6 +1121,7 @@ int sml_copy_tables(int n, void* const* dst, const void* const* src, const int64
     if (n < 0 || n > 4 || (n && (!dst || !src || !bytes))) return fail(SML_EINVAL, "sml_copy_tables", "1..4 copies per call");
     long long b[4] = {0, 0, 0, 0};
     for (int q = 0; q < n; ++q) {
+        if (bytes[q] == 0) continue;                 // an empty job: its pointers are not looked at
         if (!dst[q] || !src[q] || bytes[q] < 0 || bytes[q] % 16 || ((uintptr_t)dst[q] | (uintptr_t)src[q]) % 16)
             return fail(SML_EINVAL, "sml_copy_tables", "pointers and sizes must be multiples of 16 bytes");
         b[q] = bytes[q];

@@ -1273,18 +1273,19 @@ hipError_t sml_launch_copy_tables(int n_jobs, void* const* dst, const void* cons
 // Device-side ordering between two streams without a cross-queue barrier packet: the signalling stream runs
 // k_flag_set after the work to be waited for (in-order queue: that work is complete and released when the kernel
 // starts), the waiting stream runs k_flag_wait before its dependent kernels (their start-of-kernel acquire then sees
-// the data).  One lane polls a system-scope word; a waiter gives up after `timeout` 100-MHz ticks and poisons the word.
-__global__ void k_flag_set(int* flag, int value) {          // (a poisoned word stays poisoned: the host finds it when it collects results)
-    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= 0)
-        __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+// the data).  One lane polls a system-scope word.  flag[0] is the sequence word, flag[1] counts waiters that gave up
+// after `timeout` 100-MHz ticks (a hang guard): a time-out is an INCIDENT the host finds in flag[1] -- it does not
+// touch the sequence word, so every later waiter is still ordered behind its own signal.
+__global__ void k_flag_set(int* flag, int value) {
+    __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __global__ void k_flag_wait(int* flag, int value, long long timeout) {
     if (threadIdx.x != 0) return;
     const long long t0 = wall_clock64();
     for (;;) {
         const int v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (v >= value || v < 0) return;
-        if (wall_clock64() - t0 > timeout) { __hip_atomic_store(flag, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return; }
+        if (v >= value) return;
+        if (wall_clock64() - t0 > timeout) { __hip_atomic_fetch_add(flag + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return; }
         __builtin_amdgcn_s_sleep(32);
     }
 }

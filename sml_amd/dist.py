@@ -180,13 +180,36 @@ class DistContext(object):
             self.dist.all_gather(list(dst.view(self.world, -1).unbind(0)), src, group=self.group)
 
     def same_on_all_ranks(self, value, what):
-        """Independent-shards mode needs the same epoch length on every rank: check it, do not hang."""
+        """Independent-shards mode needs the same epoch length on every rank: check it, do not hang.  Every call joins
+        the (tiny) all-reduce, so the ranks' collective sequences stay aligned whatever they see; but the host WAITS for
+        the answer only the first time it sees a value -- the property does not change from epoch to epoch, and a drain
+        of the device per MF epoch would cost the run-ahead the single-GPU path lives on.  Later answers are read back
+        asynchronously and verified by the next call."""
         t = torch.tensor([float(value), -float(value)], device=self.device, dtype=torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
-        if t[0].item() != -t[1].item():
-            raise ValueError("%s differs between ranks (max %d, min %d): independent-shard epochs need equal sizes; "
-                             "route a shared epoch with DistContext.route_epoch instead"
-                             % (what, int(t[0].item()), int(-t[1].item())))
+
+        def verify(hi, lo):
+            if hi != -lo:
+                raise ValueError("%s differs between ranks (max %d, min %d): independent-shard epochs need equal sizes; "
+                                 "route a shared epoch with DistContext.route_epoch instead" % (what, int(hi), int(-lo)))
+        seen = self.__dict__.setdefault("_same_seen", set())
+        pend = self.__dict__.get("_same_pending")
+        if pend is not None and (pend[1] is None or pend[1].query()):
+            verify(float(pend[0][0]), float(pend[0][1]))
+            self._same_pending = pend = None
+        if (what, value) not in seen:
+            h = t.cpu()
+            verify(float(h[0]), float(h[1]))
+            seen.add((what, value))
+        elif pend is None:
+            if t.is_cuda:
+                host = torch.empty(2, dtype=torch.float64).pin_memory()
+                host.copy_(t, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                self._same_pending = (host, ev)
+            else:
+                self._same_pending = (t, None)
 
     def mf_exchange(self, triples, batch, d, loss_kind=LOSS_BCE):
         """Independent-shards mode: exchange descriptor of one MF epoch over this rank's `triples` [n,3] (every rank

@@ -459,6 +459,10 @@ class HipEngine(object):
         rows = self._dev(rows, torch.int64)
         n, c = rows.shape
         rank = torch.empty(n, device=self.device, dtype=torch.int32)
+        if n == 0:                         # a rank that owns no row of this test set
+            return rank
+        if wi.numel() * 4 > (1 << 32):     # past the blocked kernel's 32-bit byte offsets: the plain kernel ranks it
+            blocked = False
         if blocked is None:
             blocked = wi.numel() * 4 >= self.BLOCKED_EVAL_MIN_ITEM_BYTES and n * c >= (1 << 22)
         if blocked:
@@ -567,9 +571,9 @@ class HipEngine(object):
             dst, src, nbytes = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_int64 * n)()
             for q, (d, s) in enumerate(chunk):
                 if d.shape != s.shape or d.dtype != s.dtype or not (d.is_contiguous() and s.is_contiguous()) \
-                        or (d.numel() * d.element_size()) % 16 or d.data_ptr() % 16 or s.data_ptr() % 16:
-                    d.copy_(s)                    # odd shapes: torch's copy
-                    dst[q], src[q], nbytes[q] = d.data_ptr(), d.data_ptr(), 0
+                        or (d.numel() * d.element_size()) % 16 or d.data_ptr() % 16 or s.data_ptr() % 16 or d.numel() == 0:
+                    d.copy_(s)                    # odd shapes, misaligned views, empty tensors: torch's copy
+                    dst[q], src[q], nbytes[q] = None, None, 0      # (a zero-byte job: the library skips it)
                     continue
                 dst[q], src[q], nbytes[q] = d.data_ptr(), s.data_ptr(), d.numel() * d.element_size()
             check(self.lib.sml_copy_tables(n, dst, src, nbytes, self._stream()), "sml_copy_tables")
@@ -603,12 +607,17 @@ class HipEngine(object):
                   "sml_stream_wait_stream")
         else:
             if getattr(self, "_sync_flag", None) is None:
-                self._sync_flag = torch.zeros(1, device=self.device, dtype=torch.int32)
+                self._sync_flag = torch.zeros(2, device=self.device, dtype=torch.int32)   # [sequence, time-outs]
                 self._sync_seq = 0
+                self._sync_seen = 0           # time-outs already reported
             self._sync_seq += 1
             check(self.lib.sml_flag_set(_ptr(self._sync_flag), self._sync_seq, ctypes.c_void_p(cur.cuda_stream)), "sml_flag_set")
-            check(self.lib.sml_flag_wait(_ptr(self._sync_flag), self._sync_seq, 5.0, ctypes.c_void_p(side.cuda_stream)),
-                  "sml_flag_wait")
+            # The waiter starts polling as soon as the side stream is free, while its signal sits behind everything the
+            # host has already queued on the training stream (the driver runs a whole stage ahead): the time-out is a
+            # HANG GUARD, minutes not seconds (SML_FLAG_TIMEOUT_S).  A waiter that does give up is counted in flag[1]
+            # (side_sync_check); the sequence word is untouched, so later evaluations stay ordered.
+            check(self.lib.sml_flag_wait(_ptr(self._sync_flag), self._sync_seq, self._flag_timeout(),
+                                         ctypes.c_void_p(side.cuda_stream)), "sml_flag_wait")
         with torch.cuda.stream(side):
             ranks = self.eval_ranks(slot["u"], slot["i"], rows, max_workgroups=self._side_eval_cap())
             ev = torch.cuda.Event()
@@ -628,13 +637,51 @@ class HipEngine(object):
             ev.record(side)
         return (out, ev)
 
+    @staticmethod
+    def _flag_timeout():
+        import os
+        return float(os.environ.get("SML_FLAG_TIMEOUT_S", "300"))
+
+    def side_sync_check(self, block=True):
+        """Raise if a side-stream evaluation gave up waiting for its table snapshot since the last check (its ranks
+        were then computed over a snapshot that may have been incomplete).  Called wherever evaluation results are
+        collected OR dropped (run_period without a record, bench.py).  block=True synchronises with the side stream;
+        block=False never waits: it looks at the last asynchronous read-back of the counter that has completed and
+        queues the next one (a period that drops its results checks the previous period's this way, and the caller
+        ends the run with a blocking check).  An incident is reported once: the engine is re-armed, and later
+        evaluations were ordered all along (the sequence word is never poisoned)."""
+        flag = getattr(self, "_sync_flag", None)
+        if flag is None:
+            return
+        side = self._side_stream()
+        if block:
+            with torch.cuda.stream(side):          # (read on the side stream: the training stream's backlog is not waited for)
+                n = int(flag[1].item())
+        else:
+            n = self._sync_seen
+            pend = getattr(self, "_sync_pending", None)
+            if pend is not None and pend[1].query():
+                n = int(pend[0][0])
+                self._sync_pending = pend = None
+            if pend is None:
+                host = getattr(self, "_sync_host", None)
+                if host is None:
+                    host = self._sync_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+                with torch.cuda.stream(side):
+                    host.copy_(flag[1:2], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                self._sync_pending = (host, ev)
+        if n > self._sync_seen:
+            new, self._sync_seen = n - self._sync_seen, n
+            raise RuntimeError("%d side-stream evaluation(s) gave up waiting for their table snapshot (sml_flag_wait "
+                               "timeout, SML_FLAG_TIMEOUT_S=%g): their results are not trustworthy" % (new, self._flag_timeout()))
+
     def eval_result(self, pending):
         """Wait (host) for an eval_metrics_submit result: (hits, ndcg_sum)."""
         out, ev = pending[0], pending[1]
         ev.synchronize()
-        flag = getattr(self, "_sync_flag", None)
-        if flag is not None and int(flag.item()) < 0:
-            raise RuntimeError("a side-stream evaluation gave up waiting for its table snapshot (sml_flag_wait timeout)")
+        self.side_sync_check()
         h = out.cpu()
         return float(h[0]), float(h[1])
 

@@ -159,4 +159,8 @@ def run_period(engine, st, plan, hp, record=None, overlap=True):
         for tag, res in notes:
             hits, ndcg = res()
             record.append((tag, hits / n, ndcg / n))
+    elif plan.val_rows is not None and overlap and hasattr(engine, "side_sync_check"):
+        # results dropped: an evaluation that ran unordered (flag time-out) must still surface.  No host wait here --
+        # this looks at the previous period's read-back; the caller ends its run with engine.side_sync_check()
+        engine.side_sync_check(block=False)
     return mf_loss, tr_loss

@@ -14,7 +14,7 @@ Harness-side shims (the reference is untouched):
   4. test_model's NDCG wrapped back into a tensor (numpy.float32 has no .cpu()).
 
 Fixtures:  G1 transfer forward, G2 run_MF loss and
-gradients, G3 MF-stage steps, G4 TR-stage steps, G5 updata, G6 evaluation,
+gradients, G3 MF-stage steps, G4 TR-stage steps, G5 updata, G6 evaluation, G13 evaluation at 999 negatives,
 G7 end-to-end main_yelp.py log on a tiny 40-period dataset, G8 batch supply,
 G9 parameter initialisation, G7-news the main_news.py (Adressa) path end to end, G12 a mid-size period
 sequence (10,000 test rows per period: Recall@20 resolves 1e-4) with full-precision per-batch losses and
@@ -413,6 +413,55 @@ def gen_g6(T):
     save("g6_eval.npz", **out)
 
 
+# --------------------------------------------------------------------------- G13 eval at the shipped format's width
+def gen_g13(T):
+    """MFbasemode.test / test_model on rows of the shipped test format: 1 positive + 999 negatives (data/dataset2.py:356
+    neg_num=999; model/MF.py:50).  Candidates are distinct and every negative's score is at least 1e-3 away from the
+    positive's (checked in float64, offending candidates redrawn), so the ranks are exact whatever the order an
+    implementation sums the 32 products in.  Recorded from the reference: hits / ndcg / hit indices at K = 5, 10, 20, the
+    full rank of every row (topK over all 1000 candidates) and test_model's averages."""
+    from model.MF import MFbasemode
+    from data.dataset2 import testDataset
+    import evalution.evaluation2 as E
+
+    torch.manual_seed(13)
+    U, I, d, n, neg = 100, 1300, 32, 96, 999
+    mf = MFbasemode(U, I, d)
+    wu = mf.user_laten.weight.detach().double().numpy()
+    wi = mf.item_laten.weight.detach().double().numpy()
+    rng = np.random.RandomState(14)
+    rows = np.zeros((n, 2 + neg), dtype=np.int64)
+    for r in range(n):
+        u, pos = rng.randint(0, U), rng.randint(0, I)
+        s = wi @ wu[u]
+        ok = np.abs(s - s[pos]) >= 1e-3
+        ok[pos] = False
+        cand = np.nonzero(ok)[0]
+        assert cand.shape[0] >= neg
+        rows[r, 0], rows[r, 1] = u, pos
+        rows[r, 2:] = rng.choice(cand, size=neg, replace=False)
+    out = sd_np(mf, "mf.")
+    out["rows"] = rows.astype(np.int32)
+    with torch.no_grad():
+        _, _, _ = mf.test(torch.from_numpy(rows), topK=20)
+        sc = (mf.user_laten(torch.from_numpy(rows[:, 0])).unsqueeze(1) * mf.item_laten(torch.from_numpy(rows[:, 1:]))).sum(-1)
+        _, order = torch.topk(sc, 1 + neg)                  # the reference's ranking primitive over ALL candidates
+        full = (order < 1).nonzero()
+        assert full.shape[0] == n and torch.equal(full[:, 0], torch.arange(n))
+        out["rank_full"] = full[:, 1].numpy().astype(np.int32)
+    for K in (5, 10, 20):
+        with torch.no_grad():
+            hit, ndcg, idx = mf.test(torch.from_numpy(rows), topK=K)
+        out["hit_%d" % K] = np.array(float(hit))
+        out["ndcg_%d" % K] = np.array(float(ndcg))
+        out["hitidx_%d" % K] = idx.numpy().copy()
+        loader = torch.utils.data.DataLoader(testDataset(rows), batch_size=32, num_workers=0)
+        r, nd = E.test_model(mf, loader, topK=K)
+        out["recall_%d" % K] = np.array(float(r))
+        out["ndcgavg_%d" % K] = np.array(float(nd))
+    save("g13_eval_999.npz", **out)
+
+
 # --------------------------------------------------------------------------- G8 batch supply
 def gen_g8(T):
     from data.dataset2 import trainDataset_withPreSample
@@ -684,6 +733,8 @@ def main():
             gen_g3_g4_g5(T, tmp)
         if not only or "g6" in only:
             gen_g6(T)
+        if not only or "g13" in only:
+            gen_g13(T)
         if not only or "g8" in only:
             gen_g8(T)
         if not only or "g7" in only:

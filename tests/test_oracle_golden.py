@@ -146,6 +146,25 @@ def test_g6_eval():
         np.testing.assert_allclose(ndcg / n, float(z["ndcgavg_%d" % K]), rtol=1e-6)
 
 
+def test_g13_eval_999_negatives():
+    """The shipped test format's width (1 + 999 candidates): the oracle's rank-by-count equals the reference's topk
+    position for every row, and hits / ndcg / hit indices at K = 5, 10, 20."""
+    z = golden("g13_eval_999.npz")
+    wu, wi = T(z["mf.user_laten.weight"]), T(z["mf.item_laten.weight"])
+    rows = torch.from_numpy(z["rows"].astype(np.int64))
+    n = rows.shape[0]
+    assert rows.shape[1] == 1001
+    ranks = O.eval_ranks(wu, wi, rows)
+    np.testing.assert_array_equal(ranks.numpy(), z["rank_full"])
+    for K in (5, 10, 20):
+        hits, ndcg = O.eval_metrics(ranks, K)
+        assert hits == float(z["hit_%d" % K])
+        np.testing.assert_allclose(ndcg, float(z["ndcg_%d" % K]), rtol=1e-6)
+        np.testing.assert_array_equal(np.nonzero((ranks < K).numpy())[0], z["hitidx_%d" % K])
+        np.testing.assert_allclose(hits / n, float(z["recall_%d" % K]), rtol=1e-7)
+        np.testing.assert_allclose(ndcg / n, float(z["ndcgavg_%d" % K]), rtol=1e-6)
+
+
 def test_bare_step_matches_autograd_sgd():
     """a3: the oracle's bare step is synchronous minibatch SGD on the baseline.py loss."""
     g = torch.Generator().manual_seed(3)
