@@ -87,6 +87,49 @@ int sml_comm_destroy(sml_ctx* ctx);
 int sml_comm_allreduce(sml_ctx* ctx, float* buf, int64_t n, void* stream);
 int sml_comm_allgather(sml_ctx* ctx, const float* src, float* dst, int64_t n_per_rank, void* stream);
 
+/* ---- one-shot exchange over peer mappings (multi-GPU; no collective library on the data path) --------------
+ * The reference is single-device (main_yelp.py:125, .cuda() throughout model/transfer.py:317-385): this wraps its
+ * per-batch loops (theta-gradient of a 256-triple batch, model/transfer.py:701-728; item-gradient rows of a
+ * 1,024-triple batch, :463-511) for one process per GPU.  At these sizes (0.79 MB of theta gradient, 262 KB of rows
+ * per rank, every 26-42 us) a collective library's launch + protocol floor is longer than the step it sits in; with
+ * 7 direct xGMI links per GPU every rank can instead WRITE its contribution straight into every peer's memory:
+ *
+ *   regions   every rank provides an `inbox` (theta slots [2 parities][world][G floats], then row slots
+ *             [2 parities][world][rows_cap][d]) and a `flags` region (arrival counters), sized by
+ *             sml_peer_region_bytes, allocated with sml_peer_alloc (uncached / fine-grained device memory: remote
+ *             stores land in it without the owner's L2 holding stale lines) and ZEROED there.
+ *   mapping   sml_peer_attach takes RAW POINTERS: inbox[q] / flags[q] = rank q's regions as addressable from this
+ *             device.  One process per GPU: export with sml_peer_export (hipIpcGetMemHandle; dmabuf IPC:
+ *             HSA_ENABLE_IPC_MODE_LEGACY=0), all-gather the 64-byte handles by any means, sml_peer_open them
+ *             (hipIpcOpenMemHandle).  Several ranks inside one process (tests on one GPU): pass the allocations.
+ *   push      TR stage: k_transfer_wgrad's epilogue stores every finished gradient tile into slot [step & 1][rank]
+ *             of EVERY rank's inbox (system-scope write-through stores), then one system-scope counter increment
+ *             per workgroup and destination.  MF stage / bare step: a copy kernel pushes the rank's item-gradient
+ *             rows the same way.
+ *   poll+sum  the consumer (theta Adam / the row update) polls its OWN counters for the step's value, then adds the
+ *             world slots IN RANK ORDER: every rank forms bit-identical sums, replicas stay bit-identical without
+ *             a broadcast.  Two parities are enough: a rank pushes step b+2 only after consuming step b+1, which
+ *             needed every peer's b+1 push, issued after that peer consumed step b.
+ *   errors    a consumer that is not released within the time-out (sml_peer_attach) counts an incident and goes
+ *             on with what it has: sml_peer_status reports the count (synchronous).
+ * With peers attached, sml_tr_stage_epoch (grad_hook == NULL) and sml_mf_stage_epoch / sml_embed_loss_sgd_epoch
+ * (exchange hook == NULL) use this path instead of the RCCL communicator. */
+#define SML_MAX_PEERS 8
+int sml_peer_region_bytes(sml_ctx* ctx, int world, int64_t rows_cap, int64_t* inbox_bytes, int64_t* flags_bytes);
+int sml_peer_alloc(int device, int64_t bytes, void** ptr);      /* zeroed; synchronous */
+int sml_peer_free(int device, void* ptr);
+int sml_peer_export(void* ptr, void* handle64);
+int sml_peer_open(int device, const void* handle64, void** ptr);
+int sml_peer_close(int device, void* ptr);
+int sml_peer_attach(sml_ctx* ctx, int world, int rank, void* const* inbox, void* const* flags, int64_t rows_cap,
+                    double timeout_s);
+int sml_peer_detach(sml_ctx* ctx);
+int sml_peer_status(sml_ctx* ctx, int* timeouts);
+/* start-up self-check: every rank pushes n floats of `src` into all inboxes' theta slots and reads back the rank-order
+ * sum of all ranks' pushes into dst (device, n floats; n <= 2 * sml_theta_net_size).  Consumes one theta exchange step:
+ * every rank must call it the same number of times. */
+int sml_peer_allreduce_check(sml_ctx* ctx, const float* src, float* dst, int64_t n, void* stream);
+
 /* ---- a5/a6/a10: transfer net forward ------------------------------------------- */
 /* ConvTransfer_com.forward (model/conv_transfer.py:92-110) for `net` (0 = user
  * transfer, 1 = item transfer): out[n,:] = net(x_t[n,:], x_hat[n,:]).  Rows are
@@ -130,6 +173,10 @@ typedef struct {
     int64_t slot_stride;    /* rows every rank contributes per batch to dx_items_all (0: 2*batch) */
     const int64_t* item_off;/* host [n_batches+1]: batch b's global item occurrences are key/val_items[item_off[b] .. item_off[b+1])
                                (NULL: world*2*batch per full batch, the uniform layout) */
+    int64_t push_rows;      /* peer path only (sml_peer_attach, hook == NULL): rows a rank actually pushes per batch, the same
+                               on every rank, 2*batch <= push_rows <= slot_stride (0: slot_stride).  There slot_stride must
+                               equal the inboxes' rows_cap: the gathered buffer IS one parity of this rank's row slots, and
+                               dx_items_all is not used. */
 } sml_mf_exchange;
 
 /* Batches of unequal size.  A global batch split over ranks by user owner leaves every rank a DIFFERENT number of

@@ -32,7 +32,7 @@ class MFTables(ctypes.Structure):
 class MFExchange(ctypes.Structure):
     _fields_ = [("world", ctypes.c_int), ("key_items", c_void), ("val_items", c_void), ("dx_local", c_void),
                 ("dx_items_all", c_void), ("hook", MF_HOOK), ("hook_user", c_void), ("loss_scale", ctypes.c_float),
-                ("slot_stride", ctypes.c_int64), ("item_off", c_void)]
+                ("slot_stride", ctypes.c_int64), ("item_off", c_void), ("push_rows", ctypes.c_int64)]
 
 
 class BareExchange(ctypes.Structure):
@@ -94,6 +94,17 @@ SIGNATURES = {
     "sml_comm_destroy": (ctypes.c_int, [c_void]),
     "sml_comm_allreduce": (ctypes.c_int, [c_void, c_void, ctypes.c_int64, c_void]),
     "sml_comm_allgather": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int64, c_void]),
+    "sml_peer_region_bytes": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    "sml_peer_alloc": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, ctypes.POINTER(c_void)]),
+    "sml_peer_free": (ctypes.c_int, [ctypes.c_int, c_void]),
+    "sml_peer_export": (ctypes.c_int, [c_void, c_void]),
+    "sml_peer_open": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.POINTER(c_void)]),
+    "sml_peer_close": (ctypes.c_int, [ctypes.c_int, c_void]),
+    "sml_peer_attach": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_void), ctypes.POINTER(c_void), ctypes.c_int64,
+                                       ctypes.c_double]),
+    "sml_peer_detach": (ctypes.c_int, [c_void]),
+    "sml_peer_status": (ctypes.c_int, [c_void, ctypes.POINTER(ctypes.c_int)]),
+    "sml_peer_allreduce_check": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int64, c_void]),
     "sml_prof_enable": (ctypes.c_int, [c_void, ctypes.c_int]),
     "sml_debug_timeline": (ctypes.c_int, [c_void]),
     "sml_prof_reset": (ctypes.c_int, [c_void]),

@@ -166,6 +166,18 @@ struct sml_ctx {
     Buf<SmlRun> rec_x;       // run records of the multi-GPU global item list
     ncclComm_t comm = nullptr;
     int comm_world = 1, comm_rank = 0;
+    // one-shot exchange over peer mappings (sml_peer_attach): world == 0 means detached
+    struct Peer {
+        int world = 0, rank = 0;
+        char* inbox[SML_MAX_PEERS] = {nullptr};
+        unsigned long long* flags[SML_MAX_PEERS] = {nullptr};
+        int64_t theta_slot = 0;          // floats per (parity, source) theta slot
+        int64_t rows_cap = 0;            // rows per (parity, source) row slot
+        int64_t tick[2] = {0, 0};        // exchanges done, per kind (0: theta, 1: rows)
+        unsigned long long expect[2][2] = {{0, 0}, {0, 0}};   // [kind][parity]: counter value after the last push
+        long long timeout = 0;           // 100 MHz ticks
+        int* err = nullptr;              // device: incidents
+    } peer;
     Buf<int> hot_first;
     Buf<float> hot_part;
     Prof prof;
@@ -181,6 +193,7 @@ struct sml_ctx {
         sched_retired.clear();
         if (sched_ready) { (void)hipEventDestroy(sched_ready); sched_ready = nullptr; }
         hot_first.release(); hot_part.release();
+        if (peer.err) { (void)hipFree(peer.err); peer.err = nullptr; }
     }
 };
 
@@ -296,6 +309,40 @@ int ensure_pk(sml_ctx* c) {
 }
 
 int ceil_log2(int64_t x) { int b = 0; while (((int64_t)1 << b) < x) ++b; return b; }
+
+// ---- peer regions: inbox = [theta: 2 parities][world][theta_slot floats] then [rows: 2][world][rows_cap][d] floats;
+// flags = uint64 [kind 0: theta, 1: rows][parity][world]
+int64_t peer_theta_slot(int d) { return ((int64_t)2 * sml_net_size(d) + 63) / 64 * 64; }
+float* peer_theta_at(const sml_ctx* c, int owner, int parity, int src) {
+    return reinterpret_cast<float*>(c->peer.inbox[owner]) + ((int64_t)parity * c->peer.world + src) * c->peer.theta_slot;
+}
+float* peer_rows_at(const sml_ctx* c, int owner, int parity, int src) {
+    float* base = reinterpret_cast<float*>(c->peer.inbox[owner]) + (int64_t)2 * c->peer.world * c->peer.theta_slot;
+    return base + ((int64_t)parity * c->peer.world + src) * c->peer.rows_cap * c->d;
+}
+unsigned long long* peer_flag_at(const sml_ctx* c, int owner, int kind, int parity, int src) {
+    return c->peer.flags[owner] + ((int64_t)kind * 2 + parity) * c->peer.world + src;
+}
+// descriptors of the next exchange step of `kind` (0 theta, 1 rows) in which every rank's counters grow by `incr`
+void peer_step(sml_ctx* c, int kind, int incr, SmlPeerPush* push, SmlPeerPoll* poll) {
+    const int W = c->peer.world, me = c->peer.rank;
+    const int parity = (int)(c->peer.tick[kind] & 1);
+    c->peer.tick[kind] += 1;
+    c->peer.expect[kind][parity] += (unsigned long long)incr;
+    memset(push, 0, sizeof(*push)); memset(poll, 0, sizeof(*poll));
+    push->world = W;
+    for (int q = 0; q < W; ++q) {
+        push->dst[q] = kind == 0 ? peer_theta_at(c, q, parity, me) : peer_rows_at(c, q, parity, me);
+        push->flag[q] = peer_flag_at(c, q, kind, parity, me);
+    }
+    poll->world = W;
+    poll->slot0 = kind == 0 ? peer_theta_at(c, me, parity, 0) : peer_rows_at(c, me, parity, 0);
+    poll->slot_stride = kind == 0 ? c->peer.theta_slot : c->peer.rows_cap * c->d;
+    poll->flag0 = peer_flag_at(c, me, kind, parity, 0);
+    poll->expect = c->peer.expect[kind][parity];
+    poll->timeout = c->peer.timeout;
+    poll->err = c->peer.err;
+}
 
 // selection predicate over sorted positions: q starts a run of at least two equal keys
 template <typename K>
@@ -526,8 +573,14 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
         return fail(SML_EINVAL, "sml_mf_stage_epoch", "loss_kind (SML_LOSS_BPR_UNIT goes with variant 1, and only it)");
     if (xchg && (xchg->world < 1 || !xchg->key_items || !xchg->val_items || !xchg->dx_local || !xchg->dx_items_all))
         return fail(SML_EINVAL, "sml_mf_stage_epoch", "incomplete exchange descriptor");
-    if (xchg && !xchg->hook && (!ctx->comm || ctx->comm_world != xchg->world))
-        return fail(SML_ESTATE, "sml_mf_stage_epoch", "exchange without a hook needs sml_comm_init with the same world size");
+    const bool mf_peers = xchg && !xchg->hook && ctx->peer.world > 0;
+    if (mf_peers && ctx->peer.world != xchg->world) return fail(SML_ESTATE, "sml_mf_stage_epoch", "peer mappings were attached for another world size");
+    if (mf_peers && (xchg->slot_stride > 0 ? xchg->slot_stride : (int64_t)2 * batch) != ctx->peer.rows_cap)
+        return fail(SML_EINVAL, "sml_mf_stage_epoch", "on the peer path the exchange's slot_stride must equal the rows_cap the inboxes were attached with");
+    if (mf_peers && (xchg->push_rows < 0 || xchg->push_rows > ctx->peer.rows_cap || (xchg->push_rows > 0 && xchg->push_rows < 2 * (int64_t)batch)))
+        return fail(SML_EINVAL, "sml_mf_stage_epoch", "push_rows must cover a batch's 2*batch item rows and fit a slot");
+    if (xchg && !xchg->hook && !mf_peers && (!ctx->comm || ctx->comm_world != xchg->world))
+        return fail(SML_ESTATE, "sml_mf_stage_epoch", "exchange without a hook needs sml_peer_attach or sml_comm_init with the same world size");
     DevGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     const int d = ctx->d;
@@ -602,8 +655,21 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
         if (xchg) {
             // every rank contributes x_stride rows per batch (its 2*B item-gradient rows first: B may differ from rank
             // to rank and be zero); an empty local batch still joins the collective
+            const float* gathered = xchg->dx_items_all;
             if (xchg->hook) {
                 if (xchg->hook(xchg->hook_user, b) != 0) return fail(SML_ESTATE, "sml_mf_stage_epoch", "exchange hook failed");
+            } else if (mf_peers) {
+                // one-shot: this rank's x_stride rows go straight into slot [parity][rank] of every rank's inbox; the row
+                // update starts once every rank's rows have landed here (the slots of one parity are the gathered buffer)
+                const int64_t ioff = (int64_t)SML_R * tiles_of(B);
+                SmlPeerPush push; SmlPeerPoll poll;
+                const int64_t x_push = xchg->push_rows > 0 ? xchg->push_rows : x_stride;     // (the same on every rank)
+                peer_step(ctx, 1, sml_peer_push_blocks(x_push * d), &push, &poll);
+                ctx->prof.begin(PC_MISC, st);
+                HIPCHK(sml_launch_peer_push(dx_buf + ioff * d, x_push * d, push, st));
+                HIPCHK(sml_launch_peer_wait(poll, st));
+                ctx->prof.end(st);
+                gathered = poll.slot0;
             } else {
                 const int64_t ioff = (int64_t)SML_R * tiles_of(B);
                 NCCLCHK(g_rccl.AllGather(dx_buf + ioff * d, xchg->dx_items_all, (size_t)x_stride * d, ncclFloat, ctx->comm, st));
@@ -612,7 +678,7 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
             u.run_i = ctx->rec_x.p + x0;
             u.val_i = xchg->val_items;
             u.n_i = xchg->item_off ? (int)(xchg->item_off[b + 1] - x0) : xchg->world * 2 * B;
-            u.dx_i = xchg->dx_items_all;
+            u.dx_i = gathered;
         }
         u.m_user = t->m_user; u.v_user = t->v_user; u.m_item = t->m_item; u.v_item = t->v_item;
         u.last_user = t->step_user; u.last_item = t->step_item; u.sched = ctx->sched.p; u.cur_step = cur; u.lr = lr;
@@ -704,7 +770,7 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
             q.dz1 = sg.dz1; q.a1 = ctx->a1.p + slot0 * SML_C2 * d; q.dout = sg.dout; q.a2 = ctx->a2.p + slot0 * SML_HID;
             // (one GPU, Adam fused into the weight-gradient kernel, no gradient buffer asked for: the flat gradient is
             // not written at all -- 0.8 MB less for the launch to leave dirty in L2)
-            const bool fused_only = !grad_hook && ctx->comm == nullptr && theta_grad == nullptr;
+            const bool fused_only = !grad_hook && (ctx->comm == nullptr || ctx->peer.world > 0) && theta_grad == nullptr;
             q.grad = fused_only ? nullptr : grad + s * ns; q.n_rows = sg.n_rows;
         }
         w.tiles0 = f.tiles0; w.l2 = 0.0f; w.convg_part = ctx->convg.p;
@@ -713,8 +779,20 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
         w.out_np = fns; w.out_pstride = out_pstride;
         ctx->prof.begin(PC_BWD, st); HIPCHK(sml_launch_bwd(d, bsplit, w, tiles, st)); ctx->prof.end(st);
         const SmlSched sc = sched_entry((double)lr, *step + 1 + b);
-        const bool native = !grad_hook && ctx->comm != nullptr;     // a communicator exists: exchange natively
-        if (!grad_hook && !native) {
+        const bool peers = !grad_hook && ctx->peer.world > 0;       // peer mappings attached: one-shot push / poll
+        const bool native = !grad_hook && !peers && ctx->comm != nullptr;     // a communicator exists: exchange natively
+        if (peers) {
+            // the weight-gradient workgroups store their finished tiles into every rank's inbox; the Adam launch polls
+            // this rank's counters and adds the slots in rank order
+            SmlThetaAdamArgs ad;
+            memset(&ad, 0, sizeof(ad));
+            peer_step(ctx, 0, sml_wgrad_grid(d), &wg.peer, &ad.peer);
+            wg.convg_part = ctx->convg.p; wg.tiles0 = f.tiles0 * cs; wg.tiles_total = tiles * cs;
+            ctx->prof.begin(PC_WGRAD, st); HIPCHK(sml_launch_wgrad(d, wg, st)); ctx->prof.end(st);
+            ad.theta = theta; ad.m = adam_m; ad.v = adam_v; ad.grad = grad; ad.pk = ctx->pk.p;
+            ad.weight_decay = weight_decay; ad.step_size = sc.step_size; ad.bc2_sqrt = sc.bc2_sqrt;
+            ctx->prof.begin(PC_THETA_ADAM, st); HIPCHK(sml_launch_theta_adam(d, ad, st)); ctx->prof.end(st);
+        } else if (!grad_hook && !native) {
             // one GPU: the weight-gradient workgroups take the Adam step for the tiles they own
             wg.theta = theta; wg.m = adam_m; wg.v = adam_v; wg.pk = ctx->pk.p;
             wg.convg_part = ctx->convg.p; wg.tiles0 = f.tiles0 * cs; wg.tiles_total = tiles * cs;
@@ -995,6 +1073,106 @@ int sml_comm_allgather(sml_ctx* ctx, const float* src, float* dst, int64_t n_per
     if (!ctx->comm) return fail(SML_ESTATE, "sml_comm_allgather", "no communicator");
     DevGuard g(ctx->device);
     NCCLCHK(g_rccl.AllGather(src, dst, (size_t)n_per_rank, ncclFloat, ctx->comm, (hipStream_t)stream));
+    return SML_OK;
+}
+
+// ---- one-shot exchange over peer mappings ------------------------------------------------------------------------
+int sml_peer_region_bytes(sml_ctx* ctx, int world, int64_t rows_cap, int64_t* inbox_bytes, int64_t* flags_bytes) {
+    if (!ctx || world < 1 || world > SML_MAX_PEERS || rows_cap < 0 || !inbox_bytes || !flags_bytes)
+        return fail(SML_EINVAL, "sml_peer_region_bytes", "bad argument");
+    *inbox_bytes = (int64_t)2 * world * (peer_theta_slot(ctx->d) + rows_cap * ctx->d) * (int64_t)sizeof(float);
+    *flags_bytes = (int64_t)2 * 2 * world * (int64_t)sizeof(unsigned long long);
+    return SML_OK;
+}
+int sml_peer_alloc(int device, int64_t bytes, void** ptr) {
+    if (!ptr || bytes <= 0) return fail(SML_EINVAL, "sml_peer_alloc", "bad argument");
+    DevGuard g(device);
+    void* p = nullptr;
+    // uncached device memory: stores from peers land in HBM and the owner's loads never hit a stale L2 line;
+    // fine-grained if the runtime refuses that flag; plain device memory as a last resort (one-device tests)
+    hipError_t e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained); }
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&p, (size_t)bytes); }
+    if (e != hipSuccess) return fail(SML_ENOMEM, "sml_peer_alloc", hipGetErrorString(e));
+    e = hipMemset(p, 0, (size_t)bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { (void)hipFree(p); return fail(SML_EHIP, "sml_peer_alloc", hipGetErrorString(e)); }
+    *ptr = p;
+    return SML_OK;
+}
+int sml_peer_free(int device, void* ptr) {
+    if (!ptr) return SML_OK;
+    DevGuard g(device);
+    HIPCHK(hipFree(ptr));
+    return SML_OK;
+}
+int sml_peer_export(void* ptr, void* handle64) {
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    if (!ptr || !handle64) return fail(SML_EINVAL, "sml_peer_export", "null argument");
+    hipIpcMemHandle_t h;
+    HIPCHK(hipIpcGetMemHandle(&h, ptr));
+    memcpy(handle64, &h, sizeof(h));
+    return SML_OK;
+}
+int sml_peer_open(int device, const void* handle64, void** ptr) {
+    if (!handle64 || !ptr) return fail(SML_EINVAL, "sml_peer_open", "null argument");
+    DevGuard g(device);
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, sizeof(h));
+    HIPCHK(hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess));
+    return SML_OK;
+}
+int sml_peer_close(int device, void* ptr) {
+    if (!ptr) return SML_OK;
+    DevGuard g(device);
+    HIPCHK(hipIpcCloseMemHandle(ptr));
+    return SML_OK;
+}
+int sml_peer_attach(sml_ctx* ctx, int world, int rank, void* const* inbox, void* const* flags, int64_t rows_cap, double timeout_s) {
+    if (!ctx || world < 1 || world > SML_MAX_PEERS || rank < 0 || rank >= world || !inbox || !flags || rows_cap < 0 || !(timeout_s > 0))
+        return fail(SML_EINVAL, "sml_peer_attach", "bad argument");
+    for (int q = 0; q < world; ++q)
+        if (!inbox[q] || !flags[q] || (uintptr_t)inbox[q] % 16 || (uintptr_t)flags[q] % 8)
+            return fail(SML_EINVAL, "sml_peer_attach", "every rank's inbox (16-byte aligned) and flags (8-byte aligned) are needed");
+    DevGuard g(ctx->device);
+    if (!ctx->peer.err) {
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&ctx->peer.err), sizeof(int)));
+        HIPCHK(hipMemset(ctx->peer.err, 0, sizeof(int)));
+    }
+    ctx->peer.world = world; ctx->peer.rank = rank;
+    for (int q = 0; q < SML_MAX_PEERS; ++q) {
+        ctx->peer.inbox[q] = q < world ? static_cast<char*>(inbox[q]) : nullptr;
+        ctx->peer.flags[q] = q < world ? static_cast<unsigned long long*>(flags[q]) : nullptr;
+    }
+    ctx->peer.theta_slot = peer_theta_slot(ctx->d);
+    ctx->peer.rows_cap = rows_cap;
+    ctx->peer.tick[0] = ctx->peer.tick[1] = 0;          // (the regions come zeroed from sml_peer_alloc: counters start at 0)
+    memset(ctx->peer.expect, 0, sizeof(ctx->peer.expect));
+    ctx->peer.timeout = (long long)(timeout_s * 1e8);   // wall_clock64: 100 MHz
+    return SML_OK;
+}
+int sml_peer_detach(sml_ctx* ctx) {
+    if (!ctx) return SML_OK;
+    ctx->peer.world = 0;
+    return SML_OK;
+}
+int sml_peer_status(sml_ctx* ctx, int* timeouts) {
+    if (!ctx || !timeouts) return fail(SML_EINVAL, "sml_peer_status", "null argument");
+    *timeouts = 0;
+    if (!ctx->peer.err) return SML_OK;
+    DevGuard g(ctx->device);
+    HIPCHK(hipMemcpy(timeouts, ctx->peer.err, sizeof(int), hipMemcpyDeviceToHost));
+    return SML_OK;
+}
+int sml_peer_allreduce_check(sml_ctx* ctx, const float* src, float* dst, int64_t n, void* stream) {
+    if (!ctx || !src || !dst || n <= 0 || n % 4 || n > 2 * sml_net_size(ctx->d)) return fail(SML_EINVAL, "sml_peer_allreduce_check", "bad argument (n: a multiple of 4 within the theta slot)");
+    if (ctx->peer.world <= 0) return fail(SML_ESTATE, "sml_peer_allreduce_check", "no peers attached");
+    DevGuard g(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    SmlPeerPush push; SmlPeerPoll poll;
+    peer_step(ctx, 0, sml_peer_push_blocks(n), &push, &poll);
+    HIPCHK(sml_launch_peer_push(src, n, push, st));
+    HIPCHK(sml_launch_peer_sum(dst, n, poll, st));
     return SML_OK;
 }
 

@@ -1289,6 +1289,45 @@ __global__ void k_flag_wait(int* flag, int value, long long timeout) {
         __builtin_amdgcn_s_sleep(32);
     }
 }
+// ---- one-shot exchange over peer mappings: generic push / wait / sum ------------------------------------------
+// push: n16 16-byte chunks of `src` into the same offsets of every destination slot, then one counter increment per
+// workgroup and destination.  The grid is a function of the size alone (every rank pushes the same size per step, so
+// every counter grows by the same amount per step on every rank).
+__global__ __launch_bounds__(256) void k_peer_push(const f32x4* __restrict__ src, long long n16, SmlPeerPush p) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) {
+        const f32x4 v = src[i];
+        for (int q = 0; q < p.world; ++q) peer_store16(p.dst[q] + 4 * i, v);
+    }
+    peer_signal(p);
+}
+__global__ __launch_bounds__(64) void k_peer_wait(SmlPeerPoll p) { peer_wait(p); }
+// dst[i] = slot 0 [i] + slot 1 [i] + ... in rank order (the start-up self-check of the theta path)
+__global__ __launch_bounds__(256) void k_peer_sum(float* __restrict__ dst, long long n, SmlPeerPoll p) {
+    peer_wait(p);
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float g = peer_load(p.slot0 + i);
+    for (int q = 1; q < p.world; ++q) g += peer_load(p.slot0 + q * p.slot_stride + i);
+    dst[i] = g;
+}
+int sml_peer_push_blocks(long long n_floats) {
+    long long nb = (n_floats / 4 + 1023) / 1024;      // four 16-byte chunks per thread
+    return (int)(nb < 1 ? 1 : nb > 256 ? 256 : nb);
+}
+hipError_t sml_launch_peer_push(const float* src, long long n_floats, const SmlPeerPush& p, hipStream_t st) {
+    k_peer_push<<<dim3(sml_peer_push_blocks(n_floats)), dim3(256), 0, st>>>(reinterpret_cast<const f32x4*>(src), n_floats / 4, p);
+    return hipGetLastError();
+}
+hipError_t sml_launch_peer_wait(const SmlPeerPoll& p, hipStream_t st) {
+    k_peer_wait<<<dim3(1), dim3(64), 0, st>>>(p);
+    return hipGetLastError();
+}
+hipError_t sml_launch_peer_sum(float* dst, long long n_floats, const SmlPeerPoll& p, hipStream_t st) {
+    k_peer_sum<<<dim3((unsigned)((n_floats + 255) / 256)), dim3(256), 0, st>>>(dst, n_floats, p);
+    return hipGetLastError();
+}
+
 hipError_t sml_launch_flag_set(int* flag, int value, hipStream_t st) {
     k_flag_set<<<dim3(1), dim3(1), 0, st>>>(flag, value);
     return hipGetLastError();

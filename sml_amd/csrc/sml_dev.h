@@ -146,3 +146,36 @@ __device__ __forceinline__ void adam_replay_w(float& p, float& m, float& v, int 
     const int wbase = upto - SML_SW + 1;
     for (int k = from + 1; k <= to; ++k) adam_zero_step(p, m, v, k >= wbase ? win[k - wbase] : sched[k]);
 }
+
+// ---- one-shot exchange over peer mappings: device side ------------------------------------------------------------
+// A pusher's data stores are system-scope write-through stores (on their way over xGMI while the kernel still
+// computes; nothing left dirty in this XCD's L2 for the release to walk); then fence + barrier + one counter
+// increment per destination.  A consumer polls its own counters (one lane per source rank), then acquires.
+__device__ __forceinline__ void peer_store(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void peer_store16(float* p, const f32x4& v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+template <typename P>
+__device__ __forceinline__ void peer_signal(const P& p) {          // every thread of the workgroup calls this
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0)        // (uniform index into the kernel-argument array: scalar loads, no private copy)
+        for (int q = 0; q < p.world; ++q) __hip_atomic_fetch_add(p.flag[q], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+template <typename P>
+__device__ __forceinline__ void peer_wait(const P& p) {            // every thread of the workgroup calls this
+    if ((int)threadIdx.x < p.world) {
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(p.flag0 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < p.expect) {
+            if (wall_clock64() - t0 > p.timeout) { atomicAdd(p.err, 1); break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+    __threadfence_system();
+}
+__device__ __forceinline__ float peer_load(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}

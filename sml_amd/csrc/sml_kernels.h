@@ -58,6 +58,23 @@ struct SmlBwdArgs {
     float* convg_part;       // TR stage: [tiles, SML_CG] per-tile compact conv1/conv2 gradient partials; else null
 };
 
+// ---- one-shot exchange over peer mappings (include/sml_hip.h, sml_peer_*) -------------------------------------
+// destinations of one push: rank q's slot for THIS rank's contribution and its arrival counter, for this step's parity
+struct SmlPeerPush {
+    int world;                                   // 0: off
+    float* dst[SML_MAX_PEERS];
+    unsigned long long* flag[SML_MAX_PEERS];
+};
+// sources of one poll: this rank's own slots / counters of this step's parity
+struct SmlPeerPoll {
+    int world;                                   // 0: off
+    const float* slot0; long long slot_stride;   // slot q at slot0 + q * slot_stride (floats)
+    const unsigned long long* flag0;             // [world]
+    unsigned long long expect;                   // counter value that completes this step
+    long long timeout;                           // 100 MHz ticks
+    int* err;                                    // incidents (consumers that gave up)
+};
+
 struct SmlWgSeg {
     const float* dz1; const float* a1; const float* dout; const float* a2;    // a2 = Gelu(z1), saved by the forward
     float* grad;             // this net's flat gradient block
@@ -71,11 +88,13 @@ struct SmlWgArgs {
     float* theta; float* m; float* v; float* pk;
     const float* convg_part; int tiles0, tiles_total;
     float weight_decay, step_size, bc2_sqrt;
+    SmlPeerPush peer;        // several GPUs: every finished gradient tile is also stored into the peers' inboxes
 };
 
 struct SmlThetaAdamArgs {
     float* theta; float* m; float* v; float* grad; float* pk;
     float weight_decay, step_size, bc2_sqrt;
+    SmlPeerPoll peer;        // several GPUs: the gradient is the rank-order sum of the inbox slots (grad is not read)
 };
 
 // mt row-tiles of 16 per workgroup; ns workgroups share a row tile (1, or SML_FWD_NS with mt = 1)
@@ -85,6 +104,12 @@ hipError_t sml_launch_bwd(int d, int split, const SmlBwdArgs& a, int tiles_total
 hipError_t sml_launch_wgrad(int d, const SmlWgArgs& a, hipStream_t st);
 hipError_t sml_launch_theta_adam(int d, const SmlThetaAdamArgs& a, hipStream_t st);
 hipError_t sml_launch_theta_pack(int d, const float* theta, float* pk, hipStream_t st);
+int sml_wgrad_grid(int d);                       // workgroups (= pushers) of one weight-gradient launch
+// generic push / wait / rank-order sum over peer mappings (mf_kernels.hip)
+int sml_peer_push_blocks(long long n_floats);
+hipError_t sml_launch_peer_push(const float* src, long long n_floats, const SmlPeerPush& p, hipStream_t st);
+hipError_t sml_launch_peer_wait(const SmlPeerPoll& p, hipStream_t st);
+hipError_t sml_launch_peer_sum(float* dst, long long n_floats, const SmlPeerPoll& p, hipStream_t st);
 hipError_t sml_launch_selftest(const float* A, const float* W, float* pk, float* out, hipStream_t st);
 
 // ---- mf_kernels.hip ------------------------------------------------------------------

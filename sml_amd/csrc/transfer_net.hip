@@ -1198,11 +1198,13 @@ __global__ __launch_bounds__(512) void k_transfer_wgrad(SmlWgArgs a) {
             }
             for (; t < t1; ++t) g += a.convg_part[(int64_t)t * SML_CG + tid];
             if (a.seg[net].grad) a.seg[net].grad[off] = g;    // the flat gradient is complete after this launch (null: nobody reads it)
+            for (int q = 0; q < a.peer.world; ++q) peer_store(a.peer.dst[q] + i, g);
             if (fuse) {
                 adam_apply(p, m, v, g + a.weight_decay * p, sc);
                 a.theta[i] = p; a.m[i] = m; a.v[i] = v;
             }
         }
+        if (a.peer.world > 0) peer_signal(a.peer);
         TL(7);
         TL_DONE();
         return;
@@ -1288,6 +1290,8 @@ __global__ __launch_bounds__(512) void k_transfer_wgrad(SmlWgArgs a) {
     __shared__ float wt[32][33];          // the tile's updated weights, for the operand-image refresh
     auto finish = [&](int off, float gsum, float p, float m, float v) -> float {
         if (g) g[off] = gsum;
+        // several GPUs: the finished value goes straight into slot [parity][this rank] of every rank's inbox
+        for (int q = 0; q < a.peer.world; ++q) peer_store(a.peer.dst[q] + (int64_t)net * NS + off, gsum);
         if (fuse) {
             const int64_t i = (int64_t)net * NS + off;
             adam_apply(p, m, v, gsum + a.weight_decay * p, sc);
@@ -1309,6 +1313,7 @@ __global__ __launch_bounds__(512) void k_transfer_wgrad(SmlWgArgs a) {
         for (int w8 = 0; w8 < 8; ++w8) s += csum[w8][tid];
         finish(boff, s, bp, bm, bv2);
     }
+    if (a.peer.world > 0) peer_signal(a.peer);
     if (!fuse) { TL_DONE(); return; }
     // Operand-image refresh.  A 32x32 weight tile is four whole (column tile, k-step) blocks of 64 lanes x 4 floats
     // in EACH of its two images (forward and backward GEMM), i.e. eight contiguous 1 KB runs: one coalesced
@@ -1352,14 +1357,27 @@ __global__ __launch_bounds__(256) void k_theta_pack(const float* __restrict__ th
     pack_store<D>(pk + (int64_t)net * sml_pk_size(D), off, theta[i]);
 }
 
-template <int D>
+template <int D, bool PEER>
 __global__ __launch_bounds__(256) void k_theta_adam(SmlThetaAdamArgs a) {
     constexpr int NS = sml_net_size(D);
+    // several GPUs, one-shot exchange: wait until every rank's gradient tiles have landed in this rank's inbox
+    if constexpr (PEER) peer_wait(a.peer);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= 2 * NS) return;
     const int net = i / NS, off = i % NS;
     if (off < SML_OFF_F1W && !conv_slot_used_host(off)) return;       // alignment padding of the conv block
-    float g = a.grad[i];                                              // complete (and all-reduced) flat gradient
+    float g;
+    if constexpr (PEER) {
+        // the slots are added IN RANK ORDER on every rank: bit-identical sums, hence bit-identical replicas
+        float x[SML_MAX_PEERS];
+#pragma unroll
+        for (int q = 0; q < SML_MAX_PEERS; ++q) x[q] = q < a.peer.world ? peer_load(a.peer.slot0 + q * a.peer.slot_stride + i) : 0.0f;
+        g = x[0];
+#pragma unroll
+        for (int q = 1; q < SML_MAX_PEERS; ++q) if (q < a.peer.world) g += x[q];
+    } else {
+        g = a.grad[i];                                                // complete (and all-reduced) flat gradient
+    }
     float p = a.theta[i], m = a.m[i], v = a.v[i];
     g = g + a.weight_decay * p;
     SmlSched s; s.step_size = a.step_size; s.bc2_sqrt = a.bc2_sqrt;
@@ -1437,15 +1455,19 @@ hipError_t sml_launch_bwd(int d, int split, const SmlBwdArgs& a, int tiles_total
     }
     return hipGetLastError();
 }
-hipError_t sml_launch_wgrad(int d, const SmlWgArgs& a, hipStream_t st) {
+int sml_wgrad_grid(int d) {
     const int tn = 16 * (SML_C2 * d / 32) + (d / 32) * 16;
     const int extra = 2;        // + one conv-parameter workgroup per net (sums the backward's partials; Adam when fused)
-    SML_DISPATCH_D(d, k_transfer_wgrad<DD><<<dim3(2 * tn + extra), dim3(512), 0, st>>>(a));
+    return 2 * tn + extra;
+}
+hipError_t sml_launch_wgrad(int d, const SmlWgArgs& a, hipStream_t st) {
+    SML_DISPATCH_D(d, k_transfer_wgrad<DD><<<dim3(sml_wgrad_grid(d)), dim3(512), 0, st>>>(a));
     return hipGetLastError();
 }
 hipError_t sml_launch_theta_adam(int d, const SmlThetaAdamArgs& a, hipStream_t st) {
     const int n = 2 * sml_net_size(d);
-    SML_DISPATCH_D(d, k_theta_adam<DD><<<dim3((n + 255) / 256), dim3(256), 0, st>>>(a));
+    if (a.peer.world > 0) { SML_DISPATCH_D(d, k_theta_adam<DD, true><<<dim3((n + 255) / 256), dim3(256), 0, st>>>(a)); }
+    else { SML_DISPATCH_D(d, k_theta_adam<DD, false><<<dim3((n + 255) / 256), dim3(256), 0, st>>>(a)); }
     return hipGetLastError();
 }
 hipError_t sml_launch_theta_pack(int d, const float* theta, float* pk, hipStream_t st) {
