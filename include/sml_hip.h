@@ -127,8 +127,8 @@ int sml_peer_detach(sml_ctx* ctx);
 int sml_peer_status(sml_ctx* ctx, int* timeouts);
 /* start-up self-check: every rank pushes n floats of `src` into all inboxes' theta slots and reads back the rank-order
  * sum of all ranks' pushes into dst (device, n floats; n <= 2 * sml_theta_net_size).  Consumes one theta exchange step:
- * every rank must call it the same number of times. */
-int sml_peer_allreduce_check(sml_ctx* ctx, const float* src, float* dst, int64_t n, void* stream);
+ * every rank must call it the same number of times.  timeout_s > 0 replaces the attach-time hang guard for this call. */
+int sml_peer_allreduce_check(sml_ctx* ctx, const float* src, float* dst, int64_t n, double timeout_s, void* stream);
 
 /* ---- a5/a6/a10: transfer net forward ------------------------------------------- */
 /* ConvTransfer_com.forward (model/conv_transfer.py:92-110) for `net` (0 = user

@@ -104,7 +104,7 @@ SIGNATURES = {
                                        ctypes.c_double]),
     "sml_peer_detach": (ctypes.c_int, [c_void]),
     "sml_peer_status": (ctypes.c_int, [c_void, ctypes.POINTER(ctypes.c_int)]),
-    "sml_peer_allreduce_check": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int64, c_void]),
+    "sml_peer_allreduce_check": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int64, ctypes.c_double, c_void]),
     "sml_prof_enable": (ctypes.c_int, [c_void, ctypes.c_int]),
     "sml_debug_timeline": (ctypes.c_int, [c_void]),
     "sml_prof_reset": (ctypes.c_int, [c_void]),

@@ -1164,13 +1164,14 @@ int sml_peer_status(sml_ctx* ctx, int* timeouts) {
     HIPCHK(hipMemcpy(timeouts, ctx->peer.err, sizeof(int), hipMemcpyDeviceToHost));
     return SML_OK;
 }
-int sml_peer_allreduce_check(sml_ctx* ctx, const float* src, float* dst, int64_t n, void* stream) {
+int sml_peer_allreduce_check(sml_ctx* ctx, const float* src, float* dst, int64_t n, double timeout_s, void* stream) {
     if (!ctx || !src || !dst || n <= 0 || n % 4 || n > 2 * sml_net_size(ctx->d)) return fail(SML_EINVAL, "sml_peer_allreduce_check", "bad argument (n: a multiple of 4 within the theta slot)");
     if (ctx->peer.world <= 0) return fail(SML_ESTATE, "sml_peer_allreduce_check", "no peers attached");
     DevGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     SmlPeerPush push; SmlPeerPoll poll;
     peer_step(ctx, 0, sml_peer_push_blocks(n), &push, &poll);
+    if (timeout_s > 0) poll.timeout = (long long)(timeout_s * 1e8);
     HIPCHK(sml_launch_peer_push(src, n, push, st));
     HIPCHK(sml_launch_peer_sum(dst, n, poll, st));
     return SML_OK;

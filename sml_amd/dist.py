@@ -51,20 +51,21 @@ def _sort_occurrences(keys, vals):
     return keys[order].contiguous(), vals[order].to(torch.int32).contiguous()
 
 
-def global_item_lists(all_triples, batch):
+def global_item_lists(all_triples, batch, stride=None):
     """Independent-shards mode.  all_triples int64 [world, n, 3] (same n on every rank) -> (keys uint64-as-int64
     [nb-major], vals int32): for every batch b the world*2*B_b item occurrences sorted (stably) by
-    (b << 32 | item row); value = slot in the gathered gradient buffer [world][2*batch][d]: rank q's positives at
-    q*2*batch + t, negatives at q*2*batch + B_b + t."""
+    (b << 32 | item row); value = slot in the gathered gradient buffer [world][stride][d] (stride = 2*batch unless
+    the buffer is an inbox with wider slots): rank q's positives at q*stride + t, negatives at q*stride + B_b + t."""
     world, n, _ = all_triples.shape
     dev = all_triples.device
     e = torch.arange(n, device=dev)
     b = e // batch
     Bb = torch.clamp(n - b * batch, max=batch)
     t = e - b * batch
+    stride = 2 * batch if stride is None else int(stride)
     keys, vals = [], []
     for q in range(world):
-        base = q * 2 * batch
+        base = q * stride
         keys += [(b << 32) | all_triples[q, :, 1], (b << 32) | all_triples[q, :, 2]]
         vals += [base + t, base + Bb + t]
     return _sort_occurrences(torch.cat(keys), torch.cat(vals))
@@ -114,7 +115,9 @@ class EpochRoute(object):
         in the gathered buffer [world][2*cap][d]: rank q's positives at q*2*cap + t, negatives at q*2*cap + B_{q,b}
         + t -- derived locally, plus the scratch and the gather hook."""
         ctx = self.ctx
-        stride = 2 * self.cap
+        push_rows = 2 * self.cap
+        # (peer path: the gathered buffer is one parity of this rank's inbox row slots, rows_cap rows per source rank)
+        stride = ctx.peer_stride(push_rows)
         cnt = self.counts[self._owner, self._b_of]
         base = self._owner * stride + self._t_in
         dev = ctx.device
@@ -135,7 +138,7 @@ class EpochRoute(object):
             ctx.all_gather_rows(dx_all[:ctx.world * stride * d], src)
 
         return dict(world=ctx.world, keys=keys, vals=vals, dx_local=dx_local, dx_all=dx_all,
-                    hook=None if ctx.native else hook, loss_scale=1.0, slot_stride=stride, item_off=item_off)
+                    hook=None if ctx.native else hook, loss_scale=1.0, slot_stride=stride, item_off=item_off, push_rows=push_rows)
 
 
 class DistContext(object):
@@ -147,7 +150,18 @@ class DistContext(object):
         self.device = torch.device(device)
         self._buf = {}
         self.native_gather = dist.get_backend(group) == "nccl"
-        self.native = False          # True: libsml_hip's own RCCL communicator does the per-batch exchange
+        self.native = False          # True: the library does the per-batch exchange itself (no host callback per batch)
+        self.mode = "torch"          # "peer": one-shot push / poll over peer mappings; "rccl": the library's own RCCL
+        #                              communicator; "torch": torch.distributed hooks
+        self.peer_rows_cap = 0
+
+    def peer_stride(self, rows):
+        """Slot stride of the gathered item-gradient buffer for `rows` rows per rank: the inbox geometry on the peer path."""
+        if self.mode != "peer":
+            return rows
+        if rows > self.peer_rows_cap:
+            raise ValueError("a batch contributes %d item rows per rank; the peer inboxes were sized for %d" % (rows, self.peer_rows_cap))
+        return self.peer_rows_cap
 
     # ---- loss scaling
     def loss_scale(self, loss_kind):
@@ -220,8 +234,8 @@ class DistContext(object):
         alli = torch.empty((self.world,) + tuple(items.shape), dtype=items.dtype, device=items.device)
         self.dist.all_gather(list(alli.unbind(0)), items, group=self.group)
         allt = torch.cat([torch.zeros((self.world, n, 1), dtype=items.dtype, device=items.device), alli], dim=2)
-        keys, vals = global_item_lists(allt, batch)
-        stride = 2 * batch
+        stride = self.peer_stride(2 * batch)
+        keys, vals = global_item_lists(allt, batch, stride)
         dx_local, dx_all = self.scratch(batch, stride, d)
         tile = 32
 
@@ -232,7 +246,7 @@ class DistContext(object):
 
         return dict(world=self.world, keys=keys, vals=vals, dx_local=dx_local, dx_all=dx_all,
                     hook=None if self.native else hook, loss_scale=self.loss_scale(loss_kind), slot_stride=stride,
-                    item_off=None)
+                    item_off=None, push_rows=2 * batch)
 
     # ---- bare a3 step (SGD): users sharded, items replicated, per-occurrence item-gradient rows all-gathered
     def bare_exchange(self, triples, batch, d, loss_kind=LOSS_BCE):
@@ -255,8 +269,10 @@ class DistContext(object):
             Bb = min(batch, n - b * batch)
             self.all_gather_rows(dx_all, dx_local[Bb * d:(Bb + 2 * batch) * d])
 
+        # (the replicated-items bare step is exchange-bound by design -- DESIGN.md section 6 -- and is not wired to the
+        # peer inboxes: RCCL when the library has a communicator, else the torch.distributed hook)
         return dict(world=self.world, items_all=items_all.contiguous(), dx_local=dx_local, dx_all=dx_all,
-                    hook=None if self.native else hook, loss_scale=self.loss_scale(loss_kind))
+                    hook=None if self.mode == "rccl" else hook, loss_scale=self.loss_scale(loss_kind))
 
     # ---- the real driver: a shared global epoch, split by user owner
     def route_epoch(self, global_tri, batch, n_user, mean_loss):
@@ -287,26 +303,87 @@ class DistContext(object):
             self.dist.broadcast(t, src=0, group=self.group)
 
 
-def attach(engine, state, dist, hp=None, group=None):
+def _gather_objects(dist, obj, group):
+    out = [None] * dist.get_world_size(group)
+    dist.all_gather_object(out, obj, group=group)
+    return out
+
+
+def peer_setup(engine, dist, group, rows_cap, timeout_s=None):
+    """Allocate this rank's inbox / flags regions, exchange them with every rank of `group` and attach (sml_peer_attach).
+    One process per GPU: the regions travel as hipIpc handles (dmabuf IPC: HSA_ENABLE_IPC_MODE_LEGACY=0 must be in the
+    environment) and are opened with lazy peer access.  Ranks that are threads of ONE process (tests on one GPU):
+    the raw addresses travel.  Ends with a start-up self-check: every rank pushes a pattern through the theta slots and
+    reads back the rank-order sum.  Returns True when this rank's check passed."""
+    import os
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("SML_PEER_TIMEOUT_S", "120"))
+    ib, fb = engine.peer_region_bytes(world, rows_cap)
+    inbox, flags = engine.peer_alloc(ib), engine.peer_alloc(fb)
+    same_process = dist.get_backend(group) == "threads"
+    if same_process:
+        got = _gather_objects(dist, (inbox, flags), group)
+        inboxes, flagses = [g[0] for g in got], [g[1] for g in got]
+    else:
+        got = _gather_objects(dist, (engine.peer_export(inbox), engine.peer_export(flags)), group)
+        inboxes = [inbox if q == rank else engine.peer_open(got[q][0]) for q in range(world)]
+        flagses = [flags if q == rank else engine.peer_open(got[q][1]) for q in range(world)]
+    engine.peer_attach(world, rank, inboxes, flagses, rows_cap, timeout_s=timeout_s)
+    dist.barrier(group=group)                 # every rank is attached before anybody pushes
+    n = 1024
+    src = torch.arange(n, device=engine.device, dtype=torch.float32) * 0.25 + float(rank + 1)
+    want = torch.arange(n, device=engine.device, dtype=torch.float32) * 0.25 * world + world * (world + 1) / 2.0
+    ok = True
+    for _ in range(2):                        # both parities; a short hang guard of its own
+        ok = bool(torch.equal(engine.peer_allreduce_check(src, timeout_s=min(timeout_s, 20.0)), want)) and ok
+    return ok and engine.peer_status() == 0
+
+
+def attach(engine, state, dist, hp=None, group=None, rows_cap=None):
     """Wire an engine (and a PeriodState) into the process group: theta and the item tables
-    are broadcast from rank 0 so that replicas start identical."""
+    are broadcast from rank 0 so that replicas start identical.
+
+    Who carries the per-batch exchange (SML_COMM = peer | rccl | torch; default peer):
+      peer    one-shot push / poll over peer mappings (sml_peer_*): no collective library on the data path;
+      rccl    the library's own RCCL communicator issues ncclAllReduce / ncclAllGather on the compute stream;
+      torch   torch.distributed hooks called from the library per batch.
+    Every rank runs the chosen path's start-up self-check; unless ALL ranks pass, the job falls back to the next one."""
     ctx = DistContext(dist, engine.device if hasattr(engine, "device") else "cpu", group)
     engine.dist = ctx
     engine.grad_hook = ctx.tr_grad_hook
-    # Prefer the native exchange (RCCL issued by the library on the compute stream, no host callback per
-    # batch); fall back to the torch.distributed hooks unless EVERY rank's communicator passed its check.
     import os
-    if hasattr(engine, "comm_init") and os.environ.get("SML_COMM", "rccl") == "rccl":
+    import sys
+    want = os.environ.get("SML_COMM", "peer")
+
+    def all_ok(ok):
+        flag = torch.tensor([1.0 if ok else 0.0], device=ctx.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        return bool(flag.item() > 0.5)
+
+    if want == "peer" and hasattr(engine, "peer_attach"):
+        if rows_cap is None:
+            rows_cap = 2 * int(hp.MF_batch_size) if hp is not None and hasattr(hp, "MF_batch_size") else 2 * int(engine.max_batch)
+        try:
+            ok = peer_setup(engine, dist, group, int(rows_cap))
+        except Exception as e:   # noqa: BLE001 -- any failure means: use the next path
+            print("[sml_amd.dist] peer-mapping exchange unavailable on rank %d: %s" % (ctx.rank, e), file=sys.stderr)
+            ok = False
+        if all_ok(ok):
+            ctx.mode, ctx.native, ctx.peer_rows_cap = "peer", True, int(rows_cap)
+            engine.grad_hook = None
+        else:
+            engine.peer_detach()
+            want = "rccl"
+    # the native RCCL exchange (issued by the library on the compute stream, no host callback per batch)
+    if ctx.mode == "torch" and want == "rccl" and hasattr(engine, "comm_init") and dist.get_backend(group) == "nccl":
         try:
             ok = engine.comm_init(dist, group)
         except Exception as e:   # noqa: BLE001 -- any failure means: use the hook path
-            import sys
             print("[sml_amd.dist] native RCCL exchange unavailable on rank %d: %s" % (ctx.rank, e), file=sys.stderr)
             ok = False
-        flag = torch.tensor([1.0 if ok else 0.0], device=ctx.device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-        ctx.native = bool(flag.item() > 0.5)
-        if ctx.native:
+        if all_ok(ok):
+            ctx.mode, ctx.native = "rccl", True
             engine.grad_hook = None
         elif ok:
             engine.comm_destroy()

@@ -148,7 +148,7 @@ class meta_train(object):
         self.transfer._sml_engine = self.engine
         if use_dist:
             from . import dist as smldist
-            self.dist = smldist.attach(self.engine, None, dist)
+            self.dist = smldist.attach(self.engine, None, dist, hp=args)
             theta = self.engine.adopt(self.transfer) if hasattr(self.engine, "adopt") else None
             # (every rank built theta and loaded the item table from the same seeds / file: the broadcast is a guard)
             self.dist.sync_replicas([self.MFbase.item_laten.weight.data] +

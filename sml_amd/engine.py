@@ -50,6 +50,10 @@ class HipEngine(object):
         if getattr(self, "_ctx", None):
             self.lib.sml_ctx_destroy(self._ctx)
             self._ctx = None
+            for p in self.__dict__.pop("_peer_opened", []):
+                self.lib.sml_peer_close(self.device.index, ctypes.c_void_p(p))
+            # (own regions are NOT freed here: a peer may still be writing into them; they go with the process,
+            # or explicitly through sml_peer_free once every rank has detached)
 
     def __del__(self):
         try:
@@ -258,6 +262,7 @@ class HipEngine(object):
                 ioff = np.ascontiguousarray(ioff, dtype=np.int64)
                 keep = (keep, ioff)
             x.item_off = ioff.ctypes.data if ioff is not None else None
+            x.push_rows = int(ex.get("push_rows", 0))
             xp = ctypes.byref(x)
         check(self.lib.sml_mf_stage_epoch(self._ctx, _ptr(theta), ctypes.byref(t), _ptr(tri), n, int(batch_size),
                                           float(lr), float(l2), self._loss_kind(bce, norm), ctypes.byref(step),
@@ -725,6 +730,55 @@ class HipEngine(object):
 
     def comm_destroy(self):
         self.lib.sml_comm_destroy(self._ctx)
+
+    # ------------------------------------------------------------------ one-shot exchange over peer mappings
+    def peer_region_bytes(self, world, rows_cap):
+        a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(self.lib.sml_peer_region_bytes(self._ctx, int(world), int(rows_cap), ctypes.byref(a), ctypes.byref(b)),
+              "sml_peer_region_bytes")
+        return a.value, b.value
+
+    def peer_alloc(self, nbytes):
+        """Zeroed device memory for an inbox / flags region (uncached or fine-grained: see sml_peer_alloc); an int address."""
+        p = ctypes.c_void_p()
+        check(self.lib.sml_peer_alloc(self.device.index, int(nbytes), ctypes.byref(p)), "sml_peer_alloc")
+        self.__dict__.setdefault("_peer_owned", []).append(p.value)
+        return p.value
+
+    def peer_export(self, ptr):
+        buf = ctypes.create_string_buffer(64)
+        check(self.lib.sml_peer_export(ctypes.c_void_p(ptr), buf), "sml_peer_export")
+        return bytes(buf.raw)
+
+    def peer_open(self, handle):
+        p = ctypes.c_void_p()
+        check(self.lib.sml_peer_open(self.device.index, ctypes.create_string_buffer(handle, 64), ctypes.byref(p)), "sml_peer_open")
+        self.__dict__.setdefault("_peer_opened", []).append(p.value)
+        return p.value
+
+    def peer_attach(self, world, rank, inbox, flags, rows_cap, timeout_s=60.0):
+        """inbox / flags: every rank's regions as addresses valid on THIS device (own allocations, sml_peer_open results,
+        or -- several ranks in one process -- the other ranks' allocations)."""
+        n = int(world)
+        a, b = (ctypes.c_void_p * n)(*[int(x) for x in inbox]), (ctypes.c_void_p * n)(*[int(x) for x in flags])
+        check(self.lib.sml_peer_attach(self._ctx, n, int(rank), a, b, int(rows_cap), float(timeout_s)), "sml_peer_attach")
+        self.peer_world, self.peer_rows_cap = n, int(rows_cap)
+
+    def peer_detach(self):
+        self.lib.sml_peer_detach(self._ctx)
+        self.peer_world = 0
+
+    def peer_status(self):
+        """Consumers that gave up waiting for a peer's push since attach (synchronous read)."""
+        n = ctypes.c_int(0)
+        check(self.lib.sml_peer_status(self._ctx, ctypes.byref(n)), "sml_peer_status")
+        return n.value
+
+    def peer_allreduce_check(self, src, timeout_s=0.0):
+        dst = torch.empty_like(src)
+        check(self.lib.sml_peer_allreduce_check(self._ctx, _ptr(src), _ptr(dst), src.numel(), float(timeout_s), self._stream()),
+              "sml_peer_allreduce_check")
+        return dst
 
     # ------------------------------------------------------------------ measurement
     def profile(self, on):

@@ -81,14 +81,21 @@ class ThreadGroup(object):
             torch.cuda.current_stream(t.device).synchronize()
         self._done()
 
+    def all_gather_object(self, out, obj, group=None):
+        got = self._exchange(obj)
+        out[:] = got
+        self._done()
+
     def broadcast_object_list(self, box, src=0, group=None):
         got = self._exchange(list(box))
         box[:] = got[src]
         self._done()
 
 
-def run_ranks(world, fn, *args):
-    """fn(rank, group, *args) on `world` threads; returns the list of results (re-raises the first failure)."""
+def run_ranks(world, fn, *args, streams=None):
+    """fn(rank, group, *args) on `world` threads; returns the list of results (re-raises the first failure).
+    streams: one torch stream per rank (e.g. CU-masked streams over disjoint compute units, so that kernels of one rank
+    that POLL for another rank's kernels can never keep those off the chip); default: a fresh stream per rank."""
     group = ThreadGroup(world)
     out, err = [None] * world, [None] * world
 
@@ -96,7 +103,7 @@ def run_ranks(world, fn, *args):
         group.bind(rank)
         try:
             if torch.cuda.is_available():
-                with torch.cuda.stream(torch.cuda.Stream()):
+                with torch.cuda.stream(streams[rank] if streams is not None else torch.cuda.Stream()):
                     out[rank] = fn(rank, group, *args)
                     torch.cuda.synchronize()
             else:

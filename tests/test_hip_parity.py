@@ -5,6 +5,8 @@ Tolerances: everything is fp32.  Forward values: 1e-4 relative (north_star).  Gr
 and Adam-updated tensors: max-norm / Adam-aware criteria of test_oracle_golden.py,
 because both the reference and any re-implementation carry fp32 cancellation noise.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -507,7 +509,7 @@ def test_exchange_path_on_one_rank_rccl_group_equals_plain_path(monkeypatch):
                             device_id=torch.device(DEV))
     try:
         outs = []
-        for use_dist in (False, "rccl", "torch"):
+        for use_dist in (False, "rccl", "torch", "peer"):
             monkeypatch.setenv("SML_COMM", use_dist or "rccl")
             eng = engine(32)
             lr, l2, B, _ = z["hp_mf"]
@@ -516,7 +518,7 @@ def test_exchange_path_on_one_rank_rccl_group_equals_plain_path(monkeypatch):
             net = make_transfer(d, z, prefix="theta0.", device=DEV)
             if use_dist:
                 ctx = SD.attach(eng, PeriodState(mf, net), dist)
-                assert ctx.native == (use_dist == "rccl")      # the library's own communicator passed its self-check
+                assert ctx.mode == use_dist and ctx.native == (use_dist != "torch")   # the chosen path passed its self-check
             tri = torch.from_numpy(z["mf_triples"][:200])
             lu, li = T(z["Wlast_user"], DEV), T(z["Wlast_item"], DEV)
             l1 = eng.mf_stage_epoch(mf, net, lu, li, tri, int(B), lr, l2)
@@ -525,8 +527,10 @@ def test_exchange_path_on_one_rank_rccl_group_equals_plain_path(monkeypatch):
             l2_ = eng.tr_stage_epoch(net, lu, li, hu, hi, tri[:, [0, 1, 2]], 16, 1e-3, 1e-4)
             outs.append((l1.cpu(), l2_.cpu(), hu.cpu(), hi.cpu(), eng.adopt(net).cpu().clone()))
         names = ("mf losses", "tr losses", "user table", "item table", "theta")
-        for name, a, b in zip(names, outs[1], outs[2]):
+        for name, a, b, c in zip(names, outs[1], outs[2], outs[3]):
             assert torch.equal(a, b), name                     # native RCCL == torch.distributed hooks, bit for bit
+            assert torch.equal(a, c), name                     # ... == one-shot push / poll over peer mappings (to itself)
+        assert eng.peer_status() == 0
         for name, a, b in zip(names, outs[0], outs[1]):
             if name in ("tr losses", "theta"):
                 # one GPU fuses the theta Adam step into the weight-gradient kernel, the hooked path runs
@@ -1135,11 +1139,14 @@ def test_planned_batches_of_unequal_size_vs_oracle(d):
         adam_close(g[4][k], o[4][k], 1e-3, 6, frac=0.99)
 
 
-def test_driver_on_a_forced_one_rank_rccl_group_matches_the_plain_driver(tmp_path, monkeypatch):
-    """The multi-GPU driver path end to end on ONE GPU: meta_train under a 1-rank RCCL group (owner routing, batch
-    plans, the job-wide item-occurrence list, all-gather of item-gradient rows, theta all-reduce, summed evaluation
-    counts -- all through the library's own communicator) must print what the plain driver prints on the same
-    six-period dataset: losses to 1e-4, recall / ndcg within 2 rank flips of the 160-row sets."""
+@pytest.mark.parametrize("comm", ["peer", "rccl"])
+def test_driver_on_a_forced_one_rank_rccl_group_matches_the_plain_driver(tmp_path, monkeypatch, comm):
+    """The multi-GPU driver path end to end on ONE GPU: meta_train under a 1-rank group (owner routing, batch
+    plans, the job-wide item-occurrence list, exchange of item-gradient rows, theta all-reduce, summed evaluation
+    counts -- through the one-shot peer exchange, and through the library's own RCCL communicator) must print what the
+    plain driver prints on the same six-period dataset: losses to 1e-4, recall / ndcg within 2 rank flips of the
+    160-row sets."""
+    monkeypatch.setenv("SML_COMM", comm)
     import contextlib
     import io
     import re
@@ -1179,7 +1186,8 @@ def test_driver_on_a_forced_one_rank_rccl_group_matches_the_plain_driver(tmp_pat
     try:
         monkeypatch.setenv("SML_FORCE_DIST", "1")
         routed, meta = run(dist)
-        assert meta.dist is not None and meta.dist.native        # the library's own RCCL communicator carried the exchange
+        assert meta.dist is not None and meta.dist.mode == comm  # the library itself carried the exchange
+        assert comm != "peer" or meta.engine.peer_status() == 0
     finally:
         dist.destroy_process_group()
     num = re.compile(r"-?\d+\.\d+(?:e-?\d+)?")
@@ -1194,15 +1202,26 @@ def test_driver_on_a_forced_one_rank_rccl_group_matches_the_plain_driver(tmp_pat
 
 
 # ----------------------------------------------------------------------------- world_size 2 on ONE GPU (thread ranks)
-def test_two_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run(monkeypatch):
+_TWO_RANK_RESULTS = {}
+
+
+@pytest.mark.parametrize("comm", ["torch", "peer"])
+def test_two_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run(monkeypatch, comm):
     """The real HIP library under world_size 2: two thread ranks (tests/_thread_group.py), each with its own engine,
     its own user shard and an item / theta replica, split every global batch by user owner (unequal local batches,
-    one of them EMPTY on rank 1), exchange item-gradient rows and theta gradients through the hook path, and must
-    land where ONE engine lands on the same global batches: losses add up to the global ones (1e-4), user shards and
-    item table within Adam's tolerance, item replicas and theta bit-identical between the ranks."""
+    one of them EMPTY on rank 1), exchange item-gradient rows and theta gradients, and must land where ONE engine
+    lands on the same global batches: losses add up to the global ones (1e-4), user shards and item table within
+    Adam's tolerance, item replicas and theta bit-identical between the ranks.
+      torch  the hook path (host rendezvous per batch; RCCL cannot put two ranks on one device);
+      peer   the ONE-SHOT exchange over peer mappings: the ranks' inboxes are same-process allocations handed to
+             sml_peer_attach as raw pointers, the ranks run on the two CU-masked streams (disjoint compute units: a
+             kernel polling for the other rank's push can never keep the pusher off the chip), nothing on the host
+             orders the two ranks' batches -- the weight-gradient kernel's pushes, the row pushes and the device-side
+             polls do.  Results must ALSO equal the hook path's bit for bit (same rank-order sums)."""
     from _thread_group import run_ranks
     from sml_amd import dist as SD
-    monkeypatch.setenv("SML_COMM", "torch")         # (RCCL cannot put two ranks on one device: the hook path carries the exchange)
+    monkeypatch.setenv("SML_COMM", comm)
+    monkeypatch.setenv("SML_PEER_TIMEOUT_S", "20")
     torch.manual_seed(5)
     U, I, d, B, n = 200, 120, 32, 64, 300
     wu, wi = torch.randn(U, d) * 0.3, torch.randn(I, d) * 0.3
@@ -1225,7 +1244,8 @@ def test_two_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run(monkey
 
     def rank_fn(rank, group):
         e = engine(d, B)
-        ctx = SD.attach(e, None, group)
+        ctx = SD.attach(e, None, group, rows_cap=2 * B)
+        assert ctx.mode == comm
         lo, hi_ = SD.user_range(U, 2, rank)
         m = make_mf(hi_ - lo, I, d, wu[lo:hi_].numpy(), wi.numpy(), device=DEV)
         net = make_transfer(d, device=DEV)
@@ -1237,10 +1257,23 @@ def test_two_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run(monkey
         e.mf_flush(m)
         hu_, hi2 = m.user_laten.weight.detach().clone(), m.item_laten.weight.detach().clone()
         b = e.tr_stage_epoch(net, lu[lo:hi_].to(DEV), li.to(DEV), hu_, hi2, route.local_tri, route.cap, 1e-3, 1e-4, plan=route.plan)
+        torch.cuda.current_stream().synchronize()
+        assert comm != "peer" or e.peer_status() == 0
         return dict(l_mf=a.cpu().numpy(), l_tr=b.cpu().numpy(), wu=hu_.cpu(), wi=hi2.cpu(),
                     theta={k: v.detach().cpu().clone() for k, v in net.state_dict().items()})
 
-    r0, r1 = run_ranks(2, rank_fn)
+    streams = None
+    if comm == "peer":
+        n_cu = eng._n_cus()
+        streams = [eng._masked_stream(0, n_cu // 2), eng._masked_stream(n_cu // 2, n_cu)]
+    r0, r1 = run_ranks(2, rank_fn, streams=streams)
+    _TWO_RANK_RESULTS[comm] = (r0, r1)
+    if len(_TWO_RANK_RESULTS) == 2:                 # one-shot peer exchange == hook path, bit for bit
+        for ra, rb in zip(_TWO_RANK_RESULTS["torch"], _TWO_RANK_RESULTS["peer"]):
+            assert torch.equal(ra["wi"], rb["wi"]) and torch.equal(ra["wu"], rb["wu"])
+            assert np.array_equal(ra["l_mf"], rb["l_mf"]) and np.array_equal(ra["l_tr"], rb["l_tr"])
+            for k in ra["theta"]:
+                assert torch.equal(ra["theta"][k], rb["theta"][k]), k
     assert torch.equal(r0["wi"], r1["wi"])
     for k in r0["theta"]:
         assert torch.equal(r0["theta"][k], r1["theta"][k]), k
@@ -1327,8 +1360,12 @@ def test_bare_step_exchange_on_a_one_rank_rccl_group_equals_the_plain_step():
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device(DEV))
     try:
         e = engine(d, B)
-        ctx = SD.attach(e, None, dist)
-        assert ctx.native
+        os.environ["SML_COMM"] = "rccl"
+        try:
+            ctx = SD.attach(e, None, dist)
+        finally:
+            del os.environ["SML_COMM"]
+        assert ctx.mode == "rccl"
         b_u, b_i = wu.clone().to(DEV), wi.clone().to(DEV)
         t = tri.to(DEV)
         lb = e.bare_epoch(b_u, b_i, t, B, 0.05, 1e-4, 1e-4, exchange=ctx.bare_exchange(t, B, d, 0)).cpu().numpy()
