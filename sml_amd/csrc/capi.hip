@@ -155,6 +155,7 @@ struct sml_ctx {
     // transfer-net workspaces, 3*B slots each
     Buf<float> out, dout, dx, xin, z1, a1, a2, dz1, mrep, vrep;
     Buf<float> pk, grad, convg, loss_part;
+    Buf<int> arrive;         // k_tr_wgrad2's tail-workgroup arrival counter (0 between launches)
     // Adam schedule of the MF optimiser
     Buf<SmlSched> sched;
     int sched_len = 0;
@@ -186,7 +187,7 @@ struct sml_ctx {
         prof.release();
         out.release(); dout.release(); dx.release(); xin.release(); z1.release(); a1.release(); a2.release(); dz1.release();
         mrep.release(); vrep.release();
-        pk.release(); grad.release(); convg.release(); loss_part.release();
+        pk.release(); grad.release(); convg.release(); loss_part.release(); arrive.release();
         ix[0].release(); ix[1].release();
         sched.release(); dummy.release(); rec_x.release();
         for (auto& r : sched_retired) { if (r.dev) (void)hipFree(r.dev); if (r.host) (void)hipHostFree(r.host); (void)hipEventDestroy(r.done); }
@@ -296,6 +297,7 @@ int ensure_transfer_ws(sml_ctx* c, int B, bool tr_stage) {
         HIPCHK(c->dz1.ensure(slots * SML_HID));
         HIPCHK(c->convg.ensure((slots / SML_TM + 4) * (d / 16) * SML_CG));   // one partial per backward workgroup
         HIPCHK(c->grad.ensure((size_t)2 * sml_net_size(c->d)));
+        if (!c->arrive.p) { HIPCHK(c->arrive.ensure(4)); HIPCHK(hipMemset(c->arrive.p, 0, 4 * sizeof(int))); }
     } else {
         HIPCHK(c->dx.ensure(slots * d));
         HIPCHK(c->mrep.ensure(slots * d)); HIPCHK(c->vrep.ensure(slots * d));
@@ -729,7 +731,10 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
     float* grad = theta_grad ? theta_grad : ctx->grad.p;
     const int fns = fwd_split(wg_tiles(batch, 1) + wg_tiles(2 * batch, 1)), bsplit = bwd_split(wg_tiles(batch, 1) + wg_tiles(2 * batch, 1));
     const int cs = bsplit ? d / 16 : 1;                                 // backward workgroups per row tile
-    const int lstride = (wg_tiles(batch, 1) + wg_tiles(2 * batch, 1)) * (d / 16);
+    // Restructured step (default): backward head (loss -> dOut -> dZ1) + ONE launch with the weight-gradient tiles and
+    // the rest of the backward beside them.  SML_TR_V2=0 runs the round-2 kernels (k_transfer_bwd + k_transfer_wgrad).
+    const bool v2 = env_int("SML_TR_V2", 1) != 0;
+    const int lstride = (wg_tiles(batch, 1) + wg_tiles(2 * batch, 1)) * (d / 16 > 4 ? d / 16 : 4);
     const int64_t out_pstride = (int64_t)SML_R * (tiles_of(batch) + tiles_of(2 * batch)) * d;
     HIPCHK(ctx->loss_part.ensure((size_t)nb * lstride));
     ctx->prof.begin(PC_PACK, st); HIPCHK(sml_launch_theta_pack(d, theta, ctx->pk.p, st)); ctx->prof.end(st);
@@ -772,13 +777,21 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
             // not written at all -- 0.8 MB less for the launch to leave dirty in L2)
             const bool fused_only = !grad_hook && (ctx->comm == nullptr || ctx->peer.world > 0) && theta_grad == nullptr;
             q.grad = fused_only ? nullptr : grad + s * ns; q.n_rows = sg.n_rows;
+            q.theta_net = sg.theta; q.pk_net = sg.pk; q.xin = sg.xin;
         }
         w.tiles0 = f.tiles0; w.l2 = 0.0f; w.convg_part = ctx->convg.p;
         w.out_all = ctx->out.p; w.B = B; w.ioff = SML_R * tiles_of(B); w.kind = loss_kind;
         w.scale = (plan && plan->loss_scale) ? plan->loss_scale[b] : loss_scale; w.loss_part = ctx->loss_part.p + b * lstride;
-        w.out_np = fns; w.out_pstride = out_pstride;
-        ctx->prof.begin(PC_BWD, st); HIPCHK(sml_launch_bwd(d, bsplit, w, tiles, st)); ctx->prof.end(st);
+        w.out_np = fns; w.out_pstride = out_pstride; w.tiles_total = tiles;
+        ctx->prof.begin(PC_BWD, st);
+        if (v2) HIPCHK(sml_launch_tr_bwd_head(d, w, tiles, st)); else HIPCHK(sml_launch_bwd(d, bsplit, w, tiles, st));
+        ctx->prof.end(st);
         const SmlSched sc = sched_entry((double)lr, *step + 1 + b);
+        // (v2: tiles0 / tiles_total count ROW tiles, the first n_tail workgroups are the backward's tail)
+        const int wcs = v2 ? 1 : cs;
+        auto launch_wgrad = [&](const SmlWgArgs& g) { return v2 ? sml_launch_tr_wgrad2(d, g, st) : sml_launch_wgrad(d, g, st); };
+        wg.convg_part = ctx->convg.p; wg.tiles0 = f.tiles0 * wcs; wg.tiles_total = tiles * wcs;
+        wg.n_tail = tiles * (d / 16) > 0 ? tiles * (d / 16) : 1; wg.convg_out = ctx->convg.p; wg.arrive = ctx->arrive.p;
         const bool peers = !grad_hook && ctx->peer.world > 0;       // peer mappings attached: one-shot push / poll
         const bool native = !grad_hook && !peers && ctx->comm != nullptr;     // a communicator exists: exchange natively
         if (peers) {
@@ -786,23 +799,20 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
             // this rank's counters and adds the slots in rank order
             SmlThetaAdamArgs ad;
             memset(&ad, 0, sizeof(ad));
-            peer_step(ctx, 0, sml_wgrad_grid(d), &wg.peer, &ad.peer);
-            wg.convg_part = ctx->convg.p; wg.tiles0 = f.tiles0 * cs; wg.tiles_total = tiles * cs;
-            ctx->prof.begin(PC_WGRAD, st); HIPCHK(sml_launch_wgrad(d, wg, st)); ctx->prof.end(st);
+            peer_step(ctx, 0, v2 ? sml_wgrad2_pushers(d) : sml_wgrad_grid(d), &wg.peer, &ad.peer);
+            ctx->prof.begin(PC_WGRAD, st); HIPCHK(launch_wgrad(wg)); ctx->prof.end(st);
             ad.theta = theta; ad.m = adam_m; ad.v = adam_v; ad.grad = grad; ad.pk = ctx->pk.p;
             ad.weight_decay = weight_decay; ad.step_size = sc.step_size; ad.bc2_sqrt = sc.bc2_sqrt;
             ctx->prof.begin(PC_THETA_ADAM, st); HIPCHK(sml_launch_theta_adam(d, ad, st)); ctx->prof.end(st);
         } else if (!grad_hook && !native) {
             // one GPU: the weight-gradient workgroups take the Adam step for the tiles they own
             wg.theta = theta; wg.m = adam_m; wg.v = adam_v; wg.pk = ctx->pk.p;
-            wg.convg_part = ctx->convg.p; wg.tiles0 = f.tiles0 * cs; wg.tiles_total = tiles * cs;
             wg.weight_decay = weight_decay; wg.step_size = sc.step_size; wg.bc2_sqrt = sc.bc2_sqrt;
-            ctx->prof.begin(PC_WGRAD, st); HIPCHK(sml_launch_wgrad(d, wg, st)); ctx->prof.end(st);
+            ctx->prof.begin(PC_WGRAD, st); HIPCHK(launch_wgrad(wg)); ctx->prof.end(st);
         } else {
             // the weight-gradient launch leaves the flat gradient complete (its conv workgroups sum the backward's
             // partials): all-reduce it, then one Adam launch
-            wg.convg_part = ctx->convg.p; wg.tiles0 = f.tiles0 * cs; wg.tiles_total = tiles * cs;
-            ctx->prof.begin(PC_WGRAD, st); HIPCHK(sml_launch_wgrad(d, wg, st)); ctx->prof.end(st);
+            ctx->prof.begin(PC_WGRAD, st); HIPCHK(launch_wgrad(wg)); ctx->prof.end(st);
             SmlThetaAdamArgs ad;
             memset(&ad, 0, sizeof(ad));
             ad.theta = theta; ad.m = adam_m; ad.v = adam_v; ad.grad = grad; ad.pk = ctx->pk.p;

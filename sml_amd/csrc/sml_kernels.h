@@ -56,6 +56,7 @@ struct SmlBwdArgs {
     int out_np; int64_t out_pstride;   // `out_all` is the sum of out_np planes, out_pstride floats apart
     float* loss_part;        // [tiles] this batch's per-workgroup loss partials
     float* convg_part;       // TR stage: [tiles, SML_CG] per-tile compact conv1/conv2 gradient partials; else null
+    int tiles_total;         // k_tr_bwd_head: row tiles of the batch (its grid is padded to the XCD map)
 };
 
 // ---- one-shot exchange over peer mappings (include/sml_hip.h, sml_peer_*) -------------------------------------
@@ -79,6 +80,7 @@ struct SmlWgSeg {
     const float* dz1; const float* a1; const float* dout; const float* a2;    // a2 = Gelu(z1), saved by the forward
     float* grad;             // this net's flat gradient block
     int n_rows;
+    const float* theta_net; const float* pk_net; const float* xin;   // k_tr_wgrad2's tail workgroups (dA1, tail, conv gradients)
 };
 struct SmlWgArgs {
     SmlWgSeg seg[2];
@@ -89,6 +91,10 @@ struct SmlWgArgs {
     const float* convg_part; int tiles0, tiles_total;
     float weight_decay, step_size, bc2_sqrt;
     SmlPeerPush peer;        // several GPUs: every finished gradient tile is also stored into the peers' inboxes
+    // k_tr_wgrad2: the first n_tail workgroups are the backward's tail (row tile tb / (d/16), coordinate slice tb % (d/16));
+    // tiles0 / tiles_total then count ROW tiles; `arrive` is a device counter (0 between launches) the tail
+    // workgroups use to elect the last arriver, which finishes the conv parameters
+    int n_tail; float* convg_out; int* arrive;
 };
 
 struct SmlThetaAdamArgs {
@@ -102,6 +108,10 @@ hipError_t sml_launch_fwd(int d, int mt, int ns, const SmlFwdArgs& a, int tiles_
 // split != 0: d/16 workgroups per row tile (coordinate split); 0: one workgroup per row tile
 hipError_t sml_launch_bwd(int d, int split, const SmlBwdArgs& a, int tiles_total, hipStream_t st);
 hipError_t sml_launch_wgrad(int d, const SmlWgArgs& a, hipStream_t st);
+// restructured TR step: backward head (loss -> dOut -> dZ1) and the merged weight-gradient + backward-tail launch
+hipError_t sml_launch_tr_bwd_head(int d, const SmlBwdArgs& a, int tiles_total, hipStream_t st);
+hipError_t sml_launch_tr_wgrad2(int d, const SmlWgArgs& a, hipStream_t st);
+int sml_wgrad2_pushers(int d);                   // counter increments one merged launch adds per destination (fixed)
 hipError_t sml_launch_theta_adam(int d, const SmlThetaAdamArgs& a, hipStream_t st);
 hipError_t sml_launch_theta_pack(int d, const float* theta, float* pk, hipStream_t st);
 int sml_wgrad_grid(int d);                       // workgroups (= pushers) of one weight-gradient launch

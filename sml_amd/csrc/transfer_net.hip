@@ -31,7 +31,7 @@ __device__ long long* g_timeline = nullptr;     // [0] = record counter, records
     atomicMax(reinterpret_cast<unsigned long long*>(tl + 2), (unsigned long long)now_); tl[tl_all + blockIdx.x] = now_; } } while (0)   /* per-workgroup end: the LAST launch of each kernel survives */
 #define TL_PREV() do { if (tl_rec) tl_rec[8] = (long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(g_timeline + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
 #else
-#define TL_BEGIN(KID) const int tl_all = 0; (void)tl_all
+#define TL_BEGIN(KID) const int tl_all = 0; (void)tl_all; long long* const tl_rec = nullptr; (void)tl_rec
 #define TL(i) do { } while (0)
 #define TL_DONE() do { } while (0)
 #define TL_PREV() do { } while (0)
@@ -1140,6 +1140,185 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
     TL_DONE();
 }
 
+// ------------------------------------------------------------------------------------
+// TR stage, restructured step (v2): the backward is cut where the weight gradients become computable.
+//   k_tr_bwd_head   pair loss -> dOut -> dA2 = dOut * W2 -> dZ1 = dA2 * Gelu'(z1): everything the weight-gradient
+//                   tiles need (dOut, dZ1), and nothing else.  HS = 4 workgroups per 16-row tile, one 128-column slice
+//                   of the hidden layer each (pair loss repeated, 16 KB of W2 per workgroup instead of 64 KB + 160 KB
+//                   of W1): 192 light workgroups for a 768-row batch.
+//   k_tr_wgrad2     ONE launch holds the weight-gradient tiles AND the rest of the backward -- dA1 = dZ1 * W1, the
+//                   per-coordinate tail and the conv1/conv2 parameter gradients, which in the TR stage feed nothing but
+//                   190 conv parameters -- as extra workgroups dispatched first.  The 5 us of dA1 + tail leave the
+//                   step's critical path: they run BESIDE the dW1 / dW2 tiles (two 512-thread workgroups fit a CU:
+//                   <= 128 VGPRs, 50 KB of LDS each).  The last tail workgroup to arrive sums the partials in index
+//                   order (deterministic) and takes the conv parameters' Adam step.
+// ------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(512) void k_tr_bwd_head(SmlBwdArgs a) {
+    constexpr int R = SML_TM;
+    constexpr int HS = 4;                 // hidden slices (workgroups) per row tile
+    constexpr int SD = D + 4;
+    constexpr int KSD = D / 16;
+    constexpr int EPT = R * D / 512;
+    static_assert(SML_HID / 16 / HS == 8, "one dA2 column tile per wave");
+    __shared__ __attribute__((aligned(16))) float smem[cmax(R * SD, 3 * R * (D + 1))];
+    __shared__ float cf[4][SML_TM];
+    __shared__ float lred[8];
+    float* dOs = smem;                    // [R][D+4]
+    float* O3 = smem;                     // d = 128: [3][R][D+1] score staging (dead before dOs is written)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+    TL_BEGIN(2); TL_PREV();
+    // same block -> (tile, slice) map as the hidden-split forward: slice hs on XCDs {2 hs, 2 hs + 1}
+    const int x8 = (int)blockIdx.x % 8;
+    const int hs = x8 / 2, tile = 2 * ((int)blockIdx.x / 8) + (x8 % 2);
+    if (tile >= a.tiles_total) return;
+    const int sidx = tile >= a.tiles0;
+    const SmlBwdSeg sg = sidx ? a.seg[1] : a.seg[0];
+    const int row0 = (tile - (sidx ? a.tiles0 : 0)) * R;
+    const f32x4* __restrict__ p2b = reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p2b(D));
+    const int ct = hs * 8 + wv;           // this wave's dA2 column tile
+    // ---- every global load first: the three out rows' planes, this wave's z1 fragment, its W2 operand image
+    float vu[EPT][SML_FWD_NS], vi[EPT][SML_FWD_NS], vn[EPT][SML_FWD_NS];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int e = q * 512 + tid, r = e / D, w = e % D;
+        const int row = row0 + r;
+        const bool inr = row < sg.n_rows;
+        const int t = !inr ? 0 : ((sg.is_item && row >= a.B) ? row - a.B : row);
+        const float* pu = a.out_all + (int64_t)t * D + w;
+        const float* pi = a.out_all + (int64_t)(a.ioff + t) * D + w;
+        const float* pn = a.out_all + (int64_t)(a.ioff + a.B + t) * D + w;
+#pragma unroll
+        for (int p = 0; p < SML_FWD_NS; ++p) {
+            const int64_t po = (int64_t)min(p, a.out_np - 1) * a.out_pstride;
+            vu[q][p] = pu[po]; vi[q][p] = pi[po]; vn[q][p] = pn[po];
+        }
+    }
+    float z[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) z[q] = sg.z1[(int64_t)(row0 + 4 * g4 + q) * SML_HID + ct * 16 + l15];
+    f32x4 ring[KSD];
+#pragma unroll
+    for (int ks = 0; ks < KSD; ++ks) ring[ks] = p2b[(ct * KSD + ks) * 64 + lane];
+    float ou[EPT], oi[EPT], on[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int e = q * 512 + tid, r = e / D, w = e % D;
+        const float inr = (row0 + r < sg.n_rows) ? 1.0f : 0.0f;
+        ou[q] = oi[q] = on[q] = 0.0f;
+#pragma unroll
+        for (int p = 0; p < SML_FWD_NS; ++p) {      // planes added in index order
+            const float live = p < a.out_np ? inr : 0.0f;
+            ou[q] += live * vu[q][p]; oi[q] += live * vi[q][p]; on[q] += live * vn[q][p];
+        }
+        if constexpr (D > 64) {
+            O3[(0 * R + r) * (D + 1) + w] = ou[q];
+            O3[(1 * R + r) * (D + 1) + w] = oi[q];
+            O3[(2 * R + r) * (D + 1) + w] = on[q];
+        }
+    }
+    float lsum = 0.0f;
+    auto coeffs = [&](float sp, float sn, float uu, float& lt, float& d0, float& d1, float& inv_nu, float& cc) {
+        inv_nu = 1.0f; cc = 0.0f;
+        if (a.kind == SML_LOSS_BPR_NORM || a.kind == SML_LOSS_BPR_UNIT) {
+            const float nu = sqrtf(uu);
+            inv_nu = 1.0f / nu;
+            cc = a.kind == SML_LOSS_BPR_NORM ? (sp - sn) / (nu * nu * nu) : 0.0f;
+            pair_terms(SML_LOSS_BPR, (sp - sn) * inv_nu, 0.0f, 1.0f, lt, d0, d1);
+            d1 = -d0;
+        } else {
+            pair_terms(a.kind, sp, sn, 1.0f / (float)a.B, lt, d0, d1);
+        }
+    };
+    auto dout_of = [&](int row, float d0, float d1, float inv_nu, float cc, float u, float i, float n) {
+        float g;
+        if (a.kind == SML_LOSS_BPR_NORM || a.kind == SML_LOSS_BPR_UNIT) {
+            if (!sg.is_item) g = d0 * ((i - n) * inv_nu - cc * u);
+            else g = ((row < a.B) ? d0 : d1) * u * inv_nu;
+        } else {
+            if (!sg.is_item) g = d0 * i + d1 * n;
+            else g = ((row < a.B) ? d0 : d1) * u;
+        }
+        return row >= sg.n_rows ? 0.0f : g;
+    };
+    if constexpr (D <= 64) {
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int e = q * 512 + tid, r = e / D, w = e % D;
+            const int row = row0 + r;
+            float sp = ou[q] * oi[q], sn = ou[q] * on[q], uu = ou[q] * ou[q];
+#pragma unroll
+            for (int off = D / 2; off >= 1; off >>= 1) {
+                sp += __shfl_xor(sp, off, 64); sn += __shfl_xor(sn, off, 64); uu += __shfl_xor(uu, off, 64);
+            }
+            float lt, d0, d1, inv_nu, cc;
+            coeffs(sp, sn, uu, lt, d0, d1, inv_nu, cc);
+            d0 *= a.scale; d1 *= a.scale;
+            if (!sg.is_item && hs == 0 && w == 0 && row < sg.n_rows) lsum += lt * a.scale;
+            const float g = dout_of(row, d0, d1, inv_nu, cc, ou[q], oi[q], on[q]);
+            dOs[r * SD + w] = g;
+            if (hs == 0) st_out<SML_WT_BWD>(&sg.dout[(int64_t)row * D + w], g);
+        }
+    } else {
+        __syncthreads();
+        if (tid < R) {
+            float sp = 0.f, sn = 0.f, uu = 0.f;
+#pragma unroll 8
+            for (int w = 0; w < D; ++w) {
+                const float u = O3[(0 * R + tid) * (D + 1) + w];
+                sp += u * O3[(1 * R + tid) * (D + 1) + w];
+                sn += u * O3[(2 * R + tid) * (D + 1) + w];
+                uu += u * u;
+            }
+            float lt, d0, d1, inv_nu, cc;
+            coeffs(sp, sn, uu, lt, d0, d1, inv_nu, cc);
+            cf[0][tid] = d0 * a.scale; cf[1][tid] = d1 * a.scale; cf[2][tid] = inv_nu; cf[3][tid] = cc;
+            if (!sg.is_item && hs == 0 && row0 + tid < sg.n_rows) lsum = lt * a.scale;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int e = q * 512 + tid, r = e / D, w = e % D;
+            const int row = row0 + r;
+            const float g = dout_of(row, cf[0][r], cf[1][r], cf[2][r], cf[3][r], ou[q], oi[q], on[q]);
+            dOs[r * SD + w] = g;
+            if (hs == 0) st_out<SML_WT_BWD>(&sg.dout[(int64_t)row * D + w], g);
+        }
+    }
+    __syncthreads();
+    TL(2);
+    // ---- dA2 tile = dOut[R x D] * W2[:, this tile] ; dZ1 = dA2 * Gelu'(z1)
+    {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSD; ++ks) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(dOs + l15 * SD + 4 * g4 + ks * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = mfma16(av[e], ring[ks][e], acc);
+        }
+        const int n = ct * 16 + l15;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            st_out<SML_WT_BWD>(&sg.dz1[(int64_t)(row0 + 4 * g4 + q) * SML_HID + n], acc[q] * sml_gelu_grad(z[q]));
+    }
+    TL(3);
+    {
+        float v = lsum;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) lred[wv] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float sacc = 0.0f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) sacc += lred[w8];
+        a.loss_part[tile * HS + hs] = sacc;
+        TL(7);
+    }
+    TL_DONE();
+}
+
 template <int D>
 __device__ __forceinline__ void pack_store(float* __restrict__ pk, int off, float p) {
     constexpr int K1 = SML_C2 * D;
@@ -1161,54 +1340,22 @@ __device__ __forceinline__ void pack_store(float* __restrict__ pk, int off, floa
 // of the tile's weights does not depend on the reduction, so it is fetched first and is in
 // registers by the time the gradient is complete.
 // ------------------------------------------------------------------------------------
+#define SML_WG_TILE_SMEM (8 * 32 * 33 + 8 * 32 + 32 * 33)     // floats of LDS one weight-gradient tile workgroup uses
+// one 32x32 weight-gradient tile (+ fused Adam + operand-image refresh): shared by k_transfer_wgrad and k_tr_wgrad2.
+// (xcd, kk): the XCD this workgroup runs on and its index among that XCD's tiles.
 template <int D>
-__global__ __launch_bounds__(512) void k_transfer_wgrad(SmlWgArgs a) {
+__device__ __forceinline__ void wgrad_tile(const SmlWgArgs& a, int xcd, int kk, float* smem_wg, long long* tl_rec) {
     constexpr int K1 = SML_C2 * D;
     constexpr int KT = K1 / 32;
     constexpr int JT = D / 32;
     constexpr int T1 = 16 * KT, T2 = JT * 16, TN = T1 + T2;
-    __shared__ float part[8][32][33];
-    TL_BEGIN(3); TL_PREV();
-    __shared__ float csum[8][32];
     constexpr int NS = sml_net_size(D);
+    float* part = smem_wg;                 // [8][32][33]
+    float* csum = smem_wg + 8 * 32 * 33;   // [8][32]
+    float* wt = csum + 8 * 32;             // [32][33] the tile's updated weights, for the operand-image refresh
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const bool fuse = a.theta != nullptr;
     SmlSched sc; sc.step_size = a.step_size; sc.bc2_sqrt = a.bc2_sqrt;
-    // Dispatch order = start order (the 194 workgroups start over ~1.3 us) and the work is uneven: the item net has
-    // twice the user net's rows, so its tiles run ~2 us longer, and the two conv-parameter workgroups are a serial
-    // chain of partial sums.  The long ones take the LOW block indices: conv workgroups first, then the item net's
-    // tiles, the user net's last (per-workgroup end times from the in-kernel timeline: median 6.4, max 8.7 us before).
-    if ((int)blockIdx.x < 2) {
-        // conv1/conv2 parameters of one net: sum the backward workgroups' partials in order, then Adam
-        const int net = (int)blockIdx.x;
-        if (tid < 95) {
-            const int off = tid < 30 ? tid : tid < 40 ? tid + 2 : tid < 90 ? tid + 4 : tid + 6;
-            const int t0 = net ? a.tiles0 : 0, t1 = net ? a.tiles_total : a.tiles0;
-            const int64_t i = (int64_t)net * NS + off;
-            float p = 0.f, m = 0.f, v = 0.f;
-            if (fuse) { p = a.theta[i]; m = a.m[i]; v = a.v[i]; }
-            float g = 0.0f;
-            int t = t0;
-            for (; t + 8 <= t1; t += 8) {
-                float x[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) x[u] = a.convg_part[(int64_t)(t + u) * SML_CG + tid];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) g += x[u];
-            }
-            for (; t < t1; ++t) g += a.convg_part[(int64_t)t * SML_CG + tid];
-            if (a.seg[net].grad) a.seg[net].grad[off] = g;    // the flat gradient is complete after this launch (null: nobody reads it)
-            for (int q = 0; q < a.peer.world; ++q) peer_store(a.peer.dst[q] + i, g);
-            if (fuse) {
-                adam_apply(p, m, v, g + a.weight_decay * p, sc);
-                a.theta[i] = p; a.m[i] = m; a.v[i] = v;
-            }
-        }
-        if (a.peer.world > 0) peer_signal(a.peer);
-        TL(7);
-        TL_DONE();
-        return;
-    }
     // XCD-aware tile map.  Every operand of this kernel was written by the previous launches on OTHER XCDs, so a
     // tile's first read of each operand line crosses the fabric; workgroup b runs on XCD b % 8 (observed
     // dispatch order: affinity only), so XCD x takes, for both nets, the dW1 tiles of hidden blocks {2x, 2x+1}
@@ -1216,7 +1363,6 @@ __global__ __launch_bounds__(512) void k_transfer_wgrad(SmlWgArgs a) {
     // each XCD pulls an eighth of the two big operands instead of nearly all of them
     static_assert(TN % 8 == 0 && T2 == 16 * JT, "tile map");
     constexpr int PER = 2 * (KT + JT);                 // tiles per XCD per net
-    const int xcd = (int)blockIdx.x % 8, kk = ((int)blockIdx.x - 2) / 8;    // (8 consecutive blocks: one per XCD)
     const int net = 1 - kk / PER, rr = kk % PER;
     const SmlWgSeg& sg = a.seg[net];
     const bool is_w1 = rr < 2 * KT;
@@ -1281,13 +1427,12 @@ __global__ __launch_bounds__(512) void k_transfer_wgrad(SmlWgArgs a) {
     }
     TL(2);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) part[wv][mfma32_row(q, lane)][l31] = acc[q];
+    for (int q = 0; q < 16; ++q) part[(wv * 32 + mfma32_row(q, lane)) * 33 + l31] = acc[q];
     colsum += __shfl_xor(colsum, 32, 64);
-    if (lane < 32) csum[wv][lane] = colsum;
+    if (lane < 32) csum[wv * 32 + lane] = colsum;
     __syncthreads();
     TL(3);
     float* __restrict__ g = sg.grad;
-    __shared__ float wt[32][33];          // the tile's updated weights, for the operand-image refresh
     auto finish = [&](int off, float gsum, float p, float m, float v) -> float {
         if (g) g[off] = gsum;
         // several GPUs: the finished value goes straight into slot [parity][this rank] of every rank's inbox
@@ -1304,17 +1449,17 @@ __global__ __launch_bounds__(512) void k_transfer_wgrad(SmlWgArgs a) {
         const int e = q * 512 + tid, i = e >> 5, j = e & 31;
         float s = 0.0f;
 #pragma unroll
-        for (int w8 = 0; w8 < 8; ++w8) s += part[w8][i][j];
-        wt[i][j] = finish(woff[q], s, wp[q], wm[q], wvv[q]);
+        for (int w8 = 0; w8 < 8; ++w8) s += part[(w8 * 32 + i) * 33 + j];
+        wt[i * 33 + j] = finish(woff[q], s, wp[q], wm[q], wvv[q]);
     }
     if (has_bias) {
         float s = 0.0f;
 #pragma unroll
-        for (int w8 = 0; w8 < 8; ++w8) s += csum[w8][tid];
+        for (int w8 = 0; w8 < 8; ++w8) s += csum[w8 * 32 + tid];
         finish(boff, s, bp, bm, bv2);
     }
     if (a.peer.world > 0) peer_signal(a.peer);
-    if (!fuse) { TL_DONE(); return; }
+    if (!fuse) return;
     // Operand-image refresh.  A 32x32 weight tile is four whole (column tile, k-step) blocks of 64 lanes x 4 floats
     // in EACH of its two images (forward and backward GEMM), i.e. eight contiguous 1 KB runs: one coalesced
     // 16-byte store per thread instead of four scattered 4-byte ones.
@@ -1328,17 +1473,249 @@ __global__ __launch_bounds__(512) void k_transfer_wgrad(SmlWgArgs a) {
         if (img == 0) {
             // forward image: columns = weight rows, reduction = weight columns
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = wt[ct * 16 + (l & 15)][ks * 16 + 4 * (l >> 4) + e];
+            for (int e = 0; e < 4; ++e) v[e] = wt[(ct * 16 + (l & 15)) * 33 + ks * 16 + 4 * (l >> 4) + e];
             const int ksteps = is_w1 ? K1 / 16 : SML_HID / 16;
             base = (is_w1 ? sml_pk_p1(D) : sml_pk_p2(D)) + ((int64_t)((r0 >> 4) + ct) * ksteps + ((c0 >> 4) + ks)) * 256;
         } else {
             // backward image: columns = weight columns, reduction = weight rows
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = wt[ks * 16 + 4 * (l >> 4) + e][ct * 16 + (l & 15)];
+            for (int e = 0; e < 4; ++e) v[e] = wt[(ks * 16 + 4 * (l >> 4) + e) * 33 + ct * 16 + (l & 15)];
             const int ksteps = is_w1 ? SML_HID / 16 : D / 16;
             base = (is_w1 ? sml_pk_p1b(D) : sml_pk_p2b(D)) + ((int64_t)((c0 >> 4) + ct) * ksteps + ((r0 >> 4) + ks)) * 256;
         }
         st_out16_wt(pkn + base + l * 4, v);      // (write-through: the next forward reads these from other XCDs)
+    }
+    TL(7);
+}
+
+template <int D>
+__global__ __launch_bounds__(512) void k_transfer_wgrad(SmlWgArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem_wg[SML_WG_TILE_SMEM];
+    TL_BEGIN(3); TL_PREV();
+    constexpr int NS = sml_net_size(D);
+    const int tid = threadIdx.x;
+    const bool fuse = a.theta != nullptr;
+    SmlSched sc; sc.step_size = a.step_size; sc.bc2_sqrt = a.bc2_sqrt;
+    // Dispatch order = start order (the 194 workgroups start over ~1.3 us) and the work is uneven: the item net has
+    // twice the user net's rows, so its tiles run ~2 us longer, and the two conv-parameter workgroups are a serial
+    // chain of partial sums.  The long ones take the LOW block indices: conv workgroups first, then the item net's
+    // tiles, the user net's last (per-workgroup end times from the in-kernel timeline: median 6.4, max 8.7 us before).
+    if ((int)blockIdx.x < 2) {
+        // conv1/conv2 parameters of one net: sum the backward workgroups' partials in order, then Adam
+        const int net = (int)blockIdx.x;
+        if (tid < 95) {
+            const int off = tid < 30 ? tid : tid < 40 ? tid + 2 : tid < 90 ? tid + 4 : tid + 6;
+            const int t0 = net ? a.tiles0 : 0, t1 = net ? a.tiles_total : a.tiles0;
+            const int64_t i = (int64_t)net * NS + off;
+            float p = 0.f, m = 0.f, v = 0.f;
+            if (fuse) { p = a.theta[i]; m = a.m[i]; v = a.v[i]; }
+            float g = 0.0f;
+            int t = t0;
+            for (; t + 8 <= t1; t += 8) {
+                float x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = a.convg_part[(int64_t)(t + u) * SML_CG + tid];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) g += x[u];
+            }
+            for (; t < t1; ++t) g += a.convg_part[(int64_t)t * SML_CG + tid];
+            if (a.seg[net].grad) a.seg[net].grad[off] = g;    // the flat gradient is complete after this launch (null: nobody reads it)
+            for (int q = 0; q < a.peer.world; ++q) peer_store(a.peer.dst[q] + i, g);
+            if (fuse) {
+                adam_apply(p, m, v, g + a.weight_decay * p, sc);
+                a.theta[i] = p; a.m[i] = m; a.v[i] = v;
+            }
+        }
+        if (a.peer.world > 0) peer_signal(a.peer);
+        TL(7);
+        TL_DONE();
+        return;
+    }
+    wgrad_tile<D>(a, (int)blockIdx.x % 8, ((int)blockIdx.x - 2) / 8, smem_wg, tl_rec);    // (8 consecutive blocks: one per XCD)
+    TL_DONE();
+}
+
+// The merged launch of the restructured TR step (see k_tr_bwd_head).  Workgroups [0, n_tail) are the backward's
+// tail -- they have the longest chain and are dispatched first --, the rest are the weight-gradient tiles.
+template <int D>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_tr_wgrad2(SmlWgArgs a) {
+    constexpr int R = SML_TM;
+    constexpr int CS = D / 16;
+    constexpr int S2 = SML_HID + 4;
+    constexpr int PSTR = SML_C2 * 16 + 1;
+    constexpr int CGS = 20;
+    constexpr int SZ0 = cmax(cmax(R * S2, 8 * R * PSTR), 2 * 256 * CGS);
+    constexpr int TAIL_SMEM = SZ0 + 104 + 8 * 256;
+    constexpr int NS = sml_net_size(D);
+    __shared__ __attribute__((aligned(16))) float smem[cmax(TAIL_SMEM, SML_WG_TILE_SMEM)];
+    __shared__ int s_last;
+    TL_BEGIN(3); TL_PREV();
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+    if ((int)blockIdx.x >= a.n_tail) {
+        const int vb = (int)blockIdx.x - a.n_tail;
+        wgrad_tile<D>(a, (int)blockIdx.x % 8, vb / 8, smem, tl_rec);
+        TL_DONE();
+        return;
+    }
+    // ---------------- tail role: dA1 = dZ1 * W1[:, slice], per-coordinate tail, conv-gradient partial
+    float* dZs = smem;                    // [R][516]
+    float* part = smem;                   // [8][R][81], aliases dZs after the GEMM
+    float* cgA = smem;                    // [256][CGS], aliases part after the tail
+    float* cgB = smem + 256 * CGS;
+    float* cws = smem + SZ0;
+    float* red = smem + SZ0 + 104;        // [8][256]
+    const int tb = (int)blockIdx.x;
+    const int tile = tb / CS, cs = tb % CS;
+    const bool live = tile < a.tiles_total;         // (an empty batch still has one tail workgroup: it elects itself)
+    if (live) {
+        const int sidx = tile >= a.tiles0;
+        const SmlWgSeg sg = sidx ? a.seg[1] : a.seg[0];
+        const int row0 = (tile - (sidx ? a.tiles0 : 0)) * R;
+        if (tid < 104) cws[tid] = sg.theta_net[tid];
+        const int tr_ = tid >> 4, twl = tid & 15, tw = cs * 16 + twl;       // tail element of threads 0..255
+        float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+        if (tid < 256) {
+            const float* x = sg.xin + (int64_t)(row0 + tr_) * 3 * D;
+            x0 = x[tw]; x1 = x[D + tw]; x2 = x[2 * D + tw];
+        }
+        {   // the tile's dZ1 rows (written by k_tr_bwd_head, whole tiles) -> LDS: 16 x 512 floats, four 16-byte loads per thread
+            f32x4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = i * 512 + tid, r = idx >> 7, c4 = idx & 127;
+                v[i] = *reinterpret_cast<const f32x4*>(sg.dz1 + (int64_t)(row0 + r) * SML_HID + c4 * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = i * 512 + tid, r = idx >> 7, c4 = idx & 127;
+                *reinterpret_cast<f32x4*>(dZs + r * S2 + c4 * 4) = v[i];
+            }
+        }
+        __syncthreads();
+        Pro pt;
+        float gg2[SML_C2], gg1[SML_C1];
+        if (tid < 256) {
+            conv_prologue(cws, x0, x1, x2, pt);
+#pragma unroll
+            for (int c = 0; c < SML_C2; ++c) gg2[c] = sml_gelu_grad(pt.h2p[c]);
+#pragma unroll
+            for (int c = 0; c < SML_C1; ++c) gg1[c] = sml_gelu_grad(pt.h1p[c]);
+        }
+        {   // dA1[R x 5*16]: every wave takes 4 of the 32 k-steps, all 5 channels
+            const f32x4* __restrict__ p1b = reinterpret_cast<const f32x4*>(sg.pk_net + sml_pk_p1b(D));
+            f32x4 acc[1][5];
+            zero_acc(acc);
+            mma16_rows<1, 5, 4, 2>(acc, dZs + l15 * S2 + 4 * g4, 0, p1b, 32, wv * 4, lane, [cs](int t) { return t * (D / 16) + cs; });
+            __syncthreads();                        // every wave is done reading dZs
+#pragma unroll
+            for (int t = 0; t < 5; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) part[(wv * R + 4 * g4 + q) * PSTR + t * 16 + l15] = acc[0][t][q];
+        }
+        __syncthreads();
+        float cga[16], cgb[16];
+        if (tid < 256) {
+            const bool ok = row0 + tr_ < sg.n_rows;
+            float dh2p[SML_C2];
+#pragma unroll
+            for (int c = 0; c < SML_C2; ++c) {
+                float s2 = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s2 += part[(k * R + tr_) * PSTR + c * 16 + twl];
+                dh2p[c] = s2 * gg2[c];
+            }
+            float dh1p[SML_C1];
+#pragma unroll
+            for (int c = 0; c < SML_C1; ++c) {
+                float s2 = 0.0f;
+#pragma unroll
+                for (int o = 0; o < SML_C2; ++o) s2 += dh2p[o] * cws[SML_OFF_C2W + o * SML_C1 + c];
+                dh1p[c] = s2 * gg1[c];
+            }
+            // G[i][j] = sum_e A[e][i] * B[e][j],  A[e] = (dh1p[0..9], dh2p[0..4], 0),  B[e] = (x0, x1, x2, 1, h1[0..9], 0, 0)
+#pragma unroll
+            for (int c = 0; c < SML_C1; ++c) { cga[c] = ok ? dh1p[c] : 0.0f; cgb[4 + c] = pt.h1[c]; }
+#pragma unroll
+            for (int o = 0; o < SML_C2; ++o) cga[10 + o] = ok ? dh2p[o] : 0.0f;
+            cga[15] = 0.0f;
+            cgb[0] = x0; cgb[1] = x1; cgb[2] = x2; cgb[3] = 1.0f; cgb[14] = 0.0f; cgb[15] = 0.0f;
+        }
+        __syncthreads();                            // the dA1 partials are in registers by now
+        if (tid < 256) {
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                f32x4 va, vb4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { va[e] = cga[i4 * 4 + e]; vb4[e] = cgb[i4 * 4 + e]; }
+                *reinterpret_cast<f32x4*>(cgA + tid * CGS + i4 * 4) = va;
+                *reinterpret_cast<f32x4*>(cgB + tid * CGS + i4 * 4) = vb4;
+            }
+        }
+        __syncthreads();
+        {
+            const int e0 = 64 * (wv & 3) + 32 * (wv >> 2);
+            float av[8], bv[8];
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) {
+                av[s8] = cgA[(e0 + 4 * s8 + g4) * CGS + l15];
+                bv[s8] = cgB[(e0 + 4 * s8 + g4) * CGS + l15];
+            }
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) acc = mfma16(av[s8], bv[s8], acc);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[wv * 256 + (4 * g4 + q) * 16 + l15] = acc[q];
+        }
+        __syncthreads();
+        if (tid < 95) {
+            int i, j;
+            if (tid < 30) { i = tid / 3; j = tid % 3; }
+            else if (tid < 40) { i = tid - 30; j = 3; }
+            else if (tid < 90) { i = 10 + (tid - 40) / 10; j = 4 + (tid - 40) % 10; }
+            else { i = 10 + (tid - 90); j = 3; }
+            float sacc = 0.0f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) sacc += red[w8 * 256 + i * 16 + j];
+            st_out<2>(&a.convg_out[(int64_t)tb * SML_CG + tid], sacc);
+        }
+    }
+    TL(4);
+    // ---- elect the last tail workgroup: it adds the partials in index order (deterministic) and finishes the conv parameters
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = (atomicAdd(a.arrive, 1) == a.n_tail - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) { TL_DONE(); return; }
+    __threadfence();
+    {
+        const bool fuse = a.theta != nullptr;
+        SmlSched sc; sc.step_size = a.step_size; sc.bc2_sqrt = a.bc2_sqrt;
+        const int net = tid >> 7, k = tid & 127;        // threads 0..94: user net, 128..222: item net
+        if (tid < 256 && k < 95) {
+            const int off = k < 30 ? k : k < 40 ? k + 2 : k < 90 ? k + 4 : k + 6;
+            const int t0 = (net ? a.tiles0 : 0) * CS, t1 = (net ? a.tiles_total : a.tiles0) * CS;
+            const int64_t i = (int64_t)net * NS + off;
+            float p = 0.f, m = 0.f, v = 0.f;
+            if (fuse) { p = a.theta[i]; m = a.m[i]; v = a.v[i]; }
+            float g = 0.0f;
+            int t = t0;
+            for (; t + 8 <= t1; t += 8) {
+                float x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = __hip_atomic_load(&a.convg_out[(int64_t)(t + u) * SML_CG + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) g += x[u];
+            }
+            for (; t < t1; ++t) g += __hip_atomic_load(&a.convg_out[(int64_t)t * SML_CG + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.seg[net].grad) a.seg[net].grad[off] = g;
+            for (int q = 0; q < a.peer.world; ++q) peer_store(a.peer.dst[q] + i, g);
+            if (fuse) {
+                adam_apply(p, m, v, g + a.weight_decay * p, sc);
+                a.theta[i] = p; a.m[i] = m; a.v[i] = v;
+            }
+        }
+        if (tid == 0) *a.arrive = 0;                  // ready for the next launch (ordered by the kernel boundary)
+        if (a.peer.world > 0) peer_signal(a.peer);
     }
     TL(7);
     TL_DONE();
@@ -1453,6 +1830,18 @@ hipError_t sml_launch_bwd(int d, int split, const SmlBwdArgs& a, int tiles_total
         if (a.convg_part != nullptr) { SML_DISPATCH_D(d, k_transfer_bwd_full<DD, 1, true><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }
         else { SML_DISPATCH_D(d, k_transfer_bwd_full<DD, 1, false><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }
     }
+    return hipGetLastError();
+}
+int sml_wgrad_grid(int d);
+hipError_t sml_launch_tr_bwd_head(int d, const SmlBwdArgs& a, int tiles_total, hipStream_t st) {
+    if (tiles_total <= 0) return hipSuccess;
+    SML_DISPATCH_D(d, k_tr_bwd_head<DD><<<dim3(((tiles_total + 1) / 2) * 8), dim3(512), 0, st>>>(a));
+    return hipGetLastError();
+}
+int sml_wgrad2_pushers(int d) { return sml_wgrad_grid(d) - 2 + 1; }      // every tile workgroup + the last tail workgroup
+hipError_t sml_launch_tr_wgrad2(int d, const SmlWgArgs& a, hipStream_t st) {
+    const int tiles = sml_wgrad_grid(d) - 2;
+    SML_DISPATCH_D(d, k_tr_wgrad2<DD><<<dim3(a.n_tail + tiles), dim3(512), 0, st>>>(a));
     return hipGetLastError();
 }
 int sml_wgrad_grid(int d) {

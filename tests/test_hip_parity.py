@@ -1069,12 +1069,16 @@ def test_yelp_shape_period_stages_at_full_size():
     _stage_check_at_scale(U=60000, I=123000, n=75000, d=32, mf_batch=1024, tr_batch=256, neg=999, seed=34)
 
 
-@pytest.mark.parametrize("d,B,env", [(32, 768, {}), (64, 768, {}), (128, 704, {}), (64, 48, {"SML_BWD_PRE": "0"}),
-                                     (64, 48, {"SML_BWD_PRE": "1"}), (32, 48, {"SML_BWD_SPLIT": "0"}), (64, 700, {"SML_BWD_SPLIT": "1"})])
+@pytest.mark.parametrize("d,B,env", [(32, 768, {}), (64, 768, {}), (128, 704, {}), (32, 48, {}), (64, 100, {}), (128, 17, {}),
+                                     (32, 768, {"SML_TR_V2": "0"}), (64, 48, {"SML_TR_V2": "0", "SML_BWD_PRE": "0"}),
+                                     (64, 48, {"SML_TR_V2": "0", "SML_BWD_PRE": "1"}), (32, 48, {"SML_TR_V2": "0", "SML_BWD_SPLIT": "0"}),
+                                     (64, 700, {"SML_TR_V2": "0", "SML_BWD_SPLIT": "1"}), (128, 704, {"SML_TR_V2": "0"})])
 def test_tr_stage_every_backward_geometry_vs_oracle(d, B, env, monkeypatch):
-    """The TR-stage backward has several launch geometries (one workgroup per row tile once the row tiles fill the
-    chip -- TR batches above ~680 triples --, the coordinate split below that, operand rings preloaded or fetched
-    on demand at d = 64): each one against the oracle, theta after two batches included."""
+    """The TR-stage step has several launch geometries: the restructured step (default: backward head + one launch with
+    the weight-gradient tiles and the backward's tail beside them), and the round-2 kernels behind SML_TR_V2=0 (one
+    workgroup per row tile once the row tiles fill the chip -- TR batches above ~680 triples --, the coordinate split
+    below that, operand rings preloaded or fetched on demand at d = 64): each one against the oracle, theta after two
+    batches (the second one ragged) included."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     torch.manual_seed(7 * d + B)

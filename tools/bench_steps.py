@@ -27,6 +27,9 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--tr-batch", type=int, default=256)
     ap.add_argument("--mf-batch", type=int, default=1024)
+    ap.add_argument("--comm", default="none", choices=["none", "peer", "rccl", "torch"],
+                    help="drive the multi-GPU exchange path on a forced 1-rank group: the per-step overhead of each carrier "
+                         "(peer: one-shot push / poll into the rank's own inbox; rccl: the library's communicator; torch: hooks)")
     a = ap.parse_args()
     import contextlib
     import io
@@ -45,6 +48,15 @@ def main():
         net = ConvTransfer_com(a.d, a.d)
     mf, net = mf.to(dev), net.to(dev)
     eng.adopt(net)
+    if a.comm != "none":
+        import socket
+        import torch.distributed as dist
+        from sml_amd import dist as SD
+        os.environ["SML_COMM"] = a.comm
+        s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+        ctx = SD.attach(eng, None, dist, rows_cap=2 * a.mf_batch)
+        assert ctx.mode == a.comm, (ctx.mode, a.comm)
     lu = (mf.user_laten.weight.detach() * 0.9).contiguous()
     li = (mf.item_laten.weight.detach() * 0.9).contiguous()
     hu, hi = mf.user_laten.weight.detach().clone(), mf.item_laten.weight.detach().clone()
@@ -59,7 +71,7 @@ def main():
         eng.mf_stage_epoch(mf, net, lu, li, tri, a.mf_batch, 0.01, 1e-6)
         eng.mf_flush(mf)       # as the period does after every MF epoch (bounds the lazy-Adam replay windows)
 
-    out = {"d": a.d, "inter": a.inter}
+    out = {"d": a.d, "inter": a.inter, "comm": a.comm}
     for name, fn, B in (("tr", tr, a.tr_batch), ("mf", mfe, a.mf_batch)):
         nb = -(-a.inter // B)
         fn()
@@ -77,7 +89,11 @@ def main():
         prof = eng.profile_read()
         eng.profile(False)
         out[name + "_kernels_us"] = {k: round(1000.0 * ms / c, 2) for k, (c, ms) in prof.items() if c >= nb // 2}
+    if a.comm == "peer":
+        out["peer_timeouts"] = eng.peer_status()
     print(json.dumps(out))
+    if a.comm != "none":
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
