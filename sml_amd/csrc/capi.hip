@@ -155,6 +155,7 @@ struct sml_ctx {
     // transfer-net workspaces, 3*B slots each
     Buf<float> out, dout, dx, xin, z1, a1, a2, dz1, mrep, vrep;
     Buf<float> pk, grad, convg, loss_part;
+    int pk_set = 0;          // which of the two operand-image sets is current
     Buf<int> arrive;         // k_tr_wgrad2's tail-workgroup arrival counter (0 between launches)
     // Adam schedule of the MF optimiser
     Buf<SmlSched> sched;
@@ -305,10 +306,15 @@ int ensure_transfer_ws(sml_ctx* c, int B, bool tr_stage) {
     return SML_OK;
 }
 
+// TWO sets of MFMA operand images (each: user net, item net).  The restructured TR step's merged launch rewrites the
+// images (fused Adam of the weight-gradient tiles) WHILE its tail workgroups still read W1's image for dA1: the new
+// images go to the other set, and the sets swap after the launch.  Everybody else reads pk_cur().
 int ensure_pk(sml_ctx* c) {
-    HIPCHK(c->pk.ensure((size_t)2 * sml_pk_size(c->d)));
+    HIPCHK(c->pk.ensure((size_t)4 * sml_pk_size(c->d)));
     return SML_OK;
 }
+float* pk_cur(const sml_ctx* c) { return c->pk.p + (size_t)c->pk_set * 2 * sml_pk_size(c->d); }
+float* pk_other(const sml_ctx* c) { return c->pk.p + (size_t)(1 - c->pk_set) * 2 * sml_pk_size(c->d); }
 
 int ceil_log2(int64_t x) { int b = 0; while (((int64_t)1 << b) < x) ++b; return b; }
 
@@ -533,7 +539,7 @@ int sml_theta_pack(sml_ctx* ctx, const float* theta, void* stream) {
     DevGuard g(ctx->device);
     int rc = ensure_pk(ctx); if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    ctx->prof.begin(PC_PACK, st); HIPCHK(sml_launch_theta_pack(ctx->d, theta, ctx->pk.p, st)); ctx->prof.end(st);
+    ctx->prof.begin(PC_PACK, st); HIPCHK(sml_launch_theta_pack(ctx->d, theta, pk_cur(ctx), st)); ctx->prof.end(st);
     return SML_OK;
 }
 
@@ -545,12 +551,12 @@ int sml_transfer_forward(sml_ctx* ctx, const float* theta, int net, const float*
     DevGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     int rc = ensure_pk(ctx); if (rc) return rc;
-    ctx->prof.begin(PC_PACK, st); HIPCHK(sml_launch_theta_pack(ctx->d, theta, ctx->pk.p, st)); ctx->prof.end(st);
+    ctx->prof.begin(PC_PACK, st); HIPCHK(sml_launch_theta_pack(ctx->d, theta, pk_cur(ctx), st)); ctx->prof.end(st);
     SmlFwdArgs a;
     memset(&a, 0, sizeof(a));
     SmlSeg& s = a.seg[0];
     s.theta = theta + (int64_t)net * sml_net_size(ctx->d);
-    s.pk = ctx->pk.p + (int64_t)net * sml_pk_size(ctx->d);
+    s.pk = pk_cur(ctx) + (int64_t)net * sml_pk_size(ctx->d);
     s.xt_tab = x_t; s.xh_tab = x_hat; s.n_rows = (int)n_rows; s.out = out;
     a.k2 = ctx->variant == 1; a.unit_rows = (ctx->variant == 1 && net == 0);
     // table-sized calls are bound by streaming the weights through L2 once per workgroup: 32 rows per workgroup
@@ -598,7 +604,7 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
     const int64_t out_pstride = (int64_t)SML_R * (tiles_of(batch) + tiles_of(2 * batch)) * d;
     const int fns = fwd_split(wg_tiles(batch, 1) + wg_tiles(2 * batch, 1)), bsplit = bwd_split(wg_tiles(batch, 1) + wg_tiles(2 * batch, 1));
     HIPCHK(ctx->loss_part.ensure((size_t)nb * lstride));
-    ctx->prof.begin(PC_PACK, st); HIPCHK(sml_launch_theta_pack(d, theta, ctx->pk.p, st)); ctx->prof.end(st);
+    ctx->prof.begin(PC_PACK, st); HIPCHK(sml_launch_theta_pack(d, theta, pk_cur(ctx), st)); ctx->prof.end(st);
     ctx->prof.begin(PC_SORT, st); rc = sort_epoch(&ctx->ix[0], triples, n, batch, 1, t->n_user, t->n_item, false, st, plan);
     const int64_t x_total = !xchg ? 0 : xchg->item_off ? xchg->item_off[nb] : (int64_t)xchg->world * 2 * n;
     const int64_t x_stride = !xchg ? 0 : xchg->slot_stride > 0 ? xchg->slot_stride : (int64_t)2 * batch;
@@ -619,7 +625,7 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
         memset(&f, 0, sizeof(f));
         for (int s = 0; s < 2; ++s) {
             SmlSeg& sg = f.seg[s];
-            sg.theta = theta + s * ns; sg.pk = ctx->pk.p + s * ps;
+            sg.theta = theta + s * ns; sg.pk = pk_cur(ctx) + s * ps;
             sg.xt_tab = s ? t->last_item : t->last_user;
             sg.xh_tab = s ? t->w_item : t->w_user;
             sg.m_tab = s ? t->m_item : t->m_user; sg.v_tab = s ? t->v_item : t->v_user;
@@ -639,7 +645,7 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
         for (int s = 0; s < 2; ++s) {
             SmlBwdSeg& sg = w.seg[s];
             const int64_t slot0 = s ? (int64_t)SML_R * tiles_of(B) : 0;
-            sg.theta = theta + s * ns; sg.pk = ctx->pk.p + s * ps;
+            sg.theta = theta + s * ns; sg.pk = pk_cur(ctx) + s * ps;
             sg.dout = ctx->dout.p + slot0 * d; sg.is_item = s; sg.z1 = ctx->z1.p + slot0 * SML_HID; sg.xin = ctx->xin.p + slot0 * 3 * d;
             sg.dx = dx_buf + slot0 * d; sg.dz1 = nullptr; sg.n_rows = s ? 2 * B : B;
         }
@@ -737,7 +743,7 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
     const int lstride = (wg_tiles(batch, 1) + wg_tiles(2 * batch, 1)) * (d / 16 > 4 ? d / 16 : 4);
     const int64_t out_pstride = (int64_t)SML_R * (tiles_of(batch) + tiles_of(2 * batch)) * d;
     HIPCHK(ctx->loss_part.ensure((size_t)nb * lstride));
-    ctx->prof.begin(PC_PACK, st); HIPCHK(sml_launch_theta_pack(d, theta, ctx->pk.p, st)); ctx->prof.end(st);
+    ctx->prof.begin(PC_PACK, st); HIPCHK(sml_launch_theta_pack(d, theta, pk_cur(ctx), st)); ctx->prof.end(st);
     HIPCHK(hipMemsetAsync(ctx->loss_part.p, 0, (size_t)nb * lstride * sizeof(float), st));
     HIPCHK(hipMemsetAsync(grad, 0, (size_t)2 * sml_net_size(d) * sizeof(float), st));
     const int64_t ns = sml_net_size(d), ps = sml_pk_size(d);
@@ -749,7 +755,7 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
         memset(&f, 0, sizeof(f));
         for (int s = 0; s < 2; ++s) {
             SmlSeg& sg = f.seg[s];
-            sg.theta = theta + s * ns; sg.pk = ctx->pk.p + s * ps;
+            sg.theta = theta + s * ns; sg.pk = pk_cur(ctx) + s * ps;
             sg.xt_tab = s ? t->last_item : t->last_user;
             sg.xh_tab = s ? t->hat_item : t->hat_user;
             sg.tri = tri; sg.B = B; sg.is_item = s; sg.n_rows = s ? 2 * B : B;
@@ -768,7 +774,7 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
         for (int s = 0; s < 2; ++s) {
             SmlBwdSeg& sg = w.seg[s];
             const int64_t slot0 = s ? (int64_t)SML_R * tiles_of(B) : 0;
-            sg.theta = theta + s * ns; sg.pk = ctx->pk.p + s * ps;
+            sg.theta = theta + s * ns; sg.pk = pk_cur(ctx) + s * ps;
             sg.dout = ctx->dout.p + slot0 * d; sg.is_item = s; sg.z1 = ctx->z1.p + slot0 * SML_HID; sg.xin = ctx->xin.p + slot0 * 3 * d;
             sg.dx = nullptr; sg.dz1 = ctx->dz1.p + slot0 * SML_HID; sg.n_rows = s ? 2 * B : B;
             SmlWgSeg& q = wg.seg[s];
@@ -801,21 +807,23 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
             memset(&ad, 0, sizeof(ad));
             peer_step(ctx, 0, v2 ? sml_wgrad2_pushers(d) : sml_wgrad_grid(d), &wg.peer, &ad.peer);
             ctx->prof.begin(PC_WGRAD, st); HIPCHK(launch_wgrad(wg)); ctx->prof.end(st);
-            ad.theta = theta; ad.m = adam_m; ad.v = adam_v; ad.grad = grad; ad.pk = ctx->pk.p;
+            ad.theta = theta; ad.m = adam_m; ad.v = adam_v; ad.grad = grad; ad.pk = pk_cur(ctx);
             ad.weight_decay = weight_decay; ad.step_size = sc.step_size; ad.bc2_sqrt = sc.bc2_sqrt;
             ctx->prof.begin(PC_THETA_ADAM, st); HIPCHK(sml_launch_theta_adam(d, ad, st)); ctx->prof.end(st);
         } else if (!grad_hook && !native) {
             // one GPU: the weight-gradient workgroups take the Adam step for the tiles they own
-            wg.theta = theta; wg.m = adam_m; wg.v = adam_v; wg.pk = ctx->pk.p;
+            // (v2: the refreshed images go to the OTHER set -- the launch's tail workgroups are reading this one)
+            wg.theta = theta; wg.m = adam_m; wg.v = adam_v; wg.pk = v2 ? pk_other(ctx) : pk_cur(ctx);
             wg.weight_decay = weight_decay; wg.step_size = sc.step_size; wg.bc2_sqrt = sc.bc2_sqrt;
             ctx->prof.begin(PC_WGRAD, st); HIPCHK(launch_wgrad(wg)); ctx->prof.end(st);
+            if (v2) ctx->pk_set ^= 1;
         } else {
             // the weight-gradient launch leaves the flat gradient complete (its conv workgroups sum the backward's
             // partials): all-reduce it, then one Adam launch
             ctx->prof.begin(PC_WGRAD, st); HIPCHK(launch_wgrad(wg)); ctx->prof.end(st);
             SmlThetaAdamArgs ad;
             memset(&ad, 0, sizeof(ad));
-            ad.theta = theta; ad.m = adam_m; ad.v = adam_v; ad.grad = grad; ad.pk = ctx->pk.p;
+            ad.theta = theta; ad.m = adam_m; ad.v = adam_v; ad.grad = grad; ad.pk = pk_cur(ctx);
             ad.weight_decay = weight_decay; ad.step_size = sc.step_size; ad.bc2_sqrt = sc.bc2_sqrt;
             if (native) {
                 NCCLCHK(g_rccl.AllReduce(grad, grad, (size_t)(2 * ns), ncclFloat, ncclSum, ctx->comm, st));
@@ -1100,8 +1108,12 @@ int sml_peer_alloc(int device, int64_t bytes, void** ptr) {
     void* p = nullptr;
     // uncached device memory: stores from peers land in HBM and the owner's loads never hit a stale L2 line;
     // fine-grained if the runtime refuses that flag; plain device memory as a last resort (one-device tests)
-    hipError_t e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached);
-    if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained); }
+    // (SML_PEER_MEM = uncached | finegrained | plain picks the first kind tried: measurements)
+    const char* kind = getenv("SML_PEER_MEM");
+    const int first = kind && !strcmp(kind, "finegrained") ? 1 : kind && !strcmp(kind, "plain") ? 2 : 0;
+    hipError_t e = hipErrorUnknown;
+    if (first <= 0) e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess && first <= 1) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained); }
     if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&p, (size_t)bytes); }
     if (e != hipSuccess) return fail(SML_ENOMEM, "sml_peer_alloc", hipGetErrorString(e));
     e = hipMemset(p, 0, (size_t)bytes);

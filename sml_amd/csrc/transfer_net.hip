@@ -1435,8 +1435,6 @@ __device__ __forceinline__ void wgrad_tile(const SmlWgArgs& a, int xcd, int kk, 
     float* __restrict__ g = sg.grad;
     auto finish = [&](int off, float gsum, float p, float m, float v) -> float {
         if (g) g[off] = gsum;
-        // several GPUs: the finished value goes straight into slot [parity][this rank] of every rank's inbox
-        for (int q = 0; q < a.peer.world; ++q) peer_store(a.peer.dst[q] + (int64_t)net * NS + off, gsum);
         if (fuse) {
             const int64_t i = (int64_t)net * NS + off;
             adam_apply(p, m, v, gsum + a.weight_decay * p, sc);
@@ -1450,15 +1448,31 @@ __device__ __forceinline__ void wgrad_tile(const SmlWgArgs& a, int xcd, int kk, 
         float s = 0.0f;
 #pragma unroll
         for (int w8 = 0; w8 < 8; ++w8) s += part[(w8 * 32 + i) * 33 + j];
-        wt[i * 33 + j] = finish(woff[q], s, wp[q], wm[q], wvv[q]);
+        const float pnew = finish(woff[q], s, wp[q], wm[q], wvv[q]);
+        wt[i * 33 + j] = a.peer.world > 0 ? s : pnew;      // several GPUs: the tile's GRADIENT is staged for the push
     }
     if (has_bias) {
         float s = 0.0f;
 #pragma unroll
         for (int w8 = 0; w8 < 8; ++w8) s += csum[w8 * 32 + tid];
         finish(boff, s, bp, bm, bv2);
+        for (int q = 0; q < a.peer.world; ++q) peer_store(a.peer.dst[q] + (int64_t)net * NS + boff, s);
     }
-    if (a.peer.world > 0) peer_signal(a.peer);
+    if (a.peer.world > 0) {
+        // several GPUs: the finished tile goes straight into slot [parity][this rank] of EVERY rank's inbox, 16 bytes per
+        // lane (a tile row is 128 contiguous bytes of the flat gradient), then one counter increment per destination
+        __syncthreads();
+        if (tid < 256) {
+            const int i = tid >> 3, c4 = tid & 7;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = wt[i * 33 + c4 * 4 + e];
+            const int64_t o = (int64_t)net * NS + (is_w1 ? SML_OFF_F1W + (ti * 32 + i) * K1 + tj * 32 + c4 * 4
+                                                         : sml_off_f2w(D) + (ti * 32 + i) * SML_HID + tj * 32 + c4 * 4);
+            for (int q = 0; q < a.peer.world; ++q) peer_store16(a.peer.dst[q] + o, v);
+        }
+        peer_signal(a.peer);
+    }
     if (!fuse) return;
     // Operand-image refresh.  A 32x32 weight tile is four whole (column tile, k-step) blocks of 64 lanes x 4 floats
     // in EACH of its two images (forward and backward GEMM), i.e. eight contiguous 1 KB runs: one coalesced
@@ -1558,8 +1572,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         return;
     }
     // ---------------- tail role: dA1 = dZ1 * W1[:, slice], per-coordinate tail, conv-gradient partial
-    float* dZs = smem;                    // [R][516]
-    float* part = smem;                   // [8][R][81], aliases dZs after the GEMM
+    float* part = smem;                   // [8][R][81]
     float* cgA = smem;                    // [256][CGS], aliases part after the tail
     float* cgB = smem + 256 * CGS;
     float* cws = smem + SZ0;
@@ -1578,39 +1591,55 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const float* x = sg.xin + (int64_t)(row0 + tr_) * 3 * D;
             x0 = x[tw]; x1 = x[D + tw]; x2 = x[2 * D + tw];
         }
-        {   // the tile's dZ1 rows (written by k_tr_bwd_head, whole tiles) -> LDS: 16 x 512 floats, four 16-byte loads per thread
-            f32x4 v[4];
+        // dA1[R x 5*16] = dZ1[R x 512] * W1[:, slice]: every wave takes 4 of the 32 k-steps, all 5 channels.  Each wave's
+        // dZ1 fragment is a DISJOINT k-range of the tile (read once per workgroup overall): it goes from global memory
+        // straight into the MFMA A operand (lane: row l&15, 16 bytes at k = 16 ks + 4 (l>>4)) -- no LDS staging, no
+        // barrier before the products -- and the first two k-steps of the W1 image are fetched in the same round trip.
+        const f32x4* __restrict__ p1b = reinterpret_cast<const f32x4*>(sg.pk_net + sml_pk_p1b(D));
+        auto tile1 = [cs](int t) { return t * (D / 16) + cs; };
+        f32x4 av[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = i * 512 + tid, r = idx >> 7, c4 = idx & 127;
-                v[i] = *reinterpret_cast<const f32x4*>(sg.dz1 + (int64_t)(row0 + r) * SML_HID + c4 * 4);
-            }
+        for (int ks = 0; ks < 4; ++ks)
+            av[ks] = *reinterpret_cast<const f32x4*>(sg.dz1 + (int64_t)(row0 + l15) * SML_HID + (wv * 4 + ks) * 16 + 4 * g4);
+        f32x4 ring[2][5];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = i * 512 + tid, r = idx >> 7, c4 = idx & 127;
-                *reinterpret_cast<f32x4*>(dZs + r * S2 + c4 * 4) = v[i];
-            }
-        }
-        __syncthreads();
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int t = 0; t < 5; ++t) ring[i][t] = p1b[(tile1(t) * 32 + wv * 4 + i) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0x86);
+        __syncthreads();                            // cws is in LDS
         Pro pt;
         float gg2[SML_C2], gg1[SML_C1];
-        if (tid < 256) {
-            conv_prologue(cws, x0, x1, x2, pt);
+        {
+            f32x4 acc[5];
 #pragma unroll
-            for (int c = 0; c < SML_C2; ++c) gg2[c] = sml_gelu_grad(pt.h2p[c]);
+            for (int t = 0; t < 5; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int c = 0; c < SML_C1; ++c) gg1[c] = sml_gelu_grad(pt.h1p[c]);
-        }
-        {   // dA1[R x 5*16]: every wave takes 4 of the 32 k-steps, all 5 channels
-            const f32x4* __restrict__ p1b = reinterpret_cast<const f32x4*>(sg.pk_net + sml_pk_p1b(D));
-            f32x4 acc[1][5];
-            zero_acc(acc);
-            mma16_rows<1, 5, 4, 2>(acc, dZs + l15 * S2 + 4 * g4, 0, p1b, 32, wv * 4, lane, [cs](int t) { return t * (D / 16) + cs; });
-            __syncthreads();                        // every wave is done reading dZs
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int t = 0; t < 5; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[t] = mfma16(av[ks][e], ring[ks & 1][t][e], acc[t]);
+                if (ks + 2 < 4) {
+#pragma unroll
+                    for (int t = 0; t < 5; ++t) ring[ks & 1][t] = p1b[(tile1(t) * 32 + wv * 4 + ks + 2) * 64 + lane];
+                }
+                __builtin_amdgcn_sched_barrier(0x86);
+            }
+            // the tail's forward recomputation runs on the VALU while the matrix pipe drains the products above (the operand
+            // registers are free by now: computed earlier, these 25 values pushed the kernel past 128 VGPRs into spills)
+            if (tid < 256) {
+                conv_prologue(cws, x0, x1, x2, pt);
+#pragma unroll
+                for (int c = 0; c < SML_C2; ++c) gg2[c] = sml_gelu_grad(pt.h2p[c]);
+#pragma unroll
+                for (int c = 0; c < SML_C1; ++c) gg1[c] = sml_gelu_grad(pt.h1p[c]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 5; ++t)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) part[(wv * R + 4 * g4 + q) * PSTR + t * 16 + l15] = acc[0][t][q];
+                for (int q = 0; q < 4; ++q) part[(wv * R + 4 * g4 + q) * PSTR + t * 16 + l15] = acc[t][q];
         }
         __syncthreads();
         float cga[16], cgb[16];
@@ -1680,33 +1709,58 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
     }
     TL(4);
-    // ---- elect the last tail workgroup: it adds the partials in index order (deterministic) and finishes the conv parameters
-    __threadfence();
+    // ---- elect the last tail workgroup: it adds the partials in index order (deterministic) and finishes the conv parameters.
+    // NO agent-scope fence here: __threadfence() is a write-back + invalidate of this XCD's whole L2, executed by every
+    // wave of 96 workgroups underneath the weight-gradient tiles that live out of that L2 (measured: the launch took
+    // 28 us).  The partials left as write-through (sc1) stores: once they are acknowledged (vmcnt = 0) they are in
+    // memory, the arrival counter is an L2-bypassing atomic, and the last arriver reads the partials with sc1 loads.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) s_last = (atomicAdd(a.arrive, 1) == a.n_tail - 1) ? 1 : 0;
+    if (tid == 0) s_last = (__hip_atomic_fetch_add(a.arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.n_tail - 1) ? 1 : 0;
     __syncthreads();
     if (!s_last) { TL_DONE(); return; }
-    __threadfence();
     {
         const bool fuse = a.theta != nullptr;
         SmlSched sc; sc.step_size = a.step_size; sc.bc2_sqrt = a.bc2_sqrt;
-        const int net = tid >> 7, k = tid & 127;        // threads 0..94: user net, 128..222: item net
-        if (tid < 256 && k < 95) {
-            const int off = k < 30 ? k : k < 40 ? k + 2 : k < 90 ? k + 4 : k + 6;
-            const int t0 = (net ? a.tiles0 : 0) * CS, t1 = (net ? a.tiles_total : a.tiles0) * CS;
-            const int64_t i = (int64_t)net * NS + off;
-            float p = 0.f, m = 0.f, v = 0.f;
-            if (fuse) { p = a.theta[i]; m = a.m[i]; v = a.v[i]; }
-            float g = 0.0f;
-            int t = t0;
-            for (; t + 8 <= t1; t += 8) {
-                float x[8];
+        // All partial rows in ONE memory round trip: thread (rg, c4) adds the 16-byte column group c4 of the rows
+        // t = rg, rg + 21, ... (user-net rows and item-net rows apart), then the 21 row groups meet in LDS and are added
+        // in index order -- the summation order is a fixed function of the launch geometry (deterministic).
+        constexpr int RG = 21, C4 = SML_CG / 4;          // 21 x 24 = 504 threads
+        const int split = a.tiles0 * CS, total = a.tiles_total * CS;
+        float* P = smem;                                 // [2][RG][SML_CG]
+        if (tid < RG * C4) {
+            const int rg = tid / C4, c4 = tid % C4;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            for (int t0 = rg; t0 < total; t0 += 4 * RG) {
+                f32x4 x[4];
+                const float* srcp[4];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) x[u] = __hip_atomic_load(&a.convg_out[(int64_t)(t + u) * SML_CG + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int u = 0; u < 4; ++u) {
+                    const int t = t0 + u * RG;
+                    // (clamped address, weighted below: the L2-bypassing loads are unconditional)
+                    srcp[u] = a.convg_out + (int64_t)(t < total ? t : 0) * SML_CG + c4 * 4;
+                }
+                peer_load16x4(x, srcp);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) g += x[u];
+                for (int u = 0; u < 4; ++u) {
+                    const int t = t0 + u * RG;
+                    if (t < split) acc0 += x[u]; else if (t < total) acc1 += x[u];
+                }
             }
-            for (; t < t1; ++t) g += __hip_atomic_load(&a.convg_out[(int64_t)t * SML_CG + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *reinterpret_cast<f32x4*>(P + (0 * RG + rg) * SML_CG + c4 * 4) = acc0;
+            *reinterpret_cast<f32x4*>(P + (1 * RG + rg) * SML_CG + c4 * 4) = acc1;
+        }
+        const int net = tid >> 7, k = tid & 127;        // threads 0..94: user net, 128..222: item net
+        const bool mine = tid < 256 && k < 95;
+        const int off = k < 30 ? k : k < 40 ? k + 2 : k < 90 ? k + 4 : k + 6;
+        const int64_t i = (int64_t)net * NS + off;
+        float p = 0.f, m = 0.f, v = 0.f;
+        if (mine && fuse) { p = a.theta[i]; m = a.m[i]; v = a.v[i]; }
+        __syncthreads();
+        if (mine) {
+            float g = 0.0f;
+#pragma unroll
+            for (int rg = 0; rg < RG; ++rg) g += P[(net * RG + rg) * SML_CG + k];
             if (a.seg[net].grad) a.seg[net].grad[off] = g;
             for (int q = 0; q < a.peer.world; ++q) peer_store(a.peer.dst[q] + i, g);
             if (fuse) {
@@ -1714,7 +1768,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 a.theta[i] = p; a.m[i] = m; a.v[i] = v;
             }
         }
-        if (tid == 0) *a.arrive = 0;                  // ready for the next launch (ordered by the kernel boundary)
+        if (tid == 0) __hip_atomic_store(a.arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
         if (a.peer.world > 0) peer_signal(a.peer);
     }
     TL(7);
@@ -1737,30 +1791,43 @@ __global__ __launch_bounds__(256) void k_theta_pack(const float* __restrict__ th
 template <int D, bool PEER>
 __global__ __launch_bounds__(256) void k_theta_adam(SmlThetaAdamArgs a) {
     constexpr int NS = sml_net_size(D);
+    static_assert(NS % 4 == 0, "a thread's four floats belong to one net");
     // several GPUs, one-shot exchange: wait until every rank's gradient tiles have landed in this rank's inbox
     if constexpr (PEER) peer_wait(a.peer);
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 2 * NS) return;
-    const int net = i / NS, off = i % NS;
-    if (off < SML_OFF_F1W && !conv_slot_used_host(off)) return;       // alignment padding of the conv block
-    float g;
+    // four consecutive parameters per thread: 16-byte loads of gradient / theta / m / v, 16-byte stores
+    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= 2 * NS) return;
+    const int net = i0 / NS, off0 = i0 % NS;
+    f32x4 g;
     if constexpr (PEER) {
         // the slots are added IN RANK ORDER on every rank: bit-identical sums, hence bit-identical replicas
-        float x[SML_MAX_PEERS];
+        static_assert(SML_MAX_PEERS == 8, "peer_load16x8");
+        f32x4 x[8];
+        const float* src[8];
 #pragma unroll
-        for (int q = 0; q < SML_MAX_PEERS; ++q) x[q] = q < a.peer.world ? peer_load(a.peer.slot0 + q * a.peer.slot_stride + i) : 0.0f;
+        for (int q = 0; q < 8; ++q) src[q] = a.peer.slot0 + (q < a.peer.world ? q : 0) * a.peer.slot_stride + i0;   // (unused slots re-read slot 0)
+        peer_load16x8(x, src);
         g = x[0];
 #pragma unroll
         for (int q = 1; q < SML_MAX_PEERS; ++q) if (q < a.peer.world) g += x[q];
     } else {
-        g = a.grad[i];                                                // complete (and all-reduced) flat gradient
+        g = *reinterpret_cast<const f32x4*>(a.grad + i0);             // complete (and all-reduced) flat gradient
     }
-    float p = a.theta[i], m = a.m[i], v = a.v[i];
-    g = g + a.weight_decay * p;
+    f32x4 p = *reinterpret_cast<const f32x4*>(a.theta + i0), m = *reinterpret_cast<const f32x4*>(a.m + i0),
+          v = *reinterpret_cast<const f32x4*>(a.v + i0);
     SmlSched s; s.step_size = a.step_size; s.bc2_sqrt = a.bc2_sqrt;
-    adam_apply(p, m, v, g, s);
-    a.theta[i] = p; a.m[i] = m; a.v[i] = v;
-    pack_store<D>(a.pk + (int64_t)net * sml_pk_size(D), off, p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int off = off0 + e;
+        if (off < SML_OFF_F1W && !conv_slot_used_host(off)) continue;   // alignment padding of the conv block: untouched
+        float pe = p[e], me = m[e], ve = v[e];
+        adam_apply(pe, me, ve, g[e] + a.weight_decay * pe, s);
+        p[e] = pe; m[e] = me; v[e] = ve;
+        pack_store<D>(a.pk + (int64_t)net * sml_pk_size(D), off, pe);
+    }
+    *reinterpret_cast<f32x4*>(a.theta + i0) = p;
+    *reinterpret_cast<f32x4*>(a.m + i0) = m;
+    *reinterpret_cast<f32x4*>(a.v + i0) = v;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1854,7 +1921,7 @@ hipError_t sml_launch_wgrad(int d, const SmlWgArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 hipError_t sml_launch_theta_adam(int d, const SmlThetaAdamArgs& a, hipStream_t st) {
-    const int n = 2 * sml_net_size(d);
+    const int n = 2 * sml_net_size(d) / 4;         // four parameters per thread
     if (a.peer.world > 0) { SML_DISPATCH_D(d, k_theta_adam<DD, true><<<dim3((n + 255) / 256), dim3(256), 0, st>>>(a)); }
     else { SML_DISPATCH_D(d, k_theta_adam<DD, false><<<dim3((n + 255) / 256), dim3(256), 0, st>>>(a)); }
     return hipGetLastError();

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--tr-batch", type=int, default=256)
     ap.add_argument("--mf-batch", type=int, default=1024)
+    ap.add_argument("--out", default="", help="also write the JSON line to this file (RCCL prints its banner to stdout at exit)")
     ap.add_argument("--comm", default="none", choices=["none", "peer", "rccl", "torch"],
                     help="drive the multi-GPU exchange path on a forced 1-rank group: the per-step overhead of each carrier "
                          "(peer: one-shot push / poll into the rank's own inbox; rccl: the library's communicator; torch: hooks)")
@@ -92,6 +93,9 @@ def main():
     if a.comm == "peer":
         out["peer_timeouts"] = eng.peer_status()
     print(json.dumps(out))
+    if a.out:
+        with open(a.out, "w") as f:
+            f.write(json.dumps(out) + "\n")
     if a.comm != "none":
         dist.destroy_process_group()
 
