@@ -98,7 +98,10 @@ for kid, name in ((1, "fwd"), (2, "bwd"), (3, "wgrad"), (4, "fwd1"), (5, "bwd_fu
     print(name, "workgroups", int(live.sum()), "start spread %.2f us" % st_.max(), "end: median %.2f  max %.2f us" % (np.median(e), e.max()),
           "slowest blocks", [(int(idx[o]), round(float(e[o]), 2)) for o in order])
     if name == "wgrad":
-        for lo, hi, what in ((0, 2, "conv"), (2, 98, "first net's tiles"), (98, 194, "second net's tiles")):
+        v2 = os.environ.get("SML_TR_V2", "1") != "0"
+        groups = ((0, 96, "tail workgroups (dA1, tail, conv gradients)"), (96, 192, "first net's tiles"), (192, 288, "second net's tiles")) if v2 \
+            else ((0, 2, "conv"), (2, 98, "first net's tiles"), (98, 194, "second net's tiles"))
+        for lo, hi, what in groups:
             sel = (idx >= lo) & (idx < hi)
             if sel.any():
                 print("   ", what, "start median %.2f  end median %.2f  max %.2f" % (np.median(st_[sel]), np.median(e[sel]), e[sel].max()))
