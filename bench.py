@@ -299,6 +299,25 @@ def rocprof_avg_us(kernel):
         return None, None
 
 
+def pmc_mfma(kernel):
+    """MFMA-pipe busy fraction of kernel class `kernel` from the COMMITTED rocprofv3 --pmc pass of this same command
+    (profiles/r*_pmc_mfma.json, tools/profile_round.sh: SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU_MFMA_MOPS_F32,
+    GRBM_GUI_ACTIVE), averaged over the class's template instances by launch count."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_mfma.json")))
+    if not files:
+        return None, None
+    try:
+        tot, n = 0.0, 0
+        for name, e in json.load(open(files[-1])).items():
+            if name.startswith(kernel) and "mfma_busy_frac_of_all_simds" in e:
+                tot += e["launches"] * e["mfma_busy_frac_of_all_simds"]
+                n += e["launches"]
+        return (tot / n if n else None), os.path.basename(files[-1])
+    except Exception:
+        return None, None
+
+
 def host_cpu():
     model = "unknown"
     try:
@@ -314,46 +333,55 @@ def host_cpu():
 def cpu_baseline(a, hp):
     """The CPU oracle (oracle/sml_oracle.py, kind 'port') on a bounded sample of the same
     period: full-size tables (dense Adam cost scales with the table), 8 MF batches, 16 TR
-    batches, updata over 1/16 of the rows, evaluation of 2048 rows; scaled to one period."""
+    batches, updata over 1/16 of the rows, evaluation of 2048 rows; scaled to one period.
+    Timed at TWO thread counts -- 16 and os.cpu_count() -- and the faster one is `value` (both are reported: intra-op
+    threading of the oracle's small tensors stops scaling well before a 256-core host's core count)."""
     from oracle import sml_oracle as O
     from sml_amd.conv_transfer import ConvTransfer_com
     from sml_amd.mf import MFbasemode
     import contextlib, io
-    # intra-op threading of the oracle's small tensors stops scaling near 16 threads (and with
-    # one thread per core of a 256-core host each op drowns in fork/join cost): use <= 16
-    cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
-    torch.manual_seed(1)
     U, I, d, n = a.users, a.items, a.d, a.inter
-    mf = MFbasemode(U, I, d)
-    with torch.no_grad():
-        mf.user_laten.weight.mul_(0.3)
-        mf.item_laten.weight.mul_(0.3)
-    with contextlib.redirect_stdout(io.StringIO()):
-        net = ConvTransfer_com(d, d)
-    eng = O.OracleEngine(d)
-    lu, li = mf.user_laten.weight.detach() * 0.9, mf.item_laten.weight.detach() * 0.9
-    rng = np.random.RandomState(0)
     n_mf, n_tr = 8 * hp.MF_batch_size, 16 * hp.TR_batch_size
-    tri = lambda k: torch.from_numpy(np.stack([rng.randint(0, U, k), rng.randint(0, I, k), rng.randint(0, I, k)], 1))
-    t0 = time.time(); eng.mf_stage_epoch(mf, net, lu, li, tri(n_mf), hp.MF_batch_size, hp.MF_lr, hp.l2); t_mf = time.time() - t0
-    hu, hi = mf.user_laten.weight.detach().clone(), mf.item_laten.weight.detach().clone()
-    t0 = time.time(); eng.tr_stage_epoch(net, lu, li, hu, hi, tri(n_tr), hp.TR_batch_size, hp.TR_lr, hp.TR_l2); t_tr = time.time() - t0
-    ru, ri = U // 16, I // 16
-    ou, oi = torch.empty(ru, d), torch.empty(ri, d)
-    t0 = time.time(); eng.updata(net, lu[:ru], hu[:ru], li[:ri], hi[:ri], ou, oi); t_up = (time.time() - t0) * 16
-    rows = torch.from_numpy(np.concatenate([rng.randint(0, U, (2048, 1)), rng.randint(0, I, (2048, 1 + a.neg))], 1))
-    t0 = time.time(); O.eval_ranks(hu, hi, rows); t_ev = (time.time() - t0) * n / 2048.0
     evals = 0 if a.no_val else hp.multi_num * (2 + hp.MF_epochs + hp.TR_epochs)
     n_updata = hp.multi_num * (1 + (hp.TR_epochs if not a.no_val else 0)) + 1
-    period_s = hp.multi_num * (hp.MF_epochs * t_mf * n / n_mf + hp.TR_epochs * t_tr * n / n_tr) + n_updata * t_up + evals * t_ev
     triples = hp.multi_num * (hp.MF_epochs + hp.TR_epochs) * n
-    return {"value": triples / period_s, "unit": "triples/s", "cores": cores, "kind": "port", "host": host_cpu(),
-            "extrapolated": True,
+
+    def sample(cores):
+        torch.set_num_threads(cores)
+        torch.manual_seed(1)
+        mf = MFbasemode(U, I, d)
+        with torch.no_grad():
+            mf.user_laten.weight.mul_(0.3)
+            mf.item_laten.weight.mul_(0.3)
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = ConvTransfer_com(d, d)
+        eng = O.OracleEngine(d)
+        lu, li = mf.user_laten.weight.detach() * 0.9, mf.item_laten.weight.detach() * 0.9
+        rng = np.random.RandomState(0)
+        tri = lambda k: torch.from_numpy(np.stack([rng.randint(0, U, k), rng.randint(0, I, k), rng.randint(0, I, k)], 1))
+        t0 = time.time(); eng.mf_stage_epoch(mf, net, lu, li, tri(n_mf), hp.MF_batch_size, hp.MF_lr, hp.l2); t_mf = time.time() - t0
+        hu, hi = mf.user_laten.weight.detach().clone(), mf.item_laten.weight.detach().clone()
+        t0 = time.time(); eng.tr_stage_epoch(net, lu, li, hu, hi, tri(n_tr), hp.TR_batch_size, hp.TR_lr, hp.TR_l2); t_tr = time.time() - t0
+        ru, ri = U // 16, I // 16
+        ou, oi = torch.empty(ru, d), torch.empty(ri, d)
+        t0 = time.time(); eng.updata(net, lu[:ru], hu[:ru], li[:ri], hi[:ri], ou, oi); t_up = (time.time() - t0) * 16
+        rows = torch.from_numpy(np.concatenate([rng.randint(0, U, (2048, 1)), rng.randint(0, I, (2048, 1 + a.neg))], 1))
+        t0 = time.time(); O.eval_ranks(hu, hi, rows); t_ev = (time.time() - t0) * n / 2048.0
+        parts = {"mf_s": hp.multi_num * hp.MF_epochs * t_mf * n / n_mf, "tr_s": hp.multi_num * hp.TR_epochs * t_tr * n / n_tr,
+                 "updata_s": n_updata * t_up, "eval_s": evals * t_ev}
+        period_s = sum(parts.values())
+        return {"cores": cores, "value": triples / period_s, "period_s_est": period_s, **{k: round(v, 2) for k, v in parts.items()}}
+
+    counts = sorted({min(os.cpu_count() or 1, 16), os.cpu_count() or 1})
+    runs = [sample(c) for c in counts]
+    best = max(runs, key=lambda r: r["value"])
+    return {"value": best["value"], "unit": "triples/s", "cores": best["cores"], "kind": "port", "host": host_cpu(),
+            "extrapolated": True, "by_threads": runs,
             "sample": "oracle on full-size tables: %d MF triples, %d TR triples, updata on 1/16 of rows, eval of 2048 rows; "
-                      "scaled to one period (est. %.1f s/period: MF %.1f s, TR %.1f s, updata %.1f s, eval %.1f s)"
-                      % (n_mf, n_tr, period_s, hp.multi_num * hp.MF_epochs * t_mf * n / n_mf,
-                         hp.multi_num * hp.TR_epochs * t_tr * n / n_tr, n_updata * t_up, evals * t_ev)}
+                      "scaled to one period (est. %.1f s/period at %d threads: MF %.1f s, TR %.1f s, updata %.1f s, eval %.1f s); "
+                      "timed at %s threads, the faster count is `value`"
+                      % (n_mf, n_tr, best["period_s_est"], best["cores"], best["mf_s"], best["tr_s"], best["updata_s"], best["eval_s"],
+                         " and ".join(str(c) for c in counts))}
 
 
 def main():
@@ -449,6 +477,7 @@ def main():
         torch.cuda.synchronize(device)
         prof = engine.profile_read()
         engine.profile(False)
+        empty_pair_us = engine.profile_pair_overhead()
         if prof and rank == 0:
             # the evaluations run throttled (256 workgroups) on a low-priority side stream underneath the
             # training kernels: their span is not on the critical path, so the roofline object describes
@@ -457,18 +486,31 @@ def main():
             name, (cnt, ms) = dom
             bound, work, _ = kernel_work(name, a, hp, U_local)
             kern = {k: {"launches": c, "total_ms": round(m, 3), "avg_us": round(1000.0 * m / c, 2)} for k, (c, m) in prof.items()}
+            # What a HIP-event bracket adds to a short kernel's reading, measured in THIS run: the training stream is
+            # gap-free (kernel time = step time), so the bracketed kernel totals of the training stream exceed the
+            # un-bracketed step by (launches x overhead).  Never less than an empty pair's own reading.
+            train = {k: v for k, v in prof.items() if k != "k_eval_ranks"}
+            n_launch = sum(c for c, _ in train.values())
+            derived = (sum(m for _, m in train.values()) - 1000.0 * dt / a.steps) * 1000.0 / max(n_launch, 1)
+            overhead_us = max(empty_pair_us, min(derived, 6.0)) if derived > 0 else empty_pair_us
             if bound is not None and cnt:
                 per_launch = work / cnt
-                avg_s = ms / 1000.0 / cnt
+                avg_raw_s = ms / 1000.0 / cnt
+                avg_s = max(avg_raw_s - overhead_us * 1e-6, 0.25 * avg_raw_s)
                 if bound == "hbm":
                     ach, peak, unit = per_launch / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
                 else:
                     ach, peak, unit = per_launch / avg_s / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
                 tp, tfile = pmc_traffic(name)
                 rp_us, rp_file = rocprof_avg_us(name)
+                mb, mfile = pmc_mfma(name)
                 out["roofline"] = {"kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
                                    "frac": ach / peak, "traffic": None, "traffic_from_profiles": tp, "traffic_profile": tfile,
                                    "launches": cnt, "avg_launch_us": 1e6 * avg_s, "algorithmic_per_launch": per_launch,
+                                   # avg_launch_us = the bracketed reading minus the bracket's own cost, both measured in this run
+                                   "avg_launch_us_bracketed": 1e6 * avg_raw_s, "event_bracket_overhead_us": overhead_us,
+                                   "event_pair_empty_us": empty_pair_us,
+                                   "mfma_busy_frac_from_profiles": mb, "mfma_profile": mfile,
                                    # in-run HIP events (above) vs the committed rocprofv3 kernel-trace of the same command
                                    "avg_launch_us_rocprof": rp_us, "rocprof_profile": rp_file,
                                    "frac_rocprof": ((per_launch / (rp_us * 1e-6) / (1e9 if bound == "hbm" else 1e12)) / peak) if rp_us else None}

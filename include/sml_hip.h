@@ -233,6 +233,18 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
                        int64_t* step, float* batch_loss, sml_grad_hook grad_hook, void* hook_user,
                        const sml_batch_plan* plan, void* stream);
 
+/* ---- a7 with gradients: ConvTransfer_com.run_MF for a caller that backpropagates it itself ------------------------
+ * (reference model/conv_transfer.py:113-135 as called from model/transfer.py:476-502 and :714-723: the caller does
+ * zero_grad -> run_MF -> loss.backward() -> optimizer.step()).  One batch of B triples given as ROW BLOCKS, not tables:
+ * user_last / user_hat [B,d]; item_last / item_hat [2B,d] = the positives' rows then the negatives' rows.  Writes the
+ * loss (device scalar), d loss / d user_hat [B,d], d loss / d item_hat [2B,d] (gradient reaches x_hat through the
+ * stack's second row only: x_com is built from a detached x_hat, :93-99) and the flat theta gradient
+ * (2 * sml_theta_net_size floats, theta layout); any of the three gradient outputs may be NULL.  No optimiser step, no
+ * l2 term: the caller adds what its loop adds.  B <= the context's max_batch.  Asynchronous. */
+int sml_run_mf_grad(sml_ctx* ctx, const float* theta, const float* user_last, const float* user_hat,
+                    const float* item_last, const float* item_hat, int B, int loss_kind, float* loss,
+                    float* d_user_hat, float* d_item_hat, float* theta_grad, void* stream);
+
 /* ---- a3: bare fused embed + loss + SGD write-back ------------------------------ */
 /* gather 3 rows, 2 dot products, BCE (model/baseline.py:188-201) or BPR
  * (model/MF.py:139-144 without biases) loss, gradients, and synchronous minibatch
@@ -337,6 +349,9 @@ int sml_prof_enable(sml_ctx* ctx, int on);
  * returns -1 otherwise).  buf: device int64, [0] = record counter (zero it), 16-stamp records from [16]; NULL: off. */
 int sml_debug_timeline(long long* buf);
 int sml_prof_reset(sml_ctx* ctx);
+/* Average reading (microseconds) of n EMPTY event pairs on `stream`: the cost of the bracket itself, which a caller
+ * subtracts from per-launch averages of short kernels.  Synchronous. */
+int sml_prof_pair_overhead(sml_ctx* ctx, int n, void* stream, double* avg_us);
 int sml_prof_classes(void);
 const char* sml_prof_name(int cls);
 int sml_prof_get(sml_ctx* ctx, int cls, int64_t* count, double* total_ms);

@@ -68,6 +68,8 @@ SIGNATURES = {
                                           ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int,
                                           ctypes.c_float, ctypes.POINTER(ctypes.c_int64), c_void, GRAD_HOOK, c_void,
                                           ctypes.POINTER(BatchPlan), c_void]),
+    "sml_run_mf_grad": (ctypes.c_int, [c_void, c_void, c_void, c_void, c_void, c_void, ctypes.c_int, ctypes.c_int, c_void, c_void, c_void,
+                                       c_void, c_void]),
     "sml_embed_loss_sgd_epoch": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                                                 c_void, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                                 ctypes.c_float, ctypes.c_int, c_void, ctypes.c_int, ctypes.POINTER(BareExchange), c_void]),
@@ -108,6 +110,7 @@ SIGNATURES = {
     "sml_prof_enable": (ctypes.c_int, [c_void, ctypes.c_int]),
     "sml_debug_timeline": (ctypes.c_int, [c_void]),
     "sml_prof_reset": (ctypes.c_int, [c_void]),
+    "sml_prof_pair_overhead": (ctypes.c_int, [c_void, ctypes.c_int, c_void, ctypes.POINTER(ctypes.c_double)]),
     "sml_prof_classes": (ctypes.c_int, []),
     "sml_prof_name": (ctypes.c_char_p, [ctypes.c_int]),
     "sml_prof_get": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]),

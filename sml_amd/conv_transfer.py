@@ -18,6 +18,52 @@ def Gelu(x):
     return x * torch.sigmoid(1.702 * x)
 
 
+class _RunMF(torch.autograd.Function):
+    """run_MF as ONE differentiable op on the HIP engine: forward = the loss of the batch, backward = the hand-derived
+    gradients the kernels compute (d loss / d x_hat for the three row blocks and d loss / d theta), scaled by the
+    incoming gradient.  x_t (the W_{t-1} rows) gets no gradient: every caller in the reference passes plain tensors
+    there (model/transfer.py:469-471, 707-709), and x_com is built from a detached x_hat (model/conv_transfer.py:93-99)."""
+
+    @staticmethod
+    def forward(ctx, module, norm, bce, ul, uh, il, ih, nl, nh, *params):
+        eng = module._engine(uh)
+        need_rows = uh.requires_grad or ih.requires_grad or nh.requires_grad
+        need_theta = any(p.requires_grad for p in params)
+        B = uh.shape[0]
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        loss, du, di, gt = eng.run_mf_grad(module, f32(ul), f32(uh), torch.cat([f32(il), f32(nl)]), torch.cat([f32(ih), f32(nh)]),
+                                           bce=bce, norm=norm, want_rows=need_rows, want_theta=need_theta)
+        ctx.B, ctx.du, ctx.di, ctx.gt = B, du, di, gt
+        ctx.views = eng.theta_views(module) if need_theta else None
+        ctx.n_params = len(params)
+        ctx.param_ids = [id(p) for p in params]
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        B = ctx.B
+        g_uh = g * ctx.du if ctx.du is not None else None
+        g_ih = g * ctx.di[:B] if ctx.di is not None else None
+        g_nh = g * ctx.di[B:] if ctx.di is not None else None
+        gp = [None] * ctx.n_params
+        if ctx.gt is not None:
+            by_id = {id(p): (off, n, p) for p, off, n in ctx.views}
+            for k, pid in enumerate(ctx.param_ids):
+                ent = by_id.get(pid)
+                if ent is None:
+                    continue
+                off, n, p = ent
+                if p.dim() == 4 and p.shape[2] == 2 and p.shape[0] == 10:      # ConvTransfer's (2,1) conv1 kernel: see HipEngine.adopt
+                    gp[k] = g * ctx.gt[off:off + 30].view(10, 3)[:, :2].reshape(p.shape)
+                else:
+                    gp[k] = g * ctx.gt[off:off + n].view(p.shape)
+        return (None, None, None, None, g_uh, None, g_ih, None, g_nh) + tuple(gp)
+
+
+def _needs_graph(module, *tensors):
+    return torch.is_grad_enabled() and (any(t.requires_grad for t in tensors) or any(p.requires_grad for p in module.parameters()))
+
+
 class one_transfer(nn.Module):
     """conv1 (1->10, kernel (k,1)) -> Gelu -> conv2 (10->5, 1x1) -> flatten -> Gelu ->
     fc1 (5d->512) -> Gelu -> fc2 (512->out).  reference model/conv_transfer.py:18-50.
@@ -66,9 +112,17 @@ class ConvTransfer_com(nn.Module):
 
     def run_MF(self, user_weight_last, user_weight_hat, item_weight_last, item_weight_hat, negitem_weight_last,
                negitem_weight_hat, norm=False, adpative=False, BCE=True):
-        """Loss value of one batch (reference model/conv_transfer.py:113-135): BCE by
-        default, BPR when BCE=False (optionally with score / ||u'||).  Returns a 0-dim
-        tensor without a graph; training goes through HipEngine.*_stage_epoch."""
+        """Loss of one batch (reference model/conv_transfer.py:113-135): BCE by default, BPR when BCE=False (optionally
+        with score / ||u'||).  When gradients are enabled and any x_hat block or any parameter of this module
+        requires grad, the result carries a graph: loss.backward() fills x_hat.grad (through nn.Embedding, if the rows
+        came from one) and the parameters' .grad, exactly as the reference's loops expect (model/transfer.py:476-502,
+        714-723: zero_grad -> run_MF -> backward -> optimizer.step()).  The whole-epoch engine calls
+        (HipEngine.*_stage_epoch) remain the fast path; this is the drop-in one."""
+        if adpative:
+            raise NotImplementedError("run_MF(adpative=True): the reference's unused --need_adaptive branch")
+        if _needs_graph(self, user_weight_hat, item_weight_hat, negitem_weight_hat):
+            return _RunMF.apply(self, bool(norm), bool(BCE), user_weight_last, user_weight_hat, item_weight_last, item_weight_hat,
+                                negitem_weight_last, negitem_weight_hat, *list(self.parameters()))
         un = self.forward(user_weight_last, user_weight_hat, "user")
         im = self.forward(item_weight_last, item_weight_hat, "item")
         nn_ = self.forward(negitem_weight_last, negitem_weight_hat, "item")
@@ -100,7 +154,12 @@ class ConvTransfer(ConvTransfer_com):
 
     def run_MF(self, user_weight_last, user_weight_hat, item_weight_last, item_weight_hat, negitem_weight_last,
                negitem_weight_hat, norm=False):
-        """BPR loss value of one batch (model/conv_transfer.py:71-85); no graph."""
+        """BPR loss of one batch (model/conv_transfer.py:71-85); differentiable like ConvTransfer_com.run_MF."""
+        if norm:
+            raise NotImplementedError("ConvTransfer with norm=True (the reference's unused --norm flag)")
+        if _needs_graph(self, user_weight_hat, item_weight_hat, negitem_weight_hat):
+            return _RunMF.apply(self, False, False, user_weight_last, user_weight_hat, item_weight_last, item_weight_hat,
+                                negitem_weight_last, negitem_weight_hat, *list(self.parameters()))
         un = self.forward(user_weight_last, user_weight_hat, "user")        # already unit norm
         im = self.forward(item_weight_last, item_weight_hat, "item")
         nn_ = self.forward(negitem_weight_last, negitem_weight_hat, "item")

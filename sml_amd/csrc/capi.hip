@@ -839,6 +839,81 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
     return SML_OK;
 }
 
+int sml_run_mf_grad(sml_ctx* ctx, const float* theta, const float* user_last, const float* user_hat, const float* item_last,
+                    const float* item_hat, int B, int loss_kind, float* loss, float* d_user_hat, float* d_item_hat,
+                    float* theta_grad, void* stream) {
+    if (!ctx || !theta || !user_last || !user_hat || !item_last || !item_hat || !loss || B <= 0)
+        return fail(SML_EINVAL, "sml_run_mf_grad", "bad argument");
+    if (B > ctx->max_batch) return fail(SML_EINVAL, "sml_run_mf_grad", "batch exceeds ctx max_batch");
+    if (loss_kind < 0 || loss_kind > 3 || ((loss_kind == SML_LOSS_BPR_UNIT) != (ctx->variant == 1)))
+        return fail(SML_EINVAL, "sml_run_mf_grad", "loss_kind (SML_LOSS_BPR_UNIT goes with variant 1, and only it)");
+    DevGuard g(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    const int d = ctx->d;
+    int rc;
+    if ((rc = ensure_pk(ctx))) return rc;
+    if ((rc = ensure_transfer_ws(ctx, B, true))) return rc;       // TR-stage saves (a1, a2, dz1, conv partials, flat gradient)
+    if ((rc = ensure_transfer_ws(ctx, B, false))) return rc;      // + the MF stage's dx rows
+    const int64_t ns = sml_net_size(d), ps = sml_pk_size(d);
+    const int tiles0 = wg_tiles(B, 1), tiles = tiles0 + wg_tiles(2 * B, 1);
+    const int fns = fwd_split(tiles);
+    const int lstride = tiles * (d / 16 > 4 ? d / 16 : 4);
+    const int64_t out_pstride = (int64_t)SML_R * (tiles_of(B) + tiles_of(2 * B)) * d;
+    HIPCHK(ctx->loss_part.ensure((size_t)2 * lstride));
+    HIPCHK(hipMemsetAsync(ctx->loss_part.p, 0, (size_t)2 * lstride * sizeof(float), st));
+    HIPCHK(sml_launch_theta_pack(d, theta, pk_cur(ctx), st));
+    // ---- forward over contiguous row blocks (identity indexing), with every save the two backward forms need
+    SmlFwdArgs f;
+    memset(&f, 0, sizeof(f));
+    SmlBwdArgs w;
+    memset(&w, 0, sizeof(w));
+    SmlWgArgs wg;
+    memset(&wg, 0, sizeof(wg));
+    float* grad = theta_grad ? theta_grad : ctx->grad.p;
+    for (int s = 0; s < 2; ++s) {
+        const int64_t slot0 = s ? (int64_t)SML_R * tiles_of(B) : 0;
+        SmlSeg& sg = f.seg[s];
+        sg.theta = theta + s * ns; sg.pk = pk_cur(ctx) + s * ps;
+        sg.xt_tab = s ? item_last : user_last; sg.xh_tab = s ? item_hat : user_hat;
+        sg.tri = nullptr; sg.B = B; sg.is_item = s; sg.n_rows = s ? 2 * B : B;
+        sg.out = ctx->out.p + slot0 * d; sg.z1 = ctx->z1.p + slot0 * SML_HID; sg.xin = ctx->xin.p + slot0 * 3 * d;
+        sg.a1 = ctx->a1.p + slot0 * SML_C2 * d; sg.a2 = ctx->a2.p + slot0 * SML_HID;
+        SmlBwdSeg& bg = w.seg[s];
+        bg.theta = sg.theta; bg.pk = sg.pk; bg.dout = ctx->dout.p + slot0 * d; bg.is_item = s; bg.z1 = sg.z1; bg.xin = sg.xin;
+        bg.dx = ctx->dx.p + slot0 * d; bg.dz1 = ctx->dz1.p + slot0 * SML_HID; bg.n_rows = sg.n_rows;
+        SmlWgSeg& q = wg.seg[s];
+        q.dz1 = bg.dz1; q.a1 = sg.a1; q.dout = bg.dout; q.a2 = sg.a2; q.grad = grad + s * ns; q.n_rows = sg.n_rows;
+        q.theta_net = sg.theta; q.pk_net = sg.pk; q.xin = sg.xin;
+    }
+    f.tiles0 = tiles0; f.out_pstride = out_pstride; f.k2 = ctx->variant == 1; f.tiles_total = tiles;
+    HIPCHK(sml_launch_fwd(d, 1, fns, f, tiles, st));
+    w.tiles0 = tiles0; w.l2 = 0.0f; w.out_all = ctx->out.p; w.B = B; w.ioff = SML_R * tiles_of(B); w.kind = loss_kind; w.scale = 1.0f;
+    w.out_np = fns; w.out_pstride = out_pstride; w.tiles_total = tiles;
+    // ---- gradient w.r.t. the x_hat rows: the MF-stage backward (loss partials of this launch are the ones reported)
+    if (d_user_hat || d_item_hat || !theta_grad) {
+        w.convg_part = nullptr; w.loss_part = ctx->loss_part.p;
+        SmlBwdArgs wx = w;
+        wx.seg[0].dz1 = nullptr; wx.seg[1].dz1 = nullptr;
+        HIPCHK(sml_launch_bwd(d, bwd_split(tiles), wx, tiles, st));
+        if (d_user_hat) HIPCHK(hipMemcpyAsync(d_user_hat, ctx->dx.p, (size_t)B * d * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (d_item_hat) HIPCHK(hipMemcpyAsync(d_item_hat, ctx->dx.p + (size_t)SML_R * tiles_of(B) * d, (size_t)2 * B * d * sizeof(float),
+                                              hipMemcpyDeviceToDevice, st));
+        HIPCHK(sml_launch_loss_finalize(ctx->loss_part.p, 1, lstride, nullptr, loss, st));
+    }
+    // ---- gradient w.r.t. theta: backward head + weight-gradient launch WITHOUT the fused Adam (flat gradient only)
+    if (theta_grad) {
+        w.convg_part = ctx->convg.p; w.loss_part = ctx->loss_part.p + lstride;
+        w.seg[0].dx = nullptr; w.seg[1].dx = nullptr;
+        HIPCHK(sml_launch_tr_bwd_head(d, w, tiles, st));
+        wg.convg_part = ctx->convg.p; wg.tiles0 = tiles0; wg.tiles_total = tiles;
+        wg.n_tail = tiles * (d / 16); wg.convg_out = ctx->convg.p; wg.arrive = ctx->arrive.p;
+        HIPCHK(hipMemsetAsync(grad, 0, (size_t)2 * ns * sizeof(float), st));       // (the conv block's alignment padding)
+        HIPCHK(sml_launch_tr_wgrad2(d, wg, st));
+        if (!(d_user_hat || d_item_hat)) HIPCHK(sml_launch_loss_finalize(ctx->loss_part.p + lstride, 1, lstride, nullptr, loss, st));
+    }
+    return SML_OK;
+}
+
 int sml_embed_loss_sgd_prepare(sml_ctx* ctx, const int64_t* triples, int64_t n, int batch, int64_t n_user,
                                int64_t n_item, int slot, const sml_bare_exchange* xchg, void* stream) {
     if (!ctx || !triples || n <= 0 || batch <= 0 || (slot != 0 && slot != 1))
@@ -1211,6 +1286,21 @@ int sml_prof_reset(sml_ctx* ctx) {
     DevGuard g(ctx->device);
     ctx->prof.drain();
     for (int i = 0; i < PC_COUNT; ++i) { ctx->prof.total_ms[i] = 0; ctx->prof.count[i] = 0; }
+    return SML_OK;
+}
+int sml_prof_pair_overhead(sml_ctx* ctx, int n, void* stream, double* avg_us) {
+    if (!ctx || n <= 0 || n > 4096 || !avg_us) return fail(SML_EINVAL, "sml_prof_pair_overhead", "bad argument");
+    DevGuard g(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<hipEvent_t> ev((size_t)2 * n);
+    for (auto& e : ev) HIPCHK(hipEventCreate(&e));
+    // n EMPTY pairs: what a pair reads with nothing in between -- the part of a bracketed launch's reading that is not the kernel
+    for (int i = 0; i < n; ++i) { HIPCHK(hipEventRecord(ev[2 * i], st)); HIPCHK(hipEventRecord(ev[2 * i + 1], st)); }
+    HIPCHK(hipEventSynchronize(ev.back()));
+    double tot = 0.0;
+    for (int i = 0; i < n; ++i) { float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1])); tot += ms; }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    *avg_us = 1000.0 * tot / n;
     return SML_OK;
 }
 int sml_prof_classes(void) { return PC_COUNT; }

@@ -321,6 +321,31 @@ class HipEngine(object):
         self.tr_step = step.value
         return losses
 
+    # ------------------------------------------------------------------ a7 with gradients (the autograd surface)
+    def run_mf_grad(self, transfer, user_last, user_hat, item_last, item_hat, bce=True, norm=False,
+                    want_rows=True, want_theta=True):
+        """run_MF of one batch given as row blocks (user_* [B,d]; item_* [2B,d]: positives then negatives) with its
+        gradients: (loss 0-dim, d loss / d user_hat or None, d loss / d item_hat or None, flat theta gradient or None).
+        No optimiser step -- this is what sml_amd.conv_transfer's autograd Function calls."""
+        theta = self._select(transfer)
+        ul, uh = self._table(user_last), self._table(user_hat)
+        il, ih = self._table(item_last), self._table(item_hat)
+        B = ul.shape[0]
+        if uh.shape[0] != B or il.shape[0] != 2 * B or ih.shape[0] != 2 * B:
+            raise ValueError("run_mf_grad: user blocks [B,d], item blocks [2B,d]")
+        loss = torch.empty((), device=self.device, dtype=torch.float32)
+        du = torch.empty_like(uh) if want_rows else None
+        di = torch.empty_like(ih) if want_rows else None
+        gt = torch.empty_like(theta) if want_theta else None
+        check(self.lib.sml_run_mf_grad(self._ctx, _ptr(theta), _ptr(ul), _ptr(uh), _ptr(il), _ptr(ih), B, self._loss_kind(bce, norm),
+                                       _ptr(loss), _ptr(du), _ptr(di), _ptr(gt), self._stream()), "sml_run_mf_grad")
+        return loss, du, di, gt
+
+    def theta_views(self, transfer):
+        """[(parameter, offset, numel)] of the adopted transfer module inside its flat theta (adopt() first)."""
+        self.adopt(transfer)
+        return self._flat[id(transfer)][1]
+
     # ------------------------------------------------------------------ a3
     def _bare_exchange(self, ex):
         """ctypes view of sml_amd.dist.DistContext.bare_exchange(): (struct pointer or None, keep-alive)."""
@@ -785,6 +810,12 @@ class HipEngine(object):
         check(self.lib.sml_prof_enable(self._ctx, int(bool(on))), "sml_prof_enable")
         if on:
             check(self.lib.sml_prof_reset(self._ctx), "sml_prof_reset")
+
+    def profile_pair_overhead(self, n=512):
+        """Microseconds an EMPTY HIP-event pair reads on the current stream (subtract it from short kernels' averages)."""
+        us = ctypes.c_double(0.0)
+        check(self.lib.sml_prof_pair_overhead(self._ctx, int(n), self._stream(), ctypes.byref(us)), "sml_prof_pair_overhead")
+        return us.value
 
     def profile_read(self):
         """{kernel class: (launches, total ms)} measured with HIP events since profile(True)."""

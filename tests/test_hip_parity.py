@@ -269,6 +269,98 @@ def test_tr_stage_theta_gradient_vs_autograd(d):
             close(got, ref, 3e-4 if name.endswith("bias") else 5e-5)
 
 
+# ----------------------------------------------------------------------------- the autograd surface (drop-in path B)
+@pytest.mark.parametrize("d", [32, 64])
+@pytest.mark.parametrize("tag,kw", [("bce", {}), ("bpr", dict(BCE=False)), ("bprnorm", dict(BCE=False, norm=True))])
+def test_g2_run_mf_backward_fills_the_grads_the_reference_gets(d, tag, kw):
+    """ConvTransfer_com.run_MF returns a loss a caller can backpropagate (model/conv_transfer.py:113-135 as used at
+    model/transfer.py:476-502, 714-723): loss.backward() fills x_hat.grad for the three row blocks and every
+    parameter's .grad -- held against the reference's own autograd results (G2), for BCE, BPR and BPR-norm."""
+    z = golden("g2_run_mf_d%d.npz" % d)
+    net = make_transfer(d, z, device=DEV)
+    ins = [T(z[k], DEV).clone() for k in ("ul", "uh", "il", "ih", "nl", "nh")]
+    for k in (1, 3, 5):
+        ins[k].requires_grad_(True)
+    net.zero_grad()
+    loss = net.run_MF(*ins, **kw)
+    assert loss.requires_grad
+    loss.backward()
+    np.testing.assert_allclose(float(loss.detach()), float(z["loss_" + tag]), rtol=1e-4)
+    for k, name in ((1, "gu_"), (3, "gi_"), (5, "gn_")):
+        close(ins[k].grad.cpu().numpy(), z[name + tag], 5e-5)
+    for name, p in net.named_parameters():
+        close(p.grad.cpu().numpy(), z["gtheta_%s.%s" % (tag, name)], 3e-4 if name.endswith("bias") else 5e-5)
+    # a scaled upstream gradient scales everything; no_grad gives a plain value
+    net.zero_grad()
+    ins[1].grad = None
+    (2.0 * net.run_MF(*ins, **kw)).backward()
+    close(ins[1].grad.cpu().numpy(), 2.0 * z["gu_" + tag], 5e-5)
+    with torch.no_grad():
+        assert not net.run_MF(*ins, **kw).requires_grad
+
+
+@pytest.mark.parametrize("variant", ["", "_conv"])
+def test_reference_shaped_inner_loops_through_the_autograd_surface(variant):
+    """INTEGRATION.md path B, driven: the reference's OWN inner loops (model/transfer.py:463-511 and :701-728) written
+    as the reference writes them -- nn.Embedding tables, torch.optim.Adam, zero_grad -> run_MF -> + l2 -> backward ->
+    step -- with this build's ConvTransfer_com / ConvTransfer as the only replaced part, against the reference's
+    recorded batches (G3: per-batch MF-stage losses and the tables after K steps; G4: per-batch TR-stage losses and
+    theta)."""
+    z = golden("g3_mf_stage%s.npz" % variant)
+    lr, l2, B, epochs = z["hp_mf"]
+    B = int(B)
+    U, d = z["W_user0"].shape
+    mf = make_mf(U, z["W_item0"].shape[0], d, z["W_user0"], z["W_item0"], device=DEV)
+    net = make_transfer(d, z, prefix="theta0.", device=DEV)
+    lu, li = T(z["Wlast_user"], DEV), T(z["Wlast_item"], DEV)
+    opt = torch.optim.Adam(mf.parameters(), lr=float(lr), weight_decay=0)
+    tri = torch.from_numpy(z["mf_triples"]).to(DEV)
+    n = z["set_t"].shape[0]
+    losses = []
+    for ep in range(int(epochs)):
+        for b0 in range(0, n, B):
+            t = tri[ep * n + b0:ep * n + min(b0 + B, n)]
+            u, i, j = t[:, 0], t[:, 1], t[:, 2]
+            mf.zero_grad()
+            net.zero_grad()
+            uh, ih, nh = mf.user_laten(u), mf.item_laten(i), mf.item_laten(j)
+            loss = net.run_MF(lu[u], uh, li[i], ih, li[j], nh)
+            loss = loss + float(l2) * 0.5 * torch.sum(uh ** 2 + ih ** 2 + nh ** 2)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+    np.testing.assert_allclose(np.array(losses), z["mf_batch_loss"], rtol=1e-4)
+    steps = int(z["adam_step"])
+    adam_close(mf.user_laten.weight.detach().cpu().numpy(), z["W_user1"], float(lr), steps)
+    adam_close(mf.item_laten.weight.detach().cpu().numpy(), z["W_item1"], float(lr), steps)
+    # ---- the TR-stage loop (only theta requires grad; Adam with weight decay)
+    z = golden("g4_tr_stage%s.npz" % variant)
+    lr, wd, B, epochs = z["hp_tr"]
+    B = int(B)
+    d = z["Wlast_user"].shape[1]
+    net = make_transfer(d, z, prefix="theta0.", device=DEV)
+    lu, li, hu, hi = (T(z[k], DEV) for k in ("Wlast_user", "Wlast_item", "What_user", "What_item"))
+    opt = torch.optim.Adam(net.parameters(), lr=float(lr), weight_decay=float(wd))
+    tri = torch.from_numpy(z["tr_triples"]).to(DEV)
+    n = z["set_tt"].shape[0]
+    losses = []
+    for ep in range(int(epochs)):
+        for b0 in range(0, n, B):
+            t = tri[ep * n + b0:ep * n + min(b0 + B, n)]
+            u, i, j = t[:, 0], t[:, 1], t[:, 2]
+            net.zero_grad()
+            loss = net.run_MF(lu[u], hu[u], li[i], hi[i], li[j], hi[j])
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+    np.testing.assert_allclose(np.array(losses), z["tr_batch_loss"], rtol=1e-4)
+    for k, v in net.state_dict().items():
+        if variant == "_conv" and k == "item_transfer.fc2.bias":     # an exactly-zero gradient: Adam normalises rounding noise (see G4)
+            assert np.abs(v.detach().cpu().numpy() - z["theta1." + k]).max() <= 0.1 * float(lr) * len(losses), k
+            continue
+        adam_close(v.detach().cpu().numpy(), z["theta1." + k], float(lr), len(losses), frac=0.99)
+
+
 # ----------------------------------------------------------------------------- G6 (a13)
 def test_g6_eval():
     z = golden("g6_eval.npz")

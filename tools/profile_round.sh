@@ -21,6 +21,9 @@ run period_stats --kernel-trace --stats --output-format csv -d "$OUT/period_stat
 # share the device with the training stream; the kernels and their traffic are the same)
 run period_fetch --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/period_fetch" -- python3 $PERIOD --no-roofline --no-overlap
 run period_write --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/period_write" -- python3 $PERIOD --no-roofline --no-overlap
+# MFMA utilisation of the transfer kernels (north_star: "rocprof ... MFMA utilisation against MI355X peak"): busy cycles of
+# the matrix pipe, fp32 MFMA ops and the launch's active cycles, per kernel, in a counter pass of their own
+run period_mfma --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --output-format csv -d "$OUT/period_mfma" -- python3 $PERIOD --no-roofline --no-overlap
 for z in 0 1; do
     run bare_z${z}_stats --kernel-trace --stats --output-format csv -d "$OUT/bare_z${z}_stats" -- python3 $BARE --item-zipf $z
     run bare_z${z}_fetch --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/bare_z${z}_fetch" -- python3 $BARE --item-zipf $z

@@ -52,6 +52,37 @@ def counters(run_dir, counter):
     return acc
 
 
+def all_counters(run_dir):
+    """{kernel: {counter: [launches, sum]}} over every counter in the run."""
+    acc = {}
+    for path in glob.glob(os.path.join(run_dir, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                e = acc.setdefault(short(r.get("Kernel_Name", "")), {}).setdefault(r.get("Counter_Name"), [0, 0.0])
+                e[0] += 1
+                e[1] += float(r.get("Counter_Value", 0.0))
+    return acc
+
+
+# fp32 MFMA work of one instruction, for the achieved-FLOP cross-check: SQ_INSTS_VALU_MFMA_MOPS_F32 counts
+# MFMA "mega-ops" in units of 512 flops as rocprofv3 reports it on gfx950 (v_mfma_f32_16x16x4_f32 = 2*16*16*4 = 2,048 flops = 4 units)
+def mfma_summary(run_dir):
+    out = {}
+    for k, cs in all_counters(run_dir).items():
+        if not k.startswith("k_t"):
+            continue
+        n = max(cs.get("GRBM_GUI_ACTIVE", [1, 0])[0], 1)
+        avg = {c: v[1] / max(v[0], 1) for c, v in cs.items()}
+        e = {"launches": n, "avg_per_launch": avg}
+        busy, act = avg.get("SQ_VALU_MFMA_BUSY_CYCLES"), avg.get("GRBM_GUI_ACTIVE")
+        if busy and act:
+            # the SQ counter is summed over the chip's 1,024 SIMDs (256 CUs x 4); GRBM_GUI_ACTIVE is the launch's
+            # active cycles per shader engine sample: busy fraction of the matrix pipes = busy / (active * 1024)
+            e["mfma_busy_frac_of_all_simds"] = busy / (act * 1024.0)
+        out[k] = e
+    return out
+
+
 def main():
     root, tag = sys.argv[1], sys.argv[2]
     out = os.path.join(root, "summary")
@@ -68,6 +99,11 @@ def main():
                     f.write("kernel,calls,total_ms,avg_us\n")
                     for k, (c, t) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
                         f.write('"%s",%d,%.3f,%.2f\n' % (k, c, t / 1e6, t / 1e3 / max(c, 1)))
+        if run.endswith("_mfma"):
+            m = mfma_summary(d)
+            if m:
+                with open(os.path.join(out, "%s_pmc_mfma.json" % tag), "w") as f:
+                    json.dump(m, f, indent=1, sort_keys=True)
         for suffix, counter in (("_fetch", "FETCH_SIZE"), ("_write", "WRITE_SIZE")):
             if run.endswith(suffix):
                 for k, (c, v) in counters(d, counter).items():
