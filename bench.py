@@ -503,11 +503,12 @@ def main():
             kern = {k: {"launches": c, "total_ms": round(m, 3), "avg_us": round(1000.0 * m / c, 2)} for k, (c, m) in prof.items()}
             # What a HIP-event bracket adds to a short kernel's reading, measured in THIS run: the training stream is
             # gap-free (kernel time = step time), so the bracketed kernel totals of the training stream exceed the
-            # un-bracketed step by (launches x overhead).  Never less than an empty pair's own reading.
+            # un-bracketed step by (launches x overhead).  An EMPTY pair's own reading (also measured) is an upper bound:
+            # it reads more than a bracket adds around a kernel, so it is quoted, not subtracted.
             train = {k: v for k, v in prof.items() if k != "k_eval_ranks"}
             n_launch = sum(c for c, _ in train.values())
             derived = (sum(m for _, m in train.values()) - 1000.0 * dt / a.steps) * 1000.0 / max(n_launch, 1)
-            overhead_us = max(empty_pair_us, min(derived, 6.0)) if derived > 0 else empty_pair_us
+            overhead_us = min(max(derived, 0.0), empty_pair_us)
             if bound is not None and cnt:
                 per_launch = work / cnt
                 avg_raw_s = ms / 1000.0 / cnt

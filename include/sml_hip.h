@@ -286,6 +286,35 @@ int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n
                              int batch, float lr, float lam_user, float lam_item, int loss_kind,
                              float* batch_loss, int prepared_slot, const sml_bare_exchange* xchg, void* stream);
 
+/* The bare step with the ITEM TABLE SHARDED over the ranks (configs 4 / 5: 10M x 1M and 50M x 5M over 8 GPUs), on the
+ * one-shot peer exchange (sml_peer_attach; rows_cap >= 2*batch, head_rows * d <= 2 * sml_theta_net_size(d)).
+ * Replicating the items makes the step exchange-bound by a factor of ten (every rank would receive every rank's
+ * 2*batch gradient rows); here
+ *   - the head rows [0, head_rows) -- the popular items of a Zipf catalogue, whose occurrences would otherwise all
+ *     land on one owner -- are replicated (w_item_head): every rank sums its OWN occurrences' gradient rows into a
+ *     dense [head_rows, d] partial, the partials are all-reduced one-shot (pushed into every rank's inbox, added in
+ *     rank order) and every replica applies the identical update;
+ *   - a tail row r >= head_rows lives on rank (r - head_rows) / shard_rows only (item_shard[q]: every rank's shard
+ *     as addressable from this device): the gradient pass READS it from its owner over the peer mapping and STORES
+ *     the occurrence's gradient row straight into the owner's inbox; the owner adds the rows of all ranks in a fixed
+ *     order (job-wide occurrence list built from items_all) and writes its shard -- owner-computes, an all-to-all whose
+ *     volume per rank does not grow with the world size.
+ * Users are row-sharded as in sml_bare_exchange (w_user, triples with local user indices, the same n and batch on
+ * every rank).  Per batch two counter rounds order the ranks: "all gradient rows of batch b have landed" before an
+ * owner updates, "every owner has updated" before anybody reads rows for batch b + 1.  Exact synchronous SGD of the
+ * GLOBAL batch; replicas of the head stay bit-identical.  dx scratch and index lists live in the context. */
+typedef struct {
+    int world, rank;
+    int64_t head_rows, shard_rows;
+    void* const* item_shard;    /* host array [world] of device pointers: rank q's tail shard [shard_rows, d] */
+    void* w_item_head;          /* [head_rows, d] (NULL when head_rows == 0) */
+    const int64_t* items_all;   /* device [world][n][2], as in sml_bare_exchange */
+    float loss_scale;
+} sml_bare_shard;
+int sml_embed_loss_sgd_epoch_sharded(sml_ctx* ctx, void* w_user, int64_t n_user, int64_t n_item, int dtype_bytes,
+                                     const int64_t* triples, int64_t n, int batch, float lr, float lam_user, float lam_item,
+                                     int loss_kind, float* batch_loss, const sml_bare_shard* sh, void* stream);
+
 /* The same step as the reference's baselines run it (model/baseline.py:188-201 in base_train, :343-361 in
  * run_one_stage2: fine-tune / full-retrain MF): BCE + L2 loss and torch.optim.Adam(lr, wd 0) over the DENSE
  * tables, reproduced lazily per row exactly as in sml_mf_stage_epoch (same sml_mf_tables; last_* are not

@@ -40,6 +40,11 @@ class BareExchange(ctypes.Structure):
                 ("hook_user", c_void), ("loss_scale", ctypes.c_float)]
 
 
+class BareShard(ctypes.Structure):
+    _fields_ = [("world", ctypes.c_int), ("rank", ctypes.c_int), ("head_rows", ctypes.c_int64), ("shard_rows", ctypes.c_int64),
+                ("item_shard", ctypes.POINTER(c_void)), ("w_item_head", c_void), ("items_all", c_void), ("loss_scale", ctypes.c_float)]
+
+
 class BatchPlan(ctypes.Structure):
     _fields_ = [("n_batches", ctypes.c_int64), ("batch_off", c_void), ("batch_off_dev", c_void), ("loss_scale", c_void)]
 
@@ -73,6 +78,9 @@ SIGNATURES = {
     "sml_embed_loss_sgd_epoch": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                                                 c_void, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                                 ctypes.c_float, ctypes.c_int, c_void, ctypes.c_int, ctypes.POINTER(BareExchange), c_void]),
+    "sml_embed_loss_sgd_epoch_sharded": (ctypes.c_int, [c_void, c_void, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, c_void, ctypes.c_int64,
+                                                        ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int, c_void,
+                                                        ctypes.POINTER(BareShard), c_void]),
     "sml_embed_loss_adam_epoch": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                                  ctypes.c_float, ctypes.c_int, c_void, c_void, c_void]),
     "sml_embed_loss_sgd_prepare": (ctypes.c_int, [c_void, c_void, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,

@@ -175,13 +175,17 @@ struct sml_ctx {
         unsigned long long* flags[SML_MAX_PEERS] = {nullptr};
         int64_t theta_slot = 0;          // floats per (parity, source) theta slot
         int64_t rows_cap = 0;            // rows per (parity, source) row slot
-        int64_t tick[2] = {0, 0};        // exchanges done, per kind (0: theta, 1: rows)
-        unsigned long long expect[2][2] = {{0, 0}, {0, 0}};   // [kind][parity]: counter value after the last push
+        int64_t tick[3] = {0, 0, 0};     // exchanges done, per kind (0: theta / dense head, 1: rows, 2: "owner has updated")
+        unsigned long long expect[3][2] = {{0, 0}, {0, 0}, {0, 0}};   // [kind][parity]: counter value after the last push
+        bool done_pending = false;       // sharded bare step: the last batch's "owner done" round has not been waited for yet
+        SmlPeerPoll done_poll;
         long long timeout = 0;           // 100 MHz ticks
         int* err = nullptr;              // device: incidents
     } peer;
     Buf<int> hot_first;
     Buf<float> hot_part;
+    Buf<float> head_part;    // sharded bare step: this rank's dense [head_rows, d] gradient partial
+    Buf<void*> ptr_tab;      // sharded bare step: [0..8) shard pointers, [8..16) inbox bases (device table, per-lane indexed)
     Prof prof;
 
     void release_all() {
@@ -194,7 +198,7 @@ struct sml_ctx {
         for (auto& r : sched_retired) { if (r.dev) (void)hipFree(r.dev); if (r.host) (void)hipHostFree(r.host); (void)hipEventDestroy(r.done); }
         sched_retired.clear();
         if (sched_ready) { (void)hipEventDestroy(sched_ready); sched_ready = nullptr; }
-        hot_first.release(); hot_part.release();
+        hot_first.release(); hot_part.release(); head_part.release(); ptr_tab.release();
         if (peer.err) { (void)hipFree(peer.err); peer.err = nullptr; }
     }
 };
@@ -340,11 +344,11 @@ void peer_step(sml_ctx* c, int kind, int incr, SmlPeerPush* push, SmlPeerPoll* p
     memset(push, 0, sizeof(*push)); memset(poll, 0, sizeof(*poll));
     push->world = W;
     for (int q = 0; q < W; ++q) {
-        push->dst[q] = kind == 0 ? peer_theta_at(c, q, parity, me) : peer_rows_at(c, q, parity, me);
+        push->dst[q] = kind == 0 ? peer_theta_at(c, q, parity, me) : kind == 1 ? peer_rows_at(c, q, parity, me) : nullptr;
         push->flag[q] = peer_flag_at(c, q, kind, parity, me);
     }
     poll->world = W;
-    poll->slot0 = kind == 0 ? peer_theta_at(c, me, parity, 0) : peer_rows_at(c, me, parity, 0);
+    poll->slot0 = kind == 0 ? peer_theta_at(c, me, parity, 0) : kind == 1 ? peer_rows_at(c, me, parity, 0) : nullptr;
     poll->slot_stride = kind == 0 ? c->peer.theta_slot : c->peer.rows_cap * c->d;
     poll->flag0 = peer_flag_at(c, me, kind, parity, 0);
     poll->expect = c->peer.expect[kind][parity];
@@ -365,13 +369,17 @@ struct DupHead {
 // single-occurrence ones -- an in-place update on one rank would leave the other replicas behind)
 template <typename K>
 struct AnyHead {
-    const K* keys; int64_t n;
-    __host__ __device__ bool operator()(const uint32_t& q) const { return q == 0 || keys[q - 1] != keys[q]; }
+    const K* keys; int64_t n; K sent;       // sent != 0: keys whose row bits are all ones are placeholders, never a run
+    __host__ __device__ bool operator()(const uint32_t& q) const {
+        const K k = keys[q];
+        if (sent && (k & sent) == sent) return false;
+        return q == 0 || keys[q - 1] != k;
+    }
 };
 template <typename K>
-int select_all_heads(IndexSet* c, const void* keys, int64_t n, uint32_t* heads, int* n_sel, hipStream_t st) {
+int select_all_heads(IndexSet* c, const void* keys, int64_t n, uint32_t* heads, int* n_sel, hipStream_t st, uint64_t sent = 0) {
     hipcub::CountingInputIterator<uint32_t> pos(0u);
-    AnyHead<K> pred{reinterpret_cast<const K*>(keys), n};
+    AnyHead<K> pred{reinterpret_cast<const K*>(keys), n, (K)sent};
     size_t tmp = 0;
     HIPCHK(hipcub::DeviceSelect::If(nullptr, tmp, pos, heads, n_sel, (int)n, pred, st));
     HIPCHK(c->cub_tmp.ensure(tmp + 256));
@@ -390,15 +398,15 @@ int select_dup_heads(IndexSet* c, const void* keys, int64_t n, uint32_t* heads, 
 }
 
 template <typename K>
-int sort_pairs(IndexSet* c, int64_t n, int64_t n_items, int end_u, int end_i, hipStream_t st) {
+int sort_pairs(IndexSet* c, int64_t n, int64_t n_items, int end_u, int end_i, hipStream_t st, bool do_users = true) {
     K* ku = reinterpret_cast<K*>(c->key_u.p); K* ku2 = reinterpret_cast<K*>(c->key_u2.p);
     K* ki = reinterpret_cast<K*>(c->key_i.p); K* ki2 = reinterpret_cast<K*>(c->key_i2.p);
     size_t tmp1 = 0, tmp2 = 0;
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp1, ku, ku2, c->val_u.p, c->val_u2.p, (int)n, 0, end_u, st));
+    if (do_users) HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp1, ku, ku2, c->val_u.p, c->val_u2.p, (int)n, 0, end_u, st));
     HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, ki, ki2, c->val_i.p, c->val_i2.p, (int)n_items, 0, end_i, st));
     size_t tmp = tmp1 > tmp2 ? tmp1 : tmp2;
     HIPCHK(c->cub_tmp.ensure(tmp + 256));
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tmp, ku, ku2, c->val_u.p, c->val_u2.p, (int)n, 0, end_u, st));
+    if (do_users) HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tmp, ku, ku2, c->val_u.p, c->val_u2.p, (int)n, 0, end_u, st));
     HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tmp, ki, ki2, c->val_i.p, c->val_i2.p, (int)n_items, 0, end_i, st));
     return SML_OK;
 }
@@ -482,6 +490,70 @@ int sort_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
         HIPCHK(sml_launch_batch_offsets(c->runs_i.p, c->n_sel.p + 1, (int)nb, seg_i, c->off_i.p, st));
     }
     c->n = n; c->batch = batch; c->triples = tri; c->world = bx ? bx->world : 1;
+    return SML_OK;
+}
+
+// Index lists of the item-sharded bare step.  A: this rank's users (as in sort_epoch) and the JOB's occurrences of the
+// tail rows this rank owns (every run is applied by the run kernel).  Bset: this rank's own occurrences of head rows
+// (summed into the dense partial).  Occurrences that do not belong to a list carry the batch's sentinel row.
+int sort_epoch_sharded(IndexSet* A, IndexSet* Bset, const int64_t* tri, int64_t n, int batch, int64_t n_user, const sml_bare_shard* sh,
+                       int64_t rows_cap, hipStream_t st) {
+    const int W = sh->world;
+    const int64_t nb = (n + batch - 1) / batch;
+    const int bb = ceil_log2(nb + 1);
+    for (int pass = 0; pass < 2; ++pass) {
+        IndexSet* c = pass ? Bset : A;
+        if (pass == 1 && sh->head_rows == 0) break;
+        const int64_t n_items = pass ? 2 * n : (int64_t)W * 2 * n;
+        const int64_t seg_i = pass ? (int64_t)2 * batch : (int64_t)W * 2 * batch;
+        if (n_items > 0x7fffffff) return fail(SML_EINVAL, "index preparation", "too many item occurrences in one epoch");
+        if (!pass) {
+            HIPCHK(c->key_u.ensure((size_t)n + 1)); HIPCHK(c->key_u2.ensure((size_t)n + 1));
+            HIPCHK(c->val_u.ensure((size_t)n + 1)); HIPCHK(c->val_u2.ensure((size_t)n + 1));
+        }
+        HIPCHK(c->key_i.ensure((size_t)n_items + 1)); HIPCHK(c->key_i2.ensure((size_t)n_items + 1));
+        HIPCHK(c->val_i.ensure((size_t)n_items + 1)); HIPCHK(c->val_i2.ensure((size_t)n_items + 1));
+        const int rbu = ceil_log2(n_user > 0 ? n_user : 1);
+        const int rbi = ceil_log2((pass ? sh->head_rows : sh->shard_rows) + 1);
+        const bool narrow = bb + rbi <= 32 && (pass || bb + rbu <= 32);
+        c->key_bytes = narrow ? 4 : 8;
+        c->row_bits_u = narrow ? rbu : 32; c->row_bits_i = narrow ? rbi : 32;
+        if (!pass) HIPCHK(sml_launch_build_keys(c->key_bytes, tri, n, batch, 0, c->row_bits_u, c->row_bits_i, c->key_u.p, c->val_u.p,
+                                                c->key_i.p, c->val_i.p, nullptr, (int)nb, st));      // (its item keys are overwritten next)
+        SmlShardKeys sk;
+        sk.mode = pass ? 2 : 1; sk.rank = sh->rank; sk.head_rows = sh->head_rows; sk.shard_rows = sh->shard_rows; sk.rows_cap = rows_cap;
+        HIPCHK(sml_launch_build_item_keys_sh(c->key_bytes, sh->items_all, W, n, batch, c->row_bits_i, sk, c->key_i.p, c->val_i.p, st));
+        int rc = narrow ? sort_pairs<uint32_t>(c, n, n_items, c->row_bits_u + bb, c->row_bits_i + bb, st, !pass)
+                        : sort_pairs<uint64_t>(c, n, n_items, 32 + bb, 32 + bb, st, !pass);
+        if (rc) return rc;
+        HIPCHK(c->heads_i.ensure((size_t)n_items + 8)); HIPCHK(c->runs_i.ensure((size_t)n_items + 8));
+        HIPCHK(c->off_u.ensure((size_t)nb + 1)); HIPCHK(c->off_i.ensure((size_t)nb + 1)); HIPCHK(c->n_sel.ensure(4));
+        HIPCHK(hipMemsetAsync(c->n_sel.p, 0, 4 * sizeof(int), st));
+        if (!pass) {
+            HIPCHK(c->uniq.ensure((size_t)3 * nb * batch));
+            HIPCHK(c->heads_u.ensure((size_t)n / 2 + 8)); HIPCHK(c->runs_u.ensure((size_t)n / 2 + 8));
+            HIPCHK(hipMemsetAsync(c->uniq.p, 1, (size_t)3 * nb * batch, st));
+            HIPCHK(sml_launch_mark_unique(c->key_bytes, c->key_u2.p, c->val_u2.p, n, c->row_bits_u, c->uniq.p, (int64_t)3 * batch, st));
+            HIPCHK(sml_launch_zero_item_marks(c->uniq.p, n, batch, st));     // items: never in place
+            rc = narrow ? select_dup_heads<uint32_t>(c, c->key_u2.p, n, c->heads_u.p, c->n_sel.p, st)
+                        : select_dup_heads<uint64_t>(c, c->key_u2.p, n, c->heads_u.p, c->n_sel.p, st);
+            if (rc) return rc;
+            HIPCHK(sml_launch_make_runs(c->key_bytes, c->key_u2.p, c->val_u2.p, n, c->row_bits_u, c->heads_u.p, c->n_sel.p, n / 2, c->runs_u.p,
+                                        c->n_sel.p + 2, (int64_t)batch, 0, nullptr, nullptr, 0, st));
+            HIPCHK(sml_launch_batch_offsets(c->runs_u.p, c->n_sel.p, (int)nb, (int64_t)batch, c->off_u.p, st));
+        } else {
+            HIPCHK(hipMemsetAsync(c->off_u.p, 0, (size_t)(nb + 1) * sizeof(int), st));      // no user runs in this list
+        }
+        const uint64_t sent = narrow ? ((1ull << rbi) - 1) : 0xffffffffull;
+        rc = narrow ? select_all_heads<uint32_t>(c, c->key_i2.p, n_items, c->heads_i.p, c->n_sel.p + 1, st, sent)
+                    : select_all_heads<uint64_t>(c, c->key_i2.p, n_items, c->heads_i.p, c->n_sel.p + 1, st, sent);
+        if (rc) return rc;
+        HIPCHK(sml_launch_make_runs(c->key_bytes, c->key_i2.p, c->val_i2.p, n_items, c->row_bits_i, c->heads_i.p, c->n_sel.p + 1, n_items, c->runs_i.p,
+                                    c->n_sel.p + 2, seg_i, 1, nullptr, nullptr, 0, st));
+        HIPCHK(sml_launch_batch_offsets(c->runs_i.p, c->n_sel.p + 1, (int)nb, seg_i, c->off_i.p, st));
+        c->hot_cap = 0;
+        c->n = -1;        // (not a list sml_embed_loss_sgd_epoch may reuse)
+    }
     return SML_OK;
 }
 
@@ -1006,6 +1078,101 @@ int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n
     return SML_OK;
 }
 
+int sml_embed_loss_sgd_epoch_sharded(sml_ctx* ctx, void* w_user, int64_t n_user, int64_t n_item, int dtype_bytes,
+                                     const int64_t* triples, int64_t n, int batch, float lr, float lam_user, float lam_item,
+                                     int loss_kind, float* batch_loss, const sml_bare_shard* sh, void* stream) {
+    if (!ctx || !w_user || !triples || !batch_loss || !sh || n <= 0 || batch <= 0 || n_user <= 0 || n_item <= 0)
+        return fail(SML_EINVAL, "sml_embed_loss_sgd_epoch_sharded", "bad argument");
+    if (dtype_bytes != 4 && dtype_bytes != 2) return fail(SML_EINVAL, "sml_embed_loss_sgd_epoch_sharded", "dtype_bytes must be 4 or 2");
+    if (loss_kind != SML_LOSS_BCE && loss_kind != SML_LOSS_BPR) return fail(SML_EINVAL, "sml_embed_loss_sgd_epoch_sharded", "loss_kind");
+    if (batch > ctx->max_batch) return fail(SML_EINVAL, "sml_embed_loss_sgd_epoch_sharded", "batch exceeds ctx max_batch");
+    const int W = sh->world;
+    if (ctx->peer.world <= 0 || ctx->peer.world != W || ctx->peer.rank != sh->rank)
+        return fail(SML_ESTATE, "sml_embed_loss_sgd_epoch_sharded", "needs sml_peer_attach with the same world / rank");
+    if (!sh->item_shard || !sh->items_all || sh->head_rows < 0 || sh->shard_rows <= 0 || (sh->head_rows > 0 && !sh->w_item_head))
+        return fail(SML_EINVAL, "sml_embed_loss_sgd_epoch_sharded", "incomplete shard descriptor");
+    for (int q = 0; q < W; ++q) if (!sh->item_shard[q]) return fail(SML_EINVAL, "sml_embed_loss_sgd_epoch_sharded", "every rank's shard pointer is needed");
+    if (sh->head_rows + (int64_t)W * sh->shard_rows < n_item) return fail(SML_EINVAL, "sml_embed_loss_sgd_epoch_sharded", "head + shards do not cover the item table");
+    if (ctx->peer.rows_cap < 2 * (int64_t)batch) return fail(SML_EINVAL, "sml_embed_loss_sgd_epoch_sharded", "the inboxes' rows_cap must hold a batch's 2*batch gradient rows");
+    if (sh->head_rows * ctx->d > 2 * (int64_t)sml_net_size(ctx->d) || (sh->head_rows * ctx->d) % 4)
+        return fail(SML_EINVAL, "sml_embed_loss_sgd_epoch_sharded", "the dense head partial must fit a theta slot (head_rows * d <= 2 * net size)");
+    DevGuard g(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    const int d = ctx->d, me = sh->rank;
+    const int64_t nb = (n + batch - 1) / batch, H = sh->head_rows;
+    int rc;
+    HIPCHK(ctx->dx.ensure((size_t)3 * batch * d));
+    const int lpr = d * dtype_bytes / 16;
+    const int lstride = (int)(((int64_t)batch * lpr + 255) / 256);
+    HIPCHK(ctx->loss_part.ensure((size_t)nb * lstride));
+    if (H > 0) HIPCHK(ctx->head_part.ensure((size_t)H * d));
+    HIPCHK(ctx->ptr_tab.ensure(16));
+    ctx->prof.begin(PC_SORT, st);
+    rc = sort_epoch_sharded(&ctx->ix[0], &ctx->ix[1], triples, n, batch, n_user, sh, ctx->peer.rows_cap, st);
+    ctx->prof.end(st);
+    if (rc) return rc;
+    void* inboxes[8];
+    for (int q = 0; q < 8; ++q) inboxes[q] = q < W ? ctx->peer.inbox[q] : nullptr;
+    HIPCHK(sml_launch_set_ptr_tab(ctx->ptr_tab.p, sh->item_shard, W, st));
+    HIPCHK(sml_launch_set_ptr_tab(ctx->ptr_tab.p + 8, inboxes, W, st));
+    HIPCHK(hipMemsetAsync(ctx->loss_part.p, 0, (size_t)nb * lstride * sizeof(float), st));
+    IndexSet* A = &ctx->ix[0];
+    IndexSet* Bs = &ctx->ix[1];
+    for (int64_t b = 0; b < nb; ++b) {
+        const int B = (int)((n - b * batch) < batch ? (n - b * batch) : batch);
+        // (1) every owner has applied the previous batch (its shard rows are final; this parity's inbox slots are free)
+        if (ctx->peer.done_pending) { ctx->prof.begin(PC_MISC, st); HIPCHK(sml_launch_peer_wait(ctx->peer.done_poll, st)); ctx->prof.end(st); }
+        // (2) gradient pass: tail rows read from their owners, tail gradient rows stored into their owners' inboxes
+        SmlBareArgs a;
+        memset(&a, 0, sizeof(a));
+        SmlPeerPoll rows_poll;
+        int n_blocks = (int)(((int64_t)B * lpr + 255) / 256);
+        peer_step(ctx, 1, n_blocks, &a.peer, &rows_poll);
+        a.w_user = w_user; a.w_item = sh->w_item_head; a.tri = triples + b * batch * 3; a.B = B; a.dx = ctx->dx.p;
+        a.loss_part = ctx->loss_part.p + b * lstride; a.kind = loss_kind; a.lam_user = lam_user; a.lam_item = lam_item;
+        a.uniq = A->uniq.p + (size_t)3 * b * batch; a.lr = lr; a.scale = sh->loss_scale;
+        a.shard_tab = reinterpret_cast<const void* const*>(ctx->ptr_tab.p);
+        a.inbox_tab = reinterpret_cast<float* const*>(ctx->ptr_tab.p + 8);
+        a.head_rows = H; a.shard_rows = sh->shard_rows;
+        a.push_off = (long long)(a.peer.dst[me] - reinterpret_cast<float*>(ctx->peer.inbox[me]));     // the same offset inside every inbox
+        ctx->prof.begin(PC_BARE_GRAD, st); HIPCHK(sml_launch_bare_grad(d, dtype_bytes, a, nullptr, st)); ctx->prof.end(st);
+        // (3) all ranks' gradient rows of this batch have landed here -> owner update of this rank's shard (+ its duplicated user rows)
+        ctx->prof.begin(PC_MISC, st); HIPCHK(sml_launch_peer_wait(rows_poll, st)); ctx->prof.end(st);
+        SmlRunArgs u;
+        memset(&u, 0, sizeof(u));
+        u.run_u = A->runs_u.p; u.run_i = A->runs_i.p; u.off_u = A->off_u.p; u.off_i = A->off_i.p; u.batch_index = (int)b;
+        u.val_u = A->val_u2.p; u.val_i = A->val_i2.p;
+        u.dx = ctx->dx.p; u.dx_i = rows_poll.slot0; u.w_user = w_user; u.w_item = sh->item_shard[me]; u.lr = lr;
+        ctx->prof.begin(PC_SEG_SGD, st); HIPCHK(sml_launch_run_sgd(d, dtype_bytes, u, (int64_t)B / 2 + (int64_t)W * 2 * B, st)); ctx->prof.end(st);
+        // (4) tell every rank: this owner is done with batch b
+        {
+            SmlPeerPush done_push;
+            peer_step(ctx, 2, 1, &done_push, &ctx->peer.done_poll);
+            ctx->peer.done_pending = true;
+            ctx->prof.begin(PC_MISC, st); HIPCHK(sml_launch_peer_signal(done_push, st)); ctx->prof.end(st);
+        }
+        // (5) the replicated head: this rank's occurrences -> dense partial -> one-shot all-reduce -> identical update everywhere
+        if (H > 0) {
+            HIPCHK(hipMemsetAsync(ctx->head_part.p, 0, (size_t)H * d * sizeof(float), st));
+            SmlRunArgs hgt;
+            memset(&hgt, 0, sizeof(hgt));
+            hgt.run_u = Bs->runs_i.p; hgt.run_i = Bs->runs_i.p; hgt.off_u = Bs->off_u.p; hgt.off_i = Bs->off_i.p; hgt.batch_index = (int)b;
+            hgt.val_u = Bs->val_i2.p; hgt.val_i = Bs->val_i2.p;
+            hgt.dx = ctx->dx.p; hgt.dx_i = ctx->dx.p; hgt.w_user = ctx->head_part.p; hgt.w_item = ctx->head_part.p;
+            hgt.lr = -1.0f;           // 0 - (-1) * sum = the sum itself, exactly
+            ctx->prof.begin(PC_SEG_SGD, st); HIPCHK(sml_launch_run_sgd(d, 4, hgt, (int64_t)2 * B, st)); ctx->prof.end(st);
+            SmlPeerPush hp; SmlPeerPoll hq;
+            peer_step(ctx, 0, sml_peer_push_blocks(H * d), &hp, &hq);
+            ctx->prof.begin(PC_MISC, st);
+            HIPCHK(sml_launch_peer_push(ctx->head_part.p, H * d, hp, st));
+            HIPCHK(sml_launch_head_apply(d, dtype_bytes, sh->w_item_head, H, lr, hq, st));
+            ctx->prof.end(st);
+        }
+    }
+    ctx->prof.begin(PC_MISC, st); HIPCHK(sml_launch_loss_finalize(ctx->loss_part.p, (int)nb, lstride, nullptr, batch_loss, st)); ctx->prof.end(st);
+    return SML_OK;
+}
+
 int sml_embed_loss_adam_epoch(sml_ctx* ctx, const sml_mf_tables* t, const int64_t* triples, int64_t n, int batch, float lr,
                               float lam_user, float lam_item, int loss_kind, int64_t* step, float* batch_loss, void* stream) {
     if (!ctx || !t || !t->w_user || !t->w_item || !t->m_user || !t->v_user || !t->m_item || !t->v_item || !t->step_user ||
@@ -1174,7 +1341,7 @@ int sml_peer_region_bytes(sml_ctx* ctx, int world, int64_t rows_cap, int64_t* in
     if (!ctx || world < 1 || world > SML_MAX_PEERS || rows_cap < 0 || !inbox_bytes || !flags_bytes)
         return fail(SML_EINVAL, "sml_peer_region_bytes", "bad argument");
     *inbox_bytes = (int64_t)2 * world * (peer_theta_slot(ctx->d) + rows_cap * ctx->d) * (int64_t)sizeof(float);
-    *flags_bytes = (int64_t)2 * 2 * world * (int64_t)sizeof(unsigned long long);
+    *flags_bytes = (int64_t)3 * 2 * world * (int64_t)sizeof(unsigned long long);     // kinds: theta / head, rows, "owner done"
     return SML_OK;
 }
 int sml_peer_alloc(int device, int64_t bytes, void** ptr) {
@@ -1243,7 +1410,8 @@ int sml_peer_attach(sml_ctx* ctx, int world, int rank, void* const* inbox, void*
     }
     ctx->peer.theta_slot = peer_theta_slot(ctx->d);
     ctx->peer.rows_cap = rows_cap;
-    ctx->peer.tick[0] = ctx->peer.tick[1] = 0;          // (the regions come zeroed from sml_peer_alloc: counters start at 0)
+    ctx->peer.tick[0] = ctx->peer.tick[1] = ctx->peer.tick[2] = 0;   // (the regions come zeroed from sml_peer_alloc: counters start at 0)
+    ctx->peer.done_pending = false;
     memset(ctx->peer.expect, 0, sizeof(ctx->peer.expect));
     ctx->peer.timeout = (long long)(timeout_s * 1e8);   // wall_clock64: 100 MHz
     return SML_OK;

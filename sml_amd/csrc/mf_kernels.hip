@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64) void k_loss_finalize(const float* __restrict__ 
 // zero-gradient Adam steps a dense optimiser would have applied since they were last touched (replayed
 // in registers, nothing written here), every occurrence emits its gradient row, and k_run_update<Adam>
 // finishes the step.
-template <int D, typename T, bool LAZY>
+template <int D, typename T, bool LAZY, bool SH = false>
 __global__ __launch_bounds__(256) void k_bare_grad(SmlBareArgs a) {
     constexpr int VEC = RowVec<T>::VEC;
     constexpr int LPR = D / VEC;
@@ -187,8 +187,20 @@ __global__ __launch_bounds__(256) void k_bare_grad(SmlBareArgs a) {
         float u[VEC], it[VEC], ng[VEC];
         if (SML_NT & 1) RowVec<T>::load_nt(reinterpret_cast<const T*>(a.w_user) + iu * D + sub * VEC, u);
         else RowVec<T>::load(reinterpret_cast<const T*>(a.w_user) + iu * D + sub * VEC, u);
-        RowVec<T>::load(reinterpret_cast<const T*>(a.w_item) + ii * D + sub * VEC, it);
-        RowVec<T>::load(reinterpret_cast<const T*>(a.w_item) + in * D + sub * VEC, ng);
+        // (item-sharded form: head rows from the local replica, tail rows from their owner's shard over the peer mapping)
+        int qi = -1, qn = -1;                 // owners of the two item rows (-1: head / not sharded)
+        auto item_row = [&](int64_t row, int& q) -> const T* {
+            if constexpr (SH) {
+                if (row >= a.head_rows) {
+                    const int64_t r = row - a.head_rows;
+                    q = (int)(r / a.shard_rows);
+                    return reinterpret_cast<const T*>(a.shard_tab[q]) + (r - (int64_t)q * a.shard_rows) * D;
+                }
+            }
+            return reinterpret_cast<const T*>(a.w_item) + row * D;
+        };
+        RowVec<T>::load(item_row(ii, qi) + sub * VEC, it);
+        RowVec<T>::load(item_row(in, qn) + sub * VEC, ng);
         if constexpr (LAZY) {
             static_assert(!LAZY || VEC == 4, "lazy Adam runs on fp32 tables");
             float m[3][4], v[3][4];
@@ -245,12 +257,28 @@ __global__ __launch_bounds__(256) void k_bare_grad(SmlBareArgs a) {
             }
         };
         emit(one_u, reinterpret_cast<T*>(a.w_user) + iu * D + sub * VEC, u, gx, a.dx + (int64_t)t * D + sub * VEC, (SML_NT & 2) != 0);
-        emit(one_i, reinterpret_cast<T*>(a.w_item) + ii * D + sub * VEC, it, gy, a.dx + (int64_t)(a.B + t) * D + sub * VEC, (SML_NT & 4) != 0);
-        emit(one_n, reinterpret_cast<T*>(a.w_item) + in * D + sub * VEC, ng, gz, a.dx + (int64_t)(2 * a.B + t) * D + sub * VEC, (SML_NT & 4) != 0);
+        if constexpr (SH) {
+            // a tail occurrence's gradient row goes straight into its owner's inbox, slot t (positive) / B + t (negative)
+            // of this rank's row slot; a head occurrence's row stays in the local dx (dense reduction later)
+            auto push = [&](int q, int slot, const float (&g)[VEC], float* dxrow) {
+                float* dst = q >= 0 ? a.inbox_tab[q] + a.push_off + (int64_t)slot * D + sub * VEC : dxrow;
+#pragma unroll
+                for (int h = 0; h < VEC / 4; ++h) {
+                    f32x4 v; v[0] = g[h * 4]; v[1] = g[h * 4 + 1]; v[2] = g[h * 4 + 2]; v[3] = g[h * 4 + 3];
+                    if (q >= 0) peer_store16(dst + h * 4, v); else *reinterpret_cast<f32x4*>(dst + h * 4) = v;
+                }
+            };
+            push(qi, t, gy, a.dx + (int64_t)(a.B + t) * D + sub * VEC);
+            push(qn, a.B + t, gz, a.dx + (int64_t)(2 * a.B + t) * D + sub * VEC);
+        } else {
+            emit(one_i, reinterpret_cast<T*>(a.w_item) + ii * D + sub * VEC, it, gy, a.dx + (int64_t)(a.B + t) * D + sub * VEC, (SML_NT & 4) != 0);
+            emit(one_n, reinterpret_cast<T*>(a.w_item) + in * D + sub * VEC, ng, gz, a.dx + (int64_t)(2 * a.B + t) * D + sub * VEC, (SML_NT & 4) != 0);
+        }
         contrib = (sub == 0 ? lt : 0.0f) + 0.5f * (a.lam_user * sq_u + a.lam_item * sq_i);
     }
     const float tot = block_sum256(contrib, sh4);
     if (threadIdx.x == 0) a.loss_part[blockIdx.x] = tot;
+    if constexpr (SH) peer_signal(a.peer);          // this workgroup's pushes are acknowledged: +1 on every owner's counter
 }
 
 // ------------------------------------------------------------------------------------
@@ -304,6 +332,65 @@ __global__ void k_build_item_keys_x(const int64_t* __restrict__ items_all, int w
     key_i[2 * g + 1] = ((K)b << row_bits_i) | (K)(uint32_t)items_all[2 * g + 1];
     val_i[2 * g + 1] = base + Bb + t;
 }
+
+template <typename K>
+__global__ void k_build_item_keys_sh(const int64_t* __restrict__ items_all, int world, int64_t n, int batch, int row_bits_i,
+                                     SmlShardKeys sk, K* __restrict__ key_i, uint32_t* __restrict__ val_i) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // mode 1: (rank q, element e); mode 2: element e of this rank
+    const int64_t tot = sk.mode == 1 ? (int64_t)world * n : n;
+    if (g >= tot) return;
+    const int64_t q = sk.mode == 1 ? g / n : sk.rank, e = sk.mode == 1 ? g - q * n : g;
+    const int64_t b = e / batch;
+    const int64_t rem = n - b * batch;
+    const uint32_t Bb = (uint32_t)(rem < batch ? rem : batch);
+    const uint32_t t = (uint32_t)(e - b * batch);
+    const K sent = (K)((1ull << row_bits_i) - 1);
+    const int64_t* it = items_all + 2 * (q * n + e);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int64_t row = it[c];
+        K kr = sent;
+        uint32_t v = 0;
+        if (sk.mode == 1) {
+            if (row >= sk.head_rows) {
+                const int64_t r = row - sk.head_rows;
+                if (r / sk.shard_rows == sk.rank) kr = (K)(r - (int64_t)sk.rank * sk.shard_rows);
+            }
+            v = (uint32_t)(q * sk.rows_cap) + (c ? Bb + t : t);
+        } else {
+            if (row < sk.head_rows) kr = (K)row;
+            v = (c ? 2 * Bb : Bb) + t;
+        }
+        key_i[2 * g + c] = ((K)b << row_bits_i) | kr;
+        val_i[2 * g + c] = v;
+    }
+}
+
+// w_head[row] -= lr * (sum over ranks, in rank order, of the ranks' dense head partials): every replica applies the same bits
+template <int D, typename T>
+__global__ __launch_bounds__(256) void k_head_apply(T* __restrict__ w, long long head_rows, float lr, SmlPeerPoll p) {
+    constexpr int VEC = RowVec<T>::VEC;
+    constexpr int LPR = D / VEC;
+    peer_wait(p);
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long row = gid / LPR;
+    const int sub = (int)(gid % LPR);
+    if (row >= head_rows) return;
+    float g[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) g[k] = 0.0f;
+    for (int q = 0; q < p.world; ++q) {
+        const float* src = p.slot0 + q * p.slot_stride + row * D + sub * VEC;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) { const float x = peer_load(src + k); g[k] = q == 0 ? x : g[k] + x; }
+    }
+    float x[VEC];
+    RowVec<T>::load(w + row * D + sub * VEC, x);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) x[k] -= lr * g[k];
+    RowVec<T>::store(w + row * D + sub * VEC, x);
+}
+__global__ __launch_bounds__(64) void k_peer_signal(SmlPeerPush p) { peer_signal(p); }
 
 __global__ void k_zero_item_marks(uint8_t* __restrict__ uniq, int64_t n, int batch) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1122,11 +1209,46 @@ hipError_t sml_launch_bare_grad(int d, int dtype_bytes, const SmlBareArgs& a, in
     if (a.sched != nullptr) {            // lazy dense-Adam form (fp32 tables)
         if (dtype_bytes != 4) return hipErrorInvalidValue;
         SML_DISPATCH_D(d, k_bare_grad<DD, float, true><<<dim3(nb), dim3(256), 0, st>>>(a));
+    } else if (a.shard_tab != nullptr) {  // item-sharded form over peer mappings
+        if (dtype_bytes == 4) { SML_DISPATCH_D(d, k_bare_grad<DD, float, false, true><<<dim3(nb), dim3(256), 0, st>>>(a)); }
+        else if (dtype_bytes == 2) { SML_DISPATCH_D(d, k_bare_grad<DD, __half, false, true><<<dim3(nb), dim3(256), 0, st>>>(a)); }
+        else return hipErrorInvalidValue;
     } else if (dtype_bytes == 4) {
         SML_DISPATCH_D(d, k_bare_grad<DD, float, false><<<dim3(nb), dim3(256), 0, st>>>(a));
     } else if (dtype_bytes == 2) {
         SML_DISPATCH_D(d, k_bare_grad<DD, __half, false><<<dim3(nb), dim3(256), 0, st>>>(a));
     } else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+hipError_t sml_launch_build_item_keys_sh(int key_bytes, const int64_t* items_all, int world, int64_t n, int batch, int row_bits_i,
+                                         const SmlShardKeys& sk, void* key_i, uint32_t* val_i, hipStream_t st) {
+    const int64_t tot = sk.mode == 1 ? (int64_t)world * n : n;
+    if (tot <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((tot + 255) / 256));
+    if (key_bytes == 4) k_build_item_keys_sh<uint32_t><<<grid, dim3(256), 0, st>>>(items_all, world, n, batch, row_bits_i, sk, (uint32_t*)key_i, val_i);
+    else k_build_item_keys_sh<uint64_t><<<grid, dim3(256), 0, st>>>(items_all, world, n, batch, row_bits_i, sk, (uint64_t*)key_i, val_i);
+    return hipGetLastError();
+}
+hipError_t sml_launch_head_apply(int d, int dtype_bytes, void* w_head, long long head_rows, float lr, const SmlPeerPoll& p, hipStream_t st) {
+    if (head_rows <= 0) return hipSuccess;
+    const int lpr = d * dtype_bytes / 16;
+    const unsigned nb = (unsigned)((head_rows * lpr + 255) / 256);
+    if (dtype_bytes == 4) { SML_DISPATCH_D(d, k_head_apply<DD, float><<<dim3(nb), dim3(256), 0, st>>>((float*)w_head, head_rows, lr, p)); }
+    else if (dtype_bytes == 2) { SML_DISPATCH_D(d, k_head_apply<DD, __half><<<dim3(nb), dim3(256), 0, st>>>((__half*)w_head, head_rows, lr, p)); }
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+// eight pointers from the kernel arguments into a device table (per-lane indexed by the sharded gradient pass)
+struct SmlPtr8 { void* p[8]; };
+__global__ void k_set_ptr_tab(void** dst, SmlPtr8 v) { if (threadIdx.x < 8) dst[threadIdx.x] = v.p[threadIdx.x]; }
+hipError_t sml_launch_set_ptr_tab(void** dst, void* const* src, int n, hipStream_t st) {
+    SmlPtr8 v;
+    for (int q = 0; q < 8; ++q) v.p[q] = q < n ? src[q] : nullptr;
+    k_set_ptr_tab<<<dim3(1), dim3(64), 0, st>>>(dst, v);
+    return hipGetLastError();
+}
+hipError_t sml_launch_peer_signal(const SmlPeerPush& p, hipStream_t st) {
+    k_peer_signal<<<dim3(1), dim3(64), 0, st>>>(p);
     return hipGetLastError();
 }
 hipError_t sml_launch_mark_runs(int key_bytes, const void* keys, const uint32_t* vals, int64_t n, int row_bits, SmlRun* rec,

@@ -122,6 +122,13 @@ hipError_t sml_launch_peer_wait(const SmlPeerPoll& p, hipStream_t st);
 hipError_t sml_launch_peer_sum(float* dst, long long n_floats, const SmlPeerPoll& p, hipStream_t st);
 hipError_t sml_launch_selftest(const float* A, const float* W, float* pk, float* out, hipStream_t st);
 
+// sharded bare step: which occurrences a list holds
+struct SmlShardKeys {
+    int mode;                // 1: the job's occurrences of tail rows THIS rank owns (key row = row local to the shard, value =
+                             //    src rank * rows_cap + slot in that rank's batch); 2: this rank's own occurrences of head rows
+                             //    (key row = row, value = slot in the local dx)
+    int rank; long long head_rows, shard_rows, rows_cap;
+};
 // ---- mf_kernels.hip ------------------------------------------------------------------
 hipError_t sml_launch_loss_finalize(const float* part, int n_batches, int stride, const int* counts,
                                     float* out, hipStream_t st);
@@ -183,6 +190,14 @@ hipError_t sml_launch_batch_offsets(const SmlRun* runs, const int* n_sel, int nb
 // items_all [world][n][2]; slot of rank q's element t of batch b: q*2*batch + t (positive), q*2*batch + B_b + t (negative)
 hipError_t sml_launch_build_item_keys_x(int key_bytes, const int64_t* items_all, int world, int64_t n, int batch, int row_bits_i,
                                         void* key_i, uint32_t* val_i, hipStream_t st);
+// the same for the item-sharded step: occurrences that do not belong to the list get the batch's sentinel row (all
+// ones in row_bits_i bits), which sorts behind every real row of the batch and is never selected as a run
+hipError_t sml_launch_build_item_keys_sh(int key_bytes, const int64_t* items_all, int world, int64_t n, int batch, int row_bits_i,
+                                         const SmlShardKeys& sk, void* key_i, uint32_t* val_i, hipStream_t st);
+// dense all-reduced head update: w_head[row] -= lr * (slot 0 + slot 1 + ... in rank order)[row]
+hipError_t sml_launch_head_apply(int d, int dtype_bytes, void* w_head, long long head_rows, float lr, const SmlPeerPoll& p, hipStream_t st);
+hipError_t sml_launch_peer_signal(const SmlPeerPush& p, hipStream_t st);
+hipError_t sml_launch_set_ptr_tab(void** dst, void* const* src, int n, hipStream_t st);
 // uniq[b][B_b .. 3*B_b) = 0: item occurrences are never updated in place
 hipError_t sml_launch_zero_item_marks(uint8_t* uniq, int64_t n, int batch, hipStream_t st);
 // boff: device [nb+1] offsets of the batches inside tri (null: batches of `batch`, the last one ragged)
@@ -205,7 +220,16 @@ struct SmlBareArgs {
     const int32_t* last_user; const int32_t* last_item;
     const SmlSched* sched; int cur_step;
     float* xrep; float* mrep; float* vrep;   // lazy form: [3B, d] replayed rows / moments per occurrence, for the row update
+    // item-SHARDED form (several GPUs over peer mappings; shard_tab != null): item rows [0, head_rows) are read from the
+    // local replica `w_item`, row r >= head_rows from rank q = (r - head_rows) / shard_rows's shard (shard_tab[q], peer
+    // memory).  A head occurrence emits its gradient row into the local dx as usual; a tail occurrence stores it
+    // straight into its OWNER's inbox (inbox_tab[q] + push_off + slot * d), and every workgroup then bumps every
+    // rank's arrival counter once (peer).
+    const void* const* shard_tab; float* const* inbox_tab;
+    long long head_rows, shard_rows, push_off;
+    SmlPeerPush peer;
 };
+
 hipError_t sml_launch_bare_grad(int d, int dtype_bytes, const SmlBareArgs& a, int* n_blocks, hipStream_t st);
 hipError_t sml_launch_mf_forward(int d, const float* wu, const float* wi, const int64_t* user, const int64_t* item,
                                  int64_t n, int norm, float* uemb, float* iemb, float* score, hipStream_t st);

@@ -45,6 +45,24 @@ def owner_of(users, n_user, world):
     return users // per
 
 
+def item_shard_layout(n_item, world, head_rows=0):
+    """Layout of an item table sharded over `world` ranks with a replicated head: rows [0, head_rows) live on every rank,
+    row r >= head_rows on rank (r - head_rows) // shard_rows (local row (r - head_rows) % shard_rows).
+    Returns (head_rows, shard_rows)."""
+    head_rows = int(min(max(head_rows, 0), n_item))
+    tail = n_item - head_rows
+    return head_rows, max(1, -(-tail // world))
+
+
+def item_owner(rows, world, head_rows, shard_rows):
+    """(owner rank or -1 for the replicated head, local row) of global item rows (numpy / torch integer arrays)."""
+    tail = rows - head_rows
+    owner = tail // shard_rows
+    local = tail - owner * shard_rows
+    is_head = rows < head_rows
+    return (owner * (~is_head) - 1 * is_head), (local * (~is_head) + rows * is_head)
+
+
 def _sort_occurrences(keys, vals):
     """(keys, vals) stably sorted by key, on the keys' device."""
     order = torch.sort(keys, stable=True).indices
@@ -273,6 +291,39 @@ class DistContext(object):
         # peer inboxes: RCCL when the library has a communicator, else the torch.distributed hook)
         return dict(world=self.world, items_all=items_all.contiguous(), dx_local=dx_local, dx_all=dx_all,
                     hook=None if self.mode == "rccl" else hook, loss_scale=self.loss_scale(loss_kind))
+
+    # ---- bare a3 step with the ITEM TABLE SHARDED (configs 4 / 5): head replicated, tail owner-computes over the peer exchange
+    def bare_shard(self, engine, triples, n_item, head_rows, w_item_head, w_item_shard, loss_kind=LOSS_BCE):
+        """Shard descriptor of one bare epoch over this rank's `triples` [n,3] (local user index, GLOBAL item index;
+        every rank brings the same n and batch).  w_item_head: this rank's replica of rows [0, head_rows);
+        w_item_shard: this rank's tail shard [shard_rows, d] (item_shard_layout).  Every rank's shard must be readable
+        from every device: ranks that are threads of one process hand over the addresses; one process per GPU exports
+        the shard with hipIpc -- it must then be a whole allocation (HipEngine.peer_tensor).  The item columns of every
+        rank are gathered once here."""
+        if self.mode != "peer":
+            raise RuntimeError("the item-sharded bare step runs on the one-shot peer exchange (SML_COMM=peer)")
+        n = triples.shape[0]
+        self.same_on_all_ranks(n, "the epoch length n")
+        head_rows, shard_rows = item_shard_layout(n_item, self.world, head_rows)
+        if tuple(w_item_shard.shape[:1]) != (shard_rows,):
+            raise ValueError("this rank's tail shard must have %d rows" % shard_rows)
+        items = triples[:, 1:3].contiguous()
+        items_all = torch.empty((self.world,) + tuple(items.shape), dtype=items.dtype, device=items.device)
+        self.dist.all_gather(list(items_all.unbind(0)), items, group=self.group)
+        key = ("shard_ptrs", w_item_shard.data_ptr())
+        ptrs = self._buf.get(key)
+        if ptrs is None:
+            if self.dist.get_backend(self.group) == "threads":
+                ptrs = _gather_objects(self.dist, w_item_shard.data_ptr(), self.group)
+            else:
+                raw = getattr(w_item_shard, "_sml_peer_ptr", None)
+                if raw is None or raw != w_item_shard.data_ptr():
+                    raise ValueError("one process per GPU: allocate the shard with HipEngine.peer_tensor (a whole, exportable allocation)")
+                handles = _gather_objects(self.dist, engine.peer_export(raw), self.group)
+                ptrs = [raw if q == self.rank else engine.peer_open(handles[q]) for q in range(self.world)]
+            self._buf[key] = ptrs
+        return dict(world=self.world, rank=self.rank, head_rows=head_rows, shard_rows=shard_rows, item_shard=ptrs,
+                    w_item_head=w_item_head, items_all=items_all.contiguous(), loss_scale=self.loss_scale(loss_kind), n_item=int(n_item))
 
     # ---- the real driver: a shared global epoch, split by user owner
     def route_epoch(self, global_tri, batch, n_user, mean_loss):

@@ -418,6 +418,32 @@ class HipEngine(object):
               "sml_embed_loss_sgd_epoch")
         return losses
 
+    def bare_epoch_sharded(self, w_user, triples, batch_size, lr, lam_user, lam_item, shard, bce=True):
+        """The bare step with the item table SHARDED over the ranks (sml_embed_loss_sgd_epoch_sharded; peers attached):
+        `shard` is sml_amd.dist.DistContext.bare_shard()'s descriptor -- head_rows / shard_rows, every rank's tail-shard
+        address, this rank's head replica, the gathered item columns, the loss scale.  n_item = the GLOBAL table height."""
+        if w_user.dtype not in (torch.float32, torch.float16) or not w_user.is_contiguous() or w_user.shape[-1] != self.d:
+            raise ValueError("user table: contiguous fp32 / fp16 [rows,%d]" % self.d)
+        tri = self._dev(triples, torch.int64)
+        n = tri.shape[0]
+        nb = (n + batch_size - 1) // batch_size
+        losses = torch.empty(nb, device=self.device, dtype=torch.float32)
+        world = int(shard["world"])
+        ptrs = (ctypes.c_void_p * world)(*[int(p) for p in shard["item_shard"]])
+        x = _lib.BareShard()
+        x.world, x.rank = world, int(shard["rank"])
+        x.head_rows, x.shard_rows = int(shard["head_rows"]), int(shard["shard_rows"])
+        x.item_shard = ptrs
+        head = shard.get("w_item_head")
+        x.w_item_head = head.data_ptr() if head is not None and head.numel() else None
+        x.items_all = shard["items_all"].data_ptr()
+        x.loss_scale = float(shard["loss_scale"])
+        check(self.lib.sml_embed_loss_sgd_epoch_sharded(self._ctx, _ptr(w_user), w_user.shape[0], int(shard["n_item"]), w_user.element_size(),
+                                                        _ptr(tri), n, int(batch_size), float(lr), float(lam_user), float(lam_item),
+                                                        _lib.LOSS_BCE if bce else _lib.LOSS_BPR, _ptr(losses), ctypes.byref(x), self._stream()),
+              "sml_embed_loss_sgd_epoch_sharded")
+        return losses
+
     def bare_adam_epoch(self, mfbase, triples, batch_size, lr, lam_user, lam_item, bce=True):
         """One epoch of the baselines' bare-MF step (reference model/baseline.py:343-361): BCE (or BPR) + L2 with
         the dense-Adam semantics of torch.optim.Adam over MFbase, replayed lazily per row.  Shares the MF
@@ -769,6 +795,33 @@ class HipEngine(object):
         check(self.lib.sml_peer_alloc(self.device.index, int(nbytes), ctypes.byref(p)), "sml_peer_alloc")
         self.__dict__.setdefault("_peer_owned", []).append(p.value)
         return p.value
+
+    def peer_tensor(self, shape, dtype=torch.float32):
+        """A zeroed torch tensor over memory of its OWN device allocation (plain device memory, sml_peer_alloc): unlike a
+        tensor from torch's caching allocator -- a slice of a larger segment -- its address can be exported whole with
+        peer_export and opened by another process (an item-table shard other ranks read over the peer mapping)."""
+        import os
+        shape = tuple(int(v) for v in shape)
+        n = 1
+        for v in shape:
+            n *= v
+        nbytes = max(n * torch.empty((), dtype=dtype).element_size(), 16)
+        old = os.environ.get("SML_PEER_MEM")
+        os.environ["SML_PEER_MEM"] = "plain"
+        try:
+            ptr = self.peer_alloc(nbytes)
+        finally:
+            if old is None:
+                del os.environ["SML_PEER_MEM"]
+            else:
+                os.environ["SML_PEER_MEM"] = old
+        typestr = {torch.float32: "<f4", torch.float16: "<f2", torch.int32: "<i4", torch.int64: "<i8"}[dtype]
+
+        class _Raw(object):
+            __cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2, "strides": None}
+        t = torch.as_tensor(_Raw(), device=self.device)
+        t._sml_peer_ptr = ptr
+        return t
 
     def peer_export(self, ptr):
         buf = ctypes.create_string_buffer(64)

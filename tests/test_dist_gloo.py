@@ -216,3 +216,21 @@ def test_driver_under_two_ranks_prints_the_single_process_run(tmp_path, ttype):
     np.testing.assert_allclose(torch.cat([r0["wu"], r1["wu"]]).numpy(), one["wu"].numpy(), rtol=5e-3, atol=5e-4)
     np.testing.assert_allclose(r0["wi"].numpy(), one["wi"].numpy(), rtol=5e-3, atol=5e-4)
     assert strip(r1["log"]) == strip(r0["log"])      # every rank holds the job's numbers (cli.main silences all but rank 0)
+
+
+def test_item_shard_layout_routes_every_row_to_exactly_one_place():
+    """Routing of the item-sharded bare step (sml_amd.dist.item_shard_layout / item_owner; the device code applies the
+    same arithmetic): the head is replicated (owner -1), every tail row has exactly one owner and a local row inside that
+    owner's shard, the shards cover the table, and the layout degenerates properly (no head; all head; one rank)."""
+    from sml_amd import dist as SD
+    for n_item, world, head in ((120, 2, 16), (1000003, 8, 4096), (77, 8, 0), (50, 4, 50), (50, 4, 999), (9, 1, 3)):
+        H, S = SD.item_shard_layout(n_item, world, head)
+        assert 0 <= H <= n_item and S >= 1 and H + world * S >= n_item and H + world * S - n_item < world + S
+        rows = np.arange(n_item, dtype=np.int64)
+        owner, local = SD.item_owner(rows, world, H, S)
+        assert np.all(owner[:H] == -1) and np.array_equal(local[:H], rows[:H])
+        assert np.all((owner[H:] >= 0) & (owner[H:] < world)) and np.all((local[H:] >= 0) & (local[H:] < S))
+        back = np.where(owner < 0, local, H + owner * S + local)
+        assert np.array_equal(back, rows)                                 # a bijection onto (owner, local)
+        counts = np.bincount(owner[H:], minlength=world) if n_item > H else np.zeros(world, dtype=np.int64)
+        assert counts.max() <= S and (counts > 0).sum() == min(world, -(-(n_item - H) // S) if n_item > H else 0)

@@ -1440,6 +1440,65 @@ def test_bare_step_two_ranks_on_one_gpu_equal_the_global_batch_step(d, dtype, bc
     close(r0["wi"].float().numpy(), oi.numpy(), tol)
 
 
+@pytest.mark.parametrize("d,dtype,bce,head", [(32, torch.float32, True, 16), (64, torch.float32, False, 0), (128, torch.float16, False, 24),
+                                              (32, torch.float32, True, 120)])
+def test_bare_step_item_sharded_two_ranks_on_one_gpu_equal_the_global_batch_step(d, dtype, bce, head, monkeypatch):
+    """The bare a3 step with the ITEM TABLE SHARDED over world_size 2 (thread ranks on the two CU-masked streams, one-shot
+    peer exchange, same-process allocations handed over as raw pointers): the first `head` rows replicated (dense
+    one-shot all-reduce of their gradient partials), the tail owner-computes -- every rank reads tail rows from their
+    owner's shard and stores gradient rows straight into the owner's inbox; two counter rounds per batch order the
+    ranks, nothing on the host does.  Equals the oracle's synchronous SGD step over the GLOBAL batches (the same check
+    as the replicated form above), the head replicas are bit-identical, and so are the results of the replicated
+    exchange when everything is head (head = I) or nothing is (head = 0) -- both extremes included."""
+    from _thread_group import run_ranks
+    from sml_amd import dist as SD
+    monkeypatch.setenv("SML_COMM", "peer")
+    monkeypatch.setenv("SML_PEER_TIMEOUT_S", "20")
+    B, n, U_rank, I = 96, 96 * 3 - 11, 150, 120
+    wi, wus, tris = _bare_world2_inputs(d, dtype, B, n, U_rank, I, seed=3 * d)
+    lr = 0.05 if bce else 0.01
+    H, S = SD.item_shard_layout(I, 2, head)
+    eng0 = engine(d, B)
+
+    def rank_fn(rank, group):
+        e = engine(d, B)
+        ctx = SD.attach(e, None, group, rows_cap=2 * B)
+        assert ctx.mode == "peer"
+        gu = wus[rank].clone().to(DEV)
+        w_head = wi[:H].clone().to(DEV)
+        shard = torch.zeros(S, d, dtype=dtype, device=DEV)
+        lo = H + rank * S
+        rows = max(0, min(I, lo + S) - lo)
+        shard[:rows] = wi[lo:lo + rows].to(DEV)
+        tri = tris[rank].to(DEV)
+        sh = ctx.bare_shard(e, tri, I, head, w_head, shard, 0 if bce else 1)
+        assert (sh["head_rows"], sh["shard_rows"]) == (H, S)
+        losses = e.bare_epoch_sharded(gu, tri, B, lr, 1e-3, 2e-3, sh, bce=bce)
+        torch.cuda.current_stream().synchronize()
+        assert e.peer_status() == 0
+        group.barrier()                       # (nobody frees a shard another rank may still be reading)
+        return dict(l=losses.cpu().numpy(), wu=gu.float().cpu(), head=w_head.cpu(), shard=shard[:rows].cpu())
+
+    n_cu = eng0._n_cus()
+    r0, r1 = run_ranks(2, rank_fn, streams=[eng0._masked_stream(0, n_cu // 2), eng0._masked_stream(n_cu // 2, n_cu)])
+    assert torch.equal(r0["head"], r1["head"])
+    got_i = torch.cat([r0["head"], r0["shard"], r1["shard"]]).float()
+    assert got_i.shape[0] == I
+    ou, oi = torch.cat(wus).float().clone(), wi.float().clone()
+    want = []
+    for b0 in range(0, n, B):
+        t0, t1 = tris[0][b0:b0 + B], tris[1][b0:b0 + B].clone()
+        t1[:, 0] += U_rank
+        t = torch.cat([t0, t1])
+        want.append(O.bare_step(ou, oi, t[:, 0], t[:, 1], t[:, 2], lr, 1e-3, 2e-3, bce=bce))
+        if dtype == torch.float16:
+            ou, oi = ou.half().float(), oi.half().float()
+    tol = 1e-4 if dtype == torch.float32 else 2e-3
+    np.testing.assert_allclose(r0["l"] + r1["l"], want, rtol=tol)
+    close(torch.cat([r0["wu"], r1["wu"]]).numpy(), ou.numpy(), tol)
+    close(got_i.numpy(), oi.numpy(), tol)
+
+
 def test_bare_step_exchange_on_a_one_rank_rccl_group_equals_the_plain_step():
     """The same exchange through the library's OWN RCCL communicator (ncclAllGather issued between its kernels) on a
     1-rank group, with a batch large enough for the hot-row path: equals the plain single-GPU step (same arithmetic;
