@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -37,13 +38,27 @@ struct DevGuard {
     ~DevGuard() { if (changed) (void)hipSetDevice(prev); }
 };
 
+// Buffers that were outgrown are NOT freed on the spot: hipFree waits for the whole device, and on a device that
+// another rank's kernel is polling on (peer exchange: a consumer spinning for THIS host thread's next launch) that wait
+// never ends before the poller's time-out.  They are parked here and freed when a context is destroyed.
+struct Graveyard {
+    std::vector<void*> dead;
+    std::mutex mu;
+    void park(void* p) { std::lock_guard<std::mutex> g(mu); dead.push_back(p); }
+    void reap() {
+        std::vector<void*> d;
+        { std::lock_guard<std::mutex> g(mu); d.swap(dead); }
+        for (void* p : d) (void)hipFree(p);
+    }
+} g_graveyard;
+
 template <typename T>
 struct Buf {
     T* p = nullptr;
     size_t cap = 0;   // elements
     hipError_t ensure(size_t need) {
         if (need <= cap) return hipSuccess;
-        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        if (p) { g_graveyard.park(p); p = nullptr; cap = 0; }
         size_t want = need + need / 8;
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
         if (e != hipSuccess) return e;
@@ -601,7 +616,7 @@ int sml_ctx_set_variant(sml_ctx* ctx, int variant) {
 int sml_ctx_destroy(sml_ctx* ctx) {
     if (!ctx) return SML_OK;
     (void)sml_comm_destroy(ctx);
-    { DevGuard g(ctx->device); ctx->release_all(); }
+    { DevGuard g(ctx->device); ctx->release_all(); g_graveyard.reap(); }
     delete ctx;
     return SML_OK;
 }

@@ -155,7 +155,10 @@ __device__ __forceinline__ void peer_store(float* p, float v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ __forceinline__ void peer_store16(float* p, const f32x4& v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+    // (s_nop: the hazard recogniser does not look inside inline asm -- a VALU instruction that overwrites the data
+    // registers of a store wider than 8 bytes in the very next slots corrupts the last dwords: found with fp16 tables,
+    // where two of these stores follow each other from recycled registers)
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 // NO system-scope fences here: __threadfence_system() is a write-back + invalidate of this XCD's whole L2, executed by
 // every wave of every pushing / polling workgroup (measured on one GPU: +25 us on the weight-gradient launch, +12 us

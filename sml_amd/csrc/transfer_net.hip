@@ -56,7 +56,7 @@ __device__ long long* g_timeline = nullptr;     // [0] = record counter, records
 #define SML_WT_FWD_LOCAL 0
 #endif
 __device__ __forceinline__ void st_out16_wt(float* p, const f32x4& v) {       // one 16-byte write-through store
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");    // (s_nop: see peer_store16)
 }
 template <int MODE>
 __device__ __forceinline__ void st_out(float* p, float v) {

@@ -1441,7 +1441,8 @@ def test_bare_step_two_ranks_on_one_gpu_equal_the_global_batch_step(d, dtype, bc
 
 
 @pytest.mark.parametrize("d,dtype,bce,head", [(32, torch.float32, True, 16), (64, torch.float32, False, 0), (128, torch.float16, False, 24),
-                                              (32, torch.float32, True, 120)])
+                                              (32, torch.float32, True, 120), (128, torch.float32, True, 24), (128, torch.float16, False, 0),
+                                              (64, torch.float16, False, 16)])
 def test_bare_step_item_sharded_two_ranks_on_one_gpu_equal_the_global_batch_step(d, dtype, bce, head, monkeypatch):
     """The bare a3 step with the ITEM TABLE SHARDED over world_size 2 (thread ranks on the two CU-masked streams, one-shot
     peer exchange, same-process allocations handed over as raw pointers): the first `head` rows replicated (dense
