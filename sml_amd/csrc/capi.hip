@@ -648,7 +648,9 @@ int sml_transfer_forward(sml_ctx* ctx, const float* theta, int net, const float*
     a.k2 = ctx->variant == 1; a.unit_rows = (ctx->variant == 1 && net == 0);
     // table-sized calls are bound by streaming the weights through L2 once per workgroup: 32 rows per workgroup
     // halve that traffic, 48 (d = 32: what the LDS tiles allow) cut it to a third
-    const int mt = n_rows > 8192 ? (ctx->d == 32 ? 3 : 2) : 1;
+    // (SML_FWD_MT overrides for measurements: 3 = the 48-row one-workgroup-per-CU form at d = 32)
+    const int mt_env = env_int("SML_FWD_MT", 0);
+    const int mt = n_rows > 8192 ? ((mt_env == 3 && ctx->d == 32) ? 3 : 2) : 1;
     a.tiles0 = wg_tiles((int)n_rows, mt);
     a.seg[1] = s; a.seg[1].n_rows = 0;
     ctx->prof.begin(PC_FWD, st); HIPCHK(sml_launch_fwd(ctx->d, mt, 1, a, a.tiles0, st)); ctx->prof.end(st);

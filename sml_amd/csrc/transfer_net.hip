@@ -209,11 +209,15 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // `out` (planes out_pstride floats apart; the bias rides in plane 0).  The consumer (the pair loss
 // at the head of k_transfer_bwd) adds the NS planes in index order: deterministic, no atomics.
 // ------------------------------------------------------------------------------------
-template <int D, int MT, int NS>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_transfer_fwd(SmlFwdArgs a) {
+// HSEQ > 1 (table-sized calls): the workgroup walks its hidden units in HSEQ sequential passes -- fc1 of a pass, Gelu, then
+// that pass's share of fc2 accumulated in registers -- so the a2 tile in LDS holds 512 / HSEQ columns: a 32-row workgroup
+// then needs 68 KB of LDS and <= 128 VGPRs, TWO fit a CU, and one's gather / conv prologue / epilogues run under the
+// other's MFMA phases (a single 48-row workgroup per CU left the matrix pipe idle 45 % of the time).
+template <int D, int MT, int NS, int HSEQ = 1>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HSEQ > 1 ? 4 : 2, HSEQ > 1 ? 4 : 2))) void k_transfer_fwd(SmlFwdArgs a) {
     constexpr int R = SML_TM * MT;
     constexpr int K1 = SML_C2 * D;       // fc1 reduction length
-    constexpr int HL = SML_HID / NS;     // hidden units of this workgroup
+    constexpr int HL = SML_HID / NS / HSEQ;   // hidden units of one pass of this workgroup
     constexpr int S1 = K1 + 4;           // LDS row strides (multiples of 4 floats: 16-byte aligned b128 reads)
     constexpr int S2 = HL + 4;
     constexpr int KS1 = K1 / 16;
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // Hidden-split form: this wave's whole fc1 operand set (one column tile: 2 x KS1/2 k-steps) and its fc2 share fit a
     // register ring at d = 32 -- fetched now, with the biases, so neither GEMM waits for the fabric (the images
     // were rewritten by the previous batch's Adam step on other XCDs: their first read is a fabric round trip)
-    constexpr bool PRE = (CT == 1) && (KS1 / 2 <= 5);
+    constexpr bool PRE = (CT == 1) && (KS1 / 2 <= 5) && HSEQ == 1;
     constexpr int PF2 = KPW < 4 ? KPW : 4;
     const f32x4* __restrict__ img1 = reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p1(D));
     const f32x4* __restrict__ img2 = reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p2(D));
@@ -287,12 +291,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #ifndef SML_PREW
 #define SML_PREW 0
 #endif
-    constexpr bool PREW = (SML_PREW != 0) && (MT == 1) && (CT >= 2) && (D <= 64);
+    constexpr bool PREW = (SML_PREW != 0) && (MT == 1) && (CT >= 2) && (D <= 64) && HSEQ == 1;
     auto tw = [tile0](int t) { return tile0 + t; };
     f32x4 ringw1[PREW ? 5 : 1][CT], ringw2[PREW ? PF2 : 1][JTW];
-    float bias1[CT];
+    float bias1[HSEQ][CT];
 #pragma unroll
-    for (int t = 0; t < CT; ++t) bias1[t] = theta[sml_off_f1b(D) + h * HL + (wv * CT + t) * 16 + l15];
+    for (int hp = 0; hp < HSEQ; ++hp)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) bias1[hp][t] = theta[sml_off_f1b(D) + (h * HSEQ + hp) * HL + (wv * CT + t) * 16 + l15];
     float bias2[EPT];
 #pragma unroll
     for (int q = 0; q < EPT; ++q) bias2[q] = (h == 0) ? theta[sml_off_f2b(D) + (q * 512 + tid) % D] : 0.0f;
@@ -395,76 +401,81 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __syncthreads();
     TL(3);
 
-    // ---- fc1: Z1[R x HL] = A1[R x K1] * W1^T[:, slice h] ; wave wv owns CT column tiles of the slice
-    {
-        const f32x4* img = img1;
-        float zt[MT][CT][4];
-        if constexpr (CT >= 2) {
-            f32x4 acc[MT][CT];
-            zero_acc(acc);
-            if constexpr (PREW) mma16_ring<MT, CT, KS1, 5, false>(acc, ringw1, A1s + l15 * S1 + 4 * g4, SML_TM * S1, img, KS1, 0, lane, tw, nokofs);
-            else mma16_rows<MT, CT, KS1, (MT == 1 ? 5 : 2)>(acc, A1s + l15 * S1 + 4 * g4, SML_TM * S1, img, KS1, 0, lane,
-                                                           [tile0](int t) { return tile0 + t; });
+    // ---- fc1 / fc2, in HSEQ passes over this workgroup's hidden units (one pass unless HSEQ > 1)
+    f32x4 acc2[MT][JTW];
+    zero_acc(acc2);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+    for (int hp = 0; hp < HSEQ; ++hp) {
+        const int hc = h * HSEQ + hp;                 // hidden block of this pass: units [hc * HL, (hc + 1) * HL)
+        const int tile0p = hc * (HL / 16) + wv * CT;
+        // ---- fc1: Z1[R x HL] = A1[R x K1] * W1^T[:, block hc] ; wave wv owns CT column tiles of the block
+        {
+            const f32x4* img = img1;
+            float zt[MT][CT][4];
+            if constexpr (CT >= 2) {
+                f32x4 acc[MT][CT];
+                zero_acc(acc);
+                if constexpr (PREW) mma16_ring<MT, CT, KS1, 5, false>(acc, ringw1, A1s + l15 * S1 + 4 * g4, SML_TM * S1, img, KS1, 0, lane, tw, nokofs);
+                else mma16_rows<MT, CT, KS1, (MT == 1 ? 5 : 2)>(acc, A1s + l15 * S1 + 4 * g4, SML_TM * S1, img, KS1, 0, lane,
+                                                               [tile0p](int t) { return tile0p + t; });
 #pragma unroll
-                for (int t = 0; t < CT; ++t)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) zt[mt][t][q] = acc[mt][t][q];
-        } else {
-            // one column tile per wave: two independent accumulator chains over the two halves of K
-            static_assert(KS1 % 2 == 0, "even k-steps");
-            f32x4 acc[MT][2];
-            zero_acc(acc);
-            if constexpr (PRE) mma16_ring<MT, 2, KS1 / 2, 5, true>(acc, ringf1, A1s + l15 * S1 + 4 * g4, SML_TM * S1, img, KS1, 0, lane, t1, k1);
-            else mma16_rows_k<MT, 2, KS1 / 2, 5, true>(acc, A1s + l15 * S1 + 4 * g4, SML_TM * S1, img, KS1, 0, lane, t1, k1);
+                    for (int t = 0; t < CT; ++t)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+                        for (int q = 0; q < 4; ++q) zt[mt][t][q] = acc[mt][t][q];
+            } else {
+                // one column tile per wave: two independent accumulator chains over the two halves of K
+                static_assert(KS1 % 2 == 0, "even k-steps");
+                f32x4 acc[MT][2];
+                zero_acc(acc);
+                if constexpr (PRE) mma16_ring<MT, 2, KS1 / 2, 5, true>(acc, ringf1, A1s + l15 * S1 + 4 * g4, SML_TM * S1, img, KS1, 0, lane, t1, k1);
+                else mma16_rows_k<MT, 2, KS1 / 2, 5, true>(acc, A1s + l15 * S1 + 4 * g4, SML_TM * S1, img, KS1, 0, lane, [tile0p](int) { return tile0p; }, k1);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) zt[mt][0][q] = acc[mt][0][q] + acc[mt][1][q];
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) zt[mt][0][q] = acc[mt][0][q] + acc[mt][1][q];
+            }
+            TL(9);
+            if (HSEQ > 1 && hp > 0) __syncthreads();      // the previous pass's fc2 is done reading the a2 tile
+            // + bias, save z1, Gelu -> a2 tile.  (xts/nrm are dead: every wave passed the barrier above)
+            float* z1 = sg.z1;
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const int nl = (wv * CT + t) * 16 + l15;       // column inside the block
+                const int n = hc * HL + nl;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int r = mt * SML_TM + 4 * g4 + q;
+                        const float z = zt[mt][t][q] + bias1[hp][t];
+                        if (z1 != nullptr) st_out<WT_LOCAL>(&z1[(int64_t)(row0 + r) * SML_HID + n], z);
+                        const float gz = sml_gelu(z);
+                        a2s[r * S2 + nl] = gz;
+                        if (sg.a2 != nullptr) st_out<WT_LOCAL>(&sg.a2[(int64_t)(row0 + r) * SML_HID + n], gz);
+                    }
+            }
         }
-        TL(9);
-        // + bias, save z1, Gelu -> a2 tile.  (xts/nrm are dead: every wave passed the barrier above)
-        float* z1 = sg.z1;
-#pragma unroll
-        for (int t = 0; t < CT; ++t) {
-            const int nl = (wv * CT + t) * 16 + l15;       // column inside the slice
-            const int n = h * HL + nl;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r = mt * SML_TM + 4 * g4 + q;
-                    const float z = zt[mt][t][q] + bias1[t];
-                    if (z1 != nullptr) st_out<WT_LOCAL>(&z1[(int64_t)(row0 + r) * SML_HID + n], z);
-                    const float gz = sml_gelu(z);
-                    a2s[r * S2 + nl] = gz;
-                    if (sg.a2 != nullptr) st_out<WT_LOCAL>(&sg.a2[(int64_t)(row0 + r) * SML_HID + n], gz);
-                }
-        }
+        TL(4);
+        __syncthreads();
+        TL(5);
+        // ---- fc2: Out[R x D] += a2[R x HL] * W2^T[block hc, :] ; waves = KSPL (along K) x JSPL (column tiles)
+        // (the operand image is indexed by the global k-step, the LDS tile by the local one)
+        if constexpr (PRE) mma16_ring<MT, JTW, KPW, PF2, false>(acc2, ringf2, a2s + l15 * S2 + 4 * g4 - hc * HL, SML_TM * S2, img2, 32,
+                                                                hc * KL + kq * KPW, lane, t2, nokofs);
+        else if constexpr (PREW) mma16_ring<MT, JTW, KPW, PF2, false>(acc2, ringw2, a2s + l15 * S2 + 4 * g4 - hc * HL, SML_TM * S2, img2, 32,
+                                                                      hc * KL + kq * KPW, lane, t2, nokofs);
+        else mma16_rows<MT, JTW, KPW, PF2>(acc2, a2s + l15 * S2 + 4 * g4 - hc * HL, SML_TM * S2, img2, 32, hc * KL + kq * KPW, lane, t2);
     }
-    TL(4);
-    __syncthreads();
-    TL(5);
-
-    // ---- fc2: Out[R x D] (+)= a2[R x HL] * W2^T[slice h, :] ; waves = KSPL (along K) x JSPL (column tiles)
-    {
-        f32x4 acc[MT][JTW];
-        zero_acc(acc);
-        // the operand image is indexed by the global k-step, the LDS tile by the local one
-        if constexpr (PRE) mma16_ring<MT, JTW, KPW, PF2, false>(acc, ringf2, a2s + l15 * S2 + 4 * g4 - h * HL, SML_TM * S2, img2, 32,
-                                                                h * KL + kq * KPW, lane, t2, nokofs);
-        else if constexpr (PREW) mma16_ring<MT, JTW, KPW, PF2, false>(acc, ringw2, a2s + l15 * S2 + 4 * g4 - h * HL, SML_TM * S2, img2, 32,
-                                                                      h * KL + kq * KPW, lane, t2, nokofs);
-        else mma16_rows<MT, JTW, KPW, PF2>(acc, a2s + l15 * S2 + 4 * g4 - h * HL, SML_TM * S2, img2, 32, h * KL + kq * KPW, lane, t2);
+    if (HSEQ > 1) __syncthreads();                        // `part` aliases the A1 tile: every wave is done with its fc1 reads
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int t = 0; t < JTW; ++t)
+        for (int t = 0; t < JTW; ++t)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    part[(kq * R + mt * SML_TM + 4 * g4 + q) * (D + 1) + (jq * JTW + t) * 16 + l15] = acc[mt][t][q];
-    }
+            for (int q = 0; q < 4; ++q)
+                part[(kq * R + mt * SML_TM + 4 * g4 + q) * (D + 1) + (jq * JTW + t) * 16 + l15] = acc2[mt][t][q];
     __syncthreads();
     TL(6);
     float* __restrict__ outp = sg.out + (int64_t)h * a.out_pstride;
@@ -1870,7 +1881,14 @@ hipError_t sml_launch_fwd(int d, int mt, int ns, const SmlFwdArgs& a, int tiles_
     if (mt == 1 && ns == 1) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 1, 1><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }
     else if (mt == 1 && ns == 4) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 1, 4><<<dim3(((tiles_total + 1) / 2) * 8), dim3(512), 0, st>>>(a)); }
     else if (mt == 1 && ns == 2) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 1, 2><<<dim3(tiles_total * 2), dim3(512), 0, st>>>(a)); }
-    else if (mt == 2 && ns == 1) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 2, 1><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }
+    else if (mt == 2 && ns == 1) {
+        // table-sized calls: two hidden passes, two workgroups per CU (SML_FWD_HSEQ=1: the one-pass form)
+        static const bool hseq = !(getenv("SML_FWD_HSEQ") && atoi(getenv("SML_FWD_HSEQ")) == 1);
+        // (d = 128: the two-pass form still needs 118 KB of LDS -- one workgroup per CU either way -- so it keeps one pass)
+        if (hseq && d == 32) k_transfer_fwd<32, 2, 1, 2><<<dim3(tiles_total), dim3(512), 0, st>>>(a);
+        else if (hseq && d == 64) k_transfer_fwd<64, 2, 1, 2><<<dim3(tiles_total), dim3(512), 0, st>>>(a);
+        else { SML_DISPATCH_D(d, k_transfer_fwd<DD, 2, 1><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }
+    }
     else if (mt == 3 && ns == 1 && d == 32) { k_transfer_fwd<32, 3, 1><<<dim3(tiles_total), dim3(512), 0, st>>>(a); }
     else return hipErrorInvalidValue;
     return hipGetLastError();
