@@ -502,8 +502,12 @@ def test_yelp_scale_properties():
     net = make_transfer(d, device=DEV)
     last_u, hat_u = wu * 0.9, wu
     full = eng.transfer_forward(net, last_u, hat_u, "user")
-    blk = eng.transfer_forward(net, last_u[1000:1777], hat_u[1000:1777], "user")
-    assert torch.equal(full[1000:1777], blk)
+    blk = eng.transfer_forward(net, last_u[1000:10001], hat_u[1000:10001], "user")      # another table-sized call, other tile alignment
+    assert torch.equal(full[1000:10001], blk)
+    # a batch-sized call runs the one-pass form (the table-sized one walks the hidden layer in two passes: another order of
+    # the fc2 sum): equal to rounding
+    small = eng.transfer_forward(net, last_u[1000:1777], hat_u[1000:1777], "user")
+    close(small.cpu().numpy(), full[1000:1777].cpu().numpy(), 1e-5)
     # (4) bare step with lr = 0 leaves the tables bit-identical and is repeatable; the SGD delta is linear in lr
     tri = torch.from_numpy(np.stack([train[:, 0], train[:, 1], test[:, 2]], 1))
     a_u, a_i = wu.clone(), wi.clone()
