@@ -299,7 +299,7 @@ int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n
  *     the occurrence's gradient row straight into the owner's inbox; the owner adds the rows of all ranks in a fixed
  *     order (job-wide occurrence list built from items_all) and writes its shard -- owner-computes, an all-to-all whose
  *     volume per rank does not grow with the world size.
- * Users are row-sharded as in sml_bare_exchange (w_user, triples with local user indices, the same n and batch on
+ * Users are row-sharded as for the sml_bare_exchange path: w_user, triples with local user indices, the same n and batch on
  * every rank).  Per batch two counter rounds order the ranks: "all gradient rows of batch b have landed" before an
  * owner updates, "every owner has updated" before anybody reads rows for batch b + 1.  Exact synchronous SGD of the
  * GLOBAL batch; replicas of the head stay bit-identical.  dx scratch and index lists live in the context. */

@@ -60,6 +60,7 @@ class trainDataset_withPreSample(Dataset):
         np.random.shuffle(self.neg_flag)
         self.used_neg_count = 0
         self.have_read = 0
+        self._ui = None                    # contiguous int64 copy of the (user, item) columns, made on the first whole pass
 
     def __len__(self):
         return self.data_len
@@ -84,8 +85,12 @@ class trainDataset_withPreSample(Dataset):
         if self.have_read != 0 or len(order) != self.data_len:
             raise ValueError("epoch_triples needs a whole pass starting at a pass boundary")
         col = self.neg_flag[self.used_neg_count]
-        a = self.all_data                    # gather three columns, not 1001-wide rows
-        tri = np.stack([a[order, 0], a[order, 1], a[order, col]], axis=1).astype(np.int64, copy=False)
+        a = self.all_data                    # gather columns, not 1001-wide rows
+        if self._ui is None:                 # (user, item) side by side: one 16-byte gather per row and epoch instead of two
+            self._ui = np.ascontiguousarray(a[:, :2], dtype=np.int64)      # strided ones through the 8 KB rows
+        tri = np.empty((self.data_len, 3), dtype=np.int64)
+        tri[:, :2] = self._ui[order]
+        tri[:, 2] = a[order, col]
         self._advance(self.data_len)
         return tri
 
@@ -109,6 +114,7 @@ class offlineDataset_withsample(Dataset):
         self._n_users = int(pu.max()) + 1 if pu.size else 0
         self._uptr = np.ascontiguousarray(np.searchsorted(pu, np.arange(self._n_users + 1)), dtype=np.int64)
         self._uitems = np.ascontiguousarray(self._pairs % self._stride, dtype=np.int64)
+        self._ui = np.ascontiguousarray(np.stack([self.user, self.item], axis=1), dtype=np.int64)    # epoch_triples gathers both at once
 
     @property
     def user_list(self):
@@ -141,7 +147,9 @@ class offlineDataset_withsample(Dataset):
         lib = _lib.load()
         order = np.asarray(order)
         n = order.shape[0]
-        users = np.ascontiguousarray(self.user[order], dtype=np.int64)
+        out = np.empty((n, 3), dtype=np.int64)
+        out[:, :2] = self._ui[order]
+        users = np.ascontiguousarray(out[:, 0])
         pop = self.item_all.shape[0]
         items_all = np.ascontiguousarray(self.item_all, dtype=np.int64)
         negs = np.empty(n, dtype=np.int64)
@@ -158,7 +166,8 @@ class offlineDataset_withsample(Dataset):
             drawn += k
             if drawn > 64 * (n + 64):
                 raise RuntimeError("negative sampling does not terminate: a user owns (almost) every item")
-        return np.stack([users, self.item[order].astype(np.int64), negs], axis=1)
+        out[:, 2] = negs
+        return out
 
 
     def epoch_triples_device(self, engine, seed):

@@ -243,6 +243,8 @@ class meta_train(object):
         q, self._queue = getattr(self, "_queue", []), []
         for fn, args in q:
             fn(*[_val(a) for a in args])
+        if hasattr(self.engine, "side_sync_check"):
+            self.engine.side_sync_check()      # one check for all the evaluations collected above (not one read-back each)
 
     def _pair(self, resolve, n):
         """(recall, ndcg) from a (hits, ndcg_sum) resolver; lazy while output is deferred."""
@@ -257,6 +259,8 @@ class meta_train(object):
             pending = self.engine.eval_metrics_submit(ranks, topK)
 
             def local():
+                if getattr(self, "_defer", False):
+                    return self.engine.eval_result(pending, check=False)      # (_flush_output checks once for the whole stage)
                 return self.engine.eval_result(pending)
         elif hasattr(self.engine, "eval_metrics_device"):
             out = self.engine.eval_metrics_device(ranks, topK)

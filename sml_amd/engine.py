@@ -733,11 +733,13 @@ class HipEngine(object):
             raise RuntimeError("%d side-stream evaluation(s) gave up waiting for their table snapshot (sml_flag_wait "
                                "timeout, SML_FLAG_TIMEOUT_S=%g): their results are not trustworthy" % (new, self._flag_timeout()))
 
-    def eval_result(self, pending):
-        """Wait (host) for an eval_metrics_submit result: (hits, ndcg_sum)."""
+    def eval_result(self, pending, check=True):
+        """Wait (host) for an eval_metrics_submit result: (hits, ndcg_sum).  check=False: the caller collects many
+        results and calls side_sync_check() once itself (each check is a device read-back)."""
         out, ev = pending[0], pending[1]
         ev.synchronize()
-        self.side_sync_check()
+        if check:
+            self.side_sync_check()
         h = out.cpu()
         return float(h[0]), float(h[1])
 
