@@ -30,6 +30,26 @@ def engine(d, mb=4096):
     return HipEngine(DEV, d, mb)
 
 
+def _rerun_in_fresh_process(request):
+    """Thread-rank tests whose two ranks wait for each other ON THE DEVICE (one-shot peer exchange: a kernel of rank 0
+    polls for a store of a kernel of rank 1) need their two streams on hardware queues of their own.  Late in a long
+    pytest session the process has created dozens of streams (side streams, RCCL's, CU-masked ones) and the runtime
+    multiplexes them onto its few hardware queues: two streams that share one serialise, the poller sits in front of
+    the kernel it waits for, and the step only ends at the poll's time-out (found in round 3: the test passed alone and
+    failed as test 103 of the suite).  One process per GPU -- the product's layout -- cannot get into that state: a
+    poller there waits for ANOTHER device.  So such a test runs its body in a fresh interpreter.  Returns True when
+    the child ran it (and passed)."""
+    import subprocess
+    import sys
+    if os.environ.get("SML_TEST_CHILD") == "1":
+        return False
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", request.node.nodeid],
+                       env=dict(os.environ, SML_TEST_CHILD="1"), cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, "child pytest failed:\n" + r.stdout[-4000:] + "\n" + r.stderr[-2000:]
+    return True
+
+
 def test_library_loaded_and_lane_maps(eng32):
     eng32.selftest()
 
@@ -1306,11 +1326,8 @@ def test_driver_on_a_forced_one_rank_rccl_group_matches_the_plain_driver(tmp_pat
 
 
 # ----------------------------------------------------------------------------- world_size 2 on ONE GPU (thread ranks)
-_TWO_RANK_RESULTS = {}
-
-
 @pytest.mark.parametrize("comm", ["torch", "peer"])
-def test_two_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run(monkeypatch, comm):
+def test_two_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run(monkeypatch, request, comm):
     """The real HIP library under world_size 2: two thread ranks (tests/_thread_group.py), each with its own engine,
     its own user shard and an item / theta replica, split every global batch by user owner (unequal local batches,
     one of them EMPTY on rank 1), exchange item-gradient rows and theta gradients, and must land where ONE engine
@@ -1324,7 +1341,8 @@ def test_two_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run(monkey
              polls do.  Results must ALSO equal the hook path's bit for bit (same rank-order sums)."""
     from _thread_group import run_ranks
     from sml_amd import dist as SD
-    monkeypatch.setenv("SML_COMM", comm)
+    if comm == "peer" and _rerun_in_fresh_process(request):
+        return
     monkeypatch.setenv("SML_PEER_TIMEOUT_S", "20")
     torch.manual_seed(5)
     U, I, d, B, n = 200, 120, 32, 64, 300
@@ -1346,10 +1364,10 @@ def test_two_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run(monkey
     l_tr = eng.tr_stage_epoch(net0, lu.to(DEV), li.to(DEV), hu, hi, tri, B, 1e-3, 1e-4).cpu().numpy()
     theta1 = {k: v.detach().cpu().clone() for k, v in net0.state_dict().items()}
 
-    def rank_fn(rank, group):
+    def rank_fn(rank, group, mode):
         e = engine(d, B)
         ctx = SD.attach(e, None, group, rows_cap=2 * B)
-        assert ctx.mode == comm
+        assert ctx.mode == mode
         lo, hi_ = SD.user_range(U, 2, rank)
         m = make_mf(hi_ - lo, I, d, wu[lo:hi_].numpy(), wi.numpy(), device=DEV)
         net = make_transfer(d, device=DEV)
@@ -1362,18 +1380,21 @@ def test_two_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run(monkey
         hu_, hi2 = m.user_laten.weight.detach().clone(), m.item_laten.weight.detach().clone()
         b = e.tr_stage_epoch(net, lu[lo:hi_].to(DEV), li.to(DEV), hu_, hi2, route.local_tri, route.cap, 1e-3, 1e-4, plan=route.plan)
         torch.cuda.current_stream().synchronize()
-        assert comm != "peer" or e.peer_status() == 0
+        assert mode != "peer" or e.peer_status() == 0
         return dict(l_mf=a.cpu().numpy(), l_tr=b.cpu().numpy(), wu=hu_.cpu(), wi=hi2.cpu(),
                     theta={k: v.detach().cpu().clone() for k, v in net.state_dict().items()})
 
-    streams = None
-    if comm == "peer":
-        n_cu = eng._n_cus()
-        streams = [eng._masked_stream(0, n_cu // 2), eng._masked_stream(n_cu // 2, n_cu)]
-    r0, r1 = run_ranks(2, rank_fn, streams=streams)
-    _TWO_RANK_RESULTS[comm] = (r0, r1)
-    if len(_TWO_RANK_RESULTS) == 2:                 # one-shot peer exchange == hook path, bit for bit
-        for ra, rb in zip(_TWO_RANK_RESULTS["torch"], _TWO_RANK_RESULTS["peer"]):
+    results = {}
+    for mode in (("torch", "peer") if comm == "peer" else ("torch",)):       # (the peer case also runs the hook path: compared below)
+        monkeypatch.setenv("SML_COMM", mode)
+        streams = None
+        if mode == "peer":
+            n_cu = eng._n_cus()
+            streams = [eng._masked_stream(0, n_cu // 2), eng._masked_stream(n_cu // 2, n_cu)]
+        results[mode] = run_ranks(2, rank_fn, mode, streams=streams)
+    r0, r1 = results[comm]
+    if comm == "peer":                              # one-shot peer exchange == hook path, bit for bit
+        for ra, rb in zip(results["torch"], results["peer"]):
             assert torch.equal(ra["wi"], rb["wi"]) and torch.equal(ra["wu"], rb["wu"])
             assert np.array_equal(ra["l_mf"], rb["l_mf"]) and np.array_equal(ra["l_tr"], rb["l_tr"])
             for k in ra["theta"]:
@@ -1447,7 +1468,7 @@ def test_bare_step_two_ranks_on_one_gpu_equal_the_global_batch_step(d, dtype, bc
 @pytest.mark.parametrize("d,dtype,bce,head", [(32, torch.float32, True, 16), (64, torch.float32, False, 0), (128, torch.float16, False, 24),
                                               (32, torch.float32, True, 120), (128, torch.float32, True, 24), (128, torch.float16, False, 0),
                                               (64, torch.float16, False, 16)])
-def test_bare_step_item_sharded_two_ranks_on_one_gpu_equal_the_global_batch_step(d, dtype, bce, head, monkeypatch):
+def test_bare_step_item_sharded_two_ranks_on_one_gpu_equal_the_global_batch_step(d, dtype, bce, head, monkeypatch, request):
     """The bare a3 step with the ITEM TABLE SHARDED over world_size 2 (thread ranks on the two CU-masked streams, one-shot
     peer exchange, same-process allocations handed over as raw pointers): the first `head` rows replicated (dense
     one-shot all-reduce of their gradient partials), the tail owner-computes -- every rank reads tail rows from their
@@ -1457,6 +1478,8 @@ def test_bare_step_item_sharded_two_ranks_on_one_gpu_equal_the_global_batch_step
     exchange when everything is head (head = I) or nothing is (head = 0) -- both extremes included."""
     from _thread_group import run_ranks
     from sml_amd import dist as SD
+    if _rerun_in_fresh_process(request):
+        return
     monkeypatch.setenv("SML_COMM", "peer")
     monkeypatch.setenv("SML_PEER_TIMEOUT_S", "20")
     B, n, U_rank, I = 96, 96 * 3 - 11, 150, 120
