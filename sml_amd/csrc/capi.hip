@@ -305,7 +305,7 @@ int bwd_split(int row_tiles) {
 
 // slot layout of a batch: users at [0, B), items at [ioff, ioff + 2B), ioff = B rounded up to a
 // tile; both runs padded to whole tiles so the kernels store tile rows unconditionally
-int ensure_transfer_ws(sml_ctx* c, int B, bool tr_stage) {
+int ensure_transfer_ws(sml_ctx* c, int B, bool tr_stage, hipStream_t st) {
     const size_t slots = (size_t)SML_R * (tiles_of(B) + tiles_of(2 * B)), d = (size_t)c->d;
     HIPCHK(c->out.ensure(slots * d * SML_FWD_NS));     // the training forward writes SML_FWD_NS partial planes
     HIPCHK(c->dout.ensure(slots * d));
@@ -317,7 +317,10 @@ int ensure_transfer_ws(sml_ctx* c, int B, bool tr_stage) {
         HIPCHK(c->dz1.ensure(slots * SML_HID));
         HIPCHK(c->convg.ensure((slots / SML_TM + 4) * (d / 16) * SML_CG));   // one partial per backward workgroup
         HIPCHK(c->grad.ensure((size_t)2 * sml_net_size(c->d)));
-        if (!c->arrive.p) { HIPCHK(c->arrive.ensure(4)); HIPCHK(hipMemset(c->arrive.p, 0, 4 * sizeof(int))); }
+        // (on the caller's stream, never the null stream: a null-stream operation orders itself behind EVERY blocking
+        // stream of the process -- with another rank's kernel of the same process polling for this rank's next launch,
+        // that is a dead-lock until the poll's time-out: seen in the thread-rank tests)
+        if (!c->arrive.p) { HIPCHK(c->arrive.ensure(4)); HIPCHK(hipMemsetAsync(c->arrive.p, 0, 4 * sizeof(int), st)); }
     } else {
         HIPCHK(c->dx.ensure(slots * d));
         HIPCHK(c->mrep.ensure(slots * d)); HIPCHK(c->vrep.ensure(slots * d));
@@ -687,7 +690,7 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
             return fail(SML_EINVAL, "sml_mf_stage_epoch", "a planned batch is longer than `batch`");
     int rc;
     if ((rc = ensure_pk(ctx))) return rc;
-    if ((rc = ensure_transfer_ws(ctx, batch, false))) return rc;
+    if ((rc = ensure_transfer_ws(ctx, batch, false, st))) return rc;
     if ((rc = ensure_sched(ctx, lr, *step + nb + 1, st))) return rc;
     const int lstride = (wg_tiles(batch, 1) + wg_tiles(2 * batch, 1)) * (d / 16);     // one loss partial per backward workgroup
     const int64_t out_pstride = (int64_t)SML_R * (tiles_of(batch) + tiles_of(2 * batch)) * d;
@@ -822,7 +825,7 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
             return fail(SML_EINVAL, "sml_tr_stage_epoch", "a planned batch is longer than `batch`");
     int rc;
     if ((rc = ensure_pk(ctx))) return rc;
-    if ((rc = ensure_transfer_ws(ctx, batch, true))) return rc;
+    if ((rc = ensure_transfer_ws(ctx, batch, true, st))) return rc;
     float* grad = theta_grad ? theta_grad : ctx->grad.p;
     const int fns = fwd_split(wg_tiles(batch, 1) + wg_tiles(2 * batch, 1)), bsplit = bwd_split(wg_tiles(batch, 1) + wg_tiles(2 * batch, 1));
     const int cs = bsplit ? d / 16 : 1;                                 // backward workgroups per row tile
@@ -898,7 +901,13 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
             ctx->prof.begin(PC_WGRAD, st); HIPCHK(launch_wgrad(wg)); ctx->prof.end(st);
             ad.theta = theta; ad.m = adam_m; ad.v = adam_v; ad.grad = grad; ad.pk = pk_cur(ctx);
             ad.weight_decay = weight_decay; ad.step_size = sc.step_size; ad.bc2_sqrt = sc.bc2_sqrt;
-            ctx->prof.begin(PC_THETA_ADAM, st); HIPCHK(sml_launch_theta_adam(d, ad, st)); ctx->prof.end(st);
+            // every workgroup of the Adam kernel polls the counters itself (SML_PEER_POLL_IN_ADAM=0: a one-wavefront
+            // k_peer_wait launch ahead of it instead -- one launch more; same results)
+            static const bool poll_in_adam = env_int("SML_PEER_POLL_IN_ADAM", 1) != 0;
+            ctx->prof.begin(PC_THETA_ADAM, st);
+            if (!poll_in_adam) { HIPCHK(sml_launch_peer_wait(ad.peer, st)); ad.peer.waited = 1; }
+            HIPCHK(sml_launch_theta_adam(d, ad, st));
+            ctx->prof.end(st);
         } else if (!grad_hook && !native) {
             // one GPU: the weight-gradient workgroups take the Adam step for the tiles they own
             // (v2: the refreshed images go to the OTHER set -- the launch's tail workgroups are reading this one)
@@ -941,8 +950,8 @@ int sml_run_mf_grad(sml_ctx* ctx, const float* theta, const float* user_last, co
     const int d = ctx->d;
     int rc;
     if ((rc = ensure_pk(ctx))) return rc;
-    if ((rc = ensure_transfer_ws(ctx, B, true))) return rc;       // TR-stage saves (a1, a2, dz1, conv partials, flat gradient)
-    if ((rc = ensure_transfer_ws(ctx, B, false))) return rc;      // + the MF stage's dx rows
+    if ((rc = ensure_transfer_ws(ctx, B, true, st))) return rc;       // TR-stage saves (a1, a2, dz1, conv partials, flat gradient)
+    if ((rc = ensure_transfer_ws(ctx, B, false, st))) return rc;      // + the MF stage's dx rows
     const int64_t ns = sml_net_size(d), ps = sml_pk_size(d);
     const int tiles0 = wg_tiles(B, 1), tiles = tiles0 + wg_tiles(2 * B, 1);
     const int fns = fwd_split(tiles);
@@ -1371,9 +1380,12 @@ int sml_peer_alloc(int device, int64_t bytes, void** ptr) {
     const char* kind = getenv("SML_PEER_MEM");
     const int first = kind && !strcmp(kind, "finegrained") ? 1 : kind && !strcmp(kind, "plain") ? 2 : 0;
     hipError_t e = hipErrorUnknown;
-    if (first <= 0) e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached);
-    if (e != hipSuccess && first <= 1) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained); }
-    if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&p, (size_t)bytes); }
+    int got = -1;
+    if (first <= 0) { e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached); got = 0; }
+    if (e != hipSuccess && first <= 1) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained); got = 1; }
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&p, (size_t)bytes); got = 2; }
+    if (getenv("SML_DEBUG_PEER")) fprintf(stderr, "[sml] sml_peer_alloc(%lld bytes): kind %d (0 uncached, 1 fine-grained, 2 plain), %s\n",
+                                          (long long)bytes, got, hipGetErrorString(e));
     if (e != hipSuccess) return fail(SML_ENOMEM, "sml_peer_alloc", hipGetErrorString(e));
     e = hipMemset(p, 0, (size_t)bytes);
     if (e == hipSuccess) e = hipDeviceSynchronize();

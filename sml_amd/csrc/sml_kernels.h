@@ -74,6 +74,7 @@ struct SmlPeerPoll {
     unsigned long long expect;                   // counter value that completes this step
     long long timeout;                           // 100 MHz ticks
     int* err;                                    // incidents (consumers that gave up)
+    int waited;                                  // 1: a k_peer_wait launch ahead of this kernel did the waiting
 };
 
 struct SmlWgSeg {

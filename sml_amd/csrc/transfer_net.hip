@@ -1804,7 +1804,7 @@ __global__ __launch_bounds__(256) void k_theta_adam(SmlThetaAdamArgs a) {
     constexpr int NS = sml_net_size(D);
     static_assert(NS % 4 == 0, "a thread's four floats belong to one net");
     // several GPUs, one-shot exchange: wait until every rank's gradient tiles have landed in this rank's inbox
-    if constexpr (PEER) peer_wait(a.peer);
+    if constexpr (PEER) { if (!a.peer.waited) peer_wait(a.peer); }
     // four consecutive parameters per thread: 16-byte loads of gradient / theta / m / v, 16-byte stores
     const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (i0 >= 2 * NS) return;

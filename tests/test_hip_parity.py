@@ -30,24 +30,6 @@ def engine(d, mb=4096):
     return HipEngine(DEV, d, mb)
 
 
-def _rerun_in_fresh_process(request):
-    """Thread-rank tests whose two ranks wait for each other ON THE DEVICE (one-shot peer exchange: a kernel of rank 0
-    polls for a store of a kernel of rank 1) need their two streams on hardware queues of their own.  Late in a long
-    pytest session the process has created dozens of streams (side streams, RCCL's, CU-masked ones) and the runtime
-    multiplexes them onto its few hardware queues: two streams that share one serialise, the poller sits in front of
-    the kernel it waits for, and the step only ends at the poll's time-out (found in round 3: the test passed alone and
-    failed as test 103 of the suite).  One process per GPU -- the product's layout -- cannot get into that state: a
-    poller there waits for ANOTHER device.  So such a test runs its body in a fresh interpreter.  Returns True when
-    the child ran it (and passed)."""
-    import subprocess
-    import sys
-    if os.environ.get("SML_TEST_CHILD") == "1":
-        return False
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", request.node.nodeid],
-                       env=dict(os.environ, SML_TEST_CHILD="1"), cwd=root, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, "child pytest failed:\n" + r.stdout[-4000:] + "\n" + r.stderr[-2000:]
-    return True
 
 
 def test_library_loaded_and_lane_maps(eng32):
@@ -1341,8 +1323,6 @@ def test_two_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run(monkey
              polls do.  Results must ALSO equal the hook path's bit for bit (same rank-order sums)."""
     from _thread_group import run_ranks
     from sml_amd import dist as SD
-    if comm == "peer" and _rerun_in_fresh_process(request):
-        return
     monkeypatch.setenv("SML_PEER_TIMEOUT_S", "20")
     torch.manual_seed(5)
     U, I, d, B, n = 200, 120, 32, 64, 300
@@ -1478,8 +1458,6 @@ def test_bare_step_item_sharded_two_ranks_on_one_gpu_equal_the_global_batch_step
     exchange when everything is head (head = I) or nothing is (head = 0) -- both extremes included."""
     from _thread_group import run_ranks
     from sml_amd import dist as SD
-    if _rerun_in_fresh_process(request):
-        return
     monkeypatch.setenv("SML_COMM", "peer")
     monkeypatch.setenv("SML_PEER_TIMEOUT_S", "20")
     B, n, U_rank, I = 96, 96 * 3 - 11, 150, 120
