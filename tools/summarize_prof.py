@@ -64,9 +64,17 @@ def all_counters(run_dir):
     return acc
 
 
-# fp32 MFMA work of one instruction, for the achieved-FLOP cross-check: SQ_INSTS_VALU_MFMA_MOPS_F32 counts
-# MFMA "mega-ops" in units of 512 flops as rocprofv3 reports it on gfx950 (v_mfma_f32_16x16x4_f32 = 2*16*16*4 = 2,048 flops = 4 units)
-def mfma_summary(run_dir):
+# SQ_VALU_MFMA_BUSY_CYCLES counts shader cycles the matrix pipes were busy, SUMMED over the chip's SIMDs (checked on the
+# table-sized forward: 8.78 M wave-level v_mfma_f32_16x16x4_f32 x 32 cycles per SIMD each = 281 M, the counter's value);
+# SQ_INSTS_VALU_MFMA_MOPS_F32 counts fp32 MFMA work in units of 512 flops (35.1 M x 512 = 18.0 GFLOP = the launch's
+# fc1 + fc2 flops); GRBM_GUI_ACTIVE is summed over the 8 XCDs.  MFMA-busy fraction of a kernel = busy cycles / (1,024
+# SIMDs x the kernel's duration x the shader clock).  The duration comes from the UN-counted kernel trace of the same
+# command (counter passes serialise and slow the launches), the clock is the 2.4 GHz nominal: the fraction is of ALL
+# 256 CUs' matrix pipes (the training stream owns 192 of them: divide by 0.75 for the share of what it could use).
+N_SIMD, CLOCK_MHZ = 1024, 2400.0
+
+
+def mfma_summary(run_dir, durations_us):
     out = {}
     for k, cs in all_counters(run_dir).items():
         if not k.startswith("k_t"):
@@ -75,10 +83,15 @@ def mfma_summary(run_dir):
         avg = {c: v[1] / max(v[0], 1) for c, v in cs.items()}
         e = {"launches": n, "avg_per_launch": avg}
         busy, act = avg.get("SQ_VALU_MFMA_BUSY_CYCLES"), avg.get("GRBM_GUI_ACTIVE")
-        if busy and act:
-            # the SQ counter is summed over the chip's 1,024 SIMDs (256 CUs x 4); GRBM_GUI_ACTIVE is the launch's
-            # active cycles per shader engine sample: busy fraction of the matrix pipes = busy / (active * 1024)
-            e["mfma_busy_frac_of_all_simds"] = busy / (act * 1024.0)
+        if busy is not None and act:
+            e["mfma_busy_frac_in_the_counter_pass"] = busy / (act / 8.0 * N_SIMD)
+        dur = durations_us.get(k)
+        if busy is not None and dur:
+            e["avg_us_kernel_trace"] = dur
+            e["mfma_busy_frac_of_all_simds"] = busy / (N_SIMD * dur * CLOCK_MHZ)
+        mops = avg.get("SQ_INSTS_VALU_MFMA_MOPS_F32")
+        if mops is not None and dur:
+            e["mfma_tflops_by_counter"] = mops * 512.0 / (dur * 1e-6) / 1e12
         out[k] = e
     return out
 
@@ -100,7 +113,8 @@ def main():
                     for k, (c, t) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
                         f.write('"%s",%d,%.3f,%.2f\n' % (k, c, t / 1e6, t / 1e3 / max(c, 1)))
         if run.endswith("_mfma"):
-            m = mfma_summary(d)
+            stats = kernel_stats(os.path.join(root, run[:-5] + "_stats"))
+            m = mfma_summary(d, {k: t / 1e3 / max(c, 1) for k, (c, t) in stats.items()})
             if m:
                 with open(os.path.join(out, "%s_pmc_mfma.json" % tag), "w") as f:
                     json.dump(m, f, indent=1, sort_keys=True)
