@@ -254,6 +254,14 @@ def kernel_work(name, a, hp, U_local):
     return None, 0.0, 0
 
 
+# kernel names a timing class covers in the rocprofv3 summaries (the restructured TR step's kernels carry their own names)
+CLASS_KERNELS = {"k_transfer_wgrad": ("k_transfer_wgrad", "k_tr_wgrad2"), "k_transfer_bwd": ("k_transfer_bwd", "k_tr_bwd_head")}
+
+
+def _in_class(name, kernel):
+    return any(name.startswith(p) for p in CLASS_KERNELS.get(kernel, (kernel,)))
+
+
 def pmc_traffic(kernel):
     """Fabric bytes per launch of kernel class `kernel` from the COMMITTED rocprofv3 --pmc passes of this same
     command (profiles/*_pmc_per_launch.json, made by tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE in
@@ -269,7 +277,7 @@ def pmc_traffic(kernel):
         runs = json.load(open(path))["period"]
         tot, n = 0.0, 0
         for name, c in runs.items():
-            if not name.startswith(kernel):
+            if not _in_class(name, kernel):
                 continue
             k = c["FETCH_SIZE"]["launches"]
             tot += k * (2.0 * c["FETCH_SIZE"]["avg_counter_per_launch"] + c["WRITE_SIZE"]["avg_counter_per_launch"]) * 1024.0
@@ -291,7 +299,7 @@ def rocprof_avg_us(kernel):
     try:
         tot_ms, calls = 0.0, 0        # tools/summarize_prof.py's columns: kernel, calls, total_ms, avg_us
         for row in csv.DictReader(open(files[-1])):
-            if row["kernel"].startswith(kernel):
+            if _in_class(row["kernel"], kernel):
                 tot_ms += float(row["total_ms"])
                 calls += int(row["calls"])
         return (1000.0 * tot_ms / calls if calls else None), os.path.basename(files[-1])
@@ -310,7 +318,7 @@ def pmc_mfma(kernel):
     try:
         tot, n = 0.0, 0
         for name, e in json.load(open(files[-1])).items():
-            if name.startswith(kernel) and "mfma_busy_frac_of_all_simds" in e:
+            if _in_class(name, kernel) and "mfma_busy_frac_of_all_simds" in e:
                 tot += e["launches"] * e["mfma_busy_frac_of_all_simds"]
                 n += e["launches"]
         return (tot / n if n else None), os.path.basename(files[-1])
