@@ -1390,6 +1390,56 @@ def test_two_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run(monkey
         adam_close(r0["theta"][k].numpy(), theta1[k].numpy(), 1e-3, 5)
 
 
+def test_two_processes_on_one_gpu_exchange_through_hipipc_mappings(tmp_path):
+    """The one-shot peer exchange across PROCESS boundaries: two rank processes (tests/_peer_ipc_child.py) share this GPU,
+    export their uncached inbox / flags regions with hipIpcGetMemHandle, open each other's with hipIpcOpenMemHandle
+    (sml_peer_export / sml_peer_open; gloo carries the handles), run the start-up self-check, a whole-slot all-reduce and
+    the MF + TR stages of the two-rank workload above -- and must land where the thread-rank runs land: losses add up to
+    the single engine's, replicas bit-identical between the two processes, no consumer timed out."""
+    import socket
+    import subprocess
+    import sys
+    from _peer_ipc_child import workload
+    U, I, d, B, n, wu, wi, tri = workload()
+    net0 = make_transfer(d, device=DEV)
+    sd = {k: v.detach().cpu().clone() for k, v in net0.state_dict().items()}
+    torch.save(sd, str(tmp_path / "theta0.pt"))
+    lu, li = wu * 0.9, wi * 0.9
+    eng = engine(d, B)
+    mf = make_mf(U, I, d, wu.numpy(), wi.numpy(), device=DEV)
+    l_mf = eng.mf_stage_epoch(mf, net0, lu.to(DEV), li.to(DEV), tri, B, 0.01, 1e-6).cpu().numpy()
+    eng.mf_flush(mf)
+    hu, hi = mf.user_laten.weight.detach().clone(), mf.item_laten.weight.detach().clone()
+    l_tr = eng.tr_stage_epoch(net0, lu.to(DEV), li.to(DEV), hu, hi, tri, B, 1e-3, 1e-4).cpu().numpy()
+    theta1 = {k: v.detach().cpu().clone() for k, v in net0.state_dict().items()}
+    torch.cuda.synchronize()
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_peer_ipc_child.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SML_COMM="peer")
+    procs = [subprocess.Popen([sys.executable, child, str(r), "2", str(port), str(tmp_path)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p_ in procs:
+        try:
+            out, _ = p_.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p_.kill()
+            out, _ = p_.communicate()
+        outs.append(out)
+    assert all(p_.returncode == 0 for p_ in procs), "\n----\n".join(o[-3000:] for o in outs)
+    r0, r1 = (torch.load(str(tmp_path / ("rank%d.pt" % r)), weights_only=False) for r in range(2))
+    assert r0["timeouts"] == 0 and r1["timeouts"] == 0
+    assert torch.equal(r0["wi"], r1["wi"])
+    for k in r0["theta"]:
+        assert torch.equal(r0["theta"][k], r1["theta"][k]), k
+    np.testing.assert_allclose(r0["l_mf"] + r1["l_mf"], l_mf, rtol=1e-4)
+    np.testing.assert_allclose(r0["l_tr"] + r1["l_tr"], l_tr, rtol=1e-4)
+    adam_close(torch.cat([r0["wu"], r1["wu"]]).numpy(), hu.cpu().numpy(), 0.01, 5)
+    adam_close(r0["wi"].numpy(), hi.cpu().numpy(), 0.01, 5)
+    for k in theta1:
+        adam_close(r0["theta"][k].numpy(), theta1[k].numpy(), 1e-3, 5)
+
+
 # ----------------------------------------------------------------------------- bare a3 step on several GPUs
 def _bare_world2_inputs(d, dtype, B, n, U_rank, I, seed):
     torch.manual_seed(seed)
