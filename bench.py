@@ -162,7 +162,8 @@ def bench_bare(a, device, dist=None):
                                   % (a.users, world, a.items, n, a.bare_batch),
                       "parallelism": "single GPU" if world == 1 else
                       "users row-sharded x%d, items replicated, per-batch all-gather of item-gradient rows (%s)"
-                      % (world, "native RCCL" if ctx.native else "torch.distributed")},
+                      % (world, {"rccl": "native RCCL", "torch": "torch.distributed hooks"}.get(ctx.mode, "torch.distributed hooks (peer mode: "
+                                                                                                 "the replicated-items bare step is not wired to the inboxes)"))},
            # traffic (PMC bytes) cannot be read from inside the process: null here; the rocprofv3 --pmc passes of this
            # command are tools/profile_round.sh's, summarised under profiles/
            "roofline": {"kernel": "k_bare_grad + k_seg_update_sgd + k_hot_rows (one a3 step)", "bound": "hbm", "achieved": ach,
@@ -489,8 +490,10 @@ def main():
                                   "numbers); inputs resident in HBM: host batch supply and H2D are outside the timed region"
                                   % (a.users, a.items, a.inter, a.neg, a.d, hp.multi_num, hp.MF_batch_size, hp.TR_batch_size,
                                      not a.no_val),
-                      "parallelism": ("users row-sharded x%d, items replicated, %s exchange" %
-                                      (world, "native RCCL" if dctx.native else "torch.distributed"))
+                      "parallelism": ("users row-sharded x%d, items and theta replicated, independent shards (global batch = %d x the "
+                                      "reference's), %s" %
+                                      (world, world, {"peer": "one-shot exchange over peer mappings (hipIpc, no collective library on the data path)",
+                                                      "rccl": "native RCCL exchange", "torch": "torch.distributed hooks"}[dctx.mode]))
                       if dist is not None else "single GPU"}}
 
     if not a.no_roofline:
