@@ -172,8 +172,6 @@ struct sml_ctx {
     Buf<float> pk, grad, convg, loss_part;
     int pk_set = 0;          // which of the two operand-image sets is current
     Buf<int> arrive;         // k_tr_wgrad2's tail-workgroup arrival counter (0 between launches)
-    Buf<float> conv_state;   // deferred conv-parameter Adam step: [2 sets][2 nets][3: p, m, v][104]
-    int conv_set = 0;
     // Adam schedule of the MF optimiser
     Buf<SmlSched> sched;
     int sched_len = 0;
@@ -209,7 +207,7 @@ struct sml_ctx {
         prof.release();
         out.release(); dout.release(); dx.release(); xin.release(); z1.release(); a1.release(); a2.release(); dz1.release();
         mrep.release(); vrep.release();
-        pk.release(); grad.release(); convg.release(); loss_part.release(); arrive.release(); conv_state.release();
+        pk.release(); grad.release(); convg.release(); loss_part.release(); arrive.release();
         ix[0].release(); ix[1].release();
         sched.release(); dummy.release(); rec_x.release();
         for (auto& r : sched_retired) { if (r.dev) (void)hipFree(r.dev); if (r.host) (void)hipHostFree(r.host); (void)hipEventDestroy(r.done); }
@@ -834,9 +832,6 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
     // Restructured step (default): backward head (loss -> dOut -> dZ1) + ONE launch with the weight-gradient tiles and
     // the rest of the backward beside them.  SML_TR_V2=0 runs the round-2 kernels (k_transfer_bwd + k_transfer_wgrad).
     const bool v2 = env_int("SML_TR_V2", 1) != 0;
-    // Fused single-GPU step: the conv parameters' Adam step of batch b is taken by the forward of batch b + 1
-    // (SmlConvPending; SML_TR_DEFER=0: the merged launch's last tail workgroup takes it, as on the exchange paths)
-    const bool defer = v2 && !grad_hook && ctx->comm == nullptr && ctx->peer.world == 0 && theta_grad == nullptr && env_int("SML_TR_DEFER", 1) != 0;
     const int lstride = (wg_tiles(batch, 1) + wg_tiles(2 * batch, 1)) * (d / 16 > 4 ? d / 16 : 4);
     const int64_t out_pstride = (int64_t)SML_R * (tiles_of(batch) + tiles_of(2 * batch)) * d;
     HIPCHK(ctx->loss_part.ensure((size_t)nb * lstride));
@@ -844,35 +839,12 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
     HIPCHK(hipMemsetAsync(ctx->loss_part.p, 0, (size_t)nb * lstride * sizeof(float), st));
     HIPCHK(hipMemsetAsync(grad, 0, (size_t)2 * sml_net_size(d) * sizeof(float), st));
     const int64_t ns = sml_net_size(d), ps = sml_pk_size(d);
-    SmlConvPending pend;            // the conv update the next forward (or the finalize launch) has to take
-    memset(&pend, 0, sizeof(pend));
-    constexpr size_t kConvSet = 2 * 3 * 104;
-    auto conv_set_ptr = [&](int set) { return ctx->conv_state.p + (size_t)set * kConvSet; };
-    if (defer) {
-        HIPCHK(ctx->conv_state.ensure(2 * kConvSet));
-        HIPCHK(sml_launch_conv_state_load(d, theta, adam_m, adam_v, conv_set_ptr(ctx->conv_set), st));
-    }
-    auto conv_finalize = [&]() -> int {          // a pending update applied by a launch of its own; the state set follows
-        pend.in = conv_set_ptr(ctx->conv_set); pend.out = nullptr; pend.theta = theta; pend.m = adam_m; pend.v = adam_v;
-        HIPCHK(sml_launch_conv_finalize(d, pend, st));
-        HIPCHK(sml_launch_conv_state_load(d, theta, adam_m, adam_v, conv_set_ptr(ctx->conv_set), st));
-        pend.part = nullptr;
-        return SML_OK;
-    };
     for (int64_t b = 0; b < nb; ++b) {
         const int64_t off0 = plan ? plan->batch_off[b] : b * batch;
         const int B = plan ? (int)(plan->batch_off[b + 1] - off0) : (int)((n - off0) < batch ? (n - off0) : batch);
         const int64_t* tri = triples + off0 * 3;
-        if (B == 0 && pend.part) { if ((rc = conv_finalize())) return rc; }      // no forward launch to carry it
         SmlFwdArgs f;
         memset(&f, 0, sizeof(f));
-        if (pend.part) {
-            f.conv = pend;
-            f.conv.in = conv_set_ptr(ctx->conv_set); f.conv.out = conv_set_ptr(1 - ctx->conv_set);
-            f.conv.theta = theta; f.conv.m = adam_m; f.conv.v = adam_v;
-            ctx->conv_set ^= 1;           // after this forward the other set is current
-            pend.part = nullptr;
-        }
         for (int s = 0; s < 2; ++s) {
             SmlSeg& sg = f.seg[s];
             sg.theta = theta + s * ns; sg.pk = pk_cur(ctx) + s * ps;
@@ -941,15 +913,8 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
             // (v2: the refreshed images go to the OTHER set -- the launch's tail workgroups are reading this one)
             wg.theta = theta; wg.m = adam_m; wg.v = adam_v; wg.pk = v2 ? pk_other(ctx) : pk_cur(ctx);
             wg.weight_decay = weight_decay; wg.step_size = sc.step_size; wg.bc2_sqrt = sc.bc2_sqrt;
-            wg.defer_conv = (defer && B > 0) ? 1 : 0;
             ctx->prof.begin(PC_WGRAD, st); HIPCHK(launch_wgrad(wg)); ctx->prof.end(st);
             if (v2) ctx->pk_set ^= 1;
-            if (wg.defer_conv) {          // this batch's conv update rides in the next forward
-                pend.part = ctx->convg.p; pend.split = f.tiles0 * (d / 16); pend.total = tiles * (d / 16);
-                pend.weight_decay = weight_decay; pend.step_size = sc.step_size; pend.bc2_sqrt = sc.bc2_sqrt;
-            } else if (defer) {           // (an empty batch: the last arriver updated the flat buffers -- the state set follows)
-                HIPCHK(sml_launch_conv_state_load(d, theta, adam_m, adam_v, conv_set_ptr(ctx->conv_set), st));
-            }
         } else {
             // the weight-gradient launch leaves the flat gradient complete (its conv workgroups sum the backward's
             // partials): all-reduce it, then one Adam launch
@@ -967,7 +932,6 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
             ctx->prof.begin(PC_THETA_ADAM, st); HIPCHK(sml_launch_theta_adam(d, ad, st)); ctx->prof.end(st);
         }
     }
-    if (pend.part) { if ((rc = conv_finalize())) return rc; }      // the epoch's last conv update
     ctx->prof.begin(PC_MISC, st); HIPCHK(sml_launch_loss_finalize(ctx->loss_part.p, (int)nb, lstride, nullptr, batch_loss, st)); ctx->prof.end(st);
     *step += nb;
     return SML_OK;

@@ -4,21 +4,6 @@
 #include <stdint.h>
 #include "sml_dev.h"
 
-// The conv1 / conv2 parameters' Adam step of TR batch b, deferred into the forward of batch b + 1 (fused single-GPU
-// step): the merged launch's tail workgroups leave their conv-gradient partials [total][SML_CG] (user net's rows first:
-// [0, split), then the item net's) and return -- no arrival counter, no last arriver re-reading them at the END of the
-// launch's longest chain.  Every forward workgroup of batch b + 1 needs its net's 104 conv floats anyway: it adds its net's
-// partial rows (one round trip, in the shadow of its gather), takes the Adam step itself from the state set `in`
-// ([2 nets][3: p, m, v][104] floats) and uses the result; ONE workgroup per net also writes it -- to the other state set
-// `out` (a late workgroup of the same launch must still find the OLD state) and to the flat theta / m / v.
-struct SmlConvPending {
-    const float* part;       // null: nothing pending (conv parameters are read from theta)
-    int split, total;
-    float weight_decay, step_size, bc2_sqrt;
-    const float* in; float* out;
-    float* theta; float* m; float* v;      // flat buffers (both nets)
-};
-
 // One contiguous run of rows that goes through one net.
 struct SmlSeg {
     const float* theta;      // this net's flat parameter block
@@ -48,7 +33,6 @@ struct SmlFwdArgs {
     int tiles_total;
     int k2;                  // ConvTransfer nets: kernel (2,1), the x_com row is zero
     int unit_rows;           // NS = 1 only: rows of seg[0] leave divided by their norm (ConvTransfer's user output)
-    SmlConvPending conv;     // TR stage, fused single-GPU step: the PREVIOUS batch's conv-parameter Adam step, applied here
 };
 #define SML_FWD_NS 4         // largest hidden-dimension split of the training-batch forward (planes of `out`)
 
@@ -112,7 +96,6 @@ struct SmlWgArgs {
     // tiles0 / tiles_total then count ROW tiles; `arrive` is a device counter (0 between launches) the tail
     // workgroups use to elect the last arriver, which finishes the conv parameters
     int n_tail; float* convg_out; int* arrive;
-    int defer_conv;          // 1: the tail workgroups only leave their partials (the next forward finishes the conv parameters)
 };
 
 struct SmlThetaAdamArgs {
@@ -129,10 +112,7 @@ hipError_t sml_launch_wgrad(int d, const SmlWgArgs& a, hipStream_t st);
 // restructured TR step: backward head (loss -> dOut -> dZ1) and the merged weight-gradient + backward-tail launch
 hipError_t sml_launch_tr_bwd_head(int d, const SmlBwdArgs& a, int tiles_total, hipStream_t st);
 hipError_t sml_launch_tr_wgrad2(int d, const SmlWgArgs& a, hipStream_t st);
-int sml_wgrad2_pushers(int d);
-// conv-parameter state set <- flat theta / m / v; and a pending conv update applied outside a forward (epoch end, empty batch)
-hipError_t sml_launch_conv_state_load(int d, const float* theta, const float* m, const float* v, float* state, hipStream_t st);
-hipError_t sml_launch_conv_finalize(int d, const SmlConvPending& c, hipStream_t st);                   // counter increments one merged launch adds per destination (fixed)
+int sml_wgrad2_pushers(int d);                   // counter increments one merged launch adds per destination (fixed)
 hipError_t sml_launch_theta_adam(int d, const SmlThetaAdamArgs& a, hipStream_t st);
 hipError_t sml_launch_theta_pack(int d, const float* theta, float* pk, hipStream_t st);
 int sml_wgrad_grid(int d);                       // workgroups (= pushers) of one weight-gradient launch

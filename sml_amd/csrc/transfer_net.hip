@@ -197,38 +197,6 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[MT][NT]) {
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-// ---- deferred conv-parameter Adam step (SmlConvPending): the partial rows of one net, added in a FIXED order -- row t by
-// thread group t % 21, the groups then in index order -- the same order k_tr_wgrad2's last arriver uses
-#define SML_CP_RG 21
-#define SML_CP_C4 (SML_CG / 4)
-__device__ __forceinline__ f32x4 conv_partial_rows(const SmlConvPending& c, int net, int tid) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (tid >= SML_CP_RG * SML_CP_C4) return acc;
-    const int rg = tid / SML_CP_C4, c4 = tid % SML_CP_C4;
-    const int t0 = net ? c.split : 0, t1 = net ? c.total : c.split;
-    int t = t0 + ((rg - t0) % SML_CP_RG + SML_CP_RG) % SML_CP_RG;        // the first row >= t0 with t % 21 == rg
-    for (; t < t1; t += 4 * SML_CP_RG) {
-        f32x4 x[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            x[u] = *reinterpret_cast<const f32x4*>(c.part + (int64_t)min(t + u * SML_CP_RG, t1 - 1) * SML_CG + c4 * 4);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) if (t + u * SML_CP_RG < t1) acc += x[u];
-    }
-    return acc;
-}
-// thread tid < 104: this conv slot's Adam step from the group sums P [21][SML_CG]; returns the new parameter
-__device__ __forceinline__ float conv_pending_step(const SmlConvPending& c, const float* P, int off, float& p, float& m, float& v) {
-    if (!conv_slot_used_host(off)) return p;          // alignment padding of the conv block
-    const int k = conv_compact(off);
-    float g = 0.0f;
-#pragma unroll
-    for (int rg = 0; rg < SML_CP_RG; ++rg) g += P[rg * SML_CG + k];
-    SmlSched sc; sc.step_size = c.step_size; sc.bc2_sqrt = c.bc2_sqrt;
-    adam_apply(p, m, v, g + c.weight_decay * p, sc);
-    return p;
-}
-
 // ------------------------------------------------------------------------------------
 // forward: rows -> out, optionally saving z1 / (x_t, x_hat, x_com) / a1 for backward.
 // The z1 / xin / a1 scratch is padded to whole tiles by the caller, so those stores are
@@ -293,16 +261,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HSEQ > 1 ? 
     const int row0 = (tile - (sidx ? a.tiles0 : 0)) * R;
     const float* __restrict__ theta = sg.theta;
     float cw_reg = 0.0f;
-    // (TR stage, fused step: the previous batch's conv-parameter Adam step is taken HERE -- SmlConvPending)
-    const bool cpend = a.conv.part != nullptr;
-    float cst_m = 0.0f, cst_v = 0.0f;
-    f32x4 cpacc = {0.f, 0.f, 0.f, 0.f};
-    if (cpend) {
-        if (tid < 104) {
-            cw_reg = a.conv.in[(sidx * 3 + 0) * 104 + tid]; cst_m = a.conv.in[(sidx * 3 + 1) * 104 + tid]; cst_v = a.conv.in[(sidx * 3 + 2) * 104 + tid];
-        }
-        cpacc = conv_partial_rows(a.conv, sidx, tid);
-    } else if (tid < 104) cw_reg = theta[tid];        // parked in LDS once the other loads are on their way
+    if (tid < 104) cw_reg = theta[tid];               // parked in LDS once the other loads are on their way
     const bool lazy = sg.last_tab != nullptr;
     if (lazy) sched_window_load(swin, a.sched, a.cur_step - 1, tid);
     const bool saver = (h == 0);         // one workgroup of the NS writes the shared saves
@@ -390,22 +349,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HSEQ > 1 ? 
                 nr2[q] = s2;
             }
         }
-        if (cpend) {                        // group sums of the partial rows -> LDS (the A1 tile's space: not written before P2)
-            if (tid < SML_CP_RG * SML_CP_C4) *reinterpret_cast<f32x4*>(A1s + (tid / SML_CP_C4) * SML_CG + (tid % SML_CP_C4) * 4) = cpacc;
-        } else if (tid < 104) cws[tid] = cw_reg;
+        if (tid < 104) cws[tid] = cw_reg;
         __syncthreads();                   // xts, cws and the schedule window are in LDS
-        if (cpend) {
-            if (tid < 104) {
-                const float pnew = conv_pending_step(a.conv, A1s, tid, cw_reg, cst_m, cst_v);
-                cws[tid] = pnew;
-                if (h == 0 && row0 == 0) {  // this net's one writer: the OTHER state set (late workgroups still read the old one) + the flat buffers
-                    a.conv.out[(sidx * 3 + 0) * 104 + tid] = pnew; a.conv.out[(sidx * 3 + 1) * 104 + tid] = cst_m; a.conv.out[(sidx * 3 + 2) * 104 + tid] = cst_v;
-                    const int64_t i = (int64_t)sidx * sml_net_size(D) + tid;
-                    a.conv.theta[i] = pnew; a.conv.m[i] = cst_m; a.conv.v[i] = cst_v;
-                }
-            }
-            __syncthreads();               // cws is complete; the partial sums' space may become the A1 tile
-        }
         TL(2);
         if (lazy) {                        // replay the rows' pending zero-gradient Adam steps
 #pragma unroll
@@ -1780,7 +1725,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // wave of 96 workgroups underneath the weight-gradient tiles that live out of that L2 (measured: the launch took
     // 28 us).  The partials left as write-through (sc1) stores: once they are acknowledged (vmcnt = 0) they are in
     // memory, the arrival counter is an L2-bypassing atomic, and the last arriver reads the partials with sc1 loads.
-    if (a.defer_conv) { TL_DONE(); return; }         // the next forward adds the partials and finishes the conv parameters
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) s_last = (__hip_atomic_fetch_add(a.arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.n_tail - 1) ? 1 : 0;
@@ -1840,35 +1784,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     TL(7);
     TL_DONE();
-}
-
-template <int D>
-__global__ __launch_bounds__(256) void k_conv_state_load(const float* __restrict__ theta, const float* __restrict__ m,
-                                                         const float* __restrict__ v, float* __restrict__ state) {
-    const int tid = threadIdx.x;
-    if (tid >= 208) return;
-    const int net = tid / 104, i = tid % 104;
-    const int64_t g = (int64_t)net * sml_net_size(D) + i;
-    state[(net * 3 + 0) * 104 + i] = theta[g]; state[(net * 3 + 1) * 104 + i] = m[g]; state[(net * 3 + 2) * 104 + i] = v[g];
-}
-// a pending conv update applied outside a forward (the epoch's last batch; ahead of an empty batch): both nets, one workgroup
-template <int D>
-__global__ __launch_bounds__(512) void k_conv_finalize(SmlConvPending c) {
-    __shared__ __attribute__((aligned(16))) float P[2][SML_CP_RG * SML_CG];
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int net = 0; net < 2; ++net) {
-        const f32x4 acc = conv_partial_rows(c, net, tid);
-        if (tid < SML_CP_RG * SML_CP_C4) *reinterpret_cast<f32x4*>(&P[net][(tid / SML_CP_C4) * SML_CG + (tid % SML_CP_C4) * 4]) = acc;
-    }
-    __syncthreads();
-    if (tid < 208) {
-        const int net = tid / 104, i = tid % 104;
-        float p = c.in[(net * 3 + 0) * 104 + i], m = c.in[(net * 3 + 1) * 104 + i], v = c.in[(net * 3 + 2) * 104 + i];
-        conv_pending_step(c, P[net], i, p, m, v);
-        const int64_t g = (int64_t)net * sml_net_size(D) + i;
-        c.theta[g] = p; c.m[g] = m; c.v[g] = v;
-    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -2000,14 +1915,6 @@ hipError_t sml_launch_bwd(int d, int split, const SmlBwdArgs& a, int tiles_total
         if (a.convg_part != nullptr) { SML_DISPATCH_D(d, k_transfer_bwd_full<DD, 1, true><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }
         else { SML_DISPATCH_D(d, k_transfer_bwd_full<DD, 1, false><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }
     }
-    return hipGetLastError();
-}
-hipError_t sml_launch_conv_state_load(int d, const float* theta, const float* m, const float* v, float* state, hipStream_t st) {
-    SML_DISPATCH_D(d, k_conv_state_load<DD><<<dim3(1), dim3(256), 0, st>>>(theta, m, v, state));
-    return hipGetLastError();
-}
-hipError_t sml_launch_conv_finalize(int d, const SmlConvPending& c, hipStream_t st) {
-    SML_DISPATCH_D(d, k_conv_finalize<DD><<<dim3(1), dim3(512), 0, st>>>(c));
     return hipGetLastError();
 }
 int sml_wgrad_grid(int d);
