@@ -1371,7 +1371,16 @@ def test_two_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run(monkey
         if mode == "peer":
             n_cu = eng._n_cus()
             streams = [eng._masked_stream(0, n_cu // 2), eng._masked_stream(n_cu // 2, n_cu)]
-        results[mode] = run_ranks(2, rank_fn, mode, streams=streams)
+        # (a stalled rank shows where its host thread sits: gpurun_out/two_ranks_stacks_<mode>.txt)
+        import faulthandler
+        out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "two_ranks_stacks_%s.txt" % mode), "w") as fh:
+            faulthandler.dump_traceback_later(10, file=fh)
+            try:
+                results[mode] = run_ranks(2, rank_fn, mode, streams=streams)
+            finally:
+                faulthandler.cancel_dump_traceback_later()
     r0, r1 = results[comm]
     if comm == "peer":                              # one-shot peer exchange == hook path, bit for bit
         for ra, rb in zip(results["torch"], results["peer"]):
