@@ -41,14 +41,21 @@ struct DevGuard {
 // Buffers that were outgrown are NOT freed on the spot: hipFree waits for the whole device, and on a device that
 // another rank's kernel is polling on (peer exchange: a consumer spinning for THIS host thread's next launch) that wait
 // never ends before the poller's time-out.  They are parked here and freed when a context is destroyed.
+// The same holds for destroying a whole context (Python's garbage collector may finalise an old engine on ANY thread,
+// e.g. inside a rank thread whose peer is polling -- found with a stack dump of a stalled thread-rank test): everything a
+// context owns is parked, and the yard is emptied only while no context of the process has peer mappings attached.
 struct Graveyard {
-    std::vector<void*> dead;
+    std::vector<void*> dead, dead_host;
     std::mutex mu;
-    void park(void* p) { std::lock_guard<std::mutex> g(mu); dead.push_back(p); }
+    int peers_live = 0;          // contexts with peer mappings attached (their consumers may be polling on the device)
+    void park(void* p) { if (p) { std::lock_guard<std::mutex> g(mu); dead.push_back(p); } }
+    void park_host(void* p) { if (p) { std::lock_guard<std::mutex> g(mu); dead_host.push_back(p); } }
+    void peers(int delta) { std::lock_guard<std::mutex> g(mu); peers_live += delta; }
     void reap() {
-        std::vector<void*> d;
-        { std::lock_guard<std::mutex> g(mu); d.swap(dead); }
+        std::vector<void*> d, h;
+        { std::lock_guard<std::mutex> g(mu); if (peers_live > 0) return; d.swap(dead); h.swap(dead_host); }
         for (void* p : d) (void)hipFree(p);
+        for (void* p : h) (void)hipHostFree(p);
     }
 } g_graveyard;
 
@@ -65,7 +72,7 @@ struct Buf {
         cap = want;
         return hipSuccess;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { g_graveyard.park(p); p = nullptr; cap = 0; }
 };
 
 bool d_ok(int d) { return d == 32 || d == 64 || d == 128; }
@@ -156,7 +163,7 @@ struct IndexSet {
         rec_u.release(); rec_i.release(); runs_u.release(); runs_i.release();
         uniq.release(); heads_u.release(); heads_i.release(); hot_list.release(); hot_count.release(); off_u.release(); off_i.release(); n_sel.release();
         cub_tmp.release();
-        if (max_len_host) { (void)hipHostFree(max_len_host); max_len_host = nullptr; }
+        if (max_len_host) { g_graveyard.park_host(max_len_host); max_len_host = nullptr; }
         if (ready) { (void)hipEventDestroy(ready); ready = nullptr; }
     }
 };
@@ -210,11 +217,11 @@ struct sml_ctx {
         pk.release(); grad.release(); convg.release(); loss_part.release(); arrive.release();
         ix[0].release(); ix[1].release();
         sched.release(); dummy.release(); rec_x.release();
-        for (auto& r : sched_retired) { if (r.dev) (void)hipFree(r.dev); if (r.host) (void)hipHostFree(r.host); (void)hipEventDestroy(r.done); }
+        for (auto& r : sched_retired) { g_graveyard.park(r.dev); g_graveyard.park_host(r.host); (void)hipEventDestroy(r.done); }
         sched_retired.clear();
         if (sched_ready) { (void)hipEventDestroy(sched_ready); sched_ready = nullptr; }
         hot_first.release(); hot_part.release(); head_part.release(); ptr_tab.release();
-        if (peer.err) { (void)hipFree(peer.err); peer.err = nullptr; }
+        if (peer.err) { g_graveyard.park(peer.err); peer.err = nullptr; }
     }
 };
 
@@ -239,8 +246,8 @@ void sched_reap(sml_ctx* c, bool all) {
     for (size_t i = 0; i < c->sched_retired.size();) {
         SchedRetired& r = c->sched_retired[i];
         if (all || hipEventQuery(r.done) == hipSuccess) {
-            if (r.dev) (void)hipFree(r.dev);
-            if (r.host) (void)hipHostFree(r.host);
+            g_graveyard.park(r.dev);
+            g_graveyard.park_host(r.host);
             (void)hipEventDestroy(r.done);
             c->sched_retired[i] = c->sched_retired.back();
             c->sched_retired.pop_back();
@@ -619,6 +626,7 @@ int sml_ctx_set_variant(sml_ctx* ctx, int variant) {
 int sml_ctx_destroy(sml_ctx* ctx) {
     if (!ctx) return SML_OK;
     (void)sml_comm_destroy(ctx);
+    (void)sml_peer_detach(ctx);
     { DevGuard g(ctx->device); ctx->release_all(); g_graveyard.reap(); }
     delete ctx;
     return SML_OK;
@@ -1432,6 +1440,7 @@ int sml_peer_attach(sml_ctx* ctx, int world, int rank, void* const* inbox, void*
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&ctx->peer.err), sizeof(int)));
         HIPCHK(hipMemset(ctx->peer.err, 0, sizeof(int)));
     }
+    if (ctx->peer.world == 0) g_graveyard.peers(+1);
     ctx->peer.world = world; ctx->peer.rank = rank;
     for (int q = 0; q < SML_MAX_PEERS; ++q) {
         ctx->peer.inbox[q] = q < world ? static_cast<char*>(inbox[q]) : nullptr;
@@ -1447,6 +1456,7 @@ int sml_peer_attach(sml_ctx* ctx, int world, int rank, void* const* inbox, void*
 }
 int sml_peer_detach(sml_ctx* ctx) {
     if (!ctx) return SML_OK;
+    if (ctx->peer.world > 0) g_graveyard.peers(-1);
     ctx->peer.world = 0;
     return SML_OK;
 }
