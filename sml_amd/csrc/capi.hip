@@ -44,9 +44,13 @@ struct DevGuard {
 // The same holds for destroying a whole context (Python's garbage collector may finalise an old engine on ANY thread,
 // e.g. inside a rank thread whose peer is polling -- found with a stack dump of a stalled thread-rank test): everything a
 // context owns is parked, and the yard is emptied only while no context of the process has peer mappings attached.
+struct sml_ctx;
 struct Graveyard {
     std::vector<void*> dead, dead_host;
+    std::vector<sml_ctx*> zombies;   // whole contexts whose destruction (RCCL communicator, events, frees) has to wait
     std::mutex mu;
+    bool defer(sml_ctx* c) { std::lock_guard<std::mutex> g(mu); if (peers_live <= 0) return false; zombies.push_back(c); return true; }
+    std::vector<sml_ctx*> take_zombies() { std::lock_guard<std::mutex> g(mu); std::vector<sml_ctx*> z; if (peers_live <= 0) z.swap(zombies); return z; }
     int peers_live = 0;          // contexts with peer mappings attached (their consumers may be polling on the device)
     void park(void* p) { if (p) { std::lock_guard<std::mutex> g(mu); dead.push_back(p); } }
     void park_host(void* p) { if (p) { std::lock_guard<std::mutex> g(mu); dead_host.push_back(p); } }
@@ -623,12 +627,22 @@ int sml_ctx_set_variant(sml_ctx* ctx, int variant) {
     return SML_OK;
 }
 
+static void ctx_destroy_now(sml_ctx* ctx) {
+    (void)sml_comm_destroy(ctx);
+    { DevGuard g(ctx->device); ctx->release_all(); }
+    delete ctx;
+}
 int sml_ctx_destroy(sml_ctx* ctx) {
     if (!ctx) return SML_OK;
-    (void)sml_comm_destroy(ctx);
     (void)sml_peer_detach(ctx);
-    { DevGuard g(ctx->device); ctx->release_all(); g_graveyard.reap(); }
-    delete ctx;
+    // While ANY context of the process has peer mappings attached, a consumer kernel may be polling on the device for a
+    // launch of some host thread -- possibly the very thread this destructor runs on (Python's garbage collector finalises
+    // old engines wherever it happens to run).  Destroying an RCCL communicator, freeing device or pinned memory all wait
+    // for the device: the context is kept and destroyed with the next one that goes while nobody is attached.
+    if (g_graveyard.defer(ctx)) return SML_OK;
+    ctx_destroy_now(ctx);
+    for (sml_ctx* z : g_graveyard.take_zombies()) ctx_destroy_now(z);
+    g_graveyard.reap();
     return SML_OK;
 }
 
