@@ -44,7 +44,6 @@ struct DevGuard {
 // The same holds for destroying a whole context (Python's garbage collector may finalise an old engine on ANY thread,
 // e.g. inside a rank thread whose peer is polling -- found with a stack dump of a stalled thread-rank test): everything a
 // context owns is parked, and the yard is emptied only while no context of the process has peer mappings attached.
-struct sml_ctx;
 struct Graveyard {
     std::vector<void*> dead, dead_host;
     std::vector<sml_ctx*> zombies;   // whole contexts whose destruction (RCCL communicator, events, frees) has to wait
