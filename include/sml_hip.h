@@ -281,6 +281,11 @@ typedef struct {
 
 int sml_embed_loss_sgd_prepare(sml_ctx* ctx, const int64_t* triples, int64_t n, int batch,
                                int64_t n_user, int64_t n_item, int slot, const sml_bare_exchange* xchg, void* stream);
+/* Test hook: copies one of the prepared lists of `slot` to the host (blocking; the caller has synchronised the
+ * preparation stream).  which: 0/1 run records of users/items (8 x uint32: row, pos, len, pad, slot[4]), 2/3 first run
+ * of each batch, 4/5 runs per batch (-1 per batch when the lists carry nb+1 offsets instead), 6/7 sorted values,
+ * 8 unique marks, 9 hot lists, 10 hot counts, 11 (max run length, hot_cap).  Returns the bytes copied (<= bytes), < 0 on error. */
+int64_t sml_index_lists_read(sml_ctx* ctx, int slot, int which, void* host, int64_t bytes);
 int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n_user,
                              int64_t n_item, int dtype_bytes, const int64_t* triples, int64_t n,
                              int batch, float lr, float lam_user, float lam_item, int loss_kind,

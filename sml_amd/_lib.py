@@ -83,6 +83,7 @@ SIGNATURES = {
                                                         ctypes.POINTER(BareShard), c_void]),
     "sml_embed_loss_adam_epoch": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                                  ctypes.c_float, ctypes.c_int, c_void, c_void, c_void]),
+    "sml_index_lists_read": (ctypes.c_int64, [c_void, ctypes.c_int, ctypes.c_int, c_void, ctypes.c_int64]),
     "sml_embed_loss_sgd_prepare": (ctypes.c_int, [c_void, c_void, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                                   ctypes.c_int, ctypes.POINTER(BareExchange), c_void]),
     "sml_mf_forward": (ctypes.c_int, [c_void, c_void, c_void, c_void, c_void, ctypes.c_int64, ctypes.c_int, c_void,

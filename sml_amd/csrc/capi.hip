@@ -155,6 +155,11 @@ struct IndexSet {
     int hot_cap = 0;                   // 0: the hot-row path is off for this epoch's batch size
     Buf<uint8_t> uniq;
     Buf<int> off_u, off_i, n_sel;
+    // index_prep.hip (the by-hand preparation): tile histograms, bucket offsets / counts, run counts, oversized buckets
+    Buf<uint32_t> hist_u, hist_i, bko_u, bko_i, bkc_u, bkc_i, large;
+    Buf<SmlRun> stage_u, stage_i;      // per-bucket stretches of run records before the compaction
+    Buf<int> cnt_u, cnt_i;
+    bool by_hand = false;              // the lists were built by index_prep.hip: a batch's runs are off[b] .. off[b] + cnt[b]
     Buf<char> cub_tmp;
     int key_bytes = 8, row_bits_u = 32, row_bits_i = 32;
     int* max_len_host = nullptr;       // pinned: longest duplicated run of the prepared epoch (0 if none exceeds SML_HOT)
@@ -164,6 +169,8 @@ struct IndexSet {
         key_u.release(); key_u2.release(); key_i.release(); key_i2.release();
         val_u.release(); val_u2.release(); val_i.release(); val_i2.release();
         rec_u.release(); rec_i.release(); runs_u.release(); runs_i.release();
+        hist_u.release(); hist_i.release(); bko_u.release(); bko_i.release(); bkc_u.release(); bkc_i.release(); large.release();
+        cnt_u.release(); cnt_i.release(); stage_u.release(); stage_i.release();
         uniq.release(); heads_u.release(); heads_i.release(); hot_list.release(); hot_count.release(); off_u.release(); off_i.release(); n_sel.release();
         cub_tmp.release();
         if (max_len_host) { g_graveyard.park_host(max_len_host); max_len_host = nullptr; }
@@ -439,6 +446,93 @@ int sort_pairs(IndexSet* c, int64_t n, int64_t n_items, int end_u, int end_i, hi
     return SML_OK;
 }
 
+// SML_PREP=cub keeps the library sort (A/B tests); default: index_prep.hip
+static bool prep_by_hand() {
+    const char* e = getenv("SML_PREP");          // (read per call: the A/B test flips it inside one process)
+    return !(e && !strcmp(e, "cub"));
+}
+
+// The same lists as sort_epoch below, built by index_prep.hip (one GPU's own occurrences; no library code).
+int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_tiles, int64_t n_user, int64_t n_item,
+               bool dups, hipStream_t st, const sml_batch_plan* plan) {
+    const int64_t nb = plan ? plan->n_batches : (n + batch - 1) / batch;
+    c->by_hand = true;
+    if (n == 0) { c->n = 0; c->batch = batch; c->triples = tri; return SML_OK; }
+    SmlPrepArgs a;
+    memset(&a, 0, sizeof(a));
+    a.tri = tri; a.n = n; a.batch = batch; a.nb = (int)nb; a.tpb = (batch + SML_PREP_TT - 1) / SML_PREP_TT;
+    a.boff = plan ? plan->batch_off_dev : nullptr; a.pad_tiles = pad_tiles; a.records = dups ? 0 : 1;
+    const int64_t ioff_max = pad_tiles ? ((int64_t)(batch + SML_R - 1) / SML_R) * SML_R : batch;
+    int vb[2] = {ceil_log2(batch), ceil_log2(ioff_max + 2 * (int64_t)batch)};      // values: users < batch, items < ioff + 2 * batch
+    int lb[2], rb[2] = {n_user > 0 ? ceil_log2(n_user) : 32, n_item > 0 ? ceil_log2(n_item) : 32};
+    for (int T = 0; T < 2; ++T) {
+        const int64_t max_n = (int64_t)(T ? 2 : 1) * batch;
+        lb[T] = max_n <= SML_PREP_SMALL ? 0 : ceil_log2((max_n + 1023) / 1024);
+        if (lb[T] > 10) lb[T] = 10;
+    }
+    // packed 4-byte entries (row_hi << vb | value) when both tables fit -- more buckets per list buy row bits
+    bool narrow = true;
+    for (int T = 0; T < 2; ++T) if (rb[T] + vb[T] - 32 > 10) narrow = false;
+    if (narrow) { for (int T = 0; T < 2; ++T) if (rb[T] + vb[T] - 32 > lb[T]) lb[T] = rb[T] + vb[T] - 32; }
+    else vb[0] = vb[1] = 32;
+    Buf<uint32_t>* hist[2] = {&c->hist_u, &c->hist_i};
+    Buf<uint32_t>* bko[2] = {&c->bko_u, &c->bko_i};
+    Buf<uint32_t>* bkc[2] = {&c->bkc_u, &c->bkc_i};
+    HIPCHK(c->key_u.ensure((size_t)n + 1)); HIPCHK(c->key_u2.ensure((size_t)n + 1));
+    HIPCHK(c->key_i.ensure((size_t)2 * n + 1)); HIPCHK(c->key_i2.ensure((size_t)2 * n + 1));
+    HIPCHK(c->val_u2.ensure((size_t)n + 1)); HIPCHK(c->val_i2.ensure((size_t)2 * n + 1));
+    HIPCHK(c->n_sel.ensure(4));
+    const size_t large_cap = (size_t)(3 * n / SML_PREP_SMALL) + 8;
+    HIPCHK(c->large.ensure(2 * large_cap));
+    if (dups) {
+        HIPCHK(c->uniq.ensure((size_t)3 * nb * batch));
+        HIPCHK(c->runs_u.ensure((size_t)n / 2 + 8)); HIPCHK(c->runs_i.ensure((size_t)n + 8));
+        HIPCHK(c->stage_u.ensure((size_t)n / 2 + 8)); HIPCHK(c->stage_i.ensure((size_t)n + 8));
+        HIPCHK(c->off_u.ensure((size_t)nb + 1)); HIPCHK(c->off_i.ensure((size_t)nb + 1));
+        HIPCHK(c->cnt_u.ensure((size_t)nb + 1)); HIPCHK(c->cnt_i.ensure((size_t)nb + 1));
+    } else {
+        HIPCHK(c->rec_u.ensure((size_t)n)); HIPCHK(c->rec_i.ensure((size_t)2 * n));
+    }
+    for (int T = 0; T < 2; ++T) {
+        SmlPrepTable& t = a.t[T];
+        t.lb = lb[T]; t.nbk = 1 << lb[T];
+        t.hb = rb[T] > lb[T] ? rb[T] - lb[T] : 0; t.vb = vb[T];
+        t.npass = (t.hb + 8) / 9; t.pbits = t.npass ? (t.hb + t.npass - 1) / t.npass : 0;
+        HIPCHK(hist[T]->ensure((size_t)nb * (T ? 2 : 1) * a.tpb * t.nbk));
+        HIPCHK(bko[T]->ensure((size_t)2 * nb * t.nbk)); HIPCHK(bkc[T]->ensure((size_t)nb * t.nbk));
+        t.hist = hist[T]->p; t.bk = reinterpret_cast<uint2*>(bko[T]->p); t.brc = dups ? bkc[T]->p : nullptr;
+        t.ent = T ? (void*)c->key_i.p : (void*)c->key_u.p; t.ent2 = T ? (void*)c->key_i2.p : (void*)c->key_u2.p;
+        t.vals = T ? c->val_i2.p : c->val_u2.p;
+        if (dups) { t.runs_tmp = T ? c->stage_i.p : c->stage_u.p; t.runs = T ? c->runs_i.p : c->runs_u.p; t.run_off = T ? c->off_i.p : c->off_u.p; t.run_cnt = T ? c->cnt_i.p : c->cnt_u.p; }
+        else t.runs = T ? c->rec_i.p : c->rec_u.p;
+    }
+    a.large = c->large.p; a.n_large = c->n_sel.p + 3; a.large_cap = (int)large_cap;
+    HIPCHK(hipMemsetAsync(c->n_sel.p, 0, 4 * sizeof(int), st));
+    c->hot_cap = 0;
+    if (dups) {
+        a.uniq = c->uniq.p; a.uniq_stride = (int64_t)3 * batch; a.max_len = c->n_sel.p + 2;
+        HIPCHK(hipMemsetAsync(c->uniq.p, 1, (size_t)3 * nb * batch, st));
+        const int64_t hot_cap64 = ((int64_t)batch + 2 * (int64_t)batch) / SML_HOT + 8;
+        const int hot_cap = (int)(hot_cap64 < 0x7fffffff ? hot_cap64 : 0x7fffffff);
+        c->hot_cap = (batch >= 4096 && hot_cap <= SML_HOT_MAXCAP) ? hot_cap : 0;
+        if (c->hot_cap) {
+            HIPCHK(c->hot_list.ensure((size_t)nb * c->hot_cap * 3)); HIPCHK(c->hot_count.ensure((size_t)nb));
+            a.hot_list = c->hot_list.p; a.hot_count = c->hot_count.p; a.hot_cap = c->hot_cap;
+        }
+    }
+    { const char* e = getenv("SML_PREP_DEBUG"); a.debug = e ? atoi(e) : 0; }
+    if (a.debug == 4) for (int T = 0; T < 2; ++T) if (a.t[T].hb > 0) { a.t[T].npass = (a.t[T].hb + 4) / 5; a.t[T].pbits = (a.t[T].hb + a.t[T].npass - 1) / a.t[T].npass; }
+    HIPCHK(sml_launch_prep(a, narrow ? 4 : 8, st));
+    if (dups) {
+        if (!c->max_len_host) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->max_len_host), sizeof(int), hipHostMallocDefault));
+        if (!c->ready) HIPCHK(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
+        HIPCHK(hipMemcpyAsync(c->max_len_host, c->n_sel.p + 2, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipEventRecord(c->ready, st));
+    }
+    c->n = n; c->batch = batch; c->triples = tri; c->world = 1;
+    return SML_OK;
+}
+
 // sort every batch's occurrences by row (stable): users [n], items [2n]; then one run record per
 // sorted position.  n_user / n_item (0: unknown) bound the row index so the keys can be 32-bit.
 // With `dups` the duplicated runs are also compacted (stable) with their per-batch ranges, and every
@@ -446,6 +540,8 @@ int sort_pairs(IndexSet* c, int64_t n, int64_t n_items, int end_u, int end_i, hi
 int sort_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_tiles, int64_t n_user, int64_t n_item,
                bool dups, hipStream_t st, const sml_batch_plan* plan = nullptr, const sml_bare_exchange* bx = nullptr) {
     // bx (bare step on several GPUs): the item lists are the JOB's -- every rank's 2n item occurrences
+    if (!bx && prep_by_hand()) return prep_epoch(c, tri, n, batch, pad_tiles, n_user, n_item, dups, st, plan);
+    c->by_hand = false;
     const int64_t n_items = bx ? (int64_t)bx->world * 2 * n : 2 * n;
     const int64_t seg_i = bx ? (int64_t)bx->world * 2 * batch : (int64_t)2 * batch;       // item occurrences of a full batch
     if (n_items > 0x7fffffff) return fail(SML_EINVAL, "index preparation", "too many item occurrences in one epoch");
@@ -1044,6 +1140,33 @@ int sml_embed_loss_sgd_prepare(sml_ctx* ctx, const int64_t* triples, int64_t n, 
     return sort_epoch(&ctx->ix[slot], triples, n, batch, 0, n_user, n_item, true, (hipStream_t)stream, nullptr, xchg);
 }
 
+int64_t sml_index_lists_read(sml_ctx* ctx, int slot, int which, void* host, int64_t bytes) {
+    if (!ctx || (slot != 0 && slot != 1) || !host || bytes < 0) return fail(SML_EINVAL, "sml_index_lists_read", "bad argument");
+    DevGuard g(ctx->device);
+    IndexSet* X = &ctx->ix[slot];
+    const int64_t nb = X->batch > 0 ? (X->n + X->batch - 1) / X->batch : 0;
+    const void* src = nullptr; int64_t have = 0;
+    int two[2] = {0, X->hot_cap};
+    switch (which) {
+        case 0: src = X->runs_u.p; have = (int64_t)X->runs_u.cap * sizeof(SmlRun); break;
+        case 1: src = X->runs_i.p; have = (int64_t)X->runs_i.cap * sizeof(SmlRun); break;
+        case 2: src = X->off_u.p; have = (nb + 1) * 4; break;
+        case 3: src = X->off_i.p; have = (nb + 1) * 4; break;
+        case 4: src = X->by_hand ? X->cnt_u.p : nullptr; have = X->by_hand ? nb * 4 : 0; break;
+        case 5: src = X->by_hand ? X->cnt_i.p : nullptr; have = X->by_hand ? nb * 4 : 0; break;
+        case 6: src = X->val_u2.p; have = X->n * 4; break;
+        case 7: src = X->val_i2.p; have = 2 * X->n * 4; break;
+        case 8: src = X->uniq.p; have = 3 * nb * X->batch; break;
+        case 9: src = X->hot_list.p; have = X->hot_cap ? nb * X->hot_cap * 12 : 0; break;
+        case 10: src = X->hot_count.p; have = X->hot_cap ? nb * 4 : 0; break;
+        case 11: HIPCHK(hipMemcpy(two, X->n_sel.p + 2, 4, hipMemcpyDeviceToHost)); memcpy(host, two, bytes < 8 ? bytes : 8); return bytes < 8 ? bytes : 8;
+        default: return fail(SML_EINVAL, "sml_index_lists_read", "which");
+    }
+    const int64_t nbytes = have < bytes ? have : bytes;
+    if (nbytes > 0 && src) HIPCHK(hipMemcpy(host, src, (size_t)nbytes, hipMemcpyDeviceToHost));
+    return src ? nbytes : 0;
+}
+
 int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n_user, int64_t n_item, int dtype_bytes,
                              const int64_t* triples, int64_t n, int batch, float lr, float lam_user, float lam_item,
                              int loss_kind, float* batch_loss, int prepared_slot, const sml_bare_exchange* xchg, void* stream) {
@@ -1110,6 +1233,7 @@ int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n
         // stride over it (how many runs a batch has is only known on the device)
         u.run_u = X->runs_u.p; u.run_i = X->runs_i.p; u.off_u = X->off_u.p; u.off_i = X->off_i.p; u.batch_index = (int)b;
         u.val_u = X->val_u2.p; u.val_i = X->val_i2.p;
+        if (X->by_hand) { u.cnt_u = X->cnt_u.p; u.cnt_i = X->cnt_i.p; }
         u.dx = dxb; u.dx_i = xchg ? xchg->dx_items_all : dxb; u.w_user = w_user; u.w_item = w_item; u.lr = lr;
         if (hot) {
             u.hot_list = X->hot_list.p + (size_t)b * hot_cap * 3; u.hot_count = X->hot_count.p + b; u.hot_first = ctx->hot_first.p;

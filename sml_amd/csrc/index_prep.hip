@@ -1,0 +1,601 @@
+// Index preparation of an epoch, by hand (replaces the library radix sort + select + four helper kernels).
+//
+// What the step kernels need, per batch b and table (users / items) -- a "list" of N occurrences (row, value):
+//   * for every row that occurs more than once: its values (slots) in ascending occurrence order, contiguous in `vals`,
+//     and one SmlRun record (row, first position, length, first slots);
+//   * for every occurrence: the "row occurs once in this batch" mark (bare step), or one record per sorted position
+//     (MF stage);
+//   * the batch's list of hot runs (longer than SML_HOT).
+// Semantics of the reference path this serves: torch's sparse-gradient embedding update, model/baseline.py:188-201
+// (duplicate indices of a batch are summed before the step).
+//
+// Algorithm.  The batch is implicit in the position, so nothing is sorted across batches:
+//   k_prep_hist     tile histograms of the bucket id (row & (nbk-1)) -- the triples are read once for all three columns;
+//   k_prep_scan     per list: bucket offsets, the tiles' first positions per bucket, the list of oversized buckets;
+//   k_prep_scatter  stable partition: every occurrence goes to its bucket as ONE packed entry (row_hi << vb | value),
+//                   in occurrence order (ranks by wavefront ballots, no atomics: the order is a function of the input);
+//   k_prep_bucket   one workgroup per bucket: the entries are sorted by row_hi in LDS (stable radix passes of <= 9 bits),
+//                   runs are read off the sorted bucket and the outputs leave directly;
+//   k_prep_large    buckets above SML_PREP_SMALL entries (a row with thousands of occurrences): the same passes through
+//                   global memory, chunk by chunk;
+//   k_prep_compact  (bare step) the buckets' run records, written to per-bucket stretches, become one list per batch.
+// No atomics on shared counters anywhere on the path of every occurrence (one per oversized bucket, one per hot run).
+// HBM traffic per triple: 24 B (triples) x 2 + 12 B written + 12 B read + marks / records of duplicated rows -- against
+// 4 radix passes over 8-byte pairs per table before.  Occurrences of one row always meet in one bucket; buckets are cut
+// by the LOW row bits so that a popular block of neighbouring ids spreads over all of them.
+#include "sml_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ uint64_t lanes_below() { return (1ull << (threadIdx.x & 63)) - 1ull; }
+
+// lanes (among the valid ones) holding the same `key` in its low `bits` bits
+__device__ __forceinline__ uint64_t match_any(uint32_t key, bool valid, int bits) {
+    uint64_t m = __ballot(valid);
+    for (int b = 0; b < bits; ++b) {
+        const bool bit = (key >> b) & 1u;
+        const uint64_t bb = __ballot(bit);
+        m &= bit ? bb : ~bb;
+    }
+    return m;
+}
+
+// One round of the stable in-wavefront ranking: the wavefront's counter row `cnt` holds, per key, the occurrences of
+// earlier rounds; returns this occurrence's rank among the wavefront's equal keys so far.
+__device__ __forceinline__ uint32_t wave_rank(unsigned short* cnt, uint32_t key, bool valid, int bits) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t m = match_any(key, valid, bits);
+    const int leader = valid ? (__ffsll((long long)m) - 1) : lane;
+    uint32_t prev = 0;
+    if (valid && lane == leader) { prev = cnt[key]; cnt[key] = (unsigned short)(prev + __popcll(m)); }
+    prev = (uint32_t)__shfl((int)prev, leader, 64);
+    return prev + (uint32_t)__popcll(m & lanes_below());
+}
+
+struct BatchGeo { int64_t start; int Bb; uint32_t ioff; };
+__device__ __forceinline__ BatchGeo batch_geo(const SmlPrepArgs& a, int b) {
+    BatchGeo g;
+    if (a.boff != nullptr) { g.start = a.boff[b]; g.Bb = a.boff[b + 1] - a.boff[b]; }
+    else { g.start = (int64_t)b * a.batch; const int64_t rem = a.n - g.start; g.Bb = (int)(rem < a.batch ? rem : a.batch); }
+    g.ioff = a.pad_tiles ? (uint32_t)((g.Bb + SML_R - 1) / SML_R) * SML_R : (uint32_t)g.Bb;
+    return g;
+}
+
+// ------------------------------------------------------------------------------------
+// k_prep_hist: grid (tpb, nb), 1024 threads, SML_PREP_IPT triples per thread.
+// Streams of a tile: 0 = users, 1 = positives, 2 = negatives (the item list's order is positives then negatives, so the
+// two halves are separate tiles of that list: half * tpb + k).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_prep_hist(SmlPrepArgs a) {
+    __shared__ uint32_t h[3][SML_PREP_MAXBK];
+    const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const BatchGeo g = batch_geo(a, b);
+    const int nbu = a.t[0].nbk, nbi = a.t[1].nbk;
+    for (int i = tid; i < 3 * SML_PREP_MAXBK; i += 1024) (&h[0][0])[i] = 0u;
+    __syncthreads();
+    const int t0 = k * SML_PREP_TT + (tid >> 6) * (64 * SML_PREP_IPT) + (tid & 63);
+#pragma unroll
+    for (int r = 0; r < SML_PREP_IPT; ++r) {
+        const int t = t0 + r * 64;
+        const bool valid = t < g.Bb;
+        uint32_t ru = 0, rp = 0, rn = 0;
+        if (valid) {
+            const int64_t* p = a.tri + (g.start + t) * 3;
+            ru = (uint32_t)p[0]; rp = (uint32_t)p[1]; rn = (uint32_t)p[2];
+        }
+        // (a list that is one bucket: one add per wavefront instead of 64 on one address)
+        if (nbu == 1) { const uint64_t m = __ballot(valid); if ((tid & 63) == 0 && m) atomicAdd(&h[0][0], (uint32_t)__popcll(m)); }
+        else if (valid) atomicAdd(&h[0][ru & (nbu - 1)], 1u);
+        if (nbi == 1) { const uint64_t m = __ballot(valid); if ((tid & 63) == 0 && m) { atomicAdd(&h[1][0], (uint32_t)__popcll(m)); atomicAdd(&h[2][0], (uint32_t)__popcll(m)); } }
+        else if (valid) { atomicAdd(&h[1][rp & (nbi - 1)], 1u); atomicAdd(&h[2][rn & (nbi - 1)], 1u); }
+    }
+    __syncthreads();
+    uint32_t* hu = a.t[0].hist + ((int64_t)b * a.tpb + k) * nbu;
+    for (int i = tid; i < nbu; i += 1024) hu[i] = h[0][i];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        uint32_t* hi = a.t[1].hist + (((int64_t)b * 2 + half) * a.tpb + k) * nbi;
+        for (int i = tid; i < nbi; i += 1024) hi[i] = h[1 + half][i];
+    }
+}
+
+// exclusive scan of one value per thread over a 1024-thread block (wave shuffles + 16 wave totals)
+__device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* wsum /*[17]*/) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, off, 64); if (lane >= off) inc += t; }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int j = 0; j < w; ++j) before += wsum[j];
+    __syncthreads();
+    return before + inc - v;
+}
+
+// ------------------------------------------------------------------------------------
+// k_prep_scan: grid (nb, 2): one workgroup per list.  hist[k][bin] becomes the position (in the table's occurrence
+// array) where tile k's first occurrence of that bucket goes.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_prep_scan(SmlPrepArgs a) {
+    __shared__ uint32_t wsum[17];
+    const int b = blockIdx.x, T = blockIdx.y, tid = threadIdx.x;
+    const SmlPrepTable& tb = a.t[T];
+    const BatchGeo g = batch_geo(a, b);
+    const int nbk = tb.nbk, ntile = T ? 2 * a.tpb : a.tpb;
+    const int64_t list_start = T ? 2 * g.start : g.start;
+    uint32_t* H = tb.hist + (int64_t)b * ntile * nbk;
+    uint32_t tot = 0;
+    if (tid < nbk) {
+#pragma unroll 8
+        for (int k = 0; k < ntile; ++k) tot += H[(int64_t)k * nbk + tid];
+    }
+    const uint32_t off = block_excl_scan_1024(tot, wsum);
+    if (tid < nbk) {
+        tb.bk[(int64_t)b * nbk + tid] = make_uint2(off, tot);
+        uint32_t run = (uint32_t)list_start + off;
+#pragma unroll 8
+        for (int k = 0; k < ntile; ++k) { const uint32_t c = H[(int64_t)k * nbk + tid]; H[(int64_t)k * nbk + tid] = run; run += c; }
+        if (tot > SML_PREP_SMALL) {
+            const int slot = atomicAdd(a.n_large, 1);
+            if (slot < a.large_cap) { a.large[2 * slot] = ((uint32_t)T << 31) | (uint32_t)b; a.large[2 * slot + 1] = (uint32_t)tid; }
+        }
+    }
+    if (tid == 0) {
+        if (tb.run_off != nullptr) tb.run_off[b] = (int)(list_start / 2);
+        if (T == 0 && a.hot_count != nullptr) a.hot_count[b] = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_prep_scatter: same grid as k_prep_hist.  Occurrence order inside a tile: wavefront-major, then round, then lane --
+// i.e. ascending triple index; the wavefronts' counts per bucket are prefixed in wavefront order.
+// ------------------------------------------------------------------------------------
+template <typename E>
+__global__ __launch_bounds__(1024) void k_prep_scatter(SmlPrepArgs a) {
+    __shared__ unsigned short cnt[16][SML_PREP_MAXBK];
+    __shared__ uint32_t tbase[SML_PREP_MAXBK];
+    const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, wv = tid >> 6;
+    const BatchGeo g = batch_geo(a, b);
+    if (k * SML_PREP_TT >= g.Bb) return;
+    constexpr int IPT = SML_PREP_IPT;
+    uint32_t row[3][IPT];
+    const int t0 = k * SML_PREP_TT + wv * (64 * IPT) + (tid & 63);
+#pragma unroll
+    for (int r = 0; r < IPT; ++r) {
+        const int t = t0 + r * 64;
+        if (t < g.Bb) {
+            const int64_t* p = a.tri + (g.start + t) * 3;
+            row[0][r] = (uint32_t)p[0]; row[1][r] = (uint32_t)p[1]; row[2][r] = (uint32_t)p[2];
+        } else { row[0][r] = row[1][r] = row[2][r] = 0u; }
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const SmlPrepTable& tb = a.t[s ? 1 : 0];
+        const int nbk = tb.nbk, lb = tb.lb;
+        const uint32_t* base = s == 0 ? tb.hist + ((int64_t)b * a.tpb + k) * nbk
+                                      : tb.hist + (((int64_t)b * 2 + (s - 1)) * a.tpb + k) * nbk;
+        if (s) __syncthreads();                         // the previous stream's readers of cnt / tbase are done
+        for (int i = tid; i < 16 * nbk; i += 1024) cnt[i >> lb][i & (nbk - 1)] = 0;
+        for (int i = tid; i < nbk; i += 1024) tbase[i] = base[i];
+        __syncthreads();
+        uint32_t wr[IPT];
+#pragma unroll
+        for (int r = 0; r < IPT; ++r) wr[r] = wave_rank(cnt[wv], row[s][r] & (uint32_t)(nbk - 1), t0 + r * 64 < g.Bb, lb);
+        __syncthreads();
+        for (int i = tid; i < nbk; i += 1024) {
+            uint32_t run = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) { const uint32_t c = cnt[w][i]; cnt[w][i] = (unsigned short)run; run += c; }
+        }
+        __syncthreads();
+        E* ent = reinterpret_cast<E*>(tb.ent);
+        const uint32_t vbase = s == 0 ? 0u : (s == 1 ? g.ioff : g.ioff + (uint32_t)g.Bb);
+#pragma unroll
+        for (int r = 0; r < IPT; ++r) {
+            const int t = t0 + r * 64;
+            if (t < g.Bb) {
+                const uint32_t bin = row[s][r] & (uint32_t)(nbk - 1);
+                const uint32_t dest = tbase[bin] + cnt[wv][bin] + wr[r];
+                const E hi = (E)(row[s][r] >> lb);
+                ent[dest] = sizeof(E) == 8 ? (E)(((uint64_t)hi << 32) | (uint64_t)(vbase + (uint32_t)t))
+                                           : (E)((hi << tb.vb) | (E)(vbase + (uint32_t)t));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// What leaves a sorted bucket.  `get(q)` reads sorted entry q of the bucket (LDS or global), S entries, `pos0` = the
+// bucket's first position in the table's occurrence array.
+// ------------------------------------------------------------------------------------
+template <typename E>
+__device__ __forceinline__ uint32_t ent_hi(E e, int vb) { return sizeof(E) == 8 ? (uint32_t)((uint64_t)e >> 32) : (uint32_t)(e >> vb); }
+template <typename E>
+__device__ __forceinline__ uint32_t ent_val(E e, int vb) { return sizeof(E) == 8 ? (uint32_t)e : (uint32_t)(e & (((E)1 << vb) - 1)); }
+
+template <typename E, int NT, typename Get>
+__device__ __forceinline__ uint32_t emit_bucket(const SmlPrepArgs& a, const SmlPrepTable& tb, int T, int b, uint32_t bin, uint32_t pos0, int S,
+                                                Get get, uint32_t* scratch /*[NT/64]*/) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int vb = tb.vb;
+    uint8_t* uniq = a.uniq ? a.uniq + (int64_t)b * a.uniq_stride : nullptr;
+    // compact mode: the bucket's records go to ITS stretch of the staging array (a bucket of S occurrences has at most
+    // S/2 duplicated runs, and floor(pos0/2) + floor(S/2) <= floor((pos0+S)/2): the stretches do not overlap), in
+    // position order -- no counter is shared between workgroups; k_prep_compact closes the gaps.
+    SmlRun* out = a.records ? tb.runs : tb.runs_tmp + (pos0 >> 1);
+    uint32_t done = 0;                                            // compact records of earlier trips (block-uniform)
+#pragma unroll 1
+    for (int q0 = 0; q0 < S; q0 += NT) {                          // block-uniform trip count
+        const int q = q0 + tid;
+        const bool in = q < S;
+        E e = 0; uint32_t rh = 0, prev = 0, next = 0;
+        if (in) {
+            e = get(q); rh = ent_hi<E>(e, vb);
+            prev = q > 0 ? ent_hi<E>(get(q - 1), vb) : ~rh;
+            next = q + 1 < S ? ent_hi<E>(get(q + 1), vb) : ~rh;
+        }
+        const bool head = in && prev != rh, tail = in && next != rh;
+        const bool dup = in && !(head && tail);
+        const uint32_t val = ent_val<E>(e, vb);
+        if (a.records) {
+            if (in) tb.vals[pos0 + q] = val;
+        } else if (dup) {
+            tb.vals[pos0 + q] = val;
+            if (uniq) uniq[val] = 0;
+        }
+        // the run's record is written by its LAST occurrence, which looks its first one up in the sorted bucket
+        int hq = q, len = 0;
+        if (tail) {
+            if (!head) {
+                int back = 1;
+                while (back <= 4 && q - back >= 0 && ent_hi<E>(get(q - back), vb) == rh) ++back;
+                if (back <= 4) hq = q - back + 1;
+                else {                                            // lower bound of rh in [0, q - 4]
+                    int lo = 0, hi2 = q - 4;
+                    while (lo < hi2) { const int mid = (lo + hi2) >> 1; if (ent_hi<E>(get(mid), vb) < rh) lo = mid + 1; else hi2 = mid; }
+                    hq = lo;
+                }
+            }
+            len = q - hq + 1;
+        }
+        const bool want = a.records ? tail : (tail && len >= 2);
+        uint32_t idx;
+        if (!a.records) {
+            const uint64_t wm = __ballot(want);
+            if (lane == 0) scratch[wv] = (uint32_t)__popcll(wm);
+            __syncthreads();
+            uint32_t before = 0, tot = 0;
+#pragma unroll
+            for (int j = 0; j < NT / 64; ++j) { const uint32_t c = scratch[j]; before += j < wv ? c : 0u; tot += c; }
+            idx = done + before + (uint32_t)__popcll(wm & lanes_below());
+            done += tot;
+            __syncthreads();
+        } else {
+            idx = pos0 + (uint32_t)hq;
+            if (in && !head) {                                     // a position inside a run: an empty record
+                SmlRun z; z.row = (rh << tb.lb) | bin; z.pos = pos0 + (uint32_t)q; z.len = 0; z.pad = 0;
+#pragma unroll
+                for (int j = 0; j < SML_RUN_INL; ++j) z.slot[j] = 0u;
+                out[pos0 + q] = z;
+            }
+        }
+        if (want) {
+            SmlRun r;
+            r.row = (rh << tb.lb) | bin; r.pos = pos0 + (uint32_t)hq; r.len = (uint32_t)len; r.pad = 0;
+#pragma unroll
+            for (int j = 0; j < SML_RUN_INL; ++j) r.slot[j] = j < len ? ent_val<E>(get(hq + j), vb) : 0u;
+            out[idx] = r;
+            if (!a.records && len > SML_HOT) {
+                atomicMax(a.max_len, len);
+                if (a.hot_list != nullptr) {
+                    const int slot = atomicAdd(a.hot_count + b, 1);
+                    if (slot < a.hot_cap) {
+                        uint32_t* h = a.hot_list + ((int64_t)b * a.hot_cap + slot) * 3;
+                        h[0] = r.pos | ((uint32_t)T << 31); h[1] = (uint32_t)len; h[2] = r.row;
+                    }
+                }
+            }
+        }
+    }
+    return done;
+}
+
+// ------------------------------------------------------------------------------------
+// k_prep_bucket: grid (nb * nbk, 2), 256 threads; buckets of at most SML_PREP_SMALL entries.
+// ------------------------------------------------------------------------------------
+template <typename E>
+__global__ __launch_bounds__(256, sizeof(E) == 4 ? 7 : 4) void k_prep_bucket(SmlPrepArgs a) {
+    __shared__ E buf[2][SML_PREP_SMALL];
+    __shared__ unsigned short cnt[4][512];
+    __shared__ uint32_t dbase[512];
+    __shared__ uint32_t scratch[8];
+    const int T = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const SmlPrepTable& tb = a.t[T];
+    const int b = (int)(blockIdx.x >> tb.lb);
+    const uint32_t bin = blockIdx.x & (uint32_t)(tb.nbk - 1);
+    if (b >= a.nb) return;
+    const uint2 oc = tb.bk[(int64_t)b * tb.nbk + bin];             // (first position inside the list, entries)
+    int S = (int)oc.y;
+    if (S == 0 && tid == 0 && tb.brc != nullptr) tb.brc[(int64_t)b * tb.nbk + bin] = 0u;
+    if (S == 0 || S > SML_PREP_SMALL) return;
+    const BatchGeo g = batch_geo(a, b);
+    const uint32_t pos0 = (uint32_t)(T ? 2 * g.start : g.start) + oc.x;
+    const E* src = reinterpret_cast<const E*>(tb.ent) + pos0;
+    if (a.records || a.debug == 3) {
+        for (int i = tid; i < S; i += 256) buf[0][i] = src[i];
+    } else {
+        // Duplicate filter: only occurrences of rows that occur at least twice need sorting (with uniform users that is
+        // 3 % of them).  Two bitmaps over row_hi (hashed to 15 bits when it is wider: false positives only cost sorting
+        // work): "seen" and "seen again"; the candidates are then compacted in occurrence order.
+        uint32_t (*bm)[1024] = reinterpret_cast<uint32_t (*)[1024]>(&buf[1][0]);     // (the second buffer is idle until the sort)
+        const int R0 = (S + 255) >> 8;
+        const uint32_t hmask = (1u << min(tb.hb, 15)) - 1u;
+        E e0[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int i = wv * (R0 * 64) + r * 64 + lane;
+            e0[r] = (r < R0 && i < S) ? src[i] : (E)0;
+        }
+        for (int i = tid; i < 2048; i += 256) (&bm[0][0])[i] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int i = wv * (R0 * 64) + r * 64 + lane;
+            if (r < R0 && i < S) {
+                const uint32_t h = ent_hi<E>(e0[r], tb.vb) & hmask, bit = 1u << (h & 31);
+                const uint32_t old = atomicOr(&bm[0][h >> 5], bit);
+                if (old & bit) atomicOr(&bm[1][h >> 5], bit);
+            }
+        }
+        __syncthreads();
+        uint32_t wtot = 0, lidx[8];
+        bool isd[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            isd[r] = false; lidx[r] = 0;
+            if (r < R0) {
+                const int i = wv * (R0 * 64) + r * 64 + lane;
+                const uint32_t h = ent_hi<E>(e0[r], tb.vb) & hmask;
+                isd[r] = i < S && ((bm[1][h >> 5] >> (h & 31)) & 1u);
+                const uint64_t m = __ballot(isd[r]);
+                lidx[r] = wtot + (uint32_t)__popcll(m & lanes_below());
+                wtot += (uint32_t)__popcll(m);
+            }
+        }
+        if (lane == 0) scratch[wv] = wtot;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const uint32_t c = scratch[j]; before += j < wv ? c : 0u; total += c; }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) if (isd[r]) buf[0][before + lidx[r]] = e0[r];
+        S = (int)total;
+        if (S == 0) { if (tid == 0) tb.brc[(int64_t)b * tb.nbk + bin] = 0u; return; }
+    }
+    if (a.debug == 1) { __syncthreads(); if (tid == 0) tb.vals[pos0] = (uint32_t)buf[0][S - 1]; return; }
+    int cur = 0;
+    const int R = (S + 255) >> 8;                     // rounds: every wavefront owns a contiguous stripe of R * 64 entries
+    if (S <= 64 && tb.npass > 0) {
+        // a handful of entries: the first wavefront ranks them against each other (stable: equal keys by position)
+        __syncthreads();
+        if (wv == 0) {
+            const E e = lane < S ? buf[0][lane] : (E)0;
+            const uint32_t key = ent_hi<E>(e, tb.vb);
+            uint32_t rank = 0;
+            for (int j = 0; j < S; ++j) {
+                const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)key, j);
+                rank += (kj < key || (kj == key && j < lane)) ? 1u : 0u;
+            }
+            if (lane < S) buf[1][rank] = e;
+        }
+        cur = 1;
+    } else
+    for (int p = 0; p < tb.npass; ++p) {
+        const int lo = p * tb.pbits, bits = min(tb.pbits, tb.hb - lo), nd = 1 << bits;
+        // every wavefront clears ITS counter row: a slower wavefront may still be reading its own row for the previous
+        // pass's scatter (the rows of others are only touched between the two barriers below)
+        for (int i = lane; i < nd; i += 64) cnt[wv][i] = 0;
+        __syncthreads();                                 // (also: the bucket is loaded / the previous pass has landed)
+        E ev[8]; uint32_t wr[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (r < R) {
+                const int i = wv * (R * 64) + r * 64 + lane;
+                const bool valid = i < S;
+                ev[r] = valid ? buf[cur][i] : (E)0;
+                const uint32_t dg = (ent_hi<E>(ev[r], tb.vb) >> lo) & (uint32_t)(nd - 1);
+                wr[r] = wave_rank(cnt[wv], dg, valid, bits);
+            }
+        }
+        __syncthreads();
+        // per digit: the wavefronts' counts become their prefix; the digit totals are scanned over the block
+        {
+            uint32_t tot2[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int dgt = 2 * tid + j;
+                uint32_t run = 0;
+                if (dgt < nd) {
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) { const uint32_t c = cnt[w][dgt]; cnt[w][dgt] = (unsigned short)run; run += c; }
+                }
+                tot2[j] = run;
+            }
+            uint32_t inc = tot2[0] + tot2[1];
+            const uint32_t mine = inc;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, off, 64); if (lane >= off) inc += t; }
+            if (lane == 63) scratch[wv] = inc;
+            __syncthreads();
+            uint32_t before = 0;
+            for (int j = 0; j < wv; ++j) before += scratch[j];
+            const uint32_t ex = before + inc - mine;
+            if (2 * tid < nd) dbase[2 * tid] = ex;
+            if (2 * tid + 1 < nd) dbase[2 * tid + 1] = ex + tot2[0];
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (r < R) {
+                const int i = wv * (R * 64) + r * 64 + lane;
+                if (i < S) {
+                    const uint32_t dg = (ent_hi<E>(ev[r], tb.vb) >> lo) & (uint32_t)(nd - 1);
+                    buf[cur ^ 1][dbase[dg] + cnt[wv][dg] + wr[r]] = ev[r];
+                }
+            }
+        }
+        cur ^= 1;
+    }
+    __syncthreads();
+    const E* sorted = buf[cur];
+    if (a.debug == 2) { if (tid == 0) tb.vals[pos0] = (uint32_t)sorted[S - 1]; return; }
+    const uint32_t nrec = emit_bucket<E, 256>(a, tb, T, b, bin, pos0, S, [&](int q) { return sorted[q]; }, scratch);
+    if (tid == 0 && tb.brc != nullptr) tb.brc[(int64_t)b * tb.nbk + bin] = nrec;
+}
+
+// ------------------------------------------------------------------------------------
+// k_prep_large: the oversized buckets, one 1024-thread workgroup each (grid-stride over the list k_prep_scan built).
+// The same stable passes, 4096 entries at a time, between the two entry arrays.
+// ------------------------------------------------------------------------------------
+template <typename E>
+__global__ __launch_bounds__(1024) void k_prep_large(SmlPrepArgs a) {
+    __shared__ unsigned short cnt[16][512];
+    __shared__ uint32_t dbase[512];
+    __shared__ uint32_t wsum[17];
+    __shared__ uint32_t scratch[18];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n_large = min(*a.n_large, a.large_cap);
+    for (int w = blockIdx.x; w < n_large; w += gridDim.x) {
+        const uint32_t tl = a.large[2 * w], bin = a.large[2 * w + 1];
+        const int T = (int)(tl >> 31), b = (int)(tl & 0x7fffffffu);
+        const SmlPrepTable& tb = a.t[T];
+        const uint2 oc = tb.bk[(int64_t)b * tb.nbk + bin];
+        const int S = (int)oc.y;
+        const BatchGeo g = batch_geo(a, b);
+        const uint32_t pos0 = (uint32_t)(T ? 2 * g.start : g.start) + oc.x;
+        E* src = reinterpret_cast<E*>(tb.ent) + pos0;
+        E* dst = reinterpret_cast<E*>(tb.ent2) + pos0;
+        for (int p = 0; p < tb.npass; ++p) {
+            const int lo = p * tb.pbits, bits = min(tb.pbits, tb.hb - lo), nd = 1 << bits;
+            __syncthreads();
+            if (tid < 512) dbase[tid] = 0;
+            __syncthreads();
+            for (int c0 = 0; c0 < S; c0 += 4096) {                 // digit totals (one LDS atomic per group of equal lanes)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = c0 + wv * 256 + r * 64 + lane;
+                    const bool valid = i < S;
+                    const uint32_t dg = valid ? (ent_hi<E>(src[i], tb.vb) >> lo) & (uint32_t)(nd - 1) : 0u;
+                    const uint64_t m = match_any(dg, valid, bits);
+                    if (valid && lane == __ffsll((long long)m) - 1) atomicAdd(&dbase[dg], (uint32_t)__popcll(m));
+                }
+            }
+            __syncthreads();
+            {
+                const uint32_t v = tid < nd ? dbase[tid] : 0u;
+                const uint32_t ex = block_excl_scan_1024(v, wsum);
+                if (tid < nd) dbase[tid] = ex;
+            }
+            __syncthreads();
+            for (int c0 = 0; c0 < S; c0 += 4096) {
+                for (int i = tid; i < 16 * nd; i += 1024) cnt[i / nd][i % nd] = 0;
+                __syncthreads();
+                E ev[4]; uint32_t wr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = c0 + wv * 256 + r * 64 + lane;
+                    const bool valid = i < S;
+                    ev[r] = valid ? src[i] : (E)0;
+                    wr[r] = wave_rank(cnt[wv], (ent_hi<E>(ev[r], tb.vb) >> lo) & (uint32_t)(nd - 1), valid, bits);
+                }
+                __syncthreads();
+                uint32_t ctot = 0;
+                if (tid < nd) {
+#pragma unroll
+                    for (int w2 = 0; w2 < 16; ++w2) { const uint32_t c = cnt[w2][tid]; cnt[w2][tid] = (unsigned short)ctot; ctot += c; }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = c0 + wv * 256 + r * 64 + lane;
+                    if (i < S) {
+                        const uint32_t dg = (ent_hi<E>(ev[r], tb.vb) >> lo) & (uint32_t)(nd - 1);
+                        dst[dbase[dg] + cnt[wv][dg] + wr[r]] = ev[r];
+                    }
+                }
+                __syncthreads();
+                if (tid < nd) dbase[tid] += ctot;
+            }
+            __threadfence_block();
+            __syncthreads();
+            E* t2 = src; src = dst; dst = t2;
+        }
+        const E* sorted = src;
+        const uint32_t nrec = emit_bucket<E, 1024>(a, tb, T, b, bin, pos0, S, [&](int q) { return sorted[q]; }, scratch);
+        if (tid == 0 && tb.brc != nullptr) tb.brc[(int64_t)b * tb.nbk + bin] = nrec;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_prep_compact: grid (ceil(nbk / 16), nb, 2), 256 threads.  Every workgroup scans its list's per-bucket record counts
+// (a few KB from L2) and moves the records of 16 buckets from their stretches of the staging array to the list's
+// contiguous run array -- bucket order, position order: the run list is a function of the input.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_prep_compact(SmlPrepArgs a) {
+    __shared__ uint32_t pre[SML_PREP_MAXBK + 1];
+    __shared__ uint32_t wsum[4];
+    const int T = blockIdx.z, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const SmlPrepTable& tb = a.t[T];
+    const int nbk = tb.nbk;
+    if ((int)blockIdx.x * 16 >= nbk) return;
+    const uint32_t* rc = tb.brc + (int64_t)b * nbk;
+    uint32_t c[4], mine = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { c[j] = 4 * tid + j < nbk ? rc[4 * tid + j] : 0u; mine += c[j]; }
+    uint32_t inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, off, 64); if (lane >= off) inc += t; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    uint32_t run = inc - mine;
+    for (int j = 0; j < wv; ++j) run += wsum[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { if (4 * tid + j < nbk) pre[4 * tid + j] = run; run += c[j]; }
+    if (tid == 255) { pre[nbk] = run; if (blockIdx.x == 0) tb.run_cnt[b] = (int)run; }
+    __syncthreads();
+    const BatchGeo g = batch_geo(a, b);
+    const uint32_t list_start = (uint32_t)(T ? 2 * g.start : g.start);
+    const uint4* stage = reinterpret_cast<const uint4*>(tb.runs_tmp);
+    uint4* dst = reinterpret_cast<uint4*>(tb.runs + (list_start >> 1));
+    for (int k = 0; k < 16; ++k) {
+        const int bin = blockIdx.x * 16 + k;
+        if (bin >= nbk) break;
+        const uint32_t n16 = 2 * (pre[bin + 1] - pre[bin]);       // a record is two 16-byte halves
+        if (n16 == 0) continue;
+        const uint4* src = stage + 2 * (int64_t)((list_start + tb.bk[(int64_t)b * nbk + bin].x) >> 1);
+        uint4* d = dst + 2 * (int64_t)pre[bin];
+        for (uint32_t i = tid; i < n16; i += 256) d[i] = src[i];
+    }
+}
+
+template <typename E>
+hipError_t launch_prep(const SmlPrepArgs& a, hipStream_t st) {
+    const dim3 tiles((unsigned)a.tpb, (unsigned)a.nb);
+    k_prep_hist<<<tiles, dim3(1024), 0, st>>>(a);
+    k_prep_scan<<<dim3((unsigned)a.nb, 2), dim3(1024), 0, st>>>(a);
+    k_prep_scatter<E><<<tiles, dim3(1024), 0, st>>>(a);
+    const int nbk_max = a.t[0].nbk > a.t[1].nbk ? a.t[0].nbk : a.t[1].nbk;
+    // (one grid for both tables: the table with fewer buckets leaves its surplus workgroups at once)
+    k_prep_bucket<E><<<dim3((unsigned)(a.nb * nbk_max), 2), dim3(256), 0, st>>>(a);
+    k_prep_large<E><<<dim3(256), dim3(1024), 0, st>>>(a);
+    if (!a.records) k_prep_compact<<<dim3((unsigned)((nbk_max + 15) / 16), (unsigned)a.nb, 2), dim3(256), 0, st>>>(a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t sml_launch_prep(const SmlPrepArgs& a, int ent_bytes, hipStream_t st) {
+    if (a.n <= 0 || a.nb <= 0) return hipSuccess;
+    return ent_bytes == 8 ? launch_prep<uint64_t>(a, st) : launch_prep<uint32_t>(a, st);
+}

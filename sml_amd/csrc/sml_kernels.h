@@ -147,6 +147,7 @@ struct SmlRunArgs {
     const SmlRun* run_u; int n_u;
     const SmlRun* run_i; int n_i;
     const int* off_u; const int* off_i; int batch_index;
+    const int* cnt_u; const int* cnt_i;             // not null: this batch's records are off[b] .. off[b] + cnt[b] (lists built by index_prep.hip)
     const uint32_t* val_u; const uint32_t* val_i;   // whole sorted value lists (SmlRun.pos indexes them): slot of each occurrence
     const float* dx;         // per-occurrence gradient rows the user values index
     const float* dx_i;       // ... and the item values index (the all-gathered buffer on several GPUs)
@@ -173,6 +174,41 @@ struct SmlRunArgs {
 #define SML_HOT 128          // runs longer than this take the hot path
 #define SML_HOT_CHUNK 512    // occurrences per workgroup in the hot-row partial sums
 #define SML_HOT_MAXCAP 8192
+// ------------------------------------------------------------------------------------
+// Index preparation by hand (index_prep.hip): per batch and table ("list"), the occurrences are partitioned
+// by the LOW bits of their row into buckets (stable: slot order survives), each bucket is sorted by the
+// remaining row bits in LDS, and the run records / unique marks / hot-row list leave from there.
+// ------------------------------------------------------------------------------------
+#define SML_PREP_IPT 8           // triples per thread of a partition tile
+#define SML_PREP_TT (1024 * SML_PREP_IPT)   // triples per partition tile
+#define SML_PREP_MAXBK 1024      // most buckets per list
+#define SML_PREP_SMALL 2048      // entries a bucket may hold to be sorted in LDS by the small-bucket kernel
+struct SmlPrepTable {
+    int nbk, lb;                 // buckets per list (a power of two) and its log2
+    int hb;                      // row bits above the bucket bits (sorted inside the bucket)
+    int vb;                      // value bits inside an entry (32: 64-bit entries)
+    int npass, pbits;            // LDS radix passes over those bits, bits per pass (<= 9)
+    void* ent; void* ent2;       // [occurrences] partitioned entries (row_hi << vb | value); ent2: ping-pong for large buckets
+    uint32_t* hist;              // [nb][tiles][nbk] tile histograms, turned into the tiles' first positions
+    uint2* bk;                   // [nb][nbk] (first position of the bucket inside its list, entries)
+    uint32_t* brc;               // [nb][nbk] compact mode: the bucket's number of run records
+    SmlRun* runs_tmp;            // compact mode: staging array, a bucket's records start at floor(position / 2)
+    uint32_t* vals;              // [occurrences] out: values (slots) in sorted order -- written for duplicated runs (all, in records mode)
+    SmlRun* runs;                // compact mode: the table's run records, list b's at run_off[b]; records mode: one per position
+    int* run_off; int* run_cnt;  // [nb] (compact mode)
+};
+struct SmlPrepArgs {
+    const int64_t* tri; int64_t n; int batch; int nb; int tpb;   // tpb: partition tiles per batch
+    const int* boff;             // planned batches of unequal size (or null)
+    int pad_tiles;               // the batch's first item value is rounded up to a multiple of SML_R
+    int records;                 // 1: one record per sorted position (MF stage); 0: compact records of duplicated runs + unique marks
+    SmlPrepTable t[2];           // users, items
+    uint8_t* uniq; int64_t uniq_stride;
+    uint32_t* hot_list; int* hot_count; int hot_cap; int* max_len;
+    int debug;                   // measurement builds only (SML_PREP_DEBUG): 1 bucket kernel stops after the load, 2 after the sort
+    uint32_t* large; int* n_large; int large_cap;     // (table << 31 | list), bucket -- buckets the small kernel leaves
+};
+hipError_t sml_launch_prep(const SmlPrepArgs& a, int ent_bytes, hipStream_t st);
 hipError_t sml_launch_hot_apply(int d, int dtype_bytes, const SmlRunArgs& a, hipStream_t st);
 hipError_t sml_launch_run_adam(int d, const SmlRunArgs& a, int64_t max_records, hipStream_t st);
 hipError_t sml_launch_run_sgd(int d, int dtype_bytes, const SmlRunArgs& a, int64_t max_records, hipStream_t st);

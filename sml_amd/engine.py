@@ -391,6 +391,29 @@ class HipEngine(object):
         tri.record_stream(self._prep)
         return dict(slot=slot, event=ev, tri=tri, batch=int(batch_size), exchange=exchange)
 
+    def index_lists(self, prepared):
+        """Test hook: the lists a bare_prepare handle holds, as numpy arrays (see sml_index_lists_read)."""
+        import numpy as np
+        prepared["event"].synchronize()
+        n, batch = int(prepared["tri"].shape[0]), prepared["batch"]
+        nb = (n + batch - 1) // batch
+
+        def rd(which, dtype, count):
+            buf = np.zeros(max(int(count), 1), dtype)
+            got = self.lib.sml_index_lists_read(self._ctx, prepared["slot"], which, buf.ctypes.data, buf.nbytes)
+            if got < 0:
+                check(int(got), "sml_index_lists_read")
+            return buf[:got // buf.itemsize]
+
+        two = rd(11, np.int32, 2)
+        out = dict(runs_u=rd(0, np.uint32, 8 * (n // 2 + 8)).reshape(-1, 8), runs_i=rd(1, np.uint32, 8 * (n + 8)).reshape(-1, 8),
+                   off_u=rd(2, np.int32, nb + 1), off_i=rd(3, np.int32, nb + 1), cnt_u=rd(4, np.int32, nb), cnt_i=rd(5, np.int32, nb),
+                   val_u=rd(6, np.uint32, n), val_i=rd(7, np.uint32, 2 * n), uniq=rd(8, np.uint8, 3 * nb * batch),
+                   max_len=int(two[0]), hot_cap=int(two[1]))
+        out["hot_list"] = rd(9, np.uint32, nb * out["hot_cap"] * 3).reshape(nb, -1, 3) if out["hot_cap"] else None
+        out["hot_count"] = rd(10, np.int32, nb) if out["hot_cap"] else None
+        return out
+
     def bare_epoch(self, w_user, w_item, triples, batch_size, lr, lam_user, lam_item, bce=True, prepared=None, exchange=None):
         if w_user.dtype not in (torch.float32, torch.float16) or w_item.dtype != w_user.dtype:
             raise ValueError("tables must both be fp32 or both fp16")

@@ -1727,3 +1727,140 @@ def test_empty_test_shard_contributes_zero():
     assert eng.eval_metrics(r, 20) == (0.0, 0.0)
     h = eng.eval_submit(wu, wi, rows)
     assert eng.eval_result(eng.eval_metrics_submit(h, 20)) == (0.0, 0.0)
+
+
+def _prep_ab_triples(case):
+    rng = np.random.RandomState(77)
+    if case == "hot_small":
+        U, I, B, n = 5000, 3000, 8192, 2 * 8192 + 1000
+    elif case == "partitioned":
+        U, I, B, n = 200000, 50000, 65536, 2 * 65536 + 777
+    elif case == "tiny_tables":
+        U, I, B, n = 7, 5, 300, 1000
+    elif case == "one_bucket_lists":
+        U, I, B, n = 70000, 130000, 1024, 5 * 1024 + 3
+    elif case == "wide_rows":                      # 2^25 + 5 user rows at a 262,144 batch: 8-byte entries
+        U, I, B, n = (1 << 25) + 5, 40000, 262144, 262144 + 4099
+    elif case == "wide_rows_both":                 # ... and 5,000,000 items (config 5's heights), one full batch, d = 128
+        U, I, B, n = (1 << 25) + 5, 5000000, 262144, 262144
+    else:
+        raise KeyError(case)
+    u, i, j = rng.randint(0, U, n), rng.randint(0, I, n), rng.randint(0, I, n)
+    if case in ("hot_small", "partitioned", "wide_rows", "wide_rows_both"):
+        i[0:B:3] = 7 % I                              # a third of batch 0's positives on one item (an oversized bucket)
+        j[1:B:25] = 7 % I
+        u[2:B:12] = 11                                # ~B/12 occurrences of one user
+        i[B:2 * B:2] = 9 % I
+        u[B + 5:2 * B:200] = U - 1                    # the highest row
+        zipf = np.minimum((rng.pareto(1.0, n // 2) * 3).astype(np.int64), I - 1)
+        i[n - n // 2:] = np.where(rng.rand(n // 2) < 0.5, zipf, i[n - n // 2:])
+    return U, I, B, np.stack([u, i, j], 1)
+
+
+@pytest.mark.parametrize("case", ["hot_small", "partitioned", "tiny_tables", "one_bucket_lists", "wide_rows", "wide_rows_both"])
+def test_index_prep_by_hand_equals_the_library_sort_path(case, monkeypatch):
+    """index_prep.hip (bucket partition + LDS sort, run records straight from the sorted buckets) against the library
+    radix-sort path it replaces (SML_PREP=cub): the bare SGD epoch ends in bit-identical tables and losses -- same unique
+    marks, same runs, same summation order inside every run, same hot-row lists (any of these differing moves a bit)."""
+    from sml_amd.engine import HipEngine
+    U, I, B, tri = _prep_ab_triples(case)
+    d = 128 if case == "wide_rows_both" else 32
+    dt = torch.float16 if case.startswith("wide_rows") else torch.float32
+    g = torch.Generator(device=DEV).manual_seed(5)
+    wu = (torch.randn(U, d, device=DEV, generator=g) * 0.3).to(dt)
+    wi = (torch.randn(I, d, device=DEV, generator=g) * 0.3).to(dt)
+    t = T(tri, DEV)
+    out = []
+    for mode in ("cub", "hand"):
+        monkeypatch.setenv("SML_PREP", mode)
+        eng = HipEngine(DEV, d, B)
+        a_u, a_i = wu.clone(), wi.clone()
+        losses = [eng.bare_epoch(a_u, a_i, t, B, 0.05, 1e-4, 1e-4, bce=(e == 0)).cpu() for e in range(2)]
+        torch.cuda.synchronize()
+        out.append((a_u, a_i, losses))
+        eng.close()
+    assert all(torch.equal(x, y) for x, y in zip(out[0][2], out[1][2]))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert not torch.equal(out[0][1], wi)
+
+
+@pytest.mark.parametrize("B", [64, 1024, 3000])
+def test_index_prep_by_hand_equals_the_library_sort_path_for_position_records(B, monkeypatch):
+    """The MF stage's / bare Adam epoch's lists (one record per sorted position): by hand against the library sort."""
+    from sml_amd.engine import HipEngine
+    rng = np.random.RandomState(B)
+    U, I, d, n = 900, 700, 32, 4 * B + 17
+    u = np.minimum((rng.pareto(1.2, n) * 3).astype(np.int64), U - 1)
+    i = np.minimum((rng.pareto(1.0, n) * 2).astype(np.int64), I - 1)
+    tri = np.stack([u, i, rng.randint(0, I, n)], 1)
+    base = make_mf(U, I, d)
+    out = []
+    for mode in ("cub", "hand"):
+        monkeypatch.setenv("SML_PREP", mode)
+        mf = make_mf(U, I, d, base.user_laten.weight.detach().numpy() * 0.3, base.item_laten.weight.detach().numpy() * 0.3, device=DEV)
+        eng = HipEngine(DEV, d, max(B, 1024))
+        losses = [eng.bare_adam_epoch(mf, T(tri, DEV), B, 0.01, 1e-5, 2e-5, bce=(e == 0)).cpu() for e in range(2)]
+        eng.mf_flush(mf)
+        torch.cuda.synchronize()
+        out.append((mf.user_laten.weight.detach().clone(), mf.item_laten.weight.detach().clone(), losses))
+        eng.close()
+    assert all(torch.equal(x, y) for x, y in zip(out[0][2], out[1][2]))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
+def _expected_lists(tri, B):
+    """numpy restatement of what the bare step's index lists must hold: per batch and table, every row with >= 2
+    occurrences -> its values in occurrence order; the unique marks."""
+    n = tri.shape[0]
+    out = []
+    for b0 in range(0, n, B):
+        t = tri[b0:b0 + B]
+        Bb = t.shape[0]
+        lists = []
+        uniq = np.ones(3 * Bb, np.uint8)
+        for rows, vals in ((t[:, 0], np.arange(Bb)), (np.concatenate([t[:, 1], t[:, 2]]), Bb + np.arange(2 * Bb))):
+            order = np.argsort(rows, kind="stable")
+            r, v = rows[order], vals[order]
+            starts = np.flatnonzero(np.r_[True, r[1:] != r[:-1]])
+            lens = np.diff(np.r_[starts, r.size])
+            runs = {int(r[s]): v[s:s + l] for s, l in zip(starts[lens > 1], lens[lens > 1])}
+            for vv in runs.values():
+                uniq[vv] = 0
+            lists.append(runs)
+        out.append((lists[0], lists[1], uniq))
+    return out
+
+
+@pytest.mark.parametrize("mode", ["hand", "cub"])
+@pytest.mark.parametrize("case", ["hot_small", "partitioned", "tiny_tables", "wide_rows", "wide_rows_both", "one_bucket_lists"])
+def test_index_lists_hold_every_duplicated_row_once_with_its_slots_in_order(case, mode, monkeypatch):
+    """The prepared lists themselves, read back: every duplicated row of a batch has exactly one run record, its slots
+    are the row's occurrences in order, rows that occur once are marked unique, hot runs are listed."""
+    from sml_amd.engine import HipEngine
+    monkeypatch.setenv("SML_PREP", mode)
+    U, I, B, tri = _prep_ab_triples(case)
+    eng = HipEngine(DEV, 32, B)
+    L = eng.index_lists(eng.bare_prepare(T(tri, DEV), B, U, I))
+    want = _expected_lists(tri, B)
+    n = tri.shape[0]
+    for b, (wu, wi, wuniq) in enumerate(want):
+        Bb = min(B, n - b * B)
+        assert np.array_equal(L["uniq"][3 * b * B:3 * b * B + 3 * Bb], wuniq), (b, "unique marks")
+        hot_want = set()
+        for tab, runs, off, cnt, vals, wr in ((0, L["runs_u"], L["off_u"], L["cnt_u"], L["val_u"], wu), (1, L["runs_i"], L["off_i"], L["cnt_i"], L["val_i"], wi)):
+            k = int(cnt[b]) if cnt.size else int(off[b + 1] - off[b])
+            rec = runs[off[b]:off[b] + k]
+            assert k == len(wr), (b, tab, k, len(wr))
+            assert len(set(rec[:, 0].tolist())) == k                      # one record per row
+            for row, pos, ln, _, s0, s1, s2, s3 in rec.tolist():
+                w = wr[row]
+                assert ln == w.size and np.array_equal(vals[pos:pos + ln], w), (b, tab, row)
+                assert [s0, s1, s2, s3][:min(ln, 4)] == w[:4].tolist()
+                if ln > 128:
+                    hot_want.add((tab, row, ln, pos))
+        if L["hot_cap"]:
+            hl = L["hot_list"][b, :L["hot_count"][b]]
+            assert {(int(p >> 31), int(r), int(ln), int(p & 0x7fffffff)) for p, ln, r in hl.tolist()} == hot_want
+        else:
+            assert not hot_want or B < 4096
+    eng.close()
