@@ -156,7 +156,7 @@ struct IndexSet {
     Buf<uint8_t> uniq;
     Buf<int> off_u, off_i, n_sel;
     // index_prep.hip (the by-hand preparation): tile histograms, bucket offsets / counts, run counts, oversized buckets
-    Buf<uint32_t> hist_u, hist_i, bko_u, bko_i, bkc_u, bkc_i, large;
+    Buf<uint32_t> hist_u, hist_i, bko_u, bko_i, bkc_u, bkc_i, large, medium;
     Buf<SmlRun> stage_u, stage_i;      // per-bucket stretches of run records before the compaction
     Buf<int> cnt_u, cnt_i;
     bool by_hand = false;              // the lists were built by index_prep.hip: a batch's runs are off[b] .. off[b] + cnt[b]
@@ -169,7 +169,7 @@ struct IndexSet {
         key_u.release(); key_u2.release(); key_i.release(); key_i2.release();
         val_u.release(); val_u2.release(); val_i.release(); val_i2.release();
         rec_u.release(); rec_i.release(); runs_u.release(); runs_i.release();
-        hist_u.release(); hist_i.release(); bko_u.release(); bko_i.release(); bkc_u.release(); bkc_i.release(); large.release();
+        hist_u.release(); hist_i.release(); bko_u.release(); bko_i.release(); bkc_u.release(); bkc_i.release(); large.release(); medium.release();
         cnt_u.release(); cnt_i.release(); stage_u.release(); stage_i.release();
         uniq.release(); heads_u.release(); heads_i.release(); hot_list.release(); hot_count.release(); off_u.release(); off_i.release(); n_sel.release();
         cub_tmp.release();
@@ -498,6 +498,7 @@ int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
         t.lb = lb[T]; t.nbk = 1 << lb[T];
         t.hb = rb[T] > lb[T] ? rb[T] - lb[T] : 0; t.vb = vb[T];
         t.npass = (t.hb + 8) / 9; t.pbits = t.npass ? (t.hb + t.npass - 1) / t.npass : 0;
+        t.wave = (dups && ((int64_t)(T ? 2 : 1) * batch >> t.lb) <= 256 && !getenv("SML_PREP_NOWAVE")) ? 1 : 0;
         HIPCHK(hist[T]->ensure((size_t)nb * (T ? 2 : 1) * a.tpb * t.nbk));
         HIPCHK(bko[T]->ensure((size_t)2 * nb * t.nbk)); HIPCHK(bkc[T]->ensure((size_t)nb * t.nbk));
         t.hist = hist[T]->p; t.bk = reinterpret_cast<uint2*>(bko[T]->p); t.brc = dups ? bkc[T]->p : nullptr;
@@ -507,11 +508,11 @@ int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
         else t.runs = T ? c->rec_i.p : c->rec_u.p;
     }
     a.large = c->large.p; a.n_large = c->n_sel.p + 3; a.large_cap = (int)large_cap;
-    HIPCHK(hipMemsetAsync(c->n_sel.p, 0, 4 * sizeof(int), st));
+    HIPCHK(c->medium.ensure((size_t)2 * nb * (a.t[0].nbk + a.t[1].nbk) + 2));
+    a.medium = c->medium.p; a.n_medium = c->n_sel.p;
     c->hot_cap = 0;
     if (dups) {
         a.uniq = c->uniq.p; a.uniq_stride = (int64_t)3 * batch; a.max_len = c->n_sel.p + 2;
-        HIPCHK(hipMemsetAsync(c->uniq.p, 1, (size_t)3 * nb * batch, st));
         const int64_t hot_cap64 = ((int64_t)batch + 2 * (int64_t)batch) / SML_HOT + 8;
         const int hot_cap = (int)(hot_cap64 < 0x7fffffff ? hot_cap64 : 0x7fffffff);
         c->hot_cap = (batch >= 4096 && hot_cap <= SML_HOT_MAXCAP) ? hot_cap : 0;

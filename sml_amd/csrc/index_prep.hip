@@ -31,13 +31,15 @@ __device__ __forceinline__ uint64_t lanes_below() { return (1ull << (threadIdx.x
 
 // lanes (among the valid ones) holding the same `key` in its low `bits` bits
 __device__ __forceinline__ uint64_t match_any(uint32_t key, bool valid, int bits) {
-    uint64_t m = __ballot(valid);
+    const uint64_t v = __ballot(valid);
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
     for (int b = 0; b < bits; ++b) {
-        const bool bit = (key >> b) & 1u;
-        const uint64_t bb = __ballot(bit);
-        m &= bit ? bb : ~bb;
+        const uint32_t bit = (key >> b) & 1u;
+        const uint64_t bb = __ballot(bit != 0u);
+        const uint32_t flip = bit - 1u;                    // all ones for a clear bit: the lanes whose bit is clear too
+        lo &= (uint32_t)bb ^ flip; hi &= (uint32_t)(bb >> 32) ^ flip;
     }
-    return m;
+    return ((uint64_t)hi << 32) | lo;
 }
 
 // One round of the stable in-wavefront ranking: the wavefront's counter row `cnt` holds, per key, the occurrences of
@@ -72,6 +74,7 @@ __global__ __launch_bounds__(1024) void k_prep_hist(SmlPrepArgs a) {
     const BatchGeo g = batch_geo(a, b);
     const int nbu = a.t[0].nbk, nbi = a.t[1].nbk;
     for (int i = tid; i < 3 * SML_PREP_MAXBK; i += 1024) (&h[0][0])[i] = 0u;
+    if (k == 0 && b == 0 && tid < 4) a.n_medium[tid] = 0;          // n_medium, -, longest run, n_large (one int4 of counters)
     __syncthreads();
     const int t0 = k * SML_PREP_TT + (tid >> 6) * (64 * SML_PREP_IPT) + (tid & 63);
 #pragma unroll
@@ -119,23 +122,33 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* w
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_prep_scan(SmlPrepArgs a) {
     __shared__ uint32_t wsum[17];
+    __shared__ uint32_t part[1024];                                  // [tile group][bin]
     const int b = blockIdx.x, T = blockIdx.y, tid = threadIdx.x;
     const SmlPrepTable& tb = a.t[T];
     const BatchGeo g = batch_geo(a, b);
-    const int nbk = tb.nbk, ntile = T ? 2 * a.tpb : a.tpb;
+    const int nbk = tb.nbk, lb = tb.lb, ntile = T ? 2 * a.tpb : a.tpb;
     const int64_t list_start = T ? 2 * g.start : g.start;
     uint32_t* H = tb.hist + (int64_t)b * ntile * nbk;
-    uint32_t tot = 0;
-    if (tid < nbk) {
+    // all 1024 threads: thread (group, bin) owns a contiguous share of the tiles
+    const int ngrp = 1024 >> lb, grp = tid >> lb, bin = tid & (nbk - 1);
+    const int per = (ntile + ngrp - 1) / ngrp, k0 = min(ntile, grp * per), k1 = min(ntile, k0 + per);
+    uint32_t mine = 0;
 #pragma unroll 8
-        for (int k = 0; k < ntile; ++k) tot += H[(int64_t)k * nbk + tid];
+    for (int k = k0; k < k1; ++k) mine += H[(int64_t)k * nbk + bin];
+    part[tid] = mine;
+    __syncthreads();
+    uint32_t tot = 0, before = 0;
+    for (int j = 0; j < ngrp; ++j) { const uint32_t c = part[(j << lb) + bin]; tot += c; before += j < grp ? c : 0u; }
+    const uint32_t off = block_excl_scan_1024(tid < nbk ? tot : 0u, wsum);      // (threads of group 0: one per bin, in bin order)
+    if (tid < nbk) part[tid] = off;
+    __syncthreads();
+    {
+        uint32_t run = (uint32_t)list_start + part[bin] + before;
+#pragma unroll 8
+        for (int k = k0; k < k1; ++k) { const uint32_t c = H[(int64_t)k * nbk + bin]; H[(int64_t)k * nbk + bin] = run; run += c; }
     }
-    const uint32_t off = block_excl_scan_1024(tot, wsum);
     if (tid < nbk) {
         tb.bk[(int64_t)b * nbk + tid] = make_uint2(off, tot);
-        uint32_t run = (uint32_t)list_start + off;
-#pragma unroll 8
-        for (int k = 0; k < ntile; ++k) { const uint32_t c = H[(int64_t)k * nbk + tid]; H[(int64_t)k * nbk + tid] = run; run += c; }
         if (tot > SML_PREP_SMALL) {
             const int slot = atomicAdd(a.n_large, 1);
             if (slot < a.large_cap) { a.large[2 * slot] = ((uint32_t)T << 31) | (uint32_t)b; a.large[2 * slot + 1] = (uint32_t)tid; }
@@ -176,7 +189,8 @@ __global__ __launch_bounds__(1024) void k_prep_scatter(SmlPrepArgs a) {
         const uint32_t* base = s == 0 ? tb.hist + ((int64_t)b * a.tpb + k) * nbk
                                       : tb.hist + (((int64_t)b * 2 + (s - 1)) * a.tpb + k) * nbk;
         if (s) __syncthreads();                         // the previous stream's readers of cnt / tbase are done
-        for (int i = tid; i < 16 * nbk; i += 1024) cnt[i >> lb][i & (nbk - 1)] = 0;
+        if (nbk >= 2) { for (int i = tid; i < 8 * nbk; i += 1024) reinterpret_cast<uint32_t*>(&cnt[(2 * i) >> lb][0])[((2 * i) & (nbk - 1)) >> 1] = 0u; }
+        else if (tid < 16) cnt[tid][0] = 0;
         for (int i = tid; i < nbk; i += 1024) tbase[i] = base[i];
         __syncthreads();
         uint32_t wr[IPT];
@@ -191,6 +205,7 @@ __global__ __launch_bounds__(1024) void k_prep_scatter(SmlPrepArgs a) {
         __syncthreads();
         E* ent = reinterpret_cast<E*>(tb.ent);
         const uint32_t vbase = s == 0 ? 0u : (s == 1 ? g.ioff : g.ioff + (uint32_t)g.Bb);
+        uint8_t* uniq = a.uniq ? a.uniq + (int64_t)b * a.uniq_stride + vbase : nullptr;     // every mark starts at "once"
 #pragma unroll
         for (int r = 0; r < IPT; ++r) {
             const int t = t0 + r * 64;
@@ -198,6 +213,7 @@ __global__ __launch_bounds__(1024) void k_prep_scatter(SmlPrepArgs a) {
                 const uint32_t bin = row[s][r] & (uint32_t)(nbk - 1);
                 const uint32_t dest = tbase[bin] + cnt[wv][bin] + wr[r];
                 const E hi = (E)(row[s][r] >> lb);
+                if (uniq) uniq[t] = 1;
                 ent[dest] = sizeof(E) == 8 ? (E)(((uint64_t)hi << 32) | (uint64_t)(vbase + (uint32_t)t))
                                            : (E)((hi << tb.vb) | (E)(vbase + (uint32_t)t));
             }
@@ -302,19 +318,117 @@ __device__ __forceinline__ uint32_t emit_bucket(const SmlPrepArgs& a, const SmlP
 }
 
 // ------------------------------------------------------------------------------------
-// k_prep_bucket: grid (nb * nbk, 2), 256 threads; buckets of at most SML_PREP_SMALL entries.
+// k_prep_wave: lists cut into SMALL buckets (a table in wave mode: about 256 occurrences per bucket -- uniform users at
+// a 262,144 batch): one WAVEFRONT per bucket, four per workgroup, no barrier anywhere.  The duplicate filter (bitmaps
+// over a 13-bit hash of row_hi), the candidates compacted in occurrence order, and -- when at most 64 remain, which is
+// the rule where duplicates are rare -- ranked against each other in registers; the records leave from there.  A bucket
+// with more candidates is left to k_prep_bucket (listed in `medium`).
 // ------------------------------------------------------------------------------------
+__device__ __forceinline__ void prep_punt(const SmlPrepArgs& a, int T, int b, uint32_t bin) {
+    const int slot = atomicAdd(a.n_medium, 1);
+    a.medium[2 * slot] = ((uint32_t)T << 31) | (uint32_t)b; a.medium[2 * slot + 1] = bin;
+}
 template <typename E>
-__global__ __launch_bounds__(256, sizeof(E) == 4 ? 7 : 4) void k_prep_bucket(SmlPrepArgs a) {
-    __shared__ E buf[2][SML_PREP_SMALL];
-    __shared__ unsigned short cnt[4][512];
-    __shared__ uint32_t dbase[512];
-    __shared__ uint32_t scratch[8];
+__global__ __launch_bounds__(256) void k_prep_wave(SmlPrepArgs a) {
+    __shared__ uint32_t bm_all[4][2][256];
+    __shared__ E cand_all[4][64];
+    __shared__ E sorted_all[4][64];
     const int T = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const SmlPrepTable& tb = a.t[T];
-    const int b = (int)(blockIdx.x >> tb.lb);
-    const uint32_t bin = blockIdx.x & (uint32_t)(tb.nbk - 1);
+    if (!tb.wave) return;
+    const int64_t gidx = (int64_t)blockIdx.x * 4 + wv;               // bucket, list-major
+    const int b = (int)(gidx >> tb.lb);
+    const uint32_t bin = (uint32_t)gidx & (uint32_t)(tb.nbk - 1);
     if (b >= a.nb) return;
+    const uint2 oc = tb.bk[(int64_t)b * tb.nbk + bin];
+    const int S = (int)oc.y;
+    uint32_t* brc = tb.brc + (int64_t)b * tb.nbk + bin;
+    if (S == 0) { if (lane == 0) *brc = 0u; return; }
+    if (S > SML_PREP_SMALL) return;                                  // k_prep_large's (listed by k_prep_scan)
+    if (S > 512) { if (lane == 0) prep_punt(a, T, b, bin); return; }
+    const BatchGeo g = batch_geo(a, b);
+    const uint32_t pos0 = (uint32_t)(T ? 2 * g.start : g.start) + oc.x;
+    const E* src = reinterpret_cast<const E*>(tb.ent) + pos0;
+    uint32_t (*bm)[256] = bm_all[wv];
+    E* cand = cand_all[wv];
+    E* sorted = sorted_all[wv];
+    const int R0 = (S + 63) >> 6;
+    const int vb = tb.vb;
+    E e0[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) e0[r] = (r < R0 && r * 64 + lane < S) ? src[r * 64 + lane] : (E)0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) (&bm[0][0])[j * 64 + lane] = 0u;
+    const uint32_t hmask = (1u << min(tb.hb, 13)) - 1u;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (r < R0 && r * 64 + lane < S) {
+            const uint32_t h = ent_hi<E>(e0[r], vb) & hmask, bit = 1u << (h & 31);
+            const uint32_t old = atomicOr(&bm[0][h >> 5], bit);
+            if (old & bit) atomicOr(&bm[1][h >> 5], bit);
+        }
+    }
+    uint32_t nc = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (r < R0) {
+            const uint32_t h = ent_hi<E>(e0[r], vb) & hmask;
+            const bool isd = r * 64 + lane < S && ((bm[1][h >> 5] >> (h & 31)) & 1u);
+            const uint64_t m = __ballot(isd);
+            const uint32_t idx = nc + (uint32_t)__popcll(m & lanes_below());
+            if (isd && idx < 64) cand[idx] = e0[r];
+            nc += (uint32_t)__popcll(m);
+        }
+    }
+    if (nc == 0) { if (lane == 0) *brc = 0u; return; }
+    if (nc > 64) { if (lane == 0) prep_punt(a, T, b, bin); return; }
+    const int n = (int)nc;
+    {   // rank among the candidates: by row_hi, equal ones by position (stable)
+        const E e = lane < n ? cand[lane] : (E)0;
+        const uint32_t key = ent_hi<E>(e, vb);
+        uint32_t rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)key, j);
+            rank += (kj < key || (kj == key && j < lane)) ? 1u : 0u;
+        }
+        if (lane < n) sorted[rank] = e;
+    }
+    const int q = lane;
+    const bool in = q < n;
+    const E e = in ? sorted[q] : (E)0;
+    const uint32_t rh = ent_hi<E>(e, vb);
+    const uint32_t prev = (in && q > 0) ? ent_hi<E>(sorted[q - 1], vb) : ~rh;
+    const uint32_t next = (in && q + 1 < n) ? ent_hi<E>(sorted[q + 1], vb) : ~rh;
+    const bool head = in && prev != rh, tail = in && next != rh, dup = in && !(head && tail);
+    const uint32_t val = ent_val<E>(e, vb);
+    if (dup) {
+        tb.vals[pos0 + q] = val;
+        if (a.uniq) a.uniq[(int64_t)b * a.uniq_stride + val] = 0;
+    }
+    const uint64_t heads = __ballot(head);
+    const uint64_t upto = heads & ((lanes_below() << 1) | 1ull);           // heads at or below this lane
+    const int hq = 63 - __clzll((long long)(upto | 1ull));
+    const int len = q - hq + 1;
+    const bool want = tail && len >= 2;
+    const uint64_t wm = __ballot(want);
+    if (want) {
+        SmlRun r;
+        r.row = (rh << tb.lb) | bin; r.pos = pos0 + (uint32_t)hq; r.len = (uint32_t)len; r.pad = 0;
+#pragma unroll
+        for (int j = 0; j < SML_RUN_INL; ++j) r.slot[j] = j < len ? ent_val<E>(sorted[hq + j], vb) : 0u;
+        tb.runs_tmp[(pos0 >> 1) + (uint32_t)__popcll(wm & lanes_below())] = r;
+    }
+    if (lane == 0) *brc = (uint32_t)__popcll(wm);
+}
+
+// ------------------------------------------------------------------------------------
+// bucket_body / k_prep_bucket: 256 threads per bucket; buckets of at most SML_PREP_SMALL entries.
+// ------------------------------------------------------------------------------------
+template <typename E>
+__device__ __forceinline__ void bucket_body(const SmlPrepArgs& a, int T, int b, uint32_t bin, E (*buf)[SML_PREP_SMALL],
+                                            unsigned short (*cnt)[512], uint32_t* dbase, uint32_t* scratch) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const SmlPrepTable& tb = a.t[T];
     const uint2 oc = tb.bk[(int64_t)b * tb.nbk + bin];             // (first position inside the list, entries)
     int S = (int)oc.y;
     if (S == 0 && tid == 0 && tb.brc != nullptr) tb.brc[(int64_t)b * tb.nbk + bin] = 0u;
@@ -454,6 +568,27 @@ __global__ __launch_bounds__(256, sizeof(E) == 4 ? 7 : 4) void k_prep_bucket(Sml
     if (tid == 0 && tb.brc != nullptr) tb.brc[(int64_t)b * tb.nbk + bin] = nrec;
 }
 
+// listed == 0: one workgroup per bucket of table T (grid nb * nbk).  listed == 1: the buckets k_prep_wave left
+// (grid-stride over `medium`).
+template <typename E>
+__global__ __launch_bounds__(256, sizeof(E) == 4 ? 7 : 4) void k_prep_bucket(SmlPrepArgs a, int T, int listed) {
+    __shared__ E buf[2][SML_PREP_SMALL];
+    __shared__ unsigned short cnt[4][512];
+    __shared__ uint32_t dbase[512];
+    __shared__ uint32_t scratch[8];
+    if (!listed) {
+        const SmlPrepTable& tb = a.t[T];
+        bucket_body<E>(a, T, (int)(blockIdx.x >> tb.lb), blockIdx.x & (uint32_t)(tb.nbk - 1), buf, cnt, dbase, scratch);
+        return;
+    }
+    const int n_medium = *a.n_medium;
+    for (int w = blockIdx.x; w < n_medium; w += gridDim.x) {
+        const uint32_t tl = a.medium[2 * w];
+        __syncthreads();                                     // the previous bucket's readers of the LDS arrays are done
+        bucket_body<E>(a, (int)(tl >> 31), (int)(tl & 0x7fffffffu), a.medium[2 * w + 1], buf, cnt, dbase, scratch);
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // k_prep_large: the oversized buckets, one 1024-thread workgroup each (grid-stride over the list k_prep_scan built).
 // The same stable passes, 4096 entries at a time, between the two entry arrays.
@@ -538,8 +673,8 @@ __global__ __launch_bounds__(1024) void k_prep_large(SmlPrepArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
-// k_prep_compact: grid (ceil(nbk / 16), nb, 2), 256 threads.  Every workgroup scans its list's per-bucket record counts
-// (a few KB from L2) and moves the records of 16 buckets from their stretches of the staging array to the list's
+// k_prep_compact: grid (ceil(nbk / SML_PREP_CG), nb, 2), 256 threads.  Every workgroup scans its list's per-bucket record counts
+// (a few KB from L2) and moves the records of SML_PREP_CG buckets from their stretches of the staging array to the list's
 // contiguous run array -- bucket order, position order: the run list is a function of the input.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_prep_compact(SmlPrepArgs a) {
@@ -548,7 +683,7 @@ __global__ __launch_bounds__(256) void k_prep_compact(SmlPrepArgs a) {
     const int T = blockIdx.z, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const SmlPrepTable& tb = a.t[T];
     const int nbk = tb.nbk;
-    if ((int)blockIdx.x * 16 >= nbk) return;
+    if ((int)blockIdx.x * SML_PREP_CG >= nbk) return;
     const uint32_t* rc = tb.brc + (int64_t)b * nbk;
     uint32_t c[4], mine = 0;
 #pragma unroll
@@ -568,14 +703,28 @@ __global__ __launch_bounds__(256) void k_prep_compact(SmlPrepArgs a) {
     const uint32_t list_start = (uint32_t)(T ? 2 * g.start : g.start);
     const uint4* stage = reinterpret_cast<const uint4*>(tb.runs_tmp);
     uint4* dst = reinterpret_cast<uint4*>(tb.runs + (list_start >> 1));
-    for (int k = 0; k < 16; ++k) {
-        const int bin = blockIdx.x * 16 + k;
-        if (bin >= nbk) break;
-        const uint32_t n16 = 2 * (pre[bin + 1] - pre[bin]);       // a record is two 16-byte halves
-        if (n16 == 0) continue;
-        const uint4* src = stage + 2 * (int64_t)((list_start + tb.bk[(int64_t)b * nbk + bin].x) >> 1);
-        uint4* d = dst + 2 * (int64_t)pre[bin];
-        for (uint32_t i = tid; i < n16; i += 256) d[i] = src[i];
+    // the 16 buckets' records as ONE flat range of 16-byte halves (a record is two): their stretches' first records are
+    // fetched side by side, not one dependent load per bucket
+    __shared__ uint32_t first[SML_PREP_CG];
+    const int bin0 = blockIdx.x * SML_PREP_CG, nbin = min(SML_PREP_CG, nbk - bin0);
+    if (tid < nbin) first[tid] = (list_start + tb.bk[(int64_t)b * nbk + bin0 + tid].x) >> 1;
+    __syncthreads();
+    const uint32_t r0 = pre[bin0], r1 = pre[bin0 + nbin];
+    for (uint32_t i0 = 2 * r0 + tid; i0 < 2 * r1; i0 += 1024) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + 256 * u;
+            if (i < 2 * r1) {
+                const uint32_t rec = i >> 1;
+                int k = 0;
+#pragma unroll
+                for (int j = 1; j < SML_PREP_CG; ++j) k += (j < nbin && pre[bin0 + j] <= rec) ? 1 : 0;
+                v[u] = stage[2 * (int64_t)(first[k] + (rec - pre[bin0 + k])) + (i & 1u)];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (i0 + 256 * u < 2 * r1) dst[i0 + 256 * u] = v[u];
     }
 }
 
@@ -586,10 +735,14 @@ hipError_t launch_prep(const SmlPrepArgs& a, hipStream_t st) {
     k_prep_scan<<<dim3((unsigned)a.nb, 2), dim3(1024), 0, st>>>(a);
     k_prep_scatter<E><<<tiles, dim3(1024), 0, st>>>(a);
     const int nbk_max = a.t[0].nbk > a.t[1].nbk ? a.t[0].nbk : a.t[1].nbk;
-    // (one grid for both tables: the table with fewer buckets leaves its surplus workgroups at once)
-    k_prep_bucket<E><<<dim3((unsigned)(a.nb * nbk_max), 2), dim3(256), 0, st>>>(a);
+    if (a.t[0].wave || a.t[1].wave) {
+        k_prep_wave<E><<<dim3((unsigned)((a.nb * nbk_max + 3) / 4), 2), dim3(256), 0, st>>>(a);
+        k_prep_bucket<E><<<dim3(1024), dim3(256), 0, st>>>(a, 0, 1);
+    }
+    for (int T = 0; T < 2; ++T)
+        if (!a.t[T].wave) k_prep_bucket<E><<<dim3((unsigned)(a.nb * a.t[T].nbk)), dim3(256), 0, st>>>(a, T, 0);
     k_prep_large<E><<<dim3(256), dim3(1024), 0, st>>>(a);
-    if (!a.records) k_prep_compact<<<dim3((unsigned)((nbk_max + 15) / 16), (unsigned)a.nb, 2), dim3(256), 0, st>>>(a);
+    if (!a.records) k_prep_compact<<<dim3((unsigned)((nbk_max + SML_PREP_CG - 1) / SML_PREP_CG), (unsigned)a.nb, 2), dim3(256), 0, st>>>(a);
     return hipGetLastError();
 }
 

@@ -179,15 +179,17 @@ struct SmlRunArgs {
 // by the LOW bits of their row into buckets (stable: slot order survives), each bucket is sorted by the
 // remaining row bits in LDS, and the run records / unique marks / hot-row list leave from there.
 // ------------------------------------------------------------------------------------
-#define SML_PREP_IPT 8           // triples per thread of a partition tile
+#define SML_PREP_IPT 4           // triples per thread of a partition tile
 #define SML_PREP_TT (1024 * SML_PREP_IPT)   // triples per partition tile
 #define SML_PREP_MAXBK 1024      // most buckets per list
+#define SML_PREP_CG 8            // buckets per workgroup of the record compaction
 #define SML_PREP_SMALL 2048      // entries a bucket may hold to be sorted in LDS by the small-bucket kernel
 struct SmlPrepTable {
     int nbk, lb;                 // buckets per list (a power of two) and its log2
     int hb;                      // row bits above the bucket bits (sorted inside the bucket)
     int vb;                      // value bits inside an entry (32: 64-bit entries)
     int npass, pbits;            // LDS radix passes over those bits, bits per pass (<= 9)
+    int wave;                    // small buckets (compact mode): one wavefront per bucket first (k_prep_wave)
     void* ent; void* ent2;       // [occurrences] partitioned entries (row_hi << vb | value); ent2: ping-pong for large buckets
     uint32_t* hist;              // [nb][tiles][nbk] tile histograms, turned into the tiles' first positions
     uint2* bk;                   // [nb][nbk] (first position of the bucket inside its list, entries)
@@ -206,6 +208,7 @@ struct SmlPrepArgs {
     uint8_t* uniq; int64_t uniq_stride;
     uint32_t* hot_list; int* hot_count; int hot_cap; int* max_len;
     int debug;                   // measurement builds only (SML_PREP_DEBUG): 1 bucket kernel stops after the load, 2 after the sort
+    uint32_t* medium; int* n_medium;                  // same pairs: buckets k_prep_wave leaves to k_prep_bucket
     uint32_t* large; int* n_large; int large_cap;     // (table << 31 | list), bucket -- buckets the small kernel leaves
 };
 hipError_t sml_launch_prep(const SmlPrepArgs& a, int ent_bytes, hipStream_t st);

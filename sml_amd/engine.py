@@ -377,7 +377,14 @@ class HipEngine(object):
         exchange: several GPUs (DistContext.bare_exchange): the item lists are then the job's.
         Returns a handle for bare_epoch(prepared=...)."""
         if getattr(self, "_prep", None) is None:
-            self._prep = torch.cuda.Stream(device=self.device)
+            import os
+            k = int(os.environ.get("SML_PREP_CUS", "0"))
+            if k > 0:                                    # the preparation confined to the last k compute units
+                self._prep = self._masked_stream(self._n_cus() - k, self._n_cus())
+            elif os.environ.get("SML_PREP_PRIO", "") == "low":
+                self._prep = torch.cuda.Stream(device=self.device, priority=int(torch.cuda.Stream.priority_range()[0]))
+            else:
+                self._prep = torch.cuda.Stream(device=self.device)
         tri = self._dev(triples, torch.int64)
         slot = self._prep_slot = 1 - getattr(self, "_prep_slot", 1)
         cur = torch.cuda.current_stream(self.device)

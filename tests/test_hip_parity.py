@@ -1741,12 +1741,16 @@ def _prep_ab_triples(case):
         U, I, B, n = 70000, 130000, 1024, 5 * 1024 + 3
     elif case == "wide_rows":                      # 2^25 + 5 user rows at a 262,144 batch: 8-byte entries
         U, I, B, n = (1 << 25) + 5, 40000, 262144, 262144 + 4099
+    elif case == "wave_users":                     # config 4's heights: the users' lists are cut into 1,024 small buckets
+        U, I, B, n = 10000000, 1000000, 262144, 262144 + 5000
     elif case == "wide_rows_both":                 # ... and 5,000,000 items (config 5's heights), one full batch, d = 128
         U, I, B, n = (1 << 25) + 5, 5000000, 262144, 262144
     else:
         raise KeyError(case)
     u, i, j = rng.randint(0, U, n), rng.randint(0, I, n), rng.randint(0, I, n)
-    if case in ("hot_small", "partitioned", "wide_rows", "wide_rows_both"):
+    if case == "wave_users":
+        u[0:B:4] = rng.randint(0, 3000, u[0:B:4].size)       # a quarter of batch 0's users among 3,000 rows: crowded buckets
+    if case in ("hot_small", "partitioned", "wide_rows", "wide_rows_both", "wave_users"):
         i[0:B:3] = 7 % I                              # a third of batch 0's positives on one item (an oversized bucket)
         j[1:B:25] = 7 % I
         u[2:B:12] = 11                                # ~B/12 occurrences of one user
@@ -1757,7 +1761,7 @@ def _prep_ab_triples(case):
     return U, I, B, np.stack([u, i, j], 1)
 
 
-@pytest.mark.parametrize("case", ["hot_small", "partitioned", "tiny_tables", "one_bucket_lists", "wide_rows", "wide_rows_both"])
+@pytest.mark.parametrize("case", ["hot_small", "partitioned", "tiny_tables", "one_bucket_lists", "wide_rows", "wide_rows_both", "wave_users"])
 def test_index_prep_by_hand_equals_the_library_sort_path(case, monkeypatch):
     """index_prep.hip (bucket partition + LDS sort, run records straight from the sorted buckets) against the library
     radix-sort path it replaces (SML_PREP=cub): the bare SGD epoch ends in bit-identical tables and losses -- same unique
@@ -1832,7 +1836,7 @@ def _expected_lists(tri, B):
 
 
 @pytest.mark.parametrize("mode", ["hand", "cub"])
-@pytest.mark.parametrize("case", ["hot_small", "partitioned", "tiny_tables", "wide_rows", "wide_rows_both", "one_bucket_lists"])
+@pytest.mark.parametrize("case", ["hot_small", "partitioned", "tiny_tables", "wide_rows", "wide_rows_both", "one_bucket_lists", "wave_users"])
 def test_index_lists_hold_every_duplicated_row_once_with_its_slots_in_order(case, mode, monkeypatch):
     """The prepared lists themselves, read back: every duplicated row of a batch has exactly one run record, its slots
     are the row's occurrences in order, rows that occur once are marked unique, hot runs are listed."""
