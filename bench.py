@@ -191,7 +191,11 @@ def a3_object(a, device):
     preparation included) and the algorithmic bytes per triple (24 + 6*d*s)."""
     import copy
     res = {}
-    for tag, users, items, d, dt, zipf in A3_CONFIGS:
+    order = os.environ.get("SML_A3_ORDER")          # (measurement aid: the legs in another order / a subset)
+    cfgs = A3_CONFIGS if not order else [c for t in order.split(",") for c in A3_CONFIGS if c[0] == t]
+    for tag, users, items, d, dt, zipf in cfgs:
+        while tag in res:
+            tag += "'"
         b = copy.copy(a)
         b.users, b.items, b.d, b.bare_dtype, b.item_zipf = users, items, d, dt, zipf
         # (an epoch is about a millisecond: 4 untimed + 16 timed epochs per configuration -- the first epochs after the

@@ -45,6 +45,25 @@ class HipEngine(object):
         self.tr_step = 0
         self.grad_hook = None  # set by sml_amd.dist for the multi-GPU TR stage
         self.dist = None       # sml_amd.dist.DistContext when the job spans several GPUs
+        self._plain_stream()   # (created before any CU-masked stream of the process: see there)
+
+    _PLAIN = {}      # device index -> the process's one side stream over all CUs
+
+    def _plain_stream(self):
+        """The side stream for work that may use the whole chip (the bare step's index preparation).  ONE per process and
+        device, created with the first engine -- before any CU-masked stream exists: the HIP runtime keeps a small pool
+        of hardware queues and hands a new stream the least-used one, and a queue made for hipExtStreamCreateWithCUMask
+        joins that pool WITH its mask.  A stream created after the masked ones can land on the 64-CU evaluation queue
+        and run four times slower (measured: every third stream of torch's pool, in a process that had partitioned the
+        chip).  A stream that exists already keeps the unmasked queue it was given."""
+        key = self.device.index or 0
+        st = HipEngine._PLAIN.get(key)
+        if st is None:
+            st = HipEngine._PLAIN[key] = torch.cuda.Stream(device=self.device)
+            with torch.cuda.stream(st):                  # (the runtime binds the queue at the stream's first use)
+                torch.empty(1, device=self.device).zero_()
+            st.synchronize()
+        return st
 
     def close(self):
         if getattr(self, "_ctx", None):
@@ -381,10 +400,11 @@ class HipEngine(object):
             k = int(os.environ.get("SML_PREP_CUS", "0"))
             if k > 0:                                    # the preparation confined to the last k compute units
                 self._prep = self._masked_stream(self._n_cus() - k, self._n_cus())
-            elif os.environ.get("SML_PREP_PRIO", "") == "low":
-                self._prep = torch.cuda.Stream(device=self.device, priority=int(torch.cuda.Stream.priority_range()[0]))
+            elif os.environ.get("SML_PREP_PRIO", "") in ("low", "high"):
+                lo, hi = torch.cuda.Stream.priority_range()
+                self._prep = torch.cuda.Stream(device=self.device, priority=int(lo if os.environ["SML_PREP_PRIO"] == "low" else hi))
             else:
-                self._prep = torch.cuda.Stream(device=self.device)
+                self._prep = self._plain_stream()
         tri = self._dev(triples, torch.int64)
         slot = self._prep_slot = 1 - getattr(self, "_prep_slot", 1)
         cur = torch.cuda.current_stream(self.device)
