@@ -521,8 +521,6 @@ int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
             a.hot_list = c->hot_list.p; a.hot_count = c->hot_count.p; a.hot_cap = c->hot_cap;
         }
     }
-    { const char* e = getenv("SML_PREP_DEBUG"); a.debug = e ? atoi(e) : 0; }
-    if (a.debug == 4) for (int T = 0; T < 2; ++T) if (a.t[T].hb > 0) { a.t[T].npass = (a.t[T].hb + 4) / 5; a.t[T].pbits = (a.t[T].hb + a.t[T].npass - 1) / a.t[T].npass; }
     HIPCHK(sml_launch_prep(a, narrow ? 4 : 8, st));
     if (dups) {
         if (!c->max_len_host) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->max_len_host), sizeof(int), hipHostMallocDefault));

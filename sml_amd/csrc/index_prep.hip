@@ -436,7 +436,7 @@ __device__ __forceinline__ void bucket_body(const SmlPrepArgs& a, int T, int b, 
     const BatchGeo g = batch_geo(a, b);
     const uint32_t pos0 = (uint32_t)(T ? 2 * g.start : g.start) + oc.x;
     const E* src = reinterpret_cast<const E*>(tb.ent) + pos0;
-    if (a.records || a.debug == 3) {
+    if (a.records) {
         for (int i = tid; i < S; i += 256) buf[0][i] = src[i];
     } else {
         // Duplicate filter: only occurrences of rows that occur at least twice need sorting (with uniform users that is
@@ -487,7 +487,6 @@ __device__ __forceinline__ void bucket_body(const SmlPrepArgs& a, int T, int b, 
         S = (int)total;
         if (S == 0) { if (tid == 0) tb.brc[(int64_t)b * tb.nbk + bin] = 0u; return; }
     }
-    if (a.debug == 1) { __syncthreads(); if (tid == 0) tb.vals[pos0] = (uint32_t)buf[0][S - 1]; return; }
     int cur = 0;
     const int R = (S + 255) >> 8;                     // rounds: every wavefront owns a contiguous stripe of R * 64 entries
     if (S <= 64 && tb.npass > 0) {
@@ -563,7 +562,6 @@ __device__ __forceinline__ void bucket_body(const SmlPrepArgs& a, int T, int b, 
     }
     __syncthreads();
     const E* sorted = buf[cur];
-    if (a.debug == 2) { if (tid == 0) tb.vals[pos0] = (uint32_t)sorted[S - 1]; return; }
     const uint32_t nrec = emit_bucket<E, 256>(a, tb, T, b, bin, pos0, S, [&](int q) { return sorted[q]; }, scratch);
     if (tid == 0 && tb.brc != nullptr) tb.brc[(int64_t)b * tb.nbk + bin] = nrec;
 }

@@ -207,7 +207,6 @@ struct SmlPrepArgs {
     SmlPrepTable t[2];           // users, items
     uint8_t* uniq; int64_t uniq_stride;
     uint32_t* hot_list; int* hot_count; int hot_cap; int* max_len;
-    int debug;                   // measurement builds only (SML_PREP_DEBUG): 1 bucket kernel stops after the load, 2 after the sort
     uint32_t* medium; int* n_medium;                  // same pairs: buckets k_prep_wave leaves to k_prep_bucket
     uint32_t* large; int* n_large; int large_cap;     // (table << 31 | list), bucket -- buckets the small kernel leaves
 };

@@ -126,6 +126,34 @@ def main():
     if pmc:
         with open(os.path.join(out, "%s_pmc_per_launch.json" % tag), "w") as f:
             json.dump(pmc, f, indent=1, sort_keys=True)
+    # the index preparation's own rate (bare runs): per prepared epoch, the k_prep_* kernels' time (kernel trace) and
+    # fabric bytes (FETCH x 2 + WRITE, KB -> bytes: the gfx950 correction of MI355X_MICROARCH.md)
+    prep = {}
+    for run in sorted(os.listdir(root)):
+        if not (run.startswith("bare_") and run.endswith("_stats")):
+            continue
+        name = run[:-6]
+        rows = {k: v for k, v in kernel_stats(os.path.join(root, run)).items() if k.startswith("k_prep_")}
+        epochs = rows.get("k_prep_hist", [0, 0.0])[0]
+        if not epochs:
+            continue
+        e = {"epochs_prepared": epochs, "triples_per_epoch": 1 << 22,
+             "us_per_epoch": sum(t for _, t in rows.values()) / 1e3 / epochs,
+             "kernels_us_per_epoch": {k: t / 1e3 / epochs for k, (c, t) in sorted(rows.items())}}
+        c = pmc.get(name, {})
+        by = 0.0
+        for k in rows:
+            if k in c and "FETCH_SIZE" in c[k] and "WRITE_SIZE" in c[k]:
+                by += c[k]["FETCH_SIZE"]["launches"] * (2.0 * c[k]["FETCH_SIZE"]["avg_counter_per_launch"]
+                                                        + c[k]["WRITE_SIZE"]["avg_counter_per_launch"]) * 1024.0
+        if by:
+            e["fabric_bytes_per_epoch"] = by / epochs
+            e["fabric_GBps"] = by / epochs / (e["us_per_epoch"] * 1e-6) / 1e9
+            e["algorithmic_bytes_per_epoch"] = (1 << 22) * (24 + 3)       # the triples once + a mark per occurrence
+        prep[name] = e
+    if prep:
+        with open(os.path.join(out, "%s_index_prep.json" % tag), "w") as f:
+            json.dump(prep, f, indent=1, sort_keys=True)
     print("summaries in", out, ":", sorted(os.listdir(out)))
 
 
