@@ -63,6 +63,20 @@ __device__ __forceinline__ BatchGeo batch_geo(const SmlPrepArgs& a, int b) {
     return g;
 }
 
+// XCD-aware block maps.  Workgroups go to the eight XCDs round-robin by their linear index, and each XCD has its own
+// L2: the scattered 4-byte entry stores and 1-byte mark stores of one batch only merge into whole lines before they
+// leave for HBM if they all pass through ONE L2 (a batch's entry arrays and marks are a few MB).  So the linear index
+// is laid out as ((batch group * items + item) * 8 + x) with batch = group * 8 + x: batch b's workgroups all run on XCD
+// b % 8, one batch of the group after the other.  Measured (FETCH_SIZE / WRITE_SIZE): see DESIGN.md.
+struct XcdMap { int b, item; };
+__device__ __forceinline__ XcdMap xcd_map(unsigned id, int items) {
+    const int x = (int)(id & 7u);
+    const unsigned rest = id >> 3;
+    XcdMap m; m.item = (int)(rest % (unsigned)items); m.b = (int)(rest / (unsigned)items) * 8 + x;
+    return m;
+}
+static inline unsigned xcd_grid(int nb, int items) { return (unsigned)(((nb + 7) / 8) * items * 8); }
+
 // ------------------------------------------------------------------------------------
 // k_prep_hist: grid (tpb, nb), 1024 threads, SML_PREP_IPT triples per thread.
 // Streams of a tile: 0 = users, 1 = positives, 2 = negatives (the item list's order is positives then negatives, so the
@@ -161,14 +175,16 @@ __global__ __launch_bounds__(1024) void k_prep_scan(SmlPrepArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
-// k_prep_scatter: same grid as k_prep_hist.  Occurrence order inside a tile: wavefront-major, then round, then lane --
+// k_prep_scatter: one workgroup per tile as in k_prep_hist, XCD-aware linear grid.  Occurrence order inside a tile: wavefront-major, then round, then lane --
 // i.e. ascending triple index; the wavefronts' counts per bucket are prefixed in wavefront order.
 // ------------------------------------------------------------------------------------
 template <typename E>
 __global__ __launch_bounds__(1024) void k_prep_scatter(SmlPrepArgs a) {
     __shared__ unsigned short cnt[16][SML_PREP_MAXBK];
     __shared__ uint32_t tbase[SML_PREP_MAXBK];
-    const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, wv = tid >> 6;
+    const XcdMap xm = xcd_map(blockIdx.x, a.tpb);
+    const int k = xm.item, b = xm.b, tid = threadIdx.x, wv = tid >> 6;
+    if (b >= a.nb) return;
     const BatchGeo g = batch_geo(a, b);
     if (k * SML_PREP_TT >= g.Bb) return;
     constexpr int IPT = SML_PREP_IPT;
@@ -329,17 +345,17 @@ __device__ __forceinline__ void prep_punt(const SmlPrepArgs& a, int T, int b, ui
     a.medium[2 * slot] = ((uint32_t)T << 31) | (uint32_t)b; a.medium[2 * slot + 1] = bin;
 }
 template <typename E>
-__global__ __launch_bounds__(256) void k_prep_wave(SmlPrepArgs a) {
+__global__ __launch_bounds__(256) void k_prep_wave(SmlPrepArgs a, int T) {
     __shared__ uint32_t bm_all[4][2][256];
     __shared__ E cand_all[4][64];
     __shared__ E sorted_all[4][64];
-    const int T = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const SmlPrepTable& tb = a.t[T];
-    if (!tb.wave) return;
-    const int64_t gidx = (int64_t)blockIdx.x * 4 + wv;               // bucket, list-major
-    const int b = (int)(gidx >> tb.lb);
-    const uint32_t bin = (uint32_t)gidx & (uint32_t)(tb.nbk - 1);
-    if (b >= a.nb) return;
+    const int quads = (tb.nbk + 3) >> 2;                             // four buckets of one list per workgroup
+    const XcdMap xm = xcd_map(blockIdx.x, quads);
+    const int b = xm.b;
+    const uint32_t bin = (uint32_t)(xm.item * 4 + wv);
+    if (b >= a.nb || bin >= (uint32_t)tb.nbk) return;
     const uint2 oc = tb.bk[(int64_t)b * tb.nbk + bin];
     const int S = (int)oc.y;
     uint32_t* brc = tb.brc + (int64_t)b * tb.nbk + bin;
@@ -575,8 +591,8 @@ __global__ __launch_bounds__(256, sizeof(E) == 4 ? 7 : 4) void k_prep_bucket(Sml
     __shared__ uint32_t dbase[512];
     __shared__ uint32_t scratch[8];
     if (!listed) {
-        const SmlPrepTable& tb = a.t[T];
-        bucket_body<E>(a, T, (int)(blockIdx.x >> tb.lb), blockIdx.x & (uint32_t)(tb.nbk - 1), buf, cnt, dbase, scratch);
+        const XcdMap xm = xcd_map(blockIdx.x, a.t[T].nbk);
+        if (xm.b < a.nb) bucket_body<E>(a, T, xm.b, (uint32_t)xm.item, buf, cnt, dbase, scratch);
         return;
     }
     const int n_medium = *a.n_medium;
@@ -731,14 +747,13 @@ hipError_t launch_prep(const SmlPrepArgs& a, hipStream_t st) {
     const dim3 tiles((unsigned)a.tpb, (unsigned)a.nb);
     k_prep_hist<<<tiles, dim3(1024), 0, st>>>(a);
     k_prep_scan<<<dim3((unsigned)a.nb, 2), dim3(1024), 0, st>>>(a);
-    k_prep_scatter<E><<<tiles, dim3(1024), 0, st>>>(a);
+    k_prep_scatter<E><<<dim3(xcd_grid(a.nb, a.tpb)), dim3(1024), 0, st>>>(a);
     const int nbk_max = a.t[0].nbk > a.t[1].nbk ? a.t[0].nbk : a.t[1].nbk;
-    if (a.t[0].wave || a.t[1].wave) {
-        k_prep_wave<E><<<dim3((unsigned)((a.nb * nbk_max + 3) / 4), 2), dim3(256), 0, st>>>(a);
-        k_prep_bucket<E><<<dim3(1024), dim3(256), 0, st>>>(a, 0, 1);
-    }
     for (int T = 0; T < 2; ++T)
-        if (!a.t[T].wave) k_prep_bucket<E><<<dim3((unsigned)(a.nb * a.t[T].nbk)), dim3(256), 0, st>>>(a, T, 0);
+        if (a.t[T].wave) k_prep_wave<E><<<dim3(xcd_grid(a.nb, (a.t[T].nbk + 3) / 4)), dim3(256), 0, st>>>(a, T);
+    if (a.t[0].wave || a.t[1].wave) k_prep_bucket<E><<<dim3(256), dim3(256), 0, st>>>(a, 0, 1);
+    for (int T = 0; T < 2; ++T)
+        if (!a.t[T].wave) k_prep_bucket<E><<<dim3(xcd_grid(a.nb, a.t[T].nbk)), dim3(256), 0, st>>>(a, T, 0);
     k_prep_large<E><<<dim3(256), dim3(1024), 0, st>>>(a);
     if (!a.records) k_prep_compact<<<dim3((unsigned)((nbk_max + SML_PREP_CG - 1) / SML_PREP_CG), (unsigned)a.nb, 2), dim3(256), 0, st>>>(a);
     return hipGetLastError();
