@@ -251,9 +251,10 @@ int sml_run_mf_grad(sml_ctx* ctx, const float* theta, const float* user_last, co
  * SGD: W -= lr * dL/dW with duplicate rows' gradients summed before the write.
  * dtype_bytes: 4 (fp32 tables) or 2 (fp16 tables, fp32 arithmetic).
  * batch_loss[n_batches] as above.
- * prepared_slot: -1 builds the epoch's index lists (sort by (batch,row) -- 32-bit keys when the
- * batch count and n_user / n_item allow -- unique marks, compacted run records of the duplicated
- * rows) inline on `stream`; 0/1 uses the lists a previous
+ * prepared_slot: -1 builds the epoch's index lists (per batch: a stable partition of the occurrences
+ * by low row bits, every bucket sorted in LDS -- packed 4-byte entries when n_user / n_item and the
+ * batch size allow -- unique marks, compacted run records of the duplicated rows; index_prep.hip)
+ * inline on `stream`; 0/1 uses the lists a previous
  * sml_embed_loss_sgd_prepare call built for the SAME triples/n/batch -- so a caller can
  * prepare epoch e+1 on a side stream while epoch e runs.  No host wait either way: the call QUERIES whether
  * the lists it uses are complete; if they are (prepared ahead) and hold no hot run, the hot-row kernels are
