@@ -607,8 +607,14 @@ __global__ __launch_bounds__(256, sizeof(E) == 4 ? 7 : 4) void k_prep_bucket(Sml
 // k_prep_large: the oversized buckets, one 1024-thread workgroup each (grid-stride over the list k_prep_scan built).
 // The same stable passes, 4096 entries at a time, between the two entry arrays.
 // ------------------------------------------------------------------------------------
+// buckets of up to SML_PREP_LDSCAP bytes of entries stay in LDS between the passes (the wavefronts hold their stripes in
+// registers while the buffer is rewritten); larger ones go chunk-wise between the two global entry arrays
+#define SML_PREP_LDSCAP 98304
 template <typename E>
 __global__ __launch_bounds__(1024) void k_prep_large(SmlPrepArgs a) {
+    constexpr int CAP = SML_PREP_LDSCAP / (int)sizeof(E);            // 24,576 four-byte entries: 24 per thread
+    constexpr int RMAX = CAP / 1024;
+    __shared__ E lbuf[CAP];
     __shared__ unsigned short cnt[16][512];
     __shared__ uint32_t dbase[512];
     __shared__ uint32_t wsum[17];
@@ -625,6 +631,51 @@ __global__ __launch_bounds__(1024) void k_prep_large(SmlPrepArgs a) {
         const uint32_t pos0 = (uint32_t)(T ? 2 * g.start : g.start) + oc.x;
         E* src = reinterpret_cast<E*>(tb.ent) + pos0;
         E* dst = reinterpret_cast<E*>(tb.ent2) + pos0;
+        __syncthreads();                                         // the previous bucket's readers of the LDS arrays are done
+        if (S <= CAP) {
+            // ---- in LDS: wavefront w owns the stripe [w * R * 64, (w + 1) * R * 64) of the bucket, R rounds of 64
+            const int R = (S + 1023) >> 10;
+            for (int i = tid; i < S; i += 1024) lbuf[i] = src[i];
+            for (int p = 0; p < tb.npass; ++p) {
+                const int lo = p * tb.pbits, bits = min(tb.pbits, tb.hb - lo), nd = 1 << bits;
+                for (int i = lane; i < nd; i += 64) cnt[wv][i] = 0;
+                __syncthreads();                                 // (the bucket is loaded / the previous pass has landed)
+                E ev[RMAX]; unsigned short wr[RMAX];
+#pragma unroll
+                for (int r = 0; r < RMAX; ++r) {
+                    if (r < R) {
+                        const int i = wv * (R * 64) + r * 64 + lane;
+                        const bool valid = i < S;
+                        ev[r] = valid ? lbuf[i] : (E)0;
+                        wr[r] = (unsigned short)wave_rank(cnt[wv], (ent_hi<E>(ev[r], tb.vb) >> lo) & (uint32_t)(nd - 1), valid, bits);
+                    }
+                }
+                __syncthreads();                                 // every stripe is in registers, every count is in
+                uint32_t tot = 0;
+                if (tid < nd) {
+#pragma unroll
+                    for (int w2 = 0; w2 < 16; ++w2) { const uint32_t c = cnt[w2][tid]; cnt[w2][tid] = (unsigned short)tot; tot += c; }
+                }
+                const uint32_t ex = block_excl_scan_1024(tot, wsum);
+                if (tid < nd) dbase[tid] = ex;
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < RMAX; ++r) {
+                    if (r < R) {
+                        const int i = wv * (R * 64) + r * 64 + lane;
+                        if (i < S) {
+                            const uint32_t dg = (ent_hi<E>(ev[r], tb.vb) >> lo) & (uint32_t)(nd - 1);
+                            lbuf[dbase[dg] + cnt[wv][dg] + wr[r]] = ev[r];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            const E* sorted = lbuf;
+            const uint32_t nrec = emit_bucket<E, 1024>(a, tb, T, b, bin, pos0, S, [&](int q) { return sorted[q]; }, scratch);
+            if (tid == 0 && tb.brc != nullptr) tb.brc[(int64_t)b * tb.nbk + bin] = nrec;
+            continue;
+        }
         for (int p = 0; p < tb.npass; ++p) {
             const int lo = p * tb.pbits, bits = min(tb.pbits, tb.hb - lo), nd = 1 << bits;
             __syncthreads();
@@ -648,7 +699,7 @@ __global__ __launch_bounds__(1024) void k_prep_large(SmlPrepArgs a) {
             }
             __syncthreads();
             for (int c0 = 0; c0 < S; c0 += 4096) {
-                for (int i = tid; i < 16 * nd; i += 1024) cnt[i / nd][i % nd] = 0;
+                for (int i = lane; i < nd; i += 64) cnt[wv][i] = 0;
                 __syncthreads();
                 E ev[4]; uint32_t wr[4];
 #pragma unroll
