@@ -440,19 +440,28 @@ __global__ __launch_bounds__(256) void k_prep_wave(SmlPrepArgs a, int T) {
 // ------------------------------------------------------------------------------------
 // bucket_body / k_prep_bucket: 256 threads per bucket; buckets of at most SML_PREP_SMALL entries.
 // ------------------------------------------------------------------------------------
-template <typename E>
+template <typename E, bool DIRECT = false>
 __device__ __forceinline__ void bucket_body(const SmlPrepArgs& a, int T, int b, uint32_t bin, E (*buf)[SML_PREP_SMALL],
                                             unsigned short (*cnt)[512], uint32_t* dbase, uint32_t* scratch) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const SmlPrepTable& tb = a.t[T];
-    const uint2 oc = tb.bk[(int64_t)b * tb.nbk + bin];             // (first position inside the list, entries)
+    const BatchGeo g = batch_geo(a, b);
+    // DIRECT (records mode, every list one bucket of at most SML_PREP_SMALL occurrences -- the MF stage's batches): the
+    // list is read straight from the triples, there is no partition
+    const uint2 oc = DIRECT ? make_uint2(0u, (uint32_t)(T ? 2 * g.Bb : g.Bb)) : tb.bk[(int64_t)b * tb.nbk + bin];   // (first position inside the list, entries)
     int S = (int)oc.y;
     if (S == 0 && tid == 0 && tb.brc != nullptr) tb.brc[(int64_t)b * tb.nbk + bin] = 0u;
     if (S == 0 || S > SML_PREP_SMALL) return;
-    const BatchGeo g = batch_geo(a, b);
     const uint32_t pos0 = (uint32_t)(T ? 2 * g.start : g.start) + oc.x;
     const E* src = reinterpret_cast<const E*>(tb.ent) + pos0;
-    if (a.records) {
+    if (DIRECT) {
+        for (int i = tid; i < S; i += 256) {
+            const int64_t t = T == 0 ? i : (i < g.Bb ? i : i - g.Bb);
+            const uint32_t row = (uint32_t)a.tri[(g.start + t) * 3 + (T == 0 ? 0 : (i < g.Bb ? 1 : 2))];
+            const uint32_t val = T == 0 ? (uint32_t)i : g.ioff + (uint32_t)i;
+            buf[0][i] = sizeof(E) == 8 ? (E)(((uint64_t)row << 32) | val) : (E)(((E)row << tb.vb) | (E)val);
+        }
+    } else if (a.records) {
         for (int i = tid; i < S; i += 256) buf[0][i] = src[i];
     } else {
         // Duplicate filter: only occurrences of rows that occur at least twice need sorting (with uniform users that is
@@ -583,13 +592,17 @@ __device__ __forceinline__ void bucket_body(const SmlPrepArgs& a, int T, int b, 
 }
 
 // listed == 0: one workgroup per bucket of table T (grid nb * nbk).  listed == 1: the buckets k_prep_wave left
-// (grid-stride over `medium`).
+// (grid-stride over `medium`).  listed == 2: one workgroup per list, read straight from the triples.
 template <typename E>
 __global__ __launch_bounds__(256, sizeof(E) == 4 ? 7 : 4) void k_prep_bucket(SmlPrepArgs a, int T, int listed) {
     __shared__ E buf[2][SML_PREP_SMALL];
     __shared__ unsigned short cnt[4][512];
     __shared__ uint32_t dbase[512];
     __shared__ uint32_t scratch[8];
+    if (listed == 2) {                                           // straight from the triples: workgroup = (batch, table)
+        bucket_body<E, true>(a, (int)(blockIdx.x & 1u), (int)(blockIdx.x >> 1), 0u, buf, cnt, dbase, scratch);
+        return;
+    }
     if (!listed) {
         const XcdMap xm = xcd_map(blockIdx.x, a.t[T].nbk);
         if (xm.b < a.nb) bucket_body<E>(a, T, xm.b, (uint32_t)xm.item, buf, cnt, dbase, scratch);
@@ -795,6 +808,10 @@ __global__ __launch_bounds__(256) void k_prep_compact(SmlPrepArgs a) {
 
 template <typename E>
 hipError_t launch_prep(const SmlPrepArgs& a, hipStream_t st) {
+    if (a.records && a.t[0].nbk == 1 && a.t[1].nbk == 1 && 2 * (int64_t)a.batch <= SML_PREP_SMALL) {
+        k_prep_bucket<E><<<dim3((unsigned)(2 * a.nb)), dim3(256), 0, st>>>(a, 0, 2);       // ONE launch: no partition
+        return hipGetLastError();
+    }
     const dim3 tiles((unsigned)a.tpb, (unsigned)a.nb);
     k_prep_hist<<<tiles, dim3(1024), 0, st>>>(a);
     k_prep_scan<<<dim3((unsigned)a.nb, 2), dim3(1024), 0, st>>>(a);
