@@ -453,20 +453,37 @@ static bool prep_by_hand() {
 }
 
 // The same lists as sort_epoch below, built by index_prep.hip (one GPU's own occurrences; no library code).
+// mode 0: this rank's own occurrences.  1: replicated items on several GPUs (bx: the item lists are the JOB's).
+// 2 / 3: the item-sharded step's lists A (users + the job's occurrences of the tail rows this rank owns) and B (this
+// rank's own occurrences of head rows; no users) -- sh, rows_cap.  See occ_of in index_prep.hip.
 int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_tiles, int64_t n_user, int64_t n_item,
-               bool dups, hipStream_t st, const sml_batch_plan* plan) {
+               bool dups, hipStream_t st, const sml_batch_plan* plan, int mode = 0, const sml_bare_exchange* bx = nullptr,
+               const sml_bare_shard* sh = nullptr, int64_t rows_cap = 0) {
     const int64_t nb = plan ? plan->n_batches : (n + batch - 1) / batch;
     c->by_hand = true;
     if (n == 0) { c->n = 0; c->batch = batch; c->triples = tri; return SML_OK; }
+    const int W = mode == 1 ? bx->world : (mode == 2 ? sh->world : 1);
+    const int nis = 2 * W;                                  // item streams per tile
+    const int64_t n_items = (int64_t)nis * n;               // item occurrences of the epoch's lists (upper bound in modes 2 / 3)
+    if (n_items > 0x7fffffff) return fail(SML_EINVAL, "index preparation", "too many item occurrences in one epoch");
+    const bool has_users = mode != 3, allruns_i = mode != 0;
     SmlPrepArgs a;
     memset(&a, 0, sizeof(a));
     a.tri = tri; a.n = n; a.batch = batch; a.nb = (int)nb; a.tpb = (batch + SML_PREP_TT - 1) / SML_PREP_TT;
     a.boff = plan ? plan->batch_off_dev : nullptr; a.pad_tiles = pad_tiles; a.records = dups ? 0 : 1;
+    a.mode = mode; a.has_users = has_users ? 1 : 0; a.nis = nis;
+    if (mode == 1) { a.items_all = bx->items_all; a.val_q = (int64_t)2 * batch; }
+    if (mode == 2) { a.items_all = sh->items_all; a.val_q = rows_cap; }
+    if (mode >= 2) { a.head_rows = sh->head_rows; a.shard_rows = sh->shard_rows; a.shard_rank = sh->rank; }
     const int64_t ioff_max = pad_tiles ? ((int64_t)(batch + SML_R - 1) / SML_R) * SML_R : batch;
-    int vb[2] = {ceil_log2(batch), ceil_log2(ioff_max + 2 * (int64_t)batch)};      // values: users < batch, items < ioff + 2 * batch
-    int lb[2], rb[2] = {n_user > 0 ? ceil_log2(n_user) : 32, n_item > 0 ? ceil_log2(n_item) : 32};
+    // values: users < batch; items < ioff + 2 * batch (own), < world * 2 * batch (mode 1), < world * rows_cap (mode 2), < 3 * batch (mode 3)
+    const int64_t max_val_i = mode == 1 ? (int64_t)W * 2 * batch : mode == 2 ? (int64_t)W * rows_cap : mode == 3 ? (int64_t)3 * batch
+                                                                                                                  : ioff_max + 2 * (int64_t)batch;
+    const int64_t rows_i = mode == 2 ? sh->shard_rows : mode == 3 ? (sh->head_rows > 0 ? sh->head_rows : 1) : n_item;
+    int vb[2] = {ceil_log2(batch), ceil_log2(max_val_i)};
+    int lb[2], rb[2] = {n_user > 0 ? ceil_log2(n_user) : 32, rows_i > 0 ? ceil_log2(rows_i) : 32};
     for (int T = 0; T < 2; ++T) {
-        const int64_t max_n = (int64_t)(T ? 2 : 1) * batch;
+        const int64_t max_n = (int64_t)(T ? nis : 1) * batch;
         lb[T] = max_n <= SML_PREP_SMALL ? 0 : ceil_log2((max_n + 1023) / 1024);
         if (lb[T] > 10) lb[T] = 10;
     }
@@ -479,15 +496,16 @@ int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
     Buf<uint32_t>* bko[2] = {&c->bko_u, &c->bko_i};
     Buf<uint32_t>* bkc[2] = {&c->bkc_u, &c->bkc_i};
     HIPCHK(c->key_u.ensure((size_t)n + 1)); HIPCHK(c->key_u2.ensure((size_t)n + 1));
-    HIPCHK(c->key_i.ensure((size_t)2 * n + 1)); HIPCHK(c->key_i2.ensure((size_t)2 * n + 1));
-    HIPCHK(c->val_u2.ensure((size_t)n + 1)); HIPCHK(c->val_i2.ensure((size_t)2 * n + 1));
+    HIPCHK(c->key_i.ensure((size_t)n_items + 1)); HIPCHK(c->key_i2.ensure((size_t)n_items + 1));
+    HIPCHK(c->val_u2.ensure((size_t)n + 1)); HIPCHK(c->val_i2.ensure((size_t)n_items + 1));
     HIPCHK(c->n_sel.ensure(4));
-    const size_t large_cap = (size_t)(3 * n / SML_PREP_SMALL) + 8;
+    const size_t large_cap = (size_t)((n + n_items) / SML_PREP_SMALL) + 8;
     HIPCHK(c->large.ensure(2 * large_cap));
+    const size_t runs_i_cap = (size_t)(allruns_i ? n_items : n) + 8;       // duplicated runs: at most every second occurrence
     if (dups) {
         HIPCHK(c->uniq.ensure((size_t)3 * nb * batch));
-        HIPCHK(c->runs_u.ensure((size_t)n / 2 + 8)); HIPCHK(c->runs_i.ensure((size_t)n + 8));
-        HIPCHK(c->stage_u.ensure((size_t)n / 2 + 8)); HIPCHK(c->stage_i.ensure((size_t)n + 8));
+        HIPCHK(c->runs_u.ensure((size_t)n / 2 + 8)); HIPCHK(c->runs_i.ensure(runs_i_cap));
+        HIPCHK(c->stage_u.ensure((size_t)n / 2 + 8)); HIPCHK(c->stage_i.ensure(runs_i_cap));
         HIPCHK(c->off_u.ensure((size_t)nb + 1)); HIPCHK(c->off_i.ensure((size_t)nb + 1));
         HIPCHK(c->cnt_u.ensure((size_t)nb + 1)); HIPCHK(c->cnt_i.ensure((size_t)nb + 1));
     } else {
@@ -498,8 +516,11 @@ int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
         t.lb = lb[T]; t.nbk = 1 << lb[T];
         t.hb = rb[T] > lb[T] ? rb[T] - lb[T] : 0; t.vb = vb[T];
         t.npass = (t.hb + 8) / 9; t.pbits = t.npass ? (t.hb + t.npass - 1) / t.npass : 0;
-        t.wave = (dups && ((int64_t)(T ? 2 : 1) * batch >> t.lb) <= 256 && !getenv("SML_PREP_NOWAVE")) ? 1 : 0;
-        HIPCHK(hist[T]->ensure((size_t)nb * (T ? 2 : 1) * a.tpb * t.nbk));
+        t.allruns = (T == 1 && allruns_i) ? 1 : 0; t.rshift = t.allruns ? 0 : 1;
+        t.lmul = T ? nis : 1;
+        t.ntile = T ? nis * a.tpb : (has_users ? a.tpb : 0);
+        t.wave = (dups && !t.allruns && ((int64_t)(T ? nis : 1) * batch >> t.lb) <= 256 && !getenv("SML_PREP_NOWAVE")) ? 1 : 0;
+        HIPCHK(hist[T]->ensure((size_t)nb * (T ? nis : 1) * a.tpb * t.nbk));
         HIPCHK(bko[T]->ensure((size_t)2 * nb * t.nbk)); HIPCHK(bkc[T]->ensure((size_t)nb * t.nbk));
         t.hist = hist[T]->p; t.bk = reinterpret_cast<uint2*>(bko[T]->p); t.brc = dups ? bkc[T]->p : nullptr;
         t.ent = T ? (void*)c->key_i.p : (void*)c->key_u.p; t.ent2 = T ? (void*)c->key_i2.p : (void*)c->key_u2.p;
@@ -512,10 +533,10 @@ int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
     a.medium = c->medium.p; a.n_medium = c->n_sel.p;
     c->hot_cap = 0;
     if (dups) {
-        a.uniq = c->uniq.p; a.uniq_stride = (int64_t)3 * batch; a.max_len = c->n_sel.p + 2;
-        const int64_t hot_cap64 = ((int64_t)batch + 2 * (int64_t)batch) / SML_HOT + 8;
+        a.uniq = has_users ? c->uniq.p : nullptr; a.uniq_stride = (int64_t)3 * batch; a.max_len = c->n_sel.p + 2;
+        const int64_t hot_cap64 = ((int64_t)batch + (int64_t)nis * batch) / SML_HOT + 8;
         const int hot_cap = (int)(hot_cap64 < 0x7fffffff ? hot_cap64 : 0x7fffffff);
-        c->hot_cap = (batch >= 4096 && hot_cap <= SML_HOT_MAXCAP) ? hot_cap : 0;
+        c->hot_cap = (mode <= 1 && batch >= 4096 && hot_cap <= SML_HOT_MAXCAP) ? hot_cap : 0;      // (the sharded step has no hot-row path)
         if (c->hot_cap) {
             HIPCHK(c->hot_list.ensure((size_t)nb * c->hot_cap * 3)); HIPCHK(c->hot_count.ensure((size_t)nb));
             a.hot_list = c->hot_list.p; a.hot_count = c->hot_count.p; a.hot_cap = c->hot_cap;
@@ -528,7 +549,7 @@ int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
         HIPCHK(hipMemcpyAsync(c->max_len_host, c->n_sel.p + 2, sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(hipEventRecord(c->ready, st));
     }
-    c->n = n; c->batch = batch; c->triples = tri; c->world = 1;
+    c->n = mode >= 2 ? -1 : n; c->batch = batch; c->triples = tri; c->world = W;
     return SML_OK;
 }
 
@@ -539,7 +560,7 @@ int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
 int sort_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_tiles, int64_t n_user, int64_t n_item,
                bool dups, hipStream_t st, const sml_batch_plan* plan = nullptr, const sml_bare_exchange* bx = nullptr) {
     // bx (bare step on several GPUs): the item lists are the JOB's -- every rank's 2n item occurrences
-    if (!bx && prep_by_hand()) return prep_epoch(c, tri, n, batch, pad_tiles, n_user, n_item, dups, st, plan);
+    if (prep_by_hand() && (!bx || dups)) return prep_epoch(c, tri, n, batch, pad_tiles, n_user, n_item, dups, st, plan, bx ? 1 : 0, bx);
     c->by_hand = false;
     const int64_t n_items = bx ? (int64_t)bx->world * 2 * n : 2 * n;
     const int64_t seg_i = bx ? (int64_t)bx->world * 2 * batch : (int64_t)2 * batch;       // item occurrences of a full batch
@@ -623,6 +644,12 @@ int sort_epoch_sharded(IndexSet* A, IndexSet* Bset, const int64_t* tri, int64_t 
                        int64_t rows_cap, hipStream_t st) {
     const int W = sh->world;
     const int64_t nb = (n + batch - 1) / batch;
+    if (prep_by_hand()) {
+        int rc = prep_epoch(A, tri, n, batch, 0, n_user, 0, true, st, nullptr, 2, nullptr, sh, rows_cap);
+        if (!rc && sh->head_rows > 0) rc = prep_epoch(Bset, tri, n, batch, 0, n_user, 0, true, st, nullptr, 3, nullptr, sh, rows_cap);
+        return rc;
+    }
+    A->by_hand = false; Bset->by_hand = false;
     const int bb = ceil_log2(nb + 1);
     for (int pass = 0; pass < 2; ++pass) {
         IndexSet* c = pass ? Bset : A;
@@ -1312,6 +1339,7 @@ int sml_embed_loss_sgd_epoch_sharded(sml_ctx* ctx, void* w_user, int64_t n_user,
         memset(&u, 0, sizeof(u));
         u.run_u = A->runs_u.p; u.run_i = A->runs_i.p; u.off_u = A->off_u.p; u.off_i = A->off_i.p; u.batch_index = (int)b;
         u.val_u = A->val_u2.p; u.val_i = A->val_i2.p;
+        if (A->by_hand) { u.cnt_u = A->cnt_u.p; u.cnt_i = A->cnt_i.p; }
         u.dx = ctx->dx.p; u.dx_i = rows_poll.slot0; u.w_user = w_user; u.w_item = sh->item_shard[me]; u.lr = lr;
         ctx->prof.begin(PC_SEG_SGD, st); HIPCHK(sml_launch_run_sgd(d, dtype_bytes, u, (int64_t)B / 2 + (int64_t)W * 2 * B, st)); ctx->prof.end(st);
         // (4) tell every rank: this owner is done with batch b
@@ -1328,6 +1356,7 @@ int sml_embed_loss_sgd_epoch_sharded(sml_ctx* ctx, void* w_user, int64_t n_user,
             memset(&hgt, 0, sizeof(hgt));
             hgt.run_u = Bs->runs_i.p; hgt.run_i = Bs->runs_i.p; hgt.off_u = Bs->off_u.p; hgt.off_i = Bs->off_i.p; hgt.batch_index = (int)b;
             hgt.val_u = Bs->val_i2.p; hgt.val_i = Bs->val_i2.p;
+            if (Bs->by_hand) { hgt.cnt_u = Bs->cnt_u.p; hgt.cnt_i = Bs->cnt_i.p; }
             hgt.dx = ctx->dx.p; hgt.dx_i = ctx->dx.p; hgt.w_user = ctx->head_part.p; hgt.w_item = ctx->head_part.p;
             hgt.lr = -1.0f;           // 0 - (-1) * sum = the sum itself, exactly
             ctx->prof.begin(PC_SEG_SGD, st); HIPCHK(sml_launch_run_sgd(d, 4, hgt, (int64_t)2 * B, st)); ctx->prof.end(st);

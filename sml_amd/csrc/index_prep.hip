@@ -116,6 +116,114 @@ __global__ __launch_bounds__(1024) void k_prep_hist(SmlPrepArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Other occurrence sources (mode != 0): the job-wide item lists of the bare step on several GPUs.
+//   mode 1  replicated items: users = this rank's; items = every rank's (rank q, element e, column c) from items_all;
+//   mode 2  sharded items, list A: users = this rank's; items = the JOB's occurrences of the tail rows this rank owns
+//           (row index local to the shard); occurrences of other owners / of head rows are left out;
+//   mode 3  sharded items, list B: no users; items = this rank's own occurrences of head rows.
+// Streams of a tile: [users] then (q, c) for q in ranks, c in {positive, negative}; the item list's order is stream-major.
+// ------------------------------------------------------------------------------------
+struct Occ { uint32_t row, val; bool valid; };
+__device__ __forceinline__ Occ occ_of(const SmlPrepArgs& a, const BatchGeo& g, int s, int t) {
+    Occ o; o.valid = t < g.Bb; o.row = 0u; o.val = 0u;
+    if (!o.valid) return o;
+    if (a.has_users && s == 0) { o.row = (uint32_t)a.tri[(g.start + t) * 3]; o.val = (uint32_t)t; return o; }
+    const int si = s - a.has_users, q = si >> 1, c = si & 1;
+    if (a.mode == 3) {
+        const int64_t raw = a.tri[(g.start + t) * 3 + 1 + c];
+        o.valid = raw < a.head_rows; o.row = (uint32_t)raw; o.val = (uint32_t)((c ? 2 * g.Bb : g.Bb) + t);
+        return o;
+    }
+    const int64_t raw = a.items_all[((int64_t)q * a.n + g.start + t) * 2 + c];
+    o.val = (uint32_t)((int64_t)q * a.val_q + (c ? g.Bb : 0) + t);
+    if (a.mode == 1) { o.row = (uint32_t)raw; return o; }
+    const int64_t r = raw - a.head_rows;
+    o.valid = r >= 0 && r / a.shard_rows == a.shard_rank;
+    o.row = (uint32_t)(r - (int64_t)a.shard_rank * a.shard_rows);
+    return o;
+}
+
+__global__ __launch_bounds__(1024) void k_prep_hist_x(SmlPrepArgs a) {
+    __shared__ uint32_t h[SML_PREP_MAXBK];
+    const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const BatchGeo g = batch_geo(a, b);
+    if (k == 0 && b == 0 && tid < 4) a.n_medium[tid] = 0;
+    const int t0 = k * SML_PREP_TT + (tid >> 6) * (64 * SML_PREP_IPT) + (tid & 63);
+    const int ns = a.has_users + a.nis;
+    for (int s = 0; s < ns; ++s) {
+        const int T = (a.has_users && s == 0) ? 0 : 1;
+        const SmlPrepTable& tb = a.t[T];
+        const int nbk = tb.nbk;
+        __syncthreads();
+        for (int i = tid; i < nbk; i += 1024) h[i] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SML_PREP_IPT; ++r) {
+            const Occ o = occ_of(a, g, s, t0 + r * 64);
+            if (nbk == 1) { const uint64_t m = __ballot(o.valid); if ((tid & 63) == 0 && m) atomicAdd(&h[0], (uint32_t)__popcll(m)); }
+            else if (o.valid) atomicAdd(&h[o.row & (uint32_t)(nbk - 1)], 1u);
+        }
+        __syncthreads();
+        const int tile = T == 0 ? k : (s - a.has_users) * a.tpb + k;
+        uint32_t* out = tb.hist + ((int64_t)b * tb.ntile + tile) * nbk;
+        for (int i = tid; i < nbk; i += 1024) out[i] = h[i];
+    }
+}
+
+template <typename E>
+__global__ __launch_bounds__(1024) void k_prep_scatter_x(SmlPrepArgs a) {
+    __shared__ unsigned short cnt[16][SML_PREP_MAXBK];
+    __shared__ uint32_t tbase[SML_PREP_MAXBK];
+    const XcdMap xm = xcd_map(blockIdx.x, a.tpb);
+    const int k = xm.item, b = xm.b, tid = threadIdx.x, wv = tid >> 6;
+    if (b >= a.nb) return;
+    const BatchGeo g = batch_geo(a, b);
+    if (k * SML_PREP_TT >= g.Bb) return;
+    constexpr int IPT = SML_PREP_IPT;
+    const int t0 = k * SML_PREP_TT + wv * (64 * IPT) + (tid & 63);
+    const int ns = a.has_users + a.nis;
+    for (int s = 0; s < ns; ++s) {
+        const int T = (a.has_users && s == 0) ? 0 : 1;
+        const SmlPrepTable& tb = a.t[T];
+        const int nbk = tb.nbk, lb = tb.lb;
+        const int tile = T == 0 ? k : (s - a.has_users) * a.tpb + k;
+        const uint32_t* base = tb.hist + ((int64_t)b * tb.ntile + tile) * nbk;
+        __syncthreads();                                    // the previous stream's readers of cnt / tbase are done
+        if (nbk >= 2) { for (int i = tid; i < 8 * nbk; i += 1024) reinterpret_cast<uint32_t*>(&cnt[(2 * i) >> lb][0])[((2 * i) & (nbk - 1)) >> 1] = 0u; }
+        else if (tid < 16) cnt[tid][0] = 0;
+        for (int i = tid; i < nbk; i += 1024) tbase[i] = base[i];
+        __syncthreads();
+        Occ o[IPT]; uint32_t wr[IPT];
+#pragma unroll
+        for (int r = 0; r < IPT; ++r) {
+            o[r] = occ_of(a, g, s, t0 + r * 64);
+            wr[r] = wave_rank(cnt[wv], o[r].row & (uint32_t)(nbk - 1), o[r].valid, lb);
+        }
+        __syncthreads();
+        for (int i = tid; i < nbk; i += 1024) {
+            uint32_t run = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) { const uint32_t c = cnt[w][i]; cnt[w][i] = (unsigned short)run; run += c; }
+        }
+        __syncthreads();
+        E* ent = reinterpret_cast<E*>(tb.ent);
+        // marks (this rank's own occurrences): users start at "once"; the item rows are never updated in place here
+        uint8_t* uniq = (a.uniq && T == 0) ? a.uniq + (int64_t)b * a.uniq_stride : nullptr;
+#pragma unroll
+        for (int r = 0; r < IPT; ++r) {
+            const int t = t0 + r * 64;
+            if (uniq && t < g.Bb) { uniq[t] = 1; uniq[g.Bb + t] = 0; uniq[2 * g.Bb + t] = 0; }
+            if (o[r].valid) {
+                const uint32_t bin = o[r].row & (uint32_t)(nbk - 1);
+                const uint32_t dest = tbase[bin] + cnt[wv][bin] + wr[r];
+                const E hi = (E)(o[r].row >> lb);
+                ent[dest] = sizeof(E) == 8 ? (E)(((uint64_t)hi << 32) | (uint64_t)o[r].val) : (E)((hi << tb.vb) | (E)o[r].val);
+            }
+        }
+    }
+}
+
 // exclusive scan of one value per thread over a 1024-thread block (wave shuffles + 16 wave totals)
 __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* wsum /*[17]*/) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -140,9 +248,14 @@ __global__ __launch_bounds__(1024) void k_prep_scan(SmlPrepArgs a) {
     const int b = blockIdx.x, T = blockIdx.y, tid = threadIdx.x;
     const SmlPrepTable& tb = a.t[T];
     const BatchGeo g = batch_geo(a, b);
-    const int nbk = tb.nbk, lb = tb.lb, ntile = T ? 2 * a.tpb : a.tpb;
-    const int64_t list_start = T ? 2 * g.start : g.start;
+    const int nbk = tb.nbk, lb = tb.lb, ntile = tb.ntile;
+    const int64_t list_start = (int64_t)tb.lmul * g.start;
     uint32_t* H = tb.hist + (int64_t)b * ntile * nbk;
+    if (ntile == 0) {                                                // a table without occurrences (the head list has no users)
+        if (tid < nbk) tb.bk[(int64_t)b * nbk + tid] = make_uint2(0u, 0u);
+        if (tid == 0 && tb.run_off != nullptr) tb.run_off[b] = 0;
+        return;
+    }
     // all 1024 threads: thread (group, bin) owns a contiguous share of the tiles
     const int ngrp = 1024 >> lb, grp = tid >> lb, bin = tid & (nbk - 1);
     const int per = (ntile + ngrp - 1) / ngrp, k0 = min(ntile, grp * per), k1 = min(ntile, k0 + per);
@@ -169,7 +282,7 @@ __global__ __launch_bounds__(1024) void k_prep_scan(SmlPrepArgs a) {
         }
     }
     if (tid == 0) {
-        if (tb.run_off != nullptr) tb.run_off[b] = (int)(list_start / 2);
+        if (tb.run_off != nullptr) tb.run_off[b] = (int)(list_start >> tb.rshift);
         if (T == 0 && a.hot_count != nullptr) a.hot_count[b] = 0;
     }
 }
@@ -255,7 +368,7 @@ __device__ __forceinline__ uint32_t emit_bucket(const SmlPrepArgs& a, const SmlP
     // compact mode: the bucket's records go to ITS stretch of the staging array (a bucket of S occurrences has at most
     // S/2 duplicated runs, and floor(pos0/2) + floor(S/2) <= floor((pos0+S)/2): the stretches do not overlap), in
     // position order -- no counter is shared between workgroups; k_prep_compact closes the gaps.
-    SmlRun* out = a.records ? tb.runs : tb.runs_tmp + (pos0 >> 1);
+    SmlRun* out = a.records ? tb.runs : tb.runs_tmp + (pos0 >> tb.rshift);
     uint32_t done = 0;                                            // compact records of earlier trips (block-uniform)
 #pragma unroll 1
     for (int q0 = 0; q0 < S; q0 += NT) {                          // block-uniform trip count
@@ -270,7 +383,7 @@ __device__ __forceinline__ uint32_t emit_bucket(const SmlPrepArgs& a, const SmlP
         const bool head = in && prev != rh, tail = in && next != rh;
         const bool dup = in && !(head && tail);
         const uint32_t val = ent_val<E>(e, vb);
-        if (a.records) {
+        if (a.records || tb.allruns) {                              // every occurrence is listed (and no mark is this list's)
             if (in) tb.vals[pos0 + q] = val;
         } else if (dup) {
             tb.vals[pos0 + q] = val;
@@ -291,7 +404,7 @@ __device__ __forceinline__ uint32_t emit_bucket(const SmlPrepArgs& a, const SmlP
             }
             len = q - hq + 1;
         }
-        const bool want = a.records ? tail : (tail && len >= 2);
+        const bool want = (a.records || tb.allruns) ? tail : (tail && len >= 2);
         uint32_t idx;
         if (!a.records) {
             const uint64_t wm = __ballot(want);
@@ -363,7 +476,7 @@ __global__ __launch_bounds__(256) void k_prep_wave(SmlPrepArgs a, int T) {
     if (S > SML_PREP_SMALL) return;                                  // k_prep_large's (listed by k_prep_scan)
     if (S > 512) { if (lane == 0) prep_punt(a, T, b, bin); return; }
     const BatchGeo g = batch_geo(a, b);
-    const uint32_t pos0 = (uint32_t)(T ? 2 * g.start : g.start) + oc.x;
+    const uint32_t pos0 = (uint32_t)(tb.lmul * g.start) + oc.x;
     const E* src = reinterpret_cast<const E*>(tb.ent) + pos0;
     uint32_t (*bm)[256] = bm_all[wv];
     E* cand = cand_all[wv];
@@ -432,7 +545,7 @@ __global__ __launch_bounds__(256) void k_prep_wave(SmlPrepArgs a, int T) {
         r.row = (rh << tb.lb) | bin; r.pos = pos0 + (uint32_t)hq; r.len = (uint32_t)len; r.pad = 0;
 #pragma unroll
         for (int j = 0; j < SML_RUN_INL; ++j) r.slot[j] = j < len ? ent_val<E>(sorted[hq + j], vb) : 0u;
-        tb.runs_tmp[(pos0 >> 1) + (uint32_t)__popcll(wm & lanes_below())] = r;
+        tb.runs_tmp[(pos0 >> tb.rshift) + (uint32_t)__popcll(wm & lanes_below())] = r;
     }
     if (lane == 0) *brc = (uint32_t)__popcll(wm);
 }
@@ -452,7 +565,7 @@ __device__ __forceinline__ void bucket_body(const SmlPrepArgs& a, int T, int b, 
     int S = (int)oc.y;
     if (S == 0 && tid == 0 && tb.brc != nullptr) tb.brc[(int64_t)b * tb.nbk + bin] = 0u;
     if (S == 0 || S > SML_PREP_SMALL) return;
-    const uint32_t pos0 = (uint32_t)(T ? 2 * g.start : g.start) + oc.x;
+    const uint32_t pos0 = (uint32_t)(tb.lmul * g.start) + oc.x;
     const E* src = reinterpret_cast<const E*>(tb.ent) + pos0;
     if (DIRECT) {
         for (int i = tid; i < S; i += 256) {
@@ -461,7 +574,7 @@ __device__ __forceinline__ void bucket_body(const SmlPrepArgs& a, int T, int b, 
             const uint32_t val = T == 0 ? (uint32_t)i : g.ioff + (uint32_t)i;
             buf[0][i] = sizeof(E) == 8 ? (E)(((uint64_t)row << 32) | val) : (E)(((E)row << tb.vb) | (E)val);
         }
-    } else if (a.records) {
+    } else if (a.records || tb.allruns) {
         for (int i = tid; i < S; i += 256) buf[0][i] = src[i];
     } else {
         // Duplicate filter: only occurrences of rows that occur at least twice need sorting (with uniform users that is
@@ -641,7 +754,7 @@ __global__ __launch_bounds__(1024) void k_prep_large(SmlPrepArgs a) {
         const uint2 oc = tb.bk[(int64_t)b * tb.nbk + bin];
         const int S = (int)oc.y;
         const BatchGeo g = batch_geo(a, b);
-        const uint32_t pos0 = (uint32_t)(T ? 2 * g.start : g.start) + oc.x;
+        const uint32_t pos0 = (uint32_t)(tb.lmul * g.start) + oc.x;
         E* src = reinterpret_cast<E*>(tb.ent) + pos0;
         E* dst = reinterpret_cast<E*>(tb.ent2) + pos0;
         __syncthreads();                                         // the previous bucket's readers of the LDS arrays are done
@@ -778,14 +891,14 @@ __global__ __launch_bounds__(256) void k_prep_compact(SmlPrepArgs a) {
     if (tid == 255) { pre[nbk] = run; if (blockIdx.x == 0) tb.run_cnt[b] = (int)run; }
     __syncthreads();
     const BatchGeo g = batch_geo(a, b);
-    const uint32_t list_start = (uint32_t)(T ? 2 * g.start : g.start);
+    const uint32_t list_start = (uint32_t)(tb.lmul * g.start);
     const uint4* stage = reinterpret_cast<const uint4*>(tb.runs_tmp);
-    uint4* dst = reinterpret_cast<uint4*>(tb.runs + (list_start >> 1));
+    uint4* dst = reinterpret_cast<uint4*>(tb.runs + (list_start >> tb.rshift));
     // the 16 buckets' records as ONE flat range of 16-byte halves (a record is two): their stretches' first records are
     // fetched side by side, not one dependent load per bucket
     __shared__ uint32_t first[SML_PREP_CG];
     const int bin0 = blockIdx.x * SML_PREP_CG, nbin = min(SML_PREP_CG, nbk - bin0);
-    if (tid < nbin) first[tid] = (list_start + tb.bk[(int64_t)b * nbk + bin0 + tid].x) >> 1;
+    if (tid < nbin) first[tid] = (list_start + tb.bk[(int64_t)b * nbk + bin0 + tid].x) >> tb.rshift;
     __syncthreads();
     const uint32_t r0 = pre[bin0], r1 = pre[bin0 + nbin];
     for (uint32_t i0 = 2 * r0 + tid; i0 < 2 * r1; i0 += 1024) {
@@ -813,9 +926,10 @@ hipError_t launch_prep(const SmlPrepArgs& a, hipStream_t st) {
         return hipGetLastError();
     }
     const dim3 tiles((unsigned)a.tpb, (unsigned)a.nb);
-    k_prep_hist<<<tiles, dim3(1024), 0, st>>>(a);
+    if (a.mode == 0) k_prep_hist<<<tiles, dim3(1024), 0, st>>>(a); else k_prep_hist_x<<<tiles, dim3(1024), 0, st>>>(a);
     k_prep_scan<<<dim3((unsigned)a.nb, 2), dim3(1024), 0, st>>>(a);
-    k_prep_scatter<E><<<dim3(xcd_grid(a.nb, a.tpb)), dim3(1024), 0, st>>>(a);
+    if (a.mode == 0) k_prep_scatter<E><<<dim3(xcd_grid(a.nb, a.tpb)), dim3(1024), 0, st>>>(a);
+    else k_prep_scatter_x<E><<<dim3(xcd_grid(a.nb, a.tpb)), dim3(1024), 0, st>>>(a);
     const int nbk_max = a.t[0].nbk > a.t[1].nbk ? a.t[0].nbk : a.t[1].nbk;
     for (int T = 0; T < 2; ++T)
         if (a.t[T].wave) k_prep_wave<E><<<dim3(xcd_grid(a.nb, (a.t[T].nbk + 3) / 4)), dim3(256), 0, st>>>(a, T);

@@ -190,6 +190,10 @@ struct SmlPrepTable {
     int vb;                      // value bits inside an entry (32: 64-bit entries)
     int npass, pbits;            // LDS radix passes over those bits, bits per pass (<= 9)
     int wave;                    // small buckets (compact mode): one wavefront per bucket first (k_prep_wave)
+    int ntile;                   // partition tiles per list (tiles per batch x streams of this table; 0: the table has no occurrences)
+    int lmul;                    // a list starts at lmul * (the batch's first triple) in the table's occurrence arrays
+    int allruns;                 // compact mode: EVERY run gets a record (not only duplicated ones), every occurrence its value; no marks
+    int rshift;                  // a bucket's record stretch starts at position >> rshift (1: at most every second occurrence heads a record)
     void* ent; void* ent2;       // [occurrences] partitioned entries (row_hi << vb | value); ent2: ping-pong for large buckets
     uint32_t* hist;              // [nb][tiles][nbk] tile histograms, turned into the tiles' first positions
     uint2* bk;                   // [nb][nbk] (first position of the bucket inside its list, entries)
@@ -204,6 +208,10 @@ struct SmlPrepArgs {
     const int* boff;             // planned batches of unequal size (or null)
     int pad_tiles;               // the batch's first item value is rounded up to a multiple of SML_R
     int records;                 // 1: one record per sorted position (MF stage); 0: compact records of duplicated runs + unique marks
+    // occurrence source (index_prep.hip, occ_of): 0 this rank's triples; 1 / 2 / 3 the multi-GPU item lists
+    int mode, has_users, nis;    // nis: item streams per tile (2, or 2 * world)
+    const int64_t* items_all; int64_t val_q;        // [world][n][2] gathered item columns; value stride per rank
+    int64_t head_rows, shard_rows; int shard_rank;
     SmlPrepTable t[2];           // users, items
     uint8_t* uniq; int64_t uniq_stride;
     uint32_t* hot_list; int* hot_count; int hot_cap; int* max_len;

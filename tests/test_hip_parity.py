@@ -1464,8 +1464,9 @@ def _bare_world2_inputs(d, dtype, B, n, U_rank, I, seed):
     return wi, wus, tris
 
 
+@pytest.mark.parametrize("big", [False, True])
 @pytest.mark.parametrize("d,dtype,bce", [(32, torch.float32, True), (64, torch.float32, False), (128, torch.float16, False)])
-def test_bare_step_two_ranks_on_one_gpu_equal_the_global_batch_step(d, dtype, bce, monkeypatch):
+def test_bare_step_two_ranks_on_one_gpu_equal_the_global_batch_step(d, dtype, bce, big, monkeypatch):
     """The bare a3 step under world_size 2 (thread ranks on one GPU, hook exchange): users sharded -- each rank its own
     user table and triples --, item table replicated, per-occurrence item-gradient rows all-gathered every batch, the
     job's item-occurrence list built by the library from the gathered item columns.  Equals the oracle's synchronous
@@ -1473,8 +1474,17 @@ def test_bare_step_two_ranks_on_one_gpu_equal_the_global_batch_step(d, dtype, bc
     from _thread_group import run_ranks
     from sml_amd import dist as SD
     monkeypatch.setenv("SML_COMM", "torch")
-    B, n, U_rank, I = 96, 96 * 3 - 11, 150, 120
+    # big: batches of 6,000 -- the job's item list of a batch (24,000 occurrences) is cut into buckets and tiles, one item
+    # collects thousands of occurrences (an oversized bucket, a hot run)
+    B, n, U_rank, I = (6000, 6000 * 2 + 777, 20000, 9000) if big else (96, 96 * 3 - 11, 150, 120)
+    if big and d != 32:
+        pytest.skip("the large shapes run at d = 32")
     wi, wus, tris = _bare_world2_inputs(d, dtype, B, n, U_rank, I, seed=3 * d)
+    if big:
+        for t in tris:
+            t[0:B:2, 1] = 5
+            t[1:B:7, 2] = 5
+            t[B:2 * B:3, 0] = 11
     lr = 0.05 if bce else 0.01
 
     def rank_fn(rank, group):
@@ -1508,6 +1518,17 @@ def test_bare_step_two_ranks_on_one_gpu_equal_the_global_batch_step(d, dtype, bc
                                               (32, torch.float32, True, 120), (128, torch.float32, True, 24), (128, torch.float16, False, 0),
                                               (64, torch.float16, False, 16)])
 def test_bare_step_item_sharded_two_ranks_on_one_gpu_equal_the_global_batch_step(d, dtype, bce, head, monkeypatch, request):
+    _item_sharded_two_ranks(d, dtype, bce, head, False, monkeypatch)
+
+
+@pytest.mark.parametrize("head", [0, 16, 400])
+def test_bare_step_item_sharded_two_ranks_at_batches_of_6000(head, monkeypatch):
+    """The same with 6,000-triple batches: the owners' lists (24,000 occurrences per batch) go through the bucket partition
+    of index_prep.hip, one tail row and one head row collect thousands of occurrences."""
+    _item_sharded_two_ranks(32, torch.float32, True, head, True, monkeypatch)
+
+
+def _item_sharded_two_ranks(d, dtype, bce, head, big, monkeypatch):
     """The bare a3 step with the ITEM TABLE SHARDED over world_size 2 (thread ranks on the two CU-masked streams, one-shot
     peer exchange, same-process allocations handed over as raw pointers): the first `head` rows replicated (dense
     one-shot all-reduce of their gradient partials), the tail owner-computes -- every rank reads tail rows from their
@@ -1519,8 +1540,14 @@ def test_bare_step_item_sharded_two_ranks_on_one_gpu_equal_the_global_batch_step
     from sml_amd import dist as SD
     monkeypatch.setenv("SML_COMM", "peer")
     monkeypatch.setenv("SML_PEER_TIMEOUT_S", "20")
-    B, n, U_rank, I = 96, 96 * 3 - 11, 150, 120
+    B, n, U_rank, I = (6000, 6000 * 2 + 777, 20000, 9000) if big else (96, 96 * 3 - 11, 150, 120)
     wi, wus, tris = _bare_world2_inputs(d, dtype, B, n, U_rank, I, seed=3 * d)
+    if big:
+        for t in tris:
+            t[0:B:2, 1] = 5                 # a head row (head > 5) / a tail row of rank 0 (head = 0)
+            t[1:B:7, 2] = 5
+            t[2:B:3, 1] = I - 3             # a tail row of rank 1
+            t[B:2 * B:3, 0] = 11
     lr = 0.05 if bce else 0.01
     H, S = SD.item_shard_layout(I, 2, head)
     eng0 = engine(d, B)
