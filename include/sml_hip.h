@@ -62,6 +62,16 @@ int sml_ctx_destroy(sml_ctx* ctx);
  *      conv1 block with a zero third column -- no x_com row, user-net output divided by its detached norm
  *      (sml_transfer_forward with net 0 returns the normalised rows), loss SML_LOSS_BPR_UNIT. */
 int sml_ctx_set_variant(sml_ctx* ctx, int variant);
+/* --clip_grad (reference model/transfer.py:725-727, torch.nn.utils.clip_grad_norm_(transfer.parameters(), max_norm, 2)
+ * between backward and optimizer.step() in the TR loop): max_norm > 0 makes the TR stage epoch finish the flat theta
+ * gradient (after the exchange on several GPUs), take its 2-norm and scale it by min(1, max_norm / (norm + 1e-6)) before
+ * Adam; the step then runs un-fused (one reduction launch + one Adam launch more per batch).  0 switches it off.  Not
+ * available on the one-shot peer exchange. */
+int sml_ctx_set_grad_clip(sml_ctx* ctx, float max_norm);
+/* --need_adaptive (reference model/transfer.py:490-499, beta = 0.1 there): the MF stage's loss gains
+ * sum over the batch's unique users of beta * count_u / ||w_u|| (detached) * ||w_u||^2; beta > 0 adds it (one small launch per
+ * batch between the backward and the row update), 0 switches it off. */
+int sml_ctx_set_adaptive(sml_ctx* ctx, float beta);
 
 /* ---- theta layout ------------------------------------------------------------- */
 /* Floats in one net's flat block / offset of tensor `which` (0..7 in state_dict

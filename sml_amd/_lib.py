@@ -60,6 +60,8 @@ SIGNATURES = {
     "sml_version": (ctypes.c_int, []),
     "sml_ctx_create": (ctypes.c_int, [ctypes.POINTER(c_void), ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "sml_ctx_set_variant": (ctypes.c_int, [c_void, ctypes.c_int]),
+    "sml_ctx_set_grad_clip": (ctypes.c_int, [c_void, ctypes.c_float]),
+    "sml_ctx_set_adaptive": (ctypes.c_int, [c_void, ctypes.c_float]),
     "sml_ctx_destroy": (ctypes.c_int, [c_void]),
     "sml_theta_net_size": (ctypes.c_int64, [ctypes.c_int]),
     "sml_theta_offset": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int]),

@@ -183,6 +183,9 @@ struct SchedRetired { SmlSched* dev; SmlSched* host; hipEvent_t done; };
 struct sml_ctx {
     int device = 0, d = 32, max_batch = 0;
     int variant = 0;         // 0: ConvTransfer_com, 1: ConvTransfer (sml_ctx_set_variant)
+    float clip_max_norm = 0.0f;   // > 0: the TR stage clips the theta gradient's norm (sml_ctx_set_grad_clip)
+    float adaptive_beta = 0.0f;   // > 0: the MF stage adds the reference's --need_adaptive user-norm term (sml_ctx_set_adaptive)
+    Buf<float> clip_sumsq;
     IndexSet ix[2];
     // transfer-net workspaces, 3*B slots each
     Buf<float> out, dout, dx, xin, z1, a1, a2, dz1, mrep, vrep;
@@ -748,6 +751,18 @@ int sml_ctx_set_variant(sml_ctx* ctx, int variant) {
     return SML_OK;
 }
 
+int sml_ctx_set_adaptive(sml_ctx* ctx, float beta) {
+    if (!ctx || !(beta >= 0.0f)) return fail(SML_EINVAL, "sml_ctx_set_adaptive", "beta must be >= 0 (0: off)");
+    ctx->adaptive_beta = beta;
+    return SML_OK;
+}
+
+int sml_ctx_set_grad_clip(sml_ctx* ctx, float max_norm) {
+    if (!ctx || !(max_norm >= 0.0f)) return fail(SML_EINVAL, "sml_ctx_set_grad_clip", "max_norm must be >= 0 (0: off)");
+    ctx->clip_max_norm = max_norm;
+    return SML_OK;
+}
+
 static void ctx_destroy_now(sml_ctx* ctx) {
     (void)sml_comm_destroy(ctx);
     { DevGuard g(ctx->device); ctx->release_all(); }
@@ -890,6 +905,11 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
         w.loss_part = ctx->loss_part.p + b * lstride;
         w.out_np = fns; w.out_pstride = out_pstride;
         ctx->prof.begin(PC_BWD, st); HIPCHK(sml_launch_bwd(d, bsplit, w, tiles, st)); ctx->prof.end(st);
+        if (ctx->adaptive_beta > 0.0f) {      // --need_adaptive: the users' norm term joins their gradient rows and the batch's loss
+            ctx->prof.begin(PC_MISC, st);
+            HIPCHK(sml_launch_adaptive_users(d, ctx->xin.p, dx_buf, B, ctx->adaptive_beta, w.loss_part, st));
+            ctx->prof.end(st);
+        }
         SmlRunArgs u;
         memset(&u, 0, sizeof(u));
         u.run_u = ctx->ix[0].rec_u.p + off0; u.n_u = B; u.val_u = ctx->ix[0].val_u2.p;
@@ -969,6 +989,11 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
     int rc;
     if ((rc = ensure_pk(ctx))) return rc;
     if ((rc = ensure_transfer_ws(ctx, batch, true, st))) return rc;
+    // --clip_grad (model/transfer.py:725-727): the flat gradient is completed, its norm taken, and the Adam launch scales it
+    const bool clip = ctx->clip_max_norm > 0.0f;
+    if (clip && !grad_hook && ctx->peer.world > 0)
+        return fail(SML_ESTATE, "sml_tr_stage_epoch", "gradient clipping is not available on the one-shot peer exchange (detach the peers or use a hook)");
+    if (clip) HIPCHK(ctx->clip_sumsq.ensure(4));
     float* grad = theta_grad ? theta_grad : ctx->grad.p;
     const int fns = fwd_split(wg_tiles(batch, 1) + wg_tiles(2 * batch, 1)), bsplit = bwd_split(wg_tiles(batch, 1) + wg_tiles(2 * batch, 1));
     const int cs = bsplit ? d / 16 : 1;                                 // backward workgroups per row tile
@@ -1016,7 +1041,7 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
             q.dz1 = sg.dz1; q.a1 = ctx->a1.p + slot0 * SML_C2 * d; q.dout = sg.dout; q.a2 = ctx->a2.p + slot0 * SML_HID;
             // (one GPU, Adam fused into the weight-gradient kernel, no gradient buffer asked for: the flat gradient is
             // not written at all -- 0.8 MB less for the launch to leave dirty in L2)
-            const bool fused_only = !grad_hook && (ctx->comm == nullptr || ctx->peer.world > 0) && theta_grad == nullptr;
+            const bool fused_only = !clip && !grad_hook && (ctx->comm == nullptr || ctx->peer.world > 0) && theta_grad == nullptr;
             q.grad = fused_only ? nullptr : grad + s * ns; q.n_rows = sg.n_rows;
             q.theta_net = sg.theta; q.pk_net = sg.pk; q.xin = sg.xin;
         }
@@ -1051,7 +1076,7 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
             if (!poll_in_adam) { HIPCHK(sml_launch_peer_wait(ad.peer, st)); ad.peer.waited = 1; }
             HIPCHK(sml_launch_theta_adam(d, ad, st));
             ctx->prof.end(st);
-        } else if (!grad_hook && !native) {
+        } else if (!grad_hook && !native && !clip) {
             // one GPU: the weight-gradient workgroups take the Adam step for the tiles they own
             // (v2: the refreshed images go to the OTHER set -- the launch's tail workgroups are reading this one)
             wg.theta = theta; wg.m = adam_m; wg.v = adam_v; wg.pk = v2 ? pk_other(ctx) : pk_cur(ctx);
@@ -1068,11 +1093,16 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
             ad.weight_decay = weight_decay; ad.step_size = sc.step_size; ad.bc2_sqrt = sc.bc2_sqrt;
             if (native) {
                 NCCLCHK(g_rccl.AllReduce(grad, grad, (size_t)(2 * ns), ncclFloat, ncclSum, ctx->comm, st));
-            } else {
+            } else if (grad_hook) {
                 const int hr = grad_hook(hook_user, grad, 2 * ns, b);
                 if (hr != 0) return fail(SML_ESTATE, "sml_tr_stage_epoch", "grad_hook failed");
             }
-            ctx->prof.begin(PC_THETA_ADAM, st); HIPCHK(sml_launch_theta_adam(d, ad, st)); ctx->prof.end(st);
+            ctx->prof.begin(PC_THETA_ADAM, st);
+            if (clip) {        // (the norm of the job's gradient: after the exchange)
+                HIPCHK(sml_launch_grad_sumsq(grad, 2 * ns, ctx->clip_sumsq.p, st));
+                ad.clip_sumsq = ctx->clip_sumsq.p; ad.clip_max_norm = ctx->clip_max_norm;
+            }
+            HIPCHK(sml_launch_theta_adam(d, ad, st)); ctx->prof.end(st);
         }
     }
     ctx->prof.begin(PC_MISC, st); HIPCHK(sml_launch_loss_finalize(ctx->loss_part.p, (int)nb, lstride, nullptr, batch_loss, st)); ctx->prof.end(st);

@@ -149,6 +149,34 @@ __device__ __forceinline__ float block_sum256(float v, float* sh4) {
 }
 
 // one wavefront per batch: lanes stride over the batch's partials, fixed-order tree (deterministic)
+// --need_adaptive (reference model/transfer.py:490-499): loss += sum over the batch's UNIQUE users of
+// beta * count_u / ||w_u|| (detached) * ||w_u||^2 -- per occurrence that is beta * ||w_u|| of loss and
+// 2 * beta * w_u / ||w_u|| of gradient.  Runs after the backward: x_hat of user slot t is row 1 of xin[t] (the row as the
+// forward saw it, pending Adam steps replayed), its gradient row is dx[t].  One workgroup, fixed order: deterministic.
+template <int D>
+__global__ __launch_bounds__(1024) void k_adaptive_users(const float* __restrict__ xin, float* __restrict__ dx, int B, float beta,
+                                                         float* __restrict__ loss_slot) {
+    constexpr int LPR = D / 4;
+    __shared__ float part[16];
+    const int grp = threadIdx.x / LPR, sub = threadIdx.x % LPR;
+    float acc = 0.0f;
+    for (int t = grp; t < B; t += 1024 / LPR) {
+        float x[4], g[4];
+        RowVec<float>::load(xin + ((int64_t)t * 3 + 1) * D + sub * 4, x);
+        const float nrm = sqrtf(group_sum<LPR>(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]));
+        RowVec<float>::load(dx + (int64_t)t * D + sub * 4, g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] += 2.0f * beta * x[e] / nrm;
+        RowVec<float>::store(dx + (int64_t)t * D + sub * 4, g);
+        if (sub == 0) acc += beta * nrm;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { float s2 = 0.0f; for (int w = 0; w < 16; ++w) s2 += part[w]; *loss_slot += s2; }
+}
+
 __global__ __launch_bounds__(64) void k_loss_finalize(const float* __restrict__ part, int n_batches, int stride,
                                                      float* __restrict__ out) {
     const int b = blockIdx.x;
@@ -1199,6 +1227,11 @@ __global__ __launch_bounds__(1024) void k_eval_metrics(const int32_t* __restrict
         default: return hipErrorInvalidValue; \
     }
 
+hipError_t sml_launch_adaptive_users(int d, const float* xin, float* dx, int B, float beta, float* loss_slot, hipStream_t st) {
+    if (B <= 0) return hipSuccess;
+    SML_DISPATCH_D(d, k_adaptive_users<DD><<<dim3(1), dim3(1024), 0, st>>>(xin, dx, B, beta, loss_slot));
+    return hipGetLastError();
+}
 hipError_t sml_launch_loss_finalize(const float* part, int n_batches, int stride, const int*, float* out, hipStream_t st) {
     k_loss_finalize<<<dim3(n_batches), dim3(64), 0, st>>>(part, n_batches, stride, out);
     return hipGetLastError();

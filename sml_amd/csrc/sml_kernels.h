@@ -102,7 +102,9 @@ struct SmlThetaAdamArgs {
     float* theta; float* m; float* v; float* grad; float* pk;
     float weight_decay, step_size, bc2_sqrt;
     SmlPeerPoll peer;        // several GPUs: the gradient is the rank-order sum of the inbox slots (grad is not read)
+    const float* clip_sumsq; float clip_max_norm;   // --clip_grad: sum of squares of the whole gradient (device), the norm bound
 };
+hipError_t sml_launch_grad_sumsq(const float* grad, int64_t n, float* out, hipStream_t st);
 
 // mt row-tiles of 16 per workgroup; ns workgroups share a row tile (1, or SML_FWD_NS with mt = 1)
 hipError_t sml_launch_fwd(int d, int mt, int ns, const SmlFwdArgs& a, int tiles_total, hipStream_t st);
@@ -131,6 +133,7 @@ struct SmlShardKeys {
     int rank; long long head_rows, shard_rows, rows_cap;
 };
 // ---- mf_kernels.hip ------------------------------------------------------------------
+hipError_t sml_launch_adaptive_users(int d, const float* xin, float* dx, int B, float beta, float* loss_slot, hipStream_t st);
 hipError_t sml_launch_loss_finalize(const float* part, int n_batches, int stride, const int* counts,
                                     float* out, hipStream_t st);
 

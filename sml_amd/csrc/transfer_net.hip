@@ -1824,6 +1824,12 @@ __global__ __launch_bounds__(256) void k_theta_adam(SmlThetaAdamArgs a) {
     } else {
         g = *reinterpret_cast<const f32x4*>(a.grad + i0);             // complete (and all-reduced) flat gradient
     }
+    if (a.clip_sumsq != nullptr) {
+        // torch.nn.utils.clip_grad_norm_(transfer.parameters(), max_norm, 2) -- model/transfer.py:725-727: the whole
+        // gradient is scaled by min(1, max_norm / (||g||_2 + 1e-6)) before the optimiser (and its weight decay) sees it
+        const float coef = fminf(a.clip_max_norm / (sqrtf(*a.clip_sumsq) + 1e-6f), 1.0f);
+        g *= coef;
+    }
     f32x4 p = *reinterpret_cast<const f32x4*>(a.theta + i0), m = *reinterpret_cast<const f32x4*>(a.m + i0),
           v = *reinterpret_cast<const f32x4*>(a.v + i0);
     SmlSched s; s.step_size = a.step_size; s.bc2_sqrt = a.bc2_sqrt;
@@ -1839,6 +1845,21 @@ __global__ __launch_bounds__(256) void k_theta_adam(SmlThetaAdamArgs a) {
     *reinterpret_cast<f32x4*>(a.theta + i0) = p;
     *reinterpret_cast<f32x4*>(a.m + i0) = m;
     *reinterpret_cast<f32x4*>(a.v + i0) = v;
+}
+
+// sum of squares of the flat gradient, one workgroup, fixed order (the conv block's alignment padding holds zeros)
+__global__ __launch_bounds__(1024) void k_grad_sumsq(const float* __restrict__ g, long long n, float* __restrict__ out) {
+    __shared__ float part[16];
+    float acc = 0.0f;
+    for (long long i = 4ll * threadIdx.x; i < n; i += 4096) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(g + i);
+        acc += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { float t = 0.0f; for (int w = 0; w < 16; ++w) t += part[w]; *out = t; }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1942,6 +1963,10 @@ hipError_t sml_launch_theta_adam(int d, const SmlThetaAdamArgs& a, hipStream_t s
     const int n = 2 * sml_net_size(d) / 4;         // four parameters per thread
     if (a.peer.world > 0) { SML_DISPATCH_D(d, k_theta_adam<DD, true><<<dim3((n + 255) / 256), dim3(256), 0, st>>>(a)); }
     else { SML_DISPATCH_D(d, k_theta_adam<DD, false><<<dim3((n + 255) / 256), dim3(256), 0, st>>>(a)); }
+    return hipGetLastError();
+}
+hipError_t sml_launch_grad_sumsq(const float* grad, int64_t n, float* out, hipStream_t st) {
+    k_grad_sumsq<<<dim3(1), dim3(1024), 0, st>>>(grad, (long long)n, out);       // n is a multiple of four (two nets)
     return hipGetLastError();
 }
 hipError_t sml_launch_theta_pack(int d, const float* theta, float* pk, hipStream_t st) {

@@ -327,9 +327,8 @@ class meta_train(object):
     # ------------------------------------------------------------------ hot loop 1
     def MF_train_onestage(self, args, set_t, stage_id, val=None):
         """Train W_hat on D_t with theta frozen (reference model/transfer.py:417-534)."""
-        if args.need_adaptive:
-            raise NotImplementedError("--need_adaptive is marked 'not used in the final version' by the reference "
-                                      "and is outside this build's scope")
+        # --need_adaptive (model/transfer.py:427, 490-499): beta = 0.1 there
+        adaptive = 0.1 if args.need_adaptive else None
         self.transfer.eval()
         if val is not None:
             val = self._rows(val)
@@ -350,7 +349,7 @@ class meta_train(object):
             if self.dist is None:
                 losses = self.engine.mf_stage_epoch(self.MFbase, self.transfer, self.last_user_weight,
                                                     self.last_item_weight, triples, args.MF_batch_size,
-                                                    args.MF_lr, args.l2, norm=args.norm, bce=True)
+                                                    args.MF_lr, args.l2, norm=args.norm, bce=True, adaptive_beta=adaptive)
             else:
                 # the same global batches, this rank's share of each (its users' triples); batch losses add up
                 route = self.dist.route_epoch(triples, args.MF_batch_size, self.n_user_global,
@@ -358,7 +357,8 @@ class meta_train(object):
                 losses = self.engine.mf_stage_epoch(self.MFbase, self.transfer, self.last_user_weight,
                                                     self.last_item_weight, route.local_tri, route.cap,
                                                     args.MF_lr, args.l2, norm=args.norm, bce=True,
-                                                    plan=route.plan, exchange=route.exchange(self.MFbase.user_laten.weight.shape[1]))
+                                                    plan=route.plan, exchange=route.exchange(self.MFbase.user_laten.weight.shape[1]),
+                                                    adaptive_beta=adaptive)
                 losses = self._sum_losses(losses)
             self.engine.mf_flush(self.MFbase)
             self._touch_tables()
@@ -390,9 +390,9 @@ class meta_train(object):
     # ------------------------------------------------------------------ hot loop 2
     def transfer_train_onestage(self, args, set_tt, stage_id, compute_performance=False, val=None):
         """Train theta on D_{t+1} with the tables frozen (reference model/transfer.py:644-749)."""
-        if args.clip_grad:
-            raise NotImplementedError("--clip_grad is marked 'not used in the final version' by the reference "
-                                      "and is outside this build's scope")
+        # --clip_grad / --maxnorm_grad (model/transfer.py:656, 724-727): the norm of theta's gradient is clipped between
+        # backward and the optimiser step; the engine then runs the TR step un-fused
+        clip = float(args.maxnorm_grad) if args.clip_grad else None
         self._emit(lambda: print("********* this is Transfer model training stage ***********"))
         self.MFbase.eval()
         now_test = None
@@ -438,7 +438,7 @@ class meta_train(object):
             if self.dist is None:
                 losses = self.engine.tr_stage_epoch(self.transfer, self.last_user_weight, self.last_item_weight,
                                                     self.user_weight_hat, self.item_weight_hat, triples,
-                                                    args.TR_batch_size, args.TR_lr, args.TR_l2, bce=True)
+                                                    args.TR_batch_size, args.TR_lr, args.TR_l2, bce=True, clip_max_norm=clip)
             else:
                 if isinstance(triples, torch.Tensor):
                     raise NotImplementedError("--device_batches with several GPUs: the ranks must share one epoch")
@@ -446,7 +446,8 @@ class meta_train(object):
                                               mean_loss=self.transfer_variant_is_bce())
                 losses = self.engine.tr_stage_epoch(self.transfer, self.last_user_weight, self.last_item_weight,
                                                     self.user_weight_hat, self.item_weight_hat, route.local_tri,
-                                                    route.cap, args.TR_lr, args.TR_l2, bce=True, plan=route.plan)
+                                                    route.cap, args.TR_lr, args.TR_l2, bce=True, plan=route.plan,
+                                                    clip_max_norm=clip)
                 losses = self._sum_losses(losses)
             self.timing["tr"] += time.time() - t0
             self.timing["tr_triples"] += triples.shape[0]

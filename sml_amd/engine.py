@@ -243,9 +243,11 @@ class HipEngine(object):
         return ctypes.byref(p), (p, off, off_dev, sc)
 
     def mf_stage_epoch(self, mfbase, transfer, last_user, last_item, triples, batch_size, lr, l2, norm=False, bce=True,
-                       plan=None, exchange=None):
+                       plan=None, exchange=None, adaptive_beta=None):
         """plan / exchange: the multi-GPU driver's per-epoch descriptors (sml_amd.dist.EpochRoute): batches of unequal
-        local size, and the global item-occurrence list of the job."""
+        local size, and the global item-occurrence list of the job.  adaptive_beta: the reference's --need_adaptive
+        term (model/transfer.py:490-499; 0.1 there)."""
+        check(self.lib.sml_ctx_set_adaptive(self._ctx, float(adaptive_beta or 0.0)), "sml_ctx_set_adaptive")
         theta = self._select(transfer)
         tri = self._dev(triples, torch.int64)
         n = tri.shape[0]
@@ -299,7 +301,9 @@ class HipEngine(object):
 
     # ------------------------------------------------------------------ a9
     def tr_stage_epoch(self, transfer, last_user, last_item, hat_user, hat_item, triples, batch_size, lr,
-                       weight_decay, bce=True, loss_scale=None, plan=None):
+                       weight_decay, bce=True, loss_scale=None, plan=None, clip_max_norm=None):
+        """clip_max_norm: the reference's --clip_grad / --maxnorm_grad (model/transfer.py:725-727)."""
+        check(self.lib.sml_ctx_set_grad_clip(self._ctx, float(clip_max_norm or 0.0)), "sml_ctx_set_grad_clip")
         theta = self._select(transfer)
         if loss_scale is None:
             loss_scale = self.dist.tr_loss_scale(self._loss_kind(bce, False)) if self.dist is not None else 1.0

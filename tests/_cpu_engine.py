@@ -36,7 +36,8 @@ class CpuDistEngine(CpuEngine):
         return [(off[b], off[b + 1]) for b in range(len(off) - 1)], plan.get("loss_scale")
 
     def mf_stage_epoch(self, mfbase, transfer, last_user, last_item, triples, batch_size, lr, l2, norm=False, bce=True,
-                       plan=None, exchange=None):
+                       plan=None, exchange=None, adaptive_beta=None):
+        assert not adaptive_beta, "the CPU stand-in of the distributed tests has no --need_adaptive term"
         tri = torch.as_tensor(triples).reshape(-1, 3)
         ex = exchange if exchange is not None else self.dist.mf_exchange(tri, batch_size, self.d, 0 if bce else 1)
         d, n = self.d, tri.shape[0]
@@ -84,7 +85,8 @@ class CpuDistEngine(CpuEngine):
         return np.array(losses, dtype=np.float64)
 
     def tr_stage_epoch(self, transfer, last_user, last_item, hat_user, hat_item, triples, batch_size, lr,
-                       weight_decay, bce=True, loss_scale=None, plan=None):
+                       weight_decay, bce=True, loss_scale=None, plan=None, clip_max_norm=None):
+        assert not clip_max_norm, "the CPU stand-in of the distributed tests has no --clip_grad"
         tri = torch.as_tensor(triples).reshape(-1, 3)
         base_scale = self.dist.tr_loss_scale(0 if bce else 1) if loss_scale is None else loss_scale
         params = list(transfer.parameters())

@@ -91,7 +91,7 @@ def test_g5_updata(variant):
 
 
 # ----------------------------------------------------------------------------- G3 (a8)
-def _run_g3(eng, z, bce=True, norm=False):
+def _run_g3(eng, z, bce=True, norm=False, **kw):
     lr, l2, B, epochs = z["hp_mf"]
     B, epochs = int(B), int(epochs)
     U, d = z["W_user0"].shape
@@ -104,7 +104,7 @@ def _run_g3(eng, z, bce=True, norm=False):
     for ep in range(epochs):
         tri = torch.from_numpy(z["mf_triples"][ep * n:(ep + 1) * n])
         l = eng.mf_stage_epoch(mf, net, T(z["Wlast_user"], dev), T(z["Wlast_item"], dev), tri, B, lr, l2,
-                               norm=norm, bce=bce)
+                               norm=norm, bce=bce, **kw)
         eng.mf_flush(mf)
         losses.append(l.cpu().numpy() if isinstance(l, torch.Tensor) else l)
     return mf, np.concatenate(losses).astype(np.float64), lr
@@ -142,6 +142,21 @@ def test_mf_stage_bpr_kinds_vs_oracle(bce, norm):
     np.testing.assert_allclose(losses, olosses, rtol=1e-4)
     adam_close(mf.user_laten.weight.detach().cpu().numpy(), omf.user_laten.weight.detach().numpy(), lr, eng.mf_step)
     adam_close(mf.item_laten.weight.detach().cpu().numpy(), omf.item_laten.weight.detach().numpy(), lr, eng.mf_step)
+
+
+@pytest.mark.parametrize("bce", [True, False])
+def test_mf_stage_with_the_adaptive_user_norm_term_vs_oracle(bce):
+    """--need_adaptive (model/transfer.py:490-499): beta * count_u / ||w_u|| * ||w_u||^2 over the batch's unique users, added
+    to the MF stage's loss; against the oracle (the reference's formula), and it does change the result."""
+    z = golden("g3_mf_stage.npz")
+    eng = engine(32)
+    mf, losses, lr = _run_g3(eng, z, bce=bce, adaptive_beta=0.1)
+    omf, olosses, _ = _run_g3(O.OracleEngine(32), z, bce=bce, adaptive_beta=0.1)
+    np.testing.assert_allclose(losses, olosses, rtol=1e-4)
+    adam_close(mf.user_laten.weight.detach().cpu().numpy(), omf.user_laten.weight.detach().numpy(), lr, eng.mf_step)
+    adam_close(mf.item_laten.weight.detach().cpu().numpy(), omf.item_laten.weight.detach().numpy(), lr, eng.mf_step)
+    _, plain, _ = _run_g3(engine(32), z, bce=bce)
+    assert np.all(losses > plain + 1e-3)
 
 
 def test_lazy_adam_untouched_rows_equal_dense():
@@ -1203,6 +1218,62 @@ def test_tr_stage_every_backward_geometry_vs_oracle(d, B, env, monkeypatch):
         # (Adam's first steps move a weight by ~lr whatever the gradient's size: with 700-row batches a few more of the
         # 16k-80k weights per tensor sit at rounding-noise gradients than in the 48-row tests)
         adam_close(gt[k], ot[k], 1e-3, 2, frac=0.995)
+
+
+@pytest.mark.parametrize("d,B,max_norm", [(32, 256, 0.5), (64, 100, 0.05), (32, 256, 1e9)])
+def test_tr_stage_with_clipped_gradient_norm_vs_oracle(d, B, max_norm):
+    """--clip_grad / --maxnorm_grad (model/transfer.py:724-727): torch.nn.utils.clip_grad_norm_ over the transfer net's
+    parameters between backward and the optimiser step.  Three batches (the bound bites on each with a different factor;
+    the third test's bound never bites), against the oracle: losses, theta, and Adam's first moments -- which scale with
+    the clipping factor, where Adam's update itself almost does not."""
+    torch.manual_seed(5 * d + B)
+    U, I, n = 300, 200, 3 * B - 7
+    wu, wi = torch.randn(U, d) * 0.5, torch.randn(I, d) * 0.5
+    tri = torch.stack([torch.randint(0, U, (n,)), torch.randint(0, I, (n,)), torch.randint(0, I, (n,))], 1)
+    sd, res = None, []
+    hip = engine(d, 1024)
+    for eng, dev in ((hip, DEV), (O.OracleEngine(d), "cpu")):
+        net = make_transfer(d, device=dev)
+        if sd is None:
+            sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+        else:
+            net.load_state_dict(sd)
+        l = eng.tr_stage_epoch(net, (wu * 0.9).to(dev), (wi * 0.9).to(dev), wu.to(dev), wi.to(dev), tri, B, 1e-3, 1e-4, bce=False,
+                               clip_max_norm=max_norm)
+        if dev == "cpu":
+            m = {k: st.m.numpy().copy() for (k, _), st in zip(net.named_parameters(), eng.tr_state)}
+        else:
+            flat_m = eng.tr_state[0].cpu().numpy()
+            names = {id(p): k for k, p in net.named_parameters()}
+            m = {names[id(p)]: flat_m[off:off + cnt].reshape(tuple(p.shape)) for p, off, cnt in eng.theta_views(net) if p.dim() <= 2}
+        res.append((np.asarray(l.cpu() if isinstance(l, torch.Tensor) else l, dtype=np.float64),
+                    {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}, m))
+    (gl, gt, gm), (ol, ot, om) = res
+    np.testing.assert_allclose(gl, ol, rtol=1e-4)
+    for k in ot:
+        # (Adam divides by sqrt(v): with a clipped gradient -- a few 1e-3 in norm -- more elements sit where its direction is
+        # rounding noise than in the unclipped tests.  Nearly all agree tightly, none is further off than a quarter of
+        # what three steps can move it; the first moments below carry the clipping factor itself.)
+        if k == "item_transfer.fc2.bias":
+            continue        # BPR: d(s_pos - s_neg)/d(this bias) is identically zero -- both sides hold rounding noise (|m| ~ 1e-7)
+        dlt = np.abs(gt[k].astype(np.float64) - ot[k])
+        assert (dlt <= 2e-4 * np.abs(ot[k]) + 2e-5 * 1e-3 * 3).mean() >= 0.9, k
+        assert dlt.max() <= 0.25 * 1e-3 * 3, (k, dlt.max())
+    big = [k for k in gm if gm[k].size >= 512]
+    assert big
+    for k in big:
+        sig = np.abs(om[k]) > 0.1 * np.abs(om[k]).max()           # the elements that carry the moment's scale
+        ratio = gm[k][sig] / om[k][sig]
+        assert abs(np.median(ratio) - 1.0) < 1e-5 and ratio.min() > 0.99 and ratio.max() < 1.01, (k, ratio.min(), ratio.max())
+    if max_norm < 1e8:       # the bound did bite: an unclipped run leaves other first moments
+        net = make_transfer(d, device=DEV)
+        net.load_state_dict(sd)
+        e2 = engine(d, 1024)
+        e2.tr_stage_epoch(net, (wu * 0.9).to(DEV), (wi * 0.9).to(DEV), wu.to(DEV), wi.to(DEV), tri, B, 1e-3, 1e-4, bce=False)
+        k = big[0]
+        names = {id(p): kk for kk, p in net.named_parameters()}
+        free = {names[id(p)]: e2.tr_state[0].cpu().numpy()[off:off + cnt].reshape(tuple(p.shape)) for p, off, cnt in e2.theta_views(net) if p.dim() <= 2}
+        assert np.abs(free[k]).max() > 1.5 * np.abs(gm[k]).max()
 
 
 # ----------------------------------------------------------------------------- batch plans (the multi-GPU driver's batches)
