@@ -260,7 +260,7 @@ __global__ __launch_bounds__(1024) void k_prep_scan(SmlPrepArgs a) {
     const int ngrp = 1024 >> lb, grp = tid >> lb, bin = tid & (nbk - 1);
     const int per = (ntile + ngrp - 1) / ngrp, k0 = min(ntile, grp * per), k1 = min(ntile, k0 + per);
     uint32_t mine = 0;
-#pragma unroll 8
+#pragma unroll 16
     for (int k = k0; k < k1; ++k) mine += H[(int64_t)k * nbk + bin];
     part[tid] = mine;
     __syncthreads();
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(1024) void k_prep_scan(SmlPrepArgs a) {
     __syncthreads();
     {
         uint32_t run = (uint32_t)list_start + part[bin] + before;
-#pragma unroll 8
+#pragma unroll 16
         for (int k = k0; k < k1; ++k) { const uint32_t c = H[(int64_t)k * nbk + bin]; H[(int64_t)k * nbk + bin] = run; run += c; }
     }
     if (tid < nbk) {
