@@ -1,5 +1,9 @@
+"""The index lists of one of the A/B cases (tests/test_hip_parity.py: _prep_ab_triples), prepared `reps` times and read back
+(sml_index_lists_read) each time: every duplicated row once, its slots in occurrence order, the unique marks -- against numpy.
+usage: python tools/prep_stress.py <case> <reps>"""
 import os, sys
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ.setdefault("SML_PREP", "hand")
 import numpy as np, torch
 import test_hip_parity as tp
