@@ -428,6 +428,12 @@ int sml_host_resolve_negatives(const int64_t* users, int64_t n, const int64_t* c
 
 /* The same walk with the users' items in CSR form (user_ptr int64 [n_users + 1] into user_items, each user's
  * items ascending): two memory touches per candidate instead of a 17-step bisection of the pair list. */
+/* Host-side gathers of the same batch supply: out3 is the epoch's int64 [n,3] triple array.  gather_pairs: columns 0, 1 <-
+ * ui[order[e]] (ui = contiguous int64 [n_rows,2]); gather_column: column out_col <- element `col` of row order[e] of a
+ * row-major integer matrix (elem_bytes 4 or 8).  data/dataset2.py:172-201 (pre-sampled column), data/dataset.py:41-71. */
+int sml_host_gather_pairs(const int64_t* ui, int64_t n_rows, const int64_t* order, int64_t n, int64_t* out3);
+int sml_host_gather_column(const void* mat, int64_t n_rows, int64_t row_stride_bytes, int elem_bytes, int64_t col,
+                           const int64_t* order, int64_t n, int64_t* out3, int out_col);
 int sml_host_resolve_negatives_csr(const int64_t* users, int64_t n, const int64_t* cand, int64_t m,
                                    const int64_t* user_ptr, int64_t n_users, const int64_t* user_items,
                                    int64_t* negs, int64_t* consumed, int64_t* resolved);

@@ -130,6 +130,9 @@ SIGNATURES = {
     "sml_host_resolve_negatives": (ctypes.c_int, [c_void, ctypes.c_int64, c_void, ctypes.c_int64, c_void, ctypes.c_int64,
                                                   ctypes.c_int64, c_void, ctypes.POINTER(ctypes.c_int64),
                                                   ctypes.POINTER(ctypes.c_int64)]),
+    "sml_host_gather_pairs": (ctypes.c_int, [c_void, ctypes.c_int64, c_void, ctypes.c_int64, c_void]),
+    "sml_host_gather_column": (ctypes.c_int, [c_void, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, c_void, ctypes.c_int64,
+                               c_void, ctypes.c_int]),
     "sml_host_resolve_negatives_csr": (ctypes.c_int, [c_void, ctypes.c_int64, c_void, ctypes.c_int64, c_void, ctypes.c_int64, c_void,
                                                       c_void, c_void, c_void]),
     "sml_selftest": (ctypes.c_int, [ctypes.c_int]),

@@ -32,6 +32,27 @@ def loader_order(n, shuffle=True):
     return torch.randperm(n, generator=g).numpy()
 
 
+def _gather_into(tri, ui, order, mat=None, col=0):
+    """tri[:, :2] = ui[order] (and tri[:, 2] = mat[order, col]) through the compiled loops of libsml_hip.so
+    (sml_host_gather_pairs / sml_host_gather_column): numpy's fancy indexing builds a temporary and copies it through a
+    strided view -- 1.9 ms of a 75,000-row epoch's 4.4 ms on the host.  False when the arrays are not in a layout the
+    loops take (the caller then indexes with numpy)."""
+    from . import _lib
+    order = np.asarray(order)
+    if (order.dtype != np.int64 or not order.flags.c_contiguous or ui.dtype != np.int64 or not ui.flags.c_contiguous
+            or tri.dtype != np.int64 or not tri.flags.c_contiguous):
+        return False
+    if mat is not None and (mat.ndim != 2 or mat.dtype.kind != "i" or mat.dtype.itemsize not in (4, 8) or mat.strides[1] != mat.dtype.itemsize):
+        return False
+    lib = _lib.load()
+    n = order.shape[0]
+    _lib.check(lib.sml_host_gather_pairs(ui.ctypes.data, ui.shape[0], order.ctypes.data, n, tri.ctypes.data), "sml_host_gather_pairs")
+    if mat is not None:
+        _lib.check(lib.sml_host_gather_column(mat.ctypes.data, mat.shape[0], mat.strides[0], mat.dtype.itemsize, col, order.ctypes.data,
+                                              n, tri.ctypes.data, 2), "sml_host_gather_column")
+    return True
+
+
 class testDataset(Dataset):
     """reference data/dataset2.py:160-170"""
 
@@ -89,8 +110,9 @@ class trainDataset_withPreSample(Dataset):
         if self._ui is None:                 # (user, item) side by side: one 16-byte gather per row and epoch instead of two
             self._ui = np.ascontiguousarray(a[:, :2], dtype=np.int64)      # strided ones through the 8 KB rows
         tri = np.empty((self.data_len, 3), dtype=np.int64)
-        tri[:, :2] = self._ui[order]
-        tri[:, 2] = a[order, col]
+        if not _gather_into(tri, self._ui, order, a, int(col)):
+            tri[:, :2] = self._ui[order]
+            tri[:, 2] = a[order, col]
         self._advance(self.data_len)
         return tri
 
@@ -148,7 +170,8 @@ class offlineDataset_withsample(Dataset):
         order = np.asarray(order)
         n = order.shape[0]
         out = np.empty((n, 3), dtype=np.int64)
-        out[:, :2] = self._ui[order]
+        if not _gather_into(out, self._ui, order):
+            out[:, :2] = self._ui[order]
         users = np.ascontiguousarray(out[:, 0])
         pop = self.item_all.shape[0]
         items_all = np.ascontiguousarray(self.item_all, dtype=np.int64)
