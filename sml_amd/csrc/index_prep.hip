@@ -14,12 +14,16 @@
 //   k_prep_scan     per list: bucket offsets, the tiles' first positions per bucket, the list of oversized buckets;
 //   k_prep_scatter  stable partition: every occurrence goes to its bucket as ONE packed entry (row_hi << vb | value),
 //                   in occurrence order (ranks by wavefront ballots, no atomics: the order is a function of the input);
-//   k_prep_bucket   one workgroup per bucket: the entries are sorted by row_hi in LDS (stable radix passes of <= 9 bits),
-//                   runs are read off the sorted bucket and the outputs leave directly;
-//   k_prep_large    buckets above SML_PREP_SMALL entries (a row with thousands of occurrences): the same passes through
-//                   global memory, chunk by chunk;
+//   k_prep_wave     lists cut into small buckets: one WAVEFRONT per bucket -- duplicate filter (two LDS bitmaps), the few
+//                   candidates ranked in registers, the outputs leave directly; fuller buckets go onto a list;
+//   k_prep_bucket   one workgroup per bucket (or per listed bucket; or per list, straight from the triples: MF stage): the
+//                   filter, then the candidates are sorted by row_hi in LDS (stable radix passes of <= 9 bits), runs are
+//                   read off the sorted bucket and the outputs leave directly;
+//   k_prep_large    buckets above SML_PREP_SMALL entries (a row with thousands of occurrences): the same passes in LDS
+//                   + registers up to 96 KB of entries, beyond that through global memory, chunk by chunk;
 //   k_prep_compact  (bare step) the buckets' run records, written to per-bucket stretches, become one list per batch.
 // No atomics on shared counters anywhere on the path of every occurrence (one per oversized bucket, one per hot run).
+// Several GPUs: the same kernels over other occurrence streams (occ_of, k_prep_hist_x / k_prep_scatter_x).
 // HBM traffic per triple: 24 B (triples) x 2 + 12 B written + 12 B read + marks / records of duplicated rows -- against
 // 4 radix passes over 8-byte pairs per table before.  Occurrences of one row always meet in one bucket; buckets are cut
 // by the LOW row bits so that a popular block of neighbouring ids spreads over all of them.
