@@ -138,6 +138,13 @@ def bench_bare(a, device, dist=None):
         tt = torch.tensor([dtm], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dtm = float(tt.item())
+    # the index preparation alone (nothing else on the chip): its own time and rate
+    barrier()
+    tp0 = time.perf_counter()
+    for _ in range(5):
+        cur = eng.bare_prepare(tri, a.bare_batch, users_local, a.items, exchange=ex)
+    torch.cuda.synchronize(device)
+    prep_us = (time.perf_counter() - tp0) / 5 * 1e6
     cur = eng.bare_prepare(tri, a.bare_batch, users_local, a.items, exchange=ex)      # (prepared ahead, as in the timed loop)
     torch.cuda.synchronize(device)
     eng.profile(True)
@@ -170,7 +177,10 @@ def bench_bare(a, device, dist=None):
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                         "end_to_end_achieved": e2e, "end_to_end_frac": e2e / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_step": a_sgd * min(a.bare_batch, n), "algorithmic_bytes_per_triple": a_sgd},
-           "kernels": {k: {"launches": c, "total_ms": round(m, 3), "avg_us": round(1000.0 * m / c, 2)} for k, (c, m) in prof.items()}}
+           "kernels": {k: {"launches": c, "total_ms": round(m, 3), "avg_us": round(1000.0 * m / c, 2)} for k, (c, m) in prof.items()},
+           # index lists of an epoch (index_prep.hip), alone on the chip: wall per epoch; algorithmic rate = the triples once
+           # + one mark per occurrence (27 B per triple); fabric bytes per epoch from the committed counter passes
+           "index_prep": dict({"us_per_epoch": prep_us, "algorithmic_GBps": n * 27 / (prep_us * 1e-6) / 1e9}, **prep_fabric())}
     del eng, wu, wi, tri
     torch.cuda.empty_cache()
     return out
@@ -182,6 +192,20 @@ A3_CONFIGS = (   # (tag, users, items, d, dtype, item zipf): BASELINE.json confi
     ("d64_f32_zipf", 10000000, 1000000, 64, "f32", 1.0),
     ("d128_f16_uniform", 50000000, 5000000, 128, "f16", 0.0),
 )
+
+
+def prep_fabric():
+    """Fabric bytes per prepared epoch (FETCH x 2 + WRITE of the k_prep_* kernels) from the latest committed
+    profiles/r*_index_prep.json (tools/profile_round.sh; 10M x 1M, d = 32, uniform items)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_index_prep.json")))
+    if not files:
+        return {}
+    try:
+        z = json.load(open(files[-1])).get("bare_z0", {})
+        return {"fabric_bytes_per_epoch_from_profiles": z.get("fabric_bytes_per_epoch"), "fabric_profile": os.path.basename(files[-1])}
+    except Exception:
+        return {}
 
 
 def a3_object(a, device):
@@ -208,7 +232,8 @@ def a3_object(a, device):
                         "triples_per_s": r["value"], "bytes_per_triple": r["roofline"]["algorithmic_bytes_per_triple"],
                         "kernel_frac": r["roofline"]["frac"], "end_to_end_frac": r["roofline"]["end_to_end_frac"],
                         "kernel_GBps": r["roofline"]["achieved"],
-                        "kernels_avg_us": {k: v["avg_us"] for k, v in r["kernels"].items()}}
+                        "kernels_avg_us": {k: v["avg_us"] for k, v in r["kernels"].items()},
+                        "index_prep": r.get("index_prep")}
         except Exception as e:      # noqa: BLE001 -- e.g. a smaller-memory part: report, do not lose the headline line
             res[tag] = {"error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.empty_cache()
