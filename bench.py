@@ -90,14 +90,128 @@ def parse():
     ap.add_argument("--bare-triples", type=int, default=1 << 22)
     ap.add_argument("--bare-dtype", default="f32", choices=["f32", "f16"])
     ap.add_argument("--item-zipf", type=float, default=1.0)
+    ap.add_argument("--bare-items", default="sharded", choices=["sharded", "replicated"],
+                    help="several GPUs, --workload bare: item table sharded over the ranks (owner-computes over the peer exchange; "
+                         "the form configs 4 / 5 need) or replicated with a per-batch all-gather of gradient rows (exchange-bound "
+                         "by design: a labelled comparison)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="several GPUs, yelp_period: weak = every rank its own period over its own user shard (global batch = "
+                         "N x the reference's); strong = ONE period with the reference's global batches (1024 / 256) split over "
+                         "the ranks by user owner")
+    ap.add_argument("--one-device", action="store_true",
+                    help="test mode for a 1-GPU box: all N rank processes share device 0 (gloo carries torch.distributed)")
     return ap.parse_args()
+
+
+def zipf_head_rows(n_item, zipf_a, occ_per_batch, d, net_size):
+    """Rows of a Zipf(a) catalogue worth REPLICATING in the item-sharded step: those expected to occur at least 16 times
+    in a global batch (their occurrences would otherwise all land on one owner), capped by what the dense head partial
+    may hold (head_rows * d <= 2 * net size, a theta slot of the inbox).  0 for a uniform catalogue."""
+    if zipf_a <= 0.0:
+        return 0
+    ranks = np.arange(1, min(n_item, 1 << 20) + 1, dtype=np.float64)
+    h = float((1.0 / np.power(np.arange(1, n_item + 1, dtype=np.float64), zipf_a)).sum())
+    want = int((occ_per_batch / np.power(ranks, zipf_a) / h >= 16.0).sum())
+    cap = (2 * net_size // d) // 4 * 4
+    return int(min(want, cap, n_item))
+
+
+def bench_bare_sharded(a, device, dist):
+    """a3 on several GPUs the way configs 4 / 5 need it (model/baseline.py:188-201 semantics, exact synchronous SGD of the
+    GLOBAL batch): users row-sharded, the item table SHARDED too -- a replicated head of the popular rows, the tail
+    owner-computes over the one-shot peer exchange (sml_embed_loss_sgd_epoch_sharded).  Weak scaling in the triples:
+    every rank brings `bare_triples` triples per epoch and `bare_batch` per batch over a table of FIXED total size.
+    Returns the result dict, or None when the peer exchange is not available (the caller then runs the replicated form)."""
+    from sml_amd import dist as smldist
+    from sml_amd import synth
+    from sml_amd.engine import HipEngine
+    world, rank = dist.get_world_size(), dist.get_rank()
+    eng = HipEngine(device, a.d, a.bare_batch)
+    ctx = smldist.attach(eng, None, dist, rows_cap=2 * a.bare_batch)
+    ok = ctx.mode == "peer" and smldist.shard_visibility_check(eng, dist)
+    if not ok:
+        if rank == 0:
+            print("[bench] item-sharded bare step unavailable (carrier %s, shard visibility %s): replicated form instead"
+                  % (ctx.mode, "not checked" if ctx.mode != "peer" else "FAILED"), file=sys.stderr)
+        eng.peer_detach()
+        return None
+    dt = torch.float32 if a.bare_dtype == "f32" else torch.float16
+    users_local = -(-a.users // world)
+    head = zipf_head_rows(a.items, a.item_zipf, 2 * a.bare_batch * world, a.d, eng.net_size)
+    H, S = smldist.item_shard_layout(a.items, world, head)
+    g = torch.Generator(device=device).manual_seed(4)
+    w_head = (torch.randn(max(H, 1), a.d, device=device, generator=g) * 0.1).to(dt)[:H]      # the same replica on every rank
+    g.manual_seed(400 + rank)
+    shard = eng.peer_tensor((S, a.d), dt)
+    shard.copy_((torch.randn(S, a.d, device=device, generator=g) * 0.1).to(dt))
+    g.manual_seed(40 + rank)
+    wu = (torch.randn(users_local, a.d, device=device, generator=g) * 0.1).to(dt)
+    rng = np.random.RandomState(4 + 1000 * rank)
+    u, i, j = synth.synth_triples(rng, a.bare_triples, users_local, a.items, a_user=0.0, a_item=a.item_zipf)
+    tri = torch.from_numpy(np.stack([u, i, j], 1)).to(device)
+    sh = ctx.bare_shard(eng, tri, a.items, head, w_head, shard, 0)
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(a.warmup):
+        eng.bare_epoch_sharded(wu, tri, a.bare_batch, 0.05, 1e-6, 1e-6, sh, bce=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        eng.bare_epoch_sharded(wu, tri, a.bare_batch, 0.05, 1e-6, 1e-6, sh, bce=True)
+    barrier()
+    dtm = time.perf_counter() - t0
+    tt = torch.tensor([dtm], device=device, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dtm = float(tt.item())
+    eng.profile(True)
+    eng.bare_epoch_sharded(wu, tri, a.bare_batch, 0.05, 1e-6, 1e-6, sh, bce=True)
+    torch.cuda.synchronize(device)
+    prof = eng.profile_read()
+    eng.profile(False)
+    ctx.check_exchange(eng, "bench bare (item-sharded)", replicas=[w_head] if H > 0 else [])     # raises on a time-out / drifted head
+    s = wu.element_size()
+    a_sgd = 24 + 6 * a.d * s
+    n = a.bare_triples
+    t_k = sum(prof.get(k, (0, 0.0))[1] for k in ("k_bare_grad", "k_seg_update_sgd", "k_hot_rows")) / 1e3
+    ach = n * a_sgd / t_k / 1e9 if t_k > 0 else None
+    e2e = a.steps * n / dtm * a_sgd / 1e9
+    tail_frac = float(((i >= H).mean() + (j >= H).mean()) / 2.0)
+    remote = tail_frac * (world - 1) / world
+    out = {"metric": "bare embed+loss+SGD step triples/s (a3), synthetic uniform users / Zipf(%g) items, d=%d %s" % (a.item_zipf, a.d, a.bare_dtype),
+           "value": world * a.steps * n / dtm, "unit": "triples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": 1000.0 * dtm / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": a.bare_dtype, "data": "synthetic",
+           "config": {"workload": "bare: users=%d (row-sharded over %d GPU(s)) items=%d (SHARDED: %d replicated head rows + %d tail rows "
+                                  "per rank) triples/epoch/GPU=%d batch/GPU=%d (global batch %d); index lists built inline every epoch"
+                                  % (a.users, world, a.items, H, S, n, a.bare_batch, world * a.bare_batch),
+                      "parallelism": "users row-sharded x%d, items sharded x%d with a replicated head: tail rows read from / gradient "
+                                     "rows stored to their owner over peer mappings (owner-computes), dense one-shot all-reduce of the "
+                                     "head" % (world, world),
+                      "carrier": ctx.mode, "peer_timeouts": int(eng.peer_status()),
+                      "remote_item_row_fraction": remote},
+           "roofline": {"kernel": "k_bare_grad<SH> + k_run_update (owner update) per GPU", "bound": "hbm", "achieved": ach,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": None,
+                        "end_to_end_achieved": e2e, "end_to_end_frac": e2e / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_triple": a_sgd,
+                        # what crosses xGMI per triple: the remote share of 2 item rows read + 2 fp32 gradient rows stored
+                        "xgmi_bytes_per_triple": remote * (2 * a.d * s + 2 * a.d * 4),
+                        "xgmi_GBps_per_gpu_end_to_end": remote * (2 * a.d * s + 2 * a.d * 4) * a.steps * n / dtm / 1e9},
+           "kernels": {k: {"launches": c, "total_ms": round(m, 3), "avg_us": round(1000.0 * m / c, 2)} for k, (c, m) in prof.items()}}
+    dist.barrier()                       # nobody frees a shard a peer may still read
+    del eng, wu, tri, sh
+    torch.cuda.empty_cache()
+    return out
 
 
 def bench_bare(a, device, dist=None):
     """a3 alone: synchronous minibatch SGD on (user, pos, neg) triples over large tables.  Returns the result dict.
-    dist (several GPUs, weak scaling): the `users` rows are sharded over the ranks (each rank holds users/world rows and
-    draws `bare_triples` triples over them), the item table is replicated, every global batch is the union of the ranks'
-    batches: item-gradient rows are all-gathered per batch and every rank applies the identical item update."""
+    dist (several GPUs, weak scaling), the REPLICATED-items comparison form: the `users` rows are sharded over the ranks (each
+    rank holds users/world rows and draws `bare_triples` triples over them), the item table is replicated, every global batch
+    is the union of the ranks' batches: item-gradient rows are all-gathered per batch and every rank applies the identical item
+    update -- exchange-bound by a factor of ten by design; bench_bare_sharded is the form that scales."""
     from sml_amd import synth
     from sml_amd.engine import HipEngine
     world = dist.get_world_size() if dist is not None else 1
@@ -115,6 +229,7 @@ def bench_bare(a, device, dist=None):
     ex = None
     if dist is not None:
         from sml_amd import dist as smldist
+        os.environ.setdefault("SML_COMM", "rccl")       # (the replicated form is not wired to the inboxes: RCCL, else the hooks)
         ctx = smldist.attach(eng, None, dist)
         ex = ctx.bare_exchange(tri, a.bare_batch, a.d, 0)         # item columns gathered once: the triples are reused every epoch
 
@@ -168,9 +283,9 @@ def bench_bare(a, device, dist=None):
            "config": {"workload": "bare: users=%d (row-sharded over %d GPU(s)) items=%d (replicated) triples/epoch/GPU=%d batch/GPU=%d"
                                   % (a.users, world, a.items, n, a.bare_batch),
                       "parallelism": "single GPU" if world == 1 else
-                      "users row-sharded x%d, items replicated, per-batch all-gather of item-gradient rows (%s)"
-                      % (world, {"rccl": "native RCCL", "torch": "torch.distributed hooks"}.get(ctx.mode, "torch.distributed hooks (peer mode: "
-                                                                                                 "the replicated-items bare step is not wired to the inboxes)"))},
+                      "COMPARISON FORM (exchange-bound by design): users row-sharded x%d, items replicated, per-batch all-gather of "
+                      "item-gradient rows (%s)" % (world, {"rccl": "native RCCL", "torch": "torch.distributed hooks"}.get(ctx.mode, "torch.distributed hooks")),
+                      "carrier": ctx.mode if dist is not None else None},
            # traffic (PMC bytes) cannot be read from inside the process: null here; the rocprofv3 --pmc passes of this
            # command are tools/profile_round.sh's, summarised under profiles/
            "roofline": {"kernel": "k_bare_grad + k_seg_update_sgd + k_hot_rows (one a3 step)", "bound": "hbm", "achieved": ach,
@@ -375,8 +490,9 @@ def cpu_baseline(a, hp):
     """The CPU oracle (oracle/sml_oracle.py, kind 'port') on a bounded sample of the same
     period: full-size tables (dense Adam cost scales with the table), 8 MF batches, 16 TR
     batches, updata over 1/16 of the rows, evaluation of 2048 rows; scaled to one period.
-    Timed at TWO thread counts -- 16 and os.cpu_count() -- and the faster one is `value` (both are reported: intra-op
-    threading of the oracle's small tensors stops scaling well before a 256-core host's core count)."""
+    `value` is the full bounded sample at min(16, os.cpu_count()) threads; ONE batch per stage is also timed at
+    os.cpu_count() threads and reported beside it (`by_threads`): intra-op threading of the oracle's small tensors stops
+    scaling well before a 256-core host's core count, which is why the cap exists."""
     from oracle import sml_oracle as O
     from sml_amd.conv_transfer import ConvTransfer_com
     from sml_amd.mf import MFbasemode
@@ -440,24 +556,47 @@ def cpu_baseline(a, hp):
                       % (n_mf, n_tr, best["period_s_est"], best["cores"], best["mf_s"], best["tr_s"], best["updata_s"], best["eval_s"])}
 
 
+def _init_ranks(device):
+    """torch.distributed for a rank process: RCCL one process per GPU; gloo when the ranks share a device (test mode)."""
+    import torch.distributed as dist
+    from sml_amd import launch
+    if launch.backend() == "nccl":
+        dist.init_process_group("nccl", device_id=device)
+    else:
+        dist.init_process_group("gloo")
+    return dist
+
+
 def main():
     a = parse()
+    from sml_amd import launch
+    if a.gpus > 1 and not launch.is_rank_process():
+        # `python bench.py --gpus N` as the driver runs it: this process has made NO GPU call.  It starts N fresh rank
+        # processes (rendezvous and HSA_ENABLE_IPC_MODE_LEGACY=0 in their environment), relays rank 0's ONE JSON line
+        # and leaves with the ranks' exit code.
+        argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+        code, _ = launch.spawn_ranks(argv, a.gpus, one_device=a.one_device or os.environ.get("SML_ONE_DEVICE") == "1")
+        raise SystemExit(code)
+    launch.prepare_rank_env()           # (ranks started by torchrun: the IPC mode, before the first HIP call)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if a.gpus != 1 and world == 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+        raise SystemExit("bench.py --gpus %d inside a job of WORLD_SIZE %d" % (a.gpus, world))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if a.workload == "bare":
         quiet = _StdoutToStderr()
         quiet.__enter__()
         dist = None
-        if world > 1:
-            import torch.distributed as dist
-            dist.init_process_group("nccl", device_id=device)
-        res = bench_bare(a, device, dist)
+        force_dist = os.environ.get("SML_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ
+        if world > 1 or force_dist:
+            dist = _init_ranks(device)
+        res = None
+        if dist is not None and a.bare_items == "sharded":
+            res = bench_bare_sharded(a, device, dist)
+        if res is None:
+            res = bench_bare(a, device, dist)
         if rank == 0:
             quiet.emit(json.dumps(res))
         if dist is not None:
@@ -466,7 +605,7 @@ def main():
         quiet.__exit__()
         return
     from sml_amd.engine import HipEngine
-    from sml_amd.period import Hyper, run_period, synth_plan
+    from sml_amd.period import Hyper, route_plan, run_period, synth_plan
     hp = Hyper(multi_num=a.multi_num)
     quiet = _StdoutToStderr()
     quiet.__enter__()          # for the whole run: RCCL prints its banner whenever a communicator is first used --
@@ -474,47 +613,74 @@ def main():
     dist = None
     force_dist = os.environ.get("SML_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ   # exercise the exchange path at N=1
     if world > 1 or force_dist:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        dist = _init_ranks(device)
         from sml_amd import dist as smldist
     engine = HipEngine(device, a.d, max(hp.MF_batch_size, hp.TR_batch_size))
-    # weak scaling: every rank owns a shard of `users` users and processes its own period of
-    # `inter` interactions over them; items are replicated
-    U_local = a.users
-    st = build_state(engine, U_local, a.items, a.d, device, seed=2000 + rank)
+    strong = dist is not None and a.scaling == "strong"
+    # weak scaling: every rank owns a shard of `users` users and processes its own period of `inter` interactions over
+    # them (global batch = world x the reference's).  strong scaling: ONE period over `users` users, the reference's
+    # global batches split over the ranks by user owner.  Items and theta are replicated either way.
+    if strong:
+        lo, hi = smldist.user_range(a.users, world, rank)
+        U_local = max(hi - lo, 1)
+    else:
+        U_local = a.users
+    st = build_state(engine, U_local, a.items, a.d, device, seed=2000 + (0 if strong else rank))
+    dctx = None
     if dist is not None:
         dctx = smldist.attach(engine, st, dist, hp)
-    n_plans = min(a.steps + a.warmup, 2)
-    plans = [synth_plan(100 + 17 * rank + p, a.inter, U_local, a.items, a.neg, hp, device, with_val=not a.no_val)
-             for p in range(max(n_plans, 1))]
+    n_plans = max(min(a.steps + a.warmup, 2), 1)
+    exchanges = None
+    if strong:
+        # every rank draws the SAME periods (same seeds) and keeps its users' share of every global batch
+        glob = [synth_plan(100 + p, a.inter, a.users, a.items, a.neg, hp, device, with_val=not a.no_val) for p in range(n_plans)]
+        plans = [route_plan(dctx, g, hp, a.users, a.d, device) for g in glob]
+        triples_per_period = plans[0].n_global_triples
+        del glob
+    else:
+        plans = [synth_plan(100 + 17 * rank + p, a.inter, U_local, a.items, a.neg, hp, device, with_val=not a.no_val)
+                 for p in range(n_plans)]
+        triples_per_period = plans[0].n_train_triples() * world
+        if dctx is not None:
+            # the job-wide item-occurrence lists of every MF epoch, from the resident inputs (one all-gather of the item
+            # columns per epoch, here, not in the timed loop)
+            exchanges = {id(t): dctx.mf_exchange(t, hp.MF_batch_size, a.d, 0) for pl in plans for ph in pl.mf_triples for t in ph}
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    def replicas():
+        return [st.MFbase.item_laten.weight.data, engine.adopt(st.transfer)]
+
     # the chip is partitioned: training kernels on 192 CUs, the side-stream evaluations on the other 64 (engine.partition)
     with engine.partition():
         for w in range(a.warmup):
-            run_period(engine, st, plans[w % len(plans)], hp, overlap=not a.no_overlap)
+            run_period(engine, st, plans[w % len(plans)], hp, overlap=not a.no_overlap, exchanges=exchanges)
     barrier()
     t0 = time.perf_counter()
     with engine.partition():
         for s in range(a.steps):
-            run_period(engine, st, plans[(a.warmup + s) % len(plans)], hp, overlap=not a.no_overlap)
+            run_period(engine, st, plans[(a.warmup + s) % len(plans)], hp, overlap=not a.no_overlap, exchanges=exchanges)
     barrier()
     dt = time.perf_counter() - t0
     engine.side_sync_check()          # the periods dropped their evaluation results: an unordered evaluation still fails the run
+    peer_timeouts = None
     if dist is not None:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    triples_per_period = plans[0].n_train_triples()
-    value = a.steps * triples_per_period * world / dt
+        # the exchange was whole: no consumer timed out, theta and the item table are bit-identical on every rank (raises)
+        dctx.check_exchange(engine, "bench (%s scaling)" % a.scaling, replicas=replicas())
+        peer_timeouts = int(engine.peer_status()) if dctx.mode == "peer" else 0
+    value = a.steps * triples_per_period / dt
 
+    carriers = {"peer": "one-shot exchange over peer mappings (hipIpc, no collective library on the data path)",
+                "rccl": "native RCCL exchange", "torch": "torch.distributed hooks"}
     out = {"metric": "SML retrain-period training triples/s (MF + transfer stages), Yelp-shaped synthetic, d=%d" % a.d,
            "value": value, "unit": "triples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-           "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": "yelp_period: users=%d items=%d interactions/period=%d neg=%d d=%d multi_num=%d "
                                   "MF_batch=%d TR_batch=%d val_eval=%s (the reference's 40 validation evaluations per period: "
@@ -522,16 +688,23 @@ def main():
                                   "numbers); inputs resident in HBM: host batch supply and H2D are outside the timed region"
                                   % (a.users, a.items, a.inter, a.neg, a.d, hp.multi_num, hp.MF_batch_size, hp.TR_batch_size,
                                      not a.no_val),
-                      "parallelism": ("users row-sharded x%d, items and theta replicated, independent shards (global batch = %d x the "
-                                      "reference's), %s" %
-                                      (world, world, {"peer": "one-shot exchange over peer mappings (hipIpc, no collective library on the data path)",
-                                                      "rccl": "native RCCL exchange", "torch": "torch.distributed hooks"}[dctx.mode]))
-                      if dist is not None else "single GPU"}}
+                      "parallelism": (("users row-sharded x%d, items and theta replicated, %s, %s" %
+                                       (world, "ONE period: the reference's global batches (%d / %d) split over the ranks by user owner"
+                                        % (hp.MF_batch_size, hp.TR_batch_size) if strong else
+                                        "independent shards: every rank its own period (global batch = %d x the reference's)" % world,
+                                        carriers[dctx.mode]))
+                                      if dist is not None else "single GPU")}}
+    if dist is not None:
+        out["config"].update({"carrier": dctx.mode, "carrier_wanted": getattr(dctx, "wanted", None), "peer_timeouts": peer_timeouts,
+                              "replicas_bit_identical": True, "ranks_share_one_device": launch.one_device()})
+        if not strong and not a.no_roofline and os.environ.get("SML_BENCH_STRONG_LEG", "1") != "0":
+            # the strong-scaling leg beside the weak one: ONE period (the same on every rank), reference batches split by owner
+            out["strong_scaling"] = strong_leg(a, hp, engine, dctx, dist, device, world, rank)
 
     if not a.no_roofline:
         engine.profile(True)
         with engine.partition():
-            run_period(engine, st, plans[0], hp, overlap=not a.no_overlap)
+            run_period(engine, st, plans[0], hp, overlap=not a.no_overlap, exchanges=exchanges)
         torch.cuda.synchronize(device)
         prof = engine.profile_read()
         engine.profile(False)
@@ -552,7 +725,7 @@ def main():
             n_launch = sum(c for c, _ in train.values())
             derived = (sum(m for _, m in train.values()) - 1000.0 * dt / a.steps) * 1000.0 / max(n_launch, 1)
             overhead_us = min(max(derived, 0.0), empty_pair_us)
-            if bound is not None and cnt:
+            if bound is not None and cnt and not strong:
                 per_launch = work / cnt
                 avg_raw_s = ms / 1000.0 / cnt
                 avg_s = max(avg_raw_s - overhead_us * 1e-6, 0.25 * avg_raw_s)
@@ -574,10 +747,17 @@ def main():
                                    "avg_launch_us_rocprof": rp_us, "rocprof_profile": rp_file,
                                    "frac_rocprof": ((per_launch / (rp_us * 1e-6) / (1e9 if bound == "hbm" else 1e12)) / peak) if rp_us else None}
             out["kernels"] = kern
-    if rank == 0 and world == 1 and not a.no_a3:
-        del plans, st
+    if not a.no_a3:
+        del plans, st, exchanges
         torch.cuda.empty_cache()
-        out["a3"] = a3_object(a, device)
+        if world == 1 and dist is None:
+            out["a3"] = a3_object(a, device)
+        elif dist is not None and not launch.one_device():
+            # the fused embed+loss+SGD step at configs 4 / 5's shapes with the item table SHARDED over the job's ranks
+            # (every rank takes part: the legs hold collectives)
+            if dctx.mode == "peer":
+                engine.peer_detach()
+            out["a3"] = a3_object_sharded(a, device, dist)
     if rank == 0 and world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(a, hp)
     if rank == 0:
@@ -586,6 +766,73 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     quiet.__exit__()
+
+
+def strong_leg(a, hp, engine, dctx, dist, device, world, rank):
+    """Strong scaling beside the weak headline: ONE Yelp-shaped period, the same on every rank (same seed), with the
+    reference's global batches (1024 / 256 triples) split over the ranks by user owner (sml_amd.dist.EpochRoute): what
+    `main_yelp.py --gpus N` runs.  A fresh state over this rank's user range; 1 untimed + 2 timed periods."""
+    from sml_amd import dist as smldist
+    from sml_amd.period import route_plan, run_period, synth_plan
+    lo, hi = smldist.user_range(a.users, world, rank)
+    st = build_state(engine, max(hi - lo, 1), a.items, a.d, device, seed=2000)
+    dctx.sync_replicas([st.MFbase.item_laten.weight.data, st.last_item, st.hat_item, st.prev_hat_item, engine.adopt(st.transfer)])
+    plan = route_plan(dctx, synth_plan(100, a.inter, a.users, a.items, a.neg, hp, device, with_val=not a.no_val), hp, a.users, a.d, device)
+    with engine.partition():
+        run_period(engine, st, plan, hp, overlap=not a.no_overlap)
+    dist.barrier()
+    torch.cuda.synchronize(device)
+    k = 2
+    t0 = time.perf_counter()
+    with engine.partition():
+        for _ in range(k):
+            run_period(engine, st, plan, hp, overlap=not a.no_overlap)
+    dist.barrier()
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], device=device, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    engine.side_sync_check()
+    dctx.check_exchange(engine, "bench (strong-scaling leg)", replicas=[st.MFbase.item_laten.weight.data, engine.adopt(st.transfer)])
+    return {"scaling": "strong", "periods_timed": k, "ms_per_period": 1000.0 * dt / k, "triples_per_s": k * plan.n_global_triples / dt,
+            "global_batches": [hp.MF_batch_size, hp.TR_batch_size], "carrier": dctx.mode,
+            "peer_timeouts": int(engine.peer_status()) if dctx.mode == "peer" else 0}
+
+
+A3_SHARDED_CONFIGS = (   # BASELINE.json configs 4 and 5: the shapes north_star's >= 6x at 8 GPUs is quoted on
+    ("c4_d64_f32_zipf", 10000000, 1000000, 64, "f32", 1.0),
+    ("c5_d128_f16_uniform", 50000000, 5000000, 128, "f16", 0.0),
+)
+
+
+def a3_object_sharded(a, device, dist):
+    import copy
+    res = {}
+    for tag, users, items, d, dt, zipf in A3_SHARDED_CONFIGS:
+        b = copy.copy(a)
+        b.users, b.items, b.d, b.bare_dtype, b.item_zipf = users, items, d, dt, zipf
+        b.bare_batch, b.bare_triples, b.steps, b.warmup = 262144, 1 << 22, 8, 2
+        err = None
+        try:
+            r = bench_bare_sharded(b, device, dist)
+        except Exception as e:      # noqa: BLE001 -- reported below; the vote keeps the ranks together
+            r, err = None, "%s: %s" % (type(e).__name__, e)
+        ok = torch.tensor([0.0 if r is None else 1.0], device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) < 0.5:
+            res[tag] = {"error": err or "unavailable on some rank (peer exchange / shard visibility check)"}
+            torch.cuda.empty_cache()
+            if err is not None:     # a rank that raised mid-epoch cannot rejoin the collectives of the next leg
+                break
+            continue
+        res[tag] = {"users": users, "items": items, "d": d, "dtype": dt, "item_zipf": zipf, "batch_per_gpu": b.bare_batch,
+                    "n_gpus": r["n_gpus"], "ms_per_epoch": r["ms_per_step"], "triples_per_s": r["value"],
+                    "bytes_per_triple": r["roofline"]["algorithmic_bytes_per_triple"], "kernel_frac_per_gpu": r["roofline"]["frac"],
+                    "end_to_end_frac_per_gpu": r["roofline"]["end_to_end_frac"], "xgmi_GBps_per_gpu": r["roofline"]["xgmi_GBps_per_gpu_end_to_end"],
+                    "carrier": r["config"]["carrier"], "peer_timeouts": r["config"]["peer_timeouts"],
+                    "kernels_avg_us": {k: v["avg_us"] for k, v in r["kernels"].items()}}
+    return res
 
 
 if __name__ == "__main__":

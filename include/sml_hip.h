@@ -64,9 +64,9 @@ int sml_ctx_destroy(sml_ctx* ctx);
 int sml_ctx_set_variant(sml_ctx* ctx, int variant);
 /* --clip_grad (reference model/transfer.py:725-727, torch.nn.utils.clip_grad_norm_(transfer.parameters(), max_norm, 2)
  * between backward and optimizer.step() in the TR loop): max_norm > 0 makes the TR stage epoch finish the flat theta
- * gradient (after the exchange on several GPUs), take its 2-norm and scale it by min(1, max_norm / (norm + 1e-6)) before
- * Adam; the step then runs un-fused (one reduction launch + one Adam launch more per batch).  0 switches it off.  Not
- * available on the one-shot peer exchange. */
+ * gradient (after the exchange on several GPUs; on the one-shot peer exchange the rank-order sum of the inbox slots is
+ * materialised first), take its 2-norm and scale it by min(1, max_norm / (norm + 1e-6)) before Adam; the step then runs
+ * un-fused (one reduction launch + one Adam launch more per batch).  0 switches it off. */
 int sml_ctx_set_grad_clip(sml_ctx* ctx, float max_norm);
 /* --need_adaptive (reference model/transfer.py:490-499, beta = 0.1 there): the MF stage's loss gains
  * sum over the batch's unique users of beta * count_u / ||w_u|| (detached) * ||w_u||^2; beta > 0 adds it (one small launch per
@@ -128,6 +128,13 @@ int sml_comm_allgather(sml_ctx* ctx, const float* src, float* dst, int64_t n_per
 int sml_peer_region_bytes(sml_ctx* ctx, int world, int64_t rows_cap, int64_t* inbox_bytes, int64_t* flags_bytes);
 int sml_peer_alloc(int device, int64_t bytes, void** ptr);      /* zeroed; synchronous */
 int sml_peer_free(int device, void* ptr);
+/* What sml_peer_alloc got for `ptr`: 0 uncached, 1 fine-grained, 2 plain (coarse-grained) device memory, -1 not one of its
+ * allocations.  Inboxes and flags that other DEVICES write must not be plain: sml_amd.dist refuses that combination. */
+int sml_peer_mem_kind(void* ptr);
+/* dst <- src (bytes, a multiple of 16; both 16-byte aligned) through system-scope loads that bypass this device's caches:
+ * how a rank reads memory another device rewrites (an item shard of sml_embed_loss_sgd_epoch_sharded).  The start-up
+ * visibility check of sml_amd.dist uses it on a probe allocation of the same kind as the shards. */
+int sml_peer_read(int device, const void* src, void* dst, int64_t bytes, void* stream);
 int sml_peer_export(void* ptr, void* handle64);
 int sml_peer_open(int device, const void* handle64, void** ptr);
 int sml_peer_close(int device, void* ptr);

@@ -45,7 +45,10 @@ _COMMON = [
     ("--test_in_TR_Train", dict(type=bool, default=False, help='(unused)')),
     # extension (not a reference flag): draw the transfer stage's shuffles and negatives on the GPU -- the same
     # distribution, not the reference's numpy/torch random streams (default: stream-exact host path)
-    ("--device_batches", dict(type=int, default=0, help='1: build the transfer stage batches on the device (not stream-exact)')),
+    ("--device_batches", dict(type=int, default=0, help='1: build the MF and transfer stage batches on the device (not stream-exact)')),
+    # extension (the reference is single-device, main_yelp.py:125): run as N rank processes, one per GPU of this node.
+    # The process that is given --gpus N > 1 starts the ranks itself (sml_amd.launch) and only relays rank 0's output
+    ("--gpus", dict(type=int, default=1, help='N > 1: one rank process per GPU of this node (users row-sharded by owner)')),
 ]
 
 _PER_DATASET = {
@@ -94,18 +97,28 @@ def main(which, argv=None):
 
     cfg = _PER_DATASET[which]
     args = get_parse(which).parse_args(argv)
+    from . import launch
+    if args.gpus > 1 and not launch.is_rank_process():
+        # the parent of the job: NOTHING here has touched the GPU yet.  Start one fresh rank process per GPU (IPC mode and
+        # rendezvous in their environment) running this same command line, relay rank 0's output, leave with their code
+        import sys
+        script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "main_%s.py" % which)
+        rest = list(sys.argv[1:] if argv is None else argv)
+        code, _ = launch.spawn_ranks([sys.executable, script] + rest, args.gpus, one_device=os.environ.get("SML_ONE_DEVICE") == "1")
+        raise SystemExit(code)
     if which == "yelp" and "LOCAL_RANK" not in os.environ:
         os.environ["CUDA_VISIBLE_DEVICES"] = str(args.cuda)      # reference main_yelp.py:125
-    # `torchrun --nproc-per-node N main_yelp.py ...`: one process per GPU.  Every rank runs this same program on the
-    # same seeds and files; users are sharded by owner inside meta_train (sml_amd/dist.py), rank 0 prints.
+    # One process per GPU (`main_yelp.py --gpus N`, or `torchrun --nproc-per-node N main_yelp.py ...`).  Every rank runs
+    # this same program on the same seeds and files; users are sharded by owner inside meta_train (sml_amd/dist.py), rank 0 prints.
     dist = None
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        launch.prepare_rank_env()            # (torchrun does not set the IPC mode: before the first HIP call of this process)
         import torch.distributed as dist
         local = int(os.environ.get("LOCAL_RANK", "0"))
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
         if not dist.is_initialized():
-            dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+            dist.init_process_group(launch.backend() if torch.cuda.is_available() else "gloo")
         if dist.get_rank() != 0:
             import sys
             sys.stdout = open(os.devnull, "w")

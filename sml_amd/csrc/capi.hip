@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -991,8 +992,6 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
     if ((rc = ensure_transfer_ws(ctx, batch, true, st))) return rc;
     // --clip_grad (model/transfer.py:725-727): the flat gradient is completed, its norm taken, and the Adam launch scales it
     const bool clip = ctx->clip_max_norm > 0.0f;
-    if (clip && !grad_hook && ctx->peer.world > 0)
-        return fail(SML_ESTATE, "sml_tr_stage_epoch", "gradient clipping is not available on the one-shot peer exchange (detach the peers or use a hook)");
     if (clip) HIPCHK(ctx->clip_sumsq.ensure(4));
     float* grad = theta_grad ? theta_grad : ctx->grad.p;
     const int fns = fwd_split(wg_tiles(batch, 1) + wg_tiles(2 * batch, 1)), bsplit = bwd_split(wg_tiles(batch, 1) + wg_tiles(2 * batch, 1));
@@ -1073,7 +1072,15 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
             // k_peer_wait launch ahead of it instead -- one launch more; same results)
             static const bool poll_in_adam = env_int("SML_PEER_POLL_IN_ADAM", 1) != 0;
             ctx->prof.begin(PC_THETA_ADAM, st);
-            if (!poll_in_adam) { HIPCHK(sml_launch_peer_wait(ad.peer, st)); ad.peer.waited = 1; }
+            if (clip) {
+                // --clip_grad on the peer carrier: the rank-order sum of the slots is materialised once (k_peer_sum polls
+                // and adds exactly as the fused form would), its norm taken, and the plain Adam launch scales it -- every
+                // rank forms the same bits, so the replicas stay identical
+                HIPCHK(sml_launch_peer_sum(grad, 2 * ns, ad.peer, st, (int)ns));
+                HIPCHK(sml_launch_grad_sumsq(grad, 2 * ns, ctx->clip_sumsq.p, st));
+                ad.peer.world = 0;
+                ad.clip_sumsq = ctx->clip_sumsq.p; ad.clip_max_norm = ctx->clip_max_norm;
+            } else if (!poll_in_adam) { HIPCHK(sml_launch_peer_wait(ad.peer, st)); ad.peer.waited = 1; }
             HIPCHK(sml_launch_theta_adam(d, ad, st));
             ctx->prof.end(st);
         } else if (!grad_hook && !native && !clip) {
@@ -1573,6 +1580,15 @@ int sml_peer_region_bytes(sml_ctx* ctx, int world, int64_t rows_cap, int64_t* in
     *flags_bytes = (int64_t)3 * 2 * world * (int64_t)sizeof(unsigned long long);     // kinds: theta / head, rows, "owner done"
     return SML_OK;
 }
+namespace {
+std::mutex g_peer_kind_mu;
+std::map<void*, int> g_peer_kind;          // allocation -> 0 uncached, 1 fine-grained, 2 plain device memory
+}
+int sml_peer_mem_kind(void* ptr) {
+    std::lock_guard<std::mutex> l(g_peer_kind_mu);
+    auto it = g_peer_kind.find(ptr);
+    return it == g_peer_kind.end() ? -1 : it->second;
+}
 int sml_peer_alloc(int device, int64_t bytes, void** ptr) {
     if (!ptr || bytes <= 0) return fail(SML_EINVAL, "sml_peer_alloc", "bad argument");
     DevGuard g(device);
@@ -1593,13 +1609,22 @@ int sml_peer_alloc(int device, int64_t bytes, void** ptr) {
     e = hipMemset(p, 0, (size_t)bytes);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) { (void)hipFree(p); return fail(SML_EHIP, "sml_peer_alloc", hipGetErrorString(e)); }
+    { std::lock_guard<std::mutex> l(g_peer_kind_mu); g_peer_kind[p] = got; }
     *ptr = p;
     return SML_OK;
 }
 int sml_peer_free(int device, void* ptr) {
     if (!ptr) return SML_OK;
     DevGuard g(device);
+    { std::lock_guard<std::mutex> l(g_peer_kind_mu); g_peer_kind.erase(ptr); }
     HIPCHK(hipFree(ptr));
+    return SML_OK;
+}
+int sml_peer_read(int device, const void* src, void* dst, int64_t bytes, void* stream) {
+    if (!src || !dst || bytes <= 0 || bytes % 16 || (uintptr_t)src % 16 || (uintptr_t)dst % 16)
+        return fail(SML_EINVAL, "sml_peer_read", "16-byte aligned pointers and size are needed");
+    DevGuard g(device);
+    HIPCHK(sml_launch_peer_read(src, dst, bytes / 16, (hipStream_t)stream));
     return SML_OK;
 }
 int sml_peer_export(void* ptr, void* handle64) {

@@ -36,6 +36,8 @@ template <> struct RowVec<float> {
         f32x4 v; v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
         __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
     }
+    // the lane's 16 bytes as they arrived through a cache-bypassing load (peer_load16x2)
+    __device__ static void decode(const f32x4& v, float (&x)[4]) { x[0] = v[0]; x[1] = v[1]; x[2] = v[2]; x[3] = v[3]; }
 };
 template <> struct RowVec<__half> {
     static constexpr int VEC = 8;
@@ -54,6 +56,11 @@ template <> struct RowVec<__half> {
     }
     __device__ static void load_nt(const __half* p, float (&x)[8]) { load(p, x); }
     __device__ static void store_nt(__half* p, const float (&x)[8]) { store(p, x); }
+    __device__ static void decode(const f32x4& v, float (&x)[8]) {
+        const __half2* h = reinterpret_cast<const __half2*>(&v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float2 f = __half22float2(h[i]); x[2 * i] = f.x; x[2 * i + 1] = f.y; }
+    }
 };
 
 template <int LPR>
@@ -227,8 +234,20 @@ __global__ __launch_bounds__(256) void k_bare_grad(SmlBareArgs a) {
             }
             return reinterpret_cast<const T*>(a.w_item) + row * D;
         };
-        RowVec<T>::load(item_row(ii, qi) + sub * VEC, it);
-        RowVec<T>::load(item_row(in, qn) + sub * VEC, ng);
+        if constexpr (SH) {
+            // Another rank REWRITES the rows this reads, every batch, from another device.  Its update kernel has ended
+            // (and released: its L2 is written back) before its "done" signal is pushed, so the new row is in its memory;
+            // what could still be stale is a line in THIS device's L2 from the previous batch.  System-scope
+            // (sc0 sc1) loads never take such a line: both item rows are fetched past the caches, head rows included
+            // (they are local; one code path).
+            f32x4 raw[2];
+            peer_load16x2(raw, reinterpret_cast<const float*>(item_row(ii, qi) + sub * VEC), reinterpret_cast<const float*>(item_row(in, qn) + sub * VEC));
+            RowVec<T>::decode(raw[0], it);
+            RowVec<T>::decode(raw[1], ng);
+        } else {
+            RowVec<T>::load(item_row(ii, qi) + sub * VEC, it);
+            RowVec<T>::load(item_row(in, qn) + sub * VEC, ng);
+        }
         if constexpr (LAZY) {
             static_assert(!LAZY || VEC == 4, "lazy Adam runs on fp32 tables");
             float m[3][4], v[3][4];
@@ -1459,13 +1478,35 @@ __global__ __launch_bounds__(256) void k_peer_push(const f32x4* __restrict__ src
 }
 __global__ __launch_bounds__(64) void k_peer_wait(SmlPeerPoll p) { peer_wait(p); }
 // dst[i] = slot 0 [i] + slot 1 [i] + ... in rank order (the start-up self-check of the theta path)
-__global__ __launch_bounds__(256) void k_peer_sum(float* __restrict__ dst, long long n, SmlPeerPoll p) {
+// theta_net > 0: the buffer is a flat theta gradient (two nets of theta_net floats) -- the conv block's alignment padding
+// is never pushed and may hold anything an earlier use of the slot left there (the start-up self-check's pattern): it
+// leaves as zero, as in the flat gradient of the other carriers (k_grad_sumsq reads the whole buffer)
+__global__ __launch_bounds__(256) void k_peer_sum(float* __restrict__ dst, long long n, SmlPeerPoll p, int theta_net) {
     peer_wait(p);
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float g = peer_load(p.slot0 + i);
     for (int q = 1; q < p.world; ++q) g += peer_load(p.slot0 + q * p.slot_stride + i);
+    if (theta_net > 0) { const int off = (int)(i % theta_net); if (off < SML_OFF_F1W && !conv_slot_used_host(off)) g = 0.0f; }
     dst[i] = g;
+}
+// dst <- src in 16-byte chunks through system-scope (cache-bypassing) loads: how a rank reads memory another DEVICE writes
+// (the start-up check of the item shards' visibility; the same load the sharded gradient pass uses for item rows)
+__global__ __launch_bounds__(256) void k_peer_read(const float* __restrict__ src, f32x4* __restrict__ dst, long long n16) {
+    const long long stride = (long long)gridDim.x * 256 * 2;
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 2; i < n16; i += stride) {
+        f32x4 v[2];
+        const long long j = i + 1 < n16 ? i + 1 : i;
+        peer_load16x2(v, src + 4 * i, src + 4 * j);
+        dst[i] = v[0];
+        if (j != i) dst[j] = v[1];
+    }
+}
+hipError_t sml_launch_peer_read(const void* src, void* dst, long long n16, hipStream_t st) {
+    long long nb = (n16 + 511) / 512;
+    nb = nb < 1 ? 1 : nb > 1024 ? 1024 : nb;
+    k_peer_read<<<dim3((unsigned)nb), dim3(256), 0, st>>>(reinterpret_cast<const float*>(src), reinterpret_cast<f32x4*>(dst), n16);
+    return hipGetLastError();
 }
 int sml_peer_push_blocks(long long n_floats) {
     long long nb = (n_floats / 4 + 1023) / 1024;      // four 16-byte chunks per thread
@@ -1479,8 +1520,8 @@ hipError_t sml_launch_peer_wait(const SmlPeerPoll& p, hipStream_t st) {
     k_peer_wait<<<dim3(1), dim3(64), 0, st>>>(p);
     return hipGetLastError();
 }
-hipError_t sml_launch_peer_sum(float* dst, long long n_floats, const SmlPeerPoll& p, hipStream_t st) {
-    k_peer_sum<<<dim3((unsigned)((n_floats + 255) / 256)), dim3(256), 0, st>>>(dst, n_floats, p);
+hipError_t sml_launch_peer_sum(float* dst, long long n_floats, const SmlPeerPoll& p, hipStream_t st, int theta_net) {
+    k_peer_sum<<<dim3((unsigned)((n_floats + 255) / 256)), dim3(256), 0, st>>>(dst, n_floats, p, theta_net);
     return hipGetLastError();
 }
 

@@ -203,6 +203,15 @@ __device__ __forceinline__ void peer_load16x8(f32x4 (&v)[8], const float* const 
         : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
         : "memory");
 }
+__device__ __forceinline__ void peer_load16x2(f32x4 (&v)[2], const float* p0, const float* p1) {
+    asm volatile(
+        "global_load_dwordx4 %0, %2, off sc0 sc1\n"
+        "global_load_dwordx4 %1, %3, off sc0 sc1\n"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1])
+        : "v"(p0), "v"(p1)
+        : "memory");
+}
 __device__ __forceinline__ void peer_load16x4(f32x4 (&v)[4], const float* const (&p)[4]) {
     asm volatile(
         "global_load_dwordx4 %0, %4, off sc0 sc1\n"

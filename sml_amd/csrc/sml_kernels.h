@@ -122,7 +122,8 @@ int sml_wgrad_grid(int d);                       // workgroups (= pushers) of on
 int sml_peer_push_blocks(long long n_floats);
 hipError_t sml_launch_peer_push(const float* src, long long n_floats, const SmlPeerPush& p, hipStream_t st);
 hipError_t sml_launch_peer_wait(const SmlPeerPoll& p, hipStream_t st);
-hipError_t sml_launch_peer_sum(float* dst, long long n_floats, const SmlPeerPoll& p, hipStream_t st);
+hipError_t sml_launch_peer_sum(float* dst, long long n_floats, const SmlPeerPoll& p, hipStream_t st, int theta_net = 0);
+hipError_t sml_launch_peer_read(const void* src, void* dst, long long n16, hipStream_t st);
 hipError_t sml_launch_selftest(const float* A, const float* W, float* pk, float* out, hipStream_t st);
 
 // sharded bare step: which occurrences a list holds

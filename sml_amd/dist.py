@@ -208,6 +208,8 @@ class DistContext(object):
     def all_gather_rows(self, dst, src):
         if self.native_gather:
             self.dist.all_gather_into_tensor(dst, src, group=self.group)
+        elif src.is_cuda:                        # gloo has no device all-gather (two ranks sharing one device in the tests)
+            dst.view(self.world, -1).copy_(self.all_gather_dev(src.reshape(-1)))
         else:
             self.dist.all_gather(list(dst.view(self.world, -1).unbind(0)), src, group=self.group)
 
@@ -227,9 +229,13 @@ class DistContext(object):
         seen = self.__dict__.setdefault("_same_seen", set())
         pend = self.__dict__.get("_same_pending")
         if pend is not None and (pend[1] is None or pend[1].query()):
-            verify(float(pend[0][0]), float(pend[0][1]))
-            self._same_pending = pend = None
-        if (what, value) not in seen:
+            self._same_pending = None
+            pend[2](float(pend[0][0]), float(pend[0][1]))       # (verified under the name it was queued with)
+            pend = None
+        if (what, value) not in seen or self.mode == "peer":
+            # first sight of this value -- or the peer path, where a rank that runs ahead on a mismatched epoch leaves
+            # its peers polling until the hang guard: there every answer is waited for (a host wait per EPOCH, not per
+            # batch)
             h = t.cpu()
             verify(float(h[0]), float(h[1]))
             seen.add((what, value))
@@ -239,9 +245,63 @@ class DistContext(object):
                 host.copy_(t, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(self.device))
-                self._same_pending = (host, ev)
+                self._same_pending = (host, ev, verify)
             else:
-                self._same_pending = (t, None)
+                self._same_pending = (t, None, verify)
+
+    def flush_checks(self):
+        """Wait for (and verify) the last deferred same_on_all_ranks answer: the driver calls this when a stage ends."""
+        pend = self.__dict__.get("_same_pending")
+        if pend is not None:
+            self._same_pending = None
+            if pend[1] is not None:
+                pend[1].synchronize()
+            pend[2](float(pend[0][0]), float(pend[0][1]))
+
+    # ---- what the control plane can carry: RCCL moves device tensors; gloo (CPU tests, two ranks sharing one device)
+    # all-reduces / broadcasts them but has no device all-gather
+    def all_gather_dev(self, t):
+        """[world, *t.shape] on t's device: every rank's `t` (same shape everywhere)."""
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        if t.is_cuda and not self.native_gather:
+            host = [torch.empty(t.shape, dtype=t.dtype) for _ in range(self.world)]
+            self.dist.all_gather(host, t.cpu(), group=self.group)
+            for q in range(self.world):
+                out[q].copy_(host[q])
+        else:
+            self.dist.all_gather(list(out.unbind(0)), t.contiguous(), group=self.group)
+        return out
+
+    # ---- safety nets of the exchange: a consumer that gave up waiting, replicas that drifted apart
+    def check_exchange(self, engine, where, replicas=()):
+        """Raise when the one-shot peer exchange lost a step since the last call (a consumer that was not released
+        within SML_PEER_TIMEOUT_S went on with a partial sum: the replicas are then wrong) or when `replicas` --
+        tensors that must be bit-identical on every rank (theta, the item tables) -- are not.  Synchronises the
+        device; called once per stage / at the end of a benchmark, never per batch."""
+        bad = 0
+        if self.mode == "peer" and hasattr(engine, "peer_status"):
+            torch.cuda.synchronize(self.device) if self.device.type == "cuda" else None
+            bad = int(engine.peer_status()) - int(self.__dict__.get("_peer_seen", 0))
+            self._peer_seen = int(self.__dict__.get("_peer_seen", 0)) + max(bad, 0)
+        sums = []
+        for r in replicas:
+            x = r.detach().reshape(-1)
+            # an order-independent fingerprint of the BITS (a float sum would hide a sign flip behind rounding)
+            bits = x.view(torch.int32).to(torch.int64) if x.dtype == torch.float32 else x.view(torch.int16).to(torch.int64)
+            sums.append(torch.stack([bits.sum(), (bits * bits % 1000003).sum()]))
+        t = torch.cat([torch.tensor([float(bad)], dtype=torch.float64, device=self.device)] +
+                      [v.to(torch.float64) for v in sums])
+        hi, lo = t.clone(), -t
+        self.dist.all_reduce(hi, op=self.dist.ReduceOp.MAX, group=self.group)
+        self.dist.all_reduce(lo, op=self.dist.ReduceOp.MAX, group=self.group)
+        hi, lo = hi.cpu(), (-lo).cpu()
+        if float(hi[0]) > 0:
+            raise RuntimeError("%s: %d consumer(s) of the one-shot peer exchange gave up waiting for a peer's push on some rank "
+                               "(SML_PEER_TIMEOUT_S): sums were formed from partial data; the replicas are not trustworthy"
+                               % (where, int(hi[0])))
+        if not torch.equal(hi[1:], lo[1:]):
+            which = [k for k in range(len(replicas)) if not torch.equal(hi[1 + 2 * k:3 + 2 * k], lo[1 + 2 * k:3 + 2 * k])]
+            raise RuntimeError("%s: replicated tensors %s differ between the ranks (exchange carrier: %s)" % (where, which, self.mode))
 
     def mf_exchange(self, triples, batch, d, loss_kind=LOSS_BCE):
         """Independent-shards mode: exchange descriptor of one MF epoch over this rank's `triples` [n,3] (every rank
@@ -249,8 +309,7 @@ class DistContext(object):
         n = triples.shape[0]
         self.same_on_all_ranks(n, "the epoch length n")
         items = triples[:, 1:3].contiguous()
-        alli = torch.empty((self.world,) + tuple(items.shape), dtype=items.dtype, device=items.device)
-        self.dist.all_gather(list(alli.unbind(0)), items, group=self.group)
+        alli = self.all_gather_dev(items)
         allt = torch.cat([torch.zeros((self.world, n, 1), dtype=items.dtype, device=items.device), alli], dim=2)
         stride = self.peer_stride(2 * batch)
         keys, vals = global_item_lists(allt, batch, stride)
@@ -275,8 +334,7 @@ class DistContext(object):
         n = triples.shape[0]
         self.same_on_all_ranks(n, "the epoch length n")
         items = triples[:, 1:3].contiguous()
-        items_all = torch.empty((self.world,) + tuple(items.shape), dtype=items.dtype, device=items.device)
-        self.dist.all_gather(list(items_all.unbind(0)), items, group=self.group)
+        items_all = self.all_gather_dev(items)
         key = ("bare", d, batch)
         if key not in self._buf:
             self._buf[key] = (torch.zeros(3 * batch * d, device=self.device, dtype=torch.float32),
@@ -308,8 +366,7 @@ class DistContext(object):
         if tuple(w_item_shard.shape[:1]) != (shard_rows,):
             raise ValueError("this rank's tail shard must have %d rows" % shard_rows)
         items = triples[:, 1:3].contiguous()
-        items_all = torch.empty((self.world,) + tuple(items.shape), dtype=items.dtype, device=items.device)
-        self.dist.all_gather(list(items_all.unbind(0)), items, group=self.group)
+        items_all = self.all_gather_dev(items)
         key = ("shard_ptrs", w_item_shard.data_ptr())
         ptrs = self._buf.get(key)
         if ptrs is None:
@@ -360,35 +417,217 @@ def _gather_objects(dist, obj, group):
     return out
 
 
+def _vote(dist, group, device, ok):
+    """True when EVERY rank says ok.  Every rank calls this at the same points of the set-up, whatever happened to it
+    locally: the ranks' collective sequences stay aligned, and they leave a failing path together."""
+    flag = torch.tensor([1.0 if ok else 0.0], device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(flag.item() > 0.5)
+
+
+class _PeerSetup(object):
+    """The one-shot exchange's set-up as LOCAL steps with an all-ranks vote after each (a rank that raises
+    inside a step that also holds collectives leaves the others in a mismatched collective).  Owned regions and opened
+    mappings are remembered so that a fall-back can release them."""
+
+    def __init__(self, engine, dist, group, rows_cap, timeout_s):
+        import os
+        self.e, self.dist, self.group = engine, dist, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.rows_cap = int(rows_cap)
+        self.timeout_s = float(os.environ.get("SML_PEER_TIMEOUT_S", "120")) if timeout_s is None else float(timeout_s)
+        self.same_process = dist.get_backend(group) == "threads"
+        self.inbox = self.flags = None
+        self.opened = []
+        self.why = None
+
+    def _try(self, fn):
+        try:
+            fn()
+            return True
+        except Exception as e:      # noqa: BLE001 -- any local failure is a "no" in the next vote
+            self.why = "%s: %s" % (type(e).__name__, e)
+            return False
+
+    def run(self):
+        import os
+        import sys
+        e, dist, group = self.e, self.dist, self.group
+        dev = e.device
+
+        def vote(ok, step):
+            good = _vote(dist, group, dev, ok)
+            if not good and self.why and os.environ.get("SML_DEBUG_PEER"):
+                print("[sml_amd.dist] rank %d, peer set-up step %r: %s" % (self.rank, step, self.why), file=sys.stderr)
+            return good
+
+        # 1. this rank's regions
+        def alloc():
+            ib, fb = e.peer_region_bytes(self.world, self.rows_cap)
+            self.inbox, self.flags = e.peer_alloc(ib), e.peer_alloc(fb)
+        if not vote(self._try(alloc), "alloc"):
+            return False
+        # 2. which device every rank sits on, and what kind of memory it got: other DEVICES may only write into
+        #    uncached / fine-grained regions (a plain allocation leaves the owner's L2 free to serve stale lines)
+        kinds = (e.peer_mem_kind(self.inbox), e.peer_mem_kind(self.flags))
+        where = _gather_objects(dist, (_device_identity(e), kinds), group)
+        several_devices = len({w[0] for w in where}) > 1
+        plain = any(k == 2 for w in where for k in w[1])
+        if several_devices and plain:
+            self.why = "an inbox / flags region is plain device memory and the ranks sit on different devices"
+            if self.rank == 0:
+                print("[sml_amd.dist] peer exchange refused: %s" % self.why, file=sys.stderr)
+            return False
+        # 3. handles out, mappings in
+        handles = {}
+
+        def export():
+            handles["mine"] = (self.inbox, self.flags) if self.same_process else (e.peer_export(self.inbox), e.peer_export(self.flags))
+        if not vote(self._try(export), "export"):
+            return False
+        got = _gather_objects(dist, handles["mine"], group)
+        maps = {}
+
+        def open_all():
+            if self.same_process:
+                maps["inbox"], maps["flags"] = [g[0] for g in got], [g[1] for g in got]
+                return
+            ib, fl = [], []
+            for q in range(self.world):
+                if q == self.rank:
+                    ib.append(self.inbox); fl.append(self.flags)
+                else:
+                    a = e.peer_open(got[q][0]); self.opened.append(a)
+                    b = e.peer_open(got[q][1]); self.opened.append(b)
+                    ib.append(a); fl.append(b)
+            maps["inbox"], maps["flags"] = ib, fl
+        if not vote(self._try(open_all), "open"):
+            return False
+        if not vote(self._try(lambda: e.peer_attach(self.world, self.rank, maps["inbox"], maps["flags"], self.rows_cap,
+                                                    timeout_s=self.timeout_s)), "attach"):
+            return False
+        dist.barrier(group=group)                 # every rank is attached before anybody pushes
+        # 4. self-check: SML_PEER_CHECK_ROUNDS (default 6 = three per parity) one-shot all-reduces with a pattern that
+        #    changes every round -- a slot served from a stale cache line, or a counter that lags, shows as the previous
+        #    round's values; a short hang guard of its own
+        rounds = max(2, int(os.environ.get("SML_PEER_CHECK_ROUNDS", "6")))
+        n = 4096
+        base = torch.arange(n, device=dev, dtype=torch.float32)
+        state = {"ok": True}
+
+        def check():
+            for k in range(rounds):
+                src = base * (0.25 + k) + float((self.rank + 1) * (k + 1))
+                want = base * (0.25 + k) * self.world + (k + 1) * self.world * (self.world + 1) / 2.0
+                got_ = e.peer_allreduce_check(src, timeout_s=min(self.timeout_s, 20.0))
+                state["ok"] = bool(torch.equal(got_, want)) and state["ok"]
+            state["ok"] = state["ok"] and e.peer_status() == 0
+            if not state["ok"]:
+                self.why = "self-check mismatch or time-out"
+        ok = self._try(check) and state["ok"]
+        return vote(ok, "self-check")
+
+    def release(self):
+        """After a failed set-up: nobody will use the regions.  Detach, wait for every rank, then unmap and free."""
+        e = self.e
+        try:
+            e.peer_detach()
+        except Exception:      # noqa: BLE001
+            pass
+        self.dist.barrier(group=self.group)       # no peer has a kernel in flight that targets a region freed below
+        if not self.same_process:
+            for a in self.opened:
+                try:
+                    e.peer_close(a)
+                except Exception:      # noqa: BLE001
+                    pass
+        self.dist.barrier(group=self.group)       # every mapping is closed before its owner frees the memory
+        for a in (self.inbox, self.flags):
+            if a:
+                try:
+                    e.peer_free(a)
+                except Exception:      # noqa: BLE001
+                    pass
+        self.inbox = self.flags = None
+        self.opened = []
+
+
+def _device_identity(engine):
+    """Something two ranks share exactly when they sit on the same physical device: (host, bus id)."""
+    import socket
+    try:
+        bus = torch.cuda.get_device_properties(engine.device).pci_bus_id
+        dom = getattr(torch.cuda.get_device_properties(engine.device), "pci_domain_id", 0)
+        dvc = getattr(torch.cuda.get_device_properties(engine.device), "pci_device_id", 0)
+        return (socket.gethostname(), int(dom), int(bus), int(dvc))
+    except Exception:      # noqa: BLE001
+        return (socket.gethostname(), "index", int(engine.device.index or 0))
+
+
 def peer_setup(engine, dist, group, rows_cap, timeout_s=None):
     """Allocate this rank's inbox / flags regions, exchange them with every rank of `group` and attach (sml_peer_attach).
     One process per GPU: the regions travel as hipIpc handles (dmabuf IPC: HSA_ENABLE_IPC_MODE_LEGACY=0 must be in the
     environment) and are opened with lazy peer access.  Ranks that are threads of ONE process (tests on one GPU):
-    the raw addresses travel.  Ends with a start-up self-check: every rank pushes a pattern through the theta slots and
-    reads back the rank-order sum.  Returns True when this rank's check passed."""
-    import os
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    if timeout_s is None:
-        timeout_s = float(os.environ.get("SML_PEER_TIMEOUT_S", "120"))
-    ib, fb = engine.peer_region_bytes(world, rows_cap)
-    inbox, flags = engine.peer_alloc(ib), engine.peer_alloc(fb)
-    same_process = dist.get_backend(group) == "threads"
-    if same_process:
-        got = _gather_objects(dist, (inbox, flags), group)
-        inboxes, flagses = [g[0] for g in got], [g[1] for g in got]
+    the raw addresses travel.  Every local step is followed by an all-ranks vote (the ranks leave a failing set-up
+    together, collectives aligned); it ends with the start-up self-check.  Returns True when ALL ranks passed; on False
+    everything the set-up allocated or mapped has been released."""
+    ps = _PeerSetup(engine, dist, group, rows_cap, timeout_s)
+    ok = ps.run()
+    if not ok:
+        ps.release()
     else:
-        got = _gather_objects(dist, (engine.peer_export(inbox), engine.peer_export(flags)), group)
-        inboxes = [inbox if q == rank else engine.peer_open(got[q][0]) for q in range(world)]
-        flagses = [flags if q == rank else engine.peer_open(got[q][1]) for q in range(world)]
-    engine.peer_attach(world, rank, inboxes, flagses, rows_cap, timeout_s=timeout_s)
-    dist.barrier(group=group)                 # every rank is attached before anybody pushes
-    n = 1024
-    src = torch.arange(n, device=engine.device, dtype=torch.float32) * 0.25 + float(rank + 1)
-    want = torch.arange(n, device=engine.device, dtype=torch.float32) * 0.25 * world + world * (world + 1) / 2.0
-    ok = True
-    for _ in range(2):                        # both parities; a short hang guard of its own
-        ok = bool(torch.equal(engine.peer_allreduce_check(src, timeout_s=min(timeout_s, 20.0)), want)) and ok
-    return ok and engine.peer_status() == 0
+        engine._peer_setup = ps
+    return ok
+
+
+def shard_visibility_check(engine, dist, group=None, rounds=3, n=4096):
+    """Start-up check of the item-sharded bare step's one cross-device assumption: a row an OWNER rewrote
+    with ordinary stores in one kernel is seen by a READER on another device in a later kernel.  A probe of the same
+    memory kind as the shards (HipEngine.peer_tensor) is rewritten `rounds` times by its owner (a plain torch kernel),
+    and after each round every rank reads every other rank's probe through its peer mapping with the loads the gradient
+    pass uses (sml_peer_read: system scope, cache-bypassing) -- a stale line shows as the previous round's value.
+    Returns True when all ranks saw all rounds right."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = engine.device
+    state = {"ok": True}
+    probe = None
+    try:
+        probe = engine.peer_tensor((n,), torch.float32)
+        mine = probe.data_ptr() if dist.get_backend(group) == "threads" else engine.peer_export(probe.data_ptr())
+    except Exception:      # noqa: BLE001
+        state["ok"], mine = False, None
+    if not _vote(dist, group, dev, state["ok"]):
+        return False
+    got = _gather_objects(dist, mine, group)
+    ptrs, opened = [], []
+    try:
+        for q in range(world):
+            if q == rank or dist.get_backend(group) == "threads":
+                ptrs.append(got[q] if q != rank else probe.data_ptr())
+            else:
+                a = engine.peer_open(got[q]); opened.append(a); ptrs.append(a)
+    except Exception:      # noqa: BLE001
+        state["ok"] = False
+    if not _vote(dist, group, dev, state["ok"]):
+        return False
+    base = torch.arange(n, device=dev, dtype=torch.float32)
+    for k in range(rounds):
+        probe.copy_(base * (k + 1) + float(rank * 1000 + k))       # the owner's ordinary stores
+        torch.cuda.synchronize(dev)
+        dist.barrier(group=group)                                  # every owner has written round k
+        for q in range(world):
+            seen = engine.peer_read(ptrs[q], n)
+            state["ok"] = state["ok"] and bool(torch.equal(seen, base * (k + 1) + float(q * 1000 + k)))
+        torch.cuda.synchronize(dev)
+        dist.barrier(group=group)                                  # everybody has read round k before it is overwritten
+    ok = _vote(dist, group, dev, state["ok"])
+    for a in opened:
+        try:
+            engine.peer_close(a)
+        except Exception:      # noqa: BLE001
+            pass
+    dist.barrier(group=group)
+    return ok
 
 
 def attach(engine, state, dist, hp=None, group=None, rows_cap=None):
@@ -396,7 +635,12 @@ def attach(engine, state, dist, hp=None, group=None, rows_cap=None):
     are broadcast from rank 0 so that replicas start identical.
 
     Who carries the per-batch exchange (SML_COMM = peer | rccl | torch; default peer):
-      peer    one-shot push / poll over peer mappings (sml_peer_*): no collective library on the data path;
+      peer    one-shot push / poll over peer mappings (sml_peer_*): no collective library on the data path.  It is the
+              default BECAUSE its start-up self-check runs the protocol itself across the job's devices (six rounds of
+              changing patterns through both slot parities, every counter and every mapping) and every rank must pass;
+              plain-memory regions are refused when the ranks sit on different devices; and the driver / bench verify
+              after every stage that no consumer timed out and that the replicas are still bit-identical
+              (DistContext.check_exchange).  Anything short of that falls through to
       rccl    the library's own RCCL communicator issues ncclAllReduce / ncclAllGather on the compute stream;
       torch   torch.distributed hooks called from the library per batch.
     Every rank runs the chosen path's start-up self-check; unless ALL ranks pass, the job falls back to the next one."""
@@ -406,25 +650,18 @@ def attach(engine, state, dist, hp=None, group=None, rows_cap=None):
     import os
     import sys
     want = os.environ.get("SML_COMM", "peer")
-
-    def all_ok(ok):
-        flag = torch.tensor([1.0 if ok else 0.0], device=ctx.device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-        return bool(flag.item() > 0.5)
+    ctx.wanted = want
 
     if want == "peer" and hasattr(engine, "peer_attach"):
         if rows_cap is None:
             rows_cap = 2 * int(hp.MF_batch_size) if hp is not None and hasattr(hp, "MF_batch_size") else 2 * int(engine.max_batch)
-        try:
-            ok = peer_setup(engine, dist, group, int(rows_cap))
-        except Exception as e:   # noqa: BLE001 -- any failure means: use the next path
-            print("[sml_amd.dist] peer-mapping exchange unavailable on rank %d: %s" % (ctx.rank, e), file=sys.stderr)
-            ok = False
-        if all_ok(ok):
+        if peer_setup(engine, dist, group, int(rows_cap)):
             ctx.mode, ctx.native, ctx.peer_rows_cap = "peer", True, int(rows_cap)
             engine.grad_hook = None
         else:
-            engine.peer_detach()
+            if ctx.rank == 0:
+                print("[sml_amd.dist] one-shot peer exchange unavailable (set SML_DEBUG_PEER=1 for the step that failed): "
+                      "falling back to the RCCL exchange", file=sys.stderr)
             want = "rccl"
     # the native RCCL exchange (issued by the library on the compute stream, no host callback per batch)
     if ctx.mode == "torch" and want == "rccl" and hasattr(engine, "comm_init") and dist.get_backend(group) == "nccl":
@@ -433,7 +670,7 @@ def attach(engine, state, dist, hp=None, group=None, rows_cap=None):
         except Exception as e:   # noqa: BLE001 -- any failure means: use the hook path
             print("[sml_amd.dist] native RCCL exchange unavailable on rank %d: %s" % (ctx.rank, e), file=sys.stderr)
             ok = False
-        if all_ok(ok):
+        if _vote(dist, group, ctx.device, ok):
             ctx.mode, ctx.native = "rccl", True
             engine.grad_hook = None
         elif ok:

@@ -257,6 +257,23 @@ class meta_train(object):
             fn(*[_val(a) for a in args])
         if hasattr(self.engine, "side_sync_check"):
             self.engine.side_sync_check()      # one check for all the evaluations collected above (not one read-back each)
+        if not getattr(self, "_stage_failed", False):     # (a stage that raised must not enter collectives its peers may never reach)
+            self._check_exchange("stage")
+
+    def _check_exchange(self, where):
+        """Several GPUs: a stage ends with proof that its exchange was whole -- no consumer of the one-shot peer exchange
+        timed out (it would have gone on with a partial sum) and theta / the item table are still bit-identical on
+        every rank (sml_amd.dist.DistContext.check_exchange raises otherwise).  The stage's results have just been
+        waited for, so the synchronisation this needs costs nothing more."""
+        if self.dist is None:
+            return
+        self.dist.flush_checks()
+        reps = [self.MFbase.item_laten.weight.data]
+        if hasattr(self.engine, "adopt"):
+            reps.append(self.engine.adopt(self.transfer))
+        else:
+            reps += [p.data for p in self.transfer.parameters()]
+        self.dist.check_exchange(self.engine, where, replicas=reps)
 
     def _pair(self, resolve, n):
         """(recall, ndcg) from a (hits, ndcg_sum) resolver; lazy while output is deferred."""
@@ -478,7 +495,10 @@ class meta_train(object):
                                                     args.TR_batch_size, args.TR_lr, args.TR_l2, bce=True, clip_max_norm=clip)
             else:
                 if isinstance(triples, torch.Tensor):
-                    raise NotImplementedError("--device_batches with several GPUs: the ranks must share one epoch")
+                    # --device_batches on several GPUs: every rank drew the SAME epoch (the seed came from the shared
+                    # torch generator, the device generator is counter-based) -- nothing is communicated; the split by
+                    # user owner runs on the host as for the exact path (one read-back per epoch)
+                    triples = triples.cpu().numpy()
                 route = self.dist.route_epoch(triples, args.TR_batch_size, self.n_user_global,
                                               mean_loss=self.transfer_variant_is_bce())
                 losses = self.engine.tr_stage_epoch(self.transfer, self.last_user_weight, self.last_item_weight,
@@ -530,6 +550,7 @@ class meta_train(object):
         if set_t is None:
             return False
         self._defer, self._queue = self.writer is None, []
+        self._stage_failed = True
         try:
             # the training kernels of the stage run on the training partition of the chip, the queued evaluations on
             # the side stream's own CUs (HipEngine.partition; the CPU test double has no such thing)
@@ -538,6 +559,7 @@ class meta_train(object):
                 more = self._stage_body(args, stage_id, set_t, set_tt, now_test, val)
             if more and getattr(self, "_prefetch", False):
                 self._prefetch_next(stage_id + 1)
+            self._stage_failed = False
             return more
         finally:
             self._defer = False

@@ -817,7 +817,12 @@ class HipEngine(object):
         path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         if not os.path.exists(path):
             path = "librccl.so"
-        if self.lib.sml_comm_load(path.encode()) != 0:
+        loaded = self.lib.sml_comm_load(path.encode()) == 0
+        # (a vote BEFORE the first collective of this function: a rank that cannot bind RCCL must not leave the others
+        # inside the broadcast below)
+        flag = torch.tensor([1.0 if loaded else 0.0], device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if float(flag.item()) < 0.5:
             return False
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         buf = ctypes.create_string_buffer(128)
@@ -851,6 +856,30 @@ class HipEngine(object):
         check(self.lib.sml_peer_alloc(self.device.index, int(nbytes), ctypes.byref(p)), "sml_peer_alloc")
         self.__dict__.setdefault("_peer_owned", []).append(p.value)
         return p.value
+
+    def peer_mem_kind(self, ptr):
+        """0 uncached, 1 fine-grained, 2 plain device memory, -1 not a peer_alloc allocation."""
+        return int(self.lib.sml_peer_mem_kind(ctypes.c_void_p(int(ptr))))
+
+    def peer_free(self, ptr):
+        """Free a peer_alloc region (only once every rank has detached and unmapped it)."""
+        check(self.lib.sml_peer_free(self.device.index, ctypes.c_void_p(int(ptr))), "sml_peer_free")
+        owned = self.__dict__.get("_peer_owned", [])
+        if ptr in owned:
+            owned.remove(ptr)
+
+    def peer_close(self, ptr):
+        check(self.lib.sml_peer_close(self.device.index, ctypes.c_void_p(int(ptr))), "sml_peer_close")
+        opened = self.__dict__.get("_peer_opened", [])
+        if ptr in opened:
+            opened.remove(ptr)
+
+    def peer_read(self, ptr, n_floats):
+        """n_floats fp32 values at device address `ptr` (possibly another rank's memory), read with system-scope loads."""
+        out = torch.empty(int(n_floats), device=self.device, dtype=torch.float32)
+        check(self.lib.sml_peer_read(self.device.index, ctypes.c_void_p(int(ptr)), _ptr(out), int(n_floats) * 4, self._stream()),
+              "sml_peer_read")
+        return out
 
     def peer_tensor(self, shape, dtype=torch.float32):
         """A zeroed torch tensor over memory of its OWN device allocation (plain device memory, sml_peer_alloc): unlike a

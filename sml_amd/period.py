@@ -91,7 +91,35 @@ def synth_plan(seed, n_inter, n_user, n_item, neg, hp, device, user_lo=0, user_h
     return PeriodPlan(val_rows, mf, tr)
 
 
-def run_period(engine, st, plan, hp, record=None, overlap=True):
+class RoutedEpoch(object):
+    """One epoch of the reference's GLOBAL batches as this rank runs it (strong scaling): its share of every batch
+    (sml_amd.dist.EpochRoute: split by user owner, unequal and empty local batches), resident on the device."""
+
+    def __init__(self, route, d, device, with_exchange):
+        self.local_tri = torch.from_numpy(route.local_tri).to(device)
+        self.cap, self.plan = route.cap, route.plan
+        self.exchange = route.exchange(d) if with_exchange else None
+        self.n_global = route.n
+
+
+def route_plan(dctx, plan, hp, n_user_global, d, device, mean_loss=True):
+    """Strong scaling: the same period every rank holds (same seed), with every epoch's GLOBAL batches (hp.MF_batch_size /
+    hp.TR_batch_size, the reference's) split over the ranks by user owner.  Nothing about indices is communicated: every
+    rank derives all ranks' counts from the global epoch.  Returns a PeriodPlan whose epochs are RoutedEpoch objects and
+    whose validation rows are this rank's users' rows (user column re-indexed into the shard)."""
+    mf = [[RoutedEpoch(dctx.route_epoch(t.cpu().numpy(), hp.MF_batch_size, n_user_global, mean_loss), d, device, True) for t in ph]
+          for ph in plan.mf_triples]
+    tr = [[RoutedEpoch(dctx.route_epoch(t.cpu().numpy(), hp.TR_batch_size, n_user_global, mean_loss), d, device, False) for t in ph]
+          for ph in plan.tr_triples]
+    val = None
+    if plan.val_rows is not None:
+        val = torch.from_numpy(dctx.route_rows(plan.val_rows.cpu().numpy(), n_user_global)).to(device)
+    out = PeriodPlan(val, mf, tr)
+    out.n_global_triples = sum(e.n_global for ph in mf for e in ph) + sum(e.n_global for ph in tr for e in ph)
+    return out
+
+
+def run_period(engine, st, plan, hp, record=None, overlap=True, exchanges=None):
     """Execute one period.  Returns (last MF batch losses, last TR batch losses) device tensors.
 
     Validation scheduling (results identical to evaluating in place):
@@ -137,8 +165,15 @@ def run_period(engine, st, plan, hp, record=None, overlap=True):
     for ph in range(hp.multi_num):
         evaluate("before MF")
         for tri in plan.mf_triples[ph]:
-            mf_loss = engine.mf_stage_epoch(mf, net, st.last_user, st.last_item, tri, hp.MF_batch_size,
-                                            hp.MF_lr, hp.l2, norm=False, bce=True)
+            if isinstance(tri, RoutedEpoch):      # this rank's share of the reference's global batches
+                mf_loss = engine.mf_stage_epoch(mf, net, st.last_user, st.last_item, tri.local_tri, tri.cap,
+                                                hp.MF_lr, hp.l2, norm=False, bce=True, plan=tri.plan, exchange=tri.exchange)
+            else:
+                # (exchanges: several GPUs, independent shards -- the epoch's job-wide item lists, built ahead from the
+                # resident inputs; without them engine.mf_stage_epoch gathers the item columns itself, every epoch)
+                ex = exchanges.get(id(tri)) if exchanges else None
+                mf_loss = engine.mf_stage_epoch(mf, net, st.last_user, st.last_item, tri, hp.MF_batch_size,
+                                                hp.MF_lr, hp.l2, norm=False, bce=True, exchange=ex)
             engine.mf_flush(mf)
             state["version"] += 1
             evaluate("MF epoch")
@@ -148,8 +183,12 @@ def run_period(engine, st, plan, hp, record=None, overlap=True):
         updata()
         evaluate("before TR")
         for tri in plan.tr_triples[ph]:
-            tr_loss = engine.tr_stage_epoch(net, st.last_user, st.last_item, st.hat_user, st.hat_item, tri,
-                                            hp.TR_batch_size, hp.TR_lr, hp.TR_l2, bce=True)
+            if isinstance(tri, RoutedEpoch):
+                tr_loss = engine.tr_stage_epoch(net, st.last_user, st.last_item, st.hat_user, st.hat_item, tri.local_tri,
+                                                tri.cap, hp.TR_lr, hp.TR_l2, bce=True, plan=tri.plan)
+            else:
+                tr_loss = engine.tr_stage_epoch(net, st.last_user, st.last_item, st.hat_user, st.hat_item, tri,
+                                                hp.TR_batch_size, hp.TR_lr, hp.TR_l2, bce=True)
             if plan.val_rows is not None:
                 updata()
                 evaluate("TR epoch")

@@ -234,3 +234,55 @@ def test_item_shard_layout_routes_every_row_to_exactly_one_place():
         assert np.array_equal(back, rows)                                 # a bijection onto (owner, local)
         counts = np.bincount(owner[H:], minlength=world) if n_item > H else np.zeros(world, dtype=np.int64)
         assert counts.max() <= S and (counts > 0).sum() == min(world, -(-(n_item - H) // S) if n_item > H else 0)
+
+
+# ----------------------------------------------------------------------------- the rank launcher (bench.py / main_yelp.py --gpus N)
+def test_launcher_starts_fresh_ranks_with_the_ipc_environment_and_relays_rank_zero():
+    """sml_amd.launch.spawn_ranks: N fresh rank processes from a parent that makes no GPU call, the rendezvous and
+    HSA_ENABLE_IPC_MODE_LEGACY=0 in their environment, rank 0's stdout is the job's, the others' goes to stderr."""
+    import json
+    from sml_amd import launch
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_launch_child.py")
+    code, out = launch.spawn_ranks([sys.executable, child], 2, echo_stdout=False, timeout=180)
+    assert code == 0
+    # (gloo itself prints a connection banner on stdout; bench.py keeps such library chatter off the job's stdout with
+    # its fd-level redirect -- this child does not, so the JSON line is picked out)
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and "noise from rank" not in out, out
+    got = json.loads(lines[0])
+    assert got == {"sum": 3.0, "world": 2, "ipc_legacy": "0", "launched": "1", "local_rank": "0", "one_device": None, "master": "127.0.0.1"}
+    code, out = launch.spawn_ranks([sys.executable, child], 2, one_device=True, echo_stdout=False, timeout=180)
+    assert code == 0 and json.loads([l for l in out.splitlines() if l.startswith("{")][0])["one_device"] == "1"
+
+
+def test_launcher_returns_the_failing_ranks_code_and_stops_the_others():
+    from sml_amd import launch
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_launch_child.py")
+    code, out = launch.spawn_ranks([sys.executable, child, "--fail-rank", "1"], 2, echo_stdout=False, timeout=180)
+    assert code == 3
+    assert "{" not in out             # rank 0 never got past the barrier: no line, and the launcher did not hang
+
+
+def test_bench_parent_makes_no_gpu_call_before_spawning(monkeypatch):
+    """`python bench.py --gpus 2` in a process that is not a rank must hand over to the launcher before anything touches
+    torch.cuda (the parent of GPU ranks may not initialise HIP: an exec / fork after that takes the box down)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from sml_amd import launch
+    seen = {}
+
+    def fake_spawn(argv, world, one_device=False, **kw):
+        seen.update(argv=argv, world=world, one_device=one_device)
+        return 0, ""
+    monkeypatch.setattr(launch, "spawn_ranks", fake_spawn)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda *a, **k: (_ for _ in ()).throw(AssertionError("GPU call in the parent")))
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: (_ for _ in ()).throw(AssertionError("GPU call in the parent")))
+    for k in ("SML_LAUNCHED", "WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "1", "--one-device"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    assert seen["world"] == 2 and seen["one_device"] is True and seen["argv"][2:] == ["--gpus", "2", "--steps", "1", "--one-device"]

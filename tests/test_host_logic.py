@@ -478,3 +478,107 @@ def test_csr_resolver_equals_pair_list_resolver():
         assert np.array_equal(out[0][0], out[1][0])
         own = set(pairs.tolist())
         assert all(int(u) * I + int(c) not in own for u, c in zip(users[:out[1][2]], out[1][0]))
+
+
+# ----------------------------------------------------------------------------- multi-GPU set-up logic (no GPU involved)
+class _FakePeerEngine(object):
+    """The part of HipEngine's surface sml_amd.dist._PeerSetup uses, with a scripted outcome per step."""
+    device = torch.device("cpu")
+
+    def __init__(self, kind=0, fail_at=None):
+        self.kind, self.fail_at, self.calls, self.freed, self.closed = kind, fail_at, [], [], []
+
+    def _step(self, name):
+        self.calls.append(name)
+        if self.fail_at == name:
+            raise RuntimeError("scripted failure in %s" % name)
+
+    def peer_region_bytes(self, world, rows_cap):
+        return 64, 64
+
+    def peer_alloc(self, nbytes):
+        self._step("alloc")
+        return 0x1000 + 0x100 * len([c for c in self.calls if c == "alloc"])
+
+    def peer_mem_kind(self, ptr):
+        return self.kind
+
+    def peer_export(self, ptr):
+        self._step("export")
+        return b"h" * 64
+
+    def peer_open(self, handle):
+        self._step("open")
+        return 0x9000 + len(self.calls)
+
+    def peer_attach(self, *a, **k):
+        self._step("attach")
+
+    def peer_allreduce_check(self, src, timeout_s=0.0):
+        self._step("check")
+        return src * 0.0            # never the expected sum: the self-check fails
+
+    def peer_status(self):
+        return 0
+
+    def peer_detach(self):
+        self.calls.append("detach")
+
+    def peer_close(self, ptr):
+        self.closed.append(ptr)
+
+    def peer_free(self, ptr):
+        self.freed.append(ptr)
+
+
+@pytest.mark.parametrize("case", ["plain_across_devices", "one_rank_fails_to_open", "self_check_fails"])
+def test_peer_setup_leaves_a_failing_path_on_every_rank_together_and_releases_its_regions(case, monkeypatch):
+    """sml_amd.dist.peer_setup: every local step is followed by an all-ranks vote, so a rank that fails
+    alone does not leave its peers in a mismatched collective; plain (coarse-grained) inbox memory is REFUSED when the
+    ranks sit on different devices; whatever the set-up allocated or mapped is released on the way out."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _thread_group import run_ranks
+    from sml_amd import dist as SD
+    monkeypatch.setattr(SD, "_device_identity", lambda e: ("host", e.rank_tag))
+
+    class Procs(object):              # a 2-rank group that does NOT look like threads of one process: handles travel
+        def __init__(self, g):
+            self.g = g
+
+        def __getattr__(self, k):
+            return getattr(self.g, k)
+
+        def get_backend(self, group=None):
+            return "gloo"
+
+    def rank_fn(rank, group):
+        e = _FakePeerEngine(kind=2 if case == "plain_across_devices" else 0,
+                            fail_at="open" if case == "one_rank_fails_to_open" and rank == 1 else None)
+        e.rank_tag = rank             # two different devices
+        ok = SD.peer_setup(e, Procs(group), None, rows_cap=8, timeout_s=1.0)
+        return ok, e
+
+    (ok0, e0), (ok1, e1) = run_ranks(2, rank_fn)
+    assert ok0 is False and ok1 is False
+    for e in (e0, e1):
+        assert "detach" in e.calls and len(e.freed) == 2          # inbox + flags given back
+    if case == "plain_across_devices":
+        assert "export" not in e0.calls and "attach" not in e0.calls      # refused before anything is mapped
+    if case == "one_rank_fails_to_open":
+        assert "attach" not in e0.calls and "attach" not in e1.calls       # rank 0 opened fine, and still left with rank 1
+        assert len(e0.closed) == 2
+    if case == "self_check_fails":
+        assert e0.calls.count("check") >= 2 and len(e0.closed) == 2
+
+
+def test_zipf_head_rows_of_the_sharded_bare_step():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_head", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.zipf_head_rows(1000000, 0.0, 1 << 22, 64, 197000) == 0            # uniform catalogue: nothing to replicate
+    h = bench.zipf_head_rows(1000000, 1.0, 8 * 2 * 262144, 64, 197000)
+    assert 0 < h <= 2 * 197000 // 64 and h % 4 == 0                                # capped by the dense partial's slot
+    small = bench.zipf_head_rows(1000000, 1.0, 2 * 4096, 32, 98943)
+    assert 0 < small < 100                                                         # few rows reach 16 occurrences of 8,192
