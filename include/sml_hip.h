@@ -420,6 +420,17 @@ int sml_sample_negatives(sml_ctx* ctx, const int64_t* users, int64_t n, const in
                          const int64_t* user_ptr, int64_t n_users, const int64_t* user_items, uint64_t seed,
                          int64_t* negs, int32_t* failed, void* stream);
 
+/* One shuffled pass over a period's rows assembled on the device -- the device form of a DataLoader(shuffle=True) pass over
+ * trainDataset_withPreSample (reference data/dataset2.py:172-201: rows [user, item, c2, c3, ...], ONE pre-sampled column per
+ * pass is the negative) and of the (user, item) half of offlineDataset_withsample (data/dataset.py:41-71).  ui: device int64
+ * [n,2]; mat (or NULL): device integer matrix (elem_bytes 4 or 8) with row_stride elements per row -- out3[e] = (ui[r][0],
+ * ui[r][1], mat[r*row_stride + col]) with r = perm(e); NULL leaves column 2 alone (sml_sample_negatives fills it).  perm is a
+ * counter-based permutation of [0, n) keyed by `seed` (a Feistel network, cycle-walked): the same distribution as the
+ * reference's shuffle, NOT torch's randperm stream -- used only under --device_batches; every rank of a job derives the
+ * same epoch from the same seed without communication.  Asynchronous. */
+int sml_device_epoch(sml_ctx* ctx, const int64_t* ui, const void* mat, int elem_bytes, int64_t row_stride, int64_t col, int64_t n,
+                     uint64_t seed, int64_t* out3, void* stream);
+
 /* ---- host helper: batch supply ------------------------------------------------------- */
 /* Sequential rejection sampling of offlineDataset_withsample.__getitem__ (reference
  * data/dataset.py:63-71) over a pre-drawn candidate stream, on the HOST (no GPU involved):

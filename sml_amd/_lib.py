@@ -110,6 +110,8 @@ SIGNATURES = {
     "sml_peer_region_bytes": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "sml_peer_alloc": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, ctypes.POINTER(c_void)]),
     "sml_peer_free": (ctypes.c_int, [ctypes.c_int, c_void]),
+    "sml_device_epoch": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                        ctypes.c_uint64, c_void, c_void]),
     "sml_peer_mem_kind": (ctypes.c_int, [c_void]),
     "sml_peer_read": (ctypes.c_int, [ctypes.c_int, c_void, c_void, ctypes.c_int64, c_void]),
     "sml_peer_export": (ctypes.c_int, [c_void, c_void]),

@@ -118,8 +118,7 @@ class ConvTransfer_com(nn.Module):
         came from one) and the parameters' .grad, exactly as the reference's loops expect (model/transfer.py:476-502,
         714-723: zero_grad -> run_MF -> backward -> optimizer.step()).  The whole-epoch engine calls
         (HipEngine.*_stage_epoch) remain the fast path; this is the drop-in one."""
-        if adpative:
-            raise NotImplementedError("run_MF(adpative=True): the reference's unused --need_adaptive branch")
+        # adpative: the reference's branch is `pass` (model/conv_transfer.py:131-132) -- accepted, changes nothing
         if _needs_graph(self, user_weight_hat, item_weight_hat, negitem_weight_hat):
             return _RunMF.apply(self, bool(norm), bool(BCE), user_weight_last, user_weight_hat, item_weight_last, item_weight_hat,
                                 negitem_weight_last, negitem_weight_hat, *list(self.parameters()))

@@ -1778,6 +1778,15 @@ int sml_sample_negatives(sml_ctx* ctx, const int64_t* users, int64_t n, const in
     return SML_OK;
 }
 
+int sml_device_epoch(sml_ctx* ctx, const int64_t* ui, const void* mat, int elem_bytes, int64_t row_stride, int64_t col, int64_t n,
+                     uint64_t seed, int64_t* out3, void* stream) {
+    if (!ctx || !ui || !out3 || n < 0 || (mat && (elem_bytes != 4 && elem_bytes != 8)) || (mat && (row_stride <= 0 || col < 0 || col >= row_stride)))
+        return fail(SML_EINVAL, "sml_device_epoch", "bad argument");
+    DevGuard g(ctx->device);
+    HIPCHK(sml_launch_device_epoch(ui, mat, elem_bytes, row_stride, col, n, seed, out3, (hipStream_t)stream));
+    return SML_OK;
+}
+
 int sml_host_resolve_negatives_csr(const int64_t* users, int64_t n, const int64_t* cand, int64_t m,
                                    const int64_t* user_ptr, int64_t n_users, const int64_t* user_items, int64_t* negs,
                                    int64_t* consumed, int64_t* resolved) {

@@ -1214,6 +1214,40 @@ __global__ __launch_bounds__(256) void k_sample_negatives(const int64_t* __restr
     negs[e] = c;
 }
 
+// One shuffled pass over a period's rows, assembled ON THE DEVICE (the device form of a DataLoader(shuffle=True) pass over
+// trainDataset_withPreSample / offlineDataset_withsample, data/dataset2.py:172-201, data/dataset.py:41-71): element e of
+// the epoch is row perm(e), where perm is a COUNTER-BASED permutation of [0, n) -- a keyed 4-round Feistel network over
+// the 2*hb-bit square that covers n, cycle-walked back into range (a Feistel network is a bijection of its domain; walking
+// the cycles of a bijection until the value falls below n is a bijection of [0, n)).  No sort, no state: every element
+// is computed independently from (seed, e), so every rank of a job derives the same epoch from the shared seed.
+// out3[e] = (ui[r][0], ui[r][1], mat ? mat[r * stride + col] : untouched).
+__device__ __forceinline__ uint64_t feistel_perm(uint64_t x, uint64_t n, int hb, uint64_t seed) {
+    const uint64_t mask = (1ull << hb) - 1;
+    do {
+        uint64_t l = x >> hb, r = x & mask;
+#pragma unroll
+        for (int rd = 0; rd < 4; ++rd) {
+            uint64_t z = r + seed + (uint64_t)(rd + 1) * 0x9e3779b97f4a7c15ull;
+            z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+            z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+            z ^= z >> 31;
+            const uint64_t t = l ^ (z & mask);
+            l = r; r = t;
+        }
+        x = (l << hb) | r;
+    } while (x >= n);
+    return x;
+}
+template <typename E>
+__global__ __launch_bounds__(256) void k_device_epoch(const int64_t* __restrict__ ui, const E* __restrict__ mat, int64_t stride, int64_t col,
+                                                      int64_t n, int hb, uint64_t seed, int64_t* __restrict__ out3) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const int64_t r = (int64_t)feistel_perm((uint64_t)e, (uint64_t)n, hb, seed);
+    out3[3 * e] = ui[2 * r];
+    out3[3 * e + 1] = ui[2 * r + 1];
+    if (mat != nullptr) out3[3 * e + 2] = (int64_t)mat[r * stride + col];
+}
 // hits and NDCG sum over ranks (model/MF.py:60-78): hit iff rank < topk, NDCG = 1/log2(rank+2).
 // One 1024-thread block; fixed reduction tree (deterministic).
 __global__ __launch_bounds__(1024) void k_eval_metrics(const int32_t* __restrict__ rank, int64_t n, int topk,
@@ -1553,6 +1587,18 @@ hipError_t sml_launch_sample_negatives(const int64_t* users, int64_t n, const in
                                                                               seed, negs, failed);
     return hipGetLastError();
 }
+hipError_t sml_launch_device_epoch(const int64_t* ui, const void* mat, int elem_bytes, int64_t stride, int64_t col, int64_t n, uint64_t seed,
+                                   int64_t* out3, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    int bits = 1;
+    while (bits < 63 && (1ull << bits) < (uint64_t)n) ++bits;
+    const int hb = (bits + 1) / 2 > 0 ? (bits + 1) / 2 : 1;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (elem_bytes == 4) k_device_epoch<int32_t><<<grid, dim3(256), 0, st>>>(ui, (const int32_t*)mat, stride, col, n, hb, seed, out3);
+    else k_device_epoch<int64_t><<<grid, dim3(256), 0, st>>>(ui, (const int64_t*)mat, stride, col, n, hb, seed, out3);
+    return hipGetLastError();
+}
+
 hipError_t sml_launch_eval_metrics(const int32_t* rank, int64_t n, int topk, float* out, hipStream_t st) {
     k_eval_metrics<<<dim3(1), dim3(1024), 0, st>>>(rank, n, topk, out);
     return hipGetLastError();

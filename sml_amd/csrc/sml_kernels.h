@@ -298,4 +298,6 @@ hipError_t sml_launch_eval_ranks_bucketed(int d, const float* wu, const float* w
 hipError_t sml_launch_sample_negatives(const int64_t* users, int64_t n, const int64_t* item_all, int64_t pop, const int64_t* user_ptr,
                                        int64_t n_users, const int64_t* user_items, uint64_t seed, int64_t* negs, int* failed,
                                        hipStream_t st);
+hipError_t sml_launch_device_epoch(const int64_t* ui, const void* mat, int elem_bytes, int64_t stride, int64_t col, int64_t n, uint64_t seed,
+                                   int64_t* out3, hipStream_t st);
 hipError_t sml_launch_eval_metrics(const int32_t* rank, int64_t n, int topk, float* out, hipStream_t st);

@@ -116,6 +116,28 @@ class trainDataset_withPreSample(Dataset):
         self._advance(self.data_len)
         return tri
 
+    def epoch_triples_device(self, engine, seed):
+        """One full pass assembled ON THE DEVICE (fast mode, --device_batches): the pass's negative column -- chosen exactly as
+        epoch_triples chooses it: neg_flag is this object's numpy shuffle -- crosses PCIe once as a contiguous vector
+        (n * 8 bytes; the rows themselves never do), the shuffle is the counter-based permutation of sml_device_epoch
+        (the same distribution as DataLoader(shuffle=True), not torch's randperm stream), the (user, item) columns are
+        resident.  Returns an int64 [n,3] device tensor.  Every rank of a job derives the same epoch from the same seed."""
+        if self.have_read != 0:
+            raise ValueError("epoch_triples_device needs a whole pass starting at a pass boundary")
+        dev = engine.device
+        col = int(self.neg_flag[self.used_neg_count])
+        a = self.all_data
+        if self._ui is None:
+            self._ui = np.ascontiguousarray(a[:, :2], dtype=np.int64)
+        cache = self.__dict__.setdefault("_dev_ui", {})
+        ui = cache.get(str(dev))
+        if ui is None or ui[0] is not self._ui:
+            ui = cache[str(dev)] = (self._ui, torch.from_numpy(self._ui).pin_memory().to(dev, non_blocking=True))
+        colv = torch.from_numpy(np.ascontiguousarray(a[:, col], dtype=np.int64)).pin_memory().to(dev, non_blocking=True)
+        out = engine.device_epoch(ui[1], self.data_len, seed, mat=colv, row_stride=1, col=0)
+        self._advance(self.data_len)
+        return out
+
 
 class offlineDataset_withsample(Dataset):
     """(user, item) pairs; the negative is drawn per access, uniformly from the items that
@@ -195,8 +217,9 @@ class offlineDataset_withsample(Dataset):
 
     def epoch_triples_device(self, engine, seed):
         """One shuffled pass with fresh negatives, built ON THE DEVICE (fast mode: the same distribution as
-        epoch_triples, not the reference's random streams): a device permutation, two gathers and
-        engine.sample_negatives.  Returns an int64 [n,3] device tensor; nothing crosses PCIe per epoch."""
+        epoch_triples, not the reference's random streams): the counter-based permutation of sml_device_epoch over the
+        resident (user, item) pairs, then engine.sample_negatives.  Returns an int64 [n,3] device tensor; nothing crosses
+        PCIe per epoch, and every rank of a job derives the same epoch from the same seed."""
         import torch
         dev = engine.device
         cache = self.__dict__.setdefault("_dev_cache", {})
@@ -205,12 +228,15 @@ class offlineDataset_withsample(Dataset):
             t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(dev)
             c = cache[str(dev)] = dict(user=t(self.user), item=t(self.item), item_all=t(self.item_all), uptr=t(self._uptr),
                                        uitems=t(self._uitems), gen=torch.Generator(device=dev))
-        c["gen"].manual_seed(int(seed) & (2 ** 62 - 1))
-        perm = torch.randperm(len(self), device=dev, generator=c["gen"])
-        users, items = c["user"][perm], c["item"][perm]
+        if "ui" not in c:
+            c["ui"] = torch.stack([c["user"], c["item"]], dim=1).contiguous()
+        # the shuffle: sml_device_epoch's counter-based permutation (columns 0, 1 of the triples); then the negatives
+        tri = engine.device_epoch(c["ui"], len(self), seed)
+        users = tri[:, 0].contiguous()
         negs, failed = engine.sample_negatives(users, c["item_all"], c["uptr"], c["uitems"], int(seed) + 1)
         self._last_failed = failed            # device counter; checked lazily by the caller if it cares
-        return torch.stack([users, items, negs], dim=1).contiguous()
+        tri[:, 2] = negs
+        return tri
 
 
 class transfer_data(object):

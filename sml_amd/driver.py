@@ -397,8 +397,19 @@ class meta_train(object):
         for epoch in range(args.MF_epochs):
             self.MFbase.train()
             self.transfer.eval()
-            order = D.loader_order(len(train_set), shuffle=True)
-            triples = train_set.epoch_triples(order)
+            if getattr(args, "device_batches", 0) and hasattr(train_set, "epoch_triples_device") \
+                    and hasattr(self.engine, "device_epoch"):
+                # fast mode (an extension): the pass is shuffled and assembled on the device -- same distribution, not the
+                # reference's torch / numpy streams; ONE draw from the shared torch generator seeds it on every rank alike
+                triples = train_set.epoch_triples_device(self.engine, int(torch.randint(0, 2 ** 62, (1,))))
+                failed = getattr(train_set, "_last_failed", None)
+                if failed is not None and self.MF_TrainDataset is SampleDaset:
+                    self._emit(lambda failed=failed: self._raise_if_failed(failed))
+                if self.dist is not None:
+                    triples = triples.cpu().numpy()        # (split by user owner on the host, as for the exact path)
+            else:
+                order = D.loader_order(len(train_set), shuffle=True)
+                triples = train_set.epoch_triples(order)
             t0 = time.time()
             if self.dist is None:
                 losses = self.engine.mf_stage_epoch(self.MFbase, self.transfer, self.last_user_weight,
@@ -428,6 +439,11 @@ class meta_train(object):
                 self._log_mf(args, recall, ndcg, loss_all)
             else:
                 self._emit(lambda l, epoch=epoch: print("MF-stage:", stage_id, "epoch:", epoch, "loss:", l), loss_all)
+
+    @staticmethod
+    def _raise_if_failed(failed):
+        if int(failed.item()) != 0:
+            raise RuntimeError("negative sampling does not terminate: a user owns (almost) every item")
 
     def _log_mf(self, args, recall, ndcg, loss):
         if self.writer is None:

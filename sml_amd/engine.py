@@ -529,6 +529,20 @@ class HipEngine(object):
                                             _ptr(negs), _ptr(failed), self._stream()), "sml_sample_negatives")
         return negs, failed
 
+    def device_epoch(self, ui, n, seed, mat=None, row_stride=1, col=0):
+        """int64 [n,3] device triples of one shuffled pass (sml_device_epoch): columns 0, 1 = ui[perm(e)] (ui: device int64
+        [n,2]); column 2 = mat[perm(e) * row_stride + col] when a device integer matrix / column vector is given, else
+        left for sample_negatives.  perm: the counter-based permutation keyed by `seed`."""
+        out = torch.empty((int(n), 3), device=self.device, dtype=torch.int64)
+        eb = 8
+        if mat is not None:
+            if mat.dtype not in (torch.int32, torch.int64) or not mat.is_contiguous() or mat.device != self.device:
+                raise ValueError("mat: a contiguous int32 / int64 device tensor")
+            eb = mat.element_size()
+        check(self.lib.sml_device_epoch(self._ctx, _ptr(ui), _ptr(mat), eb, int(row_stride), int(col), int(n),
+                                        ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), _ptr(out), self._stream()), "sml_device_epoch")
+        return out
+
     # ------------------------------------------------------------------ a2
     def mf_forward(self, w_user, w_item, user, item, norm=False):
         wu, wi = self._table(w_user), self._table(w_item)

@@ -1029,6 +1029,54 @@ def test_device_sampler_distribution_and_constraints():
     assert cnt.sum() == obs.sum()
 
 
+def test_device_epoch_of_the_presampled_set_is_a_permutation_with_in_range_columns_the_same_on_every_rank():
+    """trainDataset_withPreSample.epoch_triples_device (the MF stage's device batch supply, data/dataset2.py:172-201): a pass
+    is a permutation of the rows, the third column is THE pass's pre-sampled column of the very row the pair came from
+    (the column sequence is the host path's: neg_flag, the per-pass advance, the positive column included -- the
+    reference's quirk), two engines (two ranks) derive the same epoch from the same seed, another seed gives another
+    order, and the order is not the identity -- nor close to it (rank correlation of positions)."""
+    from sml_amd.datasets import trainDataset_withPreSample
+    rng = np.random.RandomState(11)
+    for n in (1, 2, 777, 4096, 75000):
+        C = 2 + 7
+        a = np.concatenate([rng.randint(0, 5000, (n, 1)), rng.randint(0, 900, (n, 1)), 1000 + np.arange(n * (C - 2)).reshape(n, C - 2)], 1).astype(np.int64)
+        np.random.seed(5)
+        ds_dev, e1, e2 = trainDataset_withPreSample(a), engine(32), engine(32)
+        np.random.seed(5)
+        ds_host = trainDataset_withPreSample(a)
+        np.random.seed(5)
+        ds_dev2 = trainDataset_withPreSample(a)
+        for ep in range(9):                     # past the 8 candidate columns: the reshuffle of neg_flag is crossed
+            col = int(ds_host.neg_flag[ds_host.used_neg_count])
+            # (the three objects share numpy's global generator: each sees the same state when its pass wraps the columns)
+            np.random.seed(100 + ep); ds_host.epoch_triples(np.arange(n))
+            np.random.seed(100 + ep); t = ds_dev.epoch_triples_device(e1, 1000 + ep).cpu().numpy()
+            np.random.seed(100 + ep); t_b = ds_dev2.epoch_triples_device(e2, 1000 + ep).cpu().numpy()
+            assert np.array_equal(t, t_b)                                   # "two ranks derive identical epochs"
+            assert t.shape == (n, 3)
+            # every output row is (a[r,0], a[r,1], a[r,col]) for a row r, each r exactly once: column 2.. hold unique tags
+            if col >= 2:
+                r = (t[:, 2] - 1000 - (col - 2)) // (C - 2)
+                assert np.array_equal(np.sort(r), np.arange(n)) and np.array_equal(t[:, 2], a[r, col])
+                assert np.array_equal(t[:, :2], a[r, :2])
+                if n >= 777:
+                    assert not np.array_equal(r, np.arange(n))
+                    rho = np.corrcoef(r, np.arange(n))[0, 1]
+                    assert abs(rho) < 0.1, rho
+            else:                                                            # the positive itself drawn as the "negative" (:181, 193)
+                assert np.array_equal(t[:, 2], t[:, 1])
+                assert np.array_equal(np.sort(t[:, 0] * 1000 + t[:, 1]), np.sort(a[:, 0] * 1000 + a[:, 1]))
+        assert np.array_equal(ds_dev.neg_flag, ds_host.neg_flag) and ds_dev.used_neg_count == ds_host.used_neg_count
+    if n >= 777:
+        t2 = trainDataset_withPreSample(a)
+        np.random.seed(5)
+        x, y = t2.epoch_triples_device(e1, 1).cpu().numpy(), None
+        t3 = trainDataset_withPreSample(a)
+        t3.neg_flag = t2.neg_flag.copy()
+        y = t3.epoch_triples_device(e1, 2).cpu().numpy()
+        assert not np.array_equal(x[:, :2], y[:, :2])                        # another seed, another order
+
+
 def test_driver_runs_with_device_batches(tmp_path, monkeypatch):
     """--device_batches 1: the driver's control flow with the TR batches drawn on the device (statistically, not
     stream-wise, the reference): it runs the tiny 29-stage sequence and lands on comparable final averages."""
@@ -1167,9 +1215,18 @@ def _stage_check_at_scale(U, I, n, d, mf_batch, tr_batch, neg, seed, window=12):
     # ---- evaluation (a13) of every test row, sampled rows vs the oracle
     rows = torch.from_numpy(test).to(DEV)
     ranks = eng.eval_ranks(out_u, out_i, rows)
-    pick = torch.randint(0, n, (256,))
-    want = O.eval_ranks(out_u.cpu(), out_i.cpu(), test[pick.numpy()])
-    assert (ranks[pick.to(DEV)].cpu() - want).abs().max() <= 1
+    # EXACT ranks wherever the scores decide them (as G13 does by construction): the positive's rank from fp64 scores of the
+    # same fp32 tables; a candidate whose score sits within 1e-5 (relative) of the positive's may fall either way in
+    # fp32 -- such rows (a handful of 2,048 x 1,000 comparisons at most) are allowed exactly that many flips, all others none
+    pick = torch.randint(0, n, (2048,)).numpy()
+    tu, ti = out_u.cpu().double(), out_i.cpu().double()
+    sc = torch.einsum("nd,ncd->nc", tu[test[pick, 0]], ti[torch.from_numpy(test[pick, 1:])]).numpy()
+    diff = sc[:, 1:] - sc[:, :1]
+    amb = (np.abs(diff) <= 1e-5 * (1.0 + np.abs(sc[:, :1]))).sum(1)
+    want = (diff > 0).sum(1)
+    got = ranks[torch.from_numpy(pick).to(DEV)].cpu().numpy()
+    assert (np.abs(got - want) <= amb).all() and (amb == 0).mean() > 0.95
+    assert np.array_equal(O.eval_ranks(out_u.cpu(), out_i.cpu(), test[pick[:64]]).numpy(), got[:64]) or amb[:64].any()
     hits, ndcg = eng.eval_metrics(ranks, 20)
     assert 0 <= hits <= n and np.isfinite(ndcg)
 
