@@ -191,6 +191,7 @@ struct sml_ctx {
     // transfer-net workspaces, 3*B slots each
     Buf<float> out, dout, dx, xin, z1, a1, a2, dz1, mrep, vrep;
     Buf<float> pk, grad, convg, loss_part;
+    Buf<float> cstate;       // [2 parities][2 nets][3][SML_CG]: the conv parameters' working copy of a TR epoch (deferred conv step)
     int pk_set = 0;          // which of the two operand-image sets is current
     Buf<int> arrive;         // k_tr_wgrad2's tail-workgroup arrival counter (0 between launches)
     // Adam schedule of the MF optimiser
@@ -228,7 +229,7 @@ struct sml_ctx {
         prof.release();
         out.release(); dout.release(); dx.release(); xin.release(); z1.release(); a1.release(); a2.release(); dz1.release();
         mrep.release(); vrep.release();
-        pk.release(); grad.release(); convg.release(); loss_part.release(); arrive.release();
+        pk.release(); grad.release(); convg.release(); loss_part.release(); arrive.release(); cstate.release();
         ix[0].release(); ix[1].release();
         sched.release(); dummy.release(); rec_x.release();
         for (auto& r : sched_retired) { g_graveyard.park(r.dev); g_graveyard.park_host(r.host); (void)hipEventDestroy(r.done); }
@@ -1006,12 +1007,29 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
     HIPCHK(hipMemsetAsync(ctx->loss_part.p, 0, (size_t)nb * lstride * sizeof(float), st));
     HIPCHK(hipMemsetAsync(grad, 0, (size_t)2 * sml_net_size(d) * sizeof(float), st));
     const int64_t ns = sml_net_size(d), ps = sml_pk_size(d);
+    // Deferred conv step (one GPU, fused Adam, restructured step, hidden-split forward): the merged launch of every batch
+    // but the epoch's last leaves the conv-gradient partials to the NEXT batch's forward, which adds them and steps the 190
+    // conv parameters in its prologue (SmlFwdArgs).  SML_TR_DEFER=0: the merged launch's last tail workgroup does it.
+    const bool fused_path = !clip && !grad_hook && ctx->peer.world <= 0 && ctx->comm == nullptr;
+    const bool defer = v2 && fns == 4 && fused_path && !plan && nb > 1 && env_int("SML_TR_DEFER", 1) != 0;
+    int prev_split = 0, prev_total = 0;
+    if (defer) {
+        HIPCHK(ctx->cstate.ensure((size_t)2 * 2 * 3 * SML_CG));
+        HIPCHK(sml_launch_conv_state_init(d, theta, adam_m, adam_v, ctx->cstate.p, st));
+    }
     for (int64_t b = 0; b < nb; ++b) {
         const int64_t off0 = plan ? plan->batch_off[b] : b * batch;
         const int B = plan ? (int)(plan->batch_off[b + 1] - off0) : (int)((n - off0) < batch ? (n - off0) : batch);
         const int64_t* tri = triples + off0 * 3;
         SmlFwdArgs f;
         memset(&f, 0, sizeof(f));
+        if (defer) {
+            const SmlSched scp = sched_entry((double)lr, *step + b);      // the PREVIOUS batch's step (b >= 1)
+            f.cg_part = b > 0 ? ctx->convg.p : nullptr; f.cg_split = prev_split; f.cg_total = prev_total;
+            f.cs_in = ctx->cstate.p + (size_t)(b & 1) * 2 * 3 * SML_CG; f.cs_out = ctx->cstate.p + (size_t)((b + 1) & 1) * 2 * 3 * SML_CG;
+            f.cs_theta = theta; f.cs_m = adam_m; f.cs_v = adam_v;
+            f.cs_wd = weight_decay; f.cs_step_size = scp.step_size; f.cs_bc2_sqrt = scp.bc2_sqrt;
+        }
         for (int s = 0; s < 2; ++s) {
             SmlSeg& sg = f.seg[s];
             sg.theta = theta + s * ns; sg.pk = pk_cur(ctx) + s * ps;
@@ -1057,6 +1075,8 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
         auto launch_wgrad = [&](const SmlWgArgs& g) { return v2 ? sml_launch_tr_wgrad2(d, g, st) : sml_launch_wgrad(d, g, st); };
         wg.convg_part = ctx->convg.p; wg.tiles0 = f.tiles0 * wcs; wg.tiles_total = tiles * wcs;
         wg.n_tail = tiles * (d / 16) > 0 ? tiles * (d / 16) : 1; wg.convg_out = ctx->convg.p; wg.arrive = ctx->arrive.p;
+        wg.defer_conv = (defer && b + 1 < nb) ? 1 : 0;
+        prev_split = f.tiles0 * (d / 16); prev_total = tiles * (d / 16);
         const bool peers = !grad_hook && ctx->peer.world > 0;       // peer mappings attached: one-shot push / poll
         const bool native = !grad_hook && !peers && ctx->comm != nullptr;     // a communicator exists: exchange natively
         if (peers) {

@@ -107,12 +107,22 @@ __device__ __forceinline__ void pair_terms(int kind, float sp, float sn, float i
 struct SmlSched { float step_size; float bc2_sqrt; };
 
 // one Adam step with gradient g
+// Every operation is PINNED (explicit roundings): the same step is inlined into several kernels (row updates, the
+// weight-gradient tiles, the theta kernel, the forward's deferred conv step), and with the compiler free to contract
+// a * b + c differently from one context to the next those copies part ways by an ulp -- found when the conv parameters'
+// step moved from the merged launch into the next forward (round 4): replicas and A/B runs must stay bit-identical whichever
+// kernel takes the step.  The sequence pinned is the one the compiler had chosen for the theta kernel all along (first
+// moment: multiply, then add; second moment: v*beta2 fused with g * ((1-beta2)*g)) -- the form the G3 / G4 / G12 parity
+// margins were measured with; a TR trajectory is chaotic enough that another rounding order moves G12's worst per-batch
+// loss error from 3e-5 to 2e-4 (measured with ATen's own order, three roundings in the second moment).
 __device__ __forceinline__ void adam_apply(float& p, float& m, float& v, float g, SmlSched s) {
-    m = m + (1.0f - SML_BETA1) * (g - m);                 // exp_avg.lerp_(grad, 1-beta1)
-    v = v * SML_BETA2 + (1.0f - SML_BETA2) * g * g;       // mul_(beta2).addcmul_(g, g, 1-beta2)
-    const float denom = sqrtf(v) / s.bc2_sqrt + SML_EPS;
-    p = p + (-s.step_size * m) / denom;                   // addcdiv_(m, denom, value=-step_size)
+    m = __fadd_rn(m, __fmul_rn(1.0f - SML_BETA1, __fsub_rn(g, m)));                        // exp_avg.lerp_(grad, 1-beta1)
+    v = __fmaf_rn(g, __fmul_rn(1.0f - SML_BETA2, g), __fmul_rn(v, SML_BETA2));             // mul_(beta2).addcmul_(g, g, 1-beta2)
+    const float denom = __fadd_rn(__fdiv_rn(sqrtf(v), s.bc2_sqrt), SML_EPS);
+    p = __fsub_rn(p, __fdiv_rn(__fmul_rn(s.step_size, m), denom));                        // addcdiv_(m, denom, value=-step_size)
 }
+// gradient + weight_decay * p, pinned for the same reason
+__device__ __forceinline__ float adam_wd(float g, float wd, float p) { return __fmaf_rn(wd, p, g); }
 // one Adam step with ZERO gradient (a row that was not in the batch), algebraically
 //   p -= step_size * m / (sqrt(v)/bc2 + eps)  =  step_size*bc2*m / (sqrt(v) + eps*bc2)
 // on the transcendental unit (v_sqrt_f32, v_rcp_f32: ~1 ulp each).  A replayed window is at most

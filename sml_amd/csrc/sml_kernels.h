@@ -33,6 +33,16 @@ struct SmlFwdArgs {
     int tiles_total;
     int k2;                  // ConvTransfer nets: kernel (2,1), the x_com row is zero
     int unit_rows;           // NS = 1 only: rows of seg[0] leave divided by their norm (ConvTransfer's user output)
+    // TR stage, hidden-split form (NS = 4), one GPU: the PREVIOUS batch's conv-parameter Adam step is taken HERE (cs_in !=
+    // null).  The merged launch of batch b - 1 left its tail workgroups' compact conv-gradient partials in cg_part
+    // (rows [0, cg_split): user net, [cg_split, cg_total): item net; null: nothing pending, the parameters pass through);
+    // every workgroup adds its net's partials in the fixed order of k_tr_wgrad2's last arriver and steps its own copy of the
+    // 95 parameters from cs_in ([2 nets][3: p, m, v][SML_CG]); the net's first workgroup also stores the result to cs_out
+    // (the other parity: nobody of this launch reads it) and to the flat theta / m / v for the launches that follow.
+    const float* cg_part; int cg_split, cg_total;
+    const float* cs_in; float* cs_out;
+    float* cs_theta; float* cs_m; float* cs_v;       // flat buffers (both nets)
+    float cs_wd, cs_step_size, cs_bc2_sqrt;
 };
 #define SML_FWD_NS 4         // largest hidden-dimension split of the training-batch forward (planes of `out`)
 
@@ -96,6 +106,7 @@ struct SmlWgArgs {
     // tiles0 / tiles_total then count ROW tiles; `arrive` is a device counter (0 between launches) the tail
     // workgroups use to elect the last arriver, which finishes the conv parameters
     int n_tail; float* convg_out; int* arrive;
+    int defer_conv;          // k_tr_wgrad2: 1 = the tail workgroups only leave their partials; the NEXT forward finishes the conv parameters
 };
 
 struct SmlThetaAdamArgs {
@@ -105,6 +116,7 @@ struct SmlThetaAdamArgs {
     const float* clip_sumsq; float clip_max_norm;   // --clip_grad: sum of squares of the whole gradient (device), the norm bound
 };
 hipError_t sml_launch_grad_sumsq(const float* grad, int64_t n, float* out, hipStream_t st);
+hipError_t sml_launch_conv_state_init(int d, const float* theta, const float* m, const float* v, float* cs, hipStream_t st);
 
 // mt row-tiles of 16 per workgroup; ns workgroups share a row tile (1, or SML_FWD_NS with mt = 1)
 hipError_t sml_launch_fwd(int d, int mt, int ns, const SmlFwdArgs& a, int tiles_total, hipStream_t st);

@@ -261,7 +261,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HSEQ > 1 ? 
     const int row0 = (tile - (sidx ? a.tiles0 : 0)) * R;
     const float* __restrict__ theta = sg.theta;
     float cw_reg = 0.0f;
-    if (tid < 104) cw_reg = theta[tid];               // parked in LDS once the other loads are on their way
+    // the net's 104 conv floats: from theta -- or, when the previous batch's conv step is taken here, from the state copy
+    constexpr bool CONVSTEP = (NS == 4 && MT == 1 && HSEQ == 1);
+    const bool cstep = CONVSTEP && a.cs_in != nullptr;
+    constexpr int CRG = 21, CC4 = SML_CG / 4;          // the last arriver's geometry: 21 row groups x 24 column groups
+    f32x4 cg_acc = {0.f, 0.f, 0.f, 0.f}, cgx[4];
+    float cs_p = 0.f, cs_m = 0.f, cs_v = 0.f;
+    const int cs_k = tid;                             // compact conv index of threads 0..94
+    const int cs_off = cs_k < 30 ? cs_k : cs_k < 40 ? cs_k + 2 : cs_k < 90 ? cs_k + 4 : cs_k + 6;
+    const int cg_lo = sidx ? a.cg_split : 0, cg_hi = sidx ? a.cg_total : a.cg_split;     // this net's partial rows
+    int cg_t = 0;
+    const bool cg_mine = CONVSTEP && cstep && a.cg_part != nullptr && tid < CRG * CC4;
+    if (!cstep) { if (tid < 104) cw_reg = theta[tid]; }               // parked in LDS once the other loads are on their way
     const bool lazy = sg.last_tab != nullptr;
     if (lazy) sched_window_load(swin, a.sched, a.cur_step - 1, tid);
     const bool saver = (h == 0);         // one workgroup of the NS writes the shared saves
@@ -315,6 +326,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HSEQ > 1 ? 
             ok[q] = row < sg.n_rows;
             idx[q] = ok[q] ? seg_row_index(sg, row) : 0;
         }
+        if constexpr (CONVSTEP) {
+            if (cstep) {
+                // the pending conv step's inputs go out BEHIND the gather's index loads (loads return in issue order: ahead of
+                // them, these fabric-cold lines held the indices back) and ahead of its row loads
+                if (tid < 95) {
+                    const float* st_ = a.cs_in + (int64_t)sidx * 3 * SML_CG;
+                    cs_p = st_[cs_k]; cs_m = st_[SML_CG + cs_k]; cs_v = st_[2 * SML_CG + cs_k];
+                }
+                if (cg_mine) {
+                    // this net's partial rows rg, rg + 21, ... (ascending: the order k_tr_wgrad2's last arriver adds them in);
+                    // plain loads: the partials were stored write-through by the previous LAUNCH
+                    const int rg = tid / CC4, c4 = tid % CC4;
+                    cg_t = rg + (cg_lo > rg ? ((cg_lo - rg + CRG - 1) / CRG) * CRG : 0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int t = cg_t + u * CRG;
+                        cgx[u] = *reinterpret_cast<const f32x4*>(a.cg_part + (int64_t)(t < cg_hi ? t : cg_lo) * SML_CG + c4 * 4);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
             const int w = (q * 512 + tid) % D;
@@ -336,6 +369,51 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HSEQ > 1 ? 
             ring_preload<CT, 5>(ringw1, img1, KS1, 0, lane, tw, nokofs);
             ring_preload<JTW, PF2>(ringw2, img2, 32, h * KL + kq * KPW, lane, t2, nokofs);
         }
+        if constexpr (CONVSTEP) {
+            if (cstep) {
+                // ---- the previous batch's conv-parameter step (see SmlFwdArgs): partial rows -> 21 row-group sums in LDS ->
+                // 95 parameters, each added over the row groups in index order -> Adam.  Runs while this workgroup's row
+                // gather (issued above) is in flight; `part`/A1s is not live yet.
+                __builtin_amdgcn_sched_barrier(0);          // (the gather's loads stay ahead of the first look at the partials)
+                float* P = smem;                            // [CRG][SML_CG]
+                if (tid < CRG * CC4) {
+                    const int rg = tid / CC4, c4 = tid % CC4;
+                    if (cg_mine) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) if (cg_t + u * CRG < cg_hi) cg_acc += cgx[u];
+                        for (int t0 = cg_t + 4 * CRG; t0 < cg_hi; t0 += 4 * CRG) {          // (d >= 64: more than four rows per group)
+                            f32x4 x[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int t = t0 + u * CRG;
+                                x[u] = *reinterpret_cast<const f32x4*>(a.cg_part + (int64_t)(t < cg_hi ? t : cg_lo) * SML_CG + c4 * 4);
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) if (t0 + u * CRG < cg_hi) cg_acc += x[u];
+                        }
+                    }
+                    *reinterpret_cast<f32x4*>(P + rg * SML_CG + c4 * 4) = cg_acc;
+                }
+                __syncthreads();
+                if (tid < 95) {
+                    if (a.cg_part != nullptr) {
+                        float g = 0.0f;
+#pragma unroll
+                        for (int rg = 0; rg < CRG; ++rg) g += P[rg * SML_CG + cs_k];
+                        SmlSched sc; sc.step_size = a.cs_step_size; sc.bc2_sqrt = a.cs_bc2_sqrt;
+                        adam_apply(cs_p, cs_m, cs_v, adam_wd(g, a.cs_wd, cs_p), sc);
+                    }
+                    cws[cs_off] = cs_p;
+                    const int first_tile = sidx ? a.tiles0 : 0;
+                    if (tile == first_tile && h == 0) {         // the net's first workgroup publishes the step
+                        float* so = a.cs_out + (int64_t)sidx * 3 * SML_CG;
+                        so[cs_k] = cs_p; so[SML_CG + cs_k] = cs_m; so[2 * SML_CG + cs_k] = cs_v;
+                        const int64_t i = (int64_t)sidx * sml_net_size(D) + cs_off;
+                        a.cs_theta[i] = cs_p; a.cs_m[i] = cs_m; a.cs_v[i] = cs_v;
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
             const int e = q * 512 + tid;
@@ -349,7 +427,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HSEQ > 1 ? 
                 nr2[q] = s2;
             }
         }
-        if (tid < 104) cws[tid] = cw_reg;
+        if (!cstep && tid < 104) cws[tid] = cw_reg;      // (cstep: threads 0..94 stored the stepped parameters above)
         __syncthreads();                   // xts, cws and the schedule window are in LDS
         TL(2);
         if (lazy) {                        // replay the rows' pending zero-gradient Adam steps
@@ -1448,7 +1526,7 @@ __device__ __forceinline__ void wgrad_tile(const SmlWgArgs& a, int xcd, int kk, 
         if (g) g[off] = gsum;
         if (fuse) {
             const int64_t i = (int64_t)net * NS + off;
-            adam_apply(p, m, v, gsum + a.weight_decay * p, sc);
+            adam_apply(p, m, v, adam_wd(gsum, a.weight_decay, p), sc);
             a.theta[i] = p; a.m[i] = m; a.v[i] = v;
         }
         return p;
@@ -1547,7 +1625,7 @@ __global__ __launch_bounds__(512) void k_transfer_wgrad(SmlWgArgs a) {
             if (a.seg[net].grad) a.seg[net].grad[off] = g;    // the flat gradient is complete after this launch (null: nobody reads it)
             for (int q = 0; q < a.peer.world; ++q) peer_store(a.peer.dst[q] + i, g);
             if (fuse) {
-                adam_apply(p, m, v, g + a.weight_decay * p, sc);
+                adam_apply(p, m, v, adam_wd(g, a.weight_decay, p), sc);
                 a.theta[i] = p; a.m[i] = m; a.v[i] = v;
             }
         }
@@ -1720,6 +1798,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
     }
     TL(4);
+    // Deferred form (every batch of an epoch but the last, one GPU): the partials are all this launch owes the conv
+    // parameters -- the next batch's forward adds them (same order as below) and takes the Adam step in its prologue,
+    // under its gather's round trips.  The election, the last arriver's re-read and its serial tail (3 us at the END
+    // of this launch's chain) are gone.
+    if (a.defer_conv) { TL_DONE(); return; }
     // ---- elect the last tail workgroup: it adds the partials in index order (deterministic) and finishes the conv parameters.
     // NO agent-scope fence here: __threadfence() is a write-back + invalidate of this XCD's whole L2, executed by every
     // wave of 96 workgroups underneath the weight-gradient tiles that live out of that L2 (measured: the launch took
@@ -1775,7 +1858,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             if (a.seg[net].grad) a.seg[net].grad[off] = g;
             for (int q = 0; q < a.peer.world; ++q) peer_store(a.peer.dst[q] + i, g);
             if (fuse) {
-                adam_apply(p, m, v, g + a.weight_decay * p, sc);
+                adam_apply(p, m, v, adam_wd(g, a.weight_decay, p), sc);
                 a.theta[i] = p; a.m[i] = m; a.v[i] = v;
             }
         }
@@ -1838,7 +1921,7 @@ __global__ __launch_bounds__(256) void k_theta_adam(SmlThetaAdamArgs a) {
         const int off = off0 + e;
         if (off < SML_OFF_F1W && !conv_slot_used_host(off)) continue;   // alignment padding of the conv block: untouched
         float pe = p[e], me = m[e], ve = v[e];
-        adam_apply(pe, me, ve, g[e] + a.weight_decay * pe, s);
+        adam_apply(pe, me, ve, adam_wd(g[e], a.weight_decay, pe), s);
         p[e] = pe; m[e] = me; v[e] = ve;
         pack_store<D>(a.pk + (int64_t)net * sml_pk_size(D), off, pe);
     }
@@ -1963,6 +2046,20 @@ hipError_t sml_launch_theta_adam(int d, const SmlThetaAdamArgs& a, hipStream_t s
     const int n = 2 * sml_net_size(d) / 4;         // four parameters per thread
     if (a.peer.world > 0) { SML_DISPATCH_D(d, k_theta_adam<DD, true><<<dim3((n + 255) / 256), dim3(256), 0, st>>>(a)); }
     else { SML_DISPATCH_D(d, k_theta_adam<DD, false><<<dim3((n + 255) / 256), dim3(256), 0, st>>>(a)); }
+    return hipGetLastError();
+}
+// compact copy of both nets' conv parameters and their Adam moments: cs[net][3: p, m, v][SML_CG] (k_transfer_fwd's conv step)
+__global__ __launch_bounds__(256) void k_conv_state_init(const float* __restrict__ theta, const float* __restrict__ m, const float* __restrict__ v,
+                                                         int net_size, float* __restrict__ cs) {
+    const int net = threadIdx.x >> 7, k = threadIdx.x & 127;
+    if (k >= 95) return;
+    const int off = k < 30 ? k : k < 40 ? k + 2 : k < 90 ? k + 4 : k + 6;
+    const long long i = (long long)net * net_size + off;
+    float* o = cs + net * 3 * SML_CG;
+    o[k] = theta[i]; o[SML_CG + k] = m[i]; o[2 * SML_CG + k] = v[i];
+}
+hipError_t sml_launch_conv_state_init(int d, const float* theta, const float* m, const float* v, float* cs, hipStream_t st) {
+    k_conv_state_init<<<dim3(1), dim3(256), 0, st>>>(theta, m, v, sml_net_size(d), cs);
     return hipGetLastError();
 }
 hipError_t sml_launch_grad_sumsq(const float* grad, int64_t n, float* out, hipStream_t st) {

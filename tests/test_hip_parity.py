@@ -1145,22 +1145,23 @@ def test_bare_step_at_full_table_size_vs_oracle_on_touched_rows(cfg):
     assert not torch.equal(wu[torch.from_numpy(uu[:64]).to(DEV)], bu[torch.from_numpy(uu[:64]).to(DEV)])   # ... and the touched ones moved
 
 
-def _stage_check_at_scale(U, I, n, d, mf_batch, tr_batch, neg, seed, window=12):
+def _stage_check_at_scale(U, I, n, d, mf_batch, tr_batch, neg, seed, window=12, n_tr=None, a_user=1.1, tag="r03"):
     """One MF epoch, updata, one TR epoch and an evaluation at a full-size period shape, against the oracle on the
     compacted tables (MF / TR: every batch loss, touched rows / theta; untouched rows bit-identical), on sampled
     rows (updata, evaluation)."""
     from sml_amd import synth
     torch.manual_seed(seed)
     rng = np.random.RandomState(seed)
-    train, test = synth.sample_period(rng, n, U, I, neg=neg)
+    train, test = synth.sample_period(rng, n, U, I, neg=neg, a_user=a_user)
     tri = np.stack([train[:, 0], train[:, 1], test[:, 2]], 1)
     uu, ui, ctri = _compact(tri, U, I)
+    n_tr = n if n_tr is None else n_tr
     wu, wi = torch.randn(U, d) * 0.3, torch.randn(I, d) * 0.3
     eng = engine(d, max(mf_batch, tr_batch))
     mf = make_mf(U, I, d, wu.numpy(), wi.numpy(), device=DEV)
     net = make_transfer(d, device=DEV)
     sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
-    lu, li = (wu * 0.9).to(DEV), (wi * 0.9).to(DEV)
+    lu, li = wu.to(DEV) * 0.9, wi.to(DEV) * 0.9
     # ---- MF stage (a8) at full size
     l_mf = eng.mf_stage_epoch(mf, net, lu, li, torch.from_numpy(tri), mf_batch, 0.01, 1e-6).cpu().numpy()
     eng.mf_flush(mf)
@@ -1168,7 +1169,7 @@ def _stage_check_at_scale(U, I, n, d, mf_batch, tr_batch, neg, seed, window=12):
     onet = make_transfer(d)
     onet.load_state_dict(sd)
     oeng = O.OracleEngine(d)
-    o_mf = oeng.mf_stage_epoch(omf, onet, (wu * 0.9)[uu], (wi * 0.9)[ui], torch.from_numpy(ctri), mf_batch, 0.01, 1e-6)
+    o_mf = oeng.mf_stage_epoch(omf, onet, wu[uu] * 0.9, wi[ui] * 0.9, torch.from_numpy(ctri), mf_batch, 0.01, 1e-6)
     np.testing.assert_allclose(l_mf, o_mf, rtol=1e-4)
     hu, hi = mf.user_laten.weight.detach().clone(), mf.item_laten.weight.detach().clone()
     steps = oeng.mf_step
@@ -1182,25 +1183,25 @@ def _stage_check_at_scale(U, I, n, d, mf_batch, tr_batch, neg, seed, window=12):
     # `window` batches the engine is reset to the ORACLE's theta and Adam state (load_optimizer_state), then both run
     # the next window from identical state -- all batches of the epoch are held to 2e-4, with late-epoch optimiser
     # state, ragged last batch and every launch geometry the epoch uses; theta is compared after every window.
-    ohu, ohi = hu.cpu()[uu], hi.cpu()[ui]         # the SAME W_hat rows the HIP path trains theta on
-    nb_tr = -(-n // tr_batch)
+    ohu, ohi = hu[torch.from_numpy(uu).to(DEV)].cpu(), hi[torch.from_numpy(ui).to(DEV)].cpu()         # the SAME W_hat rows the HIP path trains theta on
+    nb_tr = -(-n_tr // tr_batch)
     worst = 0.0
     names = [k for k, _ in onet.named_parameters()]
     for w0 in range(0, nb_tr, window):
-        a0, a1 = w0 * tr_batch, min(n, (w0 + window) * tr_batch)
+        a0, a1 = w0 * tr_batch, min(n_tr, (w0 + window) * tr_batch)
         if w0 > 0:
             net.load_state_dict({k: v.detach().clone() for k, v in onet.state_dict().items()})
             eng.load_optimizer_state(transfer=net, tr_state=dict(
                 m={k: s_.m.clone() for k, s_ in zip(names, oeng.tr_state)},
                 v={k: s_.v.clone() for k, s_ in zip(names, oeng.tr_state)}, step=oeng.tr_step))
         l_tr = eng.tr_stage_epoch(net, lu, li, hu, hi, torch.from_numpy(tri[a0:a1]), tr_batch, 1e-3, 1e-4).cpu().numpy()
-        o_tr = oeng.tr_stage_epoch(onet, (wu * 0.9)[uu], (wi * 0.9)[ui], ohu, ohi, torch.from_numpy(ctri[a0:a1]), tr_batch, 1e-3, 1e-4)
+        o_tr = oeng.tr_stage_epoch(onet, wu[uu] * 0.9, wi[ui] * 0.9, ohu, ohi, torch.from_numpy(ctri[a0:a1]), tr_batch, 1e-3, 1e-4)
         assert eng.tr_step == oeng.tr_step
         worst = max(worst, float(np.max(np.abs(l_tr - o_tr) / np.abs(o_tr))))
         np.testing.assert_allclose(l_tr, o_tr, rtol=2e-4, err_msg="TR batches %d..%d" % (w0, w0 + window))
         for k, v in onet.state_dict().items():
             adam_close(net.state_dict()[k].detach().cpu().numpy(), v.numpy(), 1e-3, window, frac=0.99)
-    _report("r03_parity_fullsize_tr_windows_U%d_I%d.json" % (U, I), dict(batches=nb_tr, window=window, worst_rel_loss_error=worst))
+    _report("%s_parity_fullsize_tr_windows_U%d_I%d.json" % (tag, U, I), dict(batches=nb_tr, window=window, worst_rel_loss_error=worst, d=d))
     # ---- updata (a10) over the whole tables, sampled rows vs the oracle
     out_u, out_i = torch.empty_like(hu), torch.empty_like(hi)
     eng.updata(net, lu, hu, li, hi, out_u, out_i)
@@ -1208,10 +1209,10 @@ def _stage_check_at_scale(U, I, n, d, mf_batch, tr_batch, neg, seed, window=12):
     cpu_net = make_transfer(d)
     cpu_net.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()})
     th = O.OracleEngine.theta_of(cpu_net)
-    wantu = O.transfer_forward({k: v.detach() for k, v in th["user"].items()}, (wu * 0.9)[pick_u], hu.cpu()[pick_u])
-    wanti = O.transfer_forward({k: v.detach() for k, v in th["item"].items()}, (wi * 0.9)[pick_i], hi.cpu()[pick_i])
-    close(out_u.cpu()[pick_u].numpy(), wantu.numpy(), 1e-4)
-    close(out_i.cpu()[pick_i].numpy(), wanti.numpy(), 1e-4)
+    wantu = O.transfer_forward({k: v.detach() for k, v in th["user"].items()}, wu[pick_u] * 0.9, hu[pick_u.to(DEV)].cpu())
+    wanti = O.transfer_forward({k: v.detach() for k, v in th["item"].items()}, wi[pick_i] * 0.9, hi[pick_i.to(DEV)].cpu())
+    close(out_u[pick_u.to(DEV)].cpu().numpy(), wantu.numpy(), 1e-4)
+    close(out_i[pick_i.to(DEV)].cpu().numpy(), wanti.numpy(), 1e-4)
     # ---- evaluation (a13) of every test row, sampled rows vs the oracle
     rows = torch.from_numpy(test).to(DEV)
     ranks = eng.eval_ranks(out_u, out_i, rows)
@@ -1219,16 +1220,34 @@ def _stage_check_at_scale(U, I, n, d, mf_batch, tr_batch, neg, seed, window=12):
     # same fp32 tables; a candidate whose score sits within 1e-5 (relative) of the positive's may fall either way in
     # fp32 -- such rows (a handful of 2,048 x 1,000 comparisons at most) are allowed exactly that many flips, all others none
     pick = torch.randint(0, n, (2048,)).numpy()
-    tu, ti = out_u.cpu().double(), out_i.cpu().double()
-    sc = torch.einsum("nd,ncd->nc", tu[test[pick, 0]], ti[torch.from_numpy(test[pick, 1:])]).numpy()
+    tu = out_u[torch.from_numpy(test[pick, 0]).to(DEV)].cpu().double()               # (picked rows only: the tables may be GBs)
+    ti = out_i[torch.from_numpy(test[pick, 1:]).to(DEV)].cpu().double()
+    sc = torch.einsum("nd,ncd->nc", tu, ti).numpy()
     diff = sc[:, 1:] - sc[:, :1]
     amb = (np.abs(diff) <= 1e-5 * (1.0 + np.abs(sc[:, :1]))).sum(1)
     want = (diff > 0).sum(1)
     got = ranks[torch.from_numpy(pick).to(DEV)].cpu().numpy()
     assert (np.abs(got - want) <= amb).all() and (amb == 0).mean() > 0.95
-    assert np.array_equal(O.eval_ranks(out_u.cpu(), out_i.cpu(), test[pick[:64]]).numpy(), got[:64]) or amb[:64].any()
+    sub = test[pick[:64]]
+    su, si_, ssub = np.unique(sub[:, 0]), np.unique(sub[:, 1:]), sub.copy()
+    ssub[:, 0], ssub[:, 1:] = np.searchsorted(su, sub[:, 0]), np.searchsorted(si_, sub[:, 1:])
+    o64 = O.eval_ranks(out_u[torch.from_numpy(su).to(DEV)].cpu(), out_i[torch.from_numpy(si_).to(DEV)].cpu(), ssub).numpy()
+    assert np.array_equal(o64, got[:64]) or amb[:64].any()
     hits, ndcg = eng.eval_metrics(ranks, 20)
     assert 0 <= hits <= n and np.isfinite(ndcg)
+
+
+def test_config4_shape_sml_stages_on_tables_above_2_to_the_31_bytes():
+    """BASELINE.json config 4's shape -- 10M users x 1M items, d = 64: a user table of 2.56 GB (past 2^31 bytes, every copy of
+    it: W, W_{t-1}, W_hat, m, v) -- through the SML stages, not only the bare step: MF epoch over 2^20
+    triples (lazy Adam, 64 batches of 16,384), k_adam_flush over 11M rows, updata over the whole tables, TR windows
+    (teacher-forced, 2^16 triples in batches of 256), evaluation with the user table above 2^31 bytes -- against the oracle on
+    the compacted touched rows; untouched rows bit-identical."""
+    free, total = torch.cuda.mem_get_info()
+    if free < 40 * (1 << 30):
+        pytest.skip("needs ~40 GB of free HBM")
+    _stage_check_at_scale(U=10_000_000, I=1_000_000, n=1 << 20, d=64, mf_batch=16384, tr_batch=256, neg=99, seed=35, n_tr=1 << 16,
+                          a_user=0.0, tag="r04")
 
 
 def test_adressa_shape_period_stages_at_full_size():
@@ -1275,6 +1294,35 @@ def test_tr_stage_every_backward_geometry_vs_oracle(d, B, env, monkeypatch):
         # (Adam's first steps move a weight by ~lr whatever the gradient's size: with 700-row batches a few more of the
         # 16k-80k weights per tensor sit at rounding-noise gradients than in the 48-row tests)
         adam_close(gt[k], ot[k], 1e-3, 2, frac=0.995)
+
+
+@pytest.mark.parametrize("d,B,nb", [(32, 256, 6), (64, 256, 4), (128, 128, 3), (32, 64, 2)])
+def test_tr_conv_step_taken_by_the_next_forward_equals_the_last_arriver_form_bit_for_bit(d, B, nb, monkeypatch):
+    """Round 4: the 190 conv parameters' Adam step of TR batch b is taken in the prologue of batch b + 1's forward (every
+    workgroup adds the merged launch's partial rows in the last arriver's order and steps its own copy; the epoch's last
+    batch keeps the last-arriver form).  Same additions in the same order, same Adam arithmetic: theta, both Adam moments
+    and every batch loss must equal the SML_TR_DEFER=0 run BIT FOR BIT -- over several batches (both state parities), a
+    ragged last batch, every width, and a second epoch that starts from the first one's state."""
+    torch.manual_seed(3 * d + nb)
+    U, I, n = 400, 300, nb * B - 9
+    wu, wi = torch.randn(U, d) * 0.3, torch.randn(I, d) * 0.3
+    tri = torch.stack([torch.randint(0, U, (n,)), torch.randint(0, I, (n,)), torch.randint(0, I, (n,))], 1)
+    sd, res = None, []
+    for defer in ("0", "1"):
+        monkeypatch.setenv("SML_TR_DEFER", defer)
+        eng = engine(d, 1024)
+        net = make_transfer(d, device=DEV)
+        if sd is None:
+            sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+        else:
+            net.load_state_dict(sd)
+        ls = []
+        for ep in range(2):
+            ls.append(eng.tr_stage_epoch(net, (wu * 0.9).to(DEV), (wi * 0.9).to(DEV), wu.to(DEV), wi.to(DEV), tri, B, 1e-3, 1e-4).cpu())
+        res.append((torch.cat(ls), eng.adopt(net).detach().cpu().clone(), eng.tr_state[0].cpu().clone(), eng.tr_state[1].cpu().clone()))
+    for x, y in zip(res[0], res[1]):
+        assert torch.equal(x, y)
+    assert eng.tr_step == 2 * nb
 
 
 @pytest.mark.parametrize("d,B,max_norm", [(32, 256, 0.5), (64, 100, 0.05), (32, 256, 1e9)])
@@ -1436,8 +1484,8 @@ def test_driver_on_a_forced_one_rank_rccl_group_matches_the_plain_driver(tmp_pat
 
 
 # ----------------------------------------------------------------------------- world_size 2 on ONE GPU (thread ranks)
-@pytest.mark.parametrize("comm", ["torch", "peer"])
-def test_two_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run(monkeypatch, request, comm):
+@pytest.mark.parametrize("comm,shape", [("torch", "small"), ("peer", "small"), ("peer", "d64_batches_of_6000")])
+def test_two_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run(monkeypatch, request, comm, shape):
     """The real HIP library under world_size 2: two thread ranks (tests/_thread_group.py), each with its own engine,
     its own user shard and an item / theta replica, split every global batch by user owner (unequal local batches,
     one of them EMPTY on rank 1), exchange item-gradient rows and theta gradients, and must land where ONE engine
@@ -1453,10 +1501,12 @@ def test_two_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run(monkey
     from sml_amd import dist as SD
     monkeypatch.setenv("SML_PEER_TIMEOUT_S", "20")
     torch.manual_seed(5)
-    U, I, d, B, n = 200, 120, 32, 64, 300
+    # (the second shape: config 4's width with 6,000-triple batches -- 12,000 item-gradient rows per rank and batch through
+    # the inboxes' row slots, the job-wide item list through the bucket partition of the index preparation)
+    U, I, d, B, n = (200, 120, 32, 64, 300) if shape == "small" else (20000, 9000, 64, 6000, 3 * 6000 + 500)
     wu, wi = torch.randn(U, d) * 0.3, torch.randn(I, d) * 0.3
     u = torch.randint(0, U, (n,)); u[:9] = 3
-    u[2 * B:3 * B] = torch.randint(0, 100, (B,))            # batch 2: every user belongs to rank 0 -> rank 1's batch is empty
+    u[2 * B:3 * B] = torch.randint(0, U // 2, (B,))         # batch 2: every user belongs to rank 0 -> rank 1's batch is empty
     tri = torch.stack([u, torch.randint(0, I, (n,)), torch.randint(0, I, (n,))], 1)
     tri[5, 2] = tri[5, 1]
     net0 = make_transfer(d, device=DEV)
@@ -1486,9 +1536,11 @@ def test_two_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run(monkey
                              plan=route.plan, exchange=route.exchange(d))
         e.mf_flush(m)
         hu_, hi2 = m.user_laten.weight.detach().clone(), m.item_laten.weight.detach().clone()
+        torch.cuda.current_stream().synchronize()
+        assert mode != "peer" or e.peer_status() == 0, "a consumer of the MF stage's row exchange timed out"
         b = e.tr_stage_epoch(net, lu[lo:hi_].to(DEV), li.to(DEV), hu_, hi2, route.local_tri, route.cap, 1e-3, 1e-4, plan=route.plan)
         torch.cuda.current_stream().synchronize()
-        assert mode != "peer" or e.peer_status() == 0
+        assert mode != "peer" or e.peer_status() == 0, "a consumer of the TR stage's theta exchange timed out"
         return dict(l_mf=a.cpu().numpy(), l_tr=b.cpu().numpy(), wu=hu_.cpu(), wi=hi2.cpu(),
                     theta={k: v.detach().cpu().clone() for k, v in net.state_dict().items()})
 
@@ -1524,7 +1576,9 @@ def test_two_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run(monkey
     adam_close(torch.cat([r0["wu"], r1["wu"]]).numpy(), hu.cpu().numpy(), 0.01, 5)
     adam_close(r0["wi"].numpy(), hi.cpu().numpy(), 0.01, 5)
     for k in theta1:
-        adam_close(r0["theta"][k].numpy(), theta1[k].numpy(), 1e-3, 5)
+        # (6,000-row batches: a few more of a tensor's weights sit at rounding-noise gradients, where Adam's direction is
+        # decided by the summation order -- as in test_tr_stage_every_backward_geometry_vs_oracle)
+        adam_close(r0["theta"][k].numpy(), theta1[k].numpy(), 1e-3, 5, frac=0.999 if shape == "small" else 0.995)
 
 
 def test_two_processes_on_one_gpu_exchange_through_hipipc_mappings(tmp_path):
