@@ -328,8 +328,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HSEQ > 1 ? 
         }
         if constexpr (CONVSTEP) {
             if (cstep) {
-                // the pending conv step's inputs go out BEHIND the gather's index loads (loads return in issue order: ahead of
-                // them, these fabric-cold lines held the indices back) and ahead of its row loads
+                // the pending conv step's inputs go out BEHIND the gather's index loads and ahead of its row loads.  (Loads
+                // return in issue order.  Measured, TR step wall: issued at the kernel's top, with the operand rings, 24.0 us
+                // -- these fabric-cold lines, which 192 workgroups ask for at once, hold the index loads back; here 23.3-23.4;
+                // the last-arriver form they replace 24.1.)
                 if (tid < 95) {
                     const float* st_ = a.cs_in + (int64_t)sidx * 3 * SML_CG;
                     cs_p = st_[cs_k]; cs_m = st_[SML_CG + cs_k]; cs_v = st_[2 * SML_CG + cs_k];
@@ -394,12 +396,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HSEQ > 1 ? 
                     }
                     *reinterpret_cast<f32x4*>(P + rg * SML_CG + c4 * 4) = cg_acc;
                 }
-                __syncthreads();
+                // (a bare barrier behind the LDS writes: __syncthreads() also drains vmcnt -- it would hold this step until
+                // the gather's rows have arrived, which is exactly the time it is meant to run in)
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 if (tid < 95) {
                     if (a.cg_part != nullptr) {
+                        float pv[CRG];                   // all 21 LDS reads in flight, then the (ordered) adds: one round trip, not eleven
+#pragma unroll
+                        for (int rg = 0; rg < CRG; ++rg) pv[rg] = P[rg * SML_CG + cs_k];
+                        __builtin_amdgcn_sched_barrier(0);
                         float g = 0.0f;
 #pragma unroll
-                        for (int rg = 0; rg < CRG; ++rg) g += P[rg * SML_CG + cs_k];
+                        for (int rg = 0; rg < CRG; ++rg) g += pv[rg];
                         SmlSched sc; sc.step_size = a.cs_step_size; sc.bc2_sqrt = a.cs_bc2_sqrt;
                         adam_apply(cs_p, cs_m, cs_v, adam_wd(g, a.cs_wd, cs_p), sc);
                     }
