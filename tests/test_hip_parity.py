@@ -1296,7 +1296,7 @@ def test_tr_stage_every_backward_geometry_vs_oracle(d, B, env, monkeypatch):
         adam_close(gt[k], ot[k], 1e-3, 2, frac=0.995)
 
 
-@pytest.mark.parametrize("d,B,nb", [(32, 256, 6), (64, 256, 4), (128, 128, 3), (32, 64, 2)])
+@pytest.mark.parametrize("d,B,nb", [(32, 256, 6), (64, 256, 4), (128, 128, 3), (32, 64, 2), (32, 1000, 2), (64, 17, 3)])
 def test_tr_conv_step_taken_by_the_next_forward_equals_the_last_arriver_form_bit_for_bit(d, B, nb, monkeypatch):
     """Round 4: the 190 conv parameters' Adam step of TR batch b is taken in the prologue of batch b + 1's forward (every
     workgroup adds the merged launch's partial rows in the last arriver's order and steps its own copy; the epoch's last
@@ -1320,8 +1320,9 @@ def test_tr_conv_step_taken_by_the_next_forward_equals_the_last_arriver_form_bit
         for ep in range(2):
             ls.append(eng.tr_stage_epoch(net, (wu * 0.9).to(DEV), (wi * 0.9).to(DEV), wu.to(DEV), wi.to(DEV), tri, B, 1e-3, 1e-4).cpu())
         res.append((torch.cat(ls), eng.adopt(net).detach().cpu().clone(), eng.tr_state[0].cpu().clone(), eng.tr_state[1].cpu().clone()))
-    for x, y in zip(res[0], res[1]):
-        assert torch.equal(x, y)
+    for other in res[1:]:
+        for x, y in zip(res[0], other):
+            assert torch.equal(x, y)
     assert eng.tr_step == 2 * nb
 
 
