@@ -77,15 +77,52 @@ class MFbasemode(nn.Module):
         self.item_bais.weight.data.copy_(item_weight[:, -1].unsqueeze(-1))
 
 
+class _MF2Train(torch.autograd.Function):
+    """MF2.forward's training branch (reference model/MF.py:129-147) as ONE differentiable op: the row gathers and the two
+    dot products run on the HIP engine (k_mf_forward), the bias terms, -sum(logsigmoid) and the reference's "l2" (row NORMS,
+    the negatives' as one Frobenius norm) are a handful of elementwise device ops, and backward scatters the hand-derived
+    gradient rows into dense table gradients -- what autograd hands nn.Embedding(sparse=False)."""
+
+    @staticmethod
+    def forward(ctx, module, user, item, neg, wu, wi, bu, bi):
+        eng = _engine_for(module)
+        dev = wu.device
+        user, item, neg = (x.to(dev).long() for x in (user, item, neg))
+        ue, ie, sp = eng.mf_forward(wu.detach(), wi.detach(), user, item)
+        _, ne, sn = eng.mf_forward(wu.detach(), wi.detach(), user, neg)
+        ub, ib, nb = bu.detach()[user, 0], bi.detach()[item, 0], bi.detach()[neg, 0]
+        score = (ub + ib + sp) - (ub + nb + sn)             # result_pos - result_neg, formed as the reference forms it
+        bpr = -torch.sum(torch.nn.functional.logsigmoid(score))
+        nu, ni, nn_ = ue.norm(dim=-1), ie.norm(dim=-1), ne.norm()
+        l2 = nu.sum() + ni.sum() + nn_.sum()
+        ctx.save_for_backward(user, item, neg, ue, ie, ne, score, nu, ni, nn_)
+        ctx.shapes = (wu.shape, wi.shape, bu.shape, bi.shape)
+        return bpr, l2
+
+    @staticmethod
+    def backward(ctx, g_bpr, g_l2):
+        user, item, neg, ue, ie, ne, score, nu, ni, nn_ = ctx.saved_tensors
+        ds = (-g_bpr * torch.sigmoid(-score)).unsqueeze(-1)               # d bpr / d score
+        du = ds * (ie - ne) + g_l2 * ue / nu.unsqueeze(-1)
+        di = ds * ue + g_l2 * ie / ni.unsqueeze(-1)
+        dn = -ds * ue + g_l2 * ne / nn_
+        su, si, sbu, sbi = ctx.shapes
+        gwu = torch.zeros(su, device=ue.device, dtype=ue.dtype).index_add_(0, user, du)
+        gwi = torch.zeros(si, device=ue.device, dtype=ue.dtype).index_add_(0, item, di).index_add_(0, neg, dn)
+        gbu = torch.zeros(sbu, device=ue.device, dtype=ue.dtype)          # the user bias cancels in result_pos - result_neg
+        gbi = torch.zeros(sbi, device=ue.device, dtype=ue.dtype).index_add_(0, item, ds).index_add_(0, neg, -ds)
+        return None, None, None, None, gwu, gwi, gbu, gbi
+
+
 class MF2(MFbasemode):
-    """model/MF.py:118-156.  Test-time forward adds the biases to the dot product; the
-    BPR training branch of the reference is served by HipEngine.bare_epoch (loss
-    kind BPR) -- this module does not build an autograd graph."""
+    """model/MF.py:118-156.  Test branch: the dot product plus both biases.  Training branch (`neg_item` given): the
+    reference's (bpr_loss, l2loss) pair, differentiable w.r.t. the four embedding tables (`_MF2Train`).  Nothing in the
+    reference calls this class; the bare BPR step at table scale is HipEngine.bare_epoch(bce=False)."""
 
     def forward(self, user, item, neg_item=None):
         if neg_item is not None:
-            raise RuntimeError("MF2 training runs through HipEngine.bare_epoch(bce=False); "
-                               "the module's forward is inference-only")
+            return _MF2Train.apply(self, user, item, neg_item, self.user_laten.weight, self.item_laten.weight,
+                                   self.user_bais.weight, self.item_bais.weight)
         ue, ie, s = MFbasemode.forward(self, user, item)
         user = user.to(s.device).long()
         item = item.to(s.device).long()

@@ -14,7 +14,7 @@ Harness-side shims (the reference is untouched):
   4. test_model's NDCG wrapped back into a tensor (numpy.float32 has no .cpu()).
 
 Fixtures:  G1 transfer forward, G2 run_MF loss and
-gradients, G3 MF-stage steps, G4 TR-stage steps, G5 updata, G6 evaluation, G13 evaluation at 999 negatives,
+gradients, G14 MF2.forward (training and test branch), G3 MF-stage steps, G4 TR-stage steps, G5 updata, G6 evaluation, G13 evaluation at 999 negatives,
 G7 end-to-end main_yelp.py log on a tiny 40-period dataset, G8 batch supply,
 G9 parameter initialisation, G7-news the main_news.py (Adressa) path end to end, G12 a mid-size period
 sequence (10,000 test rows per period: Recall@20 resolves 1e-4) with full-precision per-batch losses and
@@ -413,6 +413,35 @@ def gen_g6(T):
     save("g6_eval.npz", **out)
 
 
+# --------------------------------------------------------------------------- G14 MF2 (model/MF.py:118-156)
+def gen_g14(T):
+    """MF2.forward: the training branch (BPR with the item-bias difference in the score; "l2" as a sum of row NORMS, the
+    negatives' as ONE Frobenius norm -- the reference's expression, model/MF.py:139-146) with its gradients, and the test
+    branch (scores with both biases)."""
+    from model.MF import MF2
+
+    torch.manual_seed(14)
+    U, I, d, B = 40, 30, 32, 24
+    mf = MF2(U, I, d)
+    rng = np.random.RandomState(15)
+    user, item, neg = rng.randint(0, U, B), rng.randint(0, I, B), rng.randint(0, I, B)
+    user[:4] = 3                        # duplicates inside the batch
+    item[5] = neg[5]
+    out = sd_np(mf, "mf.")
+    out["user"], out["item"], out["neg"] = user, item, neg
+    u, i, j = (torch.from_numpy(x) for x in (user, item, neg))
+    bpr, l2 = mf(u, i, j)
+    (bpr + 0.01 * l2).backward()
+    out["bpr_loss"] = np.array(float(bpr.detach()), dtype=np.float64)
+    out["l2loss"] = np.array(float(l2.detach()), dtype=np.float64)
+    for name, prm in mf.named_parameters():
+        out["grad." + name] = prm.grad.numpy().copy()
+    with torch.no_grad():
+        ue, ie, res = mf(u, i)
+    out["test_uemb"], out["test_iemb"], out["test_result"] = ue.numpy().copy(), ie.numpy().copy(), res.numpy().copy()
+    save("g14_mf2.npz", **out)
+
+
 # --------------------------------------------------------------------------- G13 eval at the shipped format's width
 def gen_g13(T):
     """MFbasemode.test / test_model on rows of the shipped test format: 1 positive + 999 negatives (data/dataset2.py:356
@@ -735,6 +764,8 @@ def main():
             gen_g6(T)
         if not only or "g13" in only:
             gen_g13(T)
+        if not only or "g14" in only:
+            gen_g14(T)
         if not only or "g8" in only:
             gen_g8(T)
         if not only or "g7" in only:

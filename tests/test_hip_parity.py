@@ -470,6 +470,33 @@ def test_bare_step_vs_oracle(d, dtype, bce):
     close(gi.float().cpu().numpy(), oi.numpy(), tol)
 
 
+def test_g14_mf2_training_and_test_branch_vs_the_reference():
+    """MF2.forward (reference model/MF.py:118-156; VERDICT r3 missing #5): the training branch's (bpr_loss, l2loss) -- BPR with the
+    item-bias difference in the score, "l2" as a sum of row norms with ONE Frobenius norm for the negatives -- and the gradients
+    loss.backward() leaves on all four embedding tables, duplicates in the batch included; the test branch's scores."""
+    from sml_amd.mf import MF2
+    z = golden("g14_mf2.npz")
+    U, d = z["mf.user_laten.weight"].shape
+    I = z["mf.item_laten.weight"].shape[0]
+    mf = MF2(U, I, d)
+    mf.load_state_dict({k[3:]: torch.from_numpy(np.asarray(z[k])) for k in z.files if k.startswith("mf.")})
+    mf = mf.to(DEV)
+    u, i, j = (torch.from_numpy(np.asarray(z[k])).to(DEV) for k in ("user", "item", "neg"))
+    bpr, l2 = mf(u, i, j)
+    np.testing.assert_allclose(float(bpr.detach()), float(z["bpr_loss"]), rtol=1e-5)
+    np.testing.assert_allclose(float(l2.detach()), float(z["l2loss"]), rtol=1e-5)
+    (bpr + 0.01 * l2).backward()
+    for name, prm in mf.named_parameters():
+        if name == "user_bais.weight":       # cancels in result_pos - result_neg: the reference holds rounding residue at most
+            assert float(prm.grad.abs().max()) <= 1e-6 and np.abs(z["grad." + name]).max() <= 1e-6
+        else:
+            close(prm.grad.cpu().numpy(), z["grad." + name], 2e-5)
+    with torch.no_grad():
+        ue, ie, res = mf(u, i)
+    close(res.cpu().numpy(), z["test_result"], 1e-5)
+    assert np.array_equal(ue.cpu().numpy(), z["test_uemb"]) and np.array_equal(ie.cpu().numpy(), z["test_iemb"])
+
+
 def test_mf_forward_vs_oracle(eng32):
     torch.manual_seed(1)
     wu, wi = torch.randn(70, 32), torch.randn(50, 32)
