@@ -144,12 +144,14 @@ __device__ __forceinline__ void mma16_ring(f32x4 (&acc)[MT][NT], f32x4 (&ring)[P
         f32x4 an[NA][MT];
         const int kn = ks + 1 < NK ? ks + 1 : ks;          // (the last step re-reads its own fragment: no branch)
         load_a(kn, an);
+        // e-major: consecutive products go to DIFFERENT accumulators (a product that reads the accumulator the previous one
+        // writes cannot issue until that one has left the pipe)
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[mt][t] = mfma16(av[SPLITK ? t : 0][mt][e], ring[slot][t][e], acc[mt][t]);
+                for (int mt = 0; mt < MT; ++mt) acc[mt][t] = mfma16(av[SPLITK ? t : 0][mt][e], ring[slot][t][e], acc[mt][t]);
         if (refill) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
