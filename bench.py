@@ -575,7 +575,11 @@ def main():
         # processes (rendezvous and HSA_ENABLE_IPC_MODE_LEGACY=0 in their environment), relays rank 0's ONE JSON line
         # and leaves with the ranks' exit code.
         argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
-        code, _ = launch.spawn_ranks(argv, a.gpus, one_device=a.one_device or os.environ.get("SML_ONE_DEVICE") == "1")
+        one = a.one_device or os.environ.get("SML_ONE_DEVICE") == "1"
+        have = torch.cuda.device_count()          # (counting devices does not initialise HIP)
+        if not one and have < a.gpus:
+            raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s) (--one-device maps every rank to device 0: a test mode)" % (a.gpus, have))
+        code, _ = launch.spawn_ranks(argv, a.gpus, one_device=one)
         raise SystemExit(code)
     launch.prepare_rank_env()           # (ranks started by torchrun: the IPC mode, before the first HIP call)
     rank = int(os.environ.get("RANK", "0"))
