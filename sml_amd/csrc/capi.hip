@@ -499,7 +499,6 @@ int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
     else vb[0] = vb[1] = 32;
     Buf<uint32_t>* hist[2] = {&c->hist_u, &c->hist_i};
     Buf<uint32_t>* bko[2] = {&c->bko_u, &c->bko_i};
-    Buf<uint32_t>* bkc[2] = {&c->bkc_u, &c->bkc_i};
     HIPCHK(c->key_u.ensure((size_t)n + 1)); HIPCHK(c->key_u2.ensure((size_t)n + 1));
     HIPCHK(c->key_i.ensure((size_t)n_items + 1)); HIPCHK(c->key_i2.ensure((size_t)n_items + 1));
     HIPCHK(c->val_u2.ensure((size_t)n + 1)); HIPCHK(c->val_i2.ensure((size_t)n_items + 1));
@@ -510,9 +509,8 @@ int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
     if (dups) {
         HIPCHK(c->uniq.ensure((size_t)3 * nb * batch));
         HIPCHK(c->runs_u.ensure((size_t)n / 2 + 8)); HIPCHK(c->runs_i.ensure(runs_i_cap));
-        HIPCHK(c->stage_u.ensure((size_t)n / 2 + 8)); HIPCHK(c->stage_i.ensure(runs_i_cap));
         HIPCHK(c->off_u.ensure((size_t)nb + 1)); HIPCHK(c->off_i.ensure((size_t)nb + 1));
-        HIPCHK(c->cnt_u.ensure((size_t)nb + 1)); HIPCHK(c->cnt_i.ensure((size_t)nb + 1));
+        HIPCHK(c->cnt_u.ensure((size_t)(nb + 1) * SML_PREP_CNT_STRIDE)); HIPCHK(c->cnt_i.ensure((size_t)(nb + 1) * SML_PREP_CNT_STRIDE));
     } else {
         HIPCHK(c->rec_u.ensure((size_t)n)); HIPCHK(c->rec_i.ensure((size_t)2 * n));
     }
@@ -526,11 +524,11 @@ int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
         t.ntile = T ? nis * a.tpb : (has_users ? a.tpb : 0);
         t.wave = (dups && !t.allruns && ((int64_t)(T ? nis : 1) * batch >> t.lb) <= 256 && !getenv("SML_PREP_NOWAVE")) ? 1 : 0;
         HIPCHK(hist[T]->ensure((size_t)nb * (T ? nis : 1) * a.tpb * t.nbk));
-        HIPCHK(bko[T]->ensure((size_t)2 * nb * t.nbk)); HIPCHK(bkc[T]->ensure((size_t)nb * t.nbk));
-        t.hist = hist[T]->p; t.bk = reinterpret_cast<uint2*>(bko[T]->p); t.brc = dups ? bkc[T]->p : nullptr;
+        HIPCHK(bko[T]->ensure((size_t)2 * nb * t.nbk));
+        t.hist = hist[T]->p; t.bk = reinterpret_cast<uint2*>(bko[T]->p); t.brc = nullptr;
         t.ent = T ? (void*)c->key_i.p : (void*)c->key_u.p; t.ent2 = T ? (void*)c->key_i2.p : (void*)c->key_u2.p;
         t.vals = T ? c->val_i2.p : c->val_u2.p;
-        if (dups) { t.runs_tmp = T ? c->stage_i.p : c->stage_u.p; t.runs = T ? c->runs_i.p : c->runs_u.p; t.run_off = T ? c->off_i.p : c->off_u.p; t.run_cnt = T ? c->cnt_i.p : c->cnt_u.p; }
+        if (dups) { t.runs_tmp = nullptr; t.runs = T ? c->runs_i.p : c->runs_u.p; t.run_off = T ? c->off_i.p : c->off_u.p; t.run_cnt = T ? c->cnt_i.p : c->cnt_u.p; }
         else t.runs = T ? c->rec_i.p : c->rec_u.p;
     }
     a.large = c->large.p; a.n_large = c->n_sel.p + 3; a.large_cap = (int)large_cap;
@@ -1235,8 +1233,15 @@ int64_t sml_index_lists_read(sml_ctx* ctx, int slot, int which, void* host, int6
         case 1: src = X->runs_i.p; have = (int64_t)X->runs_i.cap * sizeof(SmlRun); break;
         case 2: src = X->off_u.p; have = (nb + 1) * 4; break;
         case 3: src = X->off_i.p; have = (nb + 1) * 4; break;
-        case 4: src = X->by_hand ? X->cnt_u.p : nullptr; have = X->by_hand ? nb * 4 : 0; break;
-        case 5: src = X->by_hand ? X->cnt_i.p : nullptr; have = X->by_hand ? nb * 4 : 0; break;
+        case 4: case 5: {        // the batches' run counters sit a cache line apart on the device: gathered here
+            if (!X->by_hand) return 0;
+            std::vector<int> raw((size_t)nb * SML_PREP_CNT_STRIDE), cnt((size_t)nb);
+            HIPCHK(hipMemcpy(raw.data(), which == 4 ? X->cnt_u.p : X->cnt_i.p, raw.size() * sizeof(int), hipMemcpyDeviceToHost));
+            for (int64_t b = 0; b < nb; ++b) cnt[(size_t)b] = raw[(size_t)b * SML_PREP_CNT_STRIDE];
+            const int64_t nbytes = nb * 4 < bytes ? nb * 4 : bytes;
+            memcpy(host, cnt.data(), (size_t)nbytes);
+            return nbytes;
+        }
         case 6: src = X->val_u2.p; have = X->n * 4; break;
         case 7: src = X->val_i2.p; have = 2 * X->n * 4; break;
         case 8: src = X->uniq.p; have = 3 * nb * X->batch; break;

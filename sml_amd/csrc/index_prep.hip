@@ -21,8 +21,11 @@
 //                   read off the sorted bucket and the outputs leave directly;
 //   k_prep_large    buckets above SML_PREP_SMALL entries (a row with thousands of occurrences): the same passes in LDS
 //                   + registers up to 96 KB of entries, beyond that through global memory, chunk by chunk;
-//   k_prep_compact  (bare step) the buckets' run records, written to per-bucket stretches, become one list per batch.
-// No atomics on shared counters anywhere on the path of every occurrence (one per oversized bucket, one per hot run).
+// Run records (bare step) go straight into the batch's run list: a bucket counts its records, takes their place with ONE
+// returning atomicAdd on the batch's counter (a cache line per batch) and writes them -- round 3's staging array and its
+// compaction pass (k_prep_compact: 37-46 us and 160 MB per epoch) are gone; the order of the buckets inside a list is
+// arrival order, which nothing depends on.
+// No atomics on the path of every occurrence (one per bucket with duplicated rows, one per oversized bucket, one per hot run).
 // Several GPUs: the same kernels over other occurrence streams (occ_of, k_prep_hist_x / k_prep_scatter_x).
 // HBM traffic per triple: 24 B (triples) x 2 + 12 B written + 12 B read + marks / records of duplicated rows -- against
 // 4 radix passes over 8-byte pairs per table before.  Occurrences of one row always meet in one bucket; buckets are cut
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(1024) void k_prep_scan(SmlPrepArgs a) {
     uint32_t* H = tb.hist + (int64_t)b * ntile * nbk;
     if (ntile == 0) {                                                // a table without occurrences (the head list has no users)
         if (tid < nbk) tb.bk[(int64_t)b * nbk + tid] = make_uint2(0u, 0u);
-        if (tid == 0 && tb.run_off != nullptr) tb.run_off[b] = 0;
+        if (tid == 0 && tb.run_off != nullptr) { tb.run_off[b] = 0; tb.run_cnt[(int64_t)b * SML_PREP_CNT_STRIDE] = 0; }
         return;
     }
     // all 1024 threads: thread (group, bin) owns a contiguous share of the tiles
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(1024) void k_prep_scan(SmlPrepArgs a) {
         }
     }
     if (tid == 0) {
-        if (tb.run_off != nullptr) tb.run_off[b] = (int)(list_start >> tb.rshift);
+        if (tb.run_off != nullptr) { tb.run_off[b] = (int)(list_start >> tb.rshift); tb.run_cnt[(int64_t)b * SML_PREP_CNT_STRIDE] = 0; }
         if (T == 0 && a.hot_count != nullptr) a.hot_count[b] = 0;
     }
 }
@@ -369,11 +372,34 @@ __device__ __forceinline__ uint32_t emit_bucket(const SmlPrepArgs& a, const SmlP
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int vb = tb.vb;
     uint8_t* uniq = a.uniq ? a.uniq + (int64_t)b * a.uniq_stride : nullptr;
-    // compact mode: the bucket's records go to ITS stretch of the staging array (a bucket of S occurrences has at most
-    // S/2 duplicated runs, and floor(pos0/2) + floor(S/2) <= floor((pos0+S)/2): the stretches do not overlap), in
-    // position order -- no counter is shared between workgroups; k_prep_compact closes the gaps.
-    SmlRun* out = a.records ? tb.runs : tb.runs_tmp + (pos0 >> tb.rshift);
+    // compact mode (round 4): the bucket first COUNTS its records (a run's last occurrence: next entry differs; duplicated:
+    // previous one equal), takes their place in the batch's run list with ONE returning atomicAdd on the batch's counter
+    // (a cache line per batch: 16 + 16 counters in one line was what made a shared counter cost 600 us in round 3) and
+    // writes them there -- no staging array, no compaction pass.  The ORDER of the buckets inside a batch's list is then
+    // whatever order they arrive in: nothing depends on it (every run is one row, summed in its own fixed slot order).
+    SmlRun* out = tb.runs;
     uint32_t done = 0;                                            // compact records of earlier trips (block-uniform)
+    if (!a.records) {
+        uint32_t mine = 0;
+        for (int q = tid; q < S; q += NT) {
+            const uint32_t rh = ent_hi<E>(get(q), vb);
+            const bool tail = q + 1 >= S || ent_hi<E>(get(q + 1), vb) != rh;
+            const bool head = q == 0 || ent_hi<E>(get(q - 1), vb) != rh;
+            mine += (tail && (tb.allruns || !head)) ? 1u : 0u;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mine += (uint32_t)__shfl_xor((int)mine, off, 64);
+        if (lane == 0) scratch[wv] = mine;
+        __syncthreads();
+        uint32_t total = 0;
+#pragma unroll
+        for (int j = 0; j < NT / 64; ++j) total += scratch[j];
+        __syncthreads();
+        if (tid == 0) scratch[0] = total ? (uint32_t)atomicAdd(tb.run_cnt + (int64_t)b * SML_PREP_CNT_STRIDE, (int)total) : 0u;
+        __syncthreads();
+        out = tb.runs + tb.run_off[b] + scratch[0];
+        __syncthreads();
+    }
 #pragma unroll 1
     for (int q0 = 0; q0 < S; q0 += NT) {                          // block-uniform trip count
         const int q = q0 + tid;
@@ -466,92 +492,115 @@ __global__ __launch_bounds__(256) void k_prep_wave(SmlPrepArgs a, int T) {
     __shared__ uint32_t bm_all[4][2][256];
     __shared__ E cand_all[4][64];
     __shared__ E sorted_all[4][64];
+    __shared__ int wcnt[4];
+    __shared__ int wbase;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const SmlPrepTable& tb = a.t[T];
     const int quads = (tb.nbk + 3) >> 2;                             // four buckets of one list per workgroup
     const XcdMap xm = xcd_map(blockIdx.x, quads);
     const int b = xm.b;
     const uint32_t bin = (uint32_t)(xm.item * 4 + wv);
-    if (b >= a.nb || bin >= (uint32_t)tb.nbk) return;
-    const uint2 oc = tb.bk[(int64_t)b * tb.nbk + bin];
-    const int S = (int)oc.y;
-    uint32_t* brc = tb.brc + (int64_t)b * tb.nbk + bin;
-    if (S == 0) { if (lane == 0) *brc = 0u; return; }
-    if (S > SML_PREP_SMALL) return;                                  // k_prep_large's (listed by k_prep_scan)
-    if (S > 512) { if (lane == 0) prep_punt(a, T, b, bin); return; }
-    const BatchGeo g = batch_geo(a, b);
-    const uint32_t pos0 = (uint32_t)(tb.lmul * g.start) + oc.x;
-    const E* src = reinterpret_cast<const E*>(tb.ent) + pos0;
-    uint32_t (*bm)[256] = bm_all[wv];
-    E* cand = cand_all[wv];
-    E* sorted = sorted_all[wv];
-    const int R0 = (S + 63) >> 6;
-    const int vb = tb.vb;
-    E e0[8];
+    if (b >= a.nb) return;                                           // (the whole workgroup: b is block-uniform)
+    // every wavefront handles its bucket without a barrier; what it has to emit (`want`, the record, the count) meets the other
+    // three at ONE pair of barriers at the end, where the workgroup takes the four buckets' place in the batch's run list with
+    // one returning atomicAdd (one per bucket: the wave kernel went from 15 to 38 us -- 16,384 buckets queue on 16 counters)
+    bool want = false;
+    uint64_t wm = 0ull;
+    SmlRun rec;
+    rec.row = rec.pos = rec.len = rec.pad = 0u;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) e0[r] = (r < R0 && r * 64 + lane < S) ? src[r * 64 + lane] : (E)0;
+    for (int jj = 0; jj < SML_RUN_INL; ++jj) rec.slot[jj] = 0u;
+    do {
+        if (bin >= (uint32_t)tb.nbk) break;
+        const uint2 oc = tb.bk[(int64_t)b * tb.nbk + bin];
+        const int S = (int)oc.y;
+        if (S == 0) break;
+        if (S > SML_PREP_SMALL) break;                               // k_prep_large's (listed by k_prep_scan)
+        if (S > 512) { if (lane == 0) prep_punt(a, T, b, bin); break; }
+        const BatchGeo g = batch_geo(a, b);
+        const uint32_t pos0 = (uint32_t)(tb.lmul * g.start) + oc.x;
+        const E* src = reinterpret_cast<const E*>(tb.ent) + pos0;
+        uint32_t (*bm)[256] = bm_all[wv];
+        E* cand = cand_all[wv];
+        E* sorted = sorted_all[wv];
+        const int R0 = (S + 63) >> 6;
+        const int vb = tb.vb;
+        E e0[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) (&bm[0][0])[j * 64 + lane] = 0u;
-    const uint32_t hmask = (1u << min(tb.hb, 13)) - 1u;
+        for (int r = 0; r < 8; ++r) e0[r] = (r < R0 && r * 64 + lane < S) ? src[r * 64 + lane] : (E)0;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        if (r < R0 && r * 64 + lane < S) {
-            const uint32_t h = ent_hi<E>(e0[r], vb) & hmask, bit = 1u << (h & 31);
-            const uint32_t old = atomicOr(&bm[0][h >> 5], bit);
-            if (old & bit) atomicOr(&bm[1][h >> 5], bit);
+        for (int jj = 0; jj < 8; ++jj) (&bm[0][0])[jj * 64 + lane] = 0u;
+        const uint32_t hmask = (1u << min(tb.hb, 13)) - 1u;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (r < R0 && r * 64 + lane < S) {
+                const uint32_t h = ent_hi<E>(e0[r], vb) & hmask, bit = 1u << (h & 31);
+                const uint32_t old = atomicOr(&bm[0][h >> 5], bit);
+                if (old & bit) atomicOr(&bm[1][h >> 5], bit);
+            }
         }
-    }
-    uint32_t nc = 0;
+        uint32_t nc = 0;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        if (r < R0) {
-            const uint32_t h = ent_hi<E>(e0[r], vb) & hmask;
-            const bool isd = r * 64 + lane < S && ((bm[1][h >> 5] >> (h & 31)) & 1u);
-            const uint64_t m = __ballot(isd);
-            const uint32_t idx = nc + (uint32_t)__popcll(m & lanes_below());
-            if (isd && idx < 64) cand[idx] = e0[r];
-            nc += (uint32_t)__popcll(m);
+        for (int r = 0; r < 8; ++r) {
+            if (r < R0) {
+                const uint32_t h = ent_hi<E>(e0[r], vb) & hmask;
+                const bool isd = r * 64 + lane < S && ((bm[1][h >> 5] >> (h & 31)) & 1u);
+                const uint64_t m = __ballot(isd);
+                const uint32_t idx = nc + (uint32_t)__popcll(m & lanes_below());
+                if (isd && idx < 64) cand[idx] = e0[r];
+                nc += (uint32_t)__popcll(m);
+            }
         }
-    }
-    if (nc == 0) { if (lane == 0) *brc = 0u; return; }
-    if (nc > 64) { if (lane == 0) prep_punt(a, T, b, bin); return; }
-    const int n = (int)nc;
-    {   // rank among the candidates: by row_hi, equal ones by position (stable)
-        const E e = lane < n ? cand[lane] : (E)0;
-        const uint32_t key = ent_hi<E>(e, vb);
-        uint32_t rank = 0;
-        for (int j = 0; j < n; ++j) {
-            const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)key, j);
-            rank += (kj < key || (kj == key && j < lane)) ? 1u : 0u;
+        if (nc == 0) break;
+        if (nc > 64) { if (lane == 0) prep_punt(a, T, b, bin); break; }
+        const int n = (int)nc;
+        {   // rank among the candidates: by row_hi, equal ones by position (stable)
+            const E e = lane < n ? cand[lane] : (E)0;
+            const uint32_t key = ent_hi<E>(e, vb);
+            uint32_t rank = 0;
+            for (int jj = 0; jj < n; ++jj) {
+                const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)key, jj);
+                rank += (kj < key || (kj == key && jj < lane)) ? 1u : 0u;
+            }
+            if (lane < n) sorted[rank] = e;
         }
-        if (lane < n) sorted[rank] = e;
+        const int q = lane;
+        const bool in = q < n;
+        const E e = in ? sorted[q] : (E)0;
+        const uint32_t rh = ent_hi<E>(e, vb);
+        const uint32_t prev = (in && q > 0) ? ent_hi<E>(sorted[q - 1], vb) : ~rh;
+        const uint32_t next = (in && q + 1 < n) ? ent_hi<E>(sorted[q + 1], vb) : ~rh;
+        const bool head = in && prev != rh, tail = in && next != rh, dup = in && !(head && tail);
+        const uint32_t val = ent_val<E>(e, vb);
+        if (dup) {
+            tb.vals[pos0 + q] = val;
+            if (a.uniq) a.uniq[(int64_t)b * a.uniq_stride + val] = 0;
+        }
+        const uint64_t heads = __ballot(head);
+        const uint64_t upto = heads & ((lanes_below() << 1) | 1ull);           // heads at or below this lane
+        const int hq = 63 - __clzll((long long)(upto | 1ull));
+        const int len = q - hq + 1;
+        want = tail && len >= 2;
+        wm = __ballot(want);
+        if (want) {
+            rec.row = (rh << tb.lb) | bin; rec.pos = pos0 + (uint32_t)hq; rec.len = (uint32_t)len;
+#pragma unroll
+            for (int jj = 0; jj < SML_RUN_INL; ++jj) rec.slot[jj] = jj < len ? ent_val<E>(sorted[hq + jj], vb) : 0u;
+        }
+    } while (false);
+    if (lane == 0) wcnt[wv] = (int)__popcll(wm);
+    __syncthreads();
+    if (tid == 0) {
+        const int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        wbase = tot ? atomicAdd(tb.run_cnt + (int64_t)b * SML_PREP_CNT_STRIDE, tot) : 0;
     }
-    const int q = lane;
-    const bool in = q < n;
-    const E e = in ? sorted[q] : (E)0;
-    const uint32_t rh = ent_hi<E>(e, vb);
-    const uint32_t prev = (in && q > 0) ? ent_hi<E>(sorted[q - 1], vb) : ~rh;
-    const uint32_t next = (in && q + 1 < n) ? ent_hi<E>(sorted[q + 1], vb) : ~rh;
-    const bool head = in && prev != rh, tail = in && next != rh, dup = in && !(head && tail);
-    const uint32_t val = ent_val<E>(e, vb);
-    if (dup) {
-        tb.vals[pos0 + q] = val;
-        if (a.uniq) a.uniq[(int64_t)b * a.uniq_stride + val] = 0;
-    }
-    const uint64_t heads = __ballot(head);
-    const uint64_t upto = heads & ((lanes_below() << 1) | 1ull);           // heads at or below this lane
-    const int hq = 63 - __clzll((long long)(upto | 1ull));
-    const int len = q - hq + 1;
-    const bool want = tail && len >= 2;
-    const uint64_t wm = __ballot(want);
+    __syncthreads();
     if (want) {
-        SmlRun r;
-        r.row = (rh << tb.lb) | bin; r.pos = pos0 + (uint32_t)hq; r.len = (uint32_t)len; r.pad = 0;
+        int before = 0;
 #pragma unroll
-        for (int j = 0; j < SML_RUN_INL; ++j) r.slot[j] = j < len ? ent_val<E>(sorted[hq + j], vb) : 0u;
-        tb.runs_tmp[(pos0 >> tb.rshift) + (uint32_t)__popcll(wm & lanes_below())] = r;
+        for (int w = 0; w < 4; ++w) before += w < wv ? wcnt[w] : 0;
+        tb.runs[tb.run_off[b] + wbase + before + (int)__popcll(wm & lanes_below())] = rec;
     }
-    if (lane == 0) *brc = (uint32_t)__popcll(wm);
 }
 
 // ------------------------------------------------------------------------------------
@@ -567,7 +616,6 @@ __device__ __forceinline__ void bucket_body(const SmlPrepArgs& a, int T, int b, 
     // list is read straight from the triples, there is no partition
     const uint2 oc = DIRECT ? make_uint2(0u, (uint32_t)(T ? 2 * g.Bb : g.Bb)) : tb.bk[(int64_t)b * tb.nbk + bin];   // (first position inside the list, entries)
     int S = (int)oc.y;
-    if (S == 0 && tid == 0 && tb.brc != nullptr) tb.brc[(int64_t)b * tb.nbk + bin] = 0u;
     if (S == 0 || S > SML_PREP_SMALL) return;
     const uint32_t pos0 = (uint32_t)(tb.lmul * g.start) + oc.x;
     const E* src = reinterpret_cast<const E*>(tb.ent) + pos0;
@@ -627,7 +675,7 @@ __device__ __forceinline__ void bucket_body(const SmlPrepArgs& a, int T, int b, 
 #pragma unroll
         for (int r = 0; r < 8; ++r) if (isd[r]) buf[0][before + lidx[r]] = e0[r];
         S = (int)total;
-        if (S == 0) { if (tid == 0) tb.brc[(int64_t)b * tb.nbk + bin] = 0u; return; }
+        if (S == 0) return;
     }
     int cur = 0;
     const int R = (S + 255) >> 8;                     // rounds: every wavefront owns a contiguous stripe of R * 64 entries
@@ -704,8 +752,7 @@ __device__ __forceinline__ void bucket_body(const SmlPrepArgs& a, int T, int b, 
     }
     __syncthreads();
     const E* sorted = buf[cur];
-    const uint32_t nrec = emit_bucket<E, 256>(a, tb, T, b, bin, pos0, S, [&](int q) { return sorted[q]; }, scratch);
-    if (tid == 0 && tb.brc != nullptr) tb.brc[(int64_t)b * tb.nbk + bin] = nrec;
+    emit_bucket<E, 256>(a, tb, T, b, bin, pos0, S, [&](int q) { return sorted[q]; }, scratch);
 }
 
 // listed == 0: one workgroup per bucket of table T (grid nb * nbk).  listed == 1: the buckets k_prep_wave left
@@ -802,8 +849,7 @@ __global__ __launch_bounds__(1024) void k_prep_large(SmlPrepArgs a) {
             }
             __syncthreads();
             const E* sorted = lbuf;
-            const uint32_t nrec = emit_bucket<E, 1024>(a, tb, T, b, bin, pos0, S, [&](int q) { return sorted[q]; }, scratch);
-            if (tid == 0 && tb.brc != nullptr) tb.brc[(int64_t)b * tb.nbk + bin] = nrec;
+            emit_bucket<E, 1024>(a, tb, T, b, bin, pos0, S, [&](int q) { return sorted[q]; }, scratch);
             continue;
         }
         for (int p = 0; p < tb.npass; ++p) {
@@ -862,64 +908,7 @@ __global__ __launch_bounds__(1024) void k_prep_large(SmlPrepArgs a) {
             E* t2 = src; src = dst; dst = t2;
         }
         const E* sorted = src;
-        const uint32_t nrec = emit_bucket<E, 1024>(a, tb, T, b, bin, pos0, S, [&](int q) { return sorted[q]; }, scratch);
-        if (tid == 0 && tb.brc != nullptr) tb.brc[(int64_t)b * tb.nbk + bin] = nrec;
-    }
-}
-
-// ------------------------------------------------------------------------------------
-// k_prep_compact: grid (ceil(nbk / SML_PREP_CG), nb, 2), 256 threads.  Every workgroup scans its list's per-bucket record counts
-// (a few KB from L2) and moves the records of SML_PREP_CG buckets from their stretches of the staging array to the list's
-// contiguous run array -- bucket order, position order: the run list is a function of the input.
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_prep_compact(SmlPrepArgs a) {
-    __shared__ uint32_t pre[SML_PREP_MAXBK + 1];
-    __shared__ uint32_t wsum[4];
-    const int T = blockIdx.z, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const SmlPrepTable& tb = a.t[T];
-    const int nbk = tb.nbk;
-    if ((int)blockIdx.x * SML_PREP_CG >= nbk) return;
-    const uint32_t* rc = tb.brc + (int64_t)b * nbk;
-    uint32_t c[4], mine = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { c[j] = 4 * tid + j < nbk ? rc[4 * tid + j] : 0u; mine += c[j]; }
-    uint32_t inc = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, off, 64); if (lane >= off) inc += t; }
-    if (lane == 63) wsum[wv] = inc;
-    __syncthreads();
-    uint32_t run = inc - mine;
-    for (int j = 0; j < wv; ++j) run += wsum[j];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { if (4 * tid + j < nbk) pre[4 * tid + j] = run; run += c[j]; }
-    if (tid == 255) { pre[nbk] = run; if (blockIdx.x == 0) tb.run_cnt[b] = (int)run; }
-    __syncthreads();
-    const BatchGeo g = batch_geo(a, b);
-    const uint32_t list_start = (uint32_t)(tb.lmul * g.start);
-    const uint4* stage = reinterpret_cast<const uint4*>(tb.runs_tmp);
-    uint4* dst = reinterpret_cast<uint4*>(tb.runs + (list_start >> tb.rshift));
-    // the 16 buckets' records as ONE flat range of 16-byte halves (a record is two): their stretches' first records are
-    // fetched side by side, not one dependent load per bucket
-    __shared__ uint32_t first[SML_PREP_CG];
-    const int bin0 = blockIdx.x * SML_PREP_CG, nbin = min(SML_PREP_CG, nbk - bin0);
-    if (tid < nbin) first[tid] = (list_start + tb.bk[(int64_t)b * nbk + bin0 + tid].x) >> tb.rshift;
-    __syncthreads();
-    const uint32_t r0 = pre[bin0], r1 = pre[bin0 + nbin];
-    for (uint32_t i0 = 2 * r0 + tid; i0 < 2 * r1; i0 += 1024) {
-        uint4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t i = i0 + 256 * u;
-            if (i < 2 * r1) {
-                const uint32_t rec = i >> 1;
-                int k = 0;
-#pragma unroll
-                for (int j = 1; j < SML_PREP_CG; ++j) k += (j < nbin && pre[bin0 + j] <= rec) ? 1 : 0;
-                v[u] = stage[2 * (int64_t)(first[k] + (rec - pre[bin0 + k])) + (i & 1u)];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) if (i0 + 256 * u < 2 * r1) dst[i0 + 256 * u] = v[u];
+        emit_bucket<E, 1024>(a, tb, T, b, bin, pos0, S, [&](int q) { return sorted[q]; }, scratch);
     }
 }
 
@@ -934,14 +923,12 @@ hipError_t launch_prep(const SmlPrepArgs& a, hipStream_t st) {
     k_prep_scan<<<dim3((unsigned)a.nb, 2), dim3(1024), 0, st>>>(a);
     if (a.mode == 0) k_prep_scatter<E><<<dim3(xcd_grid(a.nb, a.tpb)), dim3(1024), 0, st>>>(a);
     else k_prep_scatter_x<E><<<dim3(xcd_grid(a.nb, a.tpb)), dim3(1024), 0, st>>>(a);
-    const int nbk_max = a.t[0].nbk > a.t[1].nbk ? a.t[0].nbk : a.t[1].nbk;
     for (int T = 0; T < 2; ++T)
         if (a.t[T].wave) k_prep_wave<E><<<dim3(xcd_grid(a.nb, (a.t[T].nbk + 3) / 4)), dim3(256), 0, st>>>(a, T);
     if (a.t[0].wave || a.t[1].wave) k_prep_bucket<E><<<dim3(256), dim3(256), 0, st>>>(a, 0, 1);
     for (int T = 0; T < 2; ++T)
         if (!a.t[T].wave) k_prep_bucket<E><<<dim3(xcd_grid(a.nb, a.t[T].nbk)), dim3(256), 0, st>>>(a, T, 0);
     k_prep_large<E><<<dim3(256), dim3(1024), 0, st>>>(a);
-    if (!a.records) k_prep_compact<<<dim3((unsigned)((nbk_max + SML_PREP_CG - 1) / SML_PREP_CG), (unsigned)a.nb, 2), dim3(256), 0, st>>>(a);
     return hipGetLastError();
 }
 

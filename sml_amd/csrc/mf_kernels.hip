@@ -569,7 +569,7 @@ __device__ __forceinline__ RunLists run_lists(const SmlRunArgs& a) {
         const int u0 = a.off_u[a.batch_index], i0 = a.off_i[a.batch_index];
         L.run_u += u0; L.n_u = a.off_u[a.batch_index + 1] - u0;
         L.run_i += i0; L.n_i = a.off_i[a.batch_index + 1] - i0;
-        if (a.cnt_u != nullptr) { L.n_u = a.cnt_u[a.batch_index]; L.n_i = a.cnt_i[a.batch_index]; }
+        if (a.cnt_u != nullptr) { L.n_u = a.cnt_u[a.batch_index * SML_PREP_CNT_STRIDE]; L.n_i = a.cnt_i[a.batch_index * SML_PREP_CNT_STRIDE]; }
     }
     return L;
 }

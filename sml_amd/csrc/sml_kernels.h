@@ -163,7 +163,7 @@ struct SmlRunArgs {
     const SmlRun* run_u; int n_u;
     const SmlRun* run_i; int n_i;
     const int* off_u; const int* off_i; int batch_index;
-    const int* cnt_u; const int* cnt_i;             // not null: this batch's records are off[b] .. off[b] + cnt[b] (lists built by index_prep.hip)
+    const int* cnt_u; const int* cnt_i;             // not null: this batch's records are off[b] .. off[b] + cnt[b * SML_PREP_CNT_STRIDE] (lists built by index_prep.hip)
     const uint32_t* val_u; const uint32_t* val_i;   // whole sorted value lists (SmlRun.pos indexes them): slot of each occurrence
     const float* dx;         // per-occurrence gradient rows the user values index
     const float* dx_i;       // ... and the item values index (the all-gathered buffer on several GPUs)
@@ -195,6 +195,7 @@ struct SmlRunArgs {
 // by the LOW bits of their row into buckets (stable: slot order survives), each bucket is sorted by the
 // remaining row bits in LDS, and the run records / unique marks / hot-row list leave from there.
 // ------------------------------------------------------------------------------------
+#define SML_PREP_CNT_STRIDE 32   // ints between the batches' run counters: one cache line each (every bucket of a batch bumps its batch's)
 #define SML_PREP_IPT 4           // triples per thread of a partition tile
 #define SML_PREP_TT (1024 * SML_PREP_IPT)   // triples per partition tile
 #define SML_PREP_MAXBK 1024      // most buckets per list
@@ -213,11 +214,12 @@ struct SmlPrepTable {
     void* ent; void* ent2;       // [occurrences] partitioned entries (row_hi << vb | value); ent2: ping-pong for large buckets
     uint32_t* hist;              // [nb][tiles][nbk] tile histograms, turned into the tiles' first positions
     uint2* bk;                   // [nb][nbk] (first position of the bucket inside its list, entries)
-    uint32_t* brc;               // [nb][nbk] compact mode: the bucket's number of run records
-    SmlRun* runs_tmp;            // compact mode: staging array, a bucket's records start at floor(position / 2)
+    uint32_t* brc;               // (unused since round 4: a bucket takes its records' place from the batch's counter)
+    SmlRun* runs_tmp;            // (unused since round 4)
     uint32_t* vals;              // [occurrences] out: values (slots) in sorted order -- written for duplicated runs (all, in records mode)
     SmlRun* runs;                // compact mode: the table's run records, list b's at run_off[b]; records mode: one per position
-    int* run_off; int* run_cnt;  // [nb] (compact mode)
+    int* run_off; int* run_cnt;  // [nb] / [nb * SML_PREP_CNT_STRIDE] (compact mode): list b's records are runs[run_off[b] .. + run_cnt[b * stride]),
+                                 // placed bucket by bucket through one returning atomicAdd on the batch's counter
 };
 struct SmlPrepArgs {
     const int64_t* tri; int64_t n; int batch; int nb; int tpb;   // tpb: partition tiles per batch
