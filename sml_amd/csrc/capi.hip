@@ -160,6 +160,8 @@ struct IndexSet {
     Buf<uint32_t> hist_u, hist_i, bko_u, bko_i, bkc_u, bkc_i, large, medium;
     Buf<SmlRun> stage_u, stage_i;      // per-bucket stretches of run records before the compaction
     Buf<int> cnt_u, cnt_i;
+    Buf<int> rank_viol;      // [0]: lanes the start-up probe found served out of lane order by a returning LDS atomic (wave_rank)
+    bool rank_probed = false;
     bool by_hand = false;              // the lists were built by index_prep.hip: a batch's runs are off[b] .. off[b] + cnt[b]
     Buf<char> cub_tmp;
     int key_bytes = 8, row_bits_u = 32, row_bits_i = 32;
@@ -171,7 +173,7 @@ struct IndexSet {
         val_u.release(); val_u2.release(); val_i.release(); val_i2.release();
         rec_u.release(); rec_i.release(); runs_u.release(); runs_i.release();
         hist_u.release(); hist_i.release(); bko_u.release(); bko_i.release(); bkc_u.release(); bkc_i.release(); large.release(); medium.release();
-        cnt_u.release(); cnt_i.release(); stage_u.release(); stage_i.release();
+        cnt_u.release(); cnt_i.release(); stage_u.release(); stage_i.release(); rank_viol.release();
         uniq.release(); heads_u.release(); heads_i.release(); hot_list.release(); hot_count.release(); off_u.release(); off_i.release(); n_sel.release();
         cub_tmp.release();
         if (max_len_host) { g_graveyard.park_host(max_len_host); max_len_host = nullptr; }
@@ -545,6 +547,15 @@ int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
             a.hot_list = c->hot_list.p; a.hot_count = c->hot_count.p; a.hot_cap = c->hot_cap;
         }
     }
+    // stable ranks from one returning LDS atomic per occurrence -- only where this device hands them out in lane order:
+    // measured once per index set, on the stream, ahead of its first preparation (no host wait: the kernels read the count)
+    if (!c->rank_probed) {
+        HIPCHK(c->rank_viol.ensure(4));
+        HIPCHK(hipMemsetAsync(c->rank_viol.p, 0, 4 * sizeof(int), st));
+        HIPCHK(sml_launch_rank_probe(c->rank_viol.p, st));
+        c->rank_probed = true;
+    }
+    { const char* rk = getenv("SML_PREP_RANK"); a.rank_viol = (rk && !strcmp(rk, "ballot")) ? nullptr : c->rank_viol.p; }
     HIPCHK(sml_launch_prep(a, narrow ? 4 : 8, st));
     if (dups) {
         if (!c->max_len_host) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->max_len_host), sizeof(int), hipHostMallocDefault));

@@ -51,7 +51,20 @@ __device__ __forceinline__ uint64_t match_any(uint32_t key, bool valid, int bits
 
 // One round of the stable in-wavefront ranking: the wavefront's counter row `cnt` holds, per key, the occurrences of
 // earlier rounds; returns this occurrence's rank among the wavefront's equal keys so far.
-__device__ __forceinline__ uint32_t wave_rank(unsigned short* cnt, uint32_t key, bool valid, int bits) {
+//
+// fast (round 4): ONE returning LDS atomic per occurrence.  The counter row is 16-bit counts, two per dword; a lane adds
+// 1 << 16 * (key & 1) to its key's dword and reads its rank out of the OLD value.  That is a STABLE rank only if the lanes of
+// one instruction that hit the same dword are served in ascending lane order -- which the hardware does, but no manual says
+// so: every context measures it before its first preparation (k_rank_probe: collisions of every multiplicity, 1 to 16
+// wavefronts per workgroup on separate rows; tools/lds_atomic_order_probe.hip is the long form: 2.1e9 atomics, none out of
+// order) and the kernels take this path only while the probe's violation count is zero -- otherwise the ballot ranking
+// below (about 130 instructions per round instead of 6: the partition and the bucket sorts were bound by exactly this).
+__device__ __forceinline__ uint32_t wave_rank(unsigned short* cnt, uint32_t key, bool valid, int bits, bool fast) {
+    if (fast) {
+        uint32_t old = 0;
+        if (valid) old = atomicAdd(reinterpret_cast<uint32_t*>(cnt + (key & ~1u)), 1u << (16 * (key & 1u)));
+        return (old >> (16 * (key & 1u))) & 0xffffu;
+    }
     const int lane = threadIdx.x & 63;
     const uint64_t m = match_any(key, valid, bits);
     const int leader = valid ? (__ffsll((long long)m) - 1) : lane;
@@ -180,7 +193,7 @@ __global__ __launch_bounds__(1024) void k_prep_hist_x(SmlPrepArgs a) {
 
 template <typename E>
 __global__ __launch_bounds__(1024) void k_prep_scatter_x(SmlPrepArgs a) {
-    __shared__ unsigned short cnt[16][SML_PREP_MAXBK];
+    __shared__ __attribute__((aligned(16))) unsigned short cnt[16][SML_PREP_MAXBK];
     __shared__ uint32_t tbase[SML_PREP_MAXBK];
     const XcdMap xm = xcd_map(blockIdx.x, a.tpb);
     const int k = xm.item, b = xm.b, tid = threadIdx.x, wv = tid >> 6;
@@ -188,6 +201,7 @@ __global__ __launch_bounds__(1024) void k_prep_scatter_x(SmlPrepArgs a) {
     const BatchGeo g = batch_geo(a, b);
     if (k * SML_PREP_TT >= g.Bb) return;
     constexpr int IPT = SML_PREP_IPT;
+    const bool fast = a.rank_viol != nullptr && *a.rank_viol == 0;
     const int t0 = k * SML_PREP_TT + wv * (64 * IPT) + (tid & 63);
     const int ns = a.has_users + a.nis;
     for (int s = 0; s < ns; ++s) {
@@ -205,7 +219,7 @@ __global__ __launch_bounds__(1024) void k_prep_scatter_x(SmlPrepArgs a) {
 #pragma unroll
         for (int r = 0; r < IPT; ++r) {
             o[r] = occ_of(a, g, s, t0 + r * 64);
-            wr[r] = wave_rank(cnt[wv], o[r].row & (uint32_t)(nbk - 1), o[r].valid, lb);
+            wr[r] = wave_rank(cnt[wv], o[r].row & (uint32_t)(nbk - 1), o[r].valid, lb, fast);
         }
         __syncthreads();
         for (int i = tid; i < nbk; i += 1024) {
@@ -300,7 +314,7 @@ __global__ __launch_bounds__(1024) void k_prep_scan(SmlPrepArgs a) {
 // ------------------------------------------------------------------------------------
 template <typename E>
 __global__ __launch_bounds__(1024) void k_prep_scatter(SmlPrepArgs a) {
-    __shared__ unsigned short cnt[16][SML_PREP_MAXBK];
+    __shared__ __attribute__((aligned(16))) unsigned short cnt[16][SML_PREP_MAXBK];
     __shared__ uint32_t tbase[SML_PREP_MAXBK];
     const XcdMap xm = xcd_map(blockIdx.x, a.tpb);
     const int k = xm.item, b = xm.b, tid = threadIdx.x, wv = tid >> 6;
@@ -308,6 +322,7 @@ __global__ __launch_bounds__(1024) void k_prep_scatter(SmlPrepArgs a) {
     const BatchGeo g = batch_geo(a, b);
     if (k * SML_PREP_TT >= g.Bb) return;
     constexpr int IPT = SML_PREP_IPT;
+    const bool fast = a.rank_viol != nullptr && *a.rank_viol == 0;
     uint32_t row[3][IPT];
     const int t0 = k * SML_PREP_TT + wv * (64 * IPT) + (tid & 63);
 #pragma unroll
@@ -331,7 +346,7 @@ __global__ __launch_bounds__(1024) void k_prep_scatter(SmlPrepArgs a) {
         __syncthreads();
         uint32_t wr[IPT];
 #pragma unroll
-        for (int r = 0; r < IPT; ++r) wr[r] = wave_rank(cnt[wv], row[s][r] & (uint32_t)(nbk - 1), t0 + r * 64 < g.Bb, lb);
+        for (int r = 0; r < IPT; ++r) wr[r] = wave_rank(cnt[wv], row[s][r] & (uint32_t)(nbk - 1), t0 + r * 64 < g.Bb, lb, fast);
         __syncthreads();
         for (int i = tid; i < nbk; i += 1024) {
             uint32_t run = 0;
@@ -612,6 +627,7 @@ __device__ __forceinline__ void bucket_body(const SmlPrepArgs& a, int T, int b, 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const SmlPrepTable& tb = a.t[T];
     const BatchGeo g = batch_geo(a, b);
+    const bool fast = a.rank_viol != nullptr && *a.rank_viol == 0;
     // DIRECT (records mode, every list one bucket of at most SML_PREP_SMALL occurrences -- the MF stage's batches): the
     // list is read straight from the triples, there is no partition
     const uint2 oc = DIRECT ? make_uint2(0u, (uint32_t)(T ? 2 * g.Bb : g.Bb)) : tb.bk[(int64_t)b * tb.nbk + bin];   // (first position inside the list, entries)
@@ -708,7 +724,7 @@ __device__ __forceinline__ void bucket_body(const SmlPrepArgs& a, int T, int b, 
                 const bool valid = i < S;
                 ev[r] = valid ? buf[cur][i] : (E)0;
                 const uint32_t dg = (ent_hi<E>(ev[r], tb.vb) >> lo) & (uint32_t)(nd - 1);
-                wr[r] = wave_rank(cnt[wv], dg, valid, bits);
+                wr[r] = wave_rank(cnt[wv], dg, valid, bits, fast);
             }
         }
         __syncthreads();
@@ -760,7 +776,7 @@ __device__ __forceinline__ void bucket_body(const SmlPrepArgs& a, int T, int b, 
 template <typename E>
 __global__ __launch_bounds__(256, sizeof(E) == 4 ? 7 : 4) void k_prep_bucket(SmlPrepArgs a, int T, int listed) {
     __shared__ E buf[2][SML_PREP_SMALL];
-    __shared__ unsigned short cnt[4][512];
+    __shared__ __attribute__((aligned(16))) unsigned short cnt[4][512];
     __shared__ uint32_t dbase[512];
     __shared__ uint32_t scratch[8];
     if (listed == 2) {                                           // straight from the triples: workgroup = (batch, table)
@@ -792,11 +808,12 @@ __global__ __launch_bounds__(1024) void k_prep_large(SmlPrepArgs a) {
     constexpr int CAP = SML_PREP_LDSCAP / (int)sizeof(E);            // 24,576 four-byte entries: 24 per thread
     constexpr int RMAX = CAP / 1024;
     __shared__ E lbuf[CAP];
-    __shared__ unsigned short cnt[16][512];
+    __shared__ __attribute__((aligned(16))) unsigned short cnt[16][512];
     __shared__ uint32_t dbase[512];
     __shared__ uint32_t wsum[17];
     __shared__ uint32_t scratch[18];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool fast = a.rank_viol != nullptr && *a.rank_viol == 0;
     const int n_large = min(*a.n_large, a.large_cap);
     for (int w = blockIdx.x; w < n_large; w += gridDim.x) {
         const uint32_t tl = a.large[2 * w], bin = a.large[2 * w + 1];
@@ -824,7 +841,7 @@ __global__ __launch_bounds__(1024) void k_prep_large(SmlPrepArgs a) {
                         const int i = wv * (R * 64) + r * 64 + lane;
                         const bool valid = i < S;
                         ev[r] = valid ? lbuf[i] : (E)0;
-                        wr[r] = (unsigned short)wave_rank(cnt[wv], (ent_hi<E>(ev[r], tb.vb) >> lo) & (uint32_t)(nd - 1), valid, bits);
+                        wr[r] = (unsigned short)wave_rank(cnt[wv], (ent_hi<E>(ev[r], tb.vb) >> lo) & (uint32_t)(nd - 1), valid, bits, fast);
                     }
                 }
                 __syncthreads();                                 // every stripe is in registers, every count is in
@@ -883,7 +900,7 @@ __global__ __launch_bounds__(1024) void k_prep_large(SmlPrepArgs a) {
                     const int i = c0 + wv * 256 + r * 64 + lane;
                     const bool valid = i < S;
                     ev[r] = valid ? src[i] : (E)0;
-                    wr[r] = wave_rank(cnt[wv], (ent_hi<E>(ev[r], tb.vb) >> lo) & (uint32_t)(nd - 1), valid, bits);
+                    wr[r] = wave_rank(cnt[wv], (ent_hi<E>(ev[r], tb.vb) >> lo) & (uint32_t)(nd - 1), valid, bits, fast);
                 }
                 __syncthreads();
                 uint32_t ctot = 0;
@@ -912,6 +929,36 @@ __global__ __launch_bounds__(1024) void k_prep_large(SmlPrepArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------
+// k_rank_probe: is a returning LDS atomic a stable rank on this device?  (See wave_rank.)  Every wavefront draws keys from
+// ranges of 1 .. 512 (every collision multiplicity), some lanes sit a round out, and compares the old half-word it got
+// back with the number of lower lanes on the same key: whatever the counter held before the instruction must come out the
+// same for every lane of a key.  *viol counts the lanes for which it did not.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_rank_probe(int* viol) {
+    __shared__ __attribute__((aligned(16))) unsigned short cnt[16][512];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t s = 0x9e3779b9u * ((uint32_t)blockIdx.x * 1024u + threadIdx.x + 1u);
+    auto rng = [&]() { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; };
+    int bad = 0;
+    const int ranges[8] = {1, 2, 3, 7, 32, 100, 317, 512};
+    for (int rr = 0; rr < 8; ++rr) {
+        for (int i = lane; i < 512; i += 64) cnt[wv][i] = 0;
+        for (int sub = 0; sub < 6; ++sub) {
+            const uint32_t key = rng() % (uint32_t)ranges[rr];
+            const bool valid = (rng() & 7u) != 0u;
+            const uint32_t old = wave_rank(cnt[wv], key, valid, 0, true);
+            const uint64_t m = match_any(key, valid, 9);
+            const uint32_t base = old - (uint32_t)__popcll(m & lanes_below());
+            const int leader = valid ? (__ffsll((long long)m) - 1) : lane;
+            const uint32_t base0 = (uint32_t)__shfl((int)base, leader, 64);
+            if (valid && base != base0) ++bad;
+        }
+    }
+    if (bad) atomicAdd(viol, bad);
+}
+
 template <typename E>
 hipError_t launch_prep(const SmlPrepArgs& a, hipStream_t st) {
     if (a.records && a.t[0].nbk == 1 && a.t[1].nbk == 1 && 2 * (int64_t)a.batch <= SML_PREP_SMALL) {
@@ -934,6 +981,10 @@ hipError_t launch_prep(const SmlPrepArgs& a, hipStream_t st) {
 
 }  // namespace
 
+hipError_t sml_launch_rank_probe(int* viol, hipStream_t st) {
+    k_rank_probe<<<dim3(512), dim3(1024), 0, st>>>(viol);
+    return hipGetLastError();
+}
 hipError_t sml_launch_prep(const SmlPrepArgs& a, int ent_bytes, hipStream_t st) {
     if (a.n <= 0 || a.nb <= 0) return hipSuccess;
     return ent_bytes == 8 ? launch_prep<uint64_t>(a, st) : launch_prep<uint32_t>(a, st);

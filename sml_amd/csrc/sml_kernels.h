@@ -235,7 +235,11 @@ struct SmlPrepArgs {
     uint32_t* hot_list; int* hot_count; int hot_cap; int* max_len;
     uint32_t* medium; int* n_medium;                  // same pairs: buckets k_prep_wave leaves to k_prep_bucket
     uint32_t* large; int* n_large; int large_cap;     // (table << 31 | list), bucket -- buckets the small kernel leaves
+    // stable ranks from ONE returning LDS atomic per occurrence, if *rank_viol == 0: the context's start-up probe
+    // (sml_launch_rank_probe) counted no returning atomic that was served out of lane order; null / non-zero: ballot ranking
+    const int* rank_viol;
 };
+hipError_t sml_launch_rank_probe(int* viol, hipStream_t st);
 hipError_t sml_launch_prep(const SmlPrepArgs& a, int ent_bytes, hipStream_t st);
 hipError_t sml_launch_hot_apply(int d, int dtype_bytes, const SmlRunArgs& a, hipStream_t st);
 hipError_t sml_launch_run_adam(int d, const SmlRunArgs& a, int64_t max_records, hipStream_t st);

@@ -2100,6 +2100,33 @@ def _prep_ab_triples(case):
     return U, I, B, np.stack([u, i, j], 1)
 
 
+@pytest.mark.parametrize("case", ["hot_small", "partitioned", "wave_users", "wide_rows"])
+def test_index_prep_ranks_by_returning_lds_atomics_equal_the_ballot_ranking(case, monkeypatch):
+    """Round 4: the stable ranks of the partition and of the bucket sorts come from ONE returning LDS atomic per occurrence
+    (the device serves the lanes of an instruction in lane order: measured by every index set's start-up probe, and at length by
+    tools/lds_atomic_order_probe.hip).  SML_PREP_RANK=ballot keeps round 3's ballot ranking: both must build the same lists --
+    bit-identical tables and losses after two epochs, hot rows and oversized buckets included -- and the probe must have
+    found no lane out of order on this device."""
+    from sml_amd.engine import HipEngine
+    U, I, B, tri = _prep_ab_triples(case)
+    dt = torch.float16 if case.startswith("wide_rows") else torch.float32
+    g = torch.Generator(device=DEV).manual_seed(6)
+    wu = (torch.randn(U, 32, device=DEV, generator=g) * 0.3).to(dt)
+    wi = (torch.randn(I, 32, device=DEV, generator=g) * 0.3).to(dt)
+    t = T(tri, DEV)
+    out = []
+    for mode in ("ballot", "atomic"):
+        monkeypatch.setenv("SML_PREP_RANK", mode)
+        eng = HipEngine(DEV, 32, B)
+        a_u, a_i = wu.clone(), wi.clone()
+        losses = [eng.bare_epoch(a_u, a_i, t, B, 0.05, 1e-4, 1e-4, bce=(e == 0)).cpu() for e in range(2)]
+        torch.cuda.synchronize()
+        out.append((a_u, a_i, losses))
+        eng.close()
+    assert all(torch.equal(x, y) for x, y in zip(out[0][2], out[1][2]))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
 @pytest.mark.parametrize("case", ["hot_small", "partitioned", "tiny_tables", "one_bucket_lists", "wide_rows", "wide_rows_both", "wave_users"])
 def test_index_prep_by_hand_equals_the_library_sort_path(case, monkeypatch):
     """index_prep.hip (bucket partition + LDS sort, run records straight from the sorted buckets) against the library
