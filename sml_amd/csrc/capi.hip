@@ -525,6 +525,9 @@ int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
         t.lmul = T ? nis : 1;
         t.ntile = T ? nis * a.tpb : (has_users ? a.tpb : 0);
         t.wave = (dups && !t.allruns && ((int64_t)(T ? nis : 1) * batch >> t.lb) <= 256 && !getenv("SML_PREP_NOWAVE")) ? 1 : 0;
+        // few row bits left inside a bucket: a counter per row instead of a sort (k_prep_count; SML_PREP_COUNT=0: A/B tests)
+        if (dups && !t.allruns && t.nbk > 1 && (1 << t.hb) <= SML_PREP_CROWS && ((int64_t)(T ? nis : 1) * batch >> t.lb) <= 1024 &&
+            env_int("SML_PREP_COUNT", 1) != 0 && !getenv("SML_PREP_NOWAVE")) t.wave = 2;
         HIPCHK(hist[T]->ensure((size_t)nb * (T ? nis : 1) * a.tpb * t.nbk));
         HIPCHK(bko[T]->ensure((size_t)2 * nb * t.nbk));
         t.hist = hist[T]->p; t.bk = reinterpret_cast<uint2*>(bko[T]->p); t.brc = nullptr;

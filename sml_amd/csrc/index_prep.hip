@@ -637,6 +637,157 @@ __global__ __launch_bounds__(256) void k_prep_wave(SmlPrepArgs a, int T) {
 }
 
 // ------------------------------------------------------------------------------------
+// k_prep_count (round 4): lists whose buckets leave FEW row bits (hb <= 11: a 1M-row item table cut into 512 buckets) -- one
+// WAVEFRONT per bucket, four per workgroup, and no sort at all.  Every possible row_hi of the bucket has a counter in
+// LDS.  Pass 1: each occurrence takes ONE returning LDS atomic on its row's counter: the old value is its rank inside
+// the row's run (lanes of an instruction are served in lane order -- the measured property the `fast` ranking rests on --
+// and a lane's rounds are issued in occurrence order: the rank is the stable one).  Pass 2: the counters of duplicated rows
+// (count >= 2) are scanned -- lane-major, four neighbouring counters per lane and trip: the order of the RUNS inside a bucket
+// is free, only the order inside a run is not -- and every counter becomes (count | base << 16).  Pass 3: a duplicated
+// occurrence knows its place, base + rank: its slot goes there (LDS stage, then one coalesced store of the bucket's
+// values), its unique mark is cleared, and the occurrence of rank count - 1 writes the run's record.  That replaces the
+// duplicate filter's two bitmaps + compaction + two radix passes + head / tail search of k_prep_bucket (70 us per epoch
+// for the items of a 10M x 1M job) by about 6 LDS operations per occurrence.  Buckets it cannot take (more than
+// SML_PREP_CCAP entries or SML_PREP_CDUP duplicated ones; a device whose LDS atomics failed the order probe) go onto
+// the `medium` list: k_prep_bucket's.
+// ------------------------------------------------------------------------------------
+template <typename E>
+__global__ __launch_bounds__(256) void k_prep_count(SmlPrepArgs a, int T) {
+    constexpr int RMAX = SML_PREP_CCAP / 64;                         // rounds: entries per lane
+    constexpr int QT = SML_PREP_CROWS / 256;                         // counter quads per lane
+    __shared__ __attribute__((aligned(16))) uint32_t cw_all[4][SML_PREP_CROWS];
+    __shared__ uint32_t sval_all[4][SML_PREP_CDUP];
+    __shared__ unsigned short rlist_all[4][SML_PREP_CDUP / 2];       // the bucket's duplicated rows (row_hi), in run order
+    __shared__ int wcnt[4];
+    __shared__ int wbase;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const SmlPrepTable& tb = a.t[T];
+    const int quads = (tb.nbk + 3) >> 2;                             // four buckets of one list per workgroup
+    const XcdMap xm = xcd_map(blockIdx.x, quads);
+    const int b = xm.b;
+    const uint32_t bin = (uint32_t)(xm.item * 4 + wv);
+    if (b >= a.nb) return;                                           // (the whole workgroup: b is block-uniform)
+    uint32_t* cw = cw_all[wv];
+    uint32_t* sval = sval_all[wv];
+    unsigned short* rlist = rlist_all[wv];
+    const int vb = tb.vb;
+    uint32_t pos0 = 0;
+    int nrec = 0;
+    do {
+        if (bin >= (uint32_t)tb.nbk) break;
+        const uint2 oc = tb.bk[(int64_t)b * tb.nbk + bin];
+        const int S = (int)oc.y;
+        if (S == 0) break;
+        if (S > SML_PREP_SMALL) break;                               // k_prep_large's (listed by k_prep_scan)
+        const bool fast = a.rank_viol != nullptr && *a.rank_viol == 0;
+        if (S > SML_PREP_CCAP || !fast) { if (lane == 0) prep_punt(a, T, b, bin); break; }
+        const BatchGeo g = batch_geo(a, b);
+        pos0 = (uint32_t)(tb.lmul * g.start) + oc.x;
+        const E* src = reinterpret_cast<const E*>(tb.ent) + pos0;
+        const int R = (S + 63) >> 6;
+        E e[RMAX];
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) e[r] = (r < R && r * 64 + lane < S) ? src[r * 64 + lane] : (E)0;
+        const int nd = 1 << tb.hb;
+        const int nq = (nd + 3) >> 2;                                // counter quads in use
+#pragma unroll
+        for (int k = 0; k < QT; ++k) {
+            const int q = k * 64 + lane;
+            if (q < nq) *reinterpret_cast<uint4*>(cw + 4 * q) = make_uint4(0u, 0u, 0u, 0u);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // pass 1: rank inside the row's run
+        uint32_t rk[RMAX];
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            rk[r] = 0;
+            if (r < R && r * 64 + lane < S) rk[r] = atomicAdd(&cw[ent_hi<E>(e[r], vb)], 1u);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // pass 2: the duplicated rows' runs -- their bases (exclusive scan of the counts, lane-major) and their list
+        uint4 c4[QT];
+        uint32_t mine = 0;                                           // occurrences | runs << 16 of this lane's counters
+#pragma unroll
+        for (int k = 0; k < QT; ++k) {
+            const int q = k * 64 + lane;
+            c4[k] = q < nq ? *reinterpret_cast<const uint4*>(cw + 4 * q) : make_uint4(0u, 0u, 0u, 0u);
+            const uint32_t c[4] = {c4[k].x, c4[k].y, c4[k].z, c4[k].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mine += c[j] >= 2u ? (c[j] | 0x10000u) : 0u;
+        }
+        uint32_t inc = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, off, 64); if (lane >= off) inc += t; }
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        const int ndup = (int)(tot & 0xffffu);
+        if (ndup == 0) break;
+        if (ndup > SML_PREP_CDUP) { if (lane == 0) prep_punt(a, T, b, bin); break; }
+        nrec = (int)(tot >> 16);
+        uint32_t run = (inc - mine) & 0xffffu, ri = (inc - mine) >> 16;
+#pragma unroll
+        for (int k = 0; k < QT; ++k) {
+            const int q = k * 64 + lane;
+            uint32_t c[4] = {c4[k].x, c4[k].y, c4[k].z, c4[k].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool dupl = c[j] >= 2u;
+                if (dupl) { rlist[ri] = (unsigned short)(4 * q + j); ++ri; }
+                const uint32_t n = dupl ? c[j] : 0u;
+                c[j] |= run << 16; run += n;
+            }
+            if (q < nq) *reinterpret_cast<uint4*>(cw + 4 * q) = make_uint4(c[0], c[1], c[2], c[3]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // pass 3: duplicated occurrences to their places; unique marks
+        uint8_t* uniq = a.uniq ? a.uniq + (int64_t)b * a.uniq_stride : nullptr;
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            if (r < R && r * 64 + lane < S) {
+                const uint32_t w = cw[ent_hi<E>(e[r], vb)];
+                if ((w & 0xffffu) >= 2u) {
+                    const uint32_t val = ent_val<E>(e[r], vb);
+                    sval[(w >> 16) + rk[r]] = val;
+                    if (uniq) uniq[val] = 0;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < ndup; i += 64) tb.vals[pos0 + i] = sval[i];
+    } while (false);
+    // the four buckets take their place in the batch's run list with ONE returning atomicAdd
+    if (lane == 0) wcnt[wv] = nrec;
+    __syncthreads();
+    if (tid == 0) {
+        const int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        wbase = tot ? atomicAdd(tb.run_cnt + (int64_t)b * SML_PREP_CNT_STRIDE, tot) : 0;
+    }
+    __syncthreads();
+    if (nrec == 0) return;
+    int before = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) before += w < wv ? wcnt[w] : 0;
+    SmlRun* out = tb.runs + tb.run_off[b] + wbase + before;
+    for (int i = lane; i < nrec; i += 64) {                          // one record per run: neighbouring lanes, neighbouring records
+        const uint32_t h = rlist[i], w = cw[h], len = w & 0xffffu, bs = w >> 16;
+        SmlRun rec;
+        rec.row = (h << tb.lb) | bin; rec.pos = pos0 + bs; rec.len = len; rec.pad = 0;
+#pragma unroll
+        for (int j = 0; j < SML_RUN_INL; ++j) rec.slot[j] = (uint32_t)j < len ? sval[bs + j] : 0u;
+        out[i] = rec;
+        if (len > SML_HOT) {
+            atomicMax(a.max_len, (int)len);
+            if (a.hot_list != nullptr) {
+                const int slot = atomicAdd(a.hot_count + b, 1);
+                if (slot < a.hot_cap) {
+                    uint32_t* hl = a.hot_list + ((int64_t)b * a.hot_cap + slot) * 3;
+                    hl[0] = rec.pos | ((uint32_t)T << 31); hl[1] = len; hl[2] = rec.row;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // bucket_body / k_prep_bucket: 256 threads per bucket; buckets of at most SML_PREP_SMALL entries.
 // ------------------------------------------------------------------------------------
 template <typename E, bool DIRECT = false>
@@ -988,8 +1139,10 @@ hipError_t launch_prep(const SmlPrepArgs& a, hipStream_t st) {
     k_prep_scan<<<dim3((unsigned)a.nb, 2), dim3(1024), 0, st>>>(a);
     if (a.mode == 0) k_prep_scatter<E><<<dim3(xcd_grid(a.nb, a.tpb)), dim3(1024), 0, st>>>(a);
     else k_prep_scatter_x<E><<<dim3(xcd_grid(a.nb, a.tpb)), dim3(1024), 0, st>>>(a);
-    for (int T = 0; T < 2; ++T)
-        if (a.t[T].wave) k_prep_wave<E><<<dim3(xcd_grid(a.nb, (a.t[T].nbk + 3) / 4)), dim3(256), 0, st>>>(a, T);
+    for (int T = 0; T < 2; ++T) {
+        if (a.t[T].wave == 1) k_prep_wave<E><<<dim3(xcd_grid(a.nb, (a.t[T].nbk + 3) / 4)), dim3(256), 0, st>>>(a, T);
+        if (a.t[T].wave == 2) k_prep_count<E><<<dim3(xcd_grid(a.nb, (a.t[T].nbk + 3) / 4)), dim3(256), 0, st>>>(a, T);
+    }
     if (a.t[0].wave || a.t[1].wave) k_prep_bucket<E><<<dim3(256), dim3(256), 0, st>>>(a, 0, 1);
     for (int T = 0; T < 2; ++T)
         if (!a.t[T].wave) k_prep_bucket<E><<<dim3(xcd_grid(a.nb, a.t[T].nbk)), dim3(256), 0, st>>>(a, T, 0);

@@ -201,12 +201,16 @@ struct SmlRunArgs {
 #define SML_PREP_MAXBK 1024      // most buckets per list
 #define SML_PREP_CG 8            // buckets per workgroup of the record compaction
 #define SML_PREP_SMALL 2048      // entries a bucket may hold to be sorted in LDS by the small-bucket kernel
+#define SML_PREP_CROWS 2048      // k_prep_count: most distinct row_hi values of a bucket (one LDS counter each: hb <= 11)
+#define SML_PREP_CCAP 1536       // ... most entries of a bucket it takes (24 per lane), of which at most
+#define SML_PREP_CDUP 1024       // ... this many may belong to duplicated rows (their slots are staged in LDS)
 struct SmlPrepTable {
     int nbk, lb;                 // buckets per list (a power of two) and its log2
     int hb;                      // row bits above the bucket bits (sorted inside the bucket)
     int vb;                      // value bits inside an entry (32: 64-bit entries)
     int npass, pbits;            // LDS radix passes over those bits, bits per pass (<= 9)
-    int wave;                    // small buckets (compact mode): one wavefront per bucket first (k_prep_wave)
+    int wave;                    // compact mode, one WAVEFRONT per bucket first: 1 = k_prep_wave (small buckets, few duplicates),
+                                 // 2 = k_prep_count (few row_hi bits: a counter per row)
     int ntile;                   // partition tiles per list (tiles per batch x streams of this table; 0: the table has no occurrences)
     int lmul;                    // a list starts at lmul * (the batch's first triple) in the table's occurrence arrays
     int allruns;                 // compact mode: EVERY run gets a record (not only duplicated ones), every occurrence its value; no marks
