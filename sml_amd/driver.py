@@ -235,7 +235,12 @@ class meta_train(object):
             wu, wi = self.MFbase.user_laten.weight.data, self.MFbase.item_laten.weight.data
             if hasattr(rows, "wait_ready"):
                 rows.wait_ready()               # rows uploaded ahead of their stage (_prefetch_next)
-            if hasattr(self.engine, "eval_submit"):
+            if getattr(self, "_pending_transfer", False):
+                # the tables this evaluation is about are the ones a deferred updata would write (_updata_for_tests):
+                # forward and ranks are queued together on the evaluation stream, the MF tables are not touched
+                ranks = self.engine.eval_submit_transferred(self.transfer, self.last_user_weight, self.user_weight_hat,
+                                                            self.last_item_weight, self.item_weight_hat, rows.rows)
+            elif hasattr(self.engine, "eval_submit"):
                 ranks = self.engine.eval_submit(wu, wi, rows.rows)
             else:
                 ranks = self.engine.eval_ranks(wu, wi, rows.rows)
@@ -579,6 +584,7 @@ class meta_train(object):
             return more
         finally:
             self._defer = False
+            self._pending_transfer = False       # (a stage that raised half-way leaves no deferred forward behind)
             self._flush_output()
 
     def _stage_body(self, args, stage_id, set_t, set_tt, now_test, val):
@@ -606,23 +612,50 @@ class meta_train(object):
                 self.writer.add_scalars("Scale/item_weight", {"weight_hat": torch.norm(self.item_weight_hat).item(),
                                                               "weight_last": torch.norm(self.last_item_weight).item()},
                                         stage_id)
-            self.updata()
+            self._updata_for_tests(args, val)
             if now_test is not None and phase == 0:
                 # test D_{t+1} with the first outer loop's model, before it trains theta
                 self._real_test(now_test)
             self.transfer_train_onestage(args, set_tt, stage_id, val=val)
+            self._materialise_tables()
             if args.Load_W_hat:
                 self.load_MFbase_weight(self.user_weight_hat, self.item_weight_hat)
         self.updata()
         return True
 
     # ------------------------------------------------------------------ hot loop 3
+    def _updata_for_tests(self, args, val):
+        """The updata between save_MF_weight('hat') and the transfer stage (model/transfer.py:829).  Only TESTS read what it
+        writes -- the phase-0 test of D_{t+1} and "before train transfer" -- before the updata behind the first transfer
+        epoch overwrites it (the transfer epochs read the last / hat tables, never the MF tables).  When that later updata
+        is certain (validation on, at least one transfer epoch) and the engine can queue a forward with an evaluation
+        (HipEngine.eval_submit_transferred), the forward is NOT run here: the tables count as changed, and every test
+        until the next updata queues forward + ranks on the evaluation stream.  Otherwise: updata() as the reference."""
+        eng = self.engine
+        later = (self.TR_train_sampleTYpe == 'all' or (self.TR_train_sampleTYpe == 'alone' and val is not None)) \
+            and int(args.TR_epochs) > 0
+        wu, wi = self.MFbase.user_laten.weight.data, self.MFbase.item_laten.weight.data
+        if later and self.transfer_type == 'transfer2' and hasattr(eng, "eval_submit_transferred") \
+                and eng.can_submit_transferred(wu, wi):
+            self.MFbase.eval()
+            self.transfer.eval()
+            self._pending_transfer = True
+            self._touch_tables()
+            return
+        self.updata()
+
+    def _materialise_tables(self):
+        """A deferred updata nothing overwrote (no transfer epoch ran after all): run it now."""
+        if getattr(self, "_pending_transfer", False):
+            self.updata()
+
     def updata(self):
         """W <- transfer(W_{t-1}, W_hat) over every user and item row (model/transfer.py:884-902)."""
         self.MFbase.eval()
         self.transfer.eval()
         if self.transfer_type != 'transfer2':
             raise TypeError("No such type transfer!!!")
+        self._pending_transfer = False
         t0 = time.time()
         self.engine.updata(self.transfer, self.last_user_weight, self.user_weight_hat, self.last_item_weight,
                            self.item_weight_hat, self.MFbase.user_laten.weight.data, self.MFbase.item_laten.weight.data)

@@ -66,6 +66,9 @@ class HipEngine(object):
         return st
 
     def close(self):
+        if getattr(self, "_side_ctx_h", None):
+            self.lib.sml_ctx_destroy(self._side_ctx_h)
+            self._side_ctx_h = None
         if getattr(self, "_ctx", None):
             self.lib.sml_ctx_destroy(self._ctx)
             self._ctx = None
@@ -702,6 +705,47 @@ class HipEngine(object):
                 dst[q], src[q], nbytes[q] = d.data_ptr(), s.data_ptr(), d.numel() * d.element_size()
             check(self.lib.sml_copy_tables(n, dst, src, nbytes, self._stream()), "sml_copy_tables")
 
+    def _snap_slot(self, cur):
+        """Next snapshot slot of the ring; the current stream waits (on the device) for the evaluation that last read it."""
+        ring = self.__dict__.setdefault("_snap", [])
+        k = self.__dict__.get("_snap_next", 0) % self.SNAPSHOTS
+        self._snap_next = k + 1
+        while len(ring) <= k:
+            ring.append(dict(ev=None))
+        slot = ring[k]
+        if slot["ev"] is not None:
+            cur.wait_event(slot["ev"])          # the evaluation that last read this snapshot is done (device-side wait)
+        return slot
+
+    @staticmethod
+    def _snap_buf(slot, key, like):
+        if slot.get(key) is None or slot[key].shape != like.shape:
+            slot[key] = torch.empty_like(like)
+        return slot[key]
+
+    def _side_order(self, cur, side):
+        """The side stream may start on a snapshot once the copies queued on `cur` so far are done.  Device-side ordering
+        (a flag kernel behind the copies, a polling kernel ahead of the side stream's work) instead of an event: a
+        cross-queue barrier packet cost the training stream 2-4 ms per period (31 of them), the two tiny kernels cost
+        nothing measurable."""
+        mode = __import__("os").environ.get("SML_SIDE_SYNC", "flag")
+        if mode == "event":
+            check(self.lib.sml_stream_wait_stream(ctypes.c_void_p(side.cuda_stream), ctypes.c_void_p(cur.cuda_stream)),
+                  "sml_stream_wait_stream")
+            return
+        if getattr(self, "_sync_flag", None) is None:
+            self._sync_flag = torch.zeros(2, device=self.device, dtype=torch.int32)   # [sequence, time-outs]
+            self._sync_seq = 0
+            self._sync_seen = 0           # time-outs already reported
+        self._sync_seq += 1
+        check(self.lib.sml_flag_set(_ptr(self._sync_flag), self._sync_seq, ctypes.c_void_p(cur.cuda_stream)), "sml_flag_set")
+        # The waiter starts polling as soon as the side stream is free, while its signal sits behind everything the
+        # host has already queued on the training stream (the driver runs a whole stage ahead): the time-out is a
+        # HANG GUARD, minutes not seconds (SML_FLAG_TIMEOUT_S).  A waiter that does give up is counted in flag[1]
+        # (side_sync_check); the sequence word is untouched, so later evaluations stay ordered.
+        check(self.lib.sml_flag_wait(_ptr(self._sync_flag), self._sync_seq, self._flag_timeout(),
+                                     ctypes.c_void_p(side.cuda_stream)), "sml_flag_wait")
+
     def eval_submit(self, user_tab, item_tab, rows):
         """Queue the ranks of `rows` under the tables AS THEY ARE NOW (at this point of the current stream)
         and return a handle; the caller may modify the tables right away."""
@@ -709,41 +753,66 @@ class HipEngine(object):
         rows = self._dev(rows, torch.int64)
         side = self._side_stream()
         cur = torch.cuda.current_stream(self.device)
-        ring = self.__dict__.setdefault("_snap", [])
-        k = self.__dict__.get("_snap_next", 0) % self.SNAPSHOTS
-        self._snap_next = k + 1
-        while len(ring) <= k:
-            ring.append(dict(u=None, i=None, ev=None))
-        slot = ring[k]
-        if slot["ev"] is not None:
-            cur.wait_event(slot["ev"])          # the evaluation that last read this snapshot is done (device-side wait)
-        if slot["u"] is None or slot["u"].shape != wu.shape:
-            slot["u"] = torch.empty_like(wu)
-        if slot["i"] is None or slot["i"].shape != wi.shape:
-            slot["i"] = torch.empty_like(wi)
-        self.copy_tables([(slot["u"], wu), (slot["i"], wi)])
-        # the side stream may start on the snapshot once the copies are done.  Device-side ordering (a flag kernel
-        # behind the copies, a polling kernel ahead of the rank kernel) instead of an event: a cross-queue barrier
-        # packet cost the training stream 2-4 ms per period (31 of them), the two tiny kernels cost nothing measurable
-        mode = __import__("os").environ.get("SML_SIDE_SYNC", "flag")
-        if mode == "event":
-            check(self.lib.sml_stream_wait_stream(ctypes.c_void_p(side.cuda_stream), ctypes.c_void_p(cur.cuda_stream)),
-                  "sml_stream_wait_stream")
-        else:
-            if getattr(self, "_sync_flag", None) is None:
-                self._sync_flag = torch.zeros(2, device=self.device, dtype=torch.int32)   # [sequence, time-outs]
-                self._sync_seq = 0
-                self._sync_seen = 0           # time-outs already reported
-            self._sync_seq += 1
-            check(self.lib.sml_flag_set(_ptr(self._sync_flag), self._sync_seq, ctypes.c_void_p(cur.cuda_stream)), "sml_flag_set")
-            # The waiter starts polling as soon as the side stream is free, while its signal sits behind everything the
-            # host has already queued on the training stream (the driver runs a whole stage ahead): the time-out is a
-            # HANG GUARD, minutes not seconds (SML_FLAG_TIMEOUT_S).  A waiter that does give up is counted in flag[1]
-            # (side_sync_check); the sequence word is untouched, so later evaluations stay ordered.
-            check(self.lib.sml_flag_wait(_ptr(self._sync_flag), self._sync_seq, self._flag_timeout(),
-                                         ctypes.c_void_p(side.cuda_stream)), "sml_flag_wait")
+        slot = self._snap_slot(cur)
+        su, si = self._snap_buf(slot, "u", wu), self._snap_buf(slot, "i", wi)
+        self.copy_tables([(su, wu), (si, wi)])
+        self._side_order(cur, side)
         with torch.cuda.stream(side):
-            ranks = self.eval_ranks(slot["u"], slot["i"], rows, max_workgroups=self._side_eval_cap())
+            ranks = self.eval_ranks(su, si, rows, max_workgroups=self._side_eval_cap())
+            ev = torch.cuda.Event()
+            ev.record(side)
+        slot["ev"] = ev
+        rows.record_stream(side)
+        return dict(ranks=ranks, event=ev, n=rows.shape[0])
+
+    # A table-sized forward whose ONLY reader is an evaluation does not belong on the training stream either.  The
+    # reference calls updata() ahead of every validation (model/transfer.py:737-739, 829-833); the one ahead of the "before
+    # train transfer" test is overwritten by the next updata before any training kernel reads the tables: 10 of a period's
+    # 21 table-sized forwards, 5 ms of its 110.  eval_submit_transferred snapshots what that forward READS (the four tables
+    # and theta, one copy launch) and queues the forward itself, into the snapshot slot's own tables, ahead of the rank pass on
+    # the evaluation stream's CUs.  Same kernels, same rows, same bits -- the tables the caller holds are not written.
+    TRANSFERRED_MAX_BYTES = int(__import__("os").environ.get("SML_TRANSFERRED_MAX_BYTES", str(24 << 30)))   # ring budget
+
+    def can_submit_transferred(self, user_tab, item_tab):
+        """Whether the ring's six table copies per slot fit the budget (config-4-sized tables keep the in-place order)."""
+        if __import__("os").environ.get("SML_EVAL_TRANSFERRED", "1") == "0":
+            return False
+        per_slot = 3 * (user_tab.numel() + item_tab.numel()) * 4
+        return per_slot * self.SNAPSHOTS <= self.TRANSFERRED_MAX_BYTES
+
+    def _side_ctx(self):
+        """A second library context for forwards on the side stream: its own MFMA operand images (the training context's
+        are being stepped in place by the Adam kernels of the stream this does not wait for)."""
+        if getattr(self, "_side_ctx_h", None) is None:
+            h = ctypes.c_void_p()
+            check(self.lib.sml_ctx_create(ctypes.byref(h), self.device.index or 0, self.d, 1024), "sml_ctx_create")
+            self._side_ctx_h, self._side_variant = h, 0
+        if self._side_variant != getattr(self, "_variant", 0):
+            check(self.lib.sml_ctx_set_variant(self._side_ctx_h, getattr(self, "_variant", 0)), "sml_ctx_set_variant")
+            self._side_variant = getattr(self, "_variant", 0)
+        return self._side_ctx_h
+
+    def eval_submit_transferred(self, transfer, last_user, hat_user, last_item, hat_item, rows):
+        """Queue the ranks of `rows` under the tables updata(transfer, last_*, hat_*) WOULD produce now, without producing
+        them on the current stream.  Returns a handle like eval_submit; the caller may modify all five inputs right away."""
+        theta = self._select(transfer)
+        tabs = [self._table(t) for t in (last_user, hat_user, last_item, hat_item)]
+        rows = self._dev(rows, torch.int64)
+        side = self._side_stream()
+        cur = torch.cuda.current_stream(self.device)
+        slot = self._snap_slot(cur)
+        snaps = [self._snap_buf(slot, k, t) for k, t in zip(("lu", "hu", "li", "hi"), tabs)]
+        su, si = self._snap_buf(slot, "u", tabs[0]), self._snap_buf(slot, "i", tabs[2])
+        sth = self._snap_buf(slot, "theta", theta)
+        self.copy_tables(list(zip(snaps, tabs)))
+        sth.copy_(theta)
+        self._side_order(cur, side)
+        ctx = self._side_ctx()
+        with torch.cuda.stream(side):
+            for net, (xt, xh, out) in enumerate(((snaps[0], snaps[1], su), (snaps[2], snaps[3], si))):
+                check(self.lib.sml_transfer_forward(ctx, _ptr(sth), net, _ptr(xt), _ptr(xh), _ptr(out), xt.shape[0],
+                                                    self._stream()), "sml_transfer_forward")
+            ranks = self.eval_ranks(su, si, rows, max_workgroups=self._side_eval_cap())
             ev = torch.cuda.Event()
             ev.record(side)
         slot["ev"] = ev

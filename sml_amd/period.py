@@ -158,6 +158,23 @@ def run_period(engine, st, plan, hp, record=None, overlap=True, exchanges=None):
         engine.updata(net, st.last_user, st.hat_user, st.last_item, st.hat_item, wu, wi)
         state["version"] += 1
 
+    # An updata whose output only an evaluation reads (the next updata overwrites it before any training kernel looks at
+    # the tables) is queued WITH that evaluation on the evaluation stream (engine.eval_submit_transferred): the tables
+    # this period holds are not written, the numbers are the same.
+    transferred_ok = (overlap and plan.val_rows is not None and hasattr(engine, "eval_submit_transferred")
+                      and engine.can_submit_transferred(wu, wi))
+
+    def evaluate_transferred(tag):
+        pending = engine.eval_metrics_submit(
+            engine.eval_submit_transferred(net, st.last_user, st.hat_user, st.last_item, st.hat_item, plan.val_rows), hp.topK)
+        box = {}
+
+        def res(pending=pending, box=box):
+            if "v" not in box:
+                box["v"] = engine.eval_result(pending)
+            return box["v"]
+        notes.append((tag, res))
+
     # save_MF_weight('last')
     copy = engine.copy_tables if hasattr(engine, "copy_tables") else (lambda pairs: [d.copy_(s) for d, s in pairs])
     copy([(st.last_user, wu), (st.last_item, wi)])
@@ -180,9 +197,13 @@ def run_period(engine, st, plan, hp, record=None, overlap=True, exchanges=None):
         # save_MF_weight('hat')
         copy([(st.prev_hat_user, st.hat_user), (st.prev_hat_item, st.hat_item)])
         copy([(st.hat_user, wu), (st.hat_item, wi)])
-        updata()
-        evaluate("before TR")
-        for tri in plan.tr_triples[ph]:
+        n_tr = len(plan.tr_triples[ph])
+        if transferred_ok and n_tr > 0:
+            evaluate_transferred("before TR")         # (the updata after the first TR epoch overwrites what this one would write)
+        else:
+            updata()
+            evaluate("before TR")
+        for k_tr, tri in enumerate(plan.tr_triples[ph]):
             if isinstance(tri, RoutedEpoch):
                 tr_loss = engine.tr_stage_epoch(net, st.last_user, st.last_item, st.hat_user, st.hat_item, tri.local_tri,
                                                 tri.cap, hp.TR_lr, hp.TR_l2, bce=True, plan=tri.plan)
@@ -190,8 +211,11 @@ def run_period(engine, st, plan, hp, record=None, overlap=True, exchanges=None):
                 tr_loss = engine.tr_stage_epoch(net, st.last_user, st.last_item, st.hat_user, st.hat_item, tri,
                                                 hp.TR_batch_size, hp.TR_lr, hp.TR_l2, bce=True)
             if plan.val_rows is not None:
-                updata()
-                evaluate("TR epoch")
+                if transferred_ok and k_tr + 1 < n_tr:
+                    evaluate_transferred("TR epoch")
+                else:
+                    updata()
+                    evaluate("TR epoch")
     updata()
     if record is not None and plan.val_rows is not None:
         n = plan.val_rows.shape[0]

@@ -753,6 +753,40 @@ def test_period_validation_overlap_and_cache_do_not_change_results():
     assert outs[1][0][4][1:] == outs[1][0][3][1:]
 
 
+def test_evaluation_with_its_table_sized_forward_queued_on_the_side_stream():
+    """HipEngine.eval_submit_transferred (round 4): the ranks under the tables updata() WOULD write -- forward and rank pass
+    queued on the evaluation stream over snapshots of the four input tables and theta -- equal updata() + eval_ranks in place,
+    bit for bit; the caller's tables are not written, and inputs overwritten right after the call (more submissions than the
+    ring has slots) do not reach the queued work."""
+    eng = engine(32, 256)
+    U, I, n = 3000, 2500, 4000
+    g = torch.Generator(device=DEV).manual_seed(8)
+    net = make_transfer(32, device=DEV)
+    rows = torch.cat([torch.randint(0, U, (n, 1), device=DEV, generator=g), torch.randint(0, I, (n, 101), device=DEV, generator=g)], 1)
+    tabs = lambda: [torch.randn(r, 32, device=DEV, generator=g) * 0.3 for r in (U, U, I, I)]
+    theta = eng.adopt(net)
+    want, handles = [], []
+    with eng.partition():
+        for k in range(eng.SNAPSHOTS + 2):
+            lu, hu, li, hi = tabs()
+            wu, wi = torch.zeros(U, 32, device=DEV), torch.zeros(I, 32, device=DEV)
+            eng.updata(net, lu, hu, li, hi, wu, wi)
+            want.append(eng.eval_ranks(wu, wi, rows).clone())
+            keep_u, keep_i = wu.clone(), wi.clone()
+            saved = theta.clone()
+            handles.append(eng.eval_submit_transferred(net, lu, hu, li, hi, rows))
+            assert torch.equal(wu, keep_u) and torch.equal(wi, keep_i)          # nothing of the caller's is written
+            for t in (lu, hu, li, hi):
+                t.normal_(generator=g)                                             # inputs reused at once
+            theta.mul_(1.0 + 0.01 * (k + 1))                                      # ... theta stepped (next evaluation: another net)
+            assert not torch.equal(theta, saved)
+    torch.cuda.synchronize()
+    eng.side_sync_check()
+    for w, h in zip(want, handles):
+        assert torch.equal(w, h["ranks"])
+    assert len({int(w.sum()) for w in want}) > 1                                  # (the evaluations did differ from one another)
+
+
 def test_bare_step_hot_rows_vs_oracle():
     """Large batch with Zipf-style hot rows: an item with ~3,000 occurrences (as positive and as
     negative) and a user with ~700 in one 8,192-triple batch go through the hot-row path
