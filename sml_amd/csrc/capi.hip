@@ -155,6 +155,8 @@ struct IndexSet {
     Buf<int> hot_count;                // [nb]
     int hot_cap = 0;                   // 0: the hot-row path is off for this epoch's batch size
     Buf<uint8_t> uniq;
+    Buf<uint32_t> slot_info;           // records mode, by hand: per slot, "once" or the position of its run's record (SmlFusedUpdate)
+    int64_t slot_stride = 0;           // ... slots per batch; 0: this set has none
     Buf<int> off_u, off_i, n_sel;
     // index_prep.hip (the by-hand preparation): tile histograms, bucket offsets / counts, run counts, oversized buckets
     Buf<uint32_t> hist_u, hist_i, bko_u, bko_i, bkc_u, bkc_i, large, medium;
@@ -174,7 +176,7 @@ struct IndexSet {
         rec_u.release(); rec_i.release(); runs_u.release(); runs_i.release();
         hist_u.release(); hist_i.release(); bko_u.release(); bko_i.release(); bkc_u.release(); bkc_i.release(); large.release(); medium.release();
         cnt_u.release(); cnt_i.release(); stage_u.release(); stage_i.release(); rank_viol.release();
-        uniq.release(); heads_u.release(); heads_i.release(); hot_list.release(); hot_count.release(); off_u.release(); off_i.release(); n_sel.release();
+        uniq.release(); slot_info.release(); heads_u.release(); heads_i.release(); hot_list.release(); hot_count.release(); off_u.release(); off_i.release(); n_sel.release();
         cub_tmp.release();
         if (max_len_host) { g_graveyard.park_host(max_len_host); max_len_host = nullptr; }
         if (ready) { (void)hipEventDestroy(ready); ready = nullptr; }
@@ -196,6 +198,7 @@ struct sml_ctx {
     Buf<float> cstate;       // [2 parities][2 nets][3][SML_CG]: the conv parameters' working copy of a TR epoch (deferred conv step)
     int pk_set = 0;          // which of the two operand-image sets is current
     Buf<int> arrive;         // k_tr_wgrad2's tail-workgroup arrival counter (0 between launches)
+    Buf<int> run_arrive;     // MF stage, fused row update: per-run arrival counters of a batch (0 between launches)
     // Adam schedule of the MF optimiser
     Buf<SmlSched> sched;
     int sched_len = 0;
@@ -231,7 +234,7 @@ struct sml_ctx {
         prof.release();
         out.release(); dout.release(); dx.release(); xin.release(); z1.release(); a1.release(); a2.release(); dz1.release();
         mrep.release(); vrep.release();
-        pk.release(); grad.release(); convg.release(); loss_part.release(); arrive.release(); cstate.release();
+        pk.release(); grad.release(); convg.release(); loss_part.release(); arrive.release(); run_arrive.release(); cstate.release();
         ix[0].release(); ix[1].release();
         sched.release(); dummy.release(); rec_x.release();
         for (auto& r : sched_retired) { g_graveyard.park(r.dev); g_graveyard.park_host(r.host); (void)hipEventDestroy(r.done); }
@@ -467,7 +470,7 @@ int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
                bool dups, hipStream_t st, const sml_batch_plan* plan, int mode = 0, const sml_bare_exchange* bx = nullptr,
                const sml_bare_shard* sh = nullptr, int64_t rows_cap = 0) {
     const int64_t nb = plan ? plan->n_batches : (n + batch - 1) / batch;
-    c->by_hand = true;
+    c->by_hand = true; c->slot_stride = 0;
     if (n == 0) { c->n = 0; c->batch = batch; c->triples = tri; return SML_OK; }
     const int W = mode == 1 ? bx->world : (mode == 2 ? sh->world : 1);
     const int nis = 2 * W;                                  // item streams per tile
@@ -515,6 +518,11 @@ int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
         HIPCHK(c->cnt_u.ensure((size_t)(nb + 1) * SML_PREP_CNT_STRIDE)); HIPCHK(c->cnt_i.ensure((size_t)(nb + 1) * SML_PREP_CNT_STRIDE));
     } else {
         HIPCHK(c->rec_u.ensure((size_t)n)); HIPCHK(c->rec_i.ensure((size_t)2 * n));
+        if (mode == 0) {          // every slot learns where its run's record is (the MF stage's fused row update)
+            c->slot_stride = ioff_max + 2 * (int64_t)batch;
+            HIPCHK(c->slot_info.ensure((size_t)nb * c->slot_stride));
+            a.slot_info = c->slot_info.p; a.slot_stride = c->slot_stride;
+        }
     }
     for (int T = 0; T < 2; ++T) {
         SmlPrepTable& t = a.t[T];
@@ -578,7 +586,7 @@ int sort_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
                bool dups, hipStream_t st, const sml_batch_plan* plan = nullptr, const sml_bare_exchange* bx = nullptr) {
     // bx (bare step on several GPUs): the item lists are the JOB's -- every rank's 2n item occurrences
     if (prep_by_hand() && (!bx || dups)) return prep_epoch(c, tri, n, batch, pad_tiles, n_user, n_item, dups, st, plan, bx ? 1 : 0, bx);
-    c->by_hand = false;
+    c->by_hand = false; c->slot_stride = 0;
     const int64_t n_items = bx ? (int64_t)bx->world * 2 * n : 2 * n;
     const int64_t seg_i = bx ? (int64_t)bx->world * 2 * batch : (int64_t)2 * batch;       // item occurrences of a full batch
     if (n_items > 0x7fffffff) return fail(SML_EINVAL, "index preparation", "too many item occurrences in one epoch");
@@ -880,6 +888,14 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
     HIPCHK(hipMemsetAsync(ctx->loss_part.p, 0, (size_t)nb * lstride * sizeof(float), st));
     const int64_t ns = sml_net_size(d), ps = sml_pk_size(d);
     float* dx_buf = xchg ? xchg->dx_local : ctx->dx.p;
+    // One GPU, lists built by hand, the one-workgroup-per-tile backward, a row inside one wavefront (d <= 64): the backward
+    // takes the row update itself (SmlFusedUpdate) -- no third launch per batch.  SML_MF_FUSED_UPDATE=0: A/B tests.
+    const bool fused = !xchg && !bsplit && d <= 64 && ctx->adaptive_beta <= 0.0f && ctx->ix[0].by_hand && ctx->ix[0].slot_stride > 0 &&
+                       env_int("SML_MF_FUSED_UPDATE", 1) != 0;
+    if (fused && !ctx->run_arrive.p) {
+        HIPCHK(ctx->run_arrive.ensure((size_t)3 * ctx->max_batch + 8));
+        HIPCHK(hipMemsetAsync(ctx->run_arrive.p, 0, ((size_t)3 * ctx->max_batch + 8) * sizeof(int), st));
+    }
     for (int64_t b = 0; b < nb; ++b) {
         const int64_t off0 = plan ? plan->batch_off[b] : b * batch;
         const int B = plan ? (int)(plan->batch_off[b + 1] - off0) : (int)((n - off0) < batch ? (n - off0) : batch);
@@ -918,7 +934,18 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
         w.scale = (plan && plan->loss_scale) ? plan->loss_scale[b] : xchg ? xchg->loss_scale : 1.0f;
         w.loss_part = ctx->loss_part.p + b * lstride;
         w.out_np = fns; w.out_pstride = out_pstride;
+        if (fused) {
+            SmlFusedUpdate& fu = w.fu;
+            fu.slot_info = ctx->ix[0].slot_info.p + b * ctx->ix[0].slot_stride;
+            fu.rec[0] = ctx->ix[0].rec_u.p + off0; fu.rec[1] = ctx->ix[0].rec_i.p + 2 * off0;
+            fu.val[0] = ctx->ix[0].val_u2.p; fu.val[1] = ctx->ix[0].val_i2.p;
+            fu.arrive = ctx->run_arrive.p; fu.dx_all = dx_buf; fu.tri = tri;
+            fu.w[0] = (float*)t->w_user; fu.w[1] = (float*)t->w_item; fu.m[0] = t->m_user; fu.m[1] = t->m_item;
+            fu.v[0] = t->v_user; fu.v[1] = t->v_item; fu.last[0] = t->step_user; fu.last[1] = t->step_item;
+            fu.mrep = ctx->mrep.p; fu.vrep = ctx->vrep.p; fu.sched = ctx->sched.p; fu.cur_step = cur;
+        }
         ctx->prof.begin(PC_BWD, st); HIPCHK(sml_launch_bwd(d, bsplit, w, tiles, st)); ctx->prof.end(st);
+        if (fused) continue;                  // (the backward stepped the rows)
         if (ctx->adaptive_beta > 0.0f) {      // --need_adaptive: the users' norm term joins their gradient rows and the batch's loss
             ctx->prof.begin(PC_MISC, st);
             HIPCHK(sml_launch_adaptive_users(d, ctx->xin.p, dx_buf, B, ctx->adaptive_beta, w.loss_part, st));

@@ -411,6 +411,7 @@ __device__ __forceinline__ uint32_t emit_bucket(const SmlPrepArgs& a, const SmlP
     // writes them there -- no staging array, no compaction pass.  The ORDER of the buckets inside a batch's list is then
     // whatever order they arrive in: nothing depends on it (every run is one row, summed in its own fixed slot order).
     SmlRun* out = tb.runs;
+    const uint32_t list0 = (uint32_t)(tb.lmul * batch_geo(a, b).start);      // first position of the batch's list
     uint32_t done = 0;                                            // compact records of earlier trips (block-uniform)
     if (!a.records) {
         uint32_t mine = 0;
@@ -453,8 +454,10 @@ __device__ __forceinline__ uint32_t emit_bucket(const SmlPrepArgs& a, const SmlP
             if (uniq) uniq[val] = 0;
         }
         // the run's record is written by its LAST occurrence, which looks its first one up in the sorted bucket
+        // (records mode with slot_info: EVERY occurrence looks it up -- its slot is told where the run's record is)
+        const bool tell = a.records && a.slot_info != nullptr && in;
         int hq = q, len = 0;
-        if (tail) {
+        if (tail || tell) {
             if (!head) {
                 int back = 1;
                 while (back <= 4 && q - back >= 0 && ent_hi<E>(get(q - back), vb) == rh) ++back;
@@ -465,8 +468,9 @@ __device__ __forceinline__ uint32_t emit_bucket(const SmlPrepArgs& a, const SmlP
                     hq = lo;
                 }
             }
-            len = q - hq + 1;
+            if (tail) len = q - hq + 1;
         }
+        if (tell) a.slot_info[(int64_t)b * a.slot_stride + val] = (head && tail) ? SML_SLOT_ONCE : (pos0 + (uint32_t)hq - list0);
         const bool want = (a.records || tb.allruns) ? tail : (tail && len >= 2);
         uint32_t idx;
         if (!a.records) {

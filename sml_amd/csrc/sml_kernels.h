@@ -57,8 +57,33 @@ struct SmlBwdSeg {
     float* dz1;              // TR stage: [n_rows, 512]; null in MF stage
     int n_rows;
 };
+// One run of equal keys in a sorted occurrence list: `len` occurrences of table row `row` at
+// sorted positions pos .. pos+len-1 (len = 0: this position does not start a run).  The slots
+// (gradient-row indices) of the first SML_RUN_INL occurrences ride in the record, so the common
+// short run needs no second index load.
+#define SML_RUN_INL 4
+struct __attribute__((aligned(16))) SmlRun { uint32_t row, pos, len, pad; uint32_t slot[SML_RUN_INL]; };
+#define SML_SLOT_ONCE 0x80000000u
+// MF stage, one GPU, index lists built by index_prep.hip: the row update (k_run_update<Adam>) is taken by the backward itself.
+// A row that occurs ONCE in the batch (slot_info) is stepped by the threads that hold its gradient, from the forward's replayed
+// copies (xin row 1, mrep, vrep).  An occurrence of a duplicated row leaves its gradient row (write-through), bumps the run's
+// arrival counter, and the LAST arriver adds the run's rows -- in slot order, with k_run_update's own summation order, so the
+// result is the same bits whichever kernel takes the step -- and steps the row.  slot_info == null: off (dx rows are left
+// for k_run_update).
+struct SmlFusedUpdate {
+    const uint32_t* slot_info;                 // this batch's [ioff + 2B]
+    const SmlRun* rec[2];                      // this batch's records (users, items), one per sorted position
+    const uint32_t* val[2];                    // whole-epoch sorted value lists (SmlRun.pos indexes them)
+    int* arrive;                               // [B] + [2B] arrival counters (zero between launches)
+    float* dx_all;                             // gradient rows by slot (users at 0, items at ioff)
+    const int64_t* tri;                        // this batch's triples
+    float* w[2]; float* m[2]; float* v[2]; int32_t* last[2];
+    const float* mrep; const float* vrep;      // by slot, like dx_all
+    const SmlSched* sched; int cur_step;
+};
 struct SmlBwdArgs {
     SmlBwdSeg seg[2];
+    SmlFusedUpdate fu;
     int tiles0;
     float l2;
     // the pair loss is evaluated here: out rows of the whole batch (u' at t, i' at ioff+t, n' at ioff+B+t)
@@ -150,12 +175,6 @@ hipError_t sml_launch_adaptive_users(int d, const float* xin, float* dx, int B, 
 hipError_t sml_launch_loss_finalize(const float* part, int n_batches, int stride, const int* counts,
                                     float* out, hipStream_t st);
 
-// One run of equal keys in a sorted occurrence list: `len` occurrences of table row `row` at
-// sorted positions pos .. pos+len-1 (len = 0: this position does not start a run).  The slots
-// (gradient-row indices) of the first SML_RUN_INL occurrences ride in the record, so the common
-// short run needs no second index load.
-#define SML_RUN_INL 4
-struct __attribute__((aligned(16))) SmlRun { uint32_t row, pos, len, pad; uint32_t slot[SML_RUN_INL]; };
 
 struct SmlRunArgs {
     // run records of this batch.  off_* == null: one record per sorted position (n_* of them, len 0 =
@@ -236,6 +255,10 @@ struct SmlPrepArgs {
     int64_t head_rows, shard_rows; int shard_rank;
     SmlPrepTable t[2];           // users, items
     uint8_t* uniq; int64_t uniq_stride;
+    // records mode (MF stage), optional: what every slot needs to take its row's update on its own (the fused row update of
+    // k_transfer_bwd_full): slot_info[b * slot_stride + value] = SML_SLOT_ONCE if the row occurs once in the batch, else the
+    // position (inside the batch's list) of the record of its run
+    uint32_t* slot_info; int64_t slot_stride;
     uint32_t* hot_list; int* hot_count; int hot_cap; int* max_len;
     uint32_t* medium; int* n_medium;                  // same pairs: buckets k_prep_wave leaves to k_prep_bucket
     uint32_t* large; int* n_large; int large_cap;     // (table << 31 | list), bucket -- buckets the small kernel leaves

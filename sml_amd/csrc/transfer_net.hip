@@ -601,6 +601,131 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HSEQ > 1 ? 
 }
 
 // ------------------------------------------------------------------------------------
+// MF stage: the row update inside the backward (SmlFusedUpdate; replaces the k_run_update<Adam> launch on one GPU).
+// Called by ALL threads of the workgroup for their element (row, w) of the tile's x_hat gradient `g`; x1 = the forward's
+// replayed x_hat element.  A row's D elements sit in D neighbouring lanes of ONE wavefront (D <= 64).
+//   * the row occurs once in the batch: Adam step here, from the forward's replayed moments -- k_run_update's from_scratch
+//     path element by element (same pinned arithmetic: the same bits);
+//   * duplicated row: the gradient row leaves as agent-scope (write-through) stores; once they are acknowledged the row's
+//     first lane bumps the run's arrival counter (L2-bypassing atomic); the occurrence that arrives LAST adds the run's
+//     gradient rows with cache-bypassing loads IN k_run_update's ORDER -- up to 8 rows one after the other in slot order;
+//     longer runs by the whole wavefront: 64 / (D/4) lane groups take strided shares, eight 16-byte loads in flight each,
+//     the shares meet in the same xor order -- steps the row and clears the counter for the next launch.
+// No fence: a __threadfence() here is a write-back + invalidate of the XCD's whole L2 (see k_tr_wgrad2's election).
+// ------------------------------------------------------------------------------------
+// (the loads that do not depend on the gradient are issued early by the caller where it can: FusedPre)
+struct FusedPre { uint32_t info; int64_t trow; float m, v; uint4 r0, r1; };
+template <int D>
+__device__ __forceinline__ void fused_prefetch(const SmlBwdArgs& a, int sidx, int row, int w, bool ok, FusedPre& f) {
+    const SmlFusedUpdate& fu = a.fu;
+    const int slot = (sidx ? a.ioff : 0) + row;
+    f.info = SML_SLOT_ONCE; f.trow = 0; f.m = 0.0f; f.v = 0.0f;
+    if (ok) {
+        f.info = fu.slot_info[slot];
+        const int t = (sidx && row >= a.B) ? row - a.B : row;
+        f.trow = fu.tri[(int64_t)t * 3 + (sidx ? (row >= a.B ? 2 : 1) : 0)];
+        f.m = fu.mrep[(int64_t)slot * D + w]; f.v = fu.vrep[(int64_t)slot * D + w];
+    }
+}
+// the record of a duplicated row's run (needs f.info)
+__device__ __forceinline__ void fused_prefetch_record(const SmlBwdArgs& a, int sidx, bool ok, FusedPre& f) {
+    f.r0 = make_uint4(0u, 0u, 0u, 0u); f.r1 = f.r0;
+    if (ok && f.info != SML_SLOT_ONCE) {
+        const uint4* rec = reinterpret_cast<const uint4*>(a.fu.rec[sidx] + f.info);
+        f.r0 = rec[0]; f.r1 = rec[1];
+    }
+}
+template <int D>
+__device__ __forceinline__ void fused_row_update(const SmlBwdArgs& a, int sidx, int row, int w, bool ok, float x1, float g, const FusedPre& f) {
+    static_assert(D <= 64, "a row inside one wavefront");
+    constexpr int LPR = D / 4, G = 64 / LPR, LONG = 8, LD = 8;       // (k_run_update<D, float, 1, false>'s constants)
+    const SmlFusedUpdate& fu = a.fu;
+    const int lane = threadIdx.x & 63;
+    const int lead = lane & ~(D - 1) & 63;                            // first lane of this row
+    const bool first = (lane & (D - 1)) == 0;
+    const int slot = (sidx ? a.ioff : 0) + row;
+    const uint32_t info = f.info;
+    const int64_t trow = f.trow;
+    float m = f.m, v = f.v;
+    const SmlSched sc = fu.sched[fu.cur_step];
+    const bool dup = ok && info != SML_SLOT_ONCE;
+    bool step_it = ok && !dup, long_last = false;
+    float gsum = g;
+    uint32_t rpos = 0, rlen = 0;
+    if (dup) {
+        st_out<2>(&fu.dx_all[(int64_t)slot * D + w], g);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (the row's D stores are one instruction of this wavefront)
+        const uint4 r0 = f.r0, r1 = f.r1;
+        rpos = r0.y; rlen = r0.z;
+        int* cnt = fu.arrive + (sidx ? a.B : 0) + info;
+        int old = 0;
+        if (first) old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = __shfl(old, lead, 64);
+        if (old == (int)rlen - 1) {                                   // every other occurrence's row is in memory
+            if (first) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (rlen <= (uint32_t)LONG) {
+                const uint32_t* vals = fu.val[sidx] + rpos;
+                const uint32_t inl[4] = {r1.x, r1.y, r1.z, r1.w};
+                float x[LONG];
+#pragma unroll
+                for (int j = 0; j < LONG; ++j) {
+                    x[j] = 0.0f;
+                    if ((uint32_t)j < rlen) {
+                        const uint32_t sl = j < SML_RUN_INL ? inl[j < SML_RUN_INL ? j : 0] : vals[j];
+                        x[j] = __hip_atomic_load(&fu.dx_all[(int64_t)sl * D + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                gsum = 0.0f;
+#pragma unroll
+                for (int j = 0; j < LONG; ++j) if ((uint32_t)j < rlen) gsum += x[j];
+                step_it = true;
+            } else {
+                long_last = true;
+            }
+        }
+    }
+    // long runs: the whole wavefront, one run after the other (all 64 lanes are here: the caller's loop is workgroup-uniform)
+    unsigned long long todo = __ballot(long_last && first);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const uint32_t l_pos = (uint32_t)__shfl((int)rpos, leader, 64), l_len = (uint32_t)__shfl((int)rlen, leader, 64);
+        const uint32_t* vals = fu.val[sidx] + l_pos;
+        const int grp = lane / LPR, sub = lane % LPR;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (uint32_t q0 = (uint32_t)grp; q0 < l_len; q0 += LD * G) {
+            const float* src[LD];
+#pragma unroll
+            for (int j = 0; j < LD; ++j) {
+                const uint32_t sl = q0 + j * G < l_len ? vals[q0 + j * G] : 0u;      // (clamped address, skipped below)
+                src[j] = fu.dx_all + (int64_t)sl * D + sub * 4;
+            }
+            f32x4 x[LD];
+            peer_load16x8(x, src);
+#pragma unroll
+            for (int j = 0; j < LD; ++j) if (q0 + j * G < l_len) acc += x[j];
+        }
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] += __shfl_xor(acc[q], off, 64);
+        // element w of the sum sits in component w & 3 of the lanes with sub == w >> 2
+        const float e0 = __shfl(acc[0], w >> 2, 64), e1 = __shfl(acc[1], w >> 2, 64), e2 = __shfl(acc[2], w >> 2, 64), e3 = __shfl(acc[3], w >> 2, 64);
+        if (long_last && lead == leader) {
+            gsum = (w & 3) == 0 ? e0 : (w & 3) == 1 ? e1 : (w & 3) == 2 ? e2 : e3;
+            step_it = true;
+        }
+    }
+    if (step_it) {
+        float p = x1;
+        adam_apply(p, m, v, gsum, sc);
+        const int64_t o = trow * D + w;
+        fu.w[sidx][o] = p; fu.m[sidx][o] = m; fu.v[sidx][o] = v;
+        if (first) fu.last[sidx][trow] = fu.cur_step;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // backward, one workgroup per row tile (batches large enough to fill the chip without the
 // coordinate split below): dOut -> (MF stage) dx_hat + l2*x_hat, or (TR stage) dZ1 rows +
 // conv-grad partials.  dx / dz1 scratch is padded to whole tiles (unconditional stores).
@@ -727,6 +852,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const float* x = sg.xin + (int64_t)(row0 + tid / D) * 3 * D;
         x0p = x[tid % D]; x1p = x[D + tid % D]; x2p = x[2 * D + tid % D];
     }
+    // MF stage, fused row update: what the step needs besides the gradient is on its way from here
+    constexpr bool FUSABLE = !TR && D <= 64;
+    const bool fused = FUSABLE && a.fu.slot_info != nullptr;           // (kernel-uniform)
+    FusedPre fpre;
+    fpre.info = SML_SLOT_ONCE; fpre.trow = 0; fpre.m = fpre.v = 0.0f; fpre.r0 = make_uint4(0u, 0u, 0u, 0u); fpre.r1 = fpre.r0;
+    if constexpr (FUSABLE && PRELOAD) {
+        if (fused) fused_prefetch<D>(a, sidx, row0 + tid / D, tid % D, row0 + tid / D < sg.n_rows, fpre);
+    }
     __syncthreads();
     TL(2);
     // ---- dA2[R x 512] = dOut[R x D] * W2 ; dZ1 = dA2 * Gelu'(z1) ; wave wv owns column tiles 4wv..4wv+3
@@ -757,6 +890,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     if (TR) dz1[(int64_t)(row0 + r) * SML_HID + n] = dz;
                 }
         }
+    }
+    if constexpr (FUSABLE && PRELOAD) {
+        if (fused) fused_prefetch_record(a, sidx, row0 + tid / D < sg.n_rows, fpre);      // (slot_info arrived under the first product)
     }
     __syncthreads();
     TL(3);
@@ -814,8 +950,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             dh1p[c] = s * sml_gelu_grad(p.h1p[c]);
             dxh += dh1p[c] * cws[SML_OFF_C1W + c * 3 + 1];
         }
-        if (!TR) {
-            st_out<SML_WT_MFB>(&sg.dx[(int64_t)row * D + w], dxh + a.l2 * x1);
+        if constexpr (!TR) {
+            if constexpr (D <= 64) {
+                if (fused) {
+                    if constexpr (!PRELOAD) { fused_prefetch<D>(a, sidx, row, w, ok, fpre); fused_prefetch_record(a, sidx, ok, fpre); }
+                    fused_row_update<D>(a, sidx, row, w, ok, x1, dxh + a.l2 * x1, fpre);
+                } else st_out<SML_WT_MFB>(&sg.dx[(int64_t)row * D + w], dxh + a.l2 * x1);
+            } else {
+                st_out<SML_WT_MFB>(&sg.dx[(int64_t)row * D + w], dxh + a.l2 * x1);
+            }
             if (ok) lsum += 0.5f * a.l2 * x1 * x1;      // + l2 * 0.5 * sum(x_hat^2), model/transfer.py:486-488
         }
         if constexpr (TR) {

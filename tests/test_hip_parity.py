@@ -753,6 +753,53 @@ def test_period_validation_overlap_and_cache_do_not_change_results():
     assert outs[1][0][4][1:] == outs[1][0][3][1:]
 
 
+@pytest.mark.parametrize("case", ["yelp_batch_d32", "zipf_long_runs_d32", "ragged_d64", "forced_small_batch_d32"])
+def test_mf_stage_row_update_taken_by_the_backward_is_bit_identical(case, monkeypatch):
+    """Round 4: on one GPU the MF stage's row update is taken by the backward kernel itself (SmlFusedUpdate: rows that occur
+    once in the batch are stepped by the threads that hold their gradient; a duplicated row by the occurrence that arrives
+    last, which adds the run's gradient rows in k_run_update's own order).  SML_MF_FUSED_UPDATE=0 keeps the third launch:
+    both must leave bit-identical tables, moments, step stamps and losses -- over several epochs (lazy replay of rows a
+    batch did not touch), with runs of hundreds of occurrences (the whole-wavefront sum), a ragged last batch, d = 64."""
+    d = 64 if case.endswith("d64") else 32
+    rng = np.random.RandomState(len(case))
+    U, I, B, n = 6000, 4000, 1024, 3 * 1024 + 300
+    if case == "forced_small_batch_d32":
+        U, I, B, n = 500, 300, 160, 4 * 160 + 7
+        monkeypatch.setenv("SML_BWD_SPLIT", "0")            # the one-workgroup-per-tile backward at a batch that would split
+    u, i, j = rng.randint(0, U, n), rng.randint(0, I, n), rng.randint(0, I, n)
+    if case == "zipf_long_runs_d32":
+        i = np.minimum((rng.pareto(0.9, n) * 2).astype(np.int64), I - 1)       # a few items with hundreds of occurrences per batch
+        u[::7] = 5                                                              # ... and one user with ~150
+        j[::3] = np.minimum((rng.pareto(1.1, j[::3].size) * 3).astype(np.int64), I - 1)
+    tri = torch.from_numpy(np.stack([u, i, j], 1))
+    wu0, wi0 = rng.randn(U, d).astype(np.float32) * 0.3, rng.randn(I, d).astype(np.float32) * 0.3
+    outs = []
+    for fused in ("0", "1"):
+        monkeypatch.setenv("SML_MF_FUSED_UPDATE", fused)
+        eng = engine(d, B)
+        mf = make_mf(U, I, d, wu0, wi0, device=DEV)
+        torch.manual_seed(11)
+        net = make_transfer(d, device=DEV)
+        lu, li = T(wu0 * 0.9, DEV), T(wi0 * 0.9, DEV)
+        losses = []
+        for e in range(3):
+            sel = tri if e != 1 else tri[: n // 2]                              # epoch 1 leaves rows untouched for a while
+            losses.append(eng.mf_stage_epoch(mf, net, lu, li, sel, B, 0.01, 1e-6).cpu())
+        st = {k: v.clone() for k, v in eng.mf_state.items()}                  # moments and step stamps BEFORE the flush
+        pre = (mf.user_laten.weight.detach().clone(), mf.item_laten.weight.detach().clone())
+        eng.mf_flush(mf)
+        torch.cuda.synchronize()
+        outs.append((losses, pre, st, mf.user_laten.weight.detach().clone(), mf.item_laten.weight.detach().clone()))
+        eng.close()
+    a, b = outs
+    assert all(torch.equal(x, y) for x, y in zip(a[0], b[0]))
+    assert torch.equal(a[1][0], b[1][0]) and torch.equal(a[1][1], b[1][1])
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
+    assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    assert not torch.equal(a[3], T(wu0, DEV))
+
+
 def test_evaluation_with_its_table_sized_forward_queued_on_the_side_stream():
     """HipEngine.eval_submit_transferred (round 4): the ranks under the tables updata() WOULD write -- forward and rank pass
     queued on the evaluation stream over snapshots of the four input tables and theta -- equal updata() + eval_ranks in place,
