@@ -213,6 +213,22 @@ __device__ __forceinline__ void peer_load16x8(f32x4 (&v)[8], const float* const 
         : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
         : "memory");
 }
+// eight 4-byte agent-scope (this device's L2s bypassed) loads in flight together, complete when the call returns
+__device__ __forceinline__ void agent_load4x8(float (&v)[8], const float* const (&p)[8]) {
+    asm volatile(
+        "global_load_dword %0, %8, off sc1\n"
+        "global_load_dword %1, %9, off sc1\n"
+        "global_load_dword %2, %10, off sc1\n"
+        "global_load_dword %3, %11, off sc1\n"
+        "global_load_dword %4, %12, off sc1\n"
+        "global_load_dword %5, %13, off sc1\n"
+        "global_load_dword %6, %14, off sc1\n"
+        "global_load_dword %7, %15, off sc1\n"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+        : "memory");
+}
 __device__ __forceinline__ void peer_load16x2(f32x4 (&v)[2], const float* p0, const float* p1) {
     asm volatile(
         "global_load_dwordx4 %0, %2, off sc0 sc1\n"

@@ -664,17 +664,18 @@ __device__ __forceinline__ void fused_row_update(const SmlBwdArgs& a, int sidx, 
         if (old == (int)rlen - 1) {                                   // every other occurrence's row is in memory
             if (first) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (rlen <= (uint32_t)LONG) {
+                // all of the run's rows in ONE round trip (unconditional loads, clamped addresses; the compiler waits
+                // after every atomic load of its own)
                 const uint32_t* vals = fu.val[sidx] + rpos;
                 const uint32_t inl[4] = {r1.x, r1.y, r1.z, r1.w};
-                float x[LONG];
+                uint32_t sl[LONG];
 #pragma unroll
-                for (int j = 0; j < LONG; ++j) {
-                    x[j] = 0.0f;
-                    if ((uint32_t)j < rlen) {
-                        const uint32_t sl = j < SML_RUN_INL ? inl[j < SML_RUN_INL ? j : 0] : vals[j];
-                        x[j] = __hip_atomic_load(&fu.dx_all[(int64_t)sl * D + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
+                for (int j = 0; j < LONG; ++j) sl[j] = j < SML_RUN_INL ? inl[j < SML_RUN_INL ? j : 0] : ((uint32_t)j < rlen ? vals[j] : inl[0]);
+                const float* src[LONG];
+#pragma unroll
+                for (int j = 0; j < LONG; ++j) src[j] = fu.dx_all + (int64_t)((uint32_t)j < rlen ? sl[j] : inl[0]) * D + w;
+                float x[LONG];
+                agent_load4x8(x, src);
                 gsum = 0.0f;
 #pragma unroll
                 for (int j = 0; j < LONG; ++j) if ((uint32_t)j < rlen) gsum += x[j];
