@@ -896,8 +896,7 @@ __global__ __launch_bounds__(256) void k_adam_flush(float* __restrict__ w, float
     RowVec<float>::load(w + row * D + sub * 4, p);
     RowVec<float>::load(mt + row * D + sub * 4, m);
     RowVec<float>::load(vt + row * D + sub * 4, v);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) adam_replay_w(p[k], m[k], v[k], from, cur_step, sched, swin, cur_step);
+    adam_replay_w4(p, m, v, from, cur_step, sched, swin, cur_step);
     RowVec<float>::store(w + row * D + sub * 4, p);
     RowVec<float>::store(mt + row * D + sub * 4, m);
     RowVec<float>::store(vt + row * D + sub * 4, v);

@@ -157,6 +157,20 @@ __device__ __forceinline__ void adam_replay_w(float& p, float& m, float& v, int 
     for (int k = from + 1; k <= to; ++k) adam_zero_step(p, m, v, k >= wbase ? win[k - wbase] : sched[k]);
 }
 
+// four elements of one row at once: ONE walk over the steps (one schedule read per step, four independent chains in flight)
+// instead of four walks -- the same operations per element, so the same bits as four adam_replay_w calls.  (An element
+// with m = v = 0 needs no special case: a zero-gradient step leaves it exactly unchanged.)
+__device__ __forceinline__ void adam_replay_w4(float (&p)[4], float (&m)[4], float (&v)[4], int from, int to,
+                                               const SmlSched* __restrict__ sched, const SmlSched* win, int upto) {
+    if (from < 0) return;
+    const int wbase = upto - SML_SW + 1;
+    for (int k = from + 1; k <= to; ++k) {
+        const SmlSched s = k >= wbase ? win[k - wbase] : sched[k];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) adam_zero_step(p[e], m[e], v[e], s);
+    }
+}
+
 // ---- one-shot exchange over peer mappings: device side ------------------------------------------------------------
 // A pusher's data stores are system-scope write-through stores (on their way over xGMI while the kernel still
 // computes; nothing left dirty in this XCD's L2 for the release to walk); then fence + barrier + one counter
