@@ -655,11 +655,92 @@ __global__ __launch_bounds__(256) void k_prep_wave(SmlPrepArgs a, int T) {
 // SML_PREP_CCAP entries or SML_PREP_CDUP duplicated ones; a device whose LDS atomics failed the order probe) go onto
 // the `medium` list: k_prep_bucket's.
 // ------------------------------------------------------------------------------------
+// The three passes of one bucket with a COMPILE-TIME round count RR >= ceil(S / 64): straight-line code.  A lane beyond the
+// bucket's end loads a clamped address and counts on a spare counter (cleared again before pass 3) instead of being masked
+// off: with `if (valid)` around every round the compiler built an exec-mask block with its own vmcnt(0) per round -- one store
+// round trip per round -- and spilled two dozen masks.  Returns the number of runs (records), 0 if none / punted.
+template <typename E, int RR>
+__device__ __forceinline__ int count_bucket(const SmlPrepArgs& a, const SmlPrepTable& tb, int T, int b, uint32_t bin, const E* src, int S,
+                                            uint32_t pos0, uint32_t* cw, uint32_t* sval, unsigned short* rlist) {
+    constexpr int QT = SML_PREP_CROWS / 256;                         // counter quads per lane
+    const int lane = threadIdx.x & 63;
+    const int vb = tb.vb;
+    const int lim = S - lane;                                        // round r of this lane is inside the bucket iff r * 64 < lim
+    E e[RR];
+#pragma unroll
+    for (int r = 0; r < RR; ++r) e[r] = src[min(r * 64 + lane, S - 1)];
+    const int nd = 1 << tb.hb;
+    const int nq = (nd + 3) >> 2;                                    // counter quads in use
+    const uint32_t spare = (uint32_t)(4 * nq);
+#pragma unroll
+    for (int k = 0; k < QT; ++k) {
+        const int q = k * 64 + lane;
+        if (q < nq) *reinterpret_cast<uint4*>(cw + 4 * q) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (lane == 0) cw[spare] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    // pass 1: rank inside the row's run
+    uint32_t rk[RR];
+#pragma unroll
+    for (int r = 0; r < RR; ++r) rk[r] = atomicAdd(&cw[r * 64 < lim ? ent_hi<E>(e[r], vb) : spare], 1u);
+    __builtin_amdgcn_wave_barrier();
+    // pass 2: the duplicated rows' runs -- their bases (exclusive scan of the counts, lane-major) and their list
+    uint4 c4[QT];
+    uint32_t mine = 0;                                               // occurrences | runs << 16 of this lane's counters
+#pragma unroll
+    for (int k = 0; k < QT; ++k) {
+        const int q = k * 64 + lane;
+        c4[k] = q < nq ? *reinterpret_cast<const uint4*>(cw + 4 * q) : make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t c[4] = {c4[k].x, c4[k].y, c4[k].z, c4[k].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mine += c[j] >= 2u ? (c[j] | 0x10000u) : 0u;
+    }
+    uint32_t inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, off, 64); if (lane >= off) inc += t; }
+    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    const int ndup = (int)(tot & 0xffffu);
+    if (ndup == 0) return 0;
+    if (ndup > SML_PREP_CDUP) { if (lane == 0) prep_punt(a, T, b, bin); return 0; }
+    uint32_t run = (inc - mine) & 0xffffu, ri = (inc - mine) >> 16;
+#pragma unroll
+    for (int k = 0; k < QT; ++k) {
+        const int q = k * 64 + lane;
+        uint32_t c[4] = {c4[k].x, c4[k].y, c4[k].z, c4[k].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool dupl = c[j] >= 2u;
+            if (dupl) { rlist[ri] = (unsigned short)(4 * q + j); ++ri; }
+            const uint32_t n = dupl ? c[j] : 0u;
+            c[j] |= run << 16; run += n;
+        }
+        if (q < nq) *reinterpret_cast<uint4*>(cw + 4 * q) = make_uint4(c[0], c[1], c[2], c[3]);
+    }
+    if (lane == 0) cw[spare] = 0u;                                   // (lanes beyond the end are no run)
+    __builtin_amdgcn_wave_barrier();
+    // pass 3: duplicated occurrences to their places (LDS), then their unique marks (global stores, back to back)
+    uint32_t dmask = 0;
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+        const uint32_t w = cw[r * 64 < lim ? ent_hi<E>(e[r], vb) : spare];
+        if ((w & 0xffffu) >= 2u) {
+            sval[(w >> 16) + rk[r]] = ent_val<E>(e[r], vb);
+            dmask |= 1u << r;
+        }
+    }
+    uint8_t* uniq = a.uniq ? a.uniq + (int64_t)b * a.uniq_stride : nullptr;
+    if (uniq) {
+#pragma unroll
+        for (int r = 0; r < RR; ++r) if ((dmask >> r) & 1u) uniq[ent_val<E>(e[r], vb)] = 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < ndup; i += 64) tb.vals[pos0 + i] = sval[i];
+    return (int)(tot >> 16);
+}
+
 template <typename E>
 __global__ __launch_bounds__(256) void k_prep_count(SmlPrepArgs a, int T) {
-    constexpr int RMAX = SML_PREP_CCAP / 64;                         // rounds: entries per lane
-    constexpr int QT = SML_PREP_CROWS / 256;                         // counter quads per lane
-    __shared__ __attribute__((aligned(16))) uint32_t cw_all[4][SML_PREP_CROWS];
+    __shared__ __attribute__((aligned(16))) uint32_t cw_all[4][SML_PREP_CROWS + 4];        // (+ the spare counter of lanes beyond the bucket's end)
     __shared__ uint32_t sval_all[4][SML_PREP_CDUP];
     __shared__ unsigned short rlist_all[4][SML_PREP_CDUP / 2];       // the bucket's duplicated rows (row_hi), in run order
     __shared__ int wcnt[4];
@@ -674,7 +755,6 @@ __global__ __launch_bounds__(256) void k_prep_count(SmlPrepArgs a, int T) {
     uint32_t* cw = cw_all[wv];
     uint32_t* sval = sval_all[wv];
     unsigned short* rlist = rlist_all[wv];
-    const int vb = tb.vb;
     uint32_t pos0 = 0;
     int nrec = 0;
     do {
@@ -688,75 +768,12 @@ __global__ __launch_bounds__(256) void k_prep_count(SmlPrepArgs a, int T) {
         const BatchGeo g = batch_geo(a, b);
         pos0 = (uint32_t)(tb.lmul * g.start) + oc.x;
         const E* src = reinterpret_cast<const E*>(tb.ent) + pos0;
-        const int R = (S + 63) >> 6;
-        E e[RMAX];
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r) e[r] = (r < R && r * 64 + lane < S) ? src[r * 64 + lane] : (E)0;
-        const int nd = 1 << tb.hb;
-        const int nq = (nd + 3) >> 2;                                // counter quads in use
-#pragma unroll
-        for (int k = 0; k < QT; ++k) {
-            const int q = k * 64 + lane;
-            if (q < nq) *reinterpret_cast<uint4*>(cw + 4 * q) = make_uint4(0u, 0u, 0u, 0u);
-        }
-        __builtin_amdgcn_wave_barrier();
-        // pass 1: rank inside the row's run
-        uint32_t rk[RMAX];
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-            rk[r] = 0;
-            if (r < R && r * 64 + lane < S) rk[r] = atomicAdd(&cw[ent_hi<E>(e[r], vb)], 1u);
-        }
-        __builtin_amdgcn_wave_barrier();
-        // pass 2: the duplicated rows' runs -- their bases (exclusive scan of the counts, lane-major) and their list
-        uint4 c4[QT];
-        uint32_t mine = 0;                                           // occurrences | runs << 16 of this lane's counters
-#pragma unroll
-        for (int k = 0; k < QT; ++k) {
-            const int q = k * 64 + lane;
-            c4[k] = q < nq ? *reinterpret_cast<const uint4*>(cw + 4 * q) : make_uint4(0u, 0u, 0u, 0u);
-            const uint32_t c[4] = {c4[k].x, c4[k].y, c4[k].z, c4[k].w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) mine += c[j] >= 2u ? (c[j] | 0x10000u) : 0u;
-        }
-        uint32_t inc = mine;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, off, 64); if (lane >= off) inc += t; }
-        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-        const int ndup = (int)(tot & 0xffffu);
-        if (ndup == 0) break;
-        if (ndup > SML_PREP_CDUP) { if (lane == 0) prep_punt(a, T, b, bin); break; }
-        nrec = (int)(tot >> 16);
-        uint32_t run = (inc - mine) & 0xffffu, ri = (inc - mine) >> 16;
-#pragma unroll
-        for (int k = 0; k < QT; ++k) {
-            const int q = k * 64 + lane;
-            uint32_t c[4] = {c4[k].x, c4[k].y, c4[k].z, c4[k].w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool dupl = c[j] >= 2u;
-                if (dupl) { rlist[ri] = (unsigned short)(4 * q + j); ++ri; }
-                const uint32_t n = dupl ? c[j] : 0u;
-                c[j] |= run << 16; run += n;
-            }
-            if (q < nq) *reinterpret_cast<uint4*>(cw + 4 * q) = make_uint4(c[0], c[1], c[2], c[3]);
-        }
-        __builtin_amdgcn_wave_barrier();
-        // pass 3: duplicated occurrences to their places; unique marks
-        uint8_t* uniq = a.uniq ? a.uniq + (int64_t)b * a.uniq_stride : nullptr;
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-            if (r < R && r * 64 + lane < S) {
-                const uint32_t w = cw[ent_hi<E>(e[r], vb)];
-                if ((w & 0xffffu) >= 2u) {
-                    const uint32_t val = ent_val<E>(e[r], vb);
-                    sval[(w >> 16) + rk[r]] = val;
-                    if (uniq) uniq[val] = 0;
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < ndup; i += 64) tb.vals[pos0 + i] = sval[i];
+        // (round counts in steps: a bucket of a 1M-row table's 512 holds 1,024 +- 32 entries -- 16 or 17 rounds)
+        if (S <= 4 * 64) nrec = count_bucket<E, 4>(a, tb, T, b, bin, src, S, pos0, cw, sval, rlist);
+        else if (S <= 12 * 64) nrec = count_bucket<E, 12>(a, tb, T, b, bin, src, S, pos0, cw, sval, rlist);
+        else if (S <= 16 * 64) nrec = count_bucket<E, 16>(a, tb, T, b, bin, src, S, pos0, cw, sval, rlist);
+        else if (S <= 18 * 64) nrec = count_bucket<E, 18>(a, tb, T, b, bin, src, S, pos0, cw, sval, rlist);
+        else nrec = count_bucket<E, SML_PREP_CCAP / 64>(a, tb, T, b, bin, src, S, pos0, cw, sval, rlist);
     } while (false);
     // the four buckets take their place in the batch's run list with ONE returning atomicAdd
     if (lane == 0) wcnt[wv] = nrec;
