@@ -211,8 +211,10 @@ __global__ __launch_bounds__(1024) void k_prep_scatter_x(SmlPrepArgs a) {
         const int tile = T == 0 ? k : (s - a.has_users) * a.tpb + k;
         const uint32_t* base = tb.hist + ((int64_t)b * tb.ntile + tile) * nbk;
         __syncthreads();                                    // the previous stream's readers of cnt / tbase are done
-        if (nbk >= 2) { for (int i = tid; i < 8 * nbk; i += 1024) reinterpret_cast<uint32_t*>(&cnt[(2 * i) >> lb][0])[((2 * i) & (nbk - 1)) >> 1] = 0u; }
-        else if (tid < 16) cnt[tid][0] = 0;
+        // (all 16 counter rows in two 16-byte stores per thread: the kernel is bound by instruction issue, and clearing only the
+        // nbk counters in use of every row took 8 trips of index arithmetic)
+        reinterpret_cast<uint4*>(&cnt[0][0])[tid] = make_uint4(0u, 0u, 0u, 0u);
+        reinterpret_cast<uint4*>(&cnt[0][0])[tid + 1024] = make_uint4(0u, 0u, 0u, 0u);
         for (int i = tid; i < nbk; i += 1024) tbase[i] = base[i];
         __syncthreads();
         Occ o[IPT]; uint32_t wr[IPT];
@@ -356,13 +358,29 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
 #pragma unroll
         for (int r = 0; r < IPT; ++r) wr[r] = wave_rank(cnt[wv], row[s][r] & (uint32_t)(nbk - 1), t0 + r * 64 < g.Bb, lb, fast);
         __syncthreads();
-        uint32_t tot = 0;                                  // (thread i < nbk: bucket i's entries in this tile)
-        if (tid < nbk) {
+        if (nbk >= 2) {
+            // thread i < nbk / 2: buckets 2i and 2i + 1 as ONE dword of two 16-bit counts (a tile holds 4,096 entries: no carry
+            // between the halves) -- half the threads, half the instructions of a 16-bit walk per bucket
+            uint32_t tot2 = 0;
+            if (tid < (nbk >> 1)) {
 #pragma unroll
-            for (int w = 0; w < 16; ++w) { const uint32_t c = cnt[w][tid]; cnt[w][tid] = (unsigned short)tot; tot += c; }
+                for (int w = 0; w < 16; ++w) {
+                    uint32_t* p2 = reinterpret_cast<uint32_t*>(&cnt[w][0]) + tid;
+                    const uint32_t c2 = *p2; *p2 = tot2; tot2 += c2;
+                }
+            }
+            const uint32_t lo = tot2 & 0xffffu;
+            const uint32_t ex = block_excl_scan_1024(lo + (tot2 >> 16), wsum);       // (two barriers inside)
+            if (tid < (nbk >> 1)) { lbase[2 * tid] = ex; lbase[2 * tid + 1] = ex + lo; }
+        } else {
+            uint32_t tot = 0;                              // (one bucket: thread 0)
+            if (tid < nbk) {
+#pragma unroll
+                for (int w = 0; w < 16; ++w) { const uint32_t c = cnt[w][tid]; cnt[w][tid] = (unsigned short)tot; tot += c; }
+            }
+            const uint32_t ex = block_excl_scan_1024(tot, wsum);
+            if (tid < nbk) lbase[tid] = ex;
         }
-        const uint32_t ex = block_excl_scan_1024(tot, wsum);      // (nbk <= 1024: one bucket per thread; two barriers inside)
-        if (tid < nbk) lbase[tid] = ex;
         __syncthreads();
         const uint32_t vbase = s == 0 ? 0u : (s == 1 ? g.ioff : g.ioff + (uint32_t)g.Bb);
         uint8_t* uniq = a.uniq ? a.uniq + (int64_t)b * a.uniq_stride + vbase : nullptr;     // every mark starts at "once"
