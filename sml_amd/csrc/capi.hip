@@ -944,7 +944,19 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
             fu.v[0] = t->v_user; fu.v[1] = t->v_item; fu.last[0] = t->step_user; fu.last[1] = t->step_item;
             fu.mrep = ctx->mrep.p; fu.vrep = ctx->vrep.p; fu.sched = ctx->sched.p; fu.cur_step = cur;
         }
-        ctx->prof.begin(PC_BWD, st); HIPCHK(sml_launch_bwd(d, bsplit, w, tiles, st)); ctx->prof.end(st);
+        // several GPUs, one-shot exchange, the one-workgroup-per-tile backward: its item tiles push their rows themselves and every
+        // workgroup signals -- the grid is cut for the batch CAP (the same on every rank).  SML_PEER_PUSH_LAUNCH=1: A/B (k_peer_push)
+        const bool push_fused = mf_peers && !bsplit && !env_int("SML_PEER_PUSH_LAUNCH", 0) &&
+                                (xchg->push_rows > 0 ? xchg->push_rows : x_stride) >= 2 * (int64_t)B;
+        SmlPeerPush push_f; SmlPeerPoll poll_f;
+        int bwd_grid = tiles;
+        if (push_fused) {
+            bwd_grid = wg_tiles(batch, 1) + wg_tiles(2 * batch, 1);
+            if (bwd_grid < tiles) bwd_grid = tiles;
+            peer_step(ctx, 1, bwd_grid, &push_f, &poll_f);
+            w.push = push_f; w.tiles_live = tiles;
+        }
+        ctx->prof.begin(PC_BWD, st); HIPCHK(sml_launch_bwd(d, bsplit, w, bwd_grid, st)); ctx->prof.end(st);
         if (fused) continue;                  // (the backward stepped the rows)
         if (ctx->adaptive_beta > 0.0f) {      // --need_adaptive: the users' norm term joins their gradient rows and the batch's loss
             ctx->prof.begin(PC_MISC, st);
@@ -968,10 +980,14 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
                 const int64_t ioff = (int64_t)SML_R * tiles_of(B);
                 SmlPeerPush push; SmlPeerPoll poll;
                 const int64_t x_push = xchg->push_rows > 0 ? xchg->push_rows : x_stride;     // (the same on every rank)
-                peer_step(ctx, 1, sml_peer_push_blocks(x_push * d), &push, &poll);
                 ctx->prof.begin(PC_MISC, st);
-                HIPCHK(sml_launch_peer_push(dx_buf + ioff * d, x_push * d, push, st));
-                HIPCHK(sml_launch_peer_wait(poll, st));
+                if (push_fused) poll = poll_f;                                               // (the backward pushed and signalled)
+                else {
+                    peer_step(ctx, 1, sml_peer_push_blocks(x_push * d), &push, &poll);
+                    HIPCHK(sml_launch_peer_push(dx_buf + ioff * d, x_push * d, push, st));
+                }
+                if (env_int("SML_PEER_WAIT_LAUNCH", 0)) HIPCHK(sml_launch_peer_wait(poll, st));      // (A/B: the wait as its own launch)
+                else u.wait = poll;                                                               // ... or at the head of the row update
                 ctx->prof.end(st);
                 gathered = poll.slot0;
             } else {

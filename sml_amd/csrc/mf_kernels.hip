@@ -680,6 +680,9 @@ __global__ __launch_bounds__(256) void k_run_update(SmlRunArgs a) {
         sched_window_load(swin, a.sched, a.cur_step, threadIdx.x);
         __syncthreads();
     }
+    // several GPUs (one-shot exchange): the ranks' gradient rows have landed in this rank's inbox slots when its counters
+    // reach the step's value -- polled HERE (one lane per source rank, every workgroup) instead of by a launch of its own
+    if constexpr (OPT == 1) { if (a.wait.world > 0) peer_wait(a.wait); }
     int run_blocks = gridDim.x;
     if constexpr (OPT == 0 && HOTB) {
         // the first hot_blocks workgroups reduce the hot rows' chunks (independent of the runs below; theirs is

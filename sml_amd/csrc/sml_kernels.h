@@ -46,6 +46,24 @@ struct SmlFwdArgs {
 };
 #define SML_FWD_NS 4         // largest hidden-dimension split of the training-batch forward (planes of `out`)
 
+// ---- one-shot exchange over peer mappings (include/sml_hip.h, sml_peer_*) -------------------------------------
+// destinations of one push: rank q's slot for THIS rank's contribution and its arrival counter, for this step's parity
+struct SmlPeerPush {
+    int world;                                   // 0: off
+    float* dst[SML_MAX_PEERS];
+    unsigned long long* flag[SML_MAX_PEERS];
+};
+// sources of one poll: this rank's own slots / counters of this step's parity
+struct SmlPeerPoll {
+    int world;                                   // 0: off
+    const float* slot0; long long slot_stride;   // slot q at slot0 + q * slot_stride (floats)
+    const unsigned long long* flag0;             // [world]
+    unsigned long long expect;                   // counter value that completes this step
+    long long timeout;                           // 100 MHz ticks
+    int* err;                                    // incidents (consumers that gave up)
+    int waited;                                  // 1: a k_peer_wait launch ahead of this kernel did the waiting
+};
+
 struct SmlBwdSeg {
     const float* theta;
     const float* pk;
@@ -84,6 +102,11 @@ struct SmlFusedUpdate {
 struct SmlBwdArgs {
     SmlBwdSeg seg[2];
     SmlFusedUpdate fu;
+    // MF stage on several GPUs, one-shot exchange (k_transfer_bwd_full): the item tiles store their gradient rows straight into
+    // every rank's inbox slot (row r of this rank's 2B item rows at dst[q] + r * d) and EVERY workgroup of the launch signals --
+    // the grid is cut for the epoch's batch cap, the same on every rank, so every rank's counters grow alike; workgroups
+    // beyond tiles_live (this batch is shorter than the cap) only signal.  world 0: off (k_peer_push does it).
+    SmlPeerPush push; int tiles_live;
     int tiles0;
     float l2;
     // the pair loss is evaluated here: out rows of the whole batch (u' at t, i' at ioff+t, n' at ioff+B+t)
@@ -92,24 +115,6 @@ struct SmlBwdArgs {
     float* loss_part;        // [tiles] this batch's per-workgroup loss partials
     float* convg_part;       // TR stage: [tiles, SML_CG] per-tile compact conv1/conv2 gradient partials; else null
     int tiles_total;         // k_tr_bwd_head: row tiles of the batch (its grid is padded to the XCD map)
-};
-
-// ---- one-shot exchange over peer mappings (include/sml_hip.h, sml_peer_*) -------------------------------------
-// destinations of one push: rank q's slot for THIS rank's contribution and its arrival counter, for this step's parity
-struct SmlPeerPush {
-    int world;                                   // 0: off
-    float* dst[SML_MAX_PEERS];
-    unsigned long long* flag[SML_MAX_PEERS];
-};
-// sources of one poll: this rank's own slots / counters of this step's parity
-struct SmlPeerPoll {
-    int world;                                   // 0: off
-    const float* slot0; long long slot_stride;   // slot q at slot0 + q * slot_stride (floats)
-    const unsigned long long* flag0;             // [world]
-    unsigned long long expect;                   // counter value that completes this step
-    long long timeout;                           // 100 MHz ticks
-    int* err;                                    // incidents (consumers that gave up)
-    int waited;                                  // 1: a k_peer_wait launch ahead of this kernel did the waiting
 };
 
 struct SmlWgSeg {
@@ -196,6 +201,7 @@ struct SmlRunArgs {
     const float* rep_x; const float* rep_m; const float* rep_v; int rep_u, rep_i;
     int rep_x_stride, rep_x_off;   // the replayed row of slot s starts at rep_x[s * rep_x_stride + rep_x_off]
     float lr;                                                     // SGD only
+    SmlPeerPoll wait;        // several GPUs, one-shot exchange: every workgroup first waits for the ranks' gradient rows (world 0: off)
     // hot rows (SGD, large batches): runs longer than SML_HOT are listed here (by the index preparation)
     // instead of being summed by one wavefront; the first hot_blocks workgroups of the run kernel reduce
     // their chunks and k_hot_apply finishes them.  null: off.

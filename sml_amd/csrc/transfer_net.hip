@@ -761,6 +761,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int sidx = (int)blockIdx.x >= a.tiles0;
     const SmlBwdSeg& sg = a.seg[sidx];
     const int row0 = ((int)blockIdx.x - (sidx ? a.tiles0 : 0)) * R;
+    if constexpr (!TR) {
+        if (a.push.world > 0 && (int)blockIdx.x >= a.tiles_live) { peer_signal(a.push); return; }     // (a batch shorter than the cap)
+    }
     if (tid < 104) cws[tid] = sg.theta[tid];
     // both GEMMs' first operand k-steps are on their way before the pair loss starts (they depend on theta alone)
     constexpr bool PREB = false && (MT == 1) && (D <= 64);                // (same measurement: no gain)
@@ -960,6 +963,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             } else {
                 st_out<SML_WT_MFB>(&sg.dx[(int64_t)row * D + w], dxh + a.l2 * x1);
             }
+            if (a.push.world > 0 && sidx && ok) {                    // several GPUs: the row also goes into every rank's inbox
+                for (int q = 0; q < a.push.world; ++q) peer_store(a.push.dst[q] + (int64_t)row * D + w, dxh + a.l2 * x1);
+            }
             if (ok) lsum += 0.5f * a.l2 * x1 * x1;      // + l2 * 0.5 * sum(x_hat^2), model/transfer.py:486-488
         }
         if constexpr (TR) {
@@ -1033,6 +1039,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         a.loss_part[blockIdx.x] = s;
         TL(7);
     }
+    if constexpr (!TR) { if (a.push.world > 0) peer_signal(a.push); }       // this workgroup's rows are acknowledged: +1 on every rank's counter
     TL_DONE();
 }
 
