@@ -374,14 +374,19 @@ def build_state(engine, U, I, d, device, seed):
     return PeriodState(mf, net)
 
 
-def kernel_work(name, a, hp, U_local):
+def kernel_work(name, a, hp, U_local, side_forwards=0):
     """Algorithmic work of one period per kernel class: (bound, unit_work_total, launches_expected).
-    Bytes for HBM-bound kernels, FLOP for the MFMA-bound ones."""
+    Bytes for HBM-bound kernels, FLOP for the MFMA-bound ones.
+    side_forwards: table-sized forward LAUNCHES that ran on the evaluation stream under their own class
+    (k_side_transfer_fwd: two per evaluation-only updata) -- their rows are that class's, not k_transfer_fwd's."""
     d, n = a.d, a.inter
     nb_mf = -(-n // hp.MF_batch_size)
     nb_tr = -(-n // hp.TR_batch_size)
     evals = 0 if a.no_val else hp.multi_num * (2 + hp.MF_epochs + hp.TR_epochs)
     n_updata = hp.multi_num * (1 + (hp.TR_epochs if not a.no_val else 0)) + 1
+    if name == "k_side_transfer_fwd":
+        return "mfma", (side_forwards / 2.0) * (U_local + a.items) * 6304.0 * d, side_forwards
+    n_updata -= side_forwards / 2.0
     rows_fwd = hp.multi_num * (hp.MF_epochs + hp.TR_epochs) * 3 * n + n_updata * (U_local + a.items)
     f_row = 6304.0 * d                      # conv prologue + fc1 + fc2 forward, FLOP per row
     b_row = (2.0 * d * 512 + 2.0 * 512 * 5 * d) + 160.0 * d   # dA2 + dA1 GEMMs + per-coordinate tail
@@ -710,22 +715,26 @@ def main():
         with engine.partition():
             run_period(engine, st, plans[0], hp, overlap=not a.no_overlap, exchanges=exchanges)
         torch.cuda.synchronize(device)
-        prof = engine.profile_read()
+        prof = engine.profile_read()                 # every launch of the period, on the stream it was launched on
+        prof_main = engine.profile_read("main")       # ... the training stream's alone (the evaluation-only forwards run beside it)
         engine.profile(False)
         empty_pair_us = engine.profile_pair_overhead()
         if prof and rank == 0:
             # the evaluations run throttled (256 workgroups) on a low-priority side stream underneath the
             # training kernels: their span is not on the critical path, so the roofline object describes
             # the kernel class that dominates the TRAINING stream
-            dom = max(((k, v) for k, v in prof.items() if k != "k_eval_ranks"), key=lambda kv: kv[1][1])
+            # (k_side_transfer_fwd: the evaluation-only table-sized forwards, on the evaluation stream's 64 CUs beside the
+            # training stream -- a class and a kernel name of their own, in this run and in the rocprofv3 summaries)
+            side_fwd = prof.get("k_side_transfer_fwd", (0, 0.0))[0]
+            dom = max(((k, v) for k, v in prof.items() if k not in ("k_eval_ranks", "k_side_transfer_fwd")), key=lambda kv: kv[1][1])
             name, (cnt, ms) = dom
-            bound, work, _ = kernel_work(name, a, hp, U_local)
+            bound, work, _ = kernel_work(name, a, hp, U_local, side_forwards=side_fwd)
             kern = {k: {"launches": c, "total_ms": round(m, 3), "avg_us": round(1000.0 * m / c, 2)} for k, (c, m) in prof.items()}
             # What a HIP-event bracket adds to a short kernel's reading, measured in THIS run: the training stream is
             # gap-free (kernel time = step time), so the bracketed kernel totals of the training stream exceed the
             # un-bracketed step by (launches x overhead).  An EMPTY pair's own reading (also measured) is an upper bound:
             # it reads more than a bracket adds around a kernel, so it is quoted, not subtracted.
-            train = {k: v for k, v in prof.items() if k != "k_eval_ranks"}
+            train = {k: v for k, v in prof_main.items() if k != "k_eval_ranks"}
             n_launch = sum(c for c, _ in train.values())
             derived = (sum(m for _, m in train.values()) - 1000.0 * dt / a.steps) * 1000.0 / max(n_launch, 1)
             overhead_us = min(max(derived, 0.0), empty_pair_us)

@@ -60,7 +60,11 @@ int sml_ctx_destroy(sml_ctx* ctx);
  *   0  ConvTransfer_com (conv_com, the default; model/conv_transfer.py:87-135)
  *   1  ConvTransfer     (conv; :52-85): conv1 kernel (2,1) over (x_t, x_hat) -- theta keeps the [10][3]
  *      conv1 block with a zero third column -- no x_com row, user-net output divided by its detached norm
- *      (sml_transfer_forward with net 0 returns the normalised rows), loss SML_LOSS_BPR_UNIT. */
+ *      (sml_transfer_forward with net 0 returns the normalised rows), loss SML_LOSS_BPR_UNIT.
+ * + 2 (variant 2 / 3): the context is an EVALUATION-STREAM context -- a second context whose sml_transfer_forward calls over
+ *      whole tables run beside the training context's on another stream (forwards that only an evaluation reads); nothing
+ *      changes in what they compute, but those launches carry a kernel name (k_side_transfer_fwd) and a timing class of
+ *      their own, so that traces and sml_prof_get tell them from the training stream's. */
 int sml_ctx_set_variant(sml_ctx* ctx, int variant);
 /* --clip_grad (reference model/transfer.py:725-727, torch.nn.utils.clip_grad_norm_(transfer.parameters(), max_norm, 2)
  * between backward and optimizer.step() in the TR loop): max_norm > 0 makes the TR stage epoch finish the flat theta

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsml_hip.so")
 SOURCES = ["transfer_net.hip", "mf_kernels.hip", "index_prep.hip", "capi.hip"]
-HEADERS = ["sml_dev.h", "sml_kernels.h", os.path.join("..", "..", "include", "sml_hip.h")]
+HEADERS = ["sml_dev.h", "sml_kernels.h", "transfer_fwd_body.inc", os.path.join("..", "..", "include", "sml_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 FLAGS += os.environ.get("SML_EXTRA_FLAGS", "").split()      # measurement builds, e.g. -DSML_TIMELINE (tools/timeline_probe.py)
 

@@ -100,10 +100,11 @@ struct RcclApi {
 
 // ---- optional per-kernel-class timing with HIP events on the caller's stream -------------
 enum ProfClass { PC_FWD = 0, PC_BWD, PC_WGRAD, PC_THETA_ADAM, PC_PAIR_LOSS /* hot-row kernels */, PC_SEG_ADAM, PC_SEG_SGD, PC_BARE_GRAD,
-                 PC_EVAL_RANKS, PC_FLUSH, PC_PACK, PC_SORT, PC_MISC, PC_COUNT };
+                 PC_EVAL_RANKS, PC_FLUSH, PC_PACK, PC_SORT, PC_MISC, PC_FWD_SIDE, PC_COUNT };
 const char* const kProfNames[PC_COUNT] = {"k_transfer_fwd", "k_transfer_bwd", "k_transfer_wgrad", "k_theta_adam",
                                           "k_hot_rows", "k_seg_update_adam", "k_seg_update_sgd", "k_bare_grad",
-                                          "k_eval_ranks", "k_adam_flush", "k_theta_pack", "sort_epoch", "misc"};
+                                          "k_eval_ranks", "k_adam_flush", "k_theta_pack", "sort_epoch", "misc",
+                                          "k_side_transfer_fwd"};
 struct Prof {
     bool on = false;
     std::vector<hipEvent_t> ev;     // pairs
@@ -188,6 +189,7 @@ struct SchedRetired { SmlSched* dev; SmlSched* host; hipEvent_t done; };
 struct sml_ctx {
     int device = 0, d = 32, max_batch = 0;
     int variant = 0;         // 0: ConvTransfer_com, 1: ConvTransfer (sml_ctx_set_variant)
+    bool side = false;       // an evaluation-stream context (sml_ctx_set_variant, bit 1): its table-sized forwards run under their own name / class
     float clip_max_norm = 0.0f;   // > 0: the TR stage clips the theta gradient's norm (sml_ctx_set_grad_clip)
     float adaptive_beta = 0.0f;   // > 0: the MF stage adds the reference's --need_adaptive user-norm term (sml_ctx_set_adaptive)
     Buf<float> clip_sumsq;
@@ -768,8 +770,8 @@ int sml_ctx_create(sml_ctx** out, int device, int d, int max_batch) {
 }
 
 int sml_ctx_set_variant(sml_ctx* ctx, int variant) {
-    if (!ctx || (variant != 0 && variant != 1)) return fail(SML_EINVAL, "sml_ctx_set_variant", "variant must be 0 or 1");
-    ctx->variant = variant;
+    if (!ctx || variant < 0 || variant > 3) return fail(SML_EINVAL, "sml_ctx_set_variant", "variant must be 0 or 1 (+ 2: an evaluation-stream context)");
+    ctx->variant = variant & 1; ctx->side = (variant & 2) != 0;
     return SML_OK;
 }
 
@@ -836,7 +838,8 @@ int sml_transfer_forward(sml_ctx* ctx, const float* theta, int net, const float*
     const int mt = n_rows > 8192 ? ((mt_env == 3 && ctx->d == 32) ? 3 : 2) : 1;
     a.tiles0 = wg_tiles((int)n_rows, mt);
     a.seg[1] = s; a.seg[1].n_rows = 0;
-    ctx->prof.begin(PC_FWD, st); HIPCHK(sml_launch_fwd(ctx->d, mt, 1, a, a.tiles0, st)); ctx->prof.end(st);
+    const bool side = ctx->side && mt == 2 && (ctx->d == 32 || ctx->d == 64);
+    ctx->prof.begin(side ? PC_FWD_SIDE : PC_FWD, st); HIPCHK(sml_launch_fwd(ctx->d, mt, 1, a, a.tiles0, st, side)); ctx->prof.end(st);
     return SML_OK;
 }
 

@@ -149,7 +149,7 @@ hipError_t sml_launch_grad_sumsq(const float* grad, int64_t n, float* out, hipSt
 hipError_t sml_launch_conv_state_init(int d, const float* theta, const float* m, const float* v, float* cs, hipStream_t st);
 
 // mt row-tiles of 16 per workgroup; ns workgroups share a row tile (1, or SML_FWD_NS with mt = 1)
-hipError_t sml_launch_fwd(int d, int mt, int ns, const SmlFwdArgs& a, int tiles_total, hipStream_t st);
+hipError_t sml_launch_fwd(int d, int mt, int ns, const SmlFwdArgs& a, int tiles_total, hipStream_t st, bool side = false);
 // split != 0: d/16 workgroups per row tile (coordinate split); 0: one workgroup per row tile
 hipError_t sml_launch_bwd(int d, int split, const SmlBwdArgs& a, int tiles_total, hipStream_t st);
 hipError_t sml_launch_wgrad(int d, const SmlWgArgs& a, hipStream_t st);

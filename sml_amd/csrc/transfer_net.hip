@@ -217,387 +217,15 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // other's MFMA phases (a single 48-row workgroup per CU left the matrix pipe idle 45 % of the time).
 template <int D, int MT, int NS, int HSEQ = 1>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HSEQ > 1 ? 4 : 2, HSEQ > 1 ? 4 : 2))) void k_transfer_fwd(SmlFwdArgs a) {
-    constexpr int R = SML_TM * MT;
-    constexpr int K1 = SML_C2 * D;       // fc1 reduction length
-    constexpr int HL = SML_HID / NS / HSEQ;   // hidden units of one pass of this workgroup
-    constexpr int S1 = K1 + 4;           // LDS row strides (multiples of 4 floats: 16-byte aligned b128 reads)
-    constexpr int S2 = HL + 4;
-    constexpr int KS1 = K1 / 16;
-    constexpr int EPT = R * D / 512;
-    constexpr int JT = D / 16;                                    // fc2 column tiles
-    constexpr int CT = HL / 16 / 8;                               // fc1 column tiles per wave
-    constexpr int KL = HL / 16;                                   // fc2 k-steps of this workgroup
-    constexpr int KSPL = (D == 32) ? 8 : (D == 64 ? 4 : 2);       // fc2: waves along K ...
-    constexpr int JSPL = 8 / KSPL;                                // ... x waves along the columns
-    constexpr int JTW = JT / JSPL;
-    constexpr int KPW = KL / KSPL;                                // fc2 k-steps per wave
-    static_assert(CT >= 1 && KPW >= 1 && MT * NS <= 4 && (R * D) % 512 == 0, "tiling");
-    constexpr int REG0 = cmax(R * S1, KSPL * R * (D + 1));
-    __shared__ __attribute__((aligned(16))) float smem[REG0 + cmax(R * S2, R * (D + 1) + R) + 104];
-    __shared__ SmlSched swin[SML_SW];
-    float* A1s = smem;
-    float* a2s = smem + REG0;
-    float* cws = smem + REG0 + cmax(R * S2, R * (D + 1) + R);
-    float* xts = a2s;                    // [R][D+1], dead before a2s is written
-    float* nrm = a2s + R * (D + 1);
-    float* part = smem;                  // [KSPL][R][D+1], aliases A1s after fc1
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
-    TL_BEGIN(NS == 4 ? 1 : 4); TL_PREV();
-    // hidden-split form: everything this kernel writes is read next from other XCDs -> write-through.  Unsplit form:
-    // z1 / xin / the replayed moments go to the SAME tile's backward / row update, which runs as the same block index
-    // on the same XCD -> those stay in this XCD's L2 (plain stores); only `out` crosses XCDs (the pair loss reads the
-    // partner rows' tiles)
-    constexpr int WT_LOCAL = (NS == 4) ? SML_WT_FWD : SML_WT_FWD_LOCAL;
-    // Workgroup b runs on XCD b % 8 (observed dispatch order; affinity only).  In the four-way hidden split, slice h
-    // goes to XCDs {2h, 2h+1} -- the XCDs whose weight-gradient workgroups rewrote exactly that slice of the
-    // operand images in the previous batch's Adam step (k_transfer_wgrad's tile map) -- and to no other.
-    int tile, h;
-    if constexpr (NS == 4) {
-        const int x = (int)blockIdx.x % 8;
-        h = x / 2; tile = 2 * ((int)blockIdx.x / 8) + (x % 2);
-        if (tile >= a.tiles_total) return;
-    } else { tile = (int)blockIdx.x / NS; h = (int)blockIdx.x % NS; }
-    const int sidx = tile >= a.tiles0;
-    const SmlSeg sg = sidx ? a.seg[1] : a.seg[0];     // (static select: no dependent scalar loads at the kernel's start)
-    const int row0 = (tile - (sidx ? a.tiles0 : 0)) * R;
-    const float* __restrict__ theta = sg.theta;
-    float cw_reg = 0.0f;
-    // the net's 104 conv floats: from theta -- or, when the previous batch's conv step is taken here, from the state copy
-    constexpr bool CONVSTEP = (NS == 4 && MT == 1 && HSEQ == 1);
-    const bool cstep = CONVSTEP && a.cs_in != nullptr;
-    constexpr int CRG = 21, CC4 = SML_CG / 4;          // the last arriver's geometry: 21 row groups x 24 column groups
-    f32x4 cg_acc = {0.f, 0.f, 0.f, 0.f}, cgx[4];
-    float cs_p = 0.f, cs_m = 0.f, cs_v = 0.f;
-    const int cs_k = tid;                             // compact conv index of threads 0..94
-    const int cs_off = cs_k < 30 ? cs_k : cs_k < 40 ? cs_k + 2 : cs_k < 90 ? cs_k + 4 : cs_k + 6;
-    const int cg_lo = sidx ? a.cg_split : 0, cg_hi = sidx ? a.cg_total : a.cg_split;     // this net's partial rows
-    int cg_t = 0;
-    const bool cg_mine = CONVSTEP && cstep && a.cg_part != nullptr && tid < CRG * CC4;
-    if (!cstep) { if (tid < 104) cw_reg = theta[tid]; }               // parked in LDS once the other loads are on their way
-    const bool lazy = sg.last_tab != nullptr;
-    if (lazy) sched_window_load(swin, a.sched, a.cur_step - 1, tid);
-    const bool saver = (h == 0);         // one workgroup of the NS writes the shared saves
-
-    // Hidden-split form: this wave's whole fc1 operand set (one column tile: 2 x KS1/2 k-steps) and its fc2 share fit a
-    // register ring at d = 32 -- fetched now, with the biases, so neither GEMM waits for the fabric (the images
-    // were rewritten by the previous batch's Adam step on other XCDs: their first read is a fabric round trip)
-    constexpr bool PRE = (CT == 1) && (KS1 / 2 <= 5) && HSEQ == 1;
-    constexpr int PF2 = KPW < 4 ? KPW : 4;
-    const f32x4* __restrict__ img1 = reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p1(D));
-    const f32x4* __restrict__ img2 = reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p2(D));
-    const int tile0 = h * (HL / 16) + wv * CT;
-    const int kq = wv % KSPL, jq = wv / KSPL;
-    auto t1 = [tile0](int) { return tile0; };
-    auto k1 = [](int t) { return t * (KS1 / 2); };
-    auto t2 = [jq](int t) { return jq * JTW + t; };
-    auto nokofs = [](int) { return 0; };
-    f32x4 ringf1[PRE ? 5 : 1][2], ringf2[PRE ? PF2 : 1][JTW];
-    if constexpr (PRE) {
-        ring_preload<2, 5>(ringf1, img1, KS1, 0, lane, t1, k1);
-        ring_preload<JTW, PF2>(ringf2, img2, 32, h * KL + kq * KPW, lane, t2, nokofs);
-    }
-    // Unsplit training form (MF stage: one workgroup per row tile, CT column tiles per wave): the first five k-steps of
-    // all CT tiles and the wave's fc2 share are fetched here as well, under the gather / lazy-Adam replay / prologue
-    // (optional, off: issued BEHIND the gather's loads further down -- loads return in issue order and the gather heads the chain;
-    // at the very top the MF step got slower, 41.3 -> 42.9 us; behind the gather it is neutral, 42.2 vs 42.3 us)
-#ifndef SML_PREW
-#define SML_PREW 0
-#endif
-    constexpr bool PREW = (SML_PREW != 0) && (MT == 1) && (CT >= 2) && (D <= 64) && HSEQ == 1;
-    auto tw = [tile0](int t) { return tile0 + t; };
-    f32x4 ringw1[PREW ? 5 : 1][CT], ringw2[PREW ? PF2 : 1][JTW];
-    float bias1[HSEQ][CT];
-#pragma unroll
-    for (int hp = 0; hp < HSEQ; ++hp)
-#pragma unroll
-        for (int t = 0; t < CT; ++t) bias1[hp][t] = theta[sml_off_f1b(D) + (h * HSEQ + hp) * HL + (wv * CT + t) * 16 + l15];
-    float bias2[EPT];
-#pragma unroll
-    for (int q = 0; q < EPT; ++q) bias2[q] = (h == 0) ? theta[sml_off_f2b(D) + (q * 512 + tid) % D] : 0.0f;
-
-    // ---- P1: gather x_t and x_hat; all index loads, then all row loads, are in flight together
-    float xt[EPT], xh[EPT];
-    float nr2[EPT];
-    {
-        int64_t idx[EPT];
-        bool ok[EPT];
-#pragma unroll
-        for (int q = 0; q < EPT; ++q) {
-            const int row = row0 + (q * 512 + tid) / D;
-            ok[q] = row < sg.n_rows;
-            idx[q] = ok[q] ? seg_row_index(sg, row) : 0;
-        }
-        if constexpr (CONVSTEP) {
-            if (cstep) {
-                // the pending conv step's inputs go out BEHIND the gather's index loads and ahead of its row loads.  (Loads
-                // return in issue order.  Measured, TR step wall: issued at the kernel's top, with the operand rings, 24.0 us
-                // -- these fabric-cold lines, which 192 workgroups ask for at once, hold the index loads back; here 23.3-23.4;
-                // the last-arriver form they replace 24.1.)
-                if (tid < 95) {
-                    const float* st_ = a.cs_in + (int64_t)sidx * 3 * SML_CG;
-                    cs_p = st_[cs_k]; cs_m = st_[SML_CG + cs_k]; cs_v = st_[2 * SML_CG + cs_k];
-                }
-                if (cg_mine) {
-                    // this net's partial rows rg, rg + 21, ... (ascending: the order k_tr_wgrad2's last arriver adds them in);
-                    // plain loads: the partials were stored write-through by the previous LAUNCH
-                    const int rg = tid / CC4, c4 = tid % CC4;
-                    cg_t = rg + (cg_lo > rg ? ((cg_lo - rg + CRG - 1) / CRG) * CRG : 0);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int t = cg_t + u * CRG;
-                        cgx[u] = *reinterpret_cast<const f32x4*>(a.cg_part + (int64_t)(t < cg_hi ? t : cg_lo) * SML_CG + c4 * 4);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < EPT; ++q) {
-            const int w = (q * 512 + tid) % D;
-            xt[q] = sg.xt_tab[idx[q] * D + w];
-            xh[q] = sg.xh_tab[idx[q] * D + w];
-        }
-        float m[EPT], v[EPT];
-        int from[EPT];
-        if (lazy) {
-#pragma unroll
-            for (int q = 0; q < EPT; ++q) {
-                const int w = (q * 512 + tid) % D;
-                m[q] = sg.m_tab[idx[q] * D + w];
-                v[q] = sg.v_tab[idx[q] * D + w];
-                from[q] = sg.last_tab[idx[q]];
-            }
-        }
-        if constexpr (PREW) {              // the operand rings, behind every load of the gather
-            ring_preload<CT, 5>(ringw1, img1, KS1, 0, lane, tw, nokofs);
-            ring_preload<JTW, PF2>(ringw2, img2, 32, h * KL + kq * KPW, lane, t2, nokofs);
-        }
-        if constexpr (CONVSTEP) {
-            if (cstep) {
-                // ---- the previous batch's conv-parameter step (see SmlFwdArgs): partial rows -> 21 row-group sums in LDS ->
-                // 95 parameters, each added over the row groups in index order -> Adam.  Runs while this workgroup's row
-                // gather (issued above) is in flight; `part`/A1s is not live yet.
-                __builtin_amdgcn_sched_barrier(0);          // (the gather's loads stay ahead of the first look at the partials)
-                float* P = smem;                            // [CRG][SML_CG]
-                if (tid < CRG * CC4) {
-                    const int rg = tid / CC4, c4 = tid % CC4;
-                    if (cg_mine) {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) if (cg_t + u * CRG < cg_hi) cg_acc += cgx[u];
-                        for (int t0 = cg_t + 4 * CRG; t0 < cg_hi; t0 += 4 * CRG) {          // (d >= 64: more than four rows per group)
-                            f32x4 x[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const int t = t0 + u * CRG;
-                                x[u] = *reinterpret_cast<const f32x4*>(a.cg_part + (int64_t)(t < cg_hi ? t : cg_lo) * SML_CG + c4 * 4);
-                            }
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) if (t0 + u * CRG < cg_hi) cg_acc += x[u];
-                        }
-                    }
-                    *reinterpret_cast<f32x4*>(P + rg * SML_CG + c4 * 4) = cg_acc;
-                }
-                // (a bare barrier behind the LDS writes: __syncthreads() also drains vmcnt -- it would hold this step until
-                // the gather's rows have arrived, which is exactly the time it is meant to run in)
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                if (tid < 95) {
-                    if (a.cg_part != nullptr) {
-                        float pv[CRG];                   // all 21 LDS reads in flight, then the (ordered) adds: one round trip, not eleven
-#pragma unroll
-                        for (int rg = 0; rg < CRG; ++rg) pv[rg] = P[rg * SML_CG + cs_k];
-                        __builtin_amdgcn_sched_barrier(0);
-                        float g = 0.0f;
-#pragma unroll
-                        for (int rg = 0; rg < CRG; ++rg) g += pv[rg];
-                        SmlSched sc; sc.step_size = a.cs_step_size; sc.bc2_sqrt = a.cs_bc2_sqrt;
-                        adam_apply(cs_p, cs_m, cs_v, adam_wd(g, a.cs_wd, cs_p), sc);
-                    }
-                    cws[cs_off] = cs_p;
-                    const int first_tile = sidx ? a.tiles0 : 0;
-                    if (tile == first_tile && h == 0) {         // the net's first workgroup publishes the step
-                        float* so = a.cs_out + (int64_t)sidx * 3 * SML_CG;
-                        so[cs_k] = cs_p; so[SML_CG + cs_k] = cs_m; so[2 * SML_CG + cs_k] = cs_v;
-                        const int64_t i = (int64_t)sidx * sml_net_size(D) + cs_off;
-                        a.cs_theta[i] = cs_p; a.cs_m[i] = cs_m; a.cs_v[i] = cs_v;
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < EPT; ++q) {
-            const int e = q * 512 + tid;
-            if (!ok[q]) { xt[q] = 1.0f; xh[q] = 0.0f; }
-            if constexpr (D > 64) xts[(e / D) * (D + 1) + (e % D)] = xt[q];
-            else {
-                // ||x_t||^2: a row's D elements are D adjacent lanes of one wavefront
-                float s2 = xt[q] * xt[q];
-#pragma unroll
-                for (int off = D / 2; off >= 1; off >>= 1) s2 += __shfl_xor(s2, off, 64);
-                nr2[q] = s2;
-            }
-        }
-        if (!cstep && tid < 104) cws[tid] = cw_reg;      // (cstep: threads 0..94 stored the stepped parameters above)
-        __syncthreads();                   // xts, cws and the schedule window are in LDS
-        TL(2);
-        if (lazy) {                        // replay the rows' pending zero-gradient Adam steps
-#pragma unroll
-            for (int q = 0; q < EPT; ++q)
-                if (ok[q]) adam_replay_w(xh[q], m[q], v[q], from[q], a.cur_step - 1, a.sched, swin, a.cur_step - 1);
-            if (saver && sg.mrep != nullptr) {     // the row update continues from here: it need not replay again
-#pragma unroll
-                for (int q = 0; q < EPT; ++q) {
-                    const int e = q * 512 + tid;
-                    const int64_t o = (int64_t)(row0 + e / D) * D + (e % D);
-                    st_out<WT_LOCAL>(&sg.mrep[o], ok[q] ? m[q] : 0.0f);
-                    st_out<WT_LOCAL>(&sg.vrep[o], ok[q] ? v[q] : 0.0f);
-                }
-            }
-        }
-    }
-    if constexpr (D > 64) {
-        if (tid < R) {
-            float s = 0.0f;
-#pragma unroll 8
-            for (int w = 0; w < D; ++w) { const float t = xts[tid * (D + 1) + w]; s += t * t; }
-            nrm[tid] = sqrtf(s);
-        }
-        __syncthreads();
-    }
-    // ---- P2: x_com, conv1, Gelu, conv2, Gelu -> A1 tile (channel-major flatten c*D + w)
-#pragma unroll
-    for (int q = 0; q < EPT; ++q) {
-        const int e = q * 512 + tid, r = e / D, w = e % D;
-        const int row = row0 + r;
-        const float nrow = D > 64 ? nrm[r] : sqrtf(nr2[q]);
-        const float xc = a.k2 ? 0.0f : (xt[q] * xh[q]) / nrow;     // no epsilon, as model/conv_transfer.py:99
-        Pro p;
-        conv_prologue(cws, xt[q], xh[q], xc, p);
-#pragma unroll
-        for (int c = 0; c < SML_C2; ++c) {
-            const float v = sml_gelu(p.h2p[c]);
-            A1s[r * S1 + c * D + w] = v;
-            if (saver && sg.a1 != nullptr) st_out<WT_LOCAL>(&sg.a1[(int64_t)row * K1 + c * D + w], v);
-        }
-        if (saver && sg.xin != nullptr) {
-            float* x = sg.xin + (int64_t)row * 3 * D;
-            st_out<WT_LOCAL>(&x[w], xt[q]);
-            st_out<WT_LOCAL>(&x[D + w], xh[q]);
-            st_out<WT_LOCAL>(&x[2 * D + w], xc);
-        }
-    }
-    __syncthreads();
-    TL(3);
-
-    // ---- fc1 / fc2, in HSEQ passes over this workgroup's hidden units (one pass unless HSEQ > 1)
-    f32x4 acc2[MT][JTW];
-    zero_acc(acc2);
-#pragma unroll
-    for (int hp = 0; hp < HSEQ; ++hp) {
-        const int hc = h * HSEQ + hp;                 // hidden block of this pass: units [hc * HL, (hc + 1) * HL)
-        const int tile0p = hc * (HL / 16) + wv * CT;
-        // ---- fc1: Z1[R x HL] = A1[R x K1] * W1^T[:, block hc] ; wave wv owns CT column tiles of the block
-        {
-            const f32x4* img = img1;
-            float zt[MT][CT][4];
-            if constexpr (CT >= 2) {
-                f32x4 acc[MT][CT];
-                zero_acc(acc);
-                if constexpr (PREW) mma16_ring<MT, CT, KS1, 5, false>(acc, ringw1, A1s + l15 * S1 + 4 * g4, SML_TM * S1, img, KS1, 0, lane, tw, nokofs);
-                else mma16_rows<MT, CT, KS1, (MT == 1 ? 5 : 2)>(acc, A1s + l15 * S1 + 4 * g4, SML_TM * S1, img, KS1, 0, lane,
-                                                               [tile0p](int t) { return tile0p + t; });
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int t = 0; t < CT; ++t)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) zt[mt][t][q] = acc[mt][t][q];
-            } else {
-                // one column tile per wave: two independent accumulator chains over the two halves of K
-                static_assert(KS1 % 2 == 0, "even k-steps");
-                f32x4 acc[MT][2];
-                zero_acc(acc);
-                if constexpr (PRE) mma16_ring<MT, 2, KS1 / 2, 5, true>(acc, ringf1, A1s + l15 * S1 + 4 * g4, SML_TM * S1, img, KS1, 0, lane, t1, k1);
-                else mma16_rows_k<MT, 2, KS1 / 2, 5, true>(acc, A1s + l15 * S1 + 4 * g4, SML_TM * S1, img, KS1, 0, lane, [tile0p](int) { return tile0p; }, k1);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) zt[mt][0][q] = acc[mt][0][q] + acc[mt][1][q];
-            }
-            TL(9);
-            if (HSEQ > 1 && hp > 0) __syncthreads();      // the previous pass's fc2 is done reading the a2 tile
-            // + bias, save z1, Gelu -> a2 tile.  (xts/nrm are dead: every wave passed the barrier above)
-            float* z1 = sg.z1;
-#pragma unroll
-            for (int t = 0; t < CT; ++t) {
-                const int nl = (wv * CT + t) * 16 + l15;       // column inside the block
-                const int n = hc * HL + nl;
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int r = mt * SML_TM + 4 * g4 + q;
-                        const float z = zt[mt][t][q] + bias1[hp][t];
-                        if (z1 != nullptr) st_out<WT_LOCAL>(&z1[(int64_t)(row0 + r) * SML_HID + n], z);
-                        const float gz = sml_gelu(z);
-                        a2s[r * S2 + nl] = gz;
-                        if (sg.a2 != nullptr) st_out<WT_LOCAL>(&sg.a2[(int64_t)(row0 + r) * SML_HID + n], gz);
-                    }
-            }
-        }
-        TL(4);
-        __syncthreads();
-        TL(5);
-        // ---- fc2: Out[R x D] += a2[R x HL] * W2^T[block hc, :] ; waves = KSPL (along K) x JSPL (column tiles)
-        // (the operand image is indexed by the global k-step, the LDS tile by the local one)
-        if constexpr (PRE) mma16_ring<MT, JTW, KPW, PF2, false>(acc2, ringf2, a2s + l15 * S2 + 4 * g4 - hc * HL, SML_TM * S2, img2, 32,
-                                                                hc * KL + kq * KPW, lane, t2, nokofs);
-        else if constexpr (PREW) mma16_ring<MT, JTW, KPW, PF2, false>(acc2, ringw2, a2s + l15 * S2 + 4 * g4 - hc * HL, SML_TM * S2, img2, 32,
-                                                                      hc * KL + kq * KPW, lane, t2, nokofs);
-        else mma16_rows<MT, JTW, KPW, PF2>(acc2, a2s + l15 * S2 + 4 * g4 - hc * HL, SML_TM * S2, img2, 32, hc * KL + kq * KPW, lane, t2);
-    }
-    if (HSEQ > 1) __syncthreads();                        // `part` aliases the A1 tile: every wave is done with its fc1 reads
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int t = 0; t < JTW; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                part[(kq * R + mt * SML_TM + 4 * g4 + q) * (D + 1) + (jq * JTW + t) * 16 + l15] = acc2[mt][t][q];
-    __syncthreads();
-    TL(6);
-    float* __restrict__ outp = sg.out + (int64_t)h * a.out_pstride;
-    float sres[EPT];
-#pragma unroll
-    for (int q = 0; q < EPT; ++q) {
-        const int e = q * 512 + tid, r = e / D, j = e % D;
-        float s = bias2[q];
-#pragma unroll
-        for (int k = 0; k < KSPL; ++k) s += part[(k * R + r) * (D + 1) + j];
-        sres[q] = s;
-    }
-    if (NS == 1 && a.unit_rows && sidx == 0) {
-        // ConvTransfer.forward(type='user'): x / ||x|| (model/conv_transfer.py:62-64).  Every thread parks its
-        // element in its own k = 0 slot of `part` (nobody else reads that slot), then reads its row back.
-#pragma unroll
-        for (int q = 0; q < EPT; ++q) { const int e = q * 512 + tid; part[(e / D) * (D + 1) + (e % D)] = sres[q]; }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < EPT; ++q) {
-            const int r = (q * 512 + tid) / D;
-            float n2 = 0.0f;
-#pragma unroll 8
-            for (int w = 0; w < D; ++w) { const float t = part[r * (D + 1) + w]; n2 += t * t; }
-            sres[q] = sres[q] / sqrtf(n2);
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < EPT; ++q) {
-        const int e = q * 512 + tid, r = e / D, j = e % D;
-        if (row0 + r < sg.n_rows) st_out<SML_WT_FWD>(&outp[(int64_t)(row0 + r) * D + j], sres[q]);
-    }
-    TL(7);
-    TL_DONE();
+#include "transfer_fwd_body.inc"
+}
+// The same table-sized forward under a name of its own: launched by the EVALUATION stream's context (eval_submit_transferred:
+// forwards that only an evaluation reads, on that stream's 64 CUs), so that kernel traces and the per-class timing tell it from
+// the training stream's launches -- it runs at a third of their rate by design and is not on the critical path.
+template <int D>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_side_transfer_fwd(SmlFwdArgs a) {
+    constexpr int MT = 2, NS = 1, HSEQ = 2;
+#include "transfer_fwd_body.inc"
 }
 
 // ------------------------------------------------------------------------------------
@@ -2141,8 +1769,13 @@ hipError_t sml_debug_set_timeline(long long* buf) { return hipMemcpyToSymbol(HIP
 #else
 hipError_t sml_debug_set_timeline(long long*) { return hipErrorNotSupported; }
 #endif
-hipError_t sml_launch_fwd(int d, int mt, int ns, const SmlFwdArgs& a, int tiles_total, hipStream_t st) {
+hipError_t sml_launch_fwd(int d, int mt, int ns, const SmlFwdArgs& a, int tiles_total, hipStream_t st, bool side) {
     if (tiles_total <= 0) return hipSuccess;
+    if (side && mt == 2 && ns == 1 && (d == 32 || d == 64)) {     // (the evaluation stream's table-sized forward: same code, own name)
+        if (d == 32) k_side_transfer_fwd<32><<<dim3(tiles_total), dim3(512), 0, st>>>(a);
+        else k_side_transfer_fwd<64><<<dim3(tiles_total), dim3(512), 0, st>>>(a);
+        return hipGetLastError();
+    }
     if (mt == 1 && ns == 1) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 1, 1><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }
     else if (mt == 1 && ns == 4) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 1, 4><<<dim3(((tiles_total + 1) / 2) * 8), dim3(512), 0, st>>>(a)); }
     else if (mt == 1 && ns == 2) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 1, 2><<<dim3(tiles_total * 2), dim3(512), 0, st>>>(a)); }

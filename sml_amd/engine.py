@@ -786,9 +786,10 @@ class HipEngine(object):
         if getattr(self, "_side_ctx_h", None) is None:
             h = ctypes.c_void_p()
             check(self.lib.sml_ctx_create(ctypes.byref(h), self.device.index or 0, self.d, 1024), "sml_ctx_create")
-            self._side_ctx_h, self._side_variant = h, 0
+            self._side_ctx_h, self._side_variant = h, -1
         if self._side_variant != getattr(self, "_variant", 0):
-            check(self.lib.sml_ctx_set_variant(self._side_ctx_h, getattr(self, "_variant", 0)), "sml_ctx_set_variant")
+            # (bit 1: an evaluation-stream context -- its table-sized forwards carry their own kernel name and timing class)
+            check(self.lib.sml_ctx_set_variant(self._side_ctx_h, getattr(self, "_variant", 0) | 2), "sml_ctx_set_variant")
             self._side_variant = getattr(self, "_variant", 0)
         return self._side_ctx_h
 
@@ -1027,10 +1028,19 @@ class HipEngine(object):
         return dst
 
     # ------------------------------------------------------------------ measurement
+    def _prof_ctxs(self):
+        """The library contexts whose launches are bracketed: the engine's own and, once it exists, the side stream's
+        (eval_submit_transferred runs its table-sized forwards through it, on the evaluation stream)."""
+        side = getattr(self, "_side_ctx_h", None)
+        return [self._ctx] + ([side] if side else [])
+
     def profile(self, on):
-        check(self.lib.sml_prof_enable(self._ctx, int(bool(on))), "sml_prof_enable")
-        if on:
-            check(self.lib.sml_prof_reset(self._ctx), "sml_prof_reset")
+        if on and hasattr(self, "_side_stream") and getattr(self, "_side_ctx_h", None) is None and self.device.type == "cuda":
+            self._side_ctx()                       # (so that its launches are bracketed from their first one)
+        for c in self._prof_ctxs():
+            check(self.lib.sml_prof_enable(c, int(bool(on))), "sml_prof_enable")
+            if on:
+                check(self.lib.sml_prof_reset(c), "sml_prof_reset")
 
     def profile_pair_overhead(self, n=512):
         """Microseconds an EMPTY HIP-event pair reads on the current stream (subtract it from short kernels' averages)."""
@@ -1038,14 +1048,20 @@ class HipEngine(object):
         check(self.lib.sml_prof_pair_overhead(self._ctx, int(n), self._stream(), ctypes.byref(us)), "sml_prof_pair_overhead")
         return us.value
 
-    def profile_read(self):
-        """{kernel class: (launches, total ms)} measured with HIP events since profile(True)."""
+    def profile_read(self, which="all"):
+        """{kernel class: (launches, total ms)} measured with HIP events since profile(True).  which: "all" (both contexts,
+        summed), "main" (the engine's own: the training stream) or "side" (the evaluation stream's forwards)."""
         out = {}
-        for c in range(self.lib.sml_prof_classes()):
-            cnt, ms = ctypes.c_int64(0), ctypes.c_double(0.0)
-            check(self.lib.sml_prof_get(self._ctx, c, ctypes.byref(cnt), ctypes.byref(ms)), "sml_prof_get")
-            if cnt.value:
-                out[self.lib.sml_prof_name(c).decode()] = (cnt.value, ms.value)
+        ctxs = self._prof_ctxs()
+        ctxs = ctxs[:1] if which == "main" else ctxs[1:] if which == "side" else ctxs
+        for ctx in ctxs:
+            for c in range(self.lib.sml_prof_classes()):
+                cnt, ms = ctypes.c_int64(0), ctypes.c_double(0.0)
+                check(self.lib.sml_prof_get(ctx, c, ctypes.byref(cnt), ctypes.byref(ms)), "sml_prof_get")
+                if cnt.value:
+                    name = self.lib.sml_prof_name(c).decode()
+                    have = out.get(name, (0, 0.0))
+                    out[name] = (have[0] + cnt.value, have[1] + ms.value)
         return out
 
     def selftest(self):
