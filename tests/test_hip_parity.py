@@ -687,6 +687,48 @@ def test_exchange_path_on_one_rank_rccl_group_equals_plain_path(monkeypatch):
         dist.destroy_process_group()
 
 
+def test_mf_exchange_pushed_by_the_backward_equals_the_push_and_wait_launches(monkeypatch):
+    """Round 4, one-shot exchange: at batches that take the one-workgroup-per-tile backward the item tiles push their gradient
+    rows into the inboxes themselves (grid cut for the batch cap: a ragged last batch's spare workgroups only signal) and the wait
+    sits at the head of the row update.  SML_PEER_PUSH_LAUNCH=1 / SML_PEER_WAIT_LAUNCH=1 keep k_peer_push / k_peer_wait: both
+    forms, and the hooked RCCL path, must leave bit-identical tables and losses on a one-rank group; no poll may time out."""
+    import socket
+    import torch.distributed as dist
+    from sml_amd import dist as SD
+    from sml_amd.period import PeriodState
+    rng = np.random.RandomState(12)
+    U, I, d, B, n = 4000, 3000, 32, 1024, 2 * 1024 + 300
+    tri = torch.from_numpy(np.stack([rng.randint(0, U, n), np.minimum((rng.pareto(1.0, n) * 3).astype(np.int64), I - 1), rng.randint(0, I, n)], 1)).to(DEV)
+    wu0, wi0 = rng.randn(U, d).astype(np.float32) * 0.3, rng.randn(I, d).astype(np.float32) * 0.3
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        outs = []
+        for comm, push, wait in (("rccl", "0", "0"), ("peer", "1", "1"), ("peer", "0", "1"), ("peer", "0", "0")):
+            monkeypatch.setenv("SML_COMM", comm)
+            monkeypatch.setenv("SML_PEER_PUSH_LAUNCH", push)
+            monkeypatch.setenv("SML_PEER_WAIT_LAUNCH", wait)
+            eng = engine(d, B)
+            mf = make_mf(U, I, d, wu0, wi0, device=DEV)
+            torch.manual_seed(4)
+            net = make_transfer(d, device=DEV)
+            ctx = SD.attach(eng, PeriodState(mf, net), dist)
+            assert ctx.mode == comm
+            lu, li = T(wu0 * 0.9, DEV), T(wi0 * 0.9, DEV)
+            losses = [eng.mf_stage_epoch(mf, net, lu, li, tri, B, 0.01, 1e-6, exchange=ctx.mf_exchange(tri, B, d)).cpu() for _ in range(2)]
+            eng.mf_flush(mf)
+            torch.cuda.synchronize()
+            if comm == "peer":
+                assert eng.peer_status() == 0
+            outs.append((losses, mf.user_laten.weight.detach().clone(), mf.item_laten.weight.detach().clone()))
+            eng.close()
+        for o in outs[1:]:
+            assert all(torch.equal(x, y) for x, y in zip(outs[0][0], o[0]))
+            assert torch.equal(outs[0][1], o[1]) and torch.equal(outs[0][2], o[2])
+    finally:
+        dist.destroy_process_group()
+
+
 def test_main_news_path_end_to_end(tmp_path, monkeypatch):
     """main_news.py (Adressa shape: 63 periods, train from 21, test from 48, multi_num 7,
     2+2 epochs) on another tiny synthetic dataset: runs to the final report and produces 15 test
