@@ -59,11 +59,34 @@ __device__ __forceinline__ uint64_t match_any(uint32_t key, bool valid, int bits
 // wavefronts per workgroup on separate rows; tools/lds_atomic_order_probe.hip is the long form: 2.1e9 atomics, none out of
 // order) and the kernels take this path only while the probe's violation count is zero -- otherwise the ballot ranking
 // below (about 130 instructions per round instead of 6: the partition and the bucket sorts were bound by exactly this).
+// AGG (the oversized buckets: a hot row's occurrences are most of such a bucket, and 64 atomics on one address are served one
+// after the other): the lanes that share the first lane's key -- and then the first remaining lane's -- take ONE add of their
+// number each, the rank being the lane's place among them; what is left goes lane by lane.
+template <bool AGG = false>
 __device__ __forceinline__ uint32_t wave_rank(unsigned short* cnt, uint32_t key, bool valid, int bits, bool fast) {
     if (fast) {
-        uint32_t old = 0;
-        if (valid) old = atomicAdd(reinterpret_cast<uint32_t*>(cnt + (key & ~1u)), 1u << (16 * (key & 1u)));
-        return (old >> (16 * (key & 1u))) & 0xffffu;
+        uint32_t rank = 0;
+        bool todo = valid;
+        if constexpr (AGG) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const uint64_t vm = __ballot(todo);
+                if (vm == 0ull) break;
+                const int first = __ffsll((long long)vm) - 1;
+                const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, first);
+                const uint64_t m0 = __ballot(todo && key == k0);
+                uint32_t base = 0;
+                if ((int)(threadIdx.x & 63) == first)
+                    base = atomicAdd(reinterpret_cast<uint32_t*>(cnt + (k0 & ~1u)), (uint32_t)__popcll(m0) << (16 * (k0 & 1u)));
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+                if (todo && key == k0) { rank = ((base >> (16 * (k0 & 1u))) & 0xffffu) + (uint32_t)__popcll(m0 & lanes_below()); todo = false; }
+            }
+        }
+        if (todo) {
+            const uint32_t old = atomicAdd(reinterpret_cast<uint32_t*>(cnt + (key & ~1u)), 1u << (16 * (key & 1u)));
+            rank = (old >> (16 * (key & 1u))) & 0xffffu;
+        }
+        return rank;
     }
     const int lane = threadIdx.x & 63;
     const uint64_t m = match_any(key, valid, bits);
@@ -1049,7 +1072,7 @@ __global__ __launch_bounds__(1024) void k_prep_large(SmlPrepArgs a) {
                         const int i = wv * (R * 64) + r * 64 + lane;
                         const bool valid = i < S;
                         ev[r] = valid ? lbuf[i] : (E)0;
-                        wr[r] = (unsigned short)wave_rank(cnt[wv], (ent_hi<E>(ev[r], tb.vb) >> lo) & (uint32_t)(nd - 1), valid, bits, fast);
+                        wr[r] = (unsigned short)wave_rank<true>(cnt[wv], (ent_hi<E>(ev[r], tb.vb) >> lo) & (uint32_t)(nd - 1), valid, bits, fast);
                     }
                 }
                 __syncthreads();                                 // every stripe is in registers, every count is in
@@ -1108,7 +1131,7 @@ __global__ __launch_bounds__(1024) void k_prep_large(SmlPrepArgs a) {
                     const int i = c0 + wv * 256 + r * 64 + lane;
                     const bool valid = i < S;
                     ev[r] = valid ? src[i] : (E)0;
-                    wr[r] = wave_rank(cnt[wv], (ent_hi<E>(ev[r], tb.vb) >> lo) & (uint32_t)(nd - 1), valid, bits, fast);
+                    wr[r] = wave_rank<true>(cnt[wv], (ent_hi<E>(ev[r], tb.vb) >> lo) & (uint32_t)(nd - 1), valid, bits, fast);
                 }
                 __syncthreads();
                 uint32_t ctot = 0;
