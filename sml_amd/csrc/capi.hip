@@ -895,7 +895,9 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
     // takes the row update itself (SmlFusedUpdate) -- no third launch per batch.  SML_MF_FUSED_UPDATE=0: A/B tests.
     const bool fused = !xchg && !bsplit && d <= 64 && ctx->adaptive_beta <= 0.0f && ctx->ix[0].by_hand && ctx->ix[0].slot_stride > 0 &&
                        env_int("SML_MF_FUSED_UPDATE", 1) != 0;
-    if (fused && !ctx->run_arrive.p) {
+    if (fused) {
+        // (the counters clear themselves batch by batch; they are zeroed per epoch all the same -- 12 KB -- so that an epoch
+        // that was cut short, e.g. by a failed launch, cannot leave a count behind for the next one)
         HIPCHK(ctx->run_arrive.ensure((size_t)3 * ctx->max_batch + 8));
         HIPCHK(hipMemsetAsync(ctx->run_arrive.p, 0, ((size_t)3 * ctx->max_batch + 8) * sizeof(int), st));
     }
