@@ -98,6 +98,9 @@ def parse():
                     help="several GPUs, yelp_period: weak = every rank its own period over its own user shard (global batch = "
                          "N x the reference's); strong = ONE period with the reference's global batches (1024 / 256) split over "
                          "the ranks by user owner")
+    ap.add_argument("--job-timeout", type=float, default=None,
+                    help="--gpus N > 1: seconds before the launcher stops the rank processes and exits 124 (default: SML_JOB_TIMEOUT_S, "
+                         "else 3600; 0: no limit) -- a hung rank must not hold the node's GPUs forever")
     ap.add_argument("--one-device", action="store_true",
                     help="test mode for a 1-GPU box: all N rank processes share device 0 (gloo carries torch.distributed)")
     return ap.parse_args()
@@ -323,6 +326,21 @@ def prep_fabric():
         return {}
 
 
+def gather_ceiling(d, dtype):
+    """Measured ceiling of the a3 access pattern for this row shape: three random row reads + three in-place row writes per
+    triple with nothing else in the kernel (tools/micro_gather.hip), from the latest committed profiles/r*_micro_gather.json.
+    -> {"ceiling_GBps", "ceiling_profile"} or {}."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_micro_gather.json")))
+    if not files:
+        return {}
+    try:
+        z = json.load(open(files[-1])).get("d%d_%s" % (d, "fp32" if dtype == "f32" else "fp16"))
+        return {"ceiling_GBps": 1000.0 * z["reads_writes"]["TBps"], "ceiling_profile": os.path.basename(files[-1])}
+    except Exception:
+        return {}
+
+
 def a3_object(a, device):
     """The fused embed+loss+SGD kernel pair (north_star's HBM-roofline target) at table scale,
     measured in this same run: per configuration the kernel-only fraction of the 8 TB/s roofline (HIP events over
@@ -349,6 +367,11 @@ def a3_object(a, device):
                         "kernel_GBps": r["roofline"]["achieved"],
                         "kernels_avg_us": {k: v["avg_us"] for k, v in r["kernels"].items()},
                         "index_prep": r.get("index_prep")}
+            # the kernels' algorithmic rate against the MEASURED rate of the bare access pattern (random rows read and
+            # rewritten in place, tools/micro_gather.hip) -- what "of the 8 TB/s roofline" cannot say for 128-byte random rows
+            c = gather_ceiling(d, dt)
+            if c:
+                res[tag].update(c, ceiling_frac=r["roofline"]["achieved"] / c["ceiling_GBps"])
         except Exception as e:      # noqa: BLE001 -- e.g. a smaller-memory part: report, do not lose the headline line
             res[tag] = {"error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.empty_cache()
@@ -581,10 +604,10 @@ def main():
         # and leaves with the ranks' exit code.
         argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
         one = a.one_device or os.environ.get("SML_ONE_DEVICE") == "1"
-        have = torch.cuda.device_count()          # (counting devices does not initialise HIP)
-        if not one and have < a.gpus:
+        have = launch.visible_gpus()              # (sysfs, no HIP / HSA call; None: unknown -- a rank's set_device then fails cleanly)
+        if not one and have is not None and have < a.gpus:
             raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s) (--one-device maps every rank to device 0: a test mode)" % (a.gpus, have))
-        code, _ = launch.spawn_ranks(argv, a.gpus, one_device=one)
+        code, _ = launch.spawn_ranks(argv, a.gpus, one_device=one, timeout=launch.job_timeout(a.job_timeout, 3600.0))
         raise SystemExit(code)
     launch.prepare_rank_env()           # (ranks started by torchrun: the IPC mode, before the first HIP call)
     rank = int(os.environ.get("RANK", "0"))

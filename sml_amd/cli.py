@@ -49,6 +49,8 @@ _COMMON = [
     # extension (the reference is single-device, main_yelp.py:125): run as N rank processes, one per GPU of this node.
     # The process that is given --gpus N > 1 starts the ranks itself (sml_amd.launch) and only relays rank 0's output
     ("--gpus", dict(type=int, default=1, help='N > 1: one rank process per GPU of this node (users row-sharded by owner)')),
+    ("--job_timeout", dict(type=float, default=None, help='--gpus N > 1: seconds before the launcher stops the ranks and exits 124 '
+                                                          '(default: SML_JOB_TIMEOUT_S, else no limit)')),
 ]
 
 _PER_DATASET = {
@@ -104,7 +106,8 @@ def main(which, argv=None):
         import sys
         script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "main_%s.py" % which)
         rest = list(sys.argv[1:] if argv is None else argv)
-        code, _ = launch.spawn_ranks([sys.executable, script] + rest, args.gpus, one_device=os.environ.get("SML_ONE_DEVICE") == "1")
+        code, _ = launch.spawn_ranks([sys.executable, script] + rest, args.gpus, one_device=os.environ.get("SML_ONE_DEVICE") == "1",
+                                      timeout=launch.job_timeout(args.job_timeout))
         raise SystemExit(code)
     if which == "yelp" and "LOCAL_RANK" not in os.environ:
         os.environ["CUDA_VISIBLE_DEVICES"] = str(args.cuda)      # reference main_yelp.py:125

@@ -289,8 +289,8 @@ class DistContext(object):
             # an order-independent fingerprint of the BITS (a float sum would hide a sign flip behind rounding)
             bits = x.view(torch.int32).to(torch.int64) if x.dtype == torch.float32 else x.view(torch.int16).to(torch.int64)
             sums.append(torch.stack([bits.sum(), (bits * bits % 1000003).sum()]))
-        t = torch.cat([torch.tensor([float(bad)], dtype=torch.float64, device=self.device)] +
-                      [v.to(torch.float64) for v in sums])
+        # (int64 end to end: a float64 cast is inexact above 2^53, which a 64M-element table's bit sum exceeds -- ADVICE r4)
+        t = torch.cat([torch.tensor([int(bad)], dtype=torch.int64, device=self.device)] + sums)
         hi, lo = t.clone(), -t
         self.dist.all_reduce(hi, op=self.dist.ReduceOp.MAX, group=self.group)
         self.dist.all_reduce(lo, op=self.dist.ReduceOp.MAX, group=self.group)
@@ -591,42 +591,60 @@ def shard_visibility_check(engine, dist, group=None, rounds=3, n=4096):
     dev = engine.device
     state = {"ok": True}
     probe = None
-    try:
-        probe = engine.peer_tensor((n,), torch.float32)
-        mine = probe.data_ptr() if dist.get_backend(group) == "threads" else engine.peer_export(probe.data_ptr())
-    except Exception:      # noqa: BLE001
-        state["ok"], mine = False, None
-    if not _vote(dist, group, dev, state["ok"]):
-        return False
-    got = _gather_objects(dist, mine, group)
-    ptrs, opened = [], []
-    try:
-        for q in range(world):
-            if q == rank or dist.get_backend(group) == "threads":
-                ptrs.append(got[q] if q != rank else probe.data_ptr())
-            else:
-                a = engine.peer_open(got[q]); opened.append(a); ptrs.append(a)
-    except Exception:      # noqa: BLE001
-        state["ok"] = False
-    if not _vote(dist, group, dev, state["ok"]):
-        return False
-    base = torch.arange(n, device=dev, dtype=torch.float32)
-    for k in range(rounds):
-        probe.copy_(base * (k + 1) + float(rank * 1000 + k))       # the owner's ordinary stores
-        torch.cuda.synchronize(dev)
-        dist.barrier(group=group)                                  # every owner has written round k
-        for q in range(world):
-            seen = engine.peer_read(ptrs[q], n)
-            state["ok"] = state["ok"] and bool(torch.equal(seen, base * (k + 1) + float(q * 1000 + k)))
-        torch.cuda.synchronize(dev)
-        dist.barrier(group=group)                                  # everybody has read round k before it is overwritten
-    ok = _vote(dist, group, dev, state["ok"])
-    for a in opened:
+    opened = []
+
+    def body():
+        nonlocal probe
         try:
-            engine.peer_close(a)
+            probe = engine.peer_tensor((n,), torch.float32)
+            mine = probe.data_ptr() if dist.get_backend(group) == "threads" else engine.peer_export(probe.data_ptr())
         except Exception:      # noqa: BLE001
-            pass
-    dist.barrier(group=group)
+            state["ok"], mine = False, None
+        if not _vote(dist, group, dev, state["ok"]):
+            return False
+        got = _gather_objects(dist, mine, group)
+        ptrs = []
+        try:
+            for q in range(world):
+                if q == rank or dist.get_backend(group) == "threads":
+                    ptrs.append(got[q] if q != rank else probe.data_ptr())
+                else:
+                    a = engine.peer_open(got[q]); opened.append(a); ptrs.append(a)
+        except Exception:      # noqa: BLE001
+            state["ok"] = False
+        if not _vote(dist, group, dev, state["ok"]):
+            return False
+        base = torch.arange(n, device=dev, dtype=torch.float32)
+        for k in range(rounds):
+            probe.copy_(base * (k + 1) + float(rank * 1000 + k))       # the owner's ordinary stores
+            torch.cuda.synchronize(dev)
+            dist.barrier(group=group)                                  # every owner has written round k
+            for q in range(world):
+                seen = engine.peer_read(ptrs[q], n)
+                state["ok"] = state["ok"] and bool(torch.equal(seen, base * (k + 1) + float(q * 1000 + k)))
+            torch.cuda.synchronize(dev)
+            dist.barrier(group=group)                                  # everybody has read round k before it is overwritten
+        return _vote(dist, group, dev, state["ok"])
+
+    # Every path out of body() ends with a VOTE all ranks took part in (collectives stay aligned); what this rank mapped or
+    # allocated is released here on every one of them -- mappings closed, then a barrier (no rank frees a probe somebody
+    # still has mapped), then the probe (a dedicated peer allocation, not a pooled torch tensor) -- as _PeerSetup.release
+    # does.  (the early returns leaked both for the rest of the process.)
+    ok = False
+    try:
+        ok = body()
+    finally:
+        for a in opened:
+            try:
+                engine.peer_close(a)
+            except Exception:      # noqa: BLE001
+                pass
+        dist.barrier(group=group)
+        if probe is not None:
+            try:
+                engine.peer_tensor_free(probe)
+            except Exception:      # noqa: BLE001
+                pass
     return ok
 
 

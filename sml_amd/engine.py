@@ -992,6 +992,14 @@ class HipEngine(object):
         t._sml_peer_ptr = ptr
         return t
 
+    def peer_tensor_free(self, t):
+        """Free a peer_tensor's allocation (the tensor must not be used afterwards; every rank must have unmapped it)."""
+        ptr = getattr(t, "_sml_peer_ptr", None)
+        if ptr is not None:
+            torch.cuda.synchronize(self.device)
+            t._sml_peer_ptr = None
+            self.peer_free(ptr)
+
     def peer_export(self, ptr):
         buf = ctypes.create_string_buffer(64)
         check(self.lib.sml_peer_export(ctypes.c_void_p(ptr), buf), "sml_peer_export")

@@ -2,7 +2,7 @@
 
 The reference is single-device (main_yelp.py:125: one `torch.cuda.set_device`); a job over several GPUs here is one
 process per GPU.  `bench.py --gpus N` and `main_yelp.py --gpus N` call spawn_ranks() BEFORE anything initialises HIP in
-the calling process (importing torch does not; `torch.cuda.device_count()` does not on this image): every child is a
+the calling process (importing torch does not; the GPU count comes from sysfs, `visible_gpus()`): every child is a
 fresh interpreter with
 
     RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT
@@ -10,14 +10,18 @@ fresh interpreter with
                                       one-shot peer exchange (and RCCL's own IPC) cannot map another rank's memory
     SML_LAUNCHED=1                    "this process is a rank": the child runs the workload instead of spawning again
 
-Rank 0's stdout is the job's stdout (bench.py: the ONE JSON line); the other ranks' stdout goes to stderr.  The first
-rank that exits non-zero ends the job: the others are terminated (by PID) and the launcher returns that code.
+Rank 0's stdout is the job's stdout (bench.py: the ONE JSON line; main_yelp.py: the training log, relayed line by line as
+it arrives); the other ranks' stdout goes to stderr.  The first rank that exits non-zero ends the job: the others are
+terminated (by the process groups this launcher created) and the launcher returns that code.  The ranks never outlive the
+launcher: try/finally + SIGTERM / SIGINT / SIGHUP handlers stop them, PR_SET_PDEATHSIG covers a SIGKILLed launcher, and
+`timeout` (bench.py --job-timeout, main_yelp.py --job_timeout, SML_JOB_TIMEOUT_S) bounds a job whose ranks hang.
 
 one_device=True (test mode, a 1-GPU box): every rank gets LOCAL_RANK=0 and SML_ONE_DEVICE=1 -- the ranks share device 0
 as separate processes (separate HIP contexts and queues, hipIpc mappings between them), with gloo carrying
 torch.distributed because RCCL refuses two ranks on one device.
 """
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -65,17 +69,95 @@ def backend():
     return "gloo" if one_device() else "nccl"
 
 
+def visible_gpus():
+    """GPU count of this node WITHOUT a HIP / HSA call: the KFD topology in sysfs (nodes with SIMDs are GPUs, narrowed
+    by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when they are plain lists).  None when the topology cannot be read.
+    (`torch.cuda.device_count()` stays off HIP only while its amdsmi path works; its fall-back is hipGetDeviceCount, which
+    initialises the runtime in the parent of the rank processes -- ADVICE r4.)"""
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as f:
+                for line in f:
+                    k, _, v = line.partition(" ")
+                    if k == "simd_count":
+                        n += int(v) > 0
+                        break
+    except (OSError, ValueError):
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            ids = [x for x in v.split(",") if x.strip() != ""]
+            n = min(n, len(ids))
+    return n
+
+
+def job_timeout(flag_value=None, default=None):
+    """Seconds a launched job may run: the command line's value, else SML_JOB_TIMEOUT_S, else `default`; <= 0: no limit."""
+    v = flag_value if flag_value is not None else os.environ.get("SML_JOB_TIMEOUT_S")
+    if v is None or v == "":
+        v = default
+    if v is None:
+        return None
+    v = float(v)
+    return v if v > 0 else None
+
+
+def _rank_preexec():
+    # in the child, before exec: a session (= process group) of its own, so that the launcher can signal the rank AND
+    # whatever it started with one killpg; and SIGKILL from the kernel if the launcher's thread dies first (a launcher
+    # that was SIGKILLed cannot clean up: PR_SET_PDEATHSIG = 1)
+    os.setsid()
+    try:
+        import ctypes
+        ctypes.CDLL(None, use_errno=True).prctl(1, signal.SIGKILL, 0, 0, 0)
+    except Exception:
+        pass
+
+
+def _stop(procs, grace=10.0):
+    """Terminate, then kill, every rank still alive -- by the exact process groups this launcher created."""
+    live = [p for p in procs if p.poll() is None]
+    for p in live:
+        try:
+            os.killpg(p.pid, signal.SIGTERM)
+        except (ProcessLookupError, PermissionError):
+            pass
+    deadline = time.time() + grace
+    for p in live:
+        try:
+            p.wait(timeout=max(0.1, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except (ProcessLookupError, PermissionError):
+                pass
+            p.wait()
+
+
 def spawn_ranks(argv, world, one_device=False, timeout=None, echo_stdout=True, env=None):
     """Run `argv` (a full command line, e.g. [sys.executable, "bench.py", ...]) as `world` rank processes.  Returns
-    (exit code, rank 0's stdout text).  Never imports or calls anything that initialises the GPU."""
+    (exit code, rank 0's stdout text).  Never imports or calls anything that initialises the GPU.
+
+    Rank 0's stdout is relayed LINE BY LINE as it arrives (a training log shows while the job runs) and collected for the
+    return value.  Whatever ends this call -- a rank failing, the time-out (exit code 124), SIGTERM / SIGINT / SIGHUP to the
+    launcher, an exception -- every rank's process group is terminated, then killed; a launcher that is SIGKILLed takes its
+    ranks with it through PR_SET_PDEATHSIG."""
     if world < 1:
         raise ValueError("world must be >= 1")
     port = free_port()
     procs = []
-    for r in range(world):
-        procs.append(subprocess.Popen(list(argv), env=rank_env(r, world, port, one_device, env),
-                                      stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1))
-    chunks = [[] for _ in procs]
+    chunks = [[] for _ in range(world)]
+    threads = []
+    old_handlers = {}
+
+    class _Signalled(Exception):
+        pass
+
+    def on_signal(signum, frame):
+        raise _Signalled(signum)
 
     def pump(r):
         for line in procs[r].stdout:
@@ -83,42 +165,46 @@ def spawn_ranks(argv, world, one_device=False, timeout=None, echo_stdout=True, e
             if r != 0:
                 sys.stderr.write("[rank %d] %s" % (r, line))
                 sys.stderr.flush()
-    threads = [threading.Thread(target=pump, args=(r,), daemon=True) for r in range(world)]
-    for t in threads:
-        t.start()
-    t0 = time.time()
+            elif echo_stdout:
+                sys.stdout.write(line)
+                sys.stdout.flush()
     code = 0
-    live = set(range(world))
-    while live:
-        for r in sorted(live):
-            rc = procs[r].poll()
-            if rc is None:
-                continue
-            live.discard(r)
-            if rc != 0 and code == 0:
-                code = rc
-                sys.stderr.write("[sml_amd.launch] rank %d exited with code %d: stopping the other ranks\n" % (r, rc))
-        if code != 0 or (timeout is not None and time.time() - t0 > timeout):
-            if code == 0:
-                code = 124
-                sys.stderr.write("[sml_amd.launch] time-out after %.0f s: stopping the ranks\n" % timeout)
+    try:
+        if threading.current_thread() is threading.main_thread():
+            for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+                old_handlers[sg] = signal.signal(sg, on_signal)
+        for r in range(world):
+            procs.append(subprocess.Popen(list(argv), env=rank_env(r, world, port, one_device, env), preexec_fn=_rank_preexec,
+                                          stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1))
+        threads = [threading.Thread(target=pump, args=(r,), daemon=True) for r in range(world)]
+        for t in threads:
+            t.start()
+        t0 = time.time()
+        live = set(range(world))
+        while live:
             for r in sorted(live):
-                procs[r].terminate()             # (exact PIDs this launcher started)
-            deadline = time.time() + 10.0
-            for r in sorted(live):
-                try:
-                    procs[r].wait(timeout=max(0.1, deadline - time.time()))
-                except subprocess.TimeoutExpired:
-                    procs[r].kill()
-                    procs[r].wait()
-            live.clear()
-            break
-        if live:
-            time.sleep(0.05)
-    for t in threads:
-        t.join(timeout=5.0)
-    out = "".join(chunks[0])
-    if echo_stdout and out:
-        sys.stdout.write(out)
-        sys.stdout.flush()
-    return code, out
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                live.discard(r)
+                if rc != 0 and code == 0:
+                    code = rc
+                    sys.stderr.write("[sml_amd.launch] rank %d exited with code %d: stopping the other ranks\n" % (r, rc))
+            if code != 0 or (timeout is not None and time.time() - t0 > timeout):
+                if code == 0:
+                    code = 124
+                    sys.stderr.write("[sml_amd.launch] time-out after %.0f s: stopping the ranks\n" % timeout)
+                break
+            if live:
+                time.sleep(0.05)
+    except _Signalled as e:
+        signum = int(e.args[0])
+        sys.stderr.write("[sml_amd.launch] signal %d: stopping the ranks\n" % signum)
+        code = 128 + signum
+    finally:
+        _stop(procs)                               # (no-op for ranks that have exited)
+        for sg, h in old_handlers.items():
+            signal.signal(sg, h)
+        for t in threads:
+            t.join(timeout=5.0)
+    return code, "".join(chunks[0])

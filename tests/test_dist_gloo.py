@@ -279,6 +279,11 @@ def test_bench_parent_makes_no_gpu_call_before_spawning(monkeypatch):
     monkeypatch.setattr(launch, "spawn_ranks", fake_spawn)
     monkeypatch.setattr(torch.cuda, "set_device", lambda *a, **k: (_ for _ in ()).throw(AssertionError("GPU call in the parent")))
     monkeypatch.setattr(torch.cuda, "is_available", lambda: (_ for _ in ()).throw(AssertionError("GPU call in the parent")))
+    # (torch.cuda.device_count() falls back to hipGetDeviceCount when amdsmi is unavailable -- the parent counts
+    # GPUs through sysfs instead)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: (_ for _ in ()).throw(AssertionError("GPU call in the parent")))
+    if hasattr(torch._C, "_cuda_getDeviceCount"):
+        monkeypatch.setattr(torch._C, "_cuda_getDeviceCount", lambda: (_ for _ in ()).throw(AssertionError("GPU call in the parent")))
     for k in ("SML_LAUNCHED", "WORLD_SIZE", "RANK", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "1", "--one-device"])
@@ -286,3 +291,85 @@ def test_bench_parent_makes_no_gpu_call_before_spawning(monkeypatch):
         bench.main()
     assert e.value.code == 0
     assert seen["world"] == 2 and seen["one_device"] is True and seen["argv"][2:] == ["--gpus", "2", "--steps", "1", "--one-device"]
+
+
+def _alive(pid):
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return False
+    except PermissionError:
+        return True
+    with open("/proc/%d/stat" % pid) as f:           # (a zombie is not alive)
+        return f.read().rsplit(")", 1)[1].split()[0] != "Z"
+
+
+def _wait_pids(base, world, timeout=60.0):
+    import time
+    t0 = time.time()
+    while time.time() - t0 < timeout:
+        if all(os.path.exists("%s.%d" % (base, r)) and os.path.getsize("%s.%d" % (base, r)) > 0 for r in range(world)):
+            return [int(open("%s.%d" % (base, r)).read()) for r in range(world)]
+        time.sleep(0.1)
+    raise AssertionError("ranks did not start")
+
+
+def test_launcher_time_out_ends_a_hung_job_and_leaves_no_rank_behind(tmp_path):
+    """a rank that hangs must not hold the job forever -- the time-out stops every rank (exit code 124)."""
+    import threading
+    from sml_amd import launch
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_launch_child.py")
+    base = str(tmp_path / "pid")
+    res = {}
+    th = threading.Thread(target=lambda: res.update(r=launch.spawn_ranks([sys.executable, child, "--hang", base], 2, echo_stdout=False, timeout=20)))
+    th.start()
+    pids = _wait_pids(base, 2)
+    th.join(timeout=90)
+    assert not th.is_alive()
+    code, out = res["r"]
+    assert code == 124 and "first line of a job that hangs" in out
+    assert not any(_alive(p) for p in pids)
+
+
+@pytest.mark.parametrize("sig", ["TERM", "KILL"])
+def test_launcher_that_is_signalled_takes_its_ranks_with_it(tmp_path, sig):
+    """ADVICE r4 (medium): SIGTERM to the launcher (a scheduler, a test harness's time-out) -> its handler stops the ranks;
+    SIGKILL -> PR_SET_PDEATHSIG does.  Rank 0's output has been relayed line by line before that (not buffered to the end)."""
+    import signal
+    import subprocess
+    import time
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_launch_child.py")
+    base = str(tmp_path / "pid")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = ("import sys; sys.path.insert(0, %r); from sml_amd import launch; "
+            "code, _ = launch.spawn_ranks([sys.executable, %r, '--hang', %r], 2); sys.exit(code)" % (repo, child, base))
+    p = subprocess.Popen([sys.executable, "-c", prog], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    try:
+        pids = _wait_pids(base, 2)
+        assert p.stdout.readline().strip() == "first line of a job that hangs"      # streamed while the job still runs
+        assert all(_alive(q) for q in pids)
+        p.send_signal(signal.SIGTERM if sig == "TERM" else signal.SIGKILL)
+        rc = p.wait(timeout=60)
+        assert rc == (128 + signal.SIGTERM if sig == "TERM" else -signal.SIGKILL)
+        t0 = time.time()
+        while any(_alive(q) for q in pids) and time.time() - t0 < 30:
+            time.sleep(0.1)
+        assert not any(_alive(q) for q in pids)
+    finally:
+        if p.poll() is None:
+            p.kill()
+        for r in range(2):
+            f = "%s.%d" % (base, r)
+            if os.path.exists(f):
+                try:
+                    os.kill(int(open(f).read()), signal.SIGKILL)
+                except (ProcessLookupError, ValueError):
+                    pass
+
+
+def test_visible_gpus_reads_sysfs_and_never_calls_hip(monkeypatch):
+    from sml_amd import launch
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: (_ for _ in ()).throw(AssertionError("GPU call")))
+    n = launch.visible_gpus()
+    assert n is None or n >= 0
+    assert launch.job_timeout(None, 3600.0) == 3600.0 and launch.job_timeout(0, 5.0) is None and launch.job_timeout("7") == 7.0

@@ -572,6 +572,96 @@ def test_peer_setup_leaves_a_failing_path_on_every_rank_together_and_releases_it
         assert e0.calls.count("check") >= 2 and len(e0.closed) == 2
 
 
+@pytest.mark.parametrize("case", ["all_fine", "one_rank_fails_to_open", "stale_read"])
+def test_shard_visibility_check_releases_mappings_and_probe_on_every_path(case):
+    """sml_amd.dist.shard_visibility_check: whichever vote ends it -- an open that failed on one rank, a stale
+    read, or success -- every rank closes the mappings it opened and frees its probe allocation, all ranks together."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _thread_group import run_ranks
+    from sml_amd import dist as SD
+
+    class Procs(object):
+        def __init__(self, g):
+            self.g = g
+
+        def __getattr__(self, k):
+            return getattr(self.g, k)
+
+        def get_backend(self, group=None):
+            return "gloo"
+
+    class Eng(_FakePeerEngine):
+        def __init__(self, rank, **kw):
+            super().__init__(**kw)
+            self.rank, self.probe, self.freed_probes = rank, None, 0
+
+        def peer_tensor(self, shape, dtype=torch.float32):
+            self.probe = torch.zeros(shape, dtype=dtype)
+            return self.probe
+
+        def peer_tensor_free(self, t):
+            assert t is self.probe
+            self.freed_probes += 1
+
+        def peer_export(self, ptr):
+            return ("probe of rank %d" % self.rank).encode().ljust(64, b" ")
+
+        def peer_open(self, handle):
+            self._step("open")
+            return 0x9000 + int(handle.decode().split()[3])           # "address" that names the owner rank
+
+        def peer_read(self, ptr, n):
+            owner = ptr - 0x9000 if 0x9000 <= ptr < 0x9100 else self.rank
+            t = BOARD[owner].clone()
+            return t * 0 if (case == "stale_read" and self.rank == 1 and owner == 0) else t
+
+    BOARD = {}
+    monkey = torch.cuda.synchronize
+    torch.cuda.synchronize = lambda *a, **k: None
+    try:
+        def rank_fn(rank, group):
+            e = Eng(rank, fail_at="open" if case == "one_rank_fails_to_open" and rank == 1 else None)
+            orig = e.peer_tensor
+
+            def tracked(shape, dtype=torch.float32):
+                t = orig(shape, dtype)
+                BOARD[rank] = t
+                return t
+            e.peer_tensor = tracked
+            return SD.shard_visibility_check(e, Procs(group), None, rounds=2, n=64), e
+        (ok0, e0), (ok1, e1) = run_ranks(2, rank_fn)
+    finally:
+        torch.cuda.synchronize = monkey
+    assert ok0 is ok1 is (case == "all_fine")
+    assert e0.freed_probes == 1 and e1.freed_probes == 1
+    assert len(e0.closed) == 1 and len(e1.closed) == (0 if case == "one_rank_fails_to_open" else 1)
+
+
+def test_check_exchange_fingerprints_stay_exact_above_2_to_the_53():
+    """DistContext.check_exchange: the bit fingerprints travel as int64 -- a float64 cast cannot tell two sums
+    above 2^53 that differ by one."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _thread_group import run_ranks
+    from sml_amd import dist as SD
+
+    def rank_fn(rank, group):
+        ctx = SD.DistContext(group, torch.device("cpu"))
+        ctx.mode = "torch"
+        big = torch.full((1 << 23,), 2.0 ** 31 - 1, dtype=torch.float32)       # bit pattern 0x4f000000: the sum passes 2^53
+        x = big.clone()
+        ctx.check_exchange(None, "equal replicas", replicas=[x])
+        if rank == 1:
+            x[5] = torch.tensor([x[5]]).view(torch.int32).add(1).view(torch.float32)[0]     # one ulp on one rank
+        try:
+            ctx.check_exchange(None, "one ulp apart", replicas=[x])
+        except RuntimeError as e:
+            return "differ" in str(e)
+        return False
+    assert run_ranks(2, rank_fn) == [True, True]
+
+
 def test_zipf_head_rows_of_the_sharded_bare_step():
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_for_head", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
