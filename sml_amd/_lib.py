@@ -158,12 +158,23 @@ def load():
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:
         raise RuntimeError("cannot load %s: %s" % (LIB_PATH, e))
+    _bind(lib)
+    _lib = lib
+    return lib
+
+
+def _bind(lib):
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
     return lib
+
+
+def load_other(path):
+    """Another build of the same C ABI (tests: the library compiled WITH the library-sort reference of the index
+    preparation, tests/build_reference.py).  Never used by the product: HipEngine(lib=...) is a test hook."""
+    return _bind(ctypes.CDLL(path))
 
 
 class SmlError(RuntimeError):

@@ -1,6 +1,8 @@
 // C ABI of libsml_hip.so (see include/sml_hip.h): context, scratch, per-epoch launch loops.
 #include <hip/hip_runtime.h>
+#ifdef SML_TEST_PREP_REFERENCE     // (test build only, tests/build_reference.py: the library-sort reference of the index preparation)
 #include <hipcub/hipcub.hpp>
+#endif
 #include <rccl/rccl.h>      // types only: the functions are bound at run time from the loaded librccl
 #include <dlfcn.h>
 
@@ -158,6 +160,9 @@ struct IndexSet {
     Buf<uint8_t> uniq;
     Buf<uint32_t> slot_info;           // records mode, by hand: per slot, "once" or the position of its run's record (SmlFusedUpdate)
     int64_t slot_stride = 0;           // ... slots per batch; 0: this set has none
+    // MF stage, distinct-row form (SmlDense): records by scratch row, distinct rows per (batch, table), per-tile headers / entry blocks / spill
+    Buf<SmlRun> dense_rec; Buf<int> dense_n; Buf<SmlTileHdr> tile_hdr; Buf<uint2> tile_ent, tile_spill; Buf<int> spill_cnt;
+    bool dense = false; int tiles_cap = 0;
     Buf<int> off_u, off_i, n_sel;
     // index_prep.hip (the by-hand preparation): tile histograms, bucket offsets / counts, run counts, oversized buckets
     Buf<uint32_t> hist_u, hist_i, bko_u, bko_i, bkc_u, bkc_i, large, medium;
@@ -177,6 +182,7 @@ struct IndexSet {
         rec_u.release(); rec_i.release(); runs_u.release(); runs_i.release();
         hist_u.release(); hist_i.release(); bko_u.release(); bko_i.release(); bkc_u.release(); bkc_i.release(); large.release(); medium.release();
         cnt_u.release(); cnt_i.release(); stage_u.release(); stage_i.release(); rank_viol.release();
+        dense_rec.release(); dense_n.release(); tile_hdr.release(); tile_ent.release(); tile_spill.release(); spill_cnt.release();
         uniq.release(); slot_info.release(); heads_u.release(); heads_i.release(); hot_list.release(); hot_count.release(); off_u.release(); off_i.release(); n_sel.release();
         cub_tmp.release();
         if (max_len_host) { g_graveyard.park_host(max_len_host); max_len_host = nullptr; }
@@ -403,61 +409,6 @@ void peer_step(sml_ctx* c, int kind, int incr, SmlPeerPush* push, SmlPeerPoll* p
     poll->err = c->peer.err;
 }
 
-// selection predicate over sorted positions: q starts a run of at least two equal keys
-template <typename K>
-struct DupHead {
-    const K* keys; int64_t n;
-    __host__ __device__ bool operator()(const uint32_t& q) const {
-        const K k = keys[q];
-        return (q == 0 || keys[q - 1] != k) && ((int64_t)q + 1 < n && keys[q + 1] == k);
-    }
-};
-// ... or any run (several GPUs: every item run of the job's global list is applied by the run kernel, also the
-// single-occurrence ones -- an in-place update on one rank would leave the other replicas behind)
-template <typename K>
-struct AnyHead {
-    const K* keys; int64_t n; K sent;       // sent != 0: keys whose row bits are all ones are placeholders, never a run
-    __host__ __device__ bool operator()(const uint32_t& q) const {
-        const K k = keys[q];
-        if (sent && (k & sent) == sent) return false;
-        return q == 0 || keys[q - 1] != k;
-    }
-};
-template <typename K>
-int select_all_heads(IndexSet* c, const void* keys, int64_t n, uint32_t* heads, int* n_sel, hipStream_t st, uint64_t sent = 0) {
-    hipcub::CountingInputIterator<uint32_t> pos(0u);
-    AnyHead<K> pred{reinterpret_cast<const K*>(keys), n, (K)sent};
-    size_t tmp = 0;
-    HIPCHK(hipcub::DeviceSelect::If(nullptr, tmp, pos, heads, n_sel, (int)n, pred, st));
-    HIPCHK(c->cub_tmp.ensure(tmp + 256));
-    HIPCHK(hipcub::DeviceSelect::If(c->cub_tmp.p, tmp, pos, heads, n_sel, (int)n, pred, st));
-    return SML_OK;
-}
-template <typename K>
-int select_dup_heads(IndexSet* c, const void* keys, int64_t n, uint32_t* heads, int* n_sel, hipStream_t st) {
-    hipcub::CountingInputIterator<uint32_t> pos(0u);
-    DupHead<K> pred{reinterpret_cast<const K*>(keys), n};
-    size_t tmp = 0;
-    HIPCHK(hipcub::DeviceSelect::If(nullptr, tmp, pos, heads, n_sel, (int)n, pred, st));
-    HIPCHK(c->cub_tmp.ensure(tmp + 256));
-    HIPCHK(hipcub::DeviceSelect::If(c->cub_tmp.p, tmp, pos, heads, n_sel, (int)n, pred, st));
-    return SML_OK;
-}
-
-template <typename K>
-int sort_pairs(IndexSet* c, int64_t n, int64_t n_items, int end_u, int end_i, hipStream_t st, bool do_users = true) {
-    K* ku = reinterpret_cast<K*>(c->key_u.p); K* ku2 = reinterpret_cast<K*>(c->key_u2.p);
-    K* ki = reinterpret_cast<K*>(c->key_i.p); K* ki2 = reinterpret_cast<K*>(c->key_i2.p);
-    size_t tmp1 = 0, tmp2 = 0;
-    if (do_users) HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp1, ku, ku2, c->val_u.p, c->val_u2.p, (int)n, 0, end_u, st));
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, ki, ki2, c->val_i.p, c->val_i2.p, (int)n_items, 0, end_i, st));
-    size_t tmp = tmp1 > tmp2 ? tmp1 : tmp2;
-    HIPCHK(c->cub_tmp.ensure(tmp + 256));
-    if (do_users) HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tmp, ku, ku2, c->val_u.p, c->val_u2.p, (int)n, 0, end_u, st));
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tmp, ki, ki2, c->val_i.p, c->val_i2.p, (int)n_items, 0, end_i, st));
-    return SML_OK;
-}
-
 // SML_PREP=cub keeps the library sort (A/B tests); default: index_prep.hip
 static bool prep_by_hand() {
     const char* e = getenv("SML_PREP");          // (read per call: the A/B test flips it inside one process)
@@ -470,9 +421,9 @@ static bool prep_by_hand() {
 // rank's own occurrences of head rows; no users) -- sh, rows_cap.  See occ_of in index_prep.hip.
 int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_tiles, int64_t n_user, int64_t n_item,
                bool dups, hipStream_t st, const sml_batch_plan* plan, int mode = 0, const sml_bare_exchange* bx = nullptr,
-               const sml_bare_shard* sh = nullptr, int64_t rows_cap = 0) {
+               const sml_bare_shard* sh = nullptr, int64_t rows_cap = 0, bool want_dense = false) {
     const int64_t nb = plan ? plan->n_batches : (n + batch - 1) / batch;
-    c->by_hand = true; c->slot_stride = 0;
+    c->by_hand = true; c->slot_stride = 0; c->dense = false;
     if (n == 0) { c->n = 0; c->batch = batch; c->triples = tri; return SML_OK; }
     const int W = mode == 1 ? bx->world : (mode == 2 ? sh->world : 1);
     const int nis = 2 * W;                                  // item streams per tile
@@ -524,6 +475,16 @@ int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
             c->slot_stride = ioff_max + 2 * (int64_t)batch;
             HIPCHK(c->slot_info.ensure((size_t)nb * c->slot_stride));
             a.slot_info = c->slot_info.p; a.slot_stride = c->slot_stride;
+            // distinct-row form: both lists must be ONE bucket each (the numbering is the bucket's), i.e. 2 * batch <= SML_PREP_SMALL
+            if (want_dense && pad_tiles && 2 * (int64_t)batch <= SML_PREP_SMALL) {
+                c->tiles_cap = wg_tiles(batch, 1) + wg_tiles(2 * batch, 1);
+                HIPCHK(c->dense_rec.ensure((size_t)nb * c->slot_stride)); HIPCHK(c->dense_n.ensure((size_t)2 * nb));
+                HIPCHK(c->tile_hdr.ensure((size_t)nb * c->tiles_cap)); HIPCHK(c->tile_ent.ensure((size_t)nb * c->tiles_cap * SML_TILE_ENT));
+                HIPCHK(c->tile_spill.ensure((size_t)nb * 3 * batch)); HIPCHK(c->spill_cnt.ensure((size_t)nb));
+                HIPCHK(hipMemsetAsync(c->spill_cnt.p, 0, (size_t)nb * sizeof(int), st));
+                a.dense = 1; a.dense_rec = c->dense_rec.p; a.dense_n = c->dense_n.p; a.tile_hdr = c->tile_hdr.p; a.tile_ent = c->tile_ent.p;
+                a.tile_spill = c->tile_spill.p; a.spill_cnt = c->spill_cnt.p; a.tiles_cap = c->tiles_cap;
+            }
         }
     }
     for (int T = 0; T < 2; ++T) {
@@ -569,6 +530,8 @@ int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
         c->rank_probed = true;
     }
     { const char* rk = getenv("SML_PREP_RANK"); a.rank_viol = (rk && !strcmp(rk, "ballot")) ? nullptr : c->rank_viol.p; }
+    if (a.dense && !(a.t[0].nbk == 1 && a.t[1].nbk == 1)) a.dense = 0;       // (wide rows forced more buckets: per-occurrence form)
+    c->dense = a.dense != 0;
     HIPCHK(sml_launch_prep(a, narrow ? 4 : 8, st));
     if (dups) {
         if (!c->max_len_host) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->max_len_host), sizeof(int), hipHostMallocDefault));
@@ -580,158 +543,40 @@ int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
     return SML_OK;
 }
 
-// sort every batch's occurrences by row (stable): users [n], items [2n]; then one run record per
-// sorted position.  n_user / n_item (0: unknown) bound the row index so the keys can be 32-bit.
-// With `dups` the duplicated runs are also compacted (stable) with their per-batch ranges, and every
-// occurrence gets its "row occurs once in this batch" mark -- all on the device, no host round trip.
+#ifdef SML_TEST_PREP_REFERENCE
+#include "../../tests/csrc/prep_cub_reference.inc"
+#endif
+
+// The index lists of an epoch: per batch the occurrences sorted by row (stable), run records, "row occurs once" marks -- all by
+// index_prep.hip (prep_epoch).  SML_PREP=cub asks for the library-sort REFERENCE implementation instead: that lives under
+// tests/csrc and is compiled only into the test build of this library (tests/build_reference.py, -DSML_TEST_PREP_REFERENCE);
+// the product has no library sort and says so.
 int sort_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_tiles, int64_t n_user, int64_t n_item,
-               bool dups, hipStream_t st, const sml_batch_plan* plan = nullptr, const sml_bare_exchange* bx = nullptr) {
+               bool dups, hipStream_t st, const sml_batch_plan* plan = nullptr, const sml_bare_exchange* bx = nullptr, bool want_dense = false) {
     // bx (bare step on several GPUs): the item lists are the JOB's -- every rank's 2n item occurrences
-    if (prep_by_hand() && (!bx || dups)) return prep_epoch(c, tri, n, batch, pad_tiles, n_user, n_item, dups, st, plan, bx ? 1 : 0, bx);
-    c->by_hand = false; c->slot_stride = 0;
-    const int64_t n_items = bx ? (int64_t)bx->world * 2 * n : 2 * n;
-    const int64_t seg_i = bx ? (int64_t)bx->world * 2 * batch : (int64_t)2 * batch;       // item occurrences of a full batch
-    if (n_items > 0x7fffffff) return fail(SML_EINVAL, "index preparation", "too many item occurrences in one epoch");
-    HIPCHK(c->key_u.ensure((size_t)n + 1)); HIPCHK(c->key_u2.ensure((size_t)n + 1));
-    HIPCHK(c->val_u.ensure((size_t)n + 1)); HIPCHK(c->val_u2.ensure((size_t)n + 1));
-    HIPCHK(c->key_i.ensure((size_t)n_items + 1)); HIPCHK(c->key_i2.ensure((size_t)n_items + 1));
-    HIPCHK(c->val_i.ensure((size_t)n_items + 1)); HIPCHK(c->val_i2.ensure((size_t)n_items + 1));
-    const int64_t nb = plan ? plan->n_batches : (n + batch - 1) / batch;
-    const int* boff = plan ? plan->batch_off_dev : nullptr;
-    if (n == 0) { c->n = 0; c->batch = batch; c->triples = tri; return SML_OK; }
-    const int bb = ceil_log2(nb + 1);
-    const int rbu = n_user > 0 ? ceil_log2(n_user) : 32, rbi = n_item > 0 ? ceil_log2(n_item) : 32;
-    const bool narrow = bb + rbu <= 32 && bb + rbi <= 32;
-    c->key_bytes = narrow ? 4 : 8;
-    c->row_bits_u = narrow ? rbu : 32; c->row_bits_i = narrow ? rbi : 32;
-    HIPCHK(sml_launch_build_keys(c->key_bytes, tri, n, batch, pad_tiles, c->row_bits_u, c->row_bits_i, c->key_u.p, c->val_u.p,
-                                 c->key_i.p, c->val_i.p, boff, (int)nb, st));
-    if (bx) HIPCHK(sml_launch_build_item_keys_x(c->key_bytes, bx->items_all, bx->world, n, batch, c->row_bits_i, c->key_i.p, c->val_i.p, st));
-    int rc = narrow ? sort_pairs<uint32_t>(c, n, n_items, c->row_bits_u + bb, c->row_bits_i + bb, st)
-                    : sort_pairs<uint64_t>(c, n, n_items, 32 + bb, 32 + bb, st);
-    if (rc) return rc;
-    if (!dups) {
-        // one record per sorted position (the MF stage's batches are small: no compaction)
-        HIPCHK(c->rec_u.ensure((size_t)n)); HIPCHK(c->rec_i.ensure((size_t)2 * n));
-        HIPCHK(sml_launch_mark_runs(c->key_bytes, c->key_u2.p, c->val_u2.p, n, c->row_bits_u, c->rec_u.p, nullptr, nullptr, 0, 0, st));
-        HIPCHK(sml_launch_mark_runs(c->key_bytes, c->key_i2.p, c->val_i2.p, 2 * n, c->row_bits_i, c->rec_i.p, nullptr, nullptr, 0, 0, st));
-    } else {
-        // unique marks for the in-place pass; duplicated-run heads selected by position (no per-position
-        // records: the predicate reads the sorted keys), then one record per selected head
-        HIPCHK(c->uniq.ensure((size_t)3 * nb * batch));
-        const int64_t max_heads_i = bx ? n_items : n;      // dup heads: at most every second occurrence; all heads: every one
-        HIPCHK(c->heads_u.ensure((size_t)n / 2 + 8)); HIPCHK(c->heads_i.ensure((size_t)max_heads_i + 8));
-        HIPCHK(c->runs_u.ensure((size_t)n / 2 + 8)); HIPCHK(c->runs_i.ensure((size_t)max_heads_i + 8));
-        HIPCHK(c->off_u.ensure((size_t)nb + 1)); HIPCHK(c->off_i.ensure((size_t)nb + 1)); HIPCHK(c->n_sel.ensure(4));
-        HIPCHK(hipMemsetAsync(c->uniq.p, 1, (size_t)3 * nb * batch, st));
-        HIPCHK(sml_launch_mark_unique(c->key_bytes, c->key_u2.p, c->val_u2.p, n, c->row_bits_u, c->uniq.p, (int64_t)3 * batch, st));
-        if (bx) HIPCHK(sml_launch_zero_item_marks(c->uniq.p, n, batch, st));     // items: never in place
-        else HIPCHK(sml_launch_mark_unique(c->key_bytes, c->key_i2.p, c->val_i2.p, 2 * n, c->row_bits_i, c->uniq.p, (int64_t)3 * batch, st));
-        rc = narrow ? select_dup_heads<uint32_t>(c, c->key_u2.p, n, c->heads_u.p, c->n_sel.p, st)
-                    : select_dup_heads<uint64_t>(c, c->key_u2.p, n, c->heads_u.p, c->n_sel.p, st);
-        if (rc) return rc;
-        if (bx) rc = narrow ? select_all_heads<uint32_t>(c, c->key_i2.p, n_items, c->heads_i.p, c->n_sel.p + 1, st)
-                            : select_all_heads<uint64_t>(c, c->key_i2.p, n_items, c->heads_i.p, c->n_sel.p + 1, st);
-        else rc = narrow ? select_dup_heads<uint32_t>(c, c->key_i2.p, n_items, c->heads_i.p, c->n_sel.p + 1, st)
-                         : select_dup_heads<uint64_t>(c, c->key_i2.p, n_items, c->heads_i.p, c->n_sel.p + 1, st);
-        if (rc) return rc;
-        HIPCHK(hipMemsetAsync(c->n_sel.p + 2, 0, sizeof(int), st));
-        // hot rows: with large batches a popular item collects thousands of occurrences per batch; such runs
-        // are listed per batch here and reduced by whole workgroups.  (The list is sized for the most hot runs a
-        // batch's occurrences can form; beyond SML_HOT_MAXCAP the path is off and wavefronts sum the long runs.)
-        const int64_t hot_cap64 = (batch + seg_i) / SML_HOT + 8;
-        const int hot_cap = (int)(hot_cap64 < 0x7fffffff ? hot_cap64 : 0x7fffffff);
-        c->hot_cap = (batch >= 4096 && hot_cap <= SML_HOT_MAXCAP) ? hot_cap : 0;
-        if (c->hot_cap) {
-            HIPCHK(c->hot_list.ensure((size_t)nb * c->hot_cap * 3)); HIPCHK(c->hot_count.ensure((size_t)nb));
-            HIPCHK(hipMemsetAsync(c->hot_count.p, 0, (size_t)nb * sizeof(int), st));
-        }
-        uint32_t* hl = c->hot_cap ? c->hot_list.p : nullptr;
-        HIPCHK(sml_launch_make_runs(c->key_bytes, c->key_u2.p, c->val_u2.p, n, c->row_bits_u, c->heads_u.p, c->n_sel.p, n / 2, c->runs_u.p,
-                                    c->n_sel.p + 2, (int64_t)batch, 0, hl, c->hot_count.p, c->hot_cap, st));
-        HIPCHK(sml_launch_make_runs(c->key_bytes, c->key_i2.p, c->val_i2.p, n_items, c->row_bits_i, c->heads_i.p, c->n_sel.p + 1, max_heads_i, c->runs_i.p,
-                                    c->n_sel.p + 2, seg_i, 1, hl, c->hot_count.p, c->hot_cap, st));
-        // the longest run of the epoch travels to the host: an epoch KNOWN to have no hot rows skips the hot-row
-        // kernels altogether (the epoch call queries this event, it never waits for it)
-        if (!c->max_len_host) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->max_len_host), sizeof(int), hipHostMallocDefault));
-        if (!c->ready) HIPCHK(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
-        HIPCHK(hipMemcpyAsync(c->max_len_host, c->n_sel.p + 2, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipEventRecord(c->ready, st));
-        HIPCHK(sml_launch_batch_offsets(c->runs_u.p, c->n_sel.p, (int)nb, (int64_t)batch, c->off_u.p, st));
-        HIPCHK(sml_launch_batch_offsets(c->runs_i.p, c->n_sel.p + 1, (int)nb, seg_i, c->off_i.p, st));
-    }
-    c->n = n; c->batch = batch; c->triples = tri; c->world = bx ? bx->world : 1;
-    return SML_OK;
+    if (prep_by_hand()) return prep_epoch(c, tri, n, batch, pad_tiles, n_user, n_item, dups, st, plan, bx ? 1 : 0, bx, nullptr, 0, want_dense);
+#ifdef SML_TEST_PREP_REFERENCE
+    return sort_epoch_reference(c, tri, n, batch, pad_tiles, n_user, n_item, dups, st, plan, bx);
+#else
+    return fail(SML_ESTATE, "index preparation", "SML_PREP=cub: the library-sort reference is test infrastructure (tests/build_reference.py), not in this library");
+#endif
 }
 
 // Index lists of the item-sharded bare step.  A: this rank's users (as in sort_epoch) and the JOB's occurrences of the
 // tail rows this rank owns (every run is applied by the run kernel).  Bset: this rank's own occurrences of head rows
-// (summed into the dense partial).  Occurrences that do not belong to a list carry the batch's sentinel row.
+// (summed into the dense partial).
 int sort_epoch_sharded(IndexSet* A, IndexSet* Bset, const int64_t* tri, int64_t n, int batch, int64_t n_user, const sml_bare_shard* sh,
                        int64_t rows_cap, hipStream_t st) {
-    const int W = sh->world;
-    const int64_t nb = (n + batch - 1) / batch;
     if (prep_by_hand()) {
         int rc = prep_epoch(A, tri, n, batch, 0, n_user, 0, true, st, nullptr, 2, nullptr, sh, rows_cap);
         if (!rc && sh->head_rows > 0) rc = prep_epoch(Bset, tri, n, batch, 0, n_user, 0, true, st, nullptr, 3, nullptr, sh, rows_cap);
         return rc;
     }
-    A->by_hand = false; Bset->by_hand = false;
-    const int bb = ceil_log2(nb + 1);
-    for (int pass = 0; pass < 2; ++pass) {
-        IndexSet* c = pass ? Bset : A;
-        if (pass == 1 && sh->head_rows == 0) break;
-        const int64_t n_items = pass ? 2 * n : (int64_t)W * 2 * n;
-        const int64_t seg_i = pass ? (int64_t)2 * batch : (int64_t)W * 2 * batch;
-        if (n_items > 0x7fffffff) return fail(SML_EINVAL, "index preparation", "too many item occurrences in one epoch");
-        if (!pass) {
-            HIPCHK(c->key_u.ensure((size_t)n + 1)); HIPCHK(c->key_u2.ensure((size_t)n + 1));
-            HIPCHK(c->val_u.ensure((size_t)n + 1)); HIPCHK(c->val_u2.ensure((size_t)n + 1));
-        }
-        HIPCHK(c->key_i.ensure((size_t)n_items + 1)); HIPCHK(c->key_i2.ensure((size_t)n_items + 1));
-        HIPCHK(c->val_i.ensure((size_t)n_items + 1)); HIPCHK(c->val_i2.ensure((size_t)n_items + 1));
-        const int rbu = ceil_log2(n_user > 0 ? n_user : 1);
-        const int rbi = ceil_log2((pass ? sh->head_rows : sh->shard_rows) + 1);
-        const bool narrow = bb + rbi <= 32 && (pass || bb + rbu <= 32);
-        c->key_bytes = narrow ? 4 : 8;
-        c->row_bits_u = narrow ? rbu : 32; c->row_bits_i = narrow ? rbi : 32;
-        if (!pass) HIPCHK(sml_launch_build_keys(c->key_bytes, tri, n, batch, 0, c->row_bits_u, c->row_bits_i, c->key_u.p, c->val_u.p,
-                                                c->key_i.p, c->val_i.p, nullptr, (int)nb, st));      // (its item keys are overwritten next)
-        SmlShardKeys sk;
-        sk.mode = pass ? 2 : 1; sk.rank = sh->rank; sk.head_rows = sh->head_rows; sk.shard_rows = sh->shard_rows; sk.rows_cap = rows_cap;
-        HIPCHK(sml_launch_build_item_keys_sh(c->key_bytes, sh->items_all, W, n, batch, c->row_bits_i, sk, c->key_i.p, c->val_i.p, st));
-        int rc = narrow ? sort_pairs<uint32_t>(c, n, n_items, c->row_bits_u + bb, c->row_bits_i + bb, st, !pass)
-                        : sort_pairs<uint64_t>(c, n, n_items, 32 + bb, 32 + bb, st, !pass);
-        if (rc) return rc;
-        HIPCHK(c->heads_i.ensure((size_t)n_items + 8)); HIPCHK(c->runs_i.ensure((size_t)n_items + 8));
-        HIPCHK(c->off_u.ensure((size_t)nb + 1)); HIPCHK(c->off_i.ensure((size_t)nb + 1)); HIPCHK(c->n_sel.ensure(4));
-        HIPCHK(hipMemsetAsync(c->n_sel.p, 0, 4 * sizeof(int), st));
-        if (!pass) {
-            HIPCHK(c->uniq.ensure((size_t)3 * nb * batch));
-            HIPCHK(c->heads_u.ensure((size_t)n / 2 + 8)); HIPCHK(c->runs_u.ensure((size_t)n / 2 + 8));
-            HIPCHK(hipMemsetAsync(c->uniq.p, 1, (size_t)3 * nb * batch, st));
-            HIPCHK(sml_launch_mark_unique(c->key_bytes, c->key_u2.p, c->val_u2.p, n, c->row_bits_u, c->uniq.p, (int64_t)3 * batch, st));
-            HIPCHK(sml_launch_zero_item_marks(c->uniq.p, n, batch, st));     // items: never in place
-            rc = narrow ? select_dup_heads<uint32_t>(c, c->key_u2.p, n, c->heads_u.p, c->n_sel.p, st)
-                        : select_dup_heads<uint64_t>(c, c->key_u2.p, n, c->heads_u.p, c->n_sel.p, st);
-            if (rc) return rc;
-            HIPCHK(sml_launch_make_runs(c->key_bytes, c->key_u2.p, c->val_u2.p, n, c->row_bits_u, c->heads_u.p, c->n_sel.p, n / 2, c->runs_u.p,
-                                        c->n_sel.p + 2, (int64_t)batch, 0, nullptr, nullptr, 0, st));
-            HIPCHK(sml_launch_batch_offsets(c->runs_u.p, c->n_sel.p, (int)nb, (int64_t)batch, c->off_u.p, st));
-        } else {
-            HIPCHK(hipMemsetAsync(c->off_u.p, 0, (size_t)(nb + 1) * sizeof(int), st));      // no user runs in this list
-        }
-        const uint64_t sent = narrow ? ((1ull << rbi) - 1) : 0xffffffffull;
-        rc = narrow ? select_all_heads<uint32_t>(c, c->key_i2.p, n_items, c->heads_i.p, c->n_sel.p + 1, st, sent)
-                    : select_all_heads<uint64_t>(c, c->key_i2.p, n_items, c->heads_i.p, c->n_sel.p + 1, st, sent);
-        if (rc) return rc;
-        HIPCHK(sml_launch_make_runs(c->key_bytes, c->key_i2.p, c->val_i2.p, n_items, c->row_bits_i, c->heads_i.p, c->n_sel.p + 1, n_items, c->runs_i.p,
-                                    c->n_sel.p + 2, seg_i, 1, nullptr, nullptr, 0, st));
-        HIPCHK(sml_launch_batch_offsets(c->runs_i.p, c->n_sel.p + 1, (int)nb, seg_i, c->off_i.p, st));
-        c->hot_cap = 0;
-        c->n = -1;        // (not a list sml_embed_loss_sgd_epoch may reuse)
-    }
-    return SML_OK;
+#ifdef SML_TEST_PREP_REFERENCE
+    return sort_epoch_sharded_reference(A, Bset, tri, n, batch, n_user, sh, rows_cap, st);
+#else
+    return fail(SML_ESTATE, "index preparation", "SML_PREP=cub: the library-sort reference is test infrastructure (tests/build_reference.py), not in this library");
+#endif
 }
 
 }  // namespace
@@ -880,7 +725,12 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
     const int fns = fwd_split(wg_tiles(batch, 1) + wg_tiles(2 * batch, 1)), bsplit = bwd_split(wg_tiles(batch, 1) + wg_tiles(2 * batch, 1));
     HIPCHK(ctx->loss_part.ensure((size_t)nb * lstride));
     ctx->prof.begin(PC_PACK, st); HIPCHK(sml_launch_theta_pack(d, theta, pk_cur(ctx), st)); ctx->prof.end(st);
-    ctx->prof.begin(PC_SORT, st); rc = sort_epoch(&ctx->ix[0], triples, n, batch, 1, t->n_user, t->n_item, false, st, plan);
+    // One GPU, the one-workgroup-per-tile backward, a row inside one wavefront (d <= 64): the backward takes the row update itself
+    // (SmlFusedUpdate; SML_MF_FUSED_UPDATE=0: the k_run_update launch, A/B tests) -- and, round 5, the net runs once per DISTINCT
+    // row of the batch (SmlDense; SML_MF_DISTINCT=0: one pass per occurrence, A/B tests) when the lists allow it
+    const bool can_fuse = !xchg && !bsplit && d <= 64 && ctx->adaptive_beta <= 0.0f && env_int("SML_MF_FUSED_UPDATE", 1) != 0;
+    const bool want_dense = can_fuse && fns == 1 && env_int("SML_MF_DISTINCT", 1) != 0;
+    ctx->prof.begin(PC_SORT, st); rc = sort_epoch(&ctx->ix[0], triples, n, batch, 1, t->n_user, t->n_item, false, st, plan, nullptr, want_dense);
     const int64_t x_total = !xchg ? 0 : xchg->item_off ? xchg->item_off[nb] : (int64_t)xchg->world * 2 * n;
     const int64_t x_stride = !xchg ? 0 : xchg->slot_stride > 0 ? xchg->slot_stride : (int64_t)2 * batch;
     if (!rc && xchg && x_total > 0) {   // the global item occurrence list of the job: run records over the caller's sorted keys
@@ -891,10 +741,11 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
     HIPCHK(hipMemsetAsync(ctx->loss_part.p, 0, (size_t)nb * lstride * sizeof(float), st));
     const int64_t ns = sml_net_size(d), ps = sml_pk_size(d);
     float* dx_buf = xchg ? xchg->dx_local : ctx->dx.p;
-    // One GPU, lists built by hand, the one-workgroup-per-tile backward, a row inside one wavefront (d <= 64): the backward
-    // takes the row update itself (SmlFusedUpdate) -- no third launch per batch.  SML_MF_FUSED_UPDATE=0: A/B tests.
-    const bool fused = !xchg && !bsplit && d <= 64 && ctx->adaptive_beta <= 0.0f && ctx->ix[0].by_hand && ctx->ix[0].slot_stride > 0 &&
-                       env_int("SML_MF_FUSED_UPDATE", 1) != 0;
+    const bool dense = want_dense && ctx->ix[0].by_hand && ctx->ix[0].dense;
+    const bool fused = can_fuse && !dense && ctx->ix[0].by_hand && ctx->ix[0].slot_stride > 0;
+    if (env_int("SML_TRACE", 0))        // (tests assert WHICH form ran: an A/B that silently compares a form with itself proves nothing)
+        fprintf(stderr, "[sml] mf_stage_epoch: form=%s batches=%lld batch=%d d=%d\n", dense ? "distinct-rows" : fused ? "per-occurrence+fused-update" : "per-occurrence+run-update",
+                (long long)nb, batch, d);
     if (fused) {
         // (the counters clear themselves batch by batch; they are zeroed per epoch all the same -- 12 KB -- so that an epoch
         // that was cut short, e.g. by a failed launch, cannot leave a count behind for the next one)
@@ -920,6 +771,11 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
             sg.out = ctx->out.p + slot0 * d; sg.z1 = ctx->z1.p + slot0 * SML_HID; sg.xin = ctx->xin.p + slot0 * 3 * d;
             sg.a1 = nullptr;
             sg.mrep = ctx->mrep.p + slot0 * d; sg.vrep = ctx->vrep.p + slot0 * d;
+            if (dense) {        // scratch row k = distinct row k of this list (every tile's rows named by its header)
+                sg.n_rows = SML_TM * wg_tiles(sg.n_rows, 1);          // (whole tiles: a live row may sit past the batch's ragged end)
+                sg.drec = ctx->ix[0].dense_rec.p + b * ctx->ix[0].slot_stride + slot0;
+                sg.hdr = ctx->ix[0].tile_hdr.p + b * ctx->ix[0].tiles_cap + (s ? wg_tiles(B, 1) : 0);
+            }
         }
         f.tiles0 = wg_tiles(B, 1); f.cur_step = cur; f.sched = ctx->sched.p; f.out_pstride = out_pstride; f.k2 = ctx->variant == 1;
         const int tiles = f.tiles0 + wg_tiles(2 * B, 1);
@@ -939,12 +795,21 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
         w.scale = (plan && plan->loss_scale) ? plan->loss_scale[b] : xchg ? xchg->loss_scale : 1.0f;
         w.loss_part = ctx->loss_part.p + b * lstride;
         w.out_np = fns; w.out_pstride = out_pstride;
-        if (fused) {
+        if (dense) {
+            w.dn.hdr = ctx->ix[0].tile_hdr.p + b * ctx->ix[0].tiles_cap;
+            w.dn.ent = ctx->ix[0].tile_ent.p + b * ctx->ix[0].tiles_cap * SML_TILE_ENT;
+            w.dn.spill = ctx->ix[0].tile_spill.p + b * 3 * batch;
+            w.dn.drec = ctx->ix[0].dense_rec.p + b * ctx->ix[0].slot_stride;
+        }
+        if (fused || dense) {
             SmlFusedUpdate& fu = w.fu;
-            fu.slot_info = ctx->ix[0].slot_info.p + b * ctx->ix[0].slot_stride;
-            fu.rec[0] = ctx->ix[0].rec_u.p + off0; fu.rec[1] = ctx->ix[0].rec_i.p + 2 * off0;
-            fu.val[0] = ctx->ix[0].val_u2.p; fu.val[1] = ctx->ix[0].val_i2.p;
-            fu.arrive = ctx->run_arrive.p; fu.dx_all = dx_buf; fu.tri = tri;
+            if (fused) {
+                fu.slot_info = ctx->ix[0].slot_info.p + b * ctx->ix[0].slot_stride;
+                fu.rec[0] = ctx->ix[0].rec_u.p + off0; fu.rec[1] = ctx->ix[0].rec_i.p + 2 * off0;
+                fu.val[0] = ctx->ix[0].val_u2.p; fu.val[1] = ctx->ix[0].val_i2.p;
+                fu.arrive = ctx->run_arrive.p;
+            }
+            fu.dx_all = dx_buf; fu.tri = tri;
             fu.w[0] = (float*)t->w_user; fu.w[1] = (float*)t->w_item; fu.m[0] = t->m_user; fu.m[1] = t->m_item;
             fu.v[0] = t->v_user; fu.v[1] = t->v_item; fu.last[0] = t->step_user; fu.last[1] = t->step_item;
             fu.mrep = ctx->mrep.p; fu.vrep = ctx->vrep.p; fu.sched = ctx->sched.p; fu.cur_step = cur;
@@ -962,7 +827,7 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
             w.push = push_f; w.tiles_live = tiles;
         }
         ctx->prof.begin(PC_BWD, st); HIPCHK(sml_launch_bwd(d, bsplit, w, bwd_grid, st)); ctx->prof.end(st);
-        if (fused) continue;                  // (the backward stepped the rows)
+        if (fused || dense) continue;         // (the backward stepped the rows)
         if (ctx->adaptive_beta > 0.0f) {      // --need_adaptive: the users' norm term joins their gradient rows and the batch's loss
             ctx->prof.begin(PC_MISC, st);
             HIPCHK(sml_launch_adaptive_users(d, ctx->xin.p, dx_buf, B, ctx->adaptive_beta, w.loss_part, st));

@@ -475,6 +475,72 @@ __device__ __forceinline__ uint32_t emit_bucket(const SmlPrepArgs& a, const SmlP
         out = tb.runs + tb.run_off[b] + scratch[0];
         __syncthreads();
     }
+    if (a.records && a.dense) {
+        // Distinct-row numbering (MF stage, SmlDense; the list is this ONE bucket): the runs are counted, run k -- in row
+        // order -- gets scratch row (k % ntiles) * 16 + k / ntiles of its list (tile k % ntiles: neighbouring rows, e.g. a Zipf
+        // head with consecutive ids, go to different tiles), every occurrence learns its row's scratch row (slot_info), and
+        // the run's record goes there.  No per-position records.
+        uint32_t mine = 0;
+        for (int q = tid; q < S; q += NT) mine += (q + 1 >= S || ent_hi<E>(get(q + 1), vb) != ent_hi<E>(get(q), vb)) ? 1u : 0u;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mine += (uint32_t)__shfl_xor((int)mine, off, 64);
+        if (lane == 0) scratch[wv] = mine;
+        __syncthreads();
+        uint32_t nd = 0;
+#pragma unroll
+        for (int j = 0; j < NT / 64; ++j) nd += scratch[j];
+        __syncthreads();
+        const uint32_t ntiles = (nd + 15u) >> 4;
+        const BatchGeo g = batch_geo(a, b);
+        const int64_t sbase = (int64_t)b * a.slot_stride;
+        SmlRun* drec = a.dense_rec + sbase + (T ? (int64_t)g.ioff : 0);
+        if (tid == 0) a.dense_n[2 * b + T] = (int)nd;
+#pragma unroll 1
+        for (int q0 = 0; q0 < S; q0 += NT) {
+            const int q = q0 + tid;
+            const bool in = q < S;
+            E e = 0; uint32_t rh = 0;
+            bool head = false, tail = false;
+            if (in) {
+                e = get(q); rh = ent_hi<E>(e, vb);
+                head = q == 0 || ent_hi<E>(get(q - 1), vb) != rh;
+                tail = q + 1 >= S || ent_hi<E>(get(q + 1), vb) != rh;
+            }
+            const uint32_t val = ent_val<E>(e, vb);
+            if (in) tb.vals[pos0 + q] = val;
+            const uint64_t wm = __ballot(tail);
+            if (lane == 0) scratch[wv] = (uint32_t)__popcll(wm);
+            __syncthreads();
+            uint32_t before = 0, tot = 0;
+#pragma unroll
+            for (int j = 0; j < NT / 64; ++j) { const uint32_t c = scratch[j]; before += j < wv ? c : 0u; tot += c; }
+            const uint32_t k = done + before + (uint32_t)__popcll(wm & lanes_below());       // runs that END before q = the index of q's run
+            done += tot;
+            __syncthreads();
+            const uint32_t kd = (k % ntiles) * 16u + k / ntiles;
+            if (in) a.slot_info[sbase + val] = kd;
+            if (tail) {
+                int hq = q;
+                if (!head) {
+                    int back = 1;
+                    while (back <= 4 && q - back >= 0 && ent_hi<E>(get(q - back), vb) == rh) ++back;
+                    if (back <= 4) hq = q - back + 1;
+                    else {
+                        int lo = 0, hi2 = q - 4;
+                        while (lo < hi2) { const int mid = (lo + hi2) >> 1; if (ent_hi<E>(get(mid), vb) < rh) lo = mid + 1; else hi2 = mid; }
+                        hq = lo;
+                    }
+                }
+                const int len = q - hq + 1;
+                SmlRun r;
+                r.row = (rh << tb.lb) | bin; r.pos = pos0 + (uint32_t)hq; r.len = (uint32_t)len; r.pad = 0;
+#pragma unroll
+                for (int j = 0; j < SML_RUN_INL; ++j) r.slot[j] = j < len ? ent_val<E>(get(hq + j), vb) : 0u;
+                drec[kd] = r;
+            }
+        }
+        return done;
+    }
 #pragma unroll 1
     for (int q0 = 0; q0 < S; q0 += NT) {                          // block-uniform trip count
         const int q = q0 + tid;
@@ -1162,6 +1228,64 @@ __global__ __launch_bounds__(1024) void k_prep_large(SmlPrepArgs a) {
 
 
 // ------------------------------------------------------------------------------------
+// k_mf_tiles (MF stage, distinct-row form): grid (tiles_cap, nb), one workgroup per 16-row tile of a batch -- the same tile
+// numbering as the forward / backward launches of that batch (user tiles first).  Writes the tile's header and, per occurrence
+// of its rows in (row, slot) order, one entry naming the scratch rows of the occurrence's triple: what the backward needs to
+// form the tile's summed dOut rows in one round trip (SmlDense / SmlTileHdr).  Runs behind the list kernel (it reads both
+// tables' slot_info).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mf_tiles(SmlPrepArgs a) {
+    __shared__ uint32_t s_pos[16], s_start[17], s_spill;
+    const int j = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const BatchGeo g = batch_geo(a, b);
+    const int tu = (g.Bb + 15) >> 4, ti = (2 * g.Bb + 15) >> 4;
+    SmlTileHdr* hdr = a.tile_hdr + (int64_t)b * a.tiles_cap + j;
+    const int T = j >= tu ? 1 : 0, t = j - (T ? tu : 0);
+    int nrows = 0;
+    if (j < tu + ti) {
+        const int nd = a.dense_n[2 * b + T], ntiles = (nd + 15) >> 4;
+        if (t < ntiles) nrows = (nd - t + ntiles - 1) / ntiles;          // rows r with r * ntiles + t < nd
+    }
+    if (nrows == 0) {
+        if (tid == 0) { SmlTileHdr h; memset(&h, 0, sizeof(h)); *hdr = h; }
+        return;
+    }
+    const int64_t sbase = (int64_t)b * a.slot_stride;
+    const SmlRun* drec = a.dense_rec + sbase + (T ? (int64_t)g.ioff : 0) + t * 16;
+    if (tid == 0) {
+        SmlTileHdr h; memset(&h, 0, sizeof(h));
+        uint32_t run = 0;
+        for (int r = 0; r < 16; ++r) {
+            uint32_t len = 0;
+            if (r < nrows) { const SmlRun rec = drec[r]; s_pos[r] = rec.pos; len = rec.len; }
+            s_start[r] = run; run += len; h.len[r] = (unsigned short)len;
+        }
+        s_start[16] = run;
+        h.count = run; h.nrows = (uint32_t)nrows;
+        h.spill = run > SML_TILE_ENT ? (uint32_t)atomicAdd(a.spill_cnt + b, (int)(run - SML_TILE_ENT)) : 0u;
+        s_spill = h.spill;
+        *hdr = h;
+    }
+    __syncthreads();
+    const uint32_t count = s_start[16];
+    const uint32_t* vals = a.t[T].vals;
+    const uint32_t* s2d = a.slot_info + sbase;
+    uint2* ent = a.tile_ent + ((int64_t)b * a.tiles_cap + j) * SML_TILE_ENT;
+    uint2* spill = a.tile_spill + (int64_t)b * 3 * a.batch + s_spill;
+    for (uint32_t e = (uint32_t)tid; e < count; e += 256u) {
+        int r = 0;
+#pragma unroll
+        for (int q = 1; q < 16; ++q) r += (q < nrows && s_start[q] <= e) ? 1 : 0;
+        const uint32_t slot = vals[s_pos[r] + (e - s_start[r])];
+        uint32_t tt = slot, kind = 0u;
+        if (T) { const uint32_t si = slot - g.ioff; kind = si < (uint32_t)g.Bb ? 1u : 2u; tt = kind == 1u ? si : si - (uint32_t)g.Bb; }
+        const uint32_t du = s2d[tt], di = s2d[g.ioff + tt], dn = s2d[g.ioff + (uint32_t)g.Bb + tt];
+        const uint2 v = make_uint2(du | (di << 16), dn | ((uint32_t)r << 16) | (kind << 20));
+        if (e < SML_TILE_ENT) ent[e] = v; else spill[e - SML_TILE_ENT] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // k_rank_probe: is a returning LDS atomic a stable rank on this device?  (See wave_rank.)  Every wavefront draws keys from
 // ranges of 1 .. 512 (every collision multiplicity), some lanes sit a round out, and compares the old half-word it got
 // back with the number of lower lanes on the same key: whatever the counter held before the instruction must come out the
@@ -1194,6 +1318,7 @@ template <typename E>
 hipError_t launch_prep(const SmlPrepArgs& a, hipStream_t st) {
     if (a.records && a.t[0].nbk == 1 && a.t[1].nbk == 1 && 2 * (int64_t)a.batch <= SML_PREP_SMALL) {
         k_prep_bucket<E><<<dim3((unsigned)(2 * a.nb)), dim3(256), 0, st>>>(a, 0, 2);       // ONE launch: no partition
+        if (a.dense) k_mf_tiles<<<dim3((unsigned)a.tiles_cap, (unsigned)a.nb), dim3(256), 0, st>>>(a);
         return hipGetLastError();
     }
     const dim3 tiles((unsigned)a.tpb, (unsigned)a.nb);

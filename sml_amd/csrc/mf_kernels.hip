@@ -328,90 +328,6 @@ __global__ __launch_bounds__(256) void k_bare_grad(SmlBareArgs a) {
     if constexpr (SH) peer_signal(a.peer);          // this workgroup's pushes are acknowledged: +1 on every owner's counter
 }
 
-// ------------------------------------------------------------------------------------
-// sort keys: (batch << row_bits) | row, value = slot of the occurrence inside its batch.
-// K = uint32_t whenever batch and row fit 32 bits together (4 radix passes over 8-byte pairs
-// instead of 5 over 12-byte pairs), else uint64_t with row_bits = 32.
-// ------------------------------------------------------------------------------------
-template <typename K>
-__global__ void k_build_keys(const int64_t* __restrict__ tri, int64_t n, int batch, int pad_tiles, int row_bits_u,
-                             int row_bits_i, K* __restrict__ key_u, uint32_t* __restrict__ val_u,
-                             K* __restrict__ key_i, uint32_t* __restrict__ val_i, const int* __restrict__ boff, int nb) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    int64_t b, start;
-    uint32_t Bb;
-    if (boff == nullptr) {
-        b = e / batch; start = b * batch;
-        const int64_t rem = n - start;
-        Bb = (uint32_t)(rem < batch ? rem : batch);
-    } else {                                   // planned batches of unequal size: the last b with boff[b] <= e
-        int lo = 0, hi = nb - 1;
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int64_t)boff[mid] <= e) lo = mid; else hi = mid - 1; }
-        b = lo; start = boff[lo]; Bb = (uint32_t)(boff[lo + 1] - boff[lo]);
-    }
-    const uint32_t t = (uint32_t)(e - start);
-    const uint32_t ioff = pad_tiles ? ((Bb + SML_R - 1) / SML_R) * SML_R : Bb;   // first item slot of the batch
-    key_u[e] = ((K)b << row_bits_u) | (K)(uint32_t)tri[e * 3];
-    val_u[e] = t;
-    // items: batch b's positives then negatives occupy [2*start, 2*start + 2*Bb) -- contiguous per
-    // batch, so after the (stable) sort batch b's item occurrences are exactly that range again
-    const int64_t base = 2 * start;
-    key_i[base + t] = ((K)b << row_bits_i) | (K)(uint32_t)tri[e * 3 + 1];
-    val_i[base + t] = ioff + t;
-    key_i[base + Bb + t] = ((K)b << row_bits_i) | (K)(uint32_t)tri[e * 3 + 2];
-    val_i[base + Bb + t] = ioff + Bb + t;
-}
-
-template <typename K>
-__global__ void k_build_item_keys_x(const int64_t* __restrict__ items_all, int world, int64_t n, int batch, int row_bits_i,
-                                    K* __restrict__ key_i, uint32_t* __restrict__ val_i) {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // (rank q, element e)
-    if (g >= (int64_t)world * n) return;
-    const int64_t q = g / n, e = g - q * n;
-    const int64_t b = e / batch;
-    const int64_t rem = n - b * batch;
-    const uint32_t Bb = (uint32_t)(rem < batch ? rem : batch);
-    const uint32_t t = (uint32_t)(e - b * batch);
-    const uint32_t base = (uint32_t)(q * 2 * batch);
-    key_i[2 * g] = ((K)b << row_bits_i) | (K)(uint32_t)items_all[2 * g];
-    val_i[2 * g] = base + t;
-    key_i[2 * g + 1] = ((K)b << row_bits_i) | (K)(uint32_t)items_all[2 * g + 1];
-    val_i[2 * g + 1] = base + Bb + t;
-}
-
-template <typename K>
-__global__ void k_build_item_keys_sh(const int64_t* __restrict__ items_all, int world, int64_t n, int batch, int row_bits_i,
-                                     SmlShardKeys sk, K* __restrict__ key_i, uint32_t* __restrict__ val_i) {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // mode 1: (rank q, element e); mode 2: element e of this rank
-    const int64_t tot = sk.mode == 1 ? (int64_t)world * n : n;
-    if (g >= tot) return;
-    const int64_t q = sk.mode == 1 ? g / n : sk.rank, e = sk.mode == 1 ? g - q * n : g;
-    const int64_t b = e / batch;
-    const int64_t rem = n - b * batch;
-    const uint32_t Bb = (uint32_t)(rem < batch ? rem : batch);
-    const uint32_t t = (uint32_t)(e - b * batch);
-    const K sent = (K)((1ull << row_bits_i) - 1);
-    const int64_t* it = items_all + 2 * (q * n + e);
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int64_t row = it[c];
-        K kr = sent;
-        uint32_t v = 0;
-        if (sk.mode == 1) {
-            if (row >= sk.head_rows) {
-                const int64_t r = row - sk.head_rows;
-                if (r / sk.shard_rows == sk.rank) kr = (K)(r - (int64_t)sk.rank * sk.shard_rows);
-            }
-            v = (uint32_t)(q * sk.rows_cap) + (c ? Bb + t : t);
-        } else {
-            if (row < sk.head_rows) kr = (K)row;
-            v = (c ? 2 * Bb : Bb) + t;
-        }
-        key_i[2 * g + c] = ((K)b << row_bits_i) | kr;
-        val_i[2 * g + c] = v;
-    }
-}
 
 // w_head[row] -= lr * (sum over ranks, in rank order, of the ranks' dense head partials): every replica applies the same bits
 template <int D, typename T>
@@ -439,15 +355,6 @@ __global__ __launch_bounds__(256) void k_head_apply(T* __restrict__ w, long long
 }
 __global__ __launch_bounds__(64) void k_peer_signal(SmlPeerPush p) { peer_signal(p); }
 
-__global__ void k_zero_item_marks(uint8_t* __restrict__ uniq, int64_t n, int batch) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    const int64_t b = e / batch;
-    const int64_t rem = n - b * batch;
-    const int64_t Bb = rem < batch ? rem : batch, t = e - b * batch;
-    uint8_t* u = uniq + b * 3 * batch;
-    u[Bb + t] = 0; u[2 * Bb + t] = 0;
-}
 
 // per epoch, over one sorted list: a record for every position (len = 0 unless the position
 // starts a run of equal keys); optionally the selection flag of duplicated runs (len >= 2) and
@@ -493,73 +400,8 @@ __global__ void k_mark_runs(const K* __restrict__ keys, const uint32_t* __restri
     }
 }
 
-// bare step: "row occurs once in its batch" mark of every occurrence (indexed by batch and slot)
-template <typename K>
-__global__ void k_mark_unique(const K* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t n, int row_bits,
-                              uint8_t* __restrict__ uniq, int64_t uniq_stride) {
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n) return;
-    const K k = keys[q];
-    const bool one = (q == 0 || keys[q - 1] != k) && (q + 1 >= n || keys[q + 1] != k);
-    const int64_t b = row_bits >= 32 ? (int64_t)((uint64_t)k >> 32) : (int64_t)(k >> (row_bits & 31));
-    if (!one) uniq[b * uniq_stride + vals[q]] = 0;       // the array is preset to 1: only duplicated occurrences scatter
-}
 
-// bare step: run records of the compacted duplicated-run heads (positions selected on the device)
-template <typename K>
-__global__ void k_make_runs(const K* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t n, int row_bits,
-                            const uint32_t* __restrict__ heads, const int* __restrict__ n_heads, SmlRun* __restrict__ runs,
-                            int* __restrict__ max_len, int64_t seg, int is_item, uint32_t* __restrict__ hot_list,
-                            int* __restrict__ hot_count, int hot_cap) {
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= *n_heads) return;
-    constexpr int PROBE = 8;
-    const int64_t q = heads[h];
-    const K k = keys[q];
-    K nb[PROBE + 1];
-#pragma unroll
-    for (int j = 1; j <= PROBE; ++j) nb[j] = q + j < n ? keys[q + j] : (K)~k;
-    int len = 1;
-#pragma unroll
-    for (int j = 1; j <= PROBE; ++j) len += (len == j && nb[j] == k) ? 1 : 0;
-    if (len > PROBE) {
-        int64_t lo = q + PROBE + 1, hi = n;
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (keys[mid] == k) lo = mid + 1; else hi = mid;
-        }
-        len = (int)(lo - q);
-    }
-    SmlRun r;
-    r.row = row_bits >= 32 ? (uint32_t)k : (uint32_t)(k & (((K)1 << (row_bits & 31)) - 1));
-    r.pos = (uint32_t)q; r.len = (uint32_t)len; r.pad = 0;
-#pragma unroll
-    for (int j = 0; j < SML_RUN_INL; ++j) r.slot[j] = j < len ? vals[q + j] : 0u;
-    runs[h] = r;
-    if (len > SML_HOT) {
-        atomicMax(max_len, len);      // rare: tells the host whether any batch needs the hot-row path
-        if (hot_list != nullptr) {    // the batch's hot-run list (entry order is arbitrary; every row's sum order is not)
-            const int64_t b = q / seg;
-            const int slot = atomicAdd(hot_count + b, 1);
-            if (slot < hot_cap) {
-                uint32_t* e = hot_list + (b * hot_cap + slot) * 3;
-                e[0] = (uint32_t)q | ((uint32_t)is_item << 31); e[1] = (uint32_t)len; e[2] = r.row;
-            }
-        }
-    }
-}
 
-// off[b] = first compacted run whose position is >= b * seg  (off[nb] = number of runs)
-__global__ void k_batch_offsets(const SmlRun* __restrict__ runs, const int* __restrict__ n_sel, int nb, int64_t seg,
-                                int* __restrict__ off) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b > nb) return;
-    const int n = *n_sel;
-    int lo = 0, hi = n;
-    const int64_t want = (int64_t)b * seg;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int64_t)runs[mid].pos < want) lo = mid + 1; else hi = mid; }
-    off[b] = lo;
-}
 
 // this batch's slice of the run lists
 struct RunLists { const SmlRun* run_u; int n_u; const SmlRun* run_i; int n_i; };
@@ -1271,6 +1113,11 @@ __global__ __launch_bounds__(1024) void k_eval_metrics(const int32_t* __restrict
     }
 }
 
+#ifdef SML_TEST_PREP_REFERENCE        // (test build only: helper kernels of the library-sort reference path, tests/csrc)
+#define SML_PREP_REF_DEVICE_PART
+#include "../../tests/csrc/prep_cub_kernels.inc"
+#undef SML_PREP_REF_DEVICE_PART
+#endif
 }  // namespace
 
 // ---------------------------------------------------------------------------- launchers
@@ -1309,15 +1156,6 @@ hipError_t sml_launch_bare_grad(int d, int dtype_bytes, const SmlBareArgs& a, in
     } else return hipErrorInvalidValue;
     return hipGetLastError();
 }
-hipError_t sml_launch_build_item_keys_sh(int key_bytes, const int64_t* items_all, int world, int64_t n, int batch, int row_bits_i,
-                                         const SmlShardKeys& sk, void* key_i, uint32_t* val_i, hipStream_t st) {
-    const int64_t tot = sk.mode == 1 ? (int64_t)world * n : n;
-    if (tot <= 0) return hipSuccess;
-    const dim3 grid((unsigned)((tot + 255) / 256));
-    if (key_bytes == 4) k_build_item_keys_sh<uint32_t><<<grid, dim3(256), 0, st>>>(items_all, world, n, batch, row_bits_i, sk, (uint32_t*)key_i, val_i);
-    else k_build_item_keys_sh<uint64_t><<<grid, dim3(256), 0, st>>>(items_all, world, n, batch, row_bits_i, sk, (uint64_t*)key_i, val_i);
-    return hipGetLastError();
-}
 hipError_t sml_launch_head_apply(int d, int dtype_bytes, void* w_head, long long head_rows, float lr, const SmlPeerPoll& p, hipStream_t st) {
     if (head_rows <= 0) return hipSuccess;
     const int lpr = d * dtype_bytes / 16;
@@ -1346,50 +1184,6 @@ hipError_t sml_launch_mark_runs(int key_bytes, const void* keys, const uint32_t*
     const dim3 grid((unsigned)((n + 255) / 256));
     if (key_bytes == 4) k_mark_runs<uint32_t><<<grid, dim3(256), 0, st>>>((const uint32_t*)keys, vals, n, row_bits, rec, flag_dup, uniq, uniq_stride, uniq_item_base);
     else k_mark_runs<uint64_t><<<grid, dim3(256), 0, st>>>((const uint64_t*)keys, vals, n, row_bits, rec, flag_dup, uniq, uniq_stride, uniq_item_base);
-    return hipGetLastError();
-}
-hipError_t sml_launch_mark_unique(int key_bytes, const void* keys, const uint32_t* vals, int64_t n, int row_bits, uint8_t* uniq,
-                                  int64_t uniq_stride, hipStream_t st) {
-    if (n <= 0) return hipSuccess;
-    const dim3 grid((unsigned)((n + 255) / 256));
-    if (key_bytes == 4) k_mark_unique<uint32_t><<<grid, dim3(256), 0, st>>>((const uint32_t*)keys, vals, n, row_bits, uniq, uniq_stride);
-    else k_mark_unique<uint64_t><<<grid, dim3(256), 0, st>>>((const uint64_t*)keys, vals, n, row_bits, uniq, uniq_stride);
-    return hipGetLastError();
-}
-hipError_t sml_launch_make_runs(int key_bytes, const void* keys, const uint32_t* vals, int64_t n, int row_bits, const uint32_t* heads,
-                                const int* n_heads, int64_t max_heads, SmlRun* runs, int* max_len, int64_t seg, int is_item,
-                                uint32_t* hot_list, int* hot_count, int hot_cap, hipStream_t st) {
-    if (max_heads <= 0) return hipSuccess;
-    const dim3 grid((unsigned)((max_heads + 255) / 256));
-    if (key_bytes == 4) k_make_runs<uint32_t><<<grid, dim3(256), 0, st>>>((const uint32_t*)keys, vals, n, row_bits, heads, n_heads, runs, max_len, seg, is_item, hot_list, hot_count, hot_cap);
-    else k_make_runs<uint64_t><<<grid, dim3(256), 0, st>>>((const uint64_t*)keys, vals, n, row_bits, heads, n_heads, runs, max_len, seg, is_item, hot_list, hot_count, hot_cap);
-    return hipGetLastError();
-}
-hipError_t sml_launch_build_item_keys_x(int key_bytes, const int64_t* items_all, int world, int64_t n, int batch, int row_bits_i,
-                                        void* key_i, uint32_t* val_i, hipStream_t st) {
-    const int64_t tot = (int64_t)world * n;
-    if (tot <= 0) return hipSuccess;
-    const dim3 grid((unsigned)((tot + 255) / 256));
-    if (key_bytes == 4) k_build_item_keys_x<uint32_t><<<grid, dim3(256), 0, st>>>(items_all, world, n, batch, row_bits_i, (uint32_t*)key_i, val_i);
-    else k_build_item_keys_x<uint64_t><<<grid, dim3(256), 0, st>>>(items_all, world, n, batch, row_bits_i, (uint64_t*)key_i, val_i);
-    return hipGetLastError();
-}
-hipError_t sml_launch_zero_item_marks(uint8_t* uniq, int64_t n, int batch, hipStream_t st) {
-    if (n <= 0) return hipSuccess;
-    k_zero_item_marks<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(uniq, n, batch);
-    return hipGetLastError();
-}
-hipError_t sml_launch_batch_offsets(const SmlRun* runs, const int* n_sel, int nb, int64_t seg, int* off, hipStream_t st) {
-    k_batch_offsets<<<dim3((nb + 1 + 63) / 64), dim3(64), 0, st>>>(runs, n_sel, nb, seg, off);
-    return hipGetLastError();
-}
-hipError_t sml_launch_build_keys(int key_bytes, const int64_t* tri, int64_t n, int batch, int pad_tiles, int row_bits_u,
-                                 int row_bits_i, void* key_u, uint32_t* val_u, void* key_i, uint32_t* val_i, const int* boff,
-                                 int nb, hipStream_t st) {
-    if (n <= 0) return hipSuccess;
-    const dim3 grid((unsigned)((n + 255) / 256));
-    if (key_bytes == 4) k_build_keys<uint32_t><<<grid, dim3(256), 0, st>>>(tri, n, batch, pad_tiles, row_bits_u, row_bits_i, (uint32_t*)key_u, val_u, (uint32_t*)key_i, val_i, boff, nb);
-    else k_build_keys<uint64_t><<<grid, dim3(256), 0, st>>>(tri, n, batch, pad_tiles, row_bits_u, row_bits_i, (uint64_t*)key_u, val_u, (uint64_t*)key_i, val_i, boff, nb);
     return hipGetLastError();
 }
 // grid for a run kernel: one lane group per record, capped (the kernels stride)
@@ -1605,3 +1399,8 @@ hipError_t sml_launch_eval_metrics(const int32_t* rank, int64_t n, int topk, flo
     k_eval_metrics<<<dim3(1), dim3(1024), 0, st>>>(rank, n, topk, out);
     return hipGetLastError();
 }
+#ifdef SML_TEST_PREP_REFERENCE
+#define SML_PREP_REF_HOST_PART
+#include "../../tests/csrc/prep_cub_kernels.inc"
+#undef SML_PREP_REF_HOST_PART
+#endif

@@ -4,6 +4,32 @@
 #include <stdint.h>
 #include "sml_dev.h"
 
+// One run of equal keys in a sorted occurrence list: `len` occurrences of table row `row` at
+// sorted positions pos .. pos+len-1 (len = 0: this position does not start a run).  The slots
+// (gradient-row indices) of the first SML_RUN_INL occurrences ride in the record, so the common
+// short run needs no second index load.
+#define SML_RUN_INL 4
+struct __attribute__((aligned(16))) SmlRun { uint32_t row, pos, len, pad; uint32_t slot[SML_RUN_INL]; };
+
+// ---- MF stage, distinct-row form (round 5): the transfer net runs once per DISTINCT (table, row) of a batch ----------------
+// The reference gathers one embedding row per OCCURRENCE (model/transfer.py:466-472) and autograd sums the duplicates'
+// gradients in the embedding's backward; the net is a function of the row alone, so an occurrence's output equals its row's,
+// and d loss / d x_hat[row] = J(row)^T * (sum over the row's occurrences of d loss / d out[occurrence]).  The index
+// preparation numbers a batch's distinct rows per table (sorted by row; distinct row k goes to tile k % ntiles, position
+// k / ntiles: rows with neighbouring ids -- a Zipf head -- land in different tiles), and k_mf_tiles lays out, per 16-row
+// tile, what its backward needs to form the SUM of its rows' dOut before the matrix products: one entry per occurrence, in
+// (row, slot) order -- the summation order is a function of the input alone.
+#define SML_TILE_ENT 256          // entries of a tile held in its fixed block; the rest (a row with hundreds of occurrences) spill
+struct __attribute__((aligned(16))) SmlTileHdr {
+    uint32_t count;               // occurrences of the tile's rows (entries)
+    uint32_t nrows;               // live rows of the tile (0: the tile is not in use)
+    uint32_t spill;               // entries [SML_TILE_ENT, count) are at spill[spill ...] of the batch
+    uint32_t pad;
+    unsigned short len[16];       // occurrences of row r (entries of a row are contiguous, rows ascending)
+};
+// entry: x = scratch row of the triple's user | scratch row (inside the item run) of its positive << 16;
+//        y = ... of its negative | tile row r << 16 | kind << 20 (0: the row is the triple's user, 1: its positive, 2: its negative)
+
 // One contiguous run of rows that goes through one net.
 struct SmlSeg {
     const float* theta;      // this net's flat parameter block
@@ -23,6 +49,9 @@ struct SmlSeg {
     float* a1;               // [n_rows, 5d]
     float* a2;               // TR stage: [n_rows, 512] Gelu(z1), the B operand of dW2 (the weight-gradient kernel then needs no Gelu)
     float* mrep; float* vrep;   // lazy gather: [n_rows, d] the rows' Adam moments after the replay (for the row update)
+    // MF stage, distinct-row form (SmlDense; null: off): scratch row k of this run is DISTINCT table row drec[k].row, tile j's
+    // live rows are the first hdr[j].nrows of its 16 (a tile without rows exits)
+    const SmlRun* drec; const SmlTileHdr* hdr;
 };
 struct SmlFwdArgs {
     SmlSeg seg[2];
@@ -75,12 +104,6 @@ struct SmlBwdSeg {
     float* dz1;              // TR stage: [n_rows, 512]; null in MF stage
     int n_rows;
 };
-// One run of equal keys in a sorted occurrence list: `len` occurrences of table row `row` at
-// sorted positions pos .. pos+len-1 (len = 0: this position does not start a run).  The slots
-// (gradient-row indices) of the first SML_RUN_INL occurrences ride in the record, so the common
-// short run needs no second index load.
-#define SML_RUN_INL 4
-struct __attribute__((aligned(16))) SmlRun { uint32_t row, pos, len, pad; uint32_t slot[SML_RUN_INL]; };
 #define SML_SLOT_ONCE 0x80000000u
 // MF stage, one GPU, index lists built by index_prep.hip: the row update (k_run_update<Adam>) is taken by the backward itself.
 // A row that occurs ONCE in the batch (slot_info) is stepped by the threads that hold its gradient, from the forward's replayed
@@ -99,9 +122,15 @@ struct SmlFusedUpdate {
     const float* mrep; const float* vrep;      // by slot, like dx_all
     const SmlSched* sched; int cur_step;
 };
+// distinct-row form of the MF backward (hdr == null: off): this batch's tile headers / entry blocks / spill area (workgroup =
+// tile index), the dense records (users at 0, items at ioff) and the per-batch triple count
+struct SmlDense {
+    const SmlTileHdr* hdr; const uint2* ent; const uint2* spill; const SmlRun* drec;
+};
 struct SmlBwdArgs {
     SmlBwdSeg seg[2];
     SmlFusedUpdate fu;
+    SmlDense dn;
     // MF stage on several GPUs, one-shot exchange (k_transfer_bwd_full): the item tiles store their gradient rows straight into
     // every rank's inbox slot (row r of this rank's 2B item rows at dst[q] + r * d) and EVERY workgroup of the launch signals --
     // the grid is cut for the epoch's batch cap, the same on every rank, so every rank's counters grow alike; workgroups
@@ -265,6 +294,12 @@ struct SmlPrepArgs {
     // k_transfer_bwd_full): slot_info[b * slot_stride + value] = SML_SLOT_ONCE if the row occurs once in the batch, else the
     // position (inside the batch's list) of the record of its run
     uint32_t* slot_info; int64_t slot_stride;
+    // records mode, both lists one bucket (the MF stage's batches): distinct-row numbering instead of the per-position records
+    // (SmlDense).  slot_info then holds, per slot, the scratch row of its table row (inside its run); dense_rec the records by
+    // scratch row ([nb][slot_stride]: users at 0, items at the batch's ioff); dense_n [nb][2] the distinct rows per list;
+    // k_mf_tiles writes tile_hdr [nb][tiles_cap], tile_ent [nb][tiles_cap][SML_TILE_ENT], spill [nb][3 * batch] / spill_cnt [nb]
+    int dense; SmlRun* dense_rec; int* dense_n;
+    SmlTileHdr* tile_hdr; uint2* tile_ent; uint2* tile_spill; int* spill_cnt; int tiles_cap;
     uint32_t* hot_list; int* hot_count; int hot_cap; int* max_len;
     uint32_t* medium; int* n_medium;                  // same pairs: buckets k_prep_wave leaves to k_prep_bucket
     uint32_t* large; int* n_large; int large_cap;     // (table << 31 | list), bucket -- buckets the small kernel leaves

@@ -263,6 +263,16 @@ __device__ __forceinline__ void fused_prefetch_record(const SmlBwdArgs& a, int s
         f.r0 = rec[0]; f.r1 = rec[1];
     }
 }
+// distinct-row form: the table row and the forward's replayed moments of scratch row `row` (every live row steps in place)
+template <int D>
+__device__ __forceinline__ void dense_prefetch(const SmlBwdArgs& a, int sidx, int row, int w, bool ok, FusedPre& f) {
+    const int slot = (sidx ? a.ioff : 0) + row;
+    f.info = SML_SLOT_ONCE; f.trow = 0; f.m = 0.0f; f.v = 0.0f;
+    if (ok) {
+        f.trow = (int64_t)a.dn.drec[slot].row;
+        f.m = a.fu.mrep[(int64_t)slot * D + w]; f.v = a.fu.vrep[(int64_t)slot * D + w];
+    }
+}
 template <int D>
 __device__ __forceinline__ void fused_row_update(const SmlBwdArgs& a, int sidx, int row, int w, bool ok, float x1, float g, const FusedPre& f) {
     static_assert(D <= 64, "a row inside one wavefront");
@@ -379,6 +389,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __shared__ float red[TR ? 8 : 1][256];
     __shared__ float cf[4][SML_TM * MT];
     __shared__ float lred[8];
+    // MF stage, distinct-row form (SmlDense): the per-occurrence dOut contributions of one chunk of the tile's entries, and the rows' entry ranges
+    constexpr bool DENSEOK = !TR && MT == 1 && D <= 64;
+    __shared__ __attribute__((aligned(16))) float Cs[DENSEOK ? SML_TILE_ENT * D : 4];
+    __shared__ uint32_t rlen[16], rstart[17];
+    __shared__ float Ps[DENSEOK ? 512 : 4];                       // the strided shares of a long row's sum
     float* dZs = smem;                    // [R][516]
     float* dOs = smem + R * S2;           // [R][D+4]
     float* part = smem;                   // [KSPL][R][5D+1], aliases dZs after the second GEMM
@@ -394,21 +409,192 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     if (tid < 104) cws[tid] = sg.theta[tid];
     // both GEMMs' first operand k-steps are on their way before the pair loss starts (they depend on theta alone)
-    constexpr bool PREB = false && (MT == 1) && (D <= 64);                // (same measurement: no gain)
+#ifndef SML_PREB
+#define SML_PREB 0
+#endif
+    // (off: round 2 measured no gain from hoisting these under the per-occurrence pair loss; round 5 tried again under the
+    // distinct-row head, which is two dependent round trips long -- issued behind the head's first loads: MF step 35.7 -> 36.7 us,
+    // the per-occurrence form 38.5 -> 39.3: 28 KB of operands per wave in front of the head's second trip cost more than they hide)
+    constexpr bool PREB = (SML_PREB != 0) && (MT == 1) && (D <= 32) && !TR;
     const f32x4* __restrict__ p2b = reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p2b(D));
     const f32x4* __restrict__ p1b = reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p1b(D));
     auto tileA2 = [wv](int t) { return wv * 4 + t; };
     auto tileA1 = [wv](int t) { return (wv / KSPL) * 5 + t; };
     auto nokofs = [](int) { return 0; };
     f32x4 ringb2[PREB ? KSD : 1][4], ringb1[PREB ? 4 : 1][5];
-    if constexpr (PREB) {
-        ring_preload<4, KSD>(ringb2, p2b, KSD, 0, lane, tileA2, nokofs);
-        ring_preload<5, 4>(ringb1, p1b, 32, (wv % KSPL) * KPER, lane, tileA1, nokofs);
-    }
+    float zpre[PREB ? MT : 1][4][4];
+    // (issued BEHIND the head's first loads: loads return in issue order, and 28 KB of operands per wave ahead of the head's
+    // few hundred bytes would hold the whole chain back)
+    auto preload_operands = [&]() {
+        if constexpr (PREB) {
+            ring_preload<4, KSD>(ringb2, p2b, KSD, 0, lane, tileA2, nokofs);
+            ring_preload<5, 4>(ringb1, p1b, 32, (wv % KSPL) * KPER, lane, tileA1, nokofs);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        zpre[mt][t][q] = sg.z1[(int64_t)(row0 + mt * SML_TM + 4 * g4 + q) * SML_HID + (wv * 4 + t) * 16 + l15];
+        }
+    };
 
     // ---- pair loss (model/conv_transfer.py:120-134) for this tile's rows: every row fetches the three
     // transferred rows of its triple, one thread per row forms the two scores and the loss terms,
     // then dOut is written element-wise.  User tiles own the loss value (each triple once).
+    float lsum = 0.0f;
+    const bool dense = DENSEOK && a.dn.hdr != nullptr;               // (kernel-uniform)
+    int live = R;
+    if constexpr (DENSEOK) {
+    if (dense) {
+        // ---- distinct-row form: this tile's 16 rows are DISTINCT table rows; row r's dOut is the sum over the row's occurrences
+        // (entries, in slot order) of coefficient x partner row.  One entry per group of D/4 lanes and round; the header, the
+        // tile's first SML_TILE_ENT entries and then ALL their out rows are each one round trip.
+        constexpr int LPR = D / 4, G = 512 / LPR, EPG = SML_TILE_ENT / G;
+        const int grp = tid / LPR, sub = tid % LPR;
+        const SmlTileHdr* hp = a.dn.hdr + blockIdx.x;
+        const uint4 h0 = *reinterpret_cast<const uint4*>(hp);
+        uint2 en[EPG];
+#pragma unroll
+        for (int i = 0; i < EPG; ++i) en[i] = a.dn.ent[(int64_t)blockIdx.x * SML_TILE_ENT + grp + i * G];
+        uint32_t mylen = 0;
+        if (tid < 16) mylen = hp->len[tid];
+        __builtin_amdgcn_sched_barrier(0);
+        preload_operands();
+        const int count = (int)h0.x;
+        live = (int)h0.y;
+        if (live == 0) return;                                        // (a tile beyond the batch's distinct rows)
+        if (wv == 0) {                                                // the rows' entry ranges: a prefix over the 16 lengths
+            uint32_t inc = lane < 16 ? mylen : 0u;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, off, 64); if (lane >= off) inc += t; }
+            if (lane < 16) { rlen[lane] = mylen; rstart[lane] = inc - mylen; }
+            if (lane == 15) rstart[16] = inc;
+        }
+        const float inv_b = 1.0f / (float)a.B;
+        float racc[EPT];
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) racc[q] = 0.0f;
+        const int nchunk = (count + SML_TILE_ENT - 1) / SML_TILE_ENT;
+#pragma unroll 1
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int e0 = ch * SML_TILE_ENT;
+            if (ch > 0) {                                             // (a row with hundreds of occurrences: the rest of the entries)
+                __syncthreads();                                      // the previous chunk's sums have been read
+#pragma unroll
+                for (int i = 0; i < EPG; ++i) {
+                    const int e = e0 + grp + i * G;
+                    en[i] = e < count ? a.dn.spill[(int64_t)h0.z + (e - SML_TILE_ENT)] : make_uint2(0u, 0u);
+                }
+            }
+            f32x4 U[EPG], I[EPG], N[EPG];
+#pragma unroll
+            for (int i = 0; i < EPG; ++i) {
+                const bool valid = e0 + grp + i * G < count;
+                const uint32_t du = valid ? (en[i].x & 0xffffu) : 0u, di = valid ? (en[i].x >> 16) : 0u, dn = valid ? (en[i].y & 0xffffu) : 0u;
+                U[i] = *reinterpret_cast<const f32x4*>(a.out_all + (int64_t)du * D + sub * 4);
+                I[i] = *reinterpret_cast<const f32x4*>(a.out_all + (int64_t)(a.ioff + di) * D + sub * 4);
+                N[i] = *reinterpret_cast<const f32x4*>(a.out_all + (int64_t)(a.ioff + dn) * D + sub * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < EPG; ++i) {
+                const int el = grp + i * G;                           // entry inside the chunk
+                const bool valid = e0 + el < count;
+                const uint32_t kind = (en[i].y >> 20) & 3u;
+                float sp = 0.f, sn = 0.f, uu = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { sp += U[i][c] * I[i][c]; sn += U[i][c] * N[i][c]; uu += U[i][c] * U[i][c]; }
+#pragma unroll
+                for (int off = 1; off < LPR; off <<= 1) {
+                    sp += __shfl_xor(sp, off, 64); sn += __shfl_xor(sn, off, 64); uu += __shfl_xor(uu, off, 64);
+                }
+                float lt, d0, d1, inv_nu = 1.0f, cc = 0.0f;
+                const bool nrm = a.kind == SML_LOSS_BPR_NORM || a.kind == SML_LOSS_BPR_UNIT;
+                if (nrm) {
+                    const float nu = sqrtf(uu);
+                    inv_nu = 1.0f / nu;
+                    cc = a.kind == SML_LOSS_BPR_NORM ? (sp - sn) / (nu * nu * nu) : 0.0f;
+                    pair_terms(SML_LOSS_BPR, (sp - sn) * inv_nu, 0.0f, 1.0f, lt, d0, d1);
+                    d1 = -d0;
+                } else {
+                    pair_terms(a.kind, sp, sn, inv_b, lt, d0, d1);
+                }
+                d0 *= a.scale; d1 *= a.scale;
+                f32x4 c4;
+                if (nrm) {
+                    if (kind == 0u) c4 = d0 * ((I[i] - N[i]) * inv_nu - cc * U[i]);
+                    else c4 = ((kind == 1u) ? d0 : d1) * inv_nu * U[i];
+                } else {
+                    if (kind == 0u) c4 = d0 * I[i] + d1 * N[i];
+                    else c4 = ((kind == 1u) ? d0 : d1) * U[i];
+                }
+                if (valid) {
+                    *reinterpret_cast<f32x4*>(Cs + el * D + sub * 4) = c4;
+                    if (kind == 0u && sub == 0) lsum += lt * a.scale;           // every triple once: at its user's row
+                }
+            }
+            __syncthreads();
+            // row sums, in an order that is a function of the input alone.  Short rows: thread (row, w) adds its row's entries in
+            // entry order, eight LDS reads in flight at a time (one dependent read per entry made a 140-occurrence row -- a Zipf head
+            // user -- a 6 us chain on ONE tile).  Long rows (more than LONGROW entries in this chunk; workgroup-uniform): the
+            // workgroup's 512 / D lane groups take strided shares, the shares are added in share order.
+            constexpr int LONGROW = 32, NSH = 512 / D;
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) {
+                const int e = q * 512 + tid, r = e / D, w = e % D;
+                const int lo = max((int)rstart[r], e0) - e0, hi = min((int)(rstart[r] + rlen[r]), e0 + SML_TILE_ENT) - e0;
+                if (hi - lo > LONGROW) continue;
+                float sacc = racc[q];
+                int j = lo;
+                for (; j + 8 <= hi; j += 8) {
+                    float x[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) x[u] = Cs[(j + u) * D + w];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) sacc += x[u];
+                }
+                for (; j < hi; ++j) sacc += Cs[j * D + w];
+                racc[q] = sacc;
+            }
+#pragma unroll 1
+            for (int r = 0; r < 16; ++r) {
+                const int lo = max((int)rstart[r], e0) - e0, hi = min((int)(rstart[r] + rlen[r]), e0 + SML_TILE_ENT) - e0;
+                if (hi - lo <= LONGROW) continue;                      // (the same for every thread: LDS values)
+                const int sh = tid / D, w = tid % D;
+                float part = 0.0f;
+                int j = lo + sh;
+                for (; j + 3 * NSH < hi; j += 4 * NSH) {
+                    const float x0 = Cs[j * D + w], x1 = Cs[(j + NSH) * D + w], x2 = Cs[(j + 2 * NSH) * D + w], x3 = Cs[(j + 3 * NSH) * D + w];
+                    part += x0; part += x1; part += x2; part += x3;
+                }
+                for (; j < hi; j += NSH) part += Cs[j * D + w];
+                Ps[sh * D + w] = part;
+                __syncthreads();
+                // thread (row, w) of THIS row picks the shares up (its q-th element is row r when r == (q * 512 + tid) / D)
+#pragma unroll
+                for (int q = 0; q < EPT; ++q) {
+                    const int e = q * 512 + tid;
+                    if (e / D == r) {
+                        float x[NSH];
+#pragma unroll
+                        for (int u = 0; u < NSH; ++u) x[u] = Ps[u * D + (e % D)];
+                        float sacc = racc[q];
+#pragma unroll
+                        for (int u = 0; u < NSH; ++u) sacc += x[u];
+                        racc[q] = sacc;
+                    }
+                }
+                __syncthreads();                                       // (Ps is free again)
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int e = q * 512 + tid, r = e / D, w = e % D;
+            dOs[r * SD + w] = r < live ? racc[q] : 0.0f;
+        }
+    }
+    }
+    if (!dense) {
     float* O3 = smem;                     // [3][R][D+1], aliases dZs (not yet live)
     float ou[EPT], oi[EPT], on[EPT];
 #pragma unroll
@@ -432,8 +618,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         O3[(1 * R + r) * (D + 1) + w] = oi[q];
         O3[(2 * R + r) * (D + 1) + w] = on[q];
     }
+    preload_operands();
     __syncthreads();
-    float lsum = 0.0f;
     if (tid < R) {
         float sp = 0.f, sn = 0.f, uu = 0.f;
 #pragma unroll 8
@@ -476,6 +662,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         dOs[r * SD + w] = g;
         if (TR) sg.dout[(int64_t)row * D + w] = g;
     }
+    }   // (!dense)
     // the (x_t, x_hat, x_com) rows of the tail: with one element per thread issue the loads now and
     // use them after both GEMMs; with more (d > 32) load them in the tail to keep registers free
     constexpr bool PRELOAD = (EPT == 1);
@@ -491,6 +678,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     fpre.info = SML_SLOT_ONCE; fpre.trow = 0; fpre.m = fpre.v = 0.0f; fpre.r0 = make_uint4(0u, 0u, 0u, 0u); fpre.r1 = fpre.r0;
     if constexpr (FUSABLE && PRELOAD) {
         if (fused) fused_prefetch<D>(a, sidx, row0 + tid / D, tid % D, row0 + tid / D < sg.n_rows, fpre);
+        if (dense) dense_prefetch<D>(a, sidx, row0 + tid / D, tid % D, tid / D < live, fpre);
     }
     __syncthreads();
     TL(2);
@@ -505,7 +693,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    z[mt][t][q] = sg.z1[(int64_t)(row0 + mt * SML_TM + 4 * g4 + q) * SML_HID + (wv * 4 + t) * 16 + l15];
+                    z[mt][t][q] = PREB ? zpre[mt][t][q] : sg.z1[(int64_t)(row0 + mt * SML_TM + 4 * g4 + q) * SML_HID + (wv * 4 + t) * 16 + l15];
         if constexpr (PREB) mma16_ring<MT, 4, KSD, KSD, false>(acc, ringb2, dOs + l15 * SD + 4 * g4, SML_TM * SD, p2b, KSD, 0, lane, tileA2, nokofs);
         else mma16_rows<MT, 4, KSD, KSD>(acc, dOs + l15 * SD + 4 * g4, SML_TM * SD, p2b, KSD, 0, lane, tileA2);
         float* dz1 = sg.dz1;
@@ -583,6 +771,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             dxh += dh1p[c] * cws[SML_OFF_C1W + c * 3 + 1];
         }
         if constexpr (!TR) {
+            if constexpr (DENSEOK) {
+                if (dense) {
+                    // every row of the tile is a distinct table row: its whole gradient is here -- l2 once per occurrence
+                    // (model/transfer.py:486-488 sums over the gathered rows) -- and the lazy-Adam step runs in place
+                    const bool okd = r < live;
+                    const float nocc = (float)rlen[r];
+                    if constexpr (!PRELOAD) dense_prefetch<D>(a, sidx, row, w, okd, fpre);
+                    if (okd) {
+                        float pnew = x1, mm = fpre.m, vv = fpre.v;
+                        adam_apply(pnew, mm, vv, dxh + nocc * a.l2 * x1, a.fu.sched[a.fu.cur_step]);
+                        const int64_t o = fpre.trow * D + w;
+                        a.fu.w[sidx][o] = pnew; a.fu.m[sidx][o] = mm; a.fu.v[sidx][o] = vv;
+                        if (w == 0) a.fu.last[sidx][fpre.trow] = a.fu.cur_step;
+                        lsum += nocc * 0.5f * a.l2 * x1 * x1;
+                    }
+                    continue;
+                }
+            }
             if constexpr (D <= 64) {
                 if (fused) {
                     if constexpr (!PRELOAD) { fused_prefetch<D>(a, sidx, row, w, ok, fpre); fused_prefetch_record(a, sidx, ok, fpre); }

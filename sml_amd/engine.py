@@ -22,8 +22,8 @@ def _ptr(t):
 
 
 class HipEngine(object):
-    def __init__(self, device, d, max_batch=4096):
-        self.lib = _lib.load()
+    def __init__(self, device, d, max_batch=4096, lib=None):
+        self.lib = _lib.load() if lib is None else lib           # (lib: a test hook -- _lib.load_other)
         if not torch.cuda.is_available():
             raise RuntimeError("HipEngine needs a GPU (torch.cuda.is_available() is False); there is no CPU path")
         self.device = torch.device(device)

@@ -577,7 +577,18 @@ G12 = dict(U=1500, I=2500, d=32, n_inter=10000, neg=99, n_periods=6, train_from=
            seed=2000, data_seed=4100, a_user=0.9, a_item=0.9, ck_seed=4343, snap_stages=(2, 3))
 
 
-def gen_g12(T, ref, tmp):
+# G15 (round 5): the SAME kind of sequence at the reference's DEFAULT depth -- multi_num 10 (main_yelp.py's default; G12 runs 3) --
+# over 7 stages, 4 of them test stages, with the complete numerical state recorded at the START OF EVERY stage: the transfer
+# stage's trajectory is the chaotic part of the loop, and ten phases per stage is where a re-implementation drifts furthest.
+G15 = dict(U=1500, I=2500, d=32, n_inter=10000, neg=99, n_periods=8, train_from=1, test_from=4, multi_num=10,
+           seed=2000, data_seed=4100, a_user=0.9, a_item=0.9, ck_seed=4343, snap_stages=(1, 2, 3, 4, 5, 6))      # (stage 0 starts from the seeds)
+
+
+def gen_g15(T, ref, tmp):
+    gen_g12(T, ref, tmp, c=G15, name="g15_fulldepth")
+
+
+def gen_g12(T, ref, tmp, c=None, name="g12_midsize"):
     """The reference's period loop at a size where Recall@20 resolves 1e-4: 10,000 validation / test rows per
     period.  main_yelp.py's __main__ body (seeding order main_yelp.py:137-139, transfer_data, meta_train,
     run: :159-168) is driven here with SIX periods instead of forty (train from period 1, test from period 3
@@ -590,8 +601,8 @@ def gen_g12(T, ref, tmp):
     from model.MF import MFbasemode
     import data.dataset2 as dataset2
 
-    c = G12
-    root = os.path.join(tmp, "data_g12") + "/"
+    c = G12 if c is None else c
+    root = os.path.join(tmp, "data_" + name) + "/"
     synth.write_dataset(root, "yelp", n_periods=c["n_periods"], n_inter=c["n_inter"], n_user=c["U"], n_item=c["I"],
                         neg=c["neg"], a_user=c["a_user"], a_item=c["a_item"], seed=c["data_seed"])
     torch.manual_seed(c["ck_seed"])
@@ -599,7 +610,7 @@ def gen_g12(T, ref, tmp):
     with torch.no_grad():
         mf.user_laten.weight.mul_(0.3)
         mf.item_laten.weight.mul_(0.3)
-    ck = os.path.join(tmp, "g12_init.pkl")
+    ck = os.path.join(tmp, name + "_init.pkl")
     torch.save(mf, ck)
     args = Args(data_path=root, pre_model=ck, laten=c["d"], multi_num=c["multi_num"], MF_batch_size=1024,
                 TR_batch_size=256, numworkers=0, seed=c["seed"])
@@ -617,7 +628,7 @@ def gen_g12(T, ref, tmp):
         meta = T.meta_train(args, sets, sets.user_number, sets.item_number, args.laten)
         theta0 = sd_np(meta.transfer, "theta0.")
         stage_now = [0]
-        for name, tag in (("MF_train_onestage", 0), ("transfer_train_onestage", 1)):
+        for meth, tag in (("MF_train_onestage", 0), ("transfer_train_onestage", 1)):
             def wrap(fn, tag=tag):
                 def inner(*a, **k):
                     n0 = len(losses)
@@ -625,7 +636,7 @@ def gen_g12(T, ref, tmp):
                     tags.extend([(stage_now[0], tag)] * (len(losses) - n0))
                     return r
                 return inner
-            setattr(meta, name, wrap(getattr(meta, name)))
+            setattr(meta, meth, wrap(getattr(meta, meth)))
         real_stage = meta.train_one_stage3
 
         def stage(a, stage_id):
@@ -662,10 +673,10 @@ def gen_g12(T, ref, tmp):
            "recall": np.array(meta.recall, dtype=np.float64), "ndcg": np.array([float(x) for x in meta.ndcg], dtype=np.float64),
            "test_num": np.array(meta.test_num, dtype=np.int64)}
     out.update(theta0)
-    save("g12_midsize.npz", **out)
+    save(name + ".npz", **out)
     for sid, sn in snaps.items():
-        save("g12_midsize_state_s%d.npz" % sid, **sn)
-    print("G12 log lines:", len(log.splitlines()), "batches:", len(losses), "recall:", meta.recall)
+        save(name + "_state_s%d.npz" % sid, **sn)
+    print(name, "log lines:", len(log.splitlines()), "batches:", len(losses), "recall:", meta.recall)
 
 
 # --------------------------------------------------------------------------- G10 baseline bare-MF loop
@@ -774,6 +785,8 @@ def main():
             gen_g7(T, a.ref, tmp, suffix="_news", which="news")
         if not only or "g12" in only:
             gen_g12(T, a.ref, tmp)
+        if not only or "g15" in only:
+            gen_g15(T, a.ref, tmp)
         if not only or "g10" in only:
             gen_g10(a.ref)
         if not only or "g11" in only:

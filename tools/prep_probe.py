@@ -23,12 +23,18 @@ def main():
     from sml_amd import synth
     from sml_amd.engine import HipEngine
     dev = torch.device("cuda:0")
-    eng = HipEngine(dev, 32, a.batch)
+    engines = {"hand": HipEngine(dev, 32, a.batch)}
+    # (the library-sort path is test infrastructure since round 5: tests/build_reference.py builds the library that has it)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import build_reference
+    from sml_amd import _lib
+    engines["cub"] = HipEngine(dev, 32, a.batch, lib=_lib.load_other(build_reference.build()))
     rng = np.random.RandomState(4)
     u, i, j = synth.synth_triples(rng, a.triples, a.users, a.items, a_user=0.0, a_item=a.zipf)
     tri = torch.from_numpy(np.stack([u, i, j], 1)).to(dev)
     for mode in ("hand", "cub"):
         os.environ["SML_PREP"] = mode
+        eng = engines[mode]
         for _ in range(2):
             eng.bare_prepare(tri, a.batch, a.users, a.items)
         torch.cuda.synchronize()
