@@ -60,7 +60,8 @@ int sml_ctx_destroy(sml_ctx* ctx);
  *   0  ConvTransfer_com (conv_com, the default; model/conv_transfer.py:87-135)
  *   1  ConvTransfer     (conv; :52-85): conv1 kernel (2,1) over (x_t, x_hat) -- theta keeps the [10][3]
  *      conv1 block with a zero third column -- no x_com row, user-net output divided by its detached norm
- *      (sml_transfer_forward with net 0 returns the normalised rows), loss SML_LOSS_BPR_UNIT.
+ *      (sml_transfer_forward with net 0 returns the normalised rows), loss SML_LOSS_BPR_UNIT -- or SML_LOSS_BPR_NORM for
+ *      ConvTransfer.run_MF(norm=True), model/conv_transfer.py:79-81: the same value, the norm differentiated through.
  * + 2 (variant 2 / 3): the context is an EVALUATION-STREAM context -- a second context whose sml_transfer_forward calls over
  *      whole tables run beside the training context's on another stream (forwards that only an evaluation reads); nothing
  *      changes in what they compute, but those launches carry a kernel name (k_side_transfer_fwd) and a timing class of

@@ -154,10 +154,8 @@ class ConvTransfer(ConvTransfer_com):
     def run_MF(self, user_weight_last, user_weight_hat, item_weight_last, item_weight_hat, negitem_weight_last,
                negitem_weight_hat, norm=False):
         """BPR loss of one batch (model/conv_transfer.py:71-85); differentiable like ConvTransfer_com.run_MF."""
-        if norm:
-            raise NotImplementedError("ConvTransfer with norm=True (the reference's unused --norm flag)")
         if _needs_graph(self, user_weight_hat, item_weight_hat, negitem_weight_hat):
-            return _RunMF.apply(self, False, False, user_weight_last, user_weight_hat, item_weight_last, item_weight_hat,
+            return _RunMF.apply(self, bool(norm), False, user_weight_last, user_weight_hat, item_weight_last, item_weight_hat,
                                 negitem_weight_last, negitem_weight_hat, *list(self.parameters()))
         un = self.forward(user_weight_last, user_weight_hat, "user")        # already unit norm
         im = self.forward(item_weight_last, item_weight_hat, "item")

@@ -697,8 +697,8 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
         return fail(SML_EINVAL, "sml_mf_stage_epoch", "batch plan does not cover the triples");
     if (batch > ctx->max_batch) return fail(SML_EINVAL, "sml_mf_stage_epoch", "batch exceeds ctx max_batch");
     if (n > 0x3fffffff) return fail(SML_EINVAL, "sml_mf_stage_epoch", "epoch too long");
-    if (loss_kind < 0 || loss_kind > 3 || ((loss_kind == SML_LOSS_BPR_UNIT) != (ctx->variant == 1)))
-        return fail(SML_EINVAL, "sml_mf_stage_epoch", "loss_kind (SML_LOSS_BPR_UNIT goes with variant 1, and only it)");
+    if (loss_kind < 0 || loss_kind > 3 || (ctx->variant == 1 ? (loss_kind != SML_LOSS_BPR_UNIT && loss_kind != SML_LOSS_BPR_NORM) : loss_kind == SML_LOSS_BPR_UNIT))
+        return fail(SML_EINVAL, "sml_mf_stage_epoch", "loss_kind (variant 1 takes SML_LOSS_BPR_UNIT, or SML_LOSS_BPR_NORM for run_MF(norm=True); SML_LOSS_BPR_UNIT goes with variant 1 only)");
     if (xchg && (xchg->world < 1 || !xchg->key_items || !xchg->val_items || !xchg->dx_local || !xchg->dx_items_all))
         return fail(SML_EINVAL, "sml_mf_stage_epoch", "incomplete exchange descriptor");
     const bool mf_peers = xchg && !xchg->hook && ctx->peer.world > 0;
@@ -904,8 +904,8 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
     if (plan && (plan->n_batches <= 0 || !plan->batch_off || plan->batch_off[0] != 0 || plan->batch_off[plan->n_batches] != n))
         return fail(SML_EINVAL, "sml_tr_stage_epoch", "batch plan does not cover the triples");
     if (batch > ctx->max_batch) return fail(SML_EINVAL, "sml_tr_stage_epoch", "batch exceeds ctx max_batch");
-    if (loss_kind < 0 || loss_kind > 3 || ((loss_kind == SML_LOSS_BPR_UNIT) != (ctx->variant == 1)))
-        return fail(SML_EINVAL, "sml_tr_stage_epoch", "loss_kind (SML_LOSS_BPR_UNIT goes with variant 1, and only it)");
+    if (loss_kind < 0 || loss_kind > 3 || (ctx->variant == 1 ? (loss_kind != SML_LOSS_BPR_UNIT && loss_kind != SML_LOSS_BPR_NORM) : loss_kind == SML_LOSS_BPR_UNIT))
+        return fail(SML_EINVAL, "sml_tr_stage_epoch", "loss_kind (variant 1 takes SML_LOSS_BPR_UNIT, or SML_LOSS_BPR_NORM for run_MF(norm=True); SML_LOSS_BPR_UNIT goes with variant 1 only)");
     DevGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     const int d = ctx->d;
@@ -1068,8 +1068,8 @@ int sml_run_mf_grad(sml_ctx* ctx, const float* theta, const float* user_last, co
     if (!ctx || !theta || !user_last || !user_hat || !item_last || !item_hat || !loss || B <= 0)
         return fail(SML_EINVAL, "sml_run_mf_grad", "bad argument");
     if (B > ctx->max_batch) return fail(SML_EINVAL, "sml_run_mf_grad", "batch exceeds ctx max_batch");
-    if (loss_kind < 0 || loss_kind > 3 || ((loss_kind == SML_LOSS_BPR_UNIT) != (ctx->variant == 1)))
-        return fail(SML_EINVAL, "sml_run_mf_grad", "loss_kind (SML_LOSS_BPR_UNIT goes with variant 1, and only it)");
+    if (loss_kind < 0 || loss_kind > 3 || (ctx->variant == 1 ? (loss_kind != SML_LOSS_BPR_UNIT && loss_kind != SML_LOSS_BPR_NORM) : loss_kind == SML_LOSS_BPR_UNIT))
+        return fail(SML_EINVAL, "sml_run_mf_grad", "loss_kind (variant 1 takes SML_LOSS_BPR_UNIT, or SML_LOSS_BPR_NORM for run_MF(norm=True); SML_LOSS_BPR_UNIT goes with variant 1 only)");
     DevGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     const int d = ctx->d;

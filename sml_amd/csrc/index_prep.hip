@@ -1247,24 +1247,28 @@ __global__ __launch_bounds__(256) void k_mf_tiles(SmlPrepArgs a) {
         if (t < ntiles) nrows = (nd - t + ntiles - 1) / ntiles;          // rows r with r * ntiles + t < nd
     }
     if (nrows == 0) {
-        if (tid == 0) { SmlTileHdr h; memset(&h, 0, sizeof(h)); *hdr = h; }
+        if (tid < 3) reinterpret_cast<uint4*>(hdr)[tid] = make_uint4(0u, 0u, 0u, 0u);
         return;
     }
     const int64_t sbase = (int64_t)b * a.slot_stride;
     const SmlRun* drec = a.dense_rec + sbase + (T ? (int64_t)g.ioff : 0) + t * 16;
-    if (tid == 0) {
-        SmlTileHdr h; memset(&h, 0, sizeof(h));
-        uint32_t run = 0;
-        for (int r = 0; r < 16; ++r) {
-            uint32_t len = 0;
-            if (r < nrows) { const SmlRun rec = drec[r]; s_pos[r] = rec.pos; len = rec.len; }
-            s_start[r] = run; run += len; h.len[r] = (unsigned short)len;
+    if (tid < 64) {                                                  // (wavefront 0: the 16 records in one round trip, prefix by shuffles)
+        uint32_t len = 0, pos = 0;
+        if (tid < nrows) { const uint4 r0 = *reinterpret_cast<const uint4*>(drec + tid); pos = r0.y; len = r0.z; }
+        uint32_t inc = len;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) { const uint32_t t2 = (uint32_t)__shfl_up((int)inc, off, 64); if (tid >= off) inc += t2; }
+        if (tid < 16) { s_pos[tid] = pos; s_start[tid] = inc - len; }
+        const uint32_t run = (uint32_t)__shfl((int)inc, 15, 64);
+        // the header: 16 bytes of counts + 16 lengths (two per dword)
+        const uint32_t lnext = (uint32_t)__shfl_down((int)len, 1, 64);
+        uint32_t spill = 0;
+        if (tid == 0) {
+            spill = run > SML_TILE_ENT ? (uint32_t)atomicAdd(a.spill_cnt + b, (int)(run - SML_TILE_ENT)) : 0u;
+            s_start[16] = run; s_spill = spill;
+            *reinterpret_cast<uint4*>(hdr) = make_uint4(run, (uint32_t)nrows, spill, 0u);
         }
-        s_start[16] = run;
-        h.count = run; h.nrows = (uint32_t)nrows;
-        h.spill = run > SML_TILE_ENT ? (uint32_t)atomicAdd(a.spill_cnt + b, (int)(run - SML_TILE_ENT)) : 0u;
-        s_spill = h.spill;
-        *hdr = h;
+        if (tid < 16 && (tid & 1) == 0) reinterpret_cast<uint32_t*>(hdr->len)[tid >> 1] = (len & 0xffffu) | (lnext << 16);
     }
     __syncthreads();
     const uint32_t count = s_start[16];

@@ -219,10 +219,11 @@ class HipEngine(object):
 
     def _loss_kind(self, bce, norm):
         if getattr(self, "_variant", 0) == 1:
-            # ConvTransfer.run_MF has one loss: BPR over the unit-norm user output (model/conv_transfer.py:71-85)
-            if norm:
-                raise NotImplementedError("ConvTransfer with norm=True (the reference's unused --norm flag)")
-            return _lib.LOSS_BPR_UNIT
+            # ConvTransfer.run_MF has one loss: BPR over the unit-norm user output (model/conv_transfer.py:71-85).  norm=True
+            # (:79-81) divides the score by the norm of that unit-norm output WITHOUT detaching it: with u = x / stop(|x|) the
+            # value is x.(i - n) / |x| and d/dx = (i - n) / |x| - (x.(i - n)) x / |x|^3 -- exactly the differentiable-norm BPR
+            # (SML_LOSS_BPR_NORM) on the net's raw user rows
+            return _lib.LOSS_BPR_NORM if norm else _lib.LOSS_BPR_UNIT
         if bce:
             return _lib.LOSS_BCE
         return _lib.LOSS_BPR_NORM if norm else _lib.LOSS_BPR

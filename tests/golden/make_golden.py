@@ -376,6 +376,18 @@ def gen_g11(T, tmp):
         out["gtheta_bpr.%s" % k] = p.grad.detach().numpy().copy()
     for k, nm in enumerate(("ul", "uh", "il", "ih", "nl", "nh")):
         out[nm] = ten[k].numpy()
+    # round 5: run_MF(norm=True) -- model/conv_transfer.py:79-81: the score divided by the norm of the (already unit-norm)
+    # user output, which is NOT detached there
+    ins = [t.clone() for t in ten]
+    for k in (1, 3, 5):
+        ins[k].requires_grad_(True)
+    net.zero_grad()
+    loss = net.run_MF(*ins, norm=True)
+    loss.backward()
+    out["loss_bprn"] = loss.detach().numpy()
+    out["gu_bprn"], out["gi_bprn"], out["gn_bprn"] = ins[1].grad.numpy().copy(), ins[3].grad.numpy().copy(), ins[5].grad.numpy().copy()
+    for k, p in net.named_parameters():
+        out["gtheta_bprn.%s" % k] = p.grad.detach().numpy().copy()
     save("g11_convtransfer_d32.npz", **out)
     gen_g3_g4_g5(T, tmp, ttype="conv", suffix="_conv")
 

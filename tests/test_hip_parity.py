@@ -1212,6 +1212,46 @@ def test_g11_convtransfer_forward_and_module_surface():
     np.testing.assert_allclose(y1.cpu().numpy(), z1["y_user"], rtol=1e-4, atol=2e-6)
 
 
+def test_g11_convtransfer_run_mf_with_norm_through_the_autograd_surface():
+    """ConvTransfer.run_MF(norm=True) (model/conv_transfer.py:79-81; VERDICT r4 missing #3): the score divided by the norm of the
+    unit-norm user output, which the reference does not detach -- SML_LOSS_BPR_NORM on the net's raw user rows.  Loss,
+    d loss / d x_hat for the three blocks and every parameter's gradient against the reference's autograd (G11), through
+    loss.backward(); and as one MF-stage epoch against the oracle."""
+    z = golden("g11_convtransfer_d32.npz")
+    net = make_transfer(32, z, device=DEV)
+    ins = [T(z[k], DEV) for k in ("ul", "uh", "il", "ih", "nl", "nh")]
+    np.testing.assert_allclose(float(net.run_MF(*ins, norm=True)), float(z["loss_bprn"]), rtol=1e-4)
+    for k in (1, 3, 5):
+        ins[k] = ins[k].clone().requires_grad_(True)
+    net.zero_grad()
+    loss = net.run_MF(*ins, norm=True)
+    loss.backward()
+    np.testing.assert_allclose(float(loss), float(z["loss_bprn"]), rtol=1e-4)
+    close(ins[1].grad.cpu().numpy(), z["gu_bprn"], 3e-5)
+    close(ins[3].grad.cpu().numpy(), z["gi_bprn"], 3e-5)
+    close(ins[5].grad.cpu().numpy(), z["gn_bprn"], 3e-5)
+    for k, p in net.named_parameters():
+        want_g = z["gtheta_bprn." + k]
+        if np.abs(want_g).max() == 0.0:
+            # item_transfer.fc2.bias: BPR scores u.(i - n), so a bias added to BOTH item rows cancels -- the reference's autograd
+            # returns exact zeros, the kernels' two sums cancel to rounding noise
+            assert np.abs(p.grad.cpu().numpy()).max() < 1e-5, k
+        else:
+            close(p.grad.cpu().numpy(), want_g, 3e-4 if k.endswith("bias") else 3e-5)
+    # one MF-stage epoch with the flag (both forms of the stage) against the oracle
+    rng = np.random.RandomState(3)
+    U, I, B, n, d = 700, 500, 1024, 2 * 1024 + 100, 32
+    tri = torch.from_numpy(np.stack([rng.randint(0, U, n), rng.randint(0, I, n), rng.randint(0, I, n)], 1))
+    wu0, wi0 = rng.randn(U, d).astype(np.float32) * 0.3, rng.randn(I, d).astype(np.float32) * 0.3
+    mf_cpu, net_cpu = make_mf(U, I, d, wu0, wi0), make_transfer(32, z)
+    want = O.OracleEngine(d).mf_stage_epoch(mf_cpu, net_cpu, T(wu0 * 0.9), T(wi0 * 0.9), tri, B, 0.01, 1e-6, norm=True, bce=False)
+    eng = engine(d, B)
+    mf = make_mf(U, I, d, wu0, wi0, device=DEV)
+    got = eng.mf_stage_epoch(mf, net, T(wu0 * 0.9, DEV), T(wi0 * 0.9, DEV), tri, B, 0.01, 1e-6, norm=True, bce=False).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-4)
+    eng.close()
+
+
 def test_g11_convtransfer_theta_gradient_via_one_tr_step_vs_oracle():
     """One TR batch on G11's inputs: the theta the HIP path lands on equals the oracle's (same Adam step from
     the reference-checked gradient), including the frozen zero third conv1 column."""

@@ -239,3 +239,18 @@ def test_g11_convtransfer_forward_loss_and_gradients():
     for net, mod in (("user", "user_transfer"), ("item", "item_transfer")):
         for k, p in theta[net].items():
             close(p.grad.numpy(), z["gtheta_bpr.%s.%s" % (mod, k)], 3e-4 if k.endswith("bias") else 3e-5)
+    # run_MF(norm=True), model/conv_transfer.py:79-81 (round 5): the score over the norm of the unit-norm user output, not detached
+    theta = {n: {k: v.detach().clone().requires_grad_(True) for k, v in t.items()} for n, t in theta.items()}
+    ins = [T(z[k]).clone() for k in ("ul", "uh", "il", "ih", "nl", "nh")]
+    for k in (1, 3, 5):
+        ins[k].requires_grad_(True)
+    loss = O.run_mf(theta, *ins, norm=True, bce=False)
+    loss.backward()
+    np.testing.assert_allclose(float(loss), float(z["loss_bprn"]), rtol=1e-5)
+    close(ins[1].grad.numpy(), z["gu_bprn"], 3e-5)
+    close(ins[3].grad.numpy(), z["gi_bprn"], 3e-5)
+    close(ins[5].grad.numpy(), z["gn_bprn"], 3e-5)
+    assert np.abs(z["gu_bprn"] - z["gu_bpr"]).max() > 1e-4          # (the flag changes the user rows' gradient: the fixture says so)
+    for net, mod in (("user", "user_transfer"), ("item", "item_transfer")):
+        for k, p in theta[net].items():
+            close(p.grad.numpy(), z["gtheta_bprn.%s.%s" % (mod, k)], 3e-4 if k.endswith("bias") else 3e-5)
