@@ -174,6 +174,8 @@ struct IndexSet {
     Buf<char> cub_tmp;
     int key_bytes = 8, row_bits_u = 32, row_bits_i = 32;
     int* max_len_host = nullptr;       // pinned: longest duplicated run of the prepared epoch (0 if none exceeds SML_HOT)
+    int* lists_host = nullptr;         // pinned, compact lists by hand: [off_u (nb+1)][off_i (nb+1)][cnt_u (nb*STRIDE)][cnt_i (nb*STRIDE)] -- the
+    int64_t lists_host_nb = 0, lists_nb = 0;   // (capacity; batches of the prepared epoch, 0: not read back) batches' places in the run lists, read back with max_len (same event): the run kernel then needs no offset / count loads
     hipEvent_t ready = nullptr;        // recorded after the copy into max_len_host
     int64_t n = -1; int batch = 0; const void* triples = nullptr; int world = 1;   // what was prepared here
     void release() {
@@ -186,6 +188,7 @@ struct IndexSet {
         uniq.release(); slot_info.release(); heads_u.release(); heads_i.release(); hot_list.release(); hot_count.release(); off_u.release(); off_i.release(); n_sel.release();
         cub_tmp.release();
         if (max_len_host) { g_graveyard.park_host(max_len_host); max_len_host = nullptr; }
+        if (lists_host) { g_graveyard.park_host(lists_host); lists_host = nullptr; lists_host_nb = 0; }
         if (ready) { (void)hipEventDestroy(ready); ready = nullptr; }
     }
 };
@@ -537,6 +540,22 @@ int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
         if (!c->max_len_host) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->max_len_host), sizeof(int), hipHostMallocDefault));
         if (!c->ready) HIPCHK(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
         HIPCHK(hipMemcpyAsync(c->max_len_host, c->n_sel.p + 2, sizeof(int), hipMemcpyDeviceToHost, st));
+        // the batches' run-list offsets and counts travel too (a few KB; epochs of up to 4,096 batches): an epoch prepared ahead
+        // launches its run kernels with the slices as plain arguments
+        if (mode == 0 && nb <= 4096) {
+            if (c->lists_host_nb < nb) {
+                if (c->lists_host) g_graveyard.park_host(c->lists_host);
+                c->lists_host = nullptr; c->lists_host_nb = 0;
+                HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->lists_host), (size_t)(2 * (nb + 1) + 2 * nb * SML_PREP_CNT_STRIDE) * sizeof(int), hipHostMallocDefault));
+                c->lists_host_nb = nb;
+            }
+            int* h = c->lists_host;
+            HIPCHK(hipMemcpyAsync(h, c->off_u.p, (size_t)(nb + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(h + (nb + 1), c->off_i.p, (size_t)(nb + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(h + 2 * (nb + 1), c->cnt_u.p, (size_t)nb * SML_PREP_CNT_STRIDE * sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(h + 2 * (nb + 1) + nb * SML_PREP_CNT_STRIDE, c->cnt_i.p, (size_t)nb * SML_PREP_CNT_STRIDE * sizeof(int), hipMemcpyDeviceToHost, st));
+            c->lists_nb = nb;
+        } else c->lists_nb = 0;
         HIPCHK(hipEventRecord(c->ready, st));
     }
     c->n = mode >= 2 ? -1 : n; c->batch = batch; c->triples = tri; c->world = W;
@@ -1249,6 +1268,16 @@ int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n
         u.run_u = X->runs_u.p; u.run_i = X->runs_i.p; u.off_u = X->off_u.p; u.off_i = X->off_i.p; u.batch_index = (int)b;
         u.val_u = X->val_u2.p; u.val_i = X->val_i2.p;
         if (X->by_hand) { u.cnt_u = X->cnt_u.p; u.cnt_i = X->cnt_i.p; }
+        int64_t max_rec = xchg ? (int64_t)B / 2 + (int64_t)world * 2 * B : (int64_t)3 * B / 2;
+        if (known && X->by_hand && !xchg && X->lists_nb == nb && env_int("SML_A3_KNOWN_LISTS", 1)) {
+            // the prepared epoch's list slices are on the host: plain arguments, an exact grid
+            const int* h = X->lists_host;
+            const int ou = h[b], oi = h[(nb + 1) + b];
+            const int cu = h[2 * (nb + 1) + b * SML_PREP_CNT_STRIDE], ci = h[2 * (nb + 1) + nb * SML_PREP_CNT_STRIDE + b * SML_PREP_CNT_STRIDE];
+            u.run_u = X->runs_u.p + ou; u.n_u = cu; u.run_i = X->runs_i.p + oi; u.n_i = ci;
+            u.off_u = u.off_i = nullptr; u.cnt_u = u.cnt_i = nullptr; u.known = 1;
+            max_rec = (int64_t)cu + ci;
+        }
         u.dx = dxb; u.dx_i = xchg ? xchg->dx_items_all : dxb; u.w_user = w_user; u.w_item = w_item; u.lr = lr;
         if (hot) {
             u.hot_list = X->hot_list.p + (size_t)b * hot_cap * 3; u.hot_count = X->hot_count.p + b; u.hot_first = ctx->hot_first.p;
@@ -1256,7 +1285,6 @@ int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n
         }
         // (grid: one lane group per possible record -- duplicated runs are at most every second occurrence; on several
         // GPUs every item run of the job's list is a record)
-        const int64_t max_rec = xchg ? (int64_t)B / 2 + (int64_t)world * 2 * B : (int64_t)3 * B / 2;
         ctx->prof.begin(PC_SEG_SGD, st); HIPCHK(sml_launch_run_sgd(d, dtype_bytes, u, max_rec, st)); ctx->prof.end(st);
         if (hot) { ctx->prof.begin(PC_PAIR_LOSS, st); HIPCHK(sml_launch_hot_apply(d, dtype_bytes, u, st)); ctx->prof.end(st); }
     }

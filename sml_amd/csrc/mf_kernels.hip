@@ -219,6 +219,11 @@ __global__ __launch_bounds__(256) void k_bare_grad(SmlBareArgs a) {
     float contrib = 0.0f;
     if (t < a.B) {
         const int64_t iu = a.tri[(int64_t)t * 3], ii = a.tri[(int64_t)t * 3 + 1], in = a.tri[(int64_t)t * 3 + 2];
+        // (the "row occurs once" marks ride in the FIRST round trip, with the triple: fetched where they are used they were a
+        // third dependent trip ahead of the stores)
+        uint8_t mk_u = 0, mk_i = 0, mk_n = 0;
+        if (!LAZY && a.uniq != nullptr) { mk_u = a.uniq[t]; mk_i = a.uniq[a.B + t]; mk_n = a.uniq[2 * a.B + t]; }
+        __builtin_amdgcn_sched_barrier(0);
         float u[VEC], it[VEC], ng[VEC];
         if (SML_NT & 1) RowVec<T>::load_nt(reinterpret_cast<const T*>(a.w_user) + iu * D + sub * VEC, u);
         else RowVec<T>::load(reinterpret_cast<const T*>(a.w_user) + iu * D + sub * VEC, u);
@@ -278,7 +283,26 @@ __global__ __launch_bounds__(256) void k_bare_grad(SmlBareArgs a) {
         }
         sp = group_sum<LPR>(sp); sn = group_sum<LPR>(sn);
         float lt, dsp, dsn;
-        pair_terms(a.kind, sp, sn, a.scale / (float)a.B, lt, dsp, dsn);     // (BCE: a mean over the GLOBAL batch; the BPR sum ignores it)
+        // The pair terms on the transcendental unit (v_log_f32 / v_exp_f32 / v_rcp_f32, ~1 ulp each) instead of logf / log1pf /
+        // IEEE divides: every one of a triple's D/4 lanes runs this scalar stretch, and the pass is close enough to the memory
+        // system's pace that its instruction count shows (round 5, d = 32 uniform: 40.7 -> 39.0 us per 262,144 triples).  The loss
+        // TERM moves by ~1e-7 absolute, the coefficients by an ulp: far inside the oracle tolerances of every bare-step test.
+        // (BCE: a mean over the GLOBAL batch -> inv_b; the BPR sum ignores it.)
+        {
+            const float inv_b = a.scale / (float)a.B;
+            if (a.kind == SML_LOSS_BCE) {
+                const float gp = sml_sigmoid(sp), gn = sml_sigmoid(sn);
+                const float ap = gp + 1e-15f, an = (1.0f - gn) + 1e-15f;
+                lt = -(__logf(ap) + __logf(an)) * inv_b;
+                dsp = -inv_b * gp * (1.0f - gp) * __builtin_amdgcn_rcpf(ap);
+                dsn = inv_b * gn * (1.0f - gn) * __builtin_amdgcn_rcpf(an);
+            } else {
+                const float x = sp - sn;
+                lt = fmaxf(-x, 0.0f) + __logf(1.0f + __expf(-fabsf(x)));
+                dsp = -sml_sigmoid(-x);
+                dsn = -dsp;
+            }
+        }
         // gradient rows.  An occurrence whose row appears ONCE in this batch is read by nobody else in
         // the batch, so its synchronous-SGD update is applied in place right here (exact); the others
         // hand their gradient row to the segmented update.
@@ -289,8 +313,7 @@ __global__ __launch_bounds__(256) void k_bare_grad(SmlBareArgs a) {
             gy[e] = dsp * u[e] + a.lam_item * it[e];
             gz[e] = dsn * u[e] + a.lam_item * ng[e];
         }
-        const bool one_u = !LAZY && a.uniq != nullptr && a.uniq[t], one_i = !LAZY && a.uniq != nullptr && a.uniq[a.B + t],
-                   one_n = !LAZY && a.uniq != nullptr && a.uniq[2 * a.B + t];
+        const bool one_u = mk_u != 0, one_i = mk_i != 0, one_n = mk_n != 0;
         auto emit = [&](bool in_place, T* wrow, const float (&row)[VEC], const float (&g)[VEC], float* dxrow, bool nt) {
             if (in_place) {
                 float nw[VEC];
@@ -546,7 +569,7 @@ __global__ __launch_bounds__(256) void k_run_update(SmlRunArgs a) {
     // wavefronts, so their long sums run side by side instead of one after the other in one wave.
     // Per-position records (MF stage): a run of length L is followed by L-1 empty records, which spaces
     // the heads out already; consecutive records per wave keep the record loads coalesced.
-    const bool strided = a.off_u != nullptr;
+    const bool strided = a.off_u != nullptr || a.known != 0;
     for (int base = 0; base < total; base += n_waves * G) {                 // wave-uniform trip count
         const int k = strided ? base + grp * n_waves + wave_id : base + wave_id * G + grp;
         const bool valid = k < total;

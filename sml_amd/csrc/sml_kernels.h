@@ -217,6 +217,8 @@ struct SmlRunArgs {
     const SmlRun* run_i; int n_i;
     const int* off_u; const int* off_i; int batch_index;
     const int* cnt_u; const int* cnt_i;             // not null: this batch's records are off[b] .. off[b] + cnt[b * SML_PREP_CNT_STRIDE] (lists built by index_prep.hip)
+    int known;                                      // 1: run_u / run_i / n_u / n_i ARE this batch's slice of the compacted lists (the host has read the counts back:
+                                                    // no dependent offset / count loads at the head of the kernel); off_* / cnt_* are null then
     const uint32_t* val_u; const uint32_t* val_i;   // whole sorted value lists (SmlRun.pos indexes them): slot of each occurrence
     const float* dx;         // per-occurrence gradient rows the user values index
     const float* dx_i;       // ... and the item values index (the all-gathered buffer on several GPUs)
