@@ -206,6 +206,7 @@ struct sml_ctx {
     // transfer-net workspaces, 3*B slots each
     Buf<float> out, dout, dx, xin, z1, a1, a2, dz1, mrep, vrep;
     Buf<float> pk, grad, convg, loss_part;
+    Buf<float> pkx;          // bf16x3 operand images of the table-sized forward (both nets)
     Buf<float> cstate;       // [2 parities][2 nets][3][SML_CG]: the conv parameters' working copy of a TR epoch (deferred conv step)
     int pk_set = 0;          // which of the two operand-image sets is current
     Buf<int> arrive;         // k_tr_wgrad2's tail-workgroup arrival counter (0 between launches)
@@ -245,7 +246,7 @@ struct sml_ctx {
         prof.release();
         out.release(); dout.release(); dx.release(); xin.release(); z1.release(); a1.release(); a2.release(); dz1.release();
         mrep.release(); vrep.release();
-        pk.release(); grad.release(); convg.release(); loss_part.release(); arrive.release(); run_arrive.release(); cstate.release();
+        pk.release(); pkx.release(); grad.release(); convg.release(); loss_part.release(); arrive.release(); run_arrive.release(); cstate.release();
         ix[0].release(); ix[1].release();
         sched.release(); dummy.release(); rec_x.release();
         for (auto& r : sched_retired) { g_graveyard.park(r.dev); g_graveyard.park_host(r.host); (void)hipEventDestroy(r.done); }
@@ -687,6 +688,24 @@ int sml_transfer_forward(sml_ctx* ctx, const float* theta, int net, const float*
     DevGuard g(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     int rc = ensure_pk(ctx); if (rc) return rc;
+    // table-sized calls at d = 32: the bf16x3 kernel (fp32-grade results on the bf16 matrix rate; SML_FWD_BX3=0: the fp32 products)
+    const size_t bx3 = n_rows > 8192 && env_int("SML_FWD_BX3", 1) != 0 && env_int("SML_FWD_MT", 0) == 0 ? sml_bx3_bytes(ctx->d) : 0;
+    if (bx3) {
+        HIPCHK(ctx->pkx.ensure(bx3 / sizeof(float) + 4));
+        ctx->prof.begin(PC_PACK, st); HIPCHK(sml_launch_theta_pack_bx3(ctx->d, theta, ctx->pkx.p, st)); ctx->prof.end(st);
+        SmlFwdArgs a;
+        memset(&a, 0, sizeof(a));
+        SmlSeg& s = a.seg[0];
+        s.theta = theta + (int64_t)net * sml_net_size(ctx->d);
+        s.xt_tab = x_t; s.xh_tab = x_hat; s.n_rows = (int)n_rows; s.out = out;
+        a.k2 = ctx->variant == 1; a.unit_rows = (ctx->variant == 1 && net == 0);
+        a.tiles0 = wg_tiles((int)n_rows, 2);
+        const char* pkx_net = reinterpret_cast<const char*>(ctx->pkx.p) + (size_t)net * (bx3 / 2);
+        ctx->prof.begin(ctx->side ? PC_FWD_SIDE : PC_FWD, st);
+        HIPCHK(sml_launch_fwd_bx3(ctx->d, a, pkx_net, a.tiles0, st, ctx->side));
+        ctx->prof.end(st);
+        return SML_OK;
+    }
     ctx->prof.begin(PC_PACK, st); HIPCHK(sml_launch_theta_pack(ctx->d, theta, pk_cur(ctx), st)); ctx->prof.end(st);
     SmlFwdArgs a;
     memset(&a, 0, sizeof(a));

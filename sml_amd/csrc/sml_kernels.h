@@ -188,6 +188,10 @@ hipError_t sml_launch_tr_wgrad2(int d, const SmlWgArgs& a, hipStream_t st);
 int sml_wgrad2_pushers(int d);                   // counter increments one merged launch adds per destination (fixed)
 hipError_t sml_launch_theta_adam(int d, const SmlThetaAdamArgs& a, hipStream_t st);
 hipError_t sml_launch_theta_pack(int d, const float* theta, float* pk, hipStream_t st);
+// table-sized forward on bf16 products with fp32-grade results (transfer_net.hip, k_transfer_fwd_bx3): d = 32
+size_t sml_bx3_bytes(int d);                     // operand images of both nets (0: not available at this d)
+hipError_t sml_launch_theta_pack_bx3(int d, const float* theta, void* pkx, hipStream_t st);
+hipError_t sml_launch_fwd_bx3(int d, const SmlFwdArgs& a, const void* pkx_net, int tiles, hipStream_t st, bool side);
 int sml_wgrad_grid(int d);                       // workgroups (= pushers) of one weight-gradient launch
 // generic push / wait / rank-order sum over peer mappings (mf_kernels.hip)
 int sml_peer_push_blocks(long long n_floats);

@@ -229,6 +229,231 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 
 // ------------------------------------------------------------------------------------
+// Round 5: the TABLE-SIZED forward (updata, model/transfer.py:884-902: every row of both tables through its net) on the BF16
+// matrix rate with fp32-grade results.  fc1 / fc2 are the one place of the period where the matrix pipe itself is the bound
+// (k_transfer_fwd<32,2,1,2>: 61 % MFMA-busy on its partition), and gfx950 runs v_mfma_f32_16x16x32_bf16 at 16 times the rate of
+// v_mfma_f32_16x16x4_f32 (no xf32 / tf32 forms on this part).  Every fp32 operand is split EXACTLY into three bf16 terms,
+//     x = x1 + x2 + x3 (+ a remainder below 2^-26 |x|):   x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)
+// (the subtractions are exact in fp32), and a product a*b is the six bf16 products whose weight is at least 2^-16 of it,
+//     a1 b1 + a1 b2 + a2 b1 + a2 b2 + a1 b3 + a3 b1,   accumulated in fp32 by the matrix core
+// -- what is dropped (a2 b3, a3 b2, a3 b3) is below 2^-24 |a b|, i.e. below the rounding of ONE fp32 product.  Six bf16 products
+// of K = 32 replace eight fp32 products of K = 4: 2.5 times fewer matrix-pipe cycles, for 1.5 times the operand bytes.  The
+// weights' three planes are laid out per (tile, k-step, plane, lane) once per call (k_theta_pack_bx3), the activations are split
+// when they are written to LDS.  d = 32, rows through identity indexing, no saves (the training forwards keep the fp32 products:
+// they are latency-bound, and z1 feeds a backward that is pinned to them).  Against k_transfer_fwd<32,2,1,2> on the same rows:
+// max relative difference ~1e-6 (tests).  SML_FWD_BX3=0: the fp32 kernel.
+// ------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma_bf(const uint4& a, const uint4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ uint32_t bf16_rne(float x) {          // round to nearest even (a NaN stays a NaN: 0x7fc0 + carry-free)
+    uint32_t u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ void split3(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
+    const uint32_t a = bf16_rne(x);
+    const float r1 = x - __uint_as_float(a << 16);
+    const uint32_t b = bf16_rne(r1);
+    const float r2 = r1 - __uint_as_float(b << 16);
+    h = (unsigned short)a; m = (unsigned short)b; l = (unsigned short)bf16_rne(r2);
+}
+// operand images of one net: P1x [32 column tiles][K1/32 k-steps][3 planes][64 lanes][8 bf16], P2x [D/16][16][3][64][8]
+__host__ __device__ constexpr int sml_bx3_p1(int d) { return 0; }
+__host__ __device__ constexpr int sml_bx3_p2(int d) { return 32 * (SML_C2 * d / 32) * 3 * 512; }                 // (ushorts)
+__host__ __device__ constexpr int sml_bx3_size(int d) { return sml_bx3_p2(d) + (d / 16) * 16 * 3 * 512; }
+template <int D>
+__global__ __launch_bounds__(256) void k_theta_pack_bx3(const float* __restrict__ theta, unsigned short* __restrict__ pkx) {
+    constexpr int K1 = SML_C2 * D, KS1 = K1 / 32, NF1 = SML_HID * K1, NF2 = D * SML_HID;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * (NF1 + NF2)) return;
+    const int net = i / (NF1 + NF2), e = i % (NF1 + NF2);
+    const float* th = theta + (int64_t)net * sml_net_size(D);
+    unsigned short* out = pkx + (int64_t)net * sml_bx3_size(D);
+    float x; int base;
+    if (e < NF1) {                                               // fc1.weight[n][k]: column n, reduction k
+        const int n = e / K1, k = e % K1;
+        x = th[SML_OFF_F1W + e];
+        base = sml_bx3_p1(D) + (((n >> 4) * KS1 + (k >> 5)) * 3 * 64 + ((n & 15) + 16 * ((k >> 3) & 3))) * 8 + (k & 7);
+    } else {                                                     // fc2.weight[j][n]: column j, reduction n
+        const int f = e - NF1, j = f / SML_HID, n = f % SML_HID;
+        x = th[sml_off_f2w(D) + f];
+        base = sml_bx3_p2(D) + (((j >> 4) * 16 + (n >> 5)) * 3 * 64 + ((j & 15) + 16 * ((n >> 3) & 3))) * 8 + (n & 7);
+    }
+    unsigned short h, m, l;
+    split3(x, h, m, l);
+    out[base] = h; out[base + 512] = m; out[base + 1024] = l;    // (planes are 64 lanes * 8 = 512 entries apart)
+}
+
+template <int D, bool SIDE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_transfer_fwd_bx3(SmlFwdArgs a, const unsigned short* __restrict__ pkx) {
+    static_assert(D == 32, "bf16x3 table-sized forward: d = 32");
+    constexpr int R = 32, MT = 2;                                // rows per workgroup
+    constexpr int K1 = SML_C2 * D, KS1 = K1 / 32;                // fc1 reduction: 160 = 5 k-steps of 32
+    constexpr int HSEQ = 4, HL = SML_HID / HSEQ;                 // hidden units per pass: 128 = one column tile per wave
+    constexpr int S1B = K1 + 8, S2B = HL + 8;                    // LDS row strides (bf16 elements; rows stay 16-byte aligned)
+    constexpr int EPT = R * D / 512;
+    constexpr int JT = D / 16;                                   // fc2 column tiles (2)
+    constexpr int KSPL = 8 / JT;                                 // fc2: waves along K (4: one k-step of the pass each) x JT column tiles
+    static_assert(HL / 32 == KSPL && HL / 16 == 8, "one fc1 column tile and one fc2 k-step per wave and pass");
+    __shared__ __attribute__((aligned(16))) unsigned short A1b[3][R][S1B];      // the A1 tile's three bf16 planes
+    __shared__ __attribute__((aligned(16))) unsigned short A2b[3][R][S2B];      // Gelu(z1) of the current pass
+    __shared__ float cws[104];
+    float* part = reinterpret_cast<float*>(&A2b[0][0][0]);       // [KSPL][R][D + 1] fc2 partials, after the last pass
+    static_assert(sizeof(A2b) >= KSPL * R * (D + 1) * sizeof(float), "part fits");
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+    const int tile = (int)blockIdx.x;
+    const SmlSeg sg = a.seg[0];
+    const int row0 = tile * R;
+    const float* __restrict__ theta = sg.theta;
+    if (tid < 104) cws[tid] = theta[tid];
+    const unsigned short* __restrict__ p1x = pkx + sml_bx3_p1(D);
+    const unsigned short* __restrict__ p2x = pkx + sml_bx3_p2(D);
+    // fc1 operand planes (this wave's column tile of the pass; 3 planes x 16 bytes per lane and k-step): a two-deep ring over the
+    // HSEQ * KS1 steps of the whole kernel -- step s + 1 is fetched while step s multiplies (static indices: the loops are unrolled)
+    uint4 bw[2][3];
+    auto load_b1 = [&](int s_, uint4 (&dst)[3]) {
+        const int hp_ = s_ / KS1, ks_ = s_ % KS1;
+        const int T = hp_ * (HL / 16) + wv;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            dst[p] = *reinterpret_cast<const uint4*>(p1x + ((((int64_t)T * KS1 + ks_) * 3 + p) * 64 + lane) * 8);
+    };
+    // ---- gather x_t, x_hat (identity indexing: table-sized calls pass the tables themselves)
+    float xt[EPT], xh[EPT], nr2[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int e = q * 512 + tid, r = e / D, w = e % D;
+        const int row = row0 + r;
+        const bool ok = row < sg.n_rows;
+        xt[q] = ok ? sg.xt_tab[(int64_t)row * D + w] : 1.0f;
+        xh[q] = ok ? sg.xh_tab[(int64_t)row * D + w] : 0.0f;
+    }
+    load_b1(0, bw[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        float s2 = xt[q] * xt[q];
+#pragma unroll
+        for (int off = D / 2; off >= 1; off >>= 1) s2 += __shfl_xor(s2, off, 64);
+        nr2[q] = s2;
+    }
+    __syncthreads();                                             // cws
+    // ---- x_com, conv1, Gelu, conv2, Gelu -> A1 (channel-major flatten c*D + w), split into its three planes
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        __builtin_amdgcn_sched_barrier(0);                       // (one element's prologue at a time: interleaved they spilled)
+        const int e = q * 512 + tid, r = e / D, w = e % D;
+        const float xc = a.k2 ? 0.0f : (xt[q] * xh[q]) / sqrtf(nr2[q]);        // no epsilon, as model/conv_transfer.py:99
+        Pro p;
+        conv_prologue(cws, xt[q], xh[q], xc, p);
+#pragma unroll
+        for (int c = 0; c < SML_C2; ++c) {
+            unsigned short h, m, l;
+            split3(sml_gelu(p.h2p[c]), h, m, l);
+            A1b[0][r][c * D + w] = h; A1b[1][r][c * D + w] = m; A1b[2][r][c * D + w] = l;
+        }
+    }
+    float bias2[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) bias2[q] = theta[sml_off_f2b(D) + (q * 512 + tid) % D];
+    __syncthreads();
+    const int kq = wv % KSPL, jq = wv / KSPL;                    // fc2: this wave's k-step of the pass and its column tile
+    f32x4 acc2[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc2[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int hp = 0; hp < HSEQ; ++hp) {
+        // fc2 operand planes of this pass (global k-step hp * KSPL + kq, column tile jq), and this pass's bias
+        uint4 b2[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            b2[p] = *reinterpret_cast<const uint4*>(p2x + ((((int64_t)jq * 16 + hp * KSPL + kq) * 3 + p) * 64 + lane) * 8);
+        const float bias1 = theta[sml_off_f1b(D) + hp * HL + wv * 16 + l15];
+        // ---- fc1: Z1[R x 16] of this wave's column tile; six bf16 products per (row tile, k-step)
+        f32x4 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+            const int st_ = hp * KS1 + ks;                       // (compile-time: both loops are unrolled)
+            if (st_ + 1 < HSEQ * KS1) load_b1(st_ + 1, bw[(st_ + 1) & 1]);
+            uint4 av[MT][3];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    av[mt][p] = *reinterpret_cast<const uint4*>(&A1b[p][mt * 16 + l15][ks * 32 + 8 * g4]);
+            // (plane pairs in ascending weight: the small terms first; consecutive products go to different accumulators)
+#pragma unroll
+            for (int pp = 0; pp < 6; ++pp) {
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma_bf(av[mt][PA[pp]], bw[st_ & 1][PB[pp]], acc[mt]);
+            }
+            __builtin_amdgcn_sched_barrier(0);                   // (the unrolled steps stay steps: hoisted operand reads were spilling)
+        }
+        if (hp > 0) __syncthreads();                             // the previous pass's fc2 is done with the a2 tile
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = mt * 16 + 4 * g4 + q;
+                unsigned short h, m, l;
+                split3(sml_gelu(acc[mt][q] + bias1), h, m, l);
+                A2b[0][r][wv * 16 + l15] = h; A2b[1][r][wv * 16 + l15] = m; A2b[2][r][wv * 16 + l15] = l;
+            }
+        __syncthreads();
+        // ---- fc2: Out[R x 16 (tile jq)] += a2[R x 32 (k-step kq of the pass)] * W2^T
+        {
+            uint4 av[MT][3];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    av[mt][p] = *reinterpret_cast<const uint4*>(&A2b[p][mt * 16 + l15][kq * 32 + 8 * g4]);
+#pragma unroll
+            for (int pp = 0; pp < 6; ++pp) {
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc2[mt] = mfma_bf(av[mt][PA[pp]], b2[PB[pp]], acc2[mt]);
+            }
+        }
+    }
+    __syncthreads();                                             // every wave is done reading the a2 tile: `part` may overwrite it
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            part[(kq * R + mt * 16 + 4 * g4 + q) * (D + 1) + jq * 16 + l15] = acc2[mt][q];
+    __syncthreads();
+    float sres[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int e = q * 512 + tid, r = e / D, j = e % D;
+        float sacc = bias2[q];
+#pragma unroll
+        for (int k = 0; k < KSPL; ++k) sacc += part[(k * R + r) * (D + 1) + j];
+        sres[q] = sacc;
+    }
+    if (a.unit_rows) {            // ConvTransfer.forward(type='user'): x / ||x|| (model/conv_transfer.py:62-64); a row = 32 neighbouring lanes
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            float n2 = sres[q] * sres[q];
+#pragma unroll
+            for (int off = D / 2; off >= 1; off >>= 1) n2 += __shfl_xor(n2, off, 64);
+            sres[q] = sres[q] / sqrtf(n2);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int e = q * 512 + tid, r = e / D, j = e % D;
+        if (row0 + r < sg.n_rows) st_out<SML_WT_FWD>(&sg.out[(int64_t)(row0 + r) * D + j], sres[q]);
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // MF stage: the row update inside the backward (SmlFusedUpdate; replaces the k_run_update<Adam> launch on one GPU).
 // Called by ALL threads of the workgroup for their element (row, w) of the tile's x_hat gradient `g`; x1 = the forward's
 // replayed x_hat element.  A row's D elements sit in D neighbouring lanes of ONE wavefront (D <= 64).
@@ -2064,6 +2289,20 @@ hipError_t sml_launch_conv_state_init(int d, const float* theta, const float* m,
 }
 hipError_t sml_launch_grad_sumsq(const float* grad, int64_t n, float* out, hipStream_t st) {
     k_grad_sumsq<<<dim3(1), dim3(1024), 0, st>>>(grad, (long long)n, out);       // n is a multiple of four (two nets)
+    return hipGetLastError();
+}
+// bf16x3 table-sized forward (d = 32): image size in bytes, the pack launch, the forward launch (one 32-row tile per workgroup)
+size_t sml_bx3_bytes(int d) { return d == 32 ? (size_t)2 * sml_bx3_size(32) * sizeof(unsigned short) : 0; }
+hipError_t sml_launch_theta_pack_bx3(int d, const float* theta, void* pkx, hipStream_t st) {
+    if (d != 32) return hipErrorInvalidValue;
+    const int n = 2 * (SML_HID * SML_C2 * 32 + 32 * SML_HID);
+    k_theta_pack_bx3<32><<<dim3((n + 255) / 256), dim3(256), 0, st>>>(theta, (unsigned short*)pkx);
+    return hipGetLastError();
+}
+hipError_t sml_launch_fwd_bx3(int d, const SmlFwdArgs& a, const void* pkx_net, int tiles, hipStream_t st, bool side) {
+    if (d != 32) return hipErrorInvalidValue;
+    if (side) k_transfer_fwd_bx3<32, true><<<dim3(tiles), dim3(512), 0, st>>>(a, (const unsigned short*)pkx_net);
+    else k_transfer_fwd_bx3<32, false><<<dim3(tiles), dim3(512), 0, st>>>(a, (const unsigned short*)pkx_net);
     return hipGetLastError();
 }
 hipError_t sml_launch_theta_pack(int d, const float* theta, float* pk, hipStream_t st) {

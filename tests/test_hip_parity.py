@@ -1114,6 +1114,43 @@ def test_blocked_eval_equals_plain_eval(d, neg, I):
     assert torch.equal(blk, eng.eval_ranks(wu, wi, rows, blocked=True))       # cached buckets, repeatable
 
 
+@pytest.mark.parametrize("variant", ["conv_com", "conv"])
+def test_table_sized_forward_on_bf16_products_equals_the_fp32_products(variant, monkeypatch):
+    """Round 5: table-sized forwards at d = 32 (updata, model/transfer.py:884-902) run fc1 / fc2 on the bf16 matrix rate with every
+    fp32 operand split exactly into three bf16 terms and the six products above 2^-16 of a*b kept (k_transfer_fwd_bx3): against
+    the fp32-product kernel (SML_FWD_BX3=0) on the same 40,000 rows -- ragged last tile -- max-norm relative difference below
+    3e-6, i.e. inside fp32 summation-order noise; against the oracle's CPU forward at the forward tolerance; NaN rows (a zero
+    x_t row: x_com = 0/0, as in the reference) stay NaN rows; the ConvTransfer variant's unit-norm user output."""
+    d, n = 32, 40000 + 7
+    g = torch.Generator().manual_seed(7)
+    x_t, x_hat = torch.randn(n, d, generator=g) * 0.3, torch.randn(n, d, generator=g) * 0.3
+    x_t[5] = 0.0                                        # ||x_t|| = 0 -> x_com NaN -> the whole output row NaN (ConvTransfer_com only)
+    if variant == "conv":
+        from sml_amd.conv_transfer import ConvTransfer
+        with quiet():
+            net = ConvTransfer(d, d)
+    else:
+        net = make_transfer(d)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SML_FWD_BX3", mode)
+        eng = engine(d)
+        outs[mode] = [eng.transfer_forward(net.to(DEV), x_t.to(DEV), x_hat.to(DEV), which).cpu().numpy() for which in ("user", "item")]
+        eng.close()
+    net = net.cpu()
+    for k, which in enumerate(("user", "item")):
+        a, b = outs["0"][k], outs["1"][k]
+        nan_rows = np.isnan(a).any(1)
+        assert np.array_equal(nan_rows, np.isnan(b).any(1)) and bool(nan_rows[5]) == (variant == "conv_com")
+        ok = ~nan_rows
+        scale = np.abs(a[ok]).max()
+        assert np.abs(a[ok] - b[ok]).max() / scale < 3e-6, (which, np.abs(a[ok] - b[ok]).max() / scale)
+        assert not np.array_equal(a[ok], b[ok])                                   # (another kernel did run)
+        want = O.OracleEngine(d).transfer_forward(net, x_t[:512], x_hat[:512], which).numpy()
+        okw = ~np.isnan(want).any(1)
+        np.testing.assert_allclose(b[:512][okw], want[okw], rtol=1e-4, atol=2e-6)
+
+
 # ----------------------------------------------------------------------------- G10 / bare Adam (baselines' loop)
 def test_g10_bare_adam_epochs_match_reference_and_oracle():
     """The baselines' bare-MF fine-tune loop (reference model/baseline.py SPMF.run_one_stage2, recorded as G10):
