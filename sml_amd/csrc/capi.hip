@@ -763,6 +763,13 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
     const int fns = fwd_split(wg_tiles(batch, 1) + wg_tiles(2 * batch, 1)), bsplit = bwd_split(wg_tiles(batch, 1) + wg_tiles(2 * batch, 1));
     HIPCHK(ctx->loss_part.ensure((size_t)nb * lstride));
     ctx->prof.begin(PC_PACK, st); HIPCHK(sml_launch_theta_pack(d, theta, pk_cur(ctx), st)); ctx->prof.end(st);
+    // d = 32, one workgroup per row tile: the forward's fc1 / fc2 on bf16x3 products (k_mf_fwd_bx3; SML_MF_BX3=0: fp32 products);
+    // theta is fixed during the MF stage: its bf16 planes are packed once per epoch
+    const bool mf_bx3 = fns == 1 && sml_bx3_bytes(d) > 0 && env_int("SML_MF_BX3", 1) != 0;
+    if (mf_bx3) {
+        HIPCHK(ctx->pkx.ensure(sml_bx3_bytes(d) / sizeof(float) + 4));
+        ctx->prof.begin(PC_PACK, st); HIPCHK(sml_launch_theta_pack_bx3(d, theta, ctx->pkx.p, st)); ctx->prof.end(st);
+    }
     // One GPU, the one-workgroup-per-tile backward, a row inside one wavefront (d <= 64): the backward takes the row update itself
     // (SmlFusedUpdate; SML_MF_FUSED_UPDATE=0: the k_run_update launch, A/B tests) -- and, round 5, the net runs once per DISTINCT
     // row of the batch (SmlDense; SML_MF_DISTINCT=0: one pass per occurrence, A/B tests) when the lists allow it
@@ -818,7 +825,10 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
         f.tiles0 = wg_tiles(B, 1); f.cur_step = cur; f.sched = ctx->sched.p; f.out_pstride = out_pstride; f.k2 = ctx->variant == 1;
         const int tiles = f.tiles0 + wg_tiles(2 * B, 1);
         f.tiles_total = tiles;
-        ctx->prof.begin(PC_FWD, st); HIPCHK(sml_launch_fwd(d, 1, fns, f, tiles, st)); ctx->prof.end(st);
+        ctx->prof.begin(PC_FWD, st);
+        if (mf_bx3) HIPCHK(sml_launch_mf_fwd_bx3(d, f, ctx->pkx.p, tiles, st));
+        else HIPCHK(sml_launch_fwd(d, 1, fns, f, tiles, st));
+        ctx->prof.end(st);
         SmlBwdArgs w;
         memset(&w, 0, sizeof(w));
         for (int s = 0; s < 2; ++s) {

@@ -191,6 +191,7 @@ hipError_t sml_launch_theta_pack(int d, const float* theta, float* pk, hipStream
 // table-sized forward on bf16 products with fp32-grade results (transfer_net.hip, k_transfer_fwd_bx3): d = 32
 size_t sml_bx3_bytes(int d);                     // operand images of both nets (0: not available at this d)
 hipError_t sml_launch_theta_pack_bx3(int d, const float* theta, void* pkx, hipStream_t st);
+hipError_t sml_launch_mf_fwd_bx3(int d, const SmlFwdArgs& a, const void* pkx, int tiles, hipStream_t st);      // the MF stage's 16-row forward (both nets' images)
 hipError_t sml_launch_fwd_bx3(int d, const SmlFwdArgs& a, const void* pkx_net, int tiles, hipStream_t st, bool side);
 int sml_wgrad_grid(int d);                       // workgroups (= pushers) of one weight-gradient launch
 // generic push / wait / rank-order sum over peer mappings (mf_kernels.hip)

@@ -454,6 +454,168 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 
 // ------------------------------------------------------------------------------------
+// The MF stage's forward (one 16-row tile per workgroup, the whole net: k_transfer_fwd<32,1,1>'s job) with fc1 / fc2 on the
+// bf16x3 products above.  A 16-row tile's fc1 is 160 fp32 matrix products per wave = 4.3 us of ONE CU's matrix pipe -- the
+// phase that kernel's timeline is longest in -- against 120 bf16 products at a third of the cycles each; the operand planes are
+// packed once per epoch (theta does not move during the MF stage).  Gather (triples or the distinct-row records), lazy-Adam
+// replay, the saves for the backward (x_t / x_hat / x_com, z1 in fp32, the replayed moments) and `out` as in the fp32 kernel;
+// the backward keeps the fp32 products (its GEMMs come next).  SML_MF_BX3=0: k_transfer_fwd<32,1,1>.
+// ------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_mf_fwd_bx3(SmlFwdArgs a, const unsigned short* __restrict__ pkx) {
+    static_assert(D == 32, "bf16x3 MF forward: d = 32");
+    constexpr int R = SML_TM;
+    constexpr int K1 = SML_C2 * D, KS1 = K1 / 32;
+    constexpr int CT = SML_HID / 16 / 8;                         // fc1 column tiles per wave (4)
+    constexpr int S1B = K1 + 8, S2B = SML_HID + 8;
+    constexpr int JT = D / 16, KPW = SML_HID / 32 / 8;           // fc2: 8 waves along K, KPW k-steps of 32 each (2); JT column tiles
+    __shared__ __attribute__((aligned(16))) unsigned short A1b[3][R][S1B];
+    __shared__ __attribute__((aligned(16))) unsigned short A2b[3][R][S2B];
+    __shared__ float cws[104];
+    __shared__ SmlSched swin[SML_SW];
+    float* part = reinterpret_cast<float*>(&A2b[0][0][0]);       // [8][R][D + 1] fc2 partials, once the a2 tile is done with
+    static_assert(sizeof(A2b) >= 8 * R * (D + 1) * sizeof(float), "part fits");
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+    const int tile = (int)blockIdx.x;
+    const int sidx = tile >= a.tiles0;
+    const SmlSeg sg = sidx ? a.seg[1] : a.seg[0];
+    const int tl = tile - (sidx ? a.tiles0 : 0);
+    const int row0 = tl * R;
+    const float* __restrict__ theta = sg.theta;
+    const unsigned short* __restrict__ p1x = pkx + (int64_t)sidx * sml_bx3_size(D) + sml_bx3_p1(D);
+    const unsigned short* __restrict__ p2x = pkx + (int64_t)sidx * sml_bx3_size(D) + sml_bx3_p2(D);
+    if (tid < 104) cws[tid] = theta[tid];
+    const bool lazy = sg.last_tab != nullptr;
+    if (lazy) sched_window_load(swin, a.sched, a.cur_step - 1, tid);
+    // ---- gather: one element per thread (row r = tid / D of the tile, coordinate w)
+    const int r = tid / D, w = tid % D;
+    bool ok; int64_t idx;
+    if (sg.drec != nullptr) {                                    // distinct-row form: header and records in one round trip
+        const int live = (int)sg.hdr[tl].nrows;
+        const uint32_t trow = sg.drec[row0 + r].row;
+        ok = r < live; idx = ok ? (int64_t)trow : 0;
+        if (live == 0) return;
+    } else {
+        ok = row0 + r < sg.n_rows;
+        idx = ok ? seg_row_index(sg, row0 + r) : 0;
+    }
+    float xt = sg.xt_tab[idx * D + w], xh = sg.xh_tab[idx * D + w];
+    float m = 0.0f, v = 0.0f; int from = -1;
+    if (lazy) { m = sg.m_tab[idx * D + w]; v = sg.v_tab[idx * D + w]; from = sg.last_tab[idx]; }
+    // fc1 operand planes: wave wv owns column tiles wv * CT + t; a two-deep ring over the KS1 k-steps, behind the gather's loads
+    uint4 bw[2][CT][3];
+    auto load_b1 = [&](int ks, uint4 (&dst)[CT][3]) {
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                dst[t][p] = *reinterpret_cast<const uint4*>(p1x + ((((int64_t)(wv * CT + t) * KS1 + ks) * 3 + p) * 64 + lane) * 8);
+    };
+    load_b1(0, bw[0]);
+    float bias1[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) bias1[t] = theta[sml_off_f1b(D) + (wv * CT + t) * 16 + l15];
+    const float bias2 = theta[sml_off_f2b(D) + w];
+    __builtin_amdgcn_sched_barrier(0);
+    if (!ok) { xt = 1.0f; xh = 0.0f; }
+    float nr2 = xt * xt;
+#pragma unroll
+    for (int off = D / 2; off >= 1; off >>= 1) nr2 += __shfl_xor(nr2, off, 64);
+    __syncthreads();                                             // cws and the schedule window are in LDS
+    if (lazy) {
+        if (ok) adam_replay_w(xh, m, v, from, a.cur_step - 1, a.sched, swin, a.cur_step - 1);
+        if (sg.mrep != nullptr) {                                // the row update continues from these (same tile, same XCD: plain stores)
+            sg.mrep[(int64_t)(row0 + r) * D + w] = ok ? m : 0.0f;
+            sg.vrep[(int64_t)(row0 + r) * D + w] = ok ? v : 0.0f;
+        }
+    }
+    {   // ---- x_com, conv1, Gelu, conv2, Gelu -> A1 (channel-major flatten), split into its three planes; the backward's inputs
+        const float xc = a.k2 ? 0.0f : (xt * xh) / sqrtf(nr2);   // no epsilon, as model/conv_transfer.py:99
+        Pro p;
+        conv_prologue(cws, xt, xh, xc, p);
+#pragma unroll
+        for (int c = 0; c < SML_C2; ++c) {
+            unsigned short h, mm, l;
+            split3(sml_gelu(p.h2p[c]), h, mm, l);
+            A1b[0][r][c * D + w] = h; A1b[1][r][c * D + w] = mm; A1b[2][r][c * D + w] = l;
+        }
+        if (sg.xin != nullptr) {
+            float* x = sg.xin + (int64_t)(row0 + r) * 3 * D;
+            x[w] = xt; x[D + w] = xh; x[2 * D + w] = xc;
+        }
+    }
+    __syncthreads();
+    // ---- fc1: Z1[16 x 512]; wave wv: CT column tiles, KS1 k-steps, six bf16 products per (tile, k-step)
+    f32x4 acc[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) {
+        if (ks + 1 < KS1) load_b1(ks + 1, bw[(ks + 1) & 1]);
+        uint4 av[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) av[p] = *reinterpret_cast<const uint4*>(&A1b[p][l15][ks * 32 + 8 * g4]);
+#pragma unroll
+        for (int pp = 0; pp < 6; ++pp) {
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < CT; ++t) acc[t] = mfma_bf(av[PA[pp]], bw[ks & 1][t][PB[pp]], acc[t]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // fc2 operand planes of this wave's KPW k-steps (issued now: they ride under the epilogue)
+    uint4 b2[KPW][JT][3];
+#pragma unroll
+    for (int k2 = 0; k2 < KPW; ++k2)
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                b2[k2][jt][p] = *reinterpret_cast<const uint4*>(p2x + ((((int64_t)jt * 16 + wv * KPW + k2) * 3 + p) * 64 + lane) * 8);
+    // + bias, save z1 (fp32: the backward's Gelu'), Gelu -> the a2 tile's three planes
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        const int n = (wv * CT + t) * 16 + l15;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rr = 4 * g4 + q;
+            const float z = acc[t][q] + bias1[t];
+            if (sg.z1 != nullptr) sg.z1[(int64_t)(row0 + rr) * SML_HID + n] = z;
+            unsigned short h, mm, l;
+            split3(sml_gelu(z), h, mm, l);
+            A2b[0][rr][n] = h; A2b[1][rr][n] = mm; A2b[2][rr][n] = l;
+        }
+    }
+    __syncthreads();
+    // ---- fc2: Out[16 x D] = a2[16 x 512] * W2^T; wave wv: k-steps wv * KPW .. + KPW - 1, both column tiles
+    f32x4 acc2[JT];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) acc2[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k2 = 0; k2 < KPW; ++k2) {
+        uint4 av[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) av[p] = *reinterpret_cast<const uint4*>(&A2b[p][l15][(wv * KPW + k2) * 32 + 8 * g4]);
+#pragma unroll
+        for (int pp = 0; pp < 6; ++pp) {
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) acc2[jt] = mfma_bf(av[PA[pp]], b2[k2][jt][PB[pp]], acc2[jt]);
+        }
+    }
+    __syncthreads();                                             // every wave is done with the a2 tile: `part` overwrites it
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) part[(wv * R + 4 * g4 + q) * (D + 1) + jt * 16 + l15] = acc2[jt][q];
+    __syncthreads();
+    float sres = bias2;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sres += part[(k * R + r) * (D + 1) + w];
+    if (row0 + r < sg.n_rows) st_out<SML_WT_FWD>(&sg.out[(int64_t)(row0 + r) * D + w], sres);
+}
+
+// ------------------------------------------------------------------------------------
 // MF stage: the row update inside the backward (SmlFusedUpdate; replaces the k_run_update<Adam> launch on one GPU).
 // Called by ALL threads of the workgroup for their element (row, w) of the tile's x_hat gradient `g`; x1 = the forward's
 // replayed x_hat element.  A row's D elements sit in D neighbouring lanes of ONE wavefront (D <= 64).
@@ -2303,6 +2465,11 @@ hipError_t sml_launch_fwd_bx3(int d, const SmlFwdArgs& a, const void* pkx_net, i
     if (d != 32) return hipErrorInvalidValue;
     if (side) k_transfer_fwd_bx3<32, true><<<dim3(tiles), dim3(512), 0, st>>>(a, (const unsigned short*)pkx_net);
     else k_transfer_fwd_bx3<32, false><<<dim3(tiles), dim3(512), 0, st>>>(a, (const unsigned short*)pkx_net);
+    return hipGetLastError();
+}
+hipError_t sml_launch_mf_fwd_bx3(int d, const SmlFwdArgs& a, const void* pkx, int tiles, hipStream_t st) {
+    if (d != 32) return hipErrorInvalidValue;
+    k_mf_fwd_bx3<32><<<dim3(tiles), dim3(512), 0, st>>>(a, (const unsigned short*)pkx);
     return hipGetLastError();
 }
 hipError_t sml_launch_theta_pack(int d, const float* theta, float* pk, hipStream_t st) {
