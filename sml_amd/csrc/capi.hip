@@ -173,6 +173,8 @@ struct IndexSet {
     bool by_hand = false;              // the lists were built by index_prep.hip: a batch's runs are off[b] .. off[b] + cnt[b]
     Buf<char> cub_tmp;
     int key_bytes = 8, row_bits_u = 32, row_bits_i = 32;
+    int* viol_host = nullptr;          // pinned: entries emit_bucket found out of (row, value) order, ever (SmlPrepArgs.order_viol)
+    hipEvent_t viol_ready = nullptr;
     int* max_len_host = nullptr;       // pinned: longest duplicated run of the prepared epoch (0 if none exceeds SML_HOT)
     int* lists_host = nullptr;         // pinned, compact lists by hand: [off_u (nb+1)][off_i (nb+1)][cnt_u (nb*STRIDE)][cnt_i (nb*STRIDE)] -- the
     int64_t lists_host_nb = 0, lists_nb = 0;   // (capacity; batches of the prepared epoch, 0: not read back) batches' places in the run lists, read back with max_len (same event): the run kernel then needs no offset / count loads
@@ -188,6 +190,8 @@ struct IndexSet {
         uniq.release(); slot_info.release(); heads_u.release(); heads_i.release(); hot_list.release(); hot_count.release(); off_u.release(); off_i.release(); n_sel.release();
         cub_tmp.release();
         if (max_len_host) { g_graveyard.park_host(max_len_host); max_len_host = nullptr; }
+        if (viol_host) { g_graveyard.park_host(viol_host); viol_host = nullptr; }
+        if (viol_ready) { (void)hipEventDestroy(viol_ready); viol_ready = nullptr; }
         if (lists_host) { g_graveyard.park_host(lists_host); lists_host = nullptr; lists_host_nb = 0; }
         if (ready) { (void)hipEventDestroy(ready); ready = nullptr; }
     }
@@ -423,10 +427,18 @@ static bool prep_by_hand() {
 // mode 0: this rank's own occurrences.  1: replicated items on several GPUs (bx: the item lists are the JOB's).
 // 2 / 3: the item-sharded step's lists A (users + the job's occurrences of the tail rows this rank owns) and B (this
 // rank's own occurrences of head rows; no users) -- sh, rows_cap.  See occ_of in index_prep.hip.
+// a completed read-back of the sorted-order violation count that is not zero: some earlier list of this index set was wrong
+int sort_order_check(IndexSet* c) {
+    if (c->viol_host && c->viol_ready && hipEventQuery(c->viol_ready) == hipSuccess && *c->viol_host != 0)
+        return fail(SML_ESTATE, "index preparation", "a sorted bucket left out of (row, value) order: the stable ranking failed on this device "
+                                                     "(SML_PREP_RANK=ballot selects the ballot ranking)");
+    return SML_OK;
+}
 int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_tiles, int64_t n_user, int64_t n_item,
                bool dups, hipStream_t st, const sml_batch_plan* plan, int mode = 0, const sml_bare_exchange* bx = nullptr,
                const sml_bare_shard* sh = nullptr, int64_t rows_cap = 0, bool want_dense = false) {
     const int64_t nb = plan ? plan->n_batches : (n + batch - 1) / batch;
+    { const int vrc = sort_order_check(c); if (vrc) return vrc; }
     c->by_hand = true; c->slot_stride = 0; c->dense = false;
     if (n == 0) { c->n = 0; c->batch = batch; c->triples = tri; return SML_OK; }
     const int W = mode == 1 ? bx->world : (mode == 2 ? sh->world : 1);
@@ -534,9 +546,16 @@ int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
         c->rank_probed = true;
     }
     { const char* rk = getenv("SML_PREP_RANK"); a.rank_viol = (rk && !strcmp(rk, "ballot")) ? nullptr : c->rank_viol.p; }
+    a.order_viol = c->rank_viol.p + 1;             // (word 1 of the probe's block: zeroed with it, never reset)
     if (a.dense && !(a.t[0].nbk == 1 && a.t[1].nbk == 1)) a.dense = 0;       // (wide rows forced more buckets: per-occurrence form)
     c->dense = a.dense != 0;
     HIPCHK(sml_launch_prep(a, narrow ? 4 : 8, st));
+    // the sorted-order invariant's violation count travels to the host behind every preparation (4 bytes); the NEXT call that
+    // finds a completed copy with a non-zero count fails: a list was built wrong (sort_order_check)
+    if (!c->viol_host) { HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->viol_host), sizeof(int), hipHostMallocDefault)); *c->viol_host = 0; }
+    if (!c->viol_ready) HIPCHK(hipEventCreateWithFlags(&c->viol_ready, hipEventDisableTiming));
+    HIPCHK(hipMemcpyAsync(c->viol_host, c->rank_viol.p + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(c->viol_ready, st));
     if (dups) {
         if (!c->max_len_host) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->max_len_host), sizeof(int), hipHostMallocDefault));
         if (!c->ready) HIPCHK(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
@@ -1268,6 +1287,7 @@ int sml_embed_loss_sgd_epoch(sml_ctx* ctx, void* w_user, void* w_item, int64_t n
     // reducers then find, on the device, that their lists are empty.
     const int hot_cap = X->hot_cap;
     const bool known = hipEventQuery(X->ready) == hipSuccess;
+    if ((rc = sort_order_check(X))) return rc;          // (the prepared lists' sorted-order invariant, once its read-back has landed)
     const bool hot = hot_cap > 0 && (!known || *X->max_len_host > SML_HOT);
     const int world = xchg ? xchg->world : 1;
     const int hot_chunks = (int)(((int64_t)batch + (int64_t)world * 2 * batch) / SML_HOT_CHUNK) + hot_cap;

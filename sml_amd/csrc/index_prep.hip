@@ -505,6 +505,11 @@ __device__ __forceinline__ uint32_t emit_bucket(const SmlPrepArgs& a, const SmlP
                 e = get(q); rh = ent_hi<E>(e, vb);
                 head = q == 0 || ent_hi<E>(get(q - 1), vb) != rh;
                 tail = q + 1 >= S || ent_hi<E>(get(q + 1), vb) != rh;
+                if (a.order_viol != nullptr && q + 1 < S) {
+                    const E en = get(q + 1);
+                    const uint32_t nh = ent_hi<E>(en, vb);
+                    if (nh < rh || (nh == rh && ent_val<E>(en, vb) <= ent_val<E>(e, vb))) atomicAdd(a.order_viol, 1);
+                }
             }
             const uint32_t val = ent_val<E>(e, vb);
             if (in) tb.vals[pos0 + q] = val;
@@ -550,6 +555,9 @@ __device__ __forceinline__ uint32_t emit_bucket(const SmlPrepArgs& a, const SmlP
             e = get(q); rh = ent_hi<E>(e, vb);
             prev = q > 0 ? ent_hi<E>(get(q - 1), vb) : ~rh;
             next = q + 1 < S ? ent_hi<E>(get(q + 1), vb) : ~rh;
+            // the sorted bucket's invariant (SmlPrepArgs.order_viol): (row, value) ascending -- an unstable rank would break it
+            if (a.order_viol != nullptr && q + 1 < S && (next < rh || (next == rh && ent_val<E>(get(q + 1), vb) <= ent_val<E>(e, vb))))
+                atomicAdd(a.order_viol, 1);
         }
         const bool head = in && prev != rh, tail = in && next != rh;
         const bool dup = in && !(head && tail);

@@ -313,6 +313,11 @@ struct SmlPrepArgs {
     // stable ranks from ONE returning LDS atomic per occurrence, if *rank_viol == 0: the context's start-up probe
     // (sml_launch_rank_probe) counted no returning atomic that was served out of lane order; null / non-zero: ballot ranking
     const int* rank_viol;
+    // always-on invariant of every sorted bucket that leaves through emit_bucket: neighbouring entries must be ordered by
+    // (row, value) -- a stable sort of occurrences whose values ascend in occurrence order.  Violations are COUNTED here (never reset:
+    // any non-zero value means a list of this index set was built wrong at some point) and the next epoch call that finds the count
+    // on the host fails with SML_ESTATE.  null: off.
+    int* order_viol;
 };
 hipError_t sml_launch_rank_probe(int* viol, hipStream_t st);
 hipError_t sml_launch_prep(const SmlPrepArgs& a, int ent_bytes, hipStream_t st);
