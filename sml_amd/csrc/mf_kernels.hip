@@ -184,15 +184,27 @@ __global__ __launch_bounds__(1024) void k_adaptive_users(const float* __restrict
     if (threadIdx.x == 0) { float s2 = 0.0f; for (int w = 0; w < 16; ++w) s2 += part[w]; *loss_slot += s2; }
 }
 
-__global__ __launch_bounds__(64) void k_loss_finalize(const float* __restrict__ part, int n_batches, int stride,
-                                                     float* __restrict__ out) {
+// (round 5: 256 threads per batch, eight loads in flight per thread.  One wavefront walking a bare batch's 8,192 partials with one
+// dependent load per trip took 49 us per epoch -- 3 us per 262,144-triple batch of the a3 step's END-TO-END time.  Fixed order:
+// thread t adds elements t, t + 256, ... in ascending order, lanes by the xor butterfly, the four wavefronts in index order.)
+__global__ __launch_bounds__(256) void k_loss_finalize(const float* __restrict__ part, int n_batches, int stride,
+                                                      float* __restrict__ out) {
+    __shared__ float sh4[4];
     const int b = blockIdx.x;
     if (b >= n_batches) return;
+    const float* p = part + (int64_t)b * stride;
     float s = 0.0f;
-    for (int i = threadIdx.x; i < stride; i += 64) s += part[(int64_t)b * stride + i];
+    int i = threadIdx.x;
+    for (; i + 7 * 256 < stride; i += 8 * 256) {
+        float x[8];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (threadIdx.x == 0) out[b] = s;
+        for (int u = 0; u < 8; ++u) x[u] = p[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += x[u];
+    }
+    for (; i < stride; i += 256) s += p[i];
+    const float tot = block_sum256(s, sh4);
+    if (threadIdx.x == 0) out[b] = tot;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1158,7 +1170,7 @@ hipError_t sml_launch_adaptive_users(int d, const float* xin, float* dx, int B, 
     return hipGetLastError();
 }
 hipError_t sml_launch_loss_finalize(const float* part, int n_batches, int stride, const int*, float* out, hipStream_t st) {
-    k_loss_finalize<<<dim3(n_batches), dim3(64), 0, st>>>(part, n_batches, stride, out);
+    k_loss_finalize<<<dim3(n_batches), dim3(256), 0, st>>>(part, n_batches, stride, out);
     return hipGetLastError();
 }
 hipError_t sml_launch_bare_grad(int d, int dtype_bytes, const SmlBareArgs& a, int* n_blocks, hipStream_t st) {
