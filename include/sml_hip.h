@@ -179,7 +179,8 @@ typedef struct {
  * called on the host to all-gather each rank's per-occurrence item-gradient rows
  * (dx_local[item_off .. item_off + 2*batch) -> dx_items_all[world][2*batch][d]); the item
  * update then runs over the GLOBAL occurrence list (key_items/val_items: every batch's
- * world*2*B_b occurrences sorted by (batch << 32 | item row), value = slot in dx_items_all),
+ * world*2*B_b occurrences as (batch << 32 | item row), sorted by the caller or -- lists_unsorted -- by the library,
+ * value = slot in dx_items_all),
  * so all replicas apply the identical summed update.  loss_scale = B_local / B_global.
  * hook == NULL: the library's own RCCL communicator (sml_comm_init) does the all-gather. */
 typedef int (*sml_mf_hook)(void* user, int64_t batch_index);
@@ -199,6 +200,9 @@ typedef struct {
                                on every rank, 2*batch <= push_rows <= slot_stride (0: slot_stride).  There slot_stride must
                                equal the inboxes' rows_cap: the gathered buffer IS one parity of this rank's row slots, and
                                dx_items_all is not used. */
+    int lists_unsorted;     /* 1: key_items / val_items are batch-major (batch b's occurrences at item_off[b] .. / the uniform layout) but
+                               NOT sorted inside a batch: the library builds every batch's run list itself (index_prep.hip: stable, i.e.
+                               a row's occurrences keep the caller's order -- the same on every rank).  0: sorted (stably) by the caller. */
 } sml_mf_exchange;
 
 /* Batches of unequal size.  A global batch split over ranks by user owner leaves every rank a DIFFERENT number of

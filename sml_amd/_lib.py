@@ -32,7 +32,7 @@ class MFTables(ctypes.Structure):
 class MFExchange(ctypes.Structure):
     _fields_ = [("world", ctypes.c_int), ("key_items", c_void), ("val_items", c_void), ("dx_local", c_void),
                 ("dx_items_all", c_void), ("hook", MF_HOOK), ("hook_user", c_void), ("loss_scale", ctypes.c_float),
-                ("slot_stride", ctypes.c_int64), ("item_off", c_void), ("push_rows", ctypes.c_int64)]
+                ("slot_stride", ctypes.c_int64), ("item_off", c_void), ("push_rows", ctypes.c_int64), ("lists_unsorted", ctypes.c_int)]
 
 
 class BareExchange(ctypes.Structure):

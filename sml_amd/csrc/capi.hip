@@ -223,7 +223,8 @@ struct sml_ctx {
     hipEvent_t sched_ready = nullptr;            // behind the newest table's upload
     hipStream_t sched_stream = nullptr;
     Buf<int32_t> dummy;
-    Buf<SmlRun> rec_x;       // run records of the multi-GPU global item list
+    Buf<SmlRun> rec_x;       // run records of the multi-GPU global item list (caller-sorted keys)
+    Buf<int32_t> xoff;       // ... and, for lists the library builds itself, the batches' offsets in the occurrence stream
     ncclComm_t comm = nullptr;
     int comm_world = 1, comm_rank = 0;
     // one-shot exchange over peer mappings (sml_peer_attach): world == 0 means detached
@@ -252,7 +253,7 @@ struct sml_ctx {
         mrep.release(); vrep.release();
         pk.release(); pkx.release(); grad.release(); convg.release(); loss_part.release(); arrive.release(); run_arrive.release(); cstate.release();
         ix[0].release(); ix[1].release();
-        sched.release(); dummy.release(); rec_x.release();
+        sched.release(); dummy.release(); rec_x.release(); xoff.release();
         for (auto& r : sched_retired) { g_graveyard.park(r.dev); g_graveyard.park_host(r.host); (void)hipEventDestroy(r.done); }
         sched_retired.clear();
         if (sched_ready) { (void)hipEventDestroy(sched_ready); sched_ready = nullptr; }
@@ -429,23 +430,28 @@ static bool prep_by_hand() {
 // rank's own occurrences of head rows; no users) -- sh, rows_cap.  See occ_of in index_prep.hip.
 // a completed read-back of the sorted-order violation count that is not zero: some earlier list of this index set was wrong
 int sort_order_check(IndexSet* c) {
-    if (c->viol_host && c->viol_ready && hipEventQuery(c->viol_ready) == hipSuccess && *c->viol_host != 0)
-        return fail(SML_ESTATE, "index preparation", "a sorted bucket left out of (row, value) order: the stable ranking failed on this device "
-                                                     "(SML_PREP_RANK=ballot selects the ballot ranking)");
+    if (c->viol_host && c->viol_ready && hipEventQuery(c->viol_ready) == hipSuccess && *c->viol_host != 0) {
+        char msg[320];
+        const int w1 = c->viol_host[1], w2 = c->viol_host[2];
+        snprintf(msg, sizeof(msg), "a sorted bucket left out of (row, value) order (%d entries; first: occurrence source %d, table %d, batch %d, %s mode, "
+                                   "position %d of a %d-entry bucket): the stable ranking failed on this device (SML_PREP_RANK=ballot selects the ballot ranking)",
+                 c->viol_host[0], (w1 >> 28) & 7, (w1 >> 27) & 1, w1 & 0x3ffffff, (w1 >> 26) & 1 ? "records" : "compact / dense", w2 >> 12, w2 & 0xfff);
+        return fail(SML_ESTATE, "index preparation", msg);
+    }
     return SML_OK;
 }
 int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_tiles, int64_t n_user, int64_t n_item,
                bool dups, hipStream_t st, const sml_batch_plan* plan, int mode = 0, const sml_bare_exchange* bx = nullptr,
-               const sml_bare_shard* sh = nullptr, int64_t rows_cap = 0, bool want_dense = false) {
+               const sml_bare_shard* sh = nullptr, int64_t rows_cap = 0, bool want_dense = false, const uint32_t* x_vals = nullptr) {
     const int64_t nb = plan ? plan->n_batches : (n + batch - 1) / batch;
     { const int vrc = sort_order_check(c); if (vrc) return vrc; }
     c->by_hand = true; c->slot_stride = 0; c->dense = false;
     if (n == 0) { c->n = 0; c->batch = batch; c->triples = tri; return SML_OK; }
     const int W = mode == 1 ? bx->world : (mode == 2 ? sh->world : 1);
-    const int nis = 2 * W;                                  // item streams per tile
+    const int nis = mode == 4 ? 1 : 2 * W;                  // item streams per tile (mode 4: one stream of explicit occurrences)
     const int64_t n_items = (int64_t)nis * n;               // item occurrences of the epoch's lists (upper bound in modes 2 / 3)
     if (n_items > 0x7fffffff) return fail(SML_EINVAL, "index preparation", "too many item occurrences in one epoch");
-    const bool has_users = mode != 3, allruns_i = mode != 0;
+    const bool has_users = mode != 3 && mode != 4, allruns_i = mode != 0;
     SmlPrepArgs a;
     memset(&a, 0, sizeof(a));
     a.tri = tri; a.n = n; a.batch = batch; a.nb = (int)nb; a.tpb = (batch + SML_PREP_TT - 1) / SML_PREP_TT;
@@ -453,11 +459,12 @@ int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
     a.mode = mode; a.has_users = has_users ? 1 : 0; a.nis = nis;
     if (mode == 1) { a.items_all = bx->items_all; a.val_q = (int64_t)2 * batch; }
     if (mode == 2) { a.items_all = sh->items_all; a.val_q = rows_cap; }
-    if (mode >= 2) { a.head_rows = sh->head_rows; a.shard_rows = sh->shard_rows; a.shard_rank = sh->rank; }
+    if (mode == 4) { a.x_keys = reinterpret_cast<const uint64_t*>(tri); a.x_vals = x_vals; a.tri = nullptr; }
+    if (mode == 2 || mode == 3) { a.head_rows = sh->head_rows; a.shard_rows = sh->shard_rows; a.shard_rank = sh->rank; }
     const int64_t ioff_max = pad_tiles ? ((int64_t)(batch + SML_R - 1) / SML_R) * SML_R : batch;
     // values: users < batch; items < ioff + 2 * batch (own), < world * 2 * batch (mode 1), < world * rows_cap (mode 2), < 3 * batch (mode 3)
     const int64_t max_val_i = mode == 1 ? (int64_t)W * 2 * batch : mode == 2 ? (int64_t)W * rows_cap : mode == 3 ? (int64_t)3 * batch
-                                                                                                                  : ioff_max + 2 * (int64_t)batch;
+                              : mode == 4 ? rows_cap : ioff_max + 2 * (int64_t)batch;        // (mode 4: rows_cap carries the largest value + 1)
     const int64_t rows_i = mode == 2 ? sh->shard_rows : mode == 3 ? (sh->head_rows > 0 ? sh->head_rows : 1) : n_item;
     int vb[2] = {ceil_log2(batch), ceil_log2(max_val_i)};
     int lb[2], rb[2] = {n_user > 0 ? ceil_log2(n_user) : 32, rows_i > 0 ? ceil_log2(rows_i) : 32};
@@ -486,7 +493,7 @@ int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
         HIPCHK(c->off_u.ensure((size_t)nb + 1)); HIPCHK(c->off_i.ensure((size_t)nb + 1));
         HIPCHK(c->cnt_u.ensure((size_t)(nb + 1) * SML_PREP_CNT_STRIDE)); HIPCHK(c->cnt_i.ensure((size_t)(nb + 1) * SML_PREP_CNT_STRIDE));
     } else {
-        HIPCHK(c->rec_u.ensure((size_t)n)); HIPCHK(c->rec_i.ensure((size_t)2 * n));
+        HIPCHK(c->rec_u.ensure((size_t)n)); HIPCHK(c->rec_i.ensure((size_t)(n_items > 2 * n ? n_items : 2 * n)));
         if (mode == 0) {          // every slot learns where its run's record is (the MF stage's fused row update)
             c->slot_stride = ioff_max + 2 * (int64_t)batch;
             HIPCHK(c->slot_info.ensure((size_t)nb * c->slot_stride));
@@ -547,14 +554,15 @@ int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
     }
     { const char* rk = getenv("SML_PREP_RANK"); a.rank_viol = (rk && !strcmp(rk, "ballot")) ? nullptr : c->rank_viol.p; }
     a.order_viol = c->rank_viol.p + 1;             // (word 1 of the probe's block: zeroed with it, never reset)
+    a.vals_ascend = (mode != 4 || plan == nullptr) ? 1 : 0;      // (source 4 with unequal batches: the driver's owner-split lists, values = slots by owner)
     if (a.dense && !(a.t[0].nbk == 1 && a.t[1].nbk == 1)) a.dense = 0;       // (wide rows forced more buckets: per-occurrence form)
     c->dense = a.dense != 0;
     HIPCHK(sml_launch_prep(a, narrow ? 4 : 8, st));
     // the sorted-order invariant's violation count travels to the host behind every preparation (4 bytes); the NEXT call that
     // finds a completed copy with a non-zero count fails: a list was built wrong (sort_order_check)
-    if (!c->viol_host) { HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->viol_host), sizeof(int), hipHostMallocDefault)); *c->viol_host = 0; }
+    if (!c->viol_host) { HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->viol_host), 4 * sizeof(int), hipHostMallocDefault)); memset(c->viol_host, 0, 4 * sizeof(int)); }
     if (!c->viol_ready) HIPCHK(hipEventCreateWithFlags(&c->viol_ready, hipEventDisableTiming));
-    HIPCHK(hipMemcpyAsync(c->viol_host, c->rank_viol.p + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(c->viol_host, c->rank_viol.p + 1, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(c->viol_ready, st));
     if (dups) {
         if (!c->max_len_host) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->max_len_host), sizeof(int), hipHostMallocDefault));
@@ -797,7 +805,28 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
     ctx->prof.begin(PC_SORT, st); rc = sort_epoch(&ctx->ix[0], triples, n, batch, 1, t->n_user, t->n_item, false, st, plan, nullptr, want_dense);
     const int64_t x_total = !xchg ? 0 : xchg->item_off ? xchg->item_off[nb] : (int64_t)xchg->world * 2 * n;
     const int64_t x_stride = !xchg ? 0 : xchg->slot_stride > 0 ? xchg->slot_stride : (int64_t)2 * batch;
-    if (!rc && xchg && x_total > 0) {   // the global item occurrence list of the job: run records over the caller's sorted keys
+    const bool x_by_hand = xchg && xchg->lists_unsorted != 0;
+    if (!rc && xchg && x_total > 0 && x_by_hand) {
+        // the job's item occurrences arrive batch-major and UNSORTED: every batch's run list by index_prep.hip (occurrence source 4:
+        // one stream of explicit (key, value) pairs; records mode) -- no library sort anywhere on this path since round 5
+        int64_t x_seg = (int64_t)xchg->world * 2 * batch;
+        sml_batch_plan px;
+        memset(&px, 0, sizeof(px));
+        if (xchg->item_off) {
+            std::vector<int32_t> off32((size_t)nb + 1);
+            x_seg = 1;
+            for (int64_t b = 0; b <= nb; ++b) {
+                off32[(size_t)b] = (int32_t)xchg->item_off[b];
+                if (b && xchg->item_off[b] - xchg->item_off[b - 1] > x_seg) x_seg = xchg->item_off[b] - xchg->item_off[b - 1];
+            }
+            HIPCHK(ctx->xoff.ensure((size_t)nb + 1));
+            HIPCHK(hipMemcpyAsync(ctx->xoff.p, off32.data(), ((size_t)nb + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));   // (pageable source: staged before the call returns)
+            px.n_batches = nb; px.batch_off_dev = ctx->xoff.p;
+        }
+        if (x_seg > 0x3fffffff) return fail(SML_EINVAL, "sml_mf_stage_epoch", "a batch's job-wide item list is too long");
+        rc = prep_epoch(&ctx->ix[1], reinterpret_cast<const int64_t*>(xchg->key_items), x_total, (int)x_seg, 0, 1, t->n_item, false, st,
+                        xchg->item_off ? &px : nullptr, 4, nullptr, nullptr, (int64_t)xchg->world * x_stride, false, xchg->val_items);
+    } else if (!rc && xchg && x_total > 0) {   // ... or run records over the caller's sorted keys
         HIPCHK(ctx->rec_x.ensure((size_t)x_total));
         HIPCHK(sml_launch_mark_runs(8, xchg->key_items, xchg->val_items, x_total, 32, ctx->rec_x.p, nullptr, nullptr, 0, 0, st));
     }
@@ -932,8 +961,8 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
                 NCCLCHK(g_rccl.AllGather(dx_buf + ioff * d, xchg->dx_items_all, (size_t)x_stride * d, ncclFloat, ctx->comm, st));
             }
             const int64_t x0 = xchg->item_off ? xchg->item_off[b] : (int64_t)xchg->world * 2 * b * batch;
-            u.run_i = ctx->rec_x.p + x0;
-            u.val_i = xchg->val_items;
+            u.run_i = (x_by_hand ? ctx->ix[1].rec_i.p : ctx->rec_x.p) + x0;
+            u.val_i = x_by_hand ? ctx->ix[1].val_i2.p : xchg->val_items;
             u.n_i = xchg->item_off ? (int)(xchg->item_off[b + 1] - x0) : xchg->world * 2 * B;
             u.dx_i = gathered;
         }

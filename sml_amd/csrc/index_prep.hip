@@ -171,6 +171,7 @@ struct Occ { uint32_t row, val; bool valid; };
 __device__ __forceinline__ Occ occ_of(const SmlPrepArgs& a, const BatchGeo& g, int s, int t) {
     Occ o; o.valid = t < g.Bb; o.row = 0u; o.val = 0u;
     if (!o.valid) return o;
+    if (a.mode == 4) { o.row = (uint32_t)a.x_keys[g.start + t]; o.val = a.x_vals[g.start + t]; return o; }
     if (a.has_users && s == 0) { o.row = (uint32_t)a.tri[(g.start + t) * 3]; o.val = (uint32_t)t; return o; }
     const int si = s - a.has_users, q = si >> 1, c = si & 1;
     if (a.mode == 3) {
@@ -508,7 +509,9 @@ __device__ __forceinline__ uint32_t emit_bucket(const SmlPrepArgs& a, const SmlP
                 if (a.order_viol != nullptr && q + 1 < S) {
                     const E en = get(q + 1);
                     const uint32_t nh = ent_hi<E>(en, vb);
-                    if (nh < rh || (nh == rh && ent_val<E>(en, vb) <= ent_val<E>(e, vb))) atomicAdd(a.order_viol, 1);
+                    if (nh < rh || (a.vals_ascend && nh == rh && ent_val<E>(en, vb) <= ent_val<E>(e, vb))) {
+                        if (atomicAdd(a.order_viol, 1) == 0) { a.order_viol[1] = (a.mode << 28) | (T << 27) | b; a.order_viol[2] = (q << 12) | (S & 0xfff); }
+                    }
                 }
             }
             const uint32_t val = ent_val<E>(e, vb);
@@ -556,8 +559,10 @@ __device__ __forceinline__ uint32_t emit_bucket(const SmlPrepArgs& a, const SmlP
             prev = q > 0 ? ent_hi<E>(get(q - 1), vb) : ~rh;
             next = q + 1 < S ? ent_hi<E>(get(q + 1), vb) : ~rh;
             // the sorted bucket's invariant (SmlPrepArgs.order_viol): (row, value) ascending -- an unstable rank would break it
-            if (a.order_viol != nullptr && q + 1 < S && (next < rh || (next == rh && ent_val<E>(get(q + 1), vb) <= ent_val<E>(e, vb))))
-                atomicAdd(a.order_viol, 1);
+            if (a.order_viol != nullptr && q + 1 < S && (next < rh || (a.vals_ascend && next == rh && ent_val<E>(get(q + 1), vb) <= ent_val<E>(e, vb)))) {
+                // (the first violation leaves its coordinates: occurrence source, table, batch; position and bucket size)
+                if (atomicAdd(a.order_viol, 1) == 0) { a.order_viol[1] = (a.mode << 28) | (T << 27) | b | (a.records ? (1 << 26) : 0); a.order_viol[2] = (q << 12) | (S & 0xfff); }
+            }
         }
         const bool head = in && prev != rh, tail = in && next != rh;
         const bool dup = in && !(head && tail);
@@ -1328,7 +1333,7 @@ __global__ __launch_bounds__(1024) void k_rank_probe(int* viol) {
 
 template <typename E>
 hipError_t launch_prep(const SmlPrepArgs& a, hipStream_t st) {
-    if (a.records && a.t[0].nbk == 1 && a.t[1].nbk == 1 && 2 * (int64_t)a.batch <= SML_PREP_SMALL) {
+    if (a.mode == 0 && a.records && a.t[0].nbk == 1 && a.t[1].nbk == 1 && 2 * (int64_t)a.batch <= SML_PREP_SMALL) {
         k_prep_bucket<E><<<dim3((unsigned)(2 * a.nb)), dim3(256), 0, st>>>(a, 0, 2);       // ONE launch: no partition
         if (a.dense) k_mf_tiles<<<dim3((unsigned)a.tiles_cap, (unsigned)a.nb), dim3(256), 0, st>>>(a);
         return hipGetLastError();

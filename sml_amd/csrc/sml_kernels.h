@@ -294,6 +294,9 @@ struct SmlPrepArgs {
     // occurrence source (index_prep.hip, occ_of): 0 this rank's triples; 1 / 2 / 3 the multi-GPU item lists
     int mode, has_users, nis;    // nis: item streams per tile (2, or 2 * world)
     const int64_t* items_all; int64_t val_q;        // [world][n][2] gathered item columns; value stride per rank
+    // mode 4 (the MF stage's job-wide item lists on several GPUs): ONE item stream of explicit (key, value) occurrences, batch-major
+    // -- "triple" t of batch b is occurrence boff[b] + t (or the uniform layout), row = the key's low 32 bits; no users
+    const uint64_t* x_keys; const uint32_t* x_vals;
     int64_t head_rows, shard_rows; int shard_rank;
     SmlPrepTable t[2];           // users, items
     uint8_t* uniq; int64_t uniq_stride;
@@ -318,6 +321,8 @@ struct SmlPrepArgs {
     // any non-zero value means a list of this index set was built wrong at some point) and the next epoch call that finds the count
     // on the host fails with SML_ESTATE.  null: off.
     int* order_viol;
+    int vals_ascend;             // 1: a list's values ascend in occurrence order (every source but the owner-split job-wide MF lists, whose values
+                                 // are slots by OWNER): only then does the invariant's value half apply; the row half always does
 };
 hipError_t sml_launch_rank_probe(int* viol, hipStream_t st);
 hipError_t sml_launch_prep(const SmlPrepArgs& a, int ent_bytes, hipStream_t st);

@@ -63,17 +63,22 @@ def item_owner(rows, world, head_rows, shard_rows):
     return (owner * (~is_head) - 1 * is_head), (local * (~is_head) + rows * is_head)
 
 
-def _sort_occurrences(keys, vals):
-    """(keys, vals) stably sorted by key, on the keys' device."""
-    order = torch.sort(keys, stable=True).indices
-    return keys[order].contiguous(), vals[order].to(torch.int32).contiguous()
+def _place(keys, vals, dest, total):
+    """(keys, vals) laid out BATCH-MAJOR by the destination index `dest` (a permutation of range(total)): no sort -- the
+    library builds the per-batch run lists from the unsorted occurrences itself (index_prep.hip; `lists_unsorted`)."""
+    k = torch.empty(total, dtype=torch.int64, device=keys.device)
+    v = torch.empty(total, dtype=torch.int32, device=keys.device)
+    k[dest] = keys
+    v[dest] = vals.to(torch.int32)
+    return k, v
 
 
 def global_item_lists(all_triples, batch, stride=None):
-    """Independent-shards mode.  all_triples int64 [world, n, 3] (same n on every rank) -> (keys uint64-as-int64
-    [nb-major], vals int32): for every batch b the world*2*B_b item occurrences sorted (stably) by
-    (b << 32 | item row); value = slot in the gathered gradient buffer [world][stride][d] (stride = 2*batch unless
-    the buffer is an inbox with wider slots): rank q's positives at q*stride + t, negatives at q*stride + B_b + t."""
+    """Independent-shards mode.  all_triples int64 [world, n, 3] (same n on every rank) -> (keys uint64-as-int64, vals int32),
+    BATCH-MAJOR and unsorted inside a batch: batch b's world*2*B_b item occurrences as (b << 32 | item row) in the order
+    (rank, positive / negative, element) -- the order the run kernel sums a row's occurrences in is then a function of the
+    input alone, the same on every rank; value = slot in the gathered gradient buffer [world][stride][d] (stride = 2*batch
+    unless the buffer is an inbox with wider slots): rank q's positives at q*stride + t, negatives at q*stride + B_b + t."""
     world, n, _ = all_triples.shape
     dev = all_triples.device
     e = torch.arange(n, device=dev)
@@ -81,12 +86,13 @@ def global_item_lists(all_triples, batch, stride=None):
     Bb = torch.clamp(n - b * batch, max=batch)
     t = e - b * batch
     stride = 2 * batch if stride is None else int(stride)
-    keys, vals = [], []
+    keys, vals, dest = [], [], []
     for q in range(world):
         base = q * stride
         keys += [(b << 32) | all_triples[q, :, 1], (b << 32) | all_triples[q, :, 2]]
         vals += [base + t, base + Bb + t]
-    return _sort_occurrences(torch.cat(keys), torch.cat(vals))
+        dest += [world * 2 * batch * b + (2 * q) * Bb + t, world * 2 * batch * b + (2 * q + 1) * Bb + t]
+    return _place(torch.cat(keys), torch.cat(vals), torch.cat(dest), world * 2 * n)
 
 
 class EpochRoute(object):
@@ -143,9 +149,13 @@ class EpochRoute(object):
         keys = torch.cat([(b << 32) | torch.from_numpy(np.ascontiguousarray(self._items[:, 0])).to(dev),
                           (b << 32) | torch.from_numpy(np.ascontiguousarray(self._items[:, 1])).to(dev)])
         vals = torch.cat([torch.from_numpy(base).to(dev), torch.from_numpy(base + cnt).to(dev)])
-        keys, vals = _sort_occurrences(keys, vals)
         item_off = np.zeros(self.nb + 1, dtype=np.int64)
         np.cumsum(2 * self.global_batch_sizes, out=item_off[1:])
+        # batch-major, unsorted: global batch b holds its positives (in global order) and then its negatives
+        tg = np.arange(self.n, dtype=np.int64) - self._b_of * self.batch
+        dpos = item_off[self._b_of] + tg
+        dest = torch.cat([torch.from_numpy(dpos).to(dev), torch.from_numpy(dpos + self.global_batch_sizes[self._b_of]).to(dev)])
+        keys, vals = _place(keys, vals, dest, 2 * self.n)
         dx_local, dx_all = ctx.scratch(self.cap, stride, d)
         mine = self.counts[ctx.rank]
         tile = 32
@@ -155,7 +165,7 @@ class EpochRoute(object):
             src = dx_local[ioff * d:(ioff + stride) * d]
             ctx.all_gather_rows(dx_all[:ctx.world * stride * d], src)
 
-        return dict(world=ctx.world, keys=keys, vals=vals, dx_local=dx_local, dx_all=dx_all,
+        return dict(world=ctx.world, keys=keys, vals=vals, dx_local=dx_local, dx_all=dx_all, unsorted=True,
                     hook=None if ctx.native else hook, loss_scale=1.0, slot_stride=stride, item_off=item_off, push_rows=push_rows)
 
 
@@ -321,7 +331,7 @@ class DistContext(object):
             ioff = -(-Bb // tile) * tile
             self.all_gather_rows(dx_all[:self.world * stride * d], dx_local[ioff * d:(ioff + stride) * d])
 
-        return dict(world=self.world, keys=keys, vals=vals, dx_local=dx_local, dx_all=dx_all,
+        return dict(world=self.world, keys=keys, vals=vals, dx_local=dx_local, dx_all=dx_all, unsorted=True,
                     hook=None if self.native else hook, loss_scale=self.loss_scale(loss_kind), slot_stride=stride,
                     item_off=None, push_rows=2 * batch)
 

@@ -288,6 +288,7 @@ class HipEngine(object):
                 keep = (keep, ioff)
             x.item_off = ioff.ctypes.data if ioff is not None else None
             x.push_rows = int(ex.get("push_rows", 0))
+            x.lists_unsorted = 1 if ex.get("unsorted") else 0
             xp = ctypes.byref(x)
         check(self.lib.sml_mf_stage_epoch(self._ctx, _ptr(theta), ctypes.byref(t), _ptr(tri), n, int(batch_size),
                                           float(lr), float(l2), self._loss_kind(bce, norm), ctypes.byref(step),

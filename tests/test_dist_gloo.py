@@ -120,10 +120,10 @@ def test_user_range_and_item_lists():
     tri = torch.tensor([[[0, 5, 7], [1, 5, 2], [2, 9, 5]], [[3, 7, 5], [4, 1, 1], [5, 5, 0]]])   # world 2, n 3
     keys, vals = SD.global_item_lists(tri, batch=2)
     rows, bat = (keys & 0xffffffff).tolist(), (keys >> 32).tolist()
+    # batch-major (batch 0's 8 occurrences, then batch 1's 4); inside a batch in (rank, positive / negative, element) order and NOT
+    # sorted: the library builds the run lists (round 5: no library sort on the product path)
     assert bat == sorted(bat) and bat.count(0) == 8 and bat.count(1) == 4
-    for b in (0, 1):
-        seg = [r for r, bb in zip(rows, bat) if bb == b]
-        assert seg == sorted(seg)
+    assert rows[:8] == [5, 5, 7, 2, 7, 1, 5, 1] and rows[8:] == [9, 5, 5, 0]
     # value = slot in [world][2*batch]: rank q positives q*4 + t, negatives q*4 + B_b + t
     lookup = {}
     for q in range(2):
