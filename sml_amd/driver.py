@@ -119,8 +119,15 @@ class meta_train(object):
                   str(args.TR_epochs) + str(args.TR_sample_type) + "user-norm" + str(args.norm)
             self.writer = SummaryWriter(comment=tag)
         if self.with_MF_bias:
-            raise NotImplementedError("--TR_with_MF_bias (bias column fed to the transfer net) is outside this "
-                                      "build's scope: kernels exist for d in {32, 64, 128}")
+            # The reference cannot run this flag with the convolutional transfers either (the only ones in scope): W_{t-1} gets d + 1
+            # columns (model/transfer.py:347-354) while MFbase.user_laten(user) keeps d, and ConvTransfer_com.forward multiplies the two
+            # (model/conv_transfer.py:93) -- measured on the reference here: "RuntimeError: The size of tensor a (33) must match the size
+            # of tensor b (32) at non-singleton dimension 1", raised from MF_train_onestage (transfer.py:476) in the first stage.  Same
+            # error type, raised up front.
+            raise RuntimeError("--TR_with_MF_bias: the size of tensor a (%d) must match the size of tensor b (%d) at non-singleton dimension 1 "
+                               "(W_{t-1} carries the bias column, the MF rows do not: the reference's conv / conv_com transfers fail the same way "
+                               "in their first MF batch, model/conv_transfer.py:93; the flag only works with its MLP transfers, which are out of scope)"
+                               % (laten_dim + 1, laten_dim))
         # W_{t-1}, W_hat_t, previous W_hat (model/transfer.py:358-364)
         wu, wi = self.MFbase.user_laten.weight.data, self.MFbase.item_laten.weight.data
         self.last_user_weight = torch.zeros_like(wu)

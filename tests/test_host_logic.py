@@ -786,6 +786,28 @@ def test_product_library_has_no_library_sort():
         assert guarded, src
 
 
+def test_tr_with_mf_bias_fails_like_the_reference_does(tmp_path, monkeypatch):
+    """--TR_with_MF_bias (model/transfer.py:347-354): the reference gives W_{t-1} d + 1 columns and then multiplies it with d-column MF
+    rows in ConvTransfer_com.forward (model/conv_transfer.py:93) -- run here on the reference itself (round 5): RuntimeError "The size of
+    tensor a (33) must match the size of tensor b (32) at non-singleton dimension 1" in the first MF batch.  The product raises the same
+    error type with the same sizes, up front."""
+    from sml_amd import cli, datasets, driver, synth
+    from sml_amd.mf import MFbasemode
+    monkeypatch.setattr(driver, "_default_device", lambda: torch.device("cpu"))
+    monkeypatch.setattr(driver, "_make_engine", lambda dev, d, mb: _CpuEngine(dev, d, mb))
+    root = str(tmp_path) + "/"
+    synth.write_dataset(root, "yelp", n_periods=4, n_inter=300, n_user=60, n_item=40, neg=9, seed=7)
+    torch.manual_seed(1)
+    ck = os.path.join(root, "init.pkl")
+    torch.save(MFbasemode(60, 40, 32), ck)
+    args = cli.get_parse("yelp").parse_args(["--data_path", root, "--pre_model", ck, "--laten", "32", "--numworkers", "0", "--TR_with_MF_bias", "True"])
+    with quiet():
+        sets = datasets.transfer_data(args, path=root, datasetname="yelp", file_path_list=["0", "1", "2", "3"], test_list=["2", "3"],
+                                      validation_list=None, online_train_time=1, online_test_time=2)
+        with pytest.raises(RuntimeError, match=r"size of tensor a \(33\) must match the size of tensor b \(32\)"):
+            driver.meta_train(args, sets, sets.user_number, sets.item_number, args.laten)
+
+
 def test_zipf_head_rows_of_the_sharded_bare_step():
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_for_head", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
