@@ -133,21 +133,26 @@ __global__ __launch_bounds__(1024) void k_prep_hist(SmlPrepArgs a) {
     for (int i = tid; i < 3 * SML_PREP_MAXBK; i += 1024) (&h[0][0])[i] = 0u;
     if (k == 0 && b == 0 && tid < 4) a.n_medium[tid] = 0;          // n_medium, -, longest run, n_large (one int4 of counters)
     __syncthreads();
-    const int t0 = k * SML_PREP_TT + (tid >> 6) * (64 * SML_PREP_IPT) + (tid & 63);
+    // A histogram does not care which thread counts which occurrence: the tile's 3 * 4,096 indices are read as ONE flat
+    // array, consecutive lanes consecutive 8-byte elements (a wavefront's load is 512 contiguous bytes: four lines, not the
+    // twelve a column load at a 24-byte stride touches) -- element e of the tile belongs to stream e % 3.
+    const int nel = 3 * min(SML_PREP_TT, g.Bb - k * SML_PREP_TT);
+    const int64_t* flat = a.tri + (g.start + (int64_t)k * SML_PREP_TT) * 3;
+    const int s0 = tid % 3;                                        // (1024 = 1 mod 3: load j of this thread is stream (s0 + j) % 3)
+    uint32_t v[3 * SML_PREP_IPT];
 #pragma unroll
-    for (int r = 0; r < SML_PREP_IPT; ++r) {
-        const int t = t0 + r * 64;
-        const bool valid = t < g.Bb;
-        uint32_t ru = 0, rp = 0, rn = 0;
-        if (valid) {
-            const int64_t* p = a.tri + (g.start + t) * 3;
-            ru = (uint32_t)p[0]; rp = (uint32_t)p[1]; rn = (uint32_t)p[2];
-        }
+    for (int j = 0; j < 3 * SML_PREP_IPT; ++j) { const int e = tid + 1024 * j; v[j] = e < nel ? (uint32_t)flat[e] : 0u; }
+#pragma unroll
+    for (int j = 0; j < 3 * SML_PREP_IPT; ++j) {
+        const bool valid = tid + 1024 * j < nel;
+        const int sj = (s0 + j) % 3;
         // (a list that is one bucket: one add per wavefront instead of 64 on one address)
-        if (nbu == 1) { const uint64_t m = __ballot(valid); if ((tid & 63) == 0 && m) atomicAdd(&h[0][0], (uint32_t)__popcll(m)); }
-        else if (valid) atomicAdd(&h[0][ru & (nbu - 1)], 1u);
-        if (nbi == 1) { const uint64_t m = __ballot(valid); if ((tid & 63) == 0 && m) { atomicAdd(&h[1][0], (uint32_t)__popcll(m)); atomicAdd(&h[2][0], (uint32_t)__popcll(m)); } }
-        else if (valid) { atomicAdd(&h[1][rp & (nbi - 1)], 1u); atomicAdd(&h[2][rn & (nbi - 1)], 1u); }
+        if (nbu == 1) { const uint64_t m = __ballot(valid && sj == 0); if ((tid & 63) == 0 && m) atomicAdd(&h[0][0], (uint32_t)__popcll(m)); }
+        else if (valid && sj == 0) atomicAdd(&h[0][v[j] & (nbu - 1)], 1u);
+        if (nbi == 1) {
+            const uint64_t m1 = __ballot(valid && sj == 1), m2 = __ballot(valid && sj == 2);
+            if ((tid & 63) == 0) { if (m1) atomicAdd(&h[1][0], (uint32_t)__popcll(m1)); if (m2) atomicAdd(&h[2][0], (uint32_t)__popcll(m2)); }
+        } else if (valid && sj != 0) atomicAdd(&h[sj][v[j] & (nbi - 1)], 1u);
     }
     __syncthreads();
     uint32_t* hu = a.t[0].hist + ((int64_t)b * a.tpb + k) * nbu;
@@ -306,9 +311,21 @@ __global__ __launch_bounds__(1024) void k_prep_scan(SmlPrepArgs a) {
     // all 1024 threads: thread (group, bin) owns a contiguous share of the tiles
     const int ngrp = 1024 >> lb, grp = tid >> lb, bin = tid & (nbk - 1);
     const int per = (ntile + ngrp - 1) / ngrp, k0 = min(ntile, grp * per), k1 = min(ntile, k0 + per);
+    // (a thread's share of the tiles -- 64 at the bare step's table shapes -- stays in registers: ONE round trip of loads
+    // instead of two passes of four dependent trips each; this kernel is 32 workgroups of pure latency)
+    constexpr int KEEP = 64;
+    const bool keep = per <= KEEP;                                   // (block-uniform)
+    uint32_t cnt_k[KEEP];
     uint32_t mine = 0;
+    if (keep) {
+#pragma unroll
+        for (int i = 0; i < KEEP; ++i) cnt_k[i] = k0 + i < k1 ? H[(int64_t)(k0 + i) * nbk + bin] : 0u;
+#pragma unroll
+        for (int i = 0; i < KEEP; ++i) mine += cnt_k[i];
+    } else {
 #pragma unroll 16
-    for (int k = k0; k < k1; ++k) mine += H[(int64_t)k * nbk + bin];
+        for (int k = k0; k < k1; ++k) mine += H[(int64_t)k * nbk + bin];
+    }
     part[tid] = mine;
     __syncthreads();
     uint32_t tot = 0, before = 0;
@@ -318,8 +335,13 @@ __global__ __launch_bounds__(1024) void k_prep_scan(SmlPrepArgs a) {
     __syncthreads();
     {
         uint32_t run = (uint32_t)list_start + part[bin] + before;
+        if (keep) {
+#pragma unroll
+            for (int i = 0; i < KEEP; ++i) { if (k0 + i < k1) H[(int64_t)(k0 + i) * nbk + bin] = run; run += cnt_k[i]; }
+        } else {
 #pragma unroll 16
-        for (int k = k0; k < k1; ++k) { const uint32_t c = H[(int64_t)k * nbk + bin]; H[(int64_t)k * nbk + bin] = run; run += c; }
+            for (int k = k0; k < k1; ++k) { const uint32_t c = H[(int64_t)k * nbk + bin]; H[(int64_t)k * nbk + bin] = run; run += c; }
+        }
     }
     if (tid < nbk) {
         tb.bk[(int64_t)b * nbk + tid] = make_uint2(off, tot);
