@@ -367,6 +367,30 @@ def a3_in_child(a, device):
     return a3_object(a, device)
 
 
+def a3_rocprof(tag, bytes_per_batch):
+    """The a3 step's kernels in the COMMITTED rocprofv3 --kernel-trace --stats summary of `bench.py --workload bare` at the same
+    shape (profiles/r*_bare_z0 / _z1_kernel_stats.csv, tools/profile_round.sh): steady-state µs per batch = k_bare_grad + every
+    step-kernel instance launched at least half as often (the first epoch's variants with the hot-row early-out are left out),
+    and the fraction of the 8 TB/s roofline that gives.  A HIP-event pair reads a kernel plus 1-3 us of its own: both are quoted."""
+    import csv
+    import glob
+    leg = {"d32_f32_uniform": "bare_z0", "d32_f32_zipf": "bare_z1"}.get(tag)
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_%s_kernel_stats.csv" % leg))) if leg else []
+    if not files:
+        return {}
+    try:
+        rows = [(r["kernel"], int(r["calls"]), float(r["avg_us"])) for r in csv.DictReader(open(files[-1]))
+                if r["kernel"].startswith(("k_bare_grad", "k_run_update", "k_hot_"))]
+        base = max((c for k, c, _ in rows if k.startswith("k_bare_grad")), default=0)
+        us = sum(avg for _, c, avg in rows if base and 2 * c >= base)
+        if not us:
+            return {}
+        return {"kernel_us_rocprof": us, "kernel_frac_rocprof": bytes_per_batch / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "rocprof_profile": os.path.basename(files[-1])}
+    except Exception:
+        return {}
+
+
 def a3_object(a, device):
     """The fused embed+loss+SGD kernel pair (north_star's HBM-roofline target) at table scale,
     measured in this same run: per configuration the kernel-only fraction of the 8 TB/s roofline (HIP events over
@@ -395,6 +419,7 @@ def a3_object(a, device):
                         "index_prep": r.get("index_prep")}
             # the kernels' algorithmic rate against the MEASURED rate of the bare access pattern (random rows read and
             # rewritten in place, tools/micro_gather.hip) -- what "of the 8 TB/s roofline" cannot say for 128-byte random rows
+            res[tag].update(a3_rocprof(tag, r["roofline"]["algorithmic_bytes_per_triple"] * b.bare_batch))
             c = gather_ceiling(d, dt)
             if c:
                 res[tag].update(c, ceiling_frac=r["roofline"]["achieved"] / c["ceiling_GBps"])
