@@ -1033,6 +1033,10 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
     // conv parameters in its prologue (SmlFwdArgs).  SML_TR_DEFER=0: the merged launch's last tail workgroup does it.
     const bool fused_path = !clip && !grad_hook && ctx->peer.world <= 0 && ctx->comm == nullptr;
     const bool defer = v2 && fns == 4 && fused_path && !plan && nb > 1 && env_int("SML_TR_DEFER", 1) != 0;
+    // Round 5: the forward saves z1 only; the dW2 tiles of the merged launch apply Gelu to their B operand themselves (x * sigmoid(1.702 x):
+    // ten instructions on a VALU that is idle there) -- 1.5 MB less written per step, bit-identical.  SML_TR_A2_RECOMPUTE=0: the forward
+    // saves Gelu(z1) as well (A/B tests)
+    const bool a2_recompute = v2 && env_int("SML_TR_A2_RECOMPUTE", 1) != 0;
     int prev_split = 0, prev_total = 0;
     if (defer) {
         HIPCHK(ctx->cstate.ensure((size_t)2 * 2 * 3 * SML_CG));
@@ -1059,7 +1063,7 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
             sg.tri = tri; sg.B = B; sg.is_item = s; sg.n_rows = s ? 2 * B : B;
             const int64_t slot0 = s ? (int64_t)SML_R * tiles_of(B) : 0;
             sg.out = ctx->out.p + slot0 * d; sg.z1 = ctx->z1.p + slot0 * SML_HID; sg.xin = ctx->xin.p + slot0 * 3 * d;
-            sg.a1 = ctx->a1.p + slot0 * SML_C2 * d; sg.a2 = ctx->a2.p + slot0 * SML_HID;
+            sg.a1 = ctx->a1.p + slot0 * SML_C2 * d; sg.a2 = a2_recompute ? nullptr : ctx->a2.p + slot0 * SML_HID;
         }
         f.tiles0 = wg_tiles(B, 1); f.cur_step = 0; f.sched = nullptr; f.out_pstride = out_pstride; f.k2 = ctx->variant == 1;
         const int tiles = f.tiles0 + wg_tiles(2 * B, 1);
@@ -1076,7 +1080,7 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
             sg.dout = ctx->dout.p + slot0 * d; sg.is_item = s; sg.z1 = ctx->z1.p + slot0 * SML_HID; sg.xin = ctx->xin.p + slot0 * 3 * d;
             sg.dx = nullptr; sg.dz1 = ctx->dz1.p + slot0 * SML_HID; sg.n_rows = s ? 2 * B : B;
             SmlWgSeg& q = wg.seg[s];
-            q.dz1 = sg.dz1; q.a1 = ctx->a1.p + slot0 * SML_C2 * d; q.dout = sg.dout; q.a2 = ctx->a2.p + slot0 * SML_HID;
+            q.dz1 = sg.dz1; q.a1 = ctx->a1.p + slot0 * SML_C2 * d; q.dout = sg.dout; q.a2 = a2_recompute ? sg.z1 : ctx->a2.p + slot0 * SML_HID;
             // (one GPU, Adam fused into the weight-gradient kernel, no gradient buffer asked for: the flat gradient is
             // not written at all -- 0.8 MB less for the launch to leave dirty in L2)
             const bool fused_only = !clip && !grad_hook && (ctx->comm == nullptr || ctx->peer.world > 0) && theta_grad == nullptr;
@@ -1096,7 +1100,7 @@ int sml_tr_stage_epoch(sml_ctx* ctx, float* theta, float* adam_m, float* adam_v,
         auto launch_wgrad = [&](const SmlWgArgs& g) { return v2 ? sml_launch_tr_wgrad2(d, g, st) : sml_launch_wgrad(d, g, st); };
         wg.convg_part = ctx->convg.p; wg.tiles0 = f.tiles0 * wcs; wg.tiles_total = tiles * wcs;
         wg.n_tail = tiles * (d / 16) > 0 ? tiles * (d / 16) : 1; wg.convg_out = ctx->convg.p; wg.arrive = ctx->arrive.p;
-        wg.defer_conv = (defer && b + 1 < nb) ? 1 : 0;
+        wg.defer_conv = (defer && b + 1 < nb) ? 1 : 0; wg.gelu_b = a2_recompute ? 1 : 0;
         prev_split = f.tiles0 * (d / 16); prev_total = tiles * (d / 16);
         const bool peers = !grad_hook && ctx->peer.world > 0;       // peer mappings attached: one-shot push / poll
         const bool native = !grad_hook && !peers && ctx->comm != nullptr;     // a communicator exists: exchange natively

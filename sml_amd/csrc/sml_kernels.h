@@ -166,6 +166,7 @@ struct SmlWgArgs {
     // workgroups use to elect the last arriver, which finishes the conv parameters
     int n_tail; float* convg_out; int* arrive;
     int defer_conv;          // k_tr_wgrad2: 1 = the tail workgroups only leave their partials; the NEXT forward finishes the conv parameters
+    int gelu_b;              // 1 = seg.a2 holds z1: the dW2 tiles apply Gelu to their B operand themselves (the forward saved z1 only)
 };
 
 struct SmlThetaAdamArgs {

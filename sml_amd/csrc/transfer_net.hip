@@ -1843,6 +1843,7 @@ __device__ __forceinline__ void wgrad_tile(const SmlWgArgs& a, int xcd, int kk, 
     const int lda = is_w1 ? SML_HID : D;
     const float* __restrict__ Bsrc = is_w1 ? sg.a1 : sg.a2;      // B[r][j] = Bsrc[r][tj*32 + j]  (a2 = Gelu(z1), saved by the forward)
     const int ldb = is_w1 ? K1 : SML_HID;
+    const bool gelu_b = !is_w1 && a.gelu_b != 0;                 // (workgroup-uniform)
     // this thread's two weights of the tile (+ a bias for 32 threads of the tj = 0 workgroups)
     int woff[2];
     float wp[2] = {0.f, 0.f}, wm[2] = {0.f, 0.f}, wvv[2] = {0.f, 0.f};
@@ -1890,7 +1891,7 @@ __device__ __forceinline__ void wgrad_tile(const SmlWgArgs& a, int xcd, int kk, 
             if (s4 >= 4 && !two) break;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float b = bv[s4][e];
+                const float b = gelu_b ? sml_gelu(bv[s4][e]) : bv[s4][e];
                 colsum += av[s4][e];
                 acc = mfma32(av[s4][e], b, acc);
             }

@@ -1687,6 +1687,32 @@ def test_tr_conv_step_taken_by_the_next_forward_equals_the_last_arriver_form_bit
     assert eng.tr_step == 2 * nb
 
 
+@pytest.mark.parametrize("d,B,nb", [(32, 256, 4), (64, 256, 3), (128, 128, 2), (32, 1000, 2), (64, 17, 3)])
+def test_tr_weight_gradient_tiles_applying_gelu_themselves_equal_the_saved_activation_bit_for_bit(d, B, nb, monkeypatch):
+    """Round 5: the TR forward saves z1 only and the dW2 tiles of the merged launch apply Gelu to their operand (the same
+    device function on the same fp32 values the forward had): theta, both Adam moments and every batch loss must equal the
+    SML_TR_A2_RECOMPUTE=0 run (the forward saves Gelu(z1) too) BIT FOR BIT, ragged last batch and a second epoch included."""
+    torch.manual_seed(7 * d + nb)
+    U, I, n = 400, 300, nb * B - 5
+    wu, wi = torch.randn(U, d) * 0.3, torch.randn(I, d) * 0.3
+    tri = torch.stack([torch.randint(0, U, (n,)), torch.randint(0, I, (n,)), torch.randint(0, I, (n,))], 1)
+    sd, res = None, []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SML_TR_A2_RECOMPUTE", flag)
+        eng = engine(d, 1024)
+        net = make_transfer(d, device=DEV)
+        if sd is None:
+            sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+        else:
+            net.load_state_dict(sd)
+        ls = []
+        for ep in range(2):
+            ls.append(eng.tr_stage_epoch(net, (wu * 0.9).to(DEV), (wi * 0.9).to(DEV), wu.to(DEV), wi.to(DEV), tri, B, 1e-3, 1e-4).cpu())
+        res.append((torch.cat(ls), eng.adopt(net).detach().cpu().clone(), eng.tr_state[0].cpu().clone(), eng.tr_state[1].cpu().clone()))
+    for x, y in zip(res[0], res[1]):
+        assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("d,B,max_norm", [(32, 256, 0.5), (64, 100, 0.05), (32, 256, 1e9)])
 def test_tr_stage_with_clipped_gradient_norm_vs_oracle(d, B, max_norm):
     """--clip_grad / --maxnorm_grad (model/transfer.py:724-727): torch.nn.utils.clip_grad_norm_ over the transfer net's
