@@ -77,7 +77,7 @@ N_SIMD, CLOCK_MHZ = 1024, 2400.0
 def mfma_summary(run_dir, durations_us):
     out = {}
     for k, cs in all_counters(run_dir).items():
-        if not k.startswith("k_t"):
+        if not k.startswith(("k_t", "k_mf_fwd")):
             continue
         n = max(cs.get("GRBM_GUI_ACTIVE", [1, 0])[0], 1)
         avg = {c: v[1] / max(v[0], 1) for c, v in cs.items()}
