@@ -377,6 +377,27 @@ int sml_eval_prepare(sml_ctx* ctx, const int64_t* rows, int64_t n, int n_cols, i
 int sml_eval_ranks_blocked(sml_ctx* ctx, const float* w_user, const float* w_item, const int32_t* rows_b,
                            const int32_t* bucket_off, int64_t n, int n_cols, int32_t* rank,
                            int max_workgroups, void* stream);
+/* LDS-sliced form (d = 32, n_item <= 2^20, at most 32767 candidates per row, fewer than 2^31 entries in all): the
+ * candidates are re-ordered ONCE per test set slice-major (slice = 1,024 consecutive item rows, staged in LDS; inside a
+ * slice by mini-block of 64 test rows, then by test row, every (row, slice) unit padded to an even count), and the rank pass
+ * reads item rows from LDS instead of gathering them through L1 -- same ranks as sml_eval_ranks (same rounding of every
+ * score), bit for bit.
+ *   sml_eval_sliced_slices        number of slices, 0 when the shape is outside the range above (use the forms above)
+ *   sml_eval_sliced_entries       uint32 words of `entries` (candidates + padding, an upper bound)
+ *   sml_eval_sliced_work_ints     int32 words of `work` the preparation needs (contents not needed afterwards)
+ *   sml_eval_sliced_scratch_bytes bytes of `scratch` one rank pass needs (contents not needed afterwards; 16-byte aligned)
+ *   sml_eval_prepare_sliced       entries uint32 [sml_eval_sliced_entries], seg_off int32 [slices * ceil(n / 64) + 1]
+ *   sml_eval_ranks_sliced         rows is the ORIGINAL int64 table (user and positive columns are read from it);
+ *                                 max_workgroups > 0: grid size wanted (one workgroup occupies a whole CU's LDS). */
+int sml_eval_sliced_slices(sml_ctx* ctx, int64_t n, int n_cols, int64_t n_item);
+int64_t sml_eval_sliced_entries(sml_ctx* ctx, int64_t n, int n_cols, int64_t n_item);
+int64_t sml_eval_sliced_work_ints(sml_ctx* ctx, int64_t n, int n_cols, int64_t n_item);
+int64_t sml_eval_sliced_scratch_bytes(sml_ctx* ctx, int64_t n, int n_cols, int64_t n_item);
+int sml_eval_prepare_sliced(sml_ctx* ctx, const int64_t* rows, int64_t n, int n_cols, int64_t n_item,
+                            uint32_t* entries, int32_t* seg_off, int32_t* work, void* stream);
+int sml_eval_ranks_sliced(sml_ctx* ctx, const float* w_user, const float* w_item, const int64_t* rows,
+                          const uint32_t* entries, const int32_t* seg_off, int64_t n, int n_cols, int64_t n_item,
+                          void* scratch, int32_t* rank, int max_workgroups, void* stream);
 /* ---- a11: save_MF_weight (model/transfer.py:911-943) and evaluation snapshots ------- */
 /* n <= 4 device-to-device copies (dst[q] <- src[q], bytes[q]; all multiples of 16) in one launch. */
 int sml_copy_tables(int n, void* const* dst, const void* const* src, const int64_t* bytes, void* stream);

@@ -95,6 +95,13 @@ SIGNATURES = {
     "sml_eval_prepare": (ctypes.c_int, [c_void, c_void, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, c_void, c_void, c_void]),
     "sml_eval_ranks_blocked": (ctypes.c_int, [c_void, c_void, c_void, c_void, c_void, ctypes.c_int64, ctypes.c_int, c_void, ctypes.c_int,
                                               c_void]),
+    "sml_eval_sliced_slices": (ctypes.c_int, [c_void, ctypes.c_int64, ctypes.c_int, ctypes.c_int64]),
+    "sml_eval_sliced_entries": (ctypes.c_int64, [c_void, ctypes.c_int64, ctypes.c_int, ctypes.c_int64]),
+    "sml_eval_sliced_work_ints": (ctypes.c_int64, [c_void, ctypes.c_int64, ctypes.c_int, ctypes.c_int64]),
+    "sml_eval_sliced_scratch_bytes": (ctypes.c_int64, [c_void, ctypes.c_int64, ctypes.c_int, ctypes.c_int64]),
+    "sml_eval_prepare_sliced": (ctypes.c_int, [c_void, c_void, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, c_void, c_void, c_void, c_void]),
+    "sml_eval_ranks_sliced": (ctypes.c_int, [c_void, c_void, c_void, c_void, c_void, c_void, ctypes.c_int64, ctypes.c_int, ctypes.c_int64,
+                                             c_void, c_void, ctypes.c_int, c_void]),
     "sml_stream_create_cu_range": (ctypes.c_int, [ctypes.POINTER(c_void), ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "sml_stream_destroy": (ctypes.c_int, [c_void]),
     "sml_stream_wait_stream": (ctypes.c_int, [c_void, c_void]),

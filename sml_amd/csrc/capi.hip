@@ -1567,6 +1567,72 @@ int sml_eval_ranks_blocked(sml_ctx* ctx, const float* w_user, const float* w_ite
     return SML_OK;
 }
 
+// ---- LDS-sliced evaluation (d = 32): include/sml_hip.h ------------------------------------------------------------
+namespace {
+struct EvsGeom { int ns; int64_t n_mb, n_pad, cap; };
+bool evs_geom(const sml_ctx* ctx, int64_t n, int n_cols, int64_t n_item, EvsGeom& g) {
+    g.ns = sml_evs_slices(ctx->d, n_item);
+    g.n_mb = (n + 63) / 64;
+    g.n_pad = g.n_mb * 64;
+    /* every (test row, slice) unit is padded to an even count: at most one extra entry per unit that holds a candidate */
+    g.cap = n_cols >= 2 ? n * ((int64_t)(n_cols - 2) + (g.ns < n_cols - 2 ? g.ns : n_cols - 2)) : 0;
+    return g.ns > 0 && n_cols >= 2 && n_cols - 2 <= 32767 && g.cap <= 0x7fffffffll && (int64_t)g.ns * g.n_mb < 0x7fffffffll;
+}
+}
+int sml_eval_sliced_slices(sml_ctx* ctx, int64_t n, int n_cols, int64_t n_item) {
+    if (!ctx || n < 0) return 0;
+    EvsGeom g;
+    return evs_geom(ctx, n, n_cols, n_item, g) ? g.ns : 0;
+}
+int64_t sml_eval_sliced_entries(sml_ctx* ctx, int64_t n, int n_cols, int64_t n_item) {
+    EvsGeom g;
+    if (!ctx || n < 0 || !evs_geom(ctx, n, n_cols, n_item, g)) return 0;
+    return g.cap;
+}
+int64_t sml_eval_sliced_work_ints(sml_ctx* ctx, int64_t n, int n_cols, int64_t n_item) {
+    EvsGeom g;
+    if (!ctx || n < 0 || !evs_geom(ctx, n, n_cols, n_item, g)) return 0;
+    return 5 * (int64_t)g.ns * g.n_mb;                  /* per-wavefront histograms [n_mb][4][ns] + segment counts [ns][n_mb] */
+}
+int64_t sml_eval_sliced_scratch_bytes(sml_ctx* ctx, int64_t n, int n_cols, int64_t n_item) {
+    EvsGeom g;
+    if (!ctx || n < 0 || !evs_geom(ctx, n, n_cols, n_item, g)) return 0;
+    return n * ctx->d * 4 + g.n_pad * 4 + (int64_t)g.ns * g.n_pad * 2;
+}
+int sml_eval_prepare_sliced(sml_ctx* ctx, const int64_t* rows, int64_t n, int n_cols, int64_t n_item, uint32_t* entries,
+                            int32_t* seg_off, int32_t* work, void* stream) {
+    if (ctx && n == 0 && n_cols >= 2 && n_item > 0) return SML_OK;
+    EvsGeom g;
+    if (!ctx || !rows || (!entries && n_cols > 2) || !seg_off || !work || n < 0 || n_item <= 0)      /* (no negatives: no entries) */
+        return fail(SML_EINVAL, "sml_eval_prepare_sliced", "bad argument");
+    if (!evs_geom(ctx, n, n_cols, n_item, g))
+        return fail(SML_EINVAL, "sml_eval_prepare_sliced", "the sliced evaluation needs d = 32, n_item <= 2^20, at most 32767 candidates per row and fewer than 2^31 entries: use sml_eval_prepare");
+    DevGuard dg(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    ctx->prof.begin(PC_MISC, st);
+    HIPCHK(sml_launch_evs_prepare(rows, n, n_cols, g.ns, work, work + 4 * (int64_t)g.ns * g.n_mb, seg_off, entries, st));
+    ctx->prof.end(st);
+    return SML_OK;
+}
+int sml_eval_ranks_sliced(sml_ctx* ctx, const float* w_user, const float* w_item, const int64_t* rows, const uint32_t* entries,
+                          const int32_t* seg_off, int64_t n, int n_cols, int64_t n_item, void* scratch, int32_t* rank,
+                          int max_workgroups, void* stream) {
+    if (ctx && n == 0) return SML_OK;
+    EvsGeom g;
+    if (!ctx || !w_user || !w_item || !rows || (!entries && n_cols > 2) || !seg_off || !scratch || !rank || n < 0 || n_item <= 0)
+        return fail(SML_EINVAL, "sml_eval_ranks_sliced", "bad argument");
+    if (!evs_geom(ctx, n, n_cols, n_item, g)) return fail(SML_EINVAL, "sml_eval_ranks_sliced", "shape outside the sliced evaluation's range");
+    DevGuard dg(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    float* ug = reinterpret_cast<float*>(scratch);
+    float* s0 = ug + n * ctx->d;
+    uint16_t* partial = reinterpret_cast<uint16_t*>(s0 + g.n_pad);
+    ctx->prof.begin(PC_EVAL_RANKS, st);
+    HIPCHK(sml_launch_evs_ranks(ctx->d, w_user, w_item, rows, entries, seg_off, n, n_cols, n_item, g.ns, ug, s0, partial, rank, max_workgroups, st));
+    ctx->prof.end(st);
+    return SML_OK;
+}
+
 int sml_eval_metrics(sml_ctx* ctx, const int32_t* rank, int64_t n, int topk, float* out, void* stream) {
     if (!ctx || !out || n < 0 || (n > 0 && !rank)) return fail(SML_EINVAL, "sml_eval_metrics", "bad argument");
     DevGuard g(ctx->device);

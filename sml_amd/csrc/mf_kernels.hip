@@ -1057,6 +1057,229 @@ __global__ __launch_bounds__(256) void k_eval_ranks_bucketed(const float* __rest
 
 
 // ------------------------------------------------------------------------------------
+// LDS-sliced evaluation (d = 32).  The gathering kernels above pay one 128-byte L1 line per candidate row (5.3
+// clocks per line and CU, whatever the bytes or the instruction count: DESIGN.md section 5); here the item rows are
+// read from LDS instead.  Once per test set (k_evs_count -> k_evs_scan -> k_evs_scatter) the candidates are re-ordered
+// SLICE-MAJOR: slice s = item >> 10 (1,024 item rows = 128 KB of LDS), inside a slice by MINI-BLOCK
+// of 64 test rows, inside a mini-block by test row; the candidates of one (test row, slice) UNIT are padded to an even
+// count, so entries 2k and 2k + 1 of a segment always belong to one test row.  An entry is
+//     (row in mini-block) << 25 | (item & 1023) * 128 | pad flag:
+// e >> 18 is the byte offset of the user row inside the mini-block's dense user rows, e & 0x1ff80 the LDS byte offset of
+// the item row.  Per evaluation:
+//   k_evs_pre    user row and the positive's score of every test row, once, into dense arrays (ug, s0);
+//   k_evs_ranks  workgroup (slice, part) stages its slice in LDS; each wavefront walks whole (slice, mini-block)
+//                segments, 64 entries per trip: lane group g takes entries 8g..8g+7 (ds_bpermute from the lane that loaded
+//                them), FOUR user-chunk loads per trip (one per entry pair: a wavefront-wide 16-byte load costs the CU's
+//                vector-memory path 16 clocks whatever its lanes fetch -- tools/l1_rate_probe.hip -- and that path is what
+//                bounds the pass), item chunks by ds_read_b128, the eight-at-a-time butterfly leaves lane l with the score
+//                of entry l -- the entry it loaded itself; hits are counted in 64 wavefront-private LDS counters (one per
+//                test row of the mini-block) and leave as one coalesced 128-byte store of partial[slice][row] (uint16: no
+//                atomics, no zeroing).  Software-pipelined over trips: the user chunks of trip t + 1 are in flight while
+//                trip t is scored (two register buffers, the loop unrolled twice) -- without that the sixteen wavefronts
+//                of a CU fall into step, all loading, then all computing;
+//   k_evs_sum    rank[r] = sum over slices of partial[s][r].
+// Scores round exactly as in k_eval_ranks (dot4 per lane, the xor butterfly's pairing order), so ranks are identical.
+// ------------------------------------------------------------------------------------
+#define SML_EVS_SHIFT 10
+#define SML_EVS_S (1 << SML_EVS_SHIFT)          // item rows per slice
+#define SML_EVS_STRIDE 128                      // bytes between item rows in LDS (a multiple of 128: the lane's chunk offset is OR-ed in)
+#define SML_EVS_MB 64                           // test rows per mini-block
+#define SML_EVS_WAVES 16                        // wavefronts of a rank workgroup
+#define SML_EVS_NS_MAX 1024                     // slices the preparation's LDS histograms hold
+#define SML_EVS_PAD 1u
+
+// per mini-block and wavefront (16 rows each): entries per slice (every row's count rounded up to even); mbcnt is
+// slice-major so that its flat exclusive scan IS the segment table
+__global__ __launch_bounds__(256) void k_evs_count(const int64_t* __restrict__ rows, int64_t n, int n_cols, int ns, int n_mb,
+                                                   int32_t* __restrict__ whist, int32_t* __restrict__ mbcnt) {
+    extern __shared__ int evs_hist[];            // [4][ns] per wavefront + [4][ns] per row
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int mb = blockIdx.x;
+    int* H = evs_hist + wv * ns;
+    int* Rw = evs_hist + (4 + wv) * ns;
+    for (int i = lane; i < ns; i += 64) H[i] = 0;
+    for (int k = 0; k < 16; ++k) {
+        const int64_t r = (int64_t)mb * SML_EVS_MB + wv * 16 + k;
+        if (r >= n) break;
+        const int64_t* R = rows + r * n_cols;
+        for (int i = lane; i < ns; i += 64) Rw[i] = 0;
+        __builtin_amdgcn_wave_barrier();
+        for (int c = 2 + lane; c < n_cols; c += 64) {
+            const int s = (int)min((int64_t)ns - 1, max((int64_t)0, __builtin_nontemporal_load(R + c) >> SML_EVS_SHIFT));
+            atomicAdd(&Rw[s], 1);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < ns; i += 64) H[i] += (Rw[i] + 1) & ~1;
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ns; i += 256) {
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const int h = evs_hist[w * ns + i]; whist[((int64_t)mb * 4 + w) * ns + i] = h; tot += h; }
+        mbcnt[(int64_t)i * n_mb + mb] = tot;
+    }
+}
+// exclusive scan of cnt[0..m) into off[0..m] (one workgroup; m is a few hundred thousand at most)
+__global__ __launch_bounds__(1024) void k_evs_scan(const int32_t* __restrict__ cnt, int64_t m, int32_t* __restrict__ off) {
+    __shared__ int part[1024];
+    const int64_t per = (m + 1023) / 1024;
+    const int64_t b = min(m, (int64_t)threadIdx.x * per), e = min(m, b + per);
+    int sum = 0;
+    for (int64_t i = b; i < e; ++i) sum += cnt[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - sum;
+    for (int64_t i = b; i < e; ++i) { off[i] = run; run += cnt[i]; }
+    if (threadIdx.x == 1023) off[m] = part[1023];
+}
+__global__ __launch_bounds__(256) void k_evs_scatter(const int64_t* __restrict__ rows, int64_t n, int n_cols, int ns, int n_mb,
+                                                     const int32_t* __restrict__ whist, const int32_t* __restrict__ seg_off,
+                                                     uint32_t* __restrict__ entries) {
+    extern __shared__ int evs_cur[];             // [4][ns]: next free position of (wavefront, slice) + [4][ns]: where the row began
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int mb = blockIdx.x;
+    for (int i = threadIdx.x; i < ns; i += 256) {
+        int run = seg_off[(int64_t)i * n_mb + mb];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { evs_cur[w * ns + i] = run; run += whist[((int64_t)mb * 4 + w) * ns + i]; }
+    }
+    __syncthreads();
+    int* C = evs_cur + wv * ns;
+    int* B = evs_cur + (4 + wv) * ns;
+    for (int k = 0; k < 16; ++k) {               // a wavefront's rows in order: a segment ends up sorted by test row
+        const int64_t r = (int64_t)mb * SML_EVS_MB + wv * 16 + k;
+        if (r >= n) break;
+        const int64_t* R = rows + r * n_cols;
+        const uint32_t tag = (uint32_t)(wv * 16 + k) << 25;
+        for (int i = lane; i < ns; i += 64) B[i] = C[i];
+        __builtin_amdgcn_wave_barrier();
+        for (int c = 2 + lane; c < n_cols; c += 64) {
+            const int64_t it = __builtin_nontemporal_load(R + c);
+            const int s = (int)min((int64_t)ns - 1, max((int64_t)0, it >> SML_EVS_SHIFT));
+            const int pos = atomicAdd(&C[s], 1);
+            entries[pos] = tag | (uint32_t)(it & (SML_EVS_S - 1)) * SML_EVS_STRIDE;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < ns; i += 64) {    // an odd unit gets one padding entry (scored, never counted)
+            const int c = C[i];
+            if ((c - B[i]) & 1) { entries[c] = tag | SML_EVS_PAD; C[i] = c + 1; }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+template <int D>
+__global__ __launch_bounds__(256) void k_evs_pre(const float* __restrict__ wu, const float* __restrict__ wi, const int64_t* __restrict__ rows,
+                                                 int64_t n, int n_cols, float* __restrict__ ug, float* __restrict__ s0) {
+    constexpr int LPR = D / 4;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t r = gid / LPR;
+    const int sub = (int)(gid % LPR);
+    if (r >= n) return;                          // (a lane group is inside or outside as a whole)
+    float u[4], x[4];
+    RowVec<float>::load(wu + rows[r * n_cols] * D + sub * 4, u);
+    RowVec<float>::load(wi + rows[r * n_cols + 1] * D + sub * 4, x);
+    const float s = eval_group_sum<LPR>(dot4(u, x));
+    RowVec<float>::store(ug + r * D + sub * 4, u);
+    if (sub == 0) s0[r] = s;
+}
+template <int D>
+__global__ __launch_bounds__(SML_EVS_WAVES * 64) void k_evs_ranks(const float* __restrict__ ug, const float* __restrict__ s0v,
+                                                                   const float* __restrict__ wi, const uint32_t* __restrict__ entries,
+                                                                   const int32_t* __restrict__ seg_off, int64_t n, int64_t n_item,
+                                                                   int n_mb, int parts, uint16_t* __restrict__ partial) {
+    static_assert(D == 32, "the sliced evaluation is cut for d = 32 (eight lanes per row)");
+    constexpr int LPR = D / 4;
+    extern __shared__ __align__(16) unsigned char evs_smem[];
+    int* const cnt = reinterpret_cast<int*>(evs_smem + (size_t)SML_EVS_S * SML_EVS_STRIDE);        // [waves][64]
+    const int s = blockIdx.x / parts, part = blockIdx.x % parts;
+    const int64_t i0 = (int64_t)s << SML_EVS_SHIFT;
+    const int live = (int)min((int64_t)SML_EVS_S, n_item - i0);
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(wi + i0 * D);
+        for (int i = threadIdx.x; i < SML_EVS_S * LPR; i += SML_EVS_WAVES * 64) {
+            const int row = i / LPR, ch = i % LPR;
+            *reinterpret_cast<f32x4*>(evs_smem + row * SML_EVS_STRIDE + ch * 16) = row < live ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __syncthreads();
+    // the rank loop addresses the slice by LDS byte offset (one v_and_or per item chunk): the kernel's only LDS is this
+    // dynamic block, so it starts at LDS address 0 -- checked, not assumed
+    typedef const __attribute__((address_space(3))) f32x4* lds_f32x4_ptr;
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)evs_smem != 0u) __builtin_trap();
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = lane >> 3, sub = lane & 7;
+    const uint32_t sub16 = (uint32_t)sub * 16u;
+    int* const mycnt = cnt + wv * 64;
+    const int64_t n_pad = (int64_t)n_mb * SML_EVS_MB;
+    const int32_t* const so = seg_off + (int64_t)s * n_mb;
+    uint16_t* const pout = partial + (int64_t)s * n_pad;
+    for (int mb = part * SML_EVS_WAVES + wv; mb < n_mb; mb += SML_EVS_WAVES * parts) {
+        const int seg0 = so[mb], seg1 = so[mb + 1];
+        const int64_t r0 = (int64_t)mb * SML_EVS_MB;
+        if (seg0 == seg1) { pout[r0 + lane] = 0; continue; }          // no candidate of these 64 rows in this slice
+        const float s0r = r0 + lane < n ? s0v[r0 + lane] : 0.f;
+        mycnt[lane] = 0;
+        const char* const ub = reinterpret_cast<const char*>(ug + r0 * D);
+        auto load_e = [&](int t) -> uint32_t { return t < seg1 ? __builtin_nontemporal_load(entries + min(t + lane, seg1 - 1)) : 0u; };   // (a 320 MB stream per pass: not to displace the training stream's tables from the memory-side cache)
+        // stage 2 of a trip: the lane group's eight entries, the four user chunks (one per entry pair)
+        auto fetch = [&](uint32_t e, uint32_t (&x)[8], f32x4 (&u)[4]) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = (uint32_t)__shfl((int)e, grp * 8 + j, 64);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u[k] = *reinterpret_cast<const f32x4*>(ub + ((x[2 * k] >> 18) | sub16));
+        };
+        // stage 3: item chunks from LDS, scores, counts
+        auto score = [&](uint32_t e, int t, const uint32_t (&x)[8], const f32x4 (&u)[4]) {
+            float a[8];
+            f32x4 y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = *(lds_f32x4_ptr)(uintptr_t)((x[j] & 0x1ff80u) | sub16);      // (LDS byte address: the slice starts at 0)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 uu = u[j >> 1];
+                a[j] = __fmaf_rn(uu[3], y[j][3], __fmaf_rn(uu[2], y[j][2], __fmaf_rn(uu[1], y[j][1], __fmul_rn(uu[0], y[j][0]))));   // == dot4
+            }
+            const float sc = eval8_reduce<LPR>(a, sub);          // eval8_index<8>(sub) == sub: the score of entry t + lane
+            const int myrow = (int)(e >> 25);
+            const float s0c = __shfl(s0r, myrow, 64);
+            if (t + lane < seg1 && !(e & SML_EVS_PAD) && sc > s0c) atomicAdd(&mycnt[myrow], 1);
+        };
+        uint32_t eA = load_e(seg0), eB = load_e(seg0 + 64);
+        uint32_t xA[8], xB[8];
+        f32x4 uA[4], uB[4];
+        fetch(eA, xA, uA);
+        for (int t = seg0; t < seg1; t += 128) {
+            // trip t is landing in A, the entries of trip t + 64 are in eB
+            const uint32_t eC = load_e(t + 128);
+            if (t + 64 < seg1) fetch(eB, xB, uB);
+            score(eA, t, xA, uA);
+            if (t + 64 >= seg1) break;
+            const uint32_t eD = load_e(t + 192);
+            if (t + 128 < seg1) fetch(eC, xA, uA);
+            score(eB, t + 64, xB, uB);
+            eA = eC;
+            eB = eD;
+        }
+        __builtin_nontemporal_store((uint16_t)mycnt[lane], pout + r0 + lane);
+    }
+}
+__global__ __launch_bounds__(256) void k_evs_sum(const uint16_t* __restrict__ partial, int64_t n, int64_t n_pad, int ns, int32_t* __restrict__ rank) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    int acc = 0;
+    for (int s = 0; s < ns; ++s) acc += __builtin_nontemporal_load(partial + (int64_t)s * n_pad + r);
+    rank[r] = acc;
+}
+
+// ------------------------------------------------------------------------------------
 // On-device batch supply (fast mode; the reference-exact numpy stream stays on the host): for every
 // (user, item) pair of an epoch, a negative drawn uniformly from the period's item set, redrawn while it is
 // one of the user's own items (data/dataset.py:63-71 as a distribution, not as a random-number stream).
@@ -1408,6 +1631,43 @@ hipError_t sml_launch_eval_ranks_bucketed(int d, const float* wu, const float* w
     const int64_t cap = max_blocks > 0 ? max_blocks : (d <= 64 ? 1024 : 0x7fffff00);
     if (nb > cap) nb = (cap / SML_EVB > 0 ? cap / SML_EVB : 1) * SML_EVB;
     SML_DISPATCH_D(d, k_eval_ranks_bucketed<DD><<<dim3((unsigned)nb), dim3(256), 0, st>>>(wu, wi, rows_b, bucket_off, n, n_cols, rank));
+    return hipGetLastError();
+}
+// ---- LDS-sliced evaluation (d = 32): geometry, preparation, rank pass -------------------------------------------
+int sml_evs_slices(int d, int64_t n_item) {
+    if (d != 32 || n_item <= 0) return 0;
+    const int64_t ns = (n_item + SML_EVS_S - 1) >> SML_EVS_SHIFT;
+    return ns <= SML_EVS_NS_MAX ? (int)ns : 0;
+}
+hipError_t sml_launch_evs_prepare(const int64_t* rows, int64_t n, int n_cols, int ns, int32_t* whist, int32_t* mbcnt, int32_t* seg_off,
+                                  uint32_t* entries, hipStream_t st) {
+    const int n_mb = (int)((n + SML_EVS_MB - 1) / SML_EVS_MB);
+    const size_t lds = (size_t)8 * ns * sizeof(int);
+    k_evs_count<<<dim3((unsigned)n_mb), dim3(256), lds, st>>>(rows, n, n_cols, ns, n_mb, whist, mbcnt);
+    k_evs_scan<<<dim3(1), dim3(1024), 0, st>>>(mbcnt, (int64_t)ns * n_mb, seg_off);
+    k_evs_scatter<<<dim3((unsigned)n_mb), dim3(256), lds, st>>>(rows, n, n_cols, ns, n_mb, whist, seg_off, entries);
+    return hipGetLastError();
+}
+hipError_t sml_launch_evs_ranks(int d, const float* wu, const float* wi, const int64_t* rows, const uint32_t* entries, const int32_t* seg_off,
+                                int64_t n, int n_cols, int64_t n_item, int ns, float* ug, float* s0, uint16_t* partial, int32_t* rank,
+                                int max_blocks, hipStream_t st) {
+    if (d != 32) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    const size_t lds = (size_t)SML_EVS_S * SML_EVS_STRIDE + (size_t)SML_EVS_WAVES * 64 * sizeof(int);
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_evs_ranks<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int n_mb = (int)((n + SML_EVS_MB - 1) / SML_EVS_MB);
+    k_evs_pre<32><<<dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, st>>>(wu, wi, rows, n, n_cols, ug, s0);
+    // one workgroup per CU (its slice fills the LDS): `parts` workgroups share a slice's mini-blocks
+    const int want = max_blocks > 0 ? max_blocks : 256;
+    int parts = want / ns;
+    if (parts < 1) parts = 1;
+    if (parts > (n_mb + SML_EVS_WAVES - 1) / SML_EVS_WAVES) parts = (n_mb + SML_EVS_WAVES - 1) / SML_EVS_WAVES;
+    k_evs_ranks<32><<<dim3((unsigned)(ns * parts)), dim3(SML_EVS_WAVES * 64), lds, st>>>(ug, s0, wi, entries, seg_off, n, n_item, n_mb, parts, partial);
+    k_evs_sum<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(partial, n, (int64_t)n_mb * SML_EVS_MB, ns, rank);
     return hipGetLastError();
 }
 hipError_t sml_launch_sample_negatives(const int64_t* users, int64_t n, const int64_t* item_all, int64_t pop, const int64_t* user_ptr,

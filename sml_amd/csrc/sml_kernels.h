@@ -399,6 +399,12 @@ hipError_t sml_launch_flag_wait(int* flag, int value, long long timeout_ticks, h
 hipError_t sml_launch_eval_ranks_bucketed(int d, const float* wu, const float* wi, const int32_t* rows_b,
                                           const int32_t* bucket_off, int64_t n, int n_cols, int32_t* rank, int max_blocks,
                                           hipStream_t st);
+int sml_evs_slices(int d, int64_t n_item);
+hipError_t sml_launch_evs_prepare(const int64_t* rows, int64_t n, int n_cols, int ns, int32_t* whist, int32_t* mbcnt, int32_t* seg_off,
+                                  uint32_t* entries, hipStream_t st);
+hipError_t sml_launch_evs_ranks(int d, const float* wu, const float* wi, const int64_t* rows, const uint32_t* entries, const int32_t* seg_off,
+                                int64_t n, int n_cols, int64_t n_item, int ns, float* ug, float* s0, uint16_t* partial, int32_t* rank,
+                                int max_blocks, hipStream_t st);
 hipError_t sml_launch_sample_negatives(const int64_t* users, int64_t n, const int64_t* item_all, int64_t pop, const int64_t* user_ptr,
                                        int64_t n_users, const int64_t* user_items, uint64_t seed, int64_t* negs, int* failed,
                                        hipStream_t st);

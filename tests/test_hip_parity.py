@@ -1114,6 +1114,56 @@ def test_blocked_eval_equals_plain_eval(d, neg, I):
     assert torch.equal(blk, eng.eval_ranks(wu, wi, rows, blocked=True))       # cached buckets, repeatable
 
 
+@pytest.mark.parametrize("neg,I,n,case", [(999, 123000, 1031, "random"), (99, 50000, 64, "random"), (7, 5, 130, "random"), (0, 50, 10, "random"),
+                                          (333, 3000, 257, "ties"), (999, 1025, 200, "one_slice_heavy"), (65, 2048, 1, "random"),
+                                          (40, 1 << 20, 300, "random")])
+def test_sliced_eval_equals_plain_eval(neg, I, n, case):
+    """Round 5: the LDS-sliced evaluation (candidates re-ordered slice-major once per test set, item rows read from LDS by the
+    rank pass: sml_eval_prepare_sliced / sml_eval_ranks_sliced; MFbasemode.test, model/MF.py:45-60) returns exactly the ranks of
+    the plain kernel -- ragged last slice and last mini-block, empty segments, tied and NaN scores, every candidate of a row
+    in one slice, a single row, the largest item table the form takes, and every grid size."""
+    d = 32
+    torch.manual_seed(neg + n)
+    U = 700
+    wu, wi = torch.randn(U, d).to(DEV), torch.randn(I, d).to(DEV)
+    rows = torch.cat([torch.randint(0, U, (n, 1)), torch.randint(0, I, (n, 1 + neg))], 1)
+    if case == "ties":                     # many equal rows (equal scores: not counted), a NaN row, a zero row
+        wi[::3] = wi[0]
+        wi[5] = float("nan")
+        wi[7] = 0.0
+        wu[3] = 0.0
+        rows[:, 0][::5] = 3
+    if case == "one_slice_heavy":          # all negatives of the even rows in the last (one-row) slice, of the odd rows in slice 0
+        rows[0::2, 2:] = 1024
+        rows[1::2, 2:] = torch.randint(0, 1024, (rows[1::2].shape[0], neg))
+    rows = rows.to(DEV)
+    eng = engine(d)
+    plain = eng.eval_ranks(wu, wi, rows, blocked=False)
+    for cap in (0, 1, 64, 1000):
+        got = eng.eval_ranks(wu, wi, rows, sliced=True, max_workgroups=cap)
+        assert torch.equal(plain, got), (cap, int((plain != got).sum()))
+    assert eng.__dict__.get("_eval_sliced"), "the sliced form did not run"
+
+
+def test_sliced_eval_is_refused_outside_its_range_and_the_engine_falls_back():
+    """d != 32, more than 2^20 items or more than 32767 candidates per row: sml_eval_sliced_slices says 0, the prepare call is an
+    error, and HipEngine.eval_ranks(sliced=True) ranks with the other kernels."""
+    eng64 = engine(64)
+    assert eng64.lib.sml_eval_sliced_slices(eng64._ctx, 100, 12, 5000) == 0
+    eng = engine(32)
+    assert eng.lib.sml_eval_sliced_slices(eng._ctx, 100, 12, (1 << 20) + 1) == 0
+    assert eng.lib.sml_eval_sliced_slices(eng._ctx, 100, 32769, 5000) == 5
+    assert eng.lib.sml_eval_sliced_slices(eng._ctx, 100, 32770, 5000) == 0
+    assert eng.lib.sml_eval_sliced_slices(eng._ctx, 100, 12, 5000) == 5
+    buf = torch.zeros(64, device=DEV, dtype=torch.int64)
+    rc = eng.lib.sml_eval_prepare_sliced(eng._ctx, buf.data_ptr(), 4, 12, (1 << 20) + 1, buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), None)
+    assert rc != 0
+    torch.manual_seed(0)
+    wu, wi = torch.randn(50, 64).to(DEV), torch.randn(400, 64).to(DEV)
+    rows = torch.cat([torch.randint(0, 50, (33, 1)), torch.randint(0, 400, (33, 10))], 1).to(DEV)
+    assert torch.equal(eng64.eval_ranks(wu, wi, rows, sliced=True), eng64.eval_ranks(wu, wi, rows, blocked=False))
+
+
 @pytest.mark.parametrize("variant", ["conv_com", "conv"])
 def test_table_sized_forward_on_bf16_products_equals_the_fp32_products(variant, monkeypatch):
     """Round 5: table-sized forwards at d = 32 (updata, model/transfer.py:884-902) run fc1 / fc2 on the bf16 matrix rate with every
