@@ -287,12 +287,18 @@ __global__ __launch_bounds__(256) void k_bare_grad(SmlBareArgs a) {
                 for (int r3 = 0; r3 < 3; ++r3) { RowVec<float>::store(a.mrep + o[r3], m[r3]); RowVec<float>::store(a.vrep + o[r3], v[r3]); }
             }
         }
-        float sp = 0.f, sn = 0.f, sq_u = 0.f, sq_i = 0.f;
+        // The element-wise stretches on PACKED fp32 (v_pk_mul_f32 / v_pk_fma_f32: two elements of a row per lane and
+        // instruction; a plain wavefront-wide VALU instruction costs its SIMD 4.1 clocks, a packed one 4.9 --
+        // tools/valu_rate_probe.hip): element pairs (k, k + 1) ride together, every element sees the same operations as before.
+        f32x2 sp2 = {0.f, 0.f}, sn2 = {0.f, 0.f}, squ2 = {0.f, 0.f}, sqi2 = {0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            sp += u[k] * it[k]; sn += u[k] * ng[k];
-            sq_u += u[k] * u[k]; sq_i += it[k] * it[k] + ng[k] * ng[k];
+        for (int k = 0; k < VEC; k += 2) {
+            const f32x2 uu = {u[k], u[k + 1]}, ii2 = {it[k], it[k + 1]}, nn = {ng[k], ng[k + 1]};
+            sp2 += uu * ii2; sn2 += uu * nn;
+            squ2 += uu * uu; sqi2 += ii2 * ii2 + nn * nn;
         }
+        float sp = sp2[0] + sp2[1], sn = sn2[0] + sn2[1];
+        const float sq_u = squ2[0] + squ2[1], sq_i = sqi2[0] + sqi2[1];
         sp = group_sum<LPR>(sp); sn = group_sum<LPR>(sn);
         float lt, dsp, dsn;
         // The pair terms on the transcendental unit (v_log_f32 / v_exp_f32 / v_rcp_f32, ~1 ulp each) instead of logf / log1pf /
@@ -319,18 +325,26 @@ __global__ __launch_bounds__(256) void k_bare_grad(SmlBareArgs a) {
         // the batch, so its synchronous-SGD update is applied in place right here (exact); the others
         // hand their gradient row to the segmented update.
         float gx[VEC], gy[VEC], gz[VEC];
+        {
+            const f32x2 dsp2 = {dsp, dsp}, dsn2 = {dsn, dsn}, lu2 = {a.lam_user, a.lam_user}, li2 = {a.lam_item, a.lam_item};
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            gx[e] = dsp * it[e] + dsn * ng[e] + a.lam_user * u[e];
-            gy[e] = dsp * u[e] + a.lam_item * it[e];
-            gz[e] = dsn * u[e] + a.lam_item * ng[e];
+            for (int e = 0; e < VEC; e += 2) {
+                const f32x2 uu = {u[e], u[e + 1]}, ii2 = {it[e], it[e + 1]}, nn = {ng[e], ng[e + 1]};
+                const f32x2 x = dsp2 * ii2 + dsn2 * nn + lu2 * uu, y = dsp2 * uu + li2 * ii2, z = dsn2 * uu + li2 * nn;
+                gx[e] = x[0]; gx[e + 1] = x[1]; gy[e] = y[0]; gy[e + 1] = y[1]; gz[e] = z[0]; gz[e + 1] = z[1];
+            }
         }
         const bool one_u = mk_u != 0, one_i = mk_i != 0, one_n = mk_n != 0;
         auto emit = [&](bool in_place, T* wrow, const float (&row)[VEC], const float (&g)[VEC], float* dxrow, bool nt) {
             if (in_place) {
                 float nw[VEC];
+                const f32x2 nlr = {-a.lr, -a.lr};
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) nw[e] = row[e] - a.lr * g[e];
+                for (int e = 0; e < VEC; e += 2) {
+                    const f32x2 r2 = {row[e], row[e + 1]}, g2 = {g[e], g[e + 1]};
+                    const f32x2 w2 = nlr * g2 + r2;
+                    nw[e] = w2[0]; nw[e + 1] = w2[1];
+                }
                 if (nt) RowVec<T>::store_nt(wrow, nw); else RowVec<T>::store(wrow, nw);
             } else {
 #pragma unroll

@@ -5,6 +5,7 @@
 #include "../../include/sml_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define SML_HID 512   // fc1 width                    (reference model/conv_transfer.py:33)
