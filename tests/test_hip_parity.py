@@ -2250,6 +2250,13 @@ def test_bare_step_item_sharded_two_ranks_at_batches_of_6000(head, monkeypatch):
     _item_sharded_two_ranks(32, torch.float32, True, head, True, monkeypatch)
 
 
+def test_bare_step_item_sharded_two_ranks_at_the_config_4_shape(monkeypatch):
+    """The same at BASELINE.json's config 4 shape (round 5; the review of round 4: "toy shapes or 6,000-triple batches"): 10 M users
+    in two shards of 5 M, 1 M items (6,000 head rows replicated, two tail shards), d = 64 fp32, global batches of 262,144 triples
+    (131,072 per rank) plus a ragged last batch -- two thread ranks on one device, the oracle's global-batch step beside them."""
+    _item_sharded_two_ranks(64, torch.float32, True, 6000, "config4", monkeypatch)
+
+
 def _item_sharded_two_ranks(d, dtype, bce, head, big, monkeypatch):
     """The bare a3 step with the ITEM TABLE SHARDED over world_size 2 (thread ranks on the two CU-masked streams, one-shot
     peer exchange, same-process allocations handed over as raw pointers): the first `head` rows replicated (dense
@@ -2263,6 +2270,8 @@ def _item_sharded_two_ranks(d, dtype, bce, head, big, monkeypatch):
     monkeypatch.setenv("SML_COMM", "peer")
     monkeypatch.setenv("SML_PEER_TIMEOUT_S", "20")
     B, n, U_rank, I = (6000, 6000 * 2 + 777, 20000, 9000) if big else (96, 96 * 3 - 11, 150, 120)
+    if big == "config4":
+        B, n, U_rank, I = 131072, 131072 * 2 + 777, 5000000, 1000000
     wi, wus, tris = _bare_world2_inputs(d, dtype, B, n, U_rank, I, seed=3 * d)
     if big:
         for t in tris:
@@ -2298,6 +2307,35 @@ def _item_sharded_two_ranks(d, dtype, bce, head, big, monkeypatch):
     assert torch.equal(r0["head"], r1["head"])
     got_i = torch.cat([r0["head"], r0["shard"], r1["shard"]]).float()
     assert got_i.shape[0] == I
+    if big == "config4":
+        # Two item rows collect 65,536 occurrences per rank and batch here: an fp32 sum of 131,072 gradient rows moves by more than
+        # 1e-4 with the ORDER of its terms, whoever forms it.  The float64 oracle is the reference, the fp32 oracle's distance from
+        # it the yardstick: the GPU's result may be at most twice as far (and no further than 1e-3).
+        def distance(x, ref):
+            x, ref = np.asarray(x, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+            return float(np.abs(x - ref).max() / max(np.abs(ref).max(), 1e-30))
+        got_u = torch.cat([r0["wu"], r1["wu"]]).numpy()
+        got_l = r0["l"] + r1["l"]
+        runs = {}
+        for name, dt in (("f64", torch.float64), ("f32", torch.float32)):
+            ou, oi = torch.cat(wus).to(dt), wi.to(dt)
+            ls = []
+            for b0 in range(0, n, B):
+                t0, t1 = tris[0][b0:b0 + B], tris[1][b0:b0 + B].clone()
+                t1[:, 0] += U_rank
+                t = torch.cat([t0, t1])
+                ls.append(O.bare_step(ou, oi, t[:, 0], t[:, 1], t[:, 2], lr, 1e-3, 2e-3, bce=bce))
+            runs[name] = (ls, ou.numpy(), oi.numpy())
+        ref_l, ref_u, ref_i = runs["f64"]
+        yard_u, yard_i = distance(runs["f32"][1], ref_u), distance(runs["f32"][2], ref_i)
+        err_u, err_i = distance(got_u, ref_u), distance(got_i.numpy(), ref_i)
+        report = dict(err_user=err_u, err_item=err_i, fp32_oracle_user=yard_u, fp32_oracle_item=yard_i,
+                      losses=[float(x) for x in got_l], losses_f64=[float(x) for x in ref_l])
+        _report("parity_config4_two_ranks_sharded.json", report)
+        np.testing.assert_allclose(got_l, ref_l, rtol=1e-4)
+        assert err_u <= max(1e-4, 2 * yard_u) and err_u <= 1e-3, report
+        assert err_i <= max(1e-4, 2 * yard_i) and err_i <= 1e-3, report
+        return
     ou, oi = torch.cat(wus).float().clone(), wi.float().clone()
     want = []
     for b0 in range(0, n, B):
