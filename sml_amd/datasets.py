@@ -15,8 +15,16 @@ import torch
 from torch.utils.data import Dataset
 
 
+_TORCH_DRAWS = [0]          # draws this module made from torch's global generator (EpochSpeculation predicts the next pass's shuffle from it)
+
+
+def torch_draws():
+    return _TORCH_DRAWS[0]
+
+
 def loader_base_seed_draw():
     """The draw every DataLoader iteration makes on creation (_BaseDataLoaderIter.__init__)."""
+    _TORCH_DRAWS[0] += 1
     return int(torch.empty((), dtype=torch.int64).random_().item())
 
 
@@ -26,7 +34,7 @@ def loader_order(n, shuffle=True):
     loader_base_seed_draw()
     if not shuffle:
         return np.arange(n, dtype=np.int64)
-    seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    seed = loader_base_seed_draw()          # (the sampler's seed: the same kind of draw)
     g = torch.Generator()
     g.manual_seed(seed)
     return torch.randperm(n, generator=g).numpy()
@@ -179,8 +187,9 @@ class offlineDataset_withsample(Dataset):
             neg = np.random.choice(self.item_all, 1)[0]
         return (user, item, neg)
 
-    def epoch_triples(self, order):
-        """Same triples, and same numpy global-RNG end state, as calling __getitem__ for every
+    def epoch_triples(self, order, rng=None):
+        """(rng: a numpy RandomState to draw from instead of the global one -- EpochSpeculation's private copy.)
+        Same triples, and same numpy global-RNG end state, as calling __getitem__ for every
         index of `order` in turn.  np.random.choice(a, 1) is one legacy randint(0, len(a)) draw and a
         block of such draws is the same stream, so candidates are drawn in blocks and the sequential
         accept/reject walk over them runs in compiled code (sml_host_resolve_negatives_csr, a host-side
@@ -202,7 +211,7 @@ class offlineDataset_withsample(Dataset):
         done, drawn = 0, 0
         while done < n:
             k = n - done
-            cand = np.ascontiguousarray(items_all[np.random.randint(0, pop, size=k)])
+            cand = np.ascontiguousarray(items_all[(rng if rng is not None else np.random).randint(0, pop, size=k)])
             rc = lib.sml_host_resolve_negatives_csr(users.ctypes.data + 8 * done, k, cand.ctypes.data, k,
                                                     self._uptr.ctypes.data, self._n_users, self._uitems.ctypes.data,
                                                     negs.ctypes.data + 8 * done, ctypes.byref(used), ctypes.byref(got))
@@ -237,6 +246,64 @@ class offlineDataset_withsample(Dataset):
         self._last_failed = failed            # device counter; checked lazily by the caller if it cares
         tri[:, 2] = negs
         return tri
+
+
+def _same_rng_state(a, b):
+    return (a[0] == b[0] and a[2] == b[2] and a[3] == b[3] and a[4] == b[4] and np.array_equal(a[1], b[1]))
+
+
+class EpochSpeculation(object):
+    """The NEXT pass of an offlineDataset_withsample, drawn ahead on a helper thread while the host queues the current one.
+
+    The reference-exact batch supply costs the host 3.5 ms per 75,000-triple pass (the sequential accept / reject walk of the
+    negatives), and the real driver is host-bound by about that much per phase (tools/time_driver_stage.py --profile).  The
+    pass is a pure function of (torch's shuffle, numpy's generator state at the pass's first draw), so it can be computed
+    early from PREDICTED inputs and adopted only if the prediction was right:
+      * torch: the global generator is saved, the draws the driver is expected to make before the pass (`torch_draws_before`:
+        DataLoader base seeds and sampler seeds of the MF epochs and of every test in between -- the driver counts them from
+        one phase to the next) are made, the pass's own order is drawn, the generator is restored;
+      * numpy: a private RandomState starts from the global state, makes the draws expected before the pass (the
+        pre-sampled MF dataset's constructor shuffles its column order), and the helper thread samples from it;
+      * adopt(): taken only if the order the driver really drew equals the predicted one AND the global numpy state equals
+        the state the helper started from; the global state is then set to where the helper ended.  Anything else (another
+        consumer of either generator in between, another dataset) discards the work and the caller samples in place.
+    Either way triples, logs and generator states are exactly those of the in-place path (tests/test_host_logic.py)."""
+
+    def __init__(self, train_set, torch_draws_before=0, np_shuffles_before=()):
+        import threading
+        self.train_set = train_set
+        t_state, counted = torch.get_rng_state(), _TORCH_DRAWS[0]
+        try:
+            for _ in range(int(torch_draws_before)):
+                loader_base_seed_draw()
+            self.order = loader_order(len(train_set), shuffle=True)
+        finally:
+            torch.set_rng_state(t_state)
+            _TORCH_DRAWS[0] = counted
+        self.rs = np.random.RandomState()
+        self.rs.set_state(np.random.get_state())
+        for k in np_shuffles_before:
+            self.rs.shuffle(np.arange(1, int(k) + 1))
+        self.state_before = self.rs.get_state()
+        self.triples, self.error = None, None
+        self.thread = threading.Thread(target=self._run, name="sml-epoch-speculation", daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        try:
+            self.triples = self.train_set.epoch_triples(self.order, rng=self.rs)
+        except BaseException as e:          # surfaces as "not adopted": the caller samples in place and raises there
+            self.error = e
+
+    def adopt(self, train_set, order):
+        """The pass's triples if the prediction held (global numpy state advanced as the in-place path would), else None."""
+        self.thread.join()
+        if (self.error is not None or self.triples is None or train_set is not self.train_set
+                or not np.array_equal(np.asarray(order), self.order)
+                or not _same_rng_state(np.random.get_state(), self.state_before)):
+            return None
+        np.random.set_state(self.rs.get_state())
+        return self.triples
 
 
 class transfer_data(object):

@@ -469,6 +469,31 @@ class meta_train(object):
                                self.MF_itr)
         self.MF_itr += 1
 
+    def _speculate_next_tr_pass(self, args, train_set, epoch):
+        """Start drawing the NEXT transfer-stage pass on a helper thread (datasets.EpochSpeculation: adopted only if its
+        predicted inputs turn out right, so the reference's random streams are untouched).  Next = the following epoch of
+        this call, or the first epoch of the next phase of this stage -- before which the driver draws two torch seeds per
+        MF epoch and the pre-sampled MF dataset's constructor shuffles its columns.  SML_TR_SPECULATE=0: off."""
+        import os
+        if os.environ.get("SML_TR_SPECULATE", "1") == "0" or not isinstance(train_set, D.offlineDataset_withsample):
+            return
+        ph = getattr(self, "_phase", None)               # (phase, phases of the stage, columns the MF dataset shuffles)
+        if ph is None:
+            return
+        gaps = self.__dict__.get("_tr_gaps", {})
+        if epoch + 1 < int(args.TR_epochs):
+            nxt, shuffles = (ph[0], epoch + 1), ()
+        else:
+            if ph[0] + 1 >= ph[1] or self.MF_TrainDataset is not PreSampleDatast:
+                return
+            nxt, shuffles = (ph[0] + 1, 0), (ph[2],)
+        # torch draws expected before that pass: what the same transition took in the previous stage, else (first stage) what
+        # the transition into THIS pass took -- phases repeat; a wrong guess costs one discarded pass
+        draws = gaps.get(nxt, gaps.get((ph[0], epoch)))
+        if draws is None:
+            return
+        self._tr_spec = D.EpochSpeculation(train_set, draws, shuffles)
+
     # ------------------------------------------------------------------ hot loop 2
     def transfer_train_onestage(self, args, set_tt, stage_id, compute_performance=False, val=None):
         """Train theta on D_{t+1} with the tables frozen (reference model/transfer.py:644-749)."""
@@ -514,8 +539,22 @@ class meta_train(object):
                         raise RuntimeError("negative sampling does not terminate: a user owns (almost) every item")
                 self._emit(check_failed)       # read when the stage's output is flushed: no mid-stage host wait
             else:
+                # (torch draws since the previous transfer pass's shuffle: what the next speculation has to predict)
+                key = (getattr(self, "_phase", None) or (None,))[0], epoch
+                seen = self.__dict__.setdefault("_tr_gaps", {})
+                if getattr(self, "_tr_draw_mark", None) is not None:
+                    seen[key] = D.torch_draws() - self._tr_draw_mark
+                elif getattr(self, "_tr_first_mark", None) is not None:
+                    seen["first"] = D.torch_draws() - self._tr_first_mark        # (from the end of the previous stage's queuing)
+                self._tr_first_mark = None
                 order = D.loader_order(len(train_set), shuffle=True)
-                triples = train_set.epoch_triples(order)
+                self._tr_draw_mark = D.torch_draws()
+                spec = self.__dict__.pop("_tr_spec", None)
+                triples = spec.adopt(train_set, order) if spec is not None else None
+                self.timing["tr_spec_adopted"] = self.timing.get("tr_spec_adopted", 0) + (triples is not None)
+                if triples is None:
+                    triples = train_set.epoch_triples(order)
+                self._speculate_next_tr_pass(args, train_set, epoch)
             t0 = time.time()
             if self.dist is None:
                 losses = self.engine.tr_stage_epoch(self.transfer, self.last_user_weight, self.last_item_weight,
@@ -587,6 +626,7 @@ class meta_train(object):
                 more = self._stage_body(args, stage_id, set_t, set_tt, now_test, val)
             if more and getattr(self, "_prefetch", False):
                 self._prefetch_next(stage_id + 1)
+                self._speculate_first_tr_pass()
             self._stage_failed = False
             return more
         finally:
@@ -594,7 +634,25 @@ class meta_train(object):
             self._pending_transfer = False       # (a stage that raised half-way leaves no deferred forward behind)
             self._flush_output()
 
+    def _speculate_first_tr_pass(self):
+        """The NEXT stage's first transfer pass, drawn while this stage's kernels run and the host only waits for them
+        (its sampler was built by _prefetch_next).  Between here and that pass the driver makes the torch draws the same
+        stretch took one stage earlier (counted) and the MF dataset's constructor shuffles its columns once; a wrong guess
+        -- a test stage that trains no transfer, the first stages -- is discarded (datasets.EpochSpeculation)."""
+        import os
+        self._tr_first_mark = D.torch_draws()
+        nxt, data = getattr(self, "_sample_cache_next", None), getattr(self, "_next_data", (None, None, (None,)))[2]
+        draws = self.__dict__.get("_tr_gaps", {}).get("first")
+        if (os.environ.get("SML_TR_SPECULATE", "1") == "0" or nxt is None or draws is None or data[0] is None
+                or self.MF_TrainDataset is not PreSampleDatast or not isinstance(nxt[1], D.offlineDataset_withsample)):
+            return
+        self._tr_spec = D.EpochSpeculation(nxt[1], draws, (int(data[0].shape[1]) - 1,))
+        self._tr_spec.first_of_stage = True
+
     def _stage_body(self, args, stage_id, set_t, set_tt, now_test, val):
+        self._tr_draw_mark = None                        # (transfer-pass speculation inside a stage: from its second pass on)
+        if not getattr(self.__dict__.get("_tr_spec"), "first_of_stage", False):
+            self.__dict__.pop("_tr_spec", None)
         if now_test is not None and set_tt is None:
             # --TR_stop_: theta frozen during the test periods
             s_time = time.time()
@@ -623,7 +681,11 @@ class meta_train(object):
             if now_test is not None and phase == 0:
                 # test D_{t+1} with the first outer loop's model, before it trains theta
                 self._real_test(now_test)
-            self.transfer_train_onestage(args, set_tt, stage_id, val=val)
+            self._phase = (phase, int(args.multi_num), int(set_t.shape[1]) - 1 if hasattr(set_t, "shape") and len(set_t.shape) == 2 else 0)
+            try:
+                self.transfer_train_onestage(args, set_tt, stage_id, val=val)
+            finally:
+                self._phase = None
             self._materialise_tables()
             if args.Load_W_hat:
                 self.load_MFbase_weight(self.user_weight_hat, self.item_weight_hat)

@@ -51,6 +51,83 @@ def test_g8_rejection_sampling_matches_per_item_draws():
     assert after_vec == after_seq
 
 
+def test_epoch_speculation_is_exact_or_discarded():
+    """datasets.EpochSpeculation (the transfer stage's next pass drawn ahead on a helper thread): adopted, it yields the very
+    triples and leaves both generators (and the module's draw counter) exactly where the in-place sequence [MF constructor shuffle, 2 torch draws per MF epoch,
+    loader_order, epoch_triples] leaves them; with a wrong prediction (another numpy draw in between, another order, another
+    dataset) it yields None and touches neither generator.  Data: G8's pairs (data/dataset.py:41-71)."""
+    from sml_amd import datasets as D
+    z = golden("g8_batches.npz")
+    with quiet():
+        ds = D.offlineDataset_withsample(z["pairs"])
+        other = D.offlineDataset_withsample(z["pairs"])
+    cols, mf_epochs = 1000, 2
+
+    def in_place():
+        np.random.shuffle(np.arange(1, cols + 1))               # trainDataset_withPreSample.__init__
+        for _ in range(mf_epochs):
+            D.loader_order(123)                                  # the MF epochs' DataLoader draws
+        order = D.loader_order(len(ds))
+        return order, ds.epoch_triples(order)
+
+    def states():
+        return np.random.get_state(), torch.get_rng_state(), D.torch_draws()
+
+    def same(a, b):
+        return D._same_rng_state(a[0], b[0]) and torch.equal(a[1], b[1])
+
+    torch.manual_seed(11); np.random.seed(12)
+    order_ref, tri_ref = in_place()
+    end_ref = states()
+    # the speculated path: started BEFORE the intermediate draws, adopted after them
+    torch.manual_seed(11); np.random.seed(12)
+    spec = D.EpochSpeculation(ds, torch_draws_before=2 * mf_epochs, np_shuffles_before=(cols,))
+    start = states()
+    torch.manual_seed(11); np.random.seed(12)
+    assert same(start, states()), "starting a speculation moved a generator"
+    np.random.shuffle(np.arange(1, cols + 1))
+    for _ in range(mf_epochs):
+        D.loader_order(123)
+    order = D.loader_order(len(ds))
+    np.testing.assert_array_equal(order, order_ref)
+    got = spec.adopt(ds, order)
+    assert got is not None
+    np.testing.assert_array_equal(got, tri_ref)
+    assert same(states(), end_ref)
+    # wrong predictions: discarded, generators untouched, the in-place path still gives the reference result
+    for case in ("extra numpy draw", "other order", "other dataset", "no shuffle predicted"):
+        torch.manual_seed(11); np.random.seed(12)
+        spec = D.EpochSpeculation(ds, 2 * mf_epochs, (cols,) if case != "no shuffle predicted" else ())
+        np.random.shuffle(np.arange(1, cols + 1))
+        if case == "extra numpy draw":
+            np.random.randint(0, 10)
+        for _ in range(mf_epochs):
+            D.loader_order(123)
+        order = D.loader_order(len(ds))
+        before = states()
+        if case == "other order":
+            assert spec.adopt(ds, order[::-1].copy()) is None
+        elif case == "other dataset":
+            assert spec.adopt(other, order) is None
+        else:
+            assert spec.adopt(ds, order) is None
+        assert same(states(), before), case
+    # the next epoch of the same call: no draws predicted in between
+    torch.manual_seed(21); np.random.seed(22)
+    o1 = D.loader_order(len(ds)); t1 = ds.epoch_triples(o1)
+    o2 = D.loader_order(len(ds)); t2 = ds.epoch_triples(o2)
+    end = states()
+    torch.manual_seed(21); np.random.seed(22)
+    o1b = D.loader_order(len(ds)); t1b = ds.epoch_triples(o1b)
+    spec = D.EpochSpeculation(ds)
+    o2b = D.loader_order(len(ds))
+    t2b = spec.adopt(ds, o2b)
+    np.testing.assert_array_equal(t1b, t1)
+    assert t2b is not None
+    np.testing.assert_array_equal(t2b, t2)
+    assert same(states(), end)
+
+
 def test_presample_getitem_equals_epoch_triples():
     from sml_amd import datasets as D
     z = golden("g8_batches.npz")

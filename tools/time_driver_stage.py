@@ -106,8 +106,8 @@ def main():
             meta.train_one_stage3(args, s)
         torch.cuda.synchronize()
         dt = time.time() - t0
-        print("stage %d: %.3f s wall; engine calls mf %.3f tr %.3f updata %.3f eval %.3f (cumulative, host view)"
-              % (s, dt, meta.timing["mf"], meta.timing["tr"], meta.timing["updata"], meta.timing["eval"]))
+        print("stage %d: %.3f s wall; engine calls mf %.3f tr %.3f updata %.3f eval %.3f (cumulative, host view); TR passes drawn ahead and adopted: %d"
+              % (s, dt, meta.timing["mf"], meta.timing["tr"], meta.timing["updata"], meta.timing["eval"], meta.timing.get("tr_spec_adopted", 0)))
         if timeline and s == n_stage - 1:
             base = marks[0][3]
             rows = [(nm, (h0 - t0_perf) * 1e3, (h1 - t0_perf) * 1e3, base.elapsed_time(e0), base.elapsed_time(e1)) for nm, h0, h1, e0, e1 in marks]
