@@ -1666,12 +1666,10 @@ hipError_t sml_launch_evs_ranks(int d, const float* wu, const float* wi, const i
                                 int64_t n, int n_cols, int64_t n_item, int ns, float* ug, float* s0, uint16_t* partial, int32_t* rank,
                                 int max_blocks, hipStream_t st) {
     if (d != 32) return hipErrorInvalidValue;
-    static bool attr_set = false;
     const size_t lds = (size_t)SML_EVS_S * SML_EVS_STRIDE + (size_t)SML_EVS_WAVES * 64 * sizeof(int);
-    if (!attr_set) {
+    {   // (per device, so set on every call: a process may drive several devices)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_evs_ranks<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     const int n_mb = (int)((n + SML_EVS_MB - 1) / SML_EVS_MB);
     k_evs_pre<32><<<dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, st>>>(wu, wi, rows, n, n_cols, ug, s0);
