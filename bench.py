@@ -753,6 +753,12 @@ def main():
     with engine.partition():
         for w in range(a.warmup):
             run_period(engine, st, plans[w % len(plans)], hp, overlap=not a.no_overlap, exchanges=exchanges)
+    # A full (generation-2) collection of the interpreter's garbage collector walks every object torch and this program
+    # have alive: 40-60 ms of host time during which nothing is queued (tools/bench_steps.py STEPS_NOGC, round 5).  What
+    # exists now is set aside (gc.freeze): collections inside the timed region look at the periods' own garbage only.
+    import gc
+    gc.collect()
+    gc.freeze()
     barrier()
     t0 = time.perf_counter()
     with engine.partition():

@@ -144,6 +144,11 @@ def main(which, argv=None):
                                   online_train_time=round(cfg["train_from"]), online_test_time=round(cfg["test_from"]))
     meta = transfer.meta_train(args, sets, sets.user_number, sets.item_number, args.laten) if dist is None else \
         transfer.meta_train(args, sets, sets.user_number, sets.item_number, args.laten, dist=dist)
+    # (what exists now -- torch, the model, the period loader -- is set aside from the garbage collector's full collections: one of
+    # them in the middle of a stage is 40-60 ms during which the host queues nothing)
+    import gc
+    gc.collect()
+    gc.freeze()
     meta.run(args)
     if which == "yelp":
         print("@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@TR:L2:", 1e-06)

@@ -73,23 +73,31 @@ def main():
         eng.mf_flush(mf)       # as the period does after every MF epoch (bounds the lazy-Adam replay windows)
 
     out = {"d": a.d, "inter": a.inter, "comm": a.comm}
+    if os.environ.get("STEPS_NOGC"):
+        import gc
+        gc.collect(); gc.disable()
     for name, fn, B in (("tr", tr, a.tr_batch), ("mf", mfe, a.mf_batch)):
         nb = -(-a.inter // B)
         fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+        trace = []
         for _ in range(a.reps):
+            h0 = __import__("time").perf_counter()
             fn()
+            trace.append(round((__import__("time").perf_counter() - h0) * 1e3, 2))
         e1.record()
         torch.cuda.synchronize()
+        if os.environ.get("STEPS_TRACE"):
+            out[name + "_host_ms_per_epoch"] = trace
         out[name + "_us_per_batch"] = round(1000.0 * e0.elapsed_time(e1) / a.reps / nb, 2)
         eng.profile(True)
         fn()
         torch.cuda.synchronize()
         prof = eng.profile_read()
         eng.profile(False)
-        out[name + "_kernels_us"] = {k: round(1000.0 * ms / c, 2) for k, (c, ms) in prof.items() if c >= nb // 2}
+        out[name + "_kernels_us"] = {k: round(1000.0 * ms / c, 2) for k, (c, ms) in prof.items() if c >= (1 if os.environ.get("STEPS_ALL") else nb // 2)}
     if a.comm == "peer":
         out["peer_timeouts"] = eng.peer_status()
     print(json.dumps(out))
