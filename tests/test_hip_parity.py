@@ -2257,6 +2257,99 @@ def test_bare_step_item_sharded_two_ranks_at_the_config_4_shape(monkeypatch):
     _item_sharded_two_ranks(64, torch.float32, True, 6000, "config4", monkeypatch)
 
 
+def test_bare_step_item_sharded_two_ranks_at_the_config_5_shape(monkeypatch):
+    """BASELINE.json's config 5 under two ranks on one device: 50 M users in two shards of 25 M, 5 M items (24 head rows replicated,
+    two tail shards), d = 128 fp16, global batches of 262,144 triples + a ragged one.  The tables (14 GB) are drawn ON the device;
+    the oracle runs on the rows the batches touch, compacted (the step is row-local: the same arithmetic as on the full tables),
+    in float64 as the reference and in fp32 as the yardstick, with the fp16 storage rounding after every batch; rows no batch
+    touches must keep their bits."""
+    from _thread_group import run_ranks
+    from sml_amd import dist as SD
+    monkeypatch.setenv("SML_COMM", "peer")
+    monkeypatch.setenv("SML_PEER_TIMEOUT_S", "60")
+    d, dtype, bce, head = 128, torch.float16, False, 24
+    B, U_rank, I = 131072, 25000000, 5000000
+    n = 2 * B + 777
+    lr = 0.01
+    g = torch.Generator(device=DEV).manual_seed(55)
+    wi = (torch.randn(I, d, device=DEV, generator=g) * 0.3).to(dtype)
+    wus = [(torch.randn(U_rank, d, device=DEV, generator=g, dtype=torch.float16) * 0.3).to(dtype) for _ in range(2)]
+    torch.manual_seed(56)
+    tris = []
+    for r in range(2):
+        u = torch.randint(0, U_rank, (n,)); u[:7] = 2
+        i = torch.randint(0, I, (n,)); j = torch.randint(0, I, (n,))
+        i[3] = j[3]; i[10:14] = 5; i[0:B:64] = 7                 # head rows hit from both ranks, one of them 2,048 times per batch
+        j[1:B:97] = I - 3                                        # a tail row of rank 1 with ~1,350 occurrences per batch
+        tris.append(torch.stack([u, i, j], 1))
+    # the rows the batches touch (compact index spaces for the oracle) and a sample of rows they do not
+    uidx = [torch.unique(t[:, 0]) for t in tris]
+    iidx = torch.unique(torch.cat([t[:, 1:].reshape(-1) for t in tris]))
+    orig_u = [wus[r][uidx[r].to(DEV)].float().cpu() for r in range(2)]
+    orig_i = wi[iidx.to(DEV)].float().cpu()
+    probe_u = torch.randint(0, U_rank, (4096,)); probe_i = torch.randint(0, I, (4096,))
+    probe_u = probe_u[~torch.isin(probe_u, uidx[0])]; probe_i = probe_i[~torch.isin(probe_i, iidx)]
+    keep_u, keep_i = wus[0][probe_u.to(DEV)].clone(), wi[probe_i.to(DEV)].clone()
+    H, S = SD.item_shard_layout(I, 2, head)
+    eng0 = engine(d, B)
+
+    def rank_fn(rank, group):
+        e = engine(d, B)
+        ctx = SD.attach(e, None, group, rows_cap=2 * B)
+        assert ctx.mode == "peer"
+        gu = wus[rank]                                           # (updated in place: 6.4 GB per rank)
+        w_head = wi[:H].clone()
+        shard = torch.zeros(S, d, dtype=dtype, device=DEV)
+        lo = H + rank * S
+        rows = max(0, min(I, lo + S) - lo)
+        shard[:rows] = wi[lo:lo + rows]
+        tri = tris[rank].to(DEV)
+        sh = ctx.bare_shard(e, tri, I, head, w_head, shard, 0 if bce else 1)
+        assert (sh["head_rows"], sh["shard_rows"]) == (H, S)
+        losses = e.bare_epoch_sharded(gu, tri, B, lr, 1e-3, 2e-3, sh, bce=bce)
+        torch.cuda.current_stream().synchronize()
+        assert e.peer_status() == 0
+        group.barrier()
+        return dict(l=losses.cpu().numpy(), head=w_head, shard=shard[:rows])
+
+    n_cu = eng0._n_cus()
+    r0, r1 = run_ranks(2, rank_fn, streams=[eng0._masked_stream(0, n_cu // 2), eng0._masked_stream(n_cu // 2, n_cu)])
+    assert torch.equal(r0["head"], r1["head"])
+    got_i_full = torch.cat([r0["head"], r0["shard"], r1["shard"]])
+    assert got_i_full.shape[0] == I
+    got_i = got_i_full[iidx.to(DEV)].float().cpu().numpy()
+    got_u = np.concatenate([wus[r][uidx[r].to(DEV)].float().cpu().numpy() for r in range(2)])
+    assert torch.equal(wus[0][probe_u.to(DEV)], keep_u) and torch.equal(got_i_full[probe_i.to(DEV)], keep_i), "an untouched row changed"
+    # compact triples: user index = position in [uidx[0] ; uidx[1]], item index = position in iidx
+    off1 = uidx[0].shape[0]
+
+    def compact(t, r):
+        return torch.stack([torch.searchsorted(uidx[r], t[:, 0]) + (off1 if r else 0), torch.searchsorted(iidx, t[:, 1]),
+                            torch.searchsorted(iidx, t[:, 2])], 1)
+    ct = [compact(tris[r], r) for r in range(2)]
+
+    def distance(x, ref):
+        x, ref = np.asarray(x, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+        return float(np.abs(x - ref).max() / max(np.abs(ref).max(), 1e-30))
+    runs = {}
+    for name, dt in (("f64", torch.float64), ("f32", torch.float32)):
+        ou, oi = torch.cat(orig_u).to(dt), orig_i.to(dt)
+        ls = []
+        for b0 in range(0, n, B):
+            t = torch.cat([ct[0][b0:b0 + B], ct[1][b0:b0 + B]])
+            ls.append(O.bare_step(ou, oi, t[:, 0], t[:, 1], t[:, 2], lr, 1e-3, 2e-3, bce=bce))
+            ou, oi = ou.half().to(dt), oi.half().to(dt)              # the tables are fp16: every batch ends in a rounding
+        runs[name] = (ls, ou.numpy(), oi.numpy())
+    ref_l, ref_u, ref_i = runs["f64"]
+    report = dict(err_user=distance(got_u, ref_u), err_item=distance(got_i, ref_i), fp32_oracle_user=distance(runs["f32"][1], ref_u),
+                  fp32_oracle_item=distance(runs["f32"][2], ref_i), losses=[float(x) for x in (r0["l"] + r1["l"])],
+                  losses_f64=[float(x) for x in ref_l], users_touched=int(got_u.shape[0]), items_touched=int(got_i.shape[0]))
+    _report("parity_config5_two_ranks_sharded.json", report)
+    np.testing.assert_allclose(r0["l"] + r1["l"], ref_l, rtol=2e-3)
+    assert report["err_user"] <= max(2e-3, 2 * report["fp32_oracle_user"]), report
+    assert report["err_item"] <= max(2e-3, 2 * report["fp32_oracle_item"]), report
+
+
 def _item_sharded_two_ranks(d, dtype, bce, head, big, monkeypatch):
     """The bare a3 step with the ITEM TABLE SHARDED over world_size 2 (thread ranks on the two CU-masked streams, one-shot
     peer exchange, same-process allocations handed over as raw pointers): the first `head` rows replicated (dense
