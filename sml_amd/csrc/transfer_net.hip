@@ -2470,6 +2470,7 @@ hipError_t sml_launch_fwd_bx3(int d, const SmlFwdArgs& a, const void* pkx_net, i
 }
 hipError_t sml_launch_mf_fwd_bx3(int d, const SmlFwdArgs& a, const void* pkx, int tiles, hipStream_t st) {
     if (d != 32) return hipErrorInvalidValue;
+    if (tiles <= 0) return hipSuccess;           // (several GPUs: a rank whose share of a global batch is empty still takes part in the step)
     k_mf_fwd_bx3<32><<<dim3(tiles), dim3(512), 0, st>>>(a, (const unsigned short*)pkx);
     return hipGetLastError();
 }

@@ -110,6 +110,11 @@ def run_ranks(world, fn, *args, streams=None):
                 out[rank] = fn(rank, group, *args)
         except BaseException as e:              # noqa: BLE001 -- reported by the caller; and free the peers
             err[rank] = e
+            if not group._barrier.broken:       # the FIRST failure is the cause; what follows is ranks finding the barrier broken
+                import sys
+                import traceback
+                sys.stderr.write("rank %d failed first:\n" % rank)
+                traceback.print_exc()
             group._barrier.abort()
 
     threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
