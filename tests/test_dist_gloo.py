@@ -175,8 +175,19 @@ def _driver_rank(rank, world, port, root, ck, ttype, out):
             dist.destroy_process_group()
 
 
+def test_driver_under_four_ranks_prints_the_single_process_run(tmp_path):
+    """The same with FOUR ranks (round 5: nothing had run the host logic -- routing by owner, per-rank batch counts, the job-wide
+    item lists, loss scaling, routed evaluation -- at a world size above two before the first 8-GPU job would): 75 users per rank,
+    many local batches empty."""
+    _driver_world_check(tmp_path, "conv_com", 4)
+
+
 @pytest.mark.parametrize("ttype", ["conv_com", "conv"])        # BCE (a mean over the split batch) and BPR (a sum)
 def test_driver_under_two_ranks_prints_the_single_process_run(tmp_path, ttype):
+    _driver_world_check(tmp_path, ttype, 2)
+
+
+def _driver_world_check(tmp_path, ttype, world):
     """`torchrun --nproc-per-node 2 main_yelp.py` in miniature: users row-sharded by owner (each rank keeps its rows
     only), every global batch split by owner -- unequal, sometimes empty local batches --, item-gradient exchange,
     theta all-reduce, routed evaluation.  The two ranks must print what one process prints: same lines, losses to
@@ -196,14 +207,15 @@ def test_driver_under_two_ranks_prints_the_single_process_run(tmp_path, ttype):
     torch.save(mf, ck)
     out = str(tmp_path)
     mp.spawn(_driver_rank, args=(1, 0, root, ck, ttype, out), nprocs=1, join=True)     # (own process: it patches the engine factory)
-    mp.spawn(_driver_rank, args=(2, _free_port(), root, ck, ttype, out), nprocs=2, join=True)
+    mp.spawn(_driver_rank, args=(world, _free_port(), root, ck, ttype, out), nprocs=world, join=True)
     one = torch.load(os.path.join(out, "w1_rank0.pt"), weights_only=False)
-    r0 = torch.load(os.path.join(out, "w2_rank0.pt"), weights_only=False)
-    r1 = torch.load(os.path.join(out, "w2_rank1.pt"), weights_only=False)
-    assert torch.equal(r0["wi"], r1["wi"])
-    for k in r0["theta"]:
-        assert torch.equal(r0["theta"][k], r1["theta"][k]), k
-    assert r0["wu"].shape[0] == 150 and r1["wu"].shape[0] == 150            # each rank holds its own user rows only
+    rs = [torch.load(os.path.join(out, "w%d_rank%d.pt" % (world, r)), weights_only=False) for r in range(world)]
+    r0, r1 = rs[0], rs[1]
+    for rr in rs[1:]:
+        assert torch.equal(r0["wi"], rr["wi"])
+        for k in r0["theta"]:
+            assert torch.equal(r0["theta"][k], rr["theta"][k]), k
+    assert all(rr["wu"].shape[0] == U // world for rr in rs)                # each rank holds its own user rows only
     num = re.compile(r"-?\d+\.\d+(?:e-?\d+)?")
     strip = lambda t: [re.sub(r"\s+", " ", l).replace("[ ", "[").replace(" ]", "]") for l in t.splitlines() if "time cost" not in l]
     a, b = strip(one["log"]), strip(r0["log"])
@@ -213,9 +225,10 @@ def test_driver_under_two_ranks_prints_the_single_process_run(tmp_path, ttype):
             x, y = float(x), float(y)
             tol = 2.0 / 160 + 1e-4 if ("recall" in la or "reacll" in la or "ndcg" in la) else 1e-4 * max(1.0, abs(x))
             assert abs(x - y) <= tol, (la, lb)
-    np.testing.assert_allclose(torch.cat([r0["wu"], r1["wu"]]).numpy(), one["wu"].numpy(), rtol=5e-3, atol=5e-4)
+    np.testing.assert_allclose(torch.cat([rr["wu"] for rr in rs]).numpy(), one["wu"].numpy(), rtol=5e-3, atol=5e-4)
     np.testing.assert_allclose(r0["wi"].numpy(), one["wi"].numpy(), rtol=5e-3, atol=5e-4)
-    assert strip(r1["log"]) == strip(r0["log"])      # every rank holds the job's numbers (cli.main silences all but rank 0)
+    for rr in rs[1:]:
+        assert strip(rr["log"]) == strip(r0["log"])  # every rank holds the job's numbers (cli.main silences all but rank 0)
 
 
 def test_item_shard_layout_routes_every_row_to_exactly_one_place():
