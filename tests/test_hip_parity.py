@@ -2024,7 +2024,75 @@ def test_two_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run(monkey
         adam_close(r0["theta"][k].numpy(), theta1[k].numpy(), 1e-3, steps, frac=0.999 if shape == "small" else 0.995)
 
 
-def test_two_processes_on_one_gpu_exchange_through_hipipc_mappings(tmp_path):
+@pytest.mark.parametrize("mode", ["torch", "peer"])
+def test_four_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run(monkeypatch, mode):
+    """World size FOUR (round 5: until now nothing had run the exchange at a world size above two): four thread ranks, 50 users each,
+    every global batch split four ways (several shares empty), MF stage + TR stage against ONE engine on the global batches;
+    replicas bit-identical across the four ranks.  torch: the hook path (host rendezvous).  peer: the one-shot exchange -- four
+    inboxes, four slots per parity, rank-order sums over four sources --, the ranks on four CU-masked streams of 64 CUs."""
+    from _thread_group import run_ranks
+    from sml_amd import dist as SD
+    monkeypatch.setenv("SML_PEER_TIMEOUT_S", "20")
+    monkeypatch.setenv("SML_COMM", mode)
+    W = 4
+    torch.manual_seed(5)
+    U, I, d, B, n = 200, 120, 32, 64, 300
+    wu, wi = torch.randn(U, d) * 0.3, torch.randn(I, d) * 0.3
+    u = torch.randint(0, U, (n,)); u[:9] = 3
+    u[2 * B:3 * B] = torch.randint(0, U // 4, (B,))         # batch 2: every user belongs to rank 0 -> the other ranks' shares are empty
+    tri = torch.stack([u, torch.randint(0, I, (n,)), torch.randint(0, I, (n,))], 1)
+    net0 = make_transfer(d, device=DEV)
+    sd = {k: v.detach().cpu().clone() for k, v in net0.state_dict().items()}
+    lu, li = wu * 0.9, wi * 0.9
+    eng = engine(d, B)
+    mf = make_mf(U, I, d, wu.numpy(), wi.numpy(), device=DEV)
+    l_mf = eng.mf_stage_epoch(mf, net0, lu.to(DEV), li.to(DEV), tri, B, 0.01, 1e-6).cpu().numpy()
+    eng.mf_flush(mf)
+    hu, hi = mf.user_laten.weight.detach().clone(), mf.item_laten.weight.detach().clone()
+    l_tr = eng.tr_stage_epoch(net0, lu.to(DEV), li.to(DEV), hu, hi, tri, B, 1e-3, 1e-4).cpu().numpy()
+    theta1 = {k: v.detach().cpu().clone() for k, v in net0.state_dict().items()}
+
+    def rank_fn(rank, group):
+        e = engine(d, B)
+        ctx = SD.attach(e, None, group, rows_cap=2 * B)
+        assert ctx.mode == mode
+        lo, hi_ = SD.user_range(U, W, rank)
+        m = make_mf(hi_ - lo, I, d, wu[lo:hi_].numpy(), wi.numpy(), device=DEV)
+        net = make_transfer(d, device=DEV)
+        net.load_state_dict(sd)
+        route = ctx.route_epoch(tri.numpy(), B, U, mean_loss=True)
+        assert route.counts.sum() == n and (rank == 0 or route.counts[rank, 2] == 0)
+        a = e.mf_stage_epoch(m, net, lu[lo:hi_].to(DEV), li.to(DEV), route.local_tri, route.cap, 0.01, 1e-6,
+                             plan=route.plan, exchange=route.exchange(d))
+        e.mf_flush(m)
+        hu_, hi2 = m.user_laten.weight.detach().clone(), m.item_laten.weight.detach().clone()
+        torch.cuda.current_stream().synchronize()
+        assert mode != "peer" or e.peer_status() == 0, "a consumer of the MF stage's row exchange timed out"
+        b = e.tr_stage_epoch(net, lu[lo:hi_].to(DEV), li.to(DEV), hu_, hi2, route.local_tri, route.cap, 1e-3, 1e-4, plan=route.plan)
+        torch.cuda.current_stream().synchronize()
+        assert mode != "peer" or e.peer_status() == 0, "a consumer of the TR stage's theta exchange timed out"
+        return dict(l_mf=a.cpu().numpy(), l_tr=b.cpu().numpy(), wu=hu_.cpu(), wi=hi2.cpu(),
+                    theta={k: v.detach().cpu().clone() for k, v in net.state_dict().items()})
+
+    streams = None
+    if mode == "peer":
+        n_cu = eng._n_cus()
+        streams = [eng._masked_stream(q * n_cu // W, (q + 1) * n_cu // W) for q in range(W)]
+    rs = run_ranks(W, rank_fn, streams=streams)
+    for rr in rs[1:]:
+        assert torch.equal(rs[0]["wi"], rr["wi"])
+        for k in rs[0]["theta"]:
+            assert torch.equal(rs[0]["theta"][k], rr["theta"][k]), k
+    np.testing.assert_allclose(sum(rr["l_mf"] for rr in rs), l_mf, rtol=1e-4)
+    np.testing.assert_allclose(sum(rr["l_tr"] for rr in rs), l_tr, rtol=1e-4)
+    adam_close(torch.cat([rr["wu"] for rr in rs]).numpy(), hu.cpu().numpy(), 0.01, 5)
+    adam_close(rs[0]["wi"].numpy(), hi.cpu().numpy(), 0.01, 5)
+    for k in theta1:
+        adam_close(rs[0]["theta"][k].numpy(), theta1[k].numpy(), 1e-3, 5)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_two_processes_on_one_gpu_exchange_through_hipipc_mappings(tmp_path, world):
     """The one-shot peer exchange across PROCESS boundaries: two rank processes (tests/_peer_ipc_child.py) share this GPU,
     export their uncached inbox / flags regions with hipIpcGetMemHandle, open each other's with hipIpcOpenMemHandle
     (sml_peer_export / sml_peer_open; gloo carries the handles), run the start-up self-check, a whole-slot all-reduce and
@@ -2050,8 +2118,10 @@ def test_two_processes_on_one_gpu_exchange_through_hipipc_mappings(tmp_path):
     s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_peer_ipc_child.py")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SML_COMM="peer")
-    procs = [subprocess.Popen([sys.executable, child, str(r), "2", str(port), str(tmp_path)], env=env,
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    # (world = 4, round 5: the first execution of the exchange's device code -- slots, counters, rank-order sums, the job-wide item
+    # lists -- at a world size above two; 50 users per rank, several local batches empty)
+    procs = [subprocess.Popen([sys.executable, child, str(r), str(world), str(port), str(tmp_path)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     for p_ in procs:
         try:
@@ -2061,14 +2131,16 @@ def test_two_processes_on_one_gpu_exchange_through_hipipc_mappings(tmp_path):
             out, _ = p_.communicate()
         outs.append(out)
     assert all(p_.returncode == 0 for p_ in procs), "\n----\n".join(o[-3000:] for o in outs)
-    r0, r1 = (torch.load(str(tmp_path / ("rank%d.pt" % r)), weights_only=False) for r in range(2))
-    assert r0["timeouts"] == 0 and r1["timeouts"] == 0
-    assert torch.equal(r0["wi"], r1["wi"])
-    for k in r0["theta"]:
-        assert torch.equal(r0["theta"][k], r1["theta"][k]), k
-    np.testing.assert_allclose(r0["l_mf"] + r1["l_mf"], l_mf, rtol=1e-4)
-    np.testing.assert_allclose(r0["l_tr"] + r1["l_tr"], l_tr, rtol=1e-4)
-    adam_close(torch.cat([r0["wu"], r1["wu"]]).numpy(), hu.cpu().numpy(), 0.01, 5)
+    rs = [torch.load(str(tmp_path / ("rank%d.pt" % r)), weights_only=False) for r in range(world)]
+    r0 = rs[0]
+    assert all(rr["timeouts"] == 0 for rr in rs)
+    for rr in rs[1:]:
+        assert torch.equal(r0["wi"], rr["wi"])
+        for k in r0["theta"]:
+            assert torch.equal(r0["theta"][k], rr["theta"][k]), k
+    np.testing.assert_allclose(sum(rr["l_mf"] for rr in rs), l_mf, rtol=1e-4)
+    np.testing.assert_allclose(sum(rr["l_tr"] for rr in rs), l_tr, rtol=1e-4)
+    adam_close(torch.cat([rr["wu"] for rr in rs]).numpy(), hu.cpu().numpy(), 0.01, 5)
     adam_close(r0["wi"].numpy(), hi.cpu().numpy(), 0.01, 5)
     for k in theta1:
         adam_close(r0["theta"][k].numpy(), theta1[k].numpy(), 1e-3, 5)
