@@ -2024,9 +2024,10 @@ def test_two_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run(monkey
         adam_close(r0["theta"][k].numpy(), theta1[k].numpy(), 1e-3, steps, frac=0.999 if shape == "small" else 0.995)
 
 
+@pytest.mark.parametrize("W", [4, 8])
 @pytest.mark.parametrize("mode", ["torch", "peer"])
-def test_four_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run(monkeypatch, mode):
-    """World size FOUR (round 5: until now nothing had run the exchange at a world size above two): four thread ranks, 50 users each,
+def test_four_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run(monkeypatch, mode, W):
+    """World sizes FOUR and EIGHT (round 5: until now nothing had run the exchange at a world size above two): W thread ranks, 200 / W users each,
     every global batch split four ways (several shares empty), MF stage + TR stage against ONE engine on the global batches;
     replicas bit-identical across the four ranks.  torch: the hook path (host rendezvous).  peer: the one-shot exchange -- four
     inboxes, four slots per parity, rank-order sums over four sources --, the ranks on four CU-masked streams of 64 CUs."""
@@ -2034,12 +2035,11 @@ def test_four_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run(monke
     from sml_amd import dist as SD
     monkeypatch.setenv("SML_PEER_TIMEOUT_S", "20")
     monkeypatch.setenv("SML_COMM", mode)
-    W = 4
     torch.manual_seed(5)
     U, I, d, B, n = 200, 120, 32, 64, 300
     wu, wi = torch.randn(U, d) * 0.3, torch.randn(I, d) * 0.3
     u = torch.randint(0, U, (n,)); u[:9] = 3
-    u[2 * B:3 * B] = torch.randint(0, U // 4, (B,))         # batch 2: every user belongs to rank 0 -> the other ranks' shares are empty
+    u[2 * B:3 * B] = torch.randint(0, U // W, (B,))         # batch 2: every user belongs to rank 0 -> the other ranks' shares are empty
     tri = torch.stack([u, torch.randint(0, I, (n,)), torch.randint(0, I, (n,))], 1)
     net0 = make_transfer(d, device=DEV)
     sd = {k: v.detach().cpu().clone() for k, v in net0.state_dict().items()}
