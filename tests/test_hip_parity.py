@@ -2429,6 +2429,78 @@ def test_bare_step_item_sharded_two_ranks_at_the_config_5_shape(monkeypatch):
     assert report["err_item"] <= max(2e-3, 2 * report["fp32_oracle_item"]), report
 
 
+@pytest.mark.parametrize("W,d,dtype,bce,head", [(4, 32, torch.float32, True, 16), (8, 64, torch.float32, False, 0), (8, 128, torch.float16, False, 24),
+                                                (4, 64, torch.float32, True, 400)])
+def test_bare_step_item_sharded_four_and_eight_ranks_on_one_gpu(W, d, dtype, bce, head, monkeypatch):
+    """The item-sharded bare step at world sizes FOUR and EIGHT (round 5; thread ranks on W CU-masked streams): W user shards, the item
+    tail in W shards (owner-computes: tail rows read from their owners, gradient rows stored into the owners' inboxes, a done-counter
+    round per batch), the head replicated (dense one-shot all-reduce over W slots) -- against the oracle's synchronous step over the
+    GLOBAL batches [rank 0's ; rank 1's ; ...], head replicas bit-identical on all ranks."""
+    from _thread_group import run_ranks
+    from sml_amd import dist as SD
+    monkeypatch.setenv("SML_COMM", "peer")
+    monkeypatch.setenv("SML_PEER_TIMEOUT_S", "20")
+    B, U_rank, I = 96, 150, 520
+    n = 96 * 3 - 11
+    torch.manual_seed(7 * W + d)
+    wi = (torch.randn(I, d) * 0.3).to(dtype)
+    wus = [(torch.randn(U_rank, d) * 0.3).to(dtype) for _ in range(W)]
+    tris = []
+    for r in range(W):
+        u = torch.randint(0, U_rank, (n,)); u[:7] = 2
+        i = torch.randint(0, I, (n,)); j = torch.randint(0, I, (n,))
+        i[3] = j[3]
+        i[10:14] = 5                       # an item hit from every rank inside one batch (a head row, or a tail row of rank 0)
+        j[20:23] = I - 2                   # a tail row of the last owner, hit from every rank
+        tris.append(torch.stack([u, i, j], 1))
+    lr = 0.05 if bce else 0.01
+    H, S = SD.item_shard_layout(I, W, head)
+    eng0 = engine(d, B)
+
+    def rank_fn(rank, group):
+        e = engine(d, B)
+        ctx = SD.attach(e, None, group, rows_cap=2 * B)
+        assert ctx.mode == "peer"
+        gu = wus[rank].clone().to(DEV)
+        w_head = wi[:H].clone().to(DEV)
+        shard = torch.zeros(S, d, dtype=dtype, device=DEV)
+        lo = H + rank * S
+        rows = max(0, min(I, lo + S) - lo)
+        if rows:
+            shard[:rows] = wi[lo:lo + rows].to(DEV)
+        tri = tris[rank].to(DEV)
+        sh = ctx.bare_shard(e, tri, I, head, w_head, shard, 0 if bce else 1)
+        assert (sh["head_rows"], sh["shard_rows"]) == (H, S)
+        losses = e.bare_epoch_sharded(gu, tri, B, lr, 1e-3, 2e-3, sh, bce=bce)
+        torch.cuda.current_stream().synchronize()
+        assert e.peer_status() == 0
+        group.barrier()                       # (nobody frees a shard another rank may still be reading)
+        return dict(l=losses.cpu().numpy(), wu=gu.float().cpu(), head=w_head.cpu(), shard=shard[:rows].cpu())
+
+    n_cu = eng0._n_cus()
+    rs = run_ranks(W, rank_fn, streams=[eng0._masked_stream(q * n_cu // W, (q + 1) * n_cu // W) for q in range(W)])
+    for rr in rs[1:]:
+        assert torch.equal(rs[0]["head"], rr["head"])
+    got_i = torch.cat([rs[0]["head"]] + [rr["shard"] for rr in rs]).float()
+    assert got_i.shape[0] == I
+    ou, oi = torch.cat(wus).float().clone(), wi.float().clone()
+    want = []
+    for b0 in range(0, n, B):
+        parts = []
+        for r in range(W):
+            t = tris[r][b0:b0 + B].clone()
+            t[:, 0] += r * U_rank
+            parts.append(t)
+        t = torch.cat(parts)
+        want.append(O.bare_step(ou, oi, t[:, 0], t[:, 1], t[:, 2], lr, 1e-3, 2e-3, bce=bce))
+        if dtype == torch.float16:
+            ou, oi = ou.half().float(), oi.half().float()
+    tol = 1e-4 if dtype == torch.float32 else 2e-3
+    np.testing.assert_allclose(sum(rr["l"] for rr in rs), want, rtol=tol)
+    close(torch.cat([rr["wu"] for rr in rs]).numpy(), ou.numpy(), tol)
+    close(got_i.numpy(), oi.numpy(), tol)
+
+
 def _item_sharded_two_ranks(d, dtype, bce, head, big, monkeypatch):
     """The bare a3 step with the ITEM TABLE SHARDED over world_size 2 (thread ranks on the two CU-masked streams, one-shot
     peer exchange, same-process allocations handed over as raw pointers): the first `head` rows replicated (dense
