@@ -2119,9 +2119,10 @@ def test_two_processes_on_one_gpu_exchange_through_hipipc_mappings(tmp_path, wor
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_peer_ipc_child.py")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SML_COMM="peer")
     # (world = 3, round 5: the hipIpc set-up and the exchange between PROCESSES at a world size above two, with shards of unequal
-    # size (67 / 67 / 66 users).  FOUR processes sharing this one GPU do not get through the start-up self-check -- its pollers and
-    # pushers time out: the device does not keep four processes' kernels resident side by side -- while four THREAD ranks of one
-    # process do: test_four_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run)
+    # size (67 / 67 / 66 users).  FOUR processes sharing this one GPU are time-sliced by the device: too slow for this test's 20 s
+    # hang guards (bench.py --gpus 4 --one-device completes on the peer carrier, replicas identical, at 77 s per period:
+    # profiles/r05z_bench_4ranks_one_device.json); four and eight THREAD ranks of one process are
+    # test_four_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run)
     procs = [subprocess.Popen([sys.executable, child, str(r), str(world), str(port), str(tmp_path)], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
