@@ -2091,6 +2091,62 @@ def test_four_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run(monke
         adam_close(rs[0]["theta"][k].numpy(), theta1[k].numpy(), 1e-3, 5)
 
 
+def test_main_yelp_with_two_rank_processes_prints_the_single_process_log(tmp_path, monkeypatch):
+    """The real program end to end under two rank PROCESSES on this one GPU (round 5): `SML_ONE_DEVICE=1 python main_yelp.py --gpus 2 ...`
+    -- the launcher, the hipIpc peer exchange, the owner-split global batches, routed evaluation, the deferred output, the period
+    prefetch and the drawn-ahead transfer passes on every rank -- over G7's 29-stage dataset (multi_num 2): the job prints what
+    `python main_yelp.py ...` prints in one process on the same GPU: the same lines, the first periods' numbers to 1e-3 (two ranks
+    sum in another order; the sequence is free-running), every recall / ndcg within three rank flips of the 160-row test sets."""
+    import re
+    import subprocess
+    import sys
+    from sml_amd import cli, synth
+    from sml_amd.mf import MFbasemode
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    z = golden("g7_end_to_end.npz")
+    P, n_inter, U, I, neg, seed = [int(v) for v in z["dataset"]]
+    root = str(tmp_path) + "/"
+    synth.write_dataset(root, "yelp", n_periods=P, n_inter=n_inter, n_user=U, n_item=I, neg=neg,
+                        a_user=float(z["dataset_zipf"][0]), a_item=float(z["dataset_zipf"][1]), seed=seed)
+    mf = MFbasemode(U, I, 32)
+    mf.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("mf.")})
+    ck = os.path.join(root, "BCE_init.pkl")
+    torch.save(mf, ck)
+    argv = ["--data_path", root, "--pre_model", ck] + [str(a) for a in z["argv"]] + ["--multi_num", "2"]
+    with quiet() as buf:
+        cli.main("yelp", argv)
+    one = buf.getvalue()
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SML_LAUNCHED", "SML_COMM")}
+    env.update(SML_ONE_DEVICE="1", SML_PEER_TIMEOUT_S="60")
+    p = subprocess.run([sys.executable, os.path.join(repo, "main_yelp.py"), "--gpus", "2"] + argv, env=env, cwd=repo,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    two = p.stdout
+    num = re.compile(r"-?\d+\.\d+(?:e-?\d+)?")
+    strip = lambda t: [re.sub(r"\s+", " ", l).replace("[ ", "[").replace(" ]", "]") for l in t.splitlines()
+                       if "time cost" not in l and "Namespace(" not in l and not l.startswith("[Gloo]") and l.strip()]
+    a, b = strip(one), strip(two)
+    sa, sb = [num.sub("#", l) for l in a], [num.sub("#", l) for l in b]
+    if sa != sb:
+        k = next((i for i, (x, y) in enumerate(zip(sa, sb)) if x != y), min(len(sa), len(sb)))
+        raise AssertionError("the two-rank job prints other lines: first difference at line %d of %d / %d:\n one: %r\n two: %r"
+                             % (k, len(sa), len(sb), a[k] if k < len(a) else None, b[k] if k < len(b) else None))
+    gaps = []            # (line, kind, |difference|)
+    for k, (la, lb) in enumerate(zip(a, b)):
+        metric = "recall" in la or "reacll" in la or "ndcg" in la
+        for x, y in zip(num.findall(la), num.findall(lb)):
+            gaps.append((k, "metric" if metric else "loss", abs(float(x) - float(y)) / (1.0 if metric else max(1.0, abs(float(x))))))
+    worst = lambda kind, lo, hi: max([g for k, kd, g in gaps if kd == kind and lo <= k < hi] or [0.0])
+    n_lines = len(a)
+    report = dict(lines=n_lines, metric_gap_first_60_lines=worst("metric", 0, 60), loss_gap_first_60_lines=worst("loss", 0, 60),
+                  metric_gap_first_half=worst("metric", 0, n_lines // 2), metric_gap_all=worst("metric", 0, n_lines),
+                  loss_gap_all=worst("loss", 0, n_lines))
+    _report("parity_main_yelp_two_rank_processes.json", report)
+    assert report["loss_gap_first_60_lines"] <= 1e-3 and report["metric_gap_first_60_lines"] <= 2.0 / 160 + 1e-4, report
+    assert report["metric_gap_all"] <= 8.0 / 160 + 1e-4, report          # (29 free-running stages of 160-row test sets)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_two_processes_on_one_gpu_exchange_through_hipipc_mappings(tmp_path, world):
     """The one-shot peer exchange across PROCESS boundaries: two rank processes (tests/_peer_ipc_child.py) share this GPU,
