@@ -2091,7 +2091,7 @@ def test_four_ranks_on_one_gpu_mf_and_tr_stage_equal_the_single_engine_run(monke
         adam_close(rs[0]["theta"][k].numpy(), theta1[k].numpy(), 1e-3, 5)
 
 
-@pytest.mark.parametrize("gpus", [2, 4])
+@pytest.mark.parametrize("gpus", [2, 4, 8])
 def test_main_yelp_with_two_rank_processes_prints_the_single_process_log(tmp_path, monkeypatch, gpus):
     """The real program end to end under two (and four) rank PROCESSES on this one GPU (round 5): `SML_ONE_DEVICE=1 python main_yelp.py --gpus N ...`
     -- the launcher, the hipIpc peer exchange, the owner-split global batches, routed evaluation, the deferred output, the period
