@@ -676,6 +676,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if launch.one_device():             # (test mode on a 1-GPU box, also under torchrun: SML_ONE_DEVICE=1 -- every rank on device 0)
+        local = 0
     if world != a.gpus:
         raise SystemExit("bench.py --gpus %d inside a job of WORLD_SIZE %d" % (a.gpus, world))
     torch.cuda.set_device(local)

@@ -2295,6 +2295,33 @@ def test_bench_gpus_2_starts_its_own_ranks_and_prints_one_valid_line():
     assert st["global_batches"] == [1024, 256]
 
 
+@pytest.mark.parametrize("n", [2, 4])
+def test_bench_under_torchrun_as_the_driver_launches_it(n):
+    """The contract's launch form -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` -- on this one-GPU box (SML_ONE_DEVICE=1: every rank on device 0, gloo
+    under torch.distributed): the ranks torchrun started take RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment, do not
+    start ranks of their own, run the period workload over the peer exchange, and rank 0 prints the ONE line."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SML_LAUNCHED", "SML_COMM")}
+    env.update(SML_ONE_DEVICE="1", SML_PEER_TIMEOUT_S="60")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "1", "--no-cpu", "--no-a3",
+           "--users", "6000", "--items", "12300", "--inter", "7500", "--neg", "99", "--multi_num", "2"]
+    p = subprocess.run(cmd, env=env, cwd=repo, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == n and out["scaling"] == "weak" and out["value"] > 0
+    cfg = out["config"]
+    assert cfg["carrier"] == "peer" and cfg["peer_timeouts"] == 0 and cfg["replicas_bit_identical"] is True
+
+
 def test_bench_bare_gpus_2_runs_the_item_sharded_step():
     """`python bench.py --workload bare --gpus 2`: the N > 1 bare path is the ITEM-SHARDED step (replicated head + owner-computes
     tail over the peer exchange), after the start-up shard-visibility check; the replicated all-gather form stays reachable as a
