@@ -2103,6 +2103,10 @@ def test_main_yelp_with_two_rank_processes_prints_the_single_process_log(tmp_pat
     import sys
     from sml_amd import cli, synth
     from sml_amd.mf import MFbasemode
+    if gpus == 8 and os.environ.get("SML_TEST_EIGHT_PROCESSES") != "1":
+        # (eight processes time-sliced on one device: 1-4 minutes; run by hand -- SML_TEST_EIGHT_PROCESSES=1 -- its report is committed
+        # as profiles/r05zz_parity_main_yelp_8_rank_processes.json)
+        pytest.skip("eight rank processes on one GPU take minutes: SML_TEST_EIGHT_PROCESSES=1 runs it")
     monkeypatch.setenv("LOCAL_RANK", "0")
     z = golden("g7_end_to_end.npz")
     P, n_inter, U, I, neg, seed = [int(v) for v in z["dataset"]]
