@@ -160,6 +160,7 @@ struct IndexSet {
     Buf<uint8_t> uniq;
     Buf<uint32_t> slot_info;           // records mode, by hand: per slot, "once" or the position of its run's record (SmlFusedUpdate)
     int64_t slot_stride = 0;           // ... slots per batch; 0: this set has none
+    int64_t dense_stride = 0;          // distinct-row records per batch (whole tiles of both lists)
     // MF stage, distinct-row form (SmlDense): records by scratch row, distinct rows per (batch, table), per-tile headers / entry blocks / spill
     Buf<SmlRun> dense_rec; Buf<int> dense_n; Buf<SmlTileHdr> tile_hdr; Buf<uint2> tile_ent, tile_spill; Buf<int> spill_cnt;
     bool dense = false; int tiles_cap = 0;
@@ -445,7 +446,7 @@ int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
                const sml_bare_shard* sh = nullptr, int64_t rows_cap = 0, bool want_dense = false, const uint32_t* x_vals = nullptr) {
     const int64_t nb = plan ? plan->n_batches : (n + batch - 1) / batch;
     { const int vrc = sort_order_check(c); if (vrc) return vrc; }
-    c->by_hand = true; c->slot_stride = 0; c->dense = false;
+    c->by_hand = true; c->slot_stride = 0; c->dense_stride = 0; c->dense = false;
     if (n == 0) { c->n = 0; c->batch = batch; c->triples = tri; return SML_OK; }
     const int W = mode == 1 ? bx->world : (mode == 2 ? sh->world : 1);
     const int nis = mode == 4 ? 1 : 2 * W;                  // item streams per tile (mode 4: one stream of explicit occurrences)
@@ -501,11 +502,13 @@ int prep_epoch(IndexSet* c, const int64_t* tri, int64_t n, int batch, int pad_ti
             // distinct-row form: both lists must be ONE bucket each (the numbering is the bucket's), i.e. 2 * batch <= SML_PREP_SMALL
             if (want_dense && pad_tiles && 2 * (int64_t)batch <= SML_PREP_SMALL) {
                 c->tiles_cap = wg_tiles(batch, 1) + wg_tiles(2 * batch, 1);
-                HIPCHK(c->dense_rec.ensure((size_t)nb * c->slot_stride)); HIPCHK(c->dense_n.ensure((size_t)2 * nb));
+                // records are addressed by SCRATCH ROW, which reaches the end of a list's last tile: whole tiles per list
+                c->dense_stride = ioff_max + (int64_t)SML_TM * wg_tiles(2 * batch, 1);
+                HIPCHK(c->dense_rec.ensure((size_t)nb * c->dense_stride)); HIPCHK(c->dense_n.ensure((size_t)2 * nb));
                 HIPCHK(c->tile_hdr.ensure((size_t)nb * c->tiles_cap)); HIPCHK(c->tile_ent.ensure((size_t)nb * c->tiles_cap * SML_TILE_ENT));
                 HIPCHK(c->tile_spill.ensure((size_t)nb * 3 * batch)); HIPCHK(c->spill_cnt.ensure((size_t)nb));
                 HIPCHK(hipMemsetAsync(c->spill_cnt.p, 0, (size_t)nb * sizeof(int), st));
-                a.dense = 1; a.dense_rec = c->dense_rec.p; a.dense_n = c->dense_n.p; a.tile_hdr = c->tile_hdr.p; a.tile_ent = c->tile_ent.p;
+                a.dense = 1; a.dense_rec = c->dense_rec.p; a.dense_stride = c->dense_stride; a.dense_n = c->dense_n.p; a.tile_hdr = c->tile_hdr.p; a.tile_ent = c->tile_ent.p;
                 a.tile_spill = c->tile_spill.p; a.spill_cnt = c->spill_cnt.p; a.tiles_cap = c->tiles_cap;
             }
         }
@@ -866,7 +869,7 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
             sg.mrep = ctx->mrep.p + slot0 * d; sg.vrep = ctx->vrep.p + slot0 * d;
             if (dense) {        // scratch row k = distinct row k of this list (every tile's rows named by its header)
                 sg.n_rows = SML_TM * wg_tiles(sg.n_rows, 1);          // (whole tiles: a live row may sit past the batch's ragged end)
-                sg.drec = ctx->ix[0].dense_rec.p + b * ctx->ix[0].slot_stride + slot0;
+                sg.drec = ctx->ix[0].dense_rec.p + b * ctx->ix[0].dense_stride + slot0;
                 sg.hdr = ctx->ix[0].tile_hdr.p + b * ctx->ix[0].tiles_cap + (s ? wg_tiles(B, 1) : 0);
             }
         }
@@ -895,7 +898,7 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
             w.dn.hdr = ctx->ix[0].tile_hdr.p + b * ctx->ix[0].tiles_cap;
             w.dn.ent = ctx->ix[0].tile_ent.p + b * ctx->ix[0].tiles_cap * SML_TILE_ENT;
             w.dn.spill = ctx->ix[0].tile_spill.p + b * 3 * batch;
-            w.dn.drec = ctx->ix[0].dense_rec.p + b * ctx->ix[0].slot_stride;
+            w.dn.drec = ctx->ix[0].dense_rec.p + b * ctx->ix[0].dense_stride;
         }
         if (fused || dense) {
             SmlFusedUpdate& fu = w.fu;

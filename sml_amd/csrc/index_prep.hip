@@ -515,7 +515,7 @@ __device__ __forceinline__ uint32_t emit_bucket(const SmlPrepArgs& a, const SmlP
         __syncthreads();
         const uint32_t ntiles = (nd + 15u) >> 4;
         const BatchGeo g = batch_geo(a, b);
-        const int64_t sbase = (int64_t)b * a.slot_stride;
+        const int64_t sbase = (int64_t)b * a.dense_stride;
         SmlRun* drec = a.dense_rec + sbase + (T ? (int64_t)g.ioff : 0);
         if (tid == 0) a.dense_n[2 * b + T] = (int)nd;
 #pragma unroll 1
@@ -1285,7 +1285,7 @@ __global__ __launch_bounds__(256) void k_mf_tiles(SmlPrepArgs a) {
         if (tid < 3) reinterpret_cast<uint4*>(hdr)[tid] = make_uint4(0u, 0u, 0u, 0u);
         return;
     }
-    const int64_t sbase = (int64_t)b * a.slot_stride;
+    const int64_t sbase = (int64_t)b * a.dense_stride;
     const SmlRun* drec = a.dense_rec + sbase + (T ? (int64_t)g.ioff : 0) + t * 16;
     if (tid < 64) {                                                  // (wavefront 0: the 16 records in one round trip, prefix by shuffles)
         uint32_t len = 0, pos = 0;

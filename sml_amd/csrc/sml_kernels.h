@@ -307,9 +307,11 @@ struct SmlPrepArgs {
     uint32_t* slot_info; int64_t slot_stride;
     // records mode, both lists one bucket (the MF stage's batches): distinct-row numbering instead of the per-position records
     // (SmlDense).  slot_info then holds, per slot, the scratch row of its table row (inside its run); dense_rec the records by
-    // scratch row ([nb][slot_stride]: users at 0, items at the batch's ioff); dense_n [nb][2] the distinct rows per list;
+    // scratch row ([nb][dense_stride], dense_stride = whole tiles of both lists: distinct row k sits at scratch row
+    // (k % ntiles) * 16 + k / ntiles, i.e. anywhere below ntiles * 16 -- past 2 * batch when batch % 8 != 0; users at 0, items at
+    // the batch's ioff); dense_n [nb][2] the distinct rows per list;
     // k_mf_tiles writes tile_hdr [nb][tiles_cap], tile_ent [nb][tiles_cap][SML_TILE_ENT], spill [nb][3 * batch] / spill_cnt [nb]
-    int dense; SmlRun* dense_rec; int* dense_n;
+    int dense; SmlRun* dense_rec; int* dense_n; int64_t dense_stride;
     SmlTileHdr* tile_hdr; uint2* tile_ent; uint2* tile_spill; int* spill_cnt; int tiles_cap;
     uint32_t* hot_list; int* hot_count; int hot_cap; int* max_len;
     uint32_t* medium; int* n_medium;                  // same pairs: buckets k_prep_wave leaves to k_prep_bucket

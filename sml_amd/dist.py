@@ -135,7 +135,8 @@ class EpochRoute(object):
 
     def exchange(self, d):
         """Exchange descriptor of the MF stage (engine.mf_stage_epoch(exchange=...)): the job's global item-occurrence
-        list -- for batch b every rank's 2*B_{q,b} occurrences sorted (stably) by (b << 32 | item row), value = slot
+        list -- for batch b every rank's 2*B_{q,b} occurrences, keyed (b << 32 | item row), batch-major and UNSORTED inside a
+        batch (index_prep.hip builds every batch's run list on the device: `unsorted=True` -> sml_mf_exchange.lists_unsorted), value = slot
         in the gathered buffer [world][2*cap][d]: rank q's positives at q*2*cap + t, negatives at q*2*cap + B_{q,b}
         + t -- derived locally, plus the scratch and the gather hook."""
         ctx = self.ctx
@@ -636,25 +637,32 @@ def shard_visibility_check(engine, dist, group=None, rounds=3, n=4096):
             dist.barrier(group=group)                                  # everybody has read round k before it is overwritten
         return _vote(dist, group, dev, state["ok"])
 
-    # Every path out of body() ends with a VOTE all ranks took part in (collectives stay aligned); what this rank mapped or
-    # allocated is released here on every one of them -- mappings closed, then a barrier (no rank frees a probe somebody
-    # still has mapped), then the probe (a dedicated peer allocation, not a pooled torch tensor) -- as _PeerSetup.release
-    # does.  (the early returns leaked both for the rest of the process.)
-    ok = False
-    try:
-        ok = body()
-    finally:
+    # Every path out of body() that RETURNS ends with a vote all ranks took part in (collectives stay aligned); what this rank
+    # mapped or allocated is then released -- mappings closed, then a barrier (no rank frees a probe somebody still has
+    # mapped), then the probe (a dedicated peer allocation, not a pooled torch tensor) -- as _PeerSetup.release does (ADVICE
+    # r4: the early returns leaked both).  An EXCEPTION out of body() (peer_read / copy_ failing on this rank only) is not a
+    # collective exit: this rank closes its own mappings, takes part in NO barrier (it would pair with the peers' in-loop
+    # barrier, or block where nobody else arrives) and does not free the probe its peers may still read; it re-raises, the
+    # process ends with an error and the launcher tears the job down.
+    def close_mappings():
         for a in opened:
             try:
                 engine.peer_close(a)
             except Exception:      # noqa: BLE001
                 pass
-        dist.barrier(group=group)
-        if probe is not None:
-            try:
-                engine.peer_tensor_free(probe)
-            except Exception:      # noqa: BLE001
-                pass
+
+    try:
+        ok = body()
+    except BaseException:
+        close_mappings()
+        raise
+    close_mappings()
+    dist.barrier(group=group)
+    if probe is not None:
+        try:
+            engine.peer_tensor_free(probe)
+        except Exception:      # noqa: BLE001
+            pass
     return ok
 
 

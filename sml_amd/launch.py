@@ -71,7 +71,9 @@ def backend():
 
 def visible_gpus():
     """GPU count of this node WITHOUT a HIP / HSA call: the KFD topology in sysfs (nodes with SIMDs are GPUs, narrowed
-    by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when they are plain lists).  None when the topology cannot be read.
+    by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES -- torch on ROCm honours the last one and
+    cli.py sets it -- when they are plain lists; a variable that is set and EMPTY hides every device).  None when the
+    topology cannot be read.
     (`torch.cuda.device_count()` stays off HIP only while its amdsmi path works; its fall-back is hipGetDeviceCount, which
     initialises the runtime in the parent of the rank processes -- ADVICE r4.)"""
     root = "/sys/class/kfd/kfd/topology/nodes"
@@ -86,9 +88,9 @@ def visible_gpus():
                         break
     except (OSError, ValueError):
         return None
-    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
-        if v is not None and v.strip() != "":
+        if v is not None:
             ids = [x for x in v.split(",") if x.strip() != ""]
             n = min(n, len(ids))
     return n
@@ -105,16 +107,25 @@ def job_timeout(flag_value=None, default=None):
     return v if v > 0 else None
 
 
+# PR_SET_PDEATHSIG for the rank processes: resolved at import, so that the hook between fork and exec is ONE C call (no import,
+# no allocation-heavy Python in a child forked from a process that may have threads -- ADVICE r5); the ranks' own session
+# (= process group, so the launcher can signal a rank AND whatever it started with one killpg) comes from
+# Popen(start_new_session=True), which is setsid() done by the interpreter's C code
+try:
+    import ctypes as _ctypes
+    _prctl = _ctypes.CDLL(None, use_errno=True).prctl
+    _prctl.argtypes = [_ctypes.c_int, _ctypes.c_ulong, _ctypes.c_ulong, _ctypes.c_ulong, _ctypes.c_ulong]
+    _prctl.restype = _ctypes.c_int
+except Exception:                                  # pragma: no cover  (no libc prctl: the launcher's own clean-up still runs)
+    _prctl = None
+_SIGKILL = int(signal.SIGKILL)
+
+
 def _rank_preexec():
-    # in the child, before exec: a session (= process group) of its own, so that the launcher can signal the rank AND
-    # whatever it started with one killpg; and SIGKILL from the kernel if the launcher's thread dies first (a launcher
-    # that was SIGKILLed cannot clean up: PR_SET_PDEATHSIG = 1)
-    os.setsid()
-    try:
-        import ctypes
-        ctypes.CDLL(None, use_errno=True).prctl(1, signal.SIGKILL, 0, 0, 0)
-    except Exception:
-        pass
+    # in the child, before exec: SIGKILL from the kernel if the launcher's thread dies first (a launcher that was
+    # SIGKILLed cannot clean up: PR_SET_PDEATHSIG = 1)
+    if _prctl is not None:
+        _prctl(1, _SIGKILL, 0, 0, 0)
 
 
 def _stop(procs, grace=10.0):
@@ -156,7 +167,12 @@ def spawn_ranks(argv, world, one_device=False, timeout=None, echo_stdout=True, e
     class _Signalled(Exception):
         pass
 
+    cleaning = []                                  # non-empty once the clean-up runs: further signals are recorded, not raised
+
     def on_signal(signum, frame):
+        if cleaning:
+            cleaning.append(signum)
+            return
         raise _Signalled(signum)
 
     def pump(r):
@@ -175,7 +191,7 @@ def spawn_ranks(argv, world, one_device=False, timeout=None, echo_stdout=True, e
                 old_handlers[sg] = signal.signal(sg, on_signal)
         for r in range(world):
             procs.append(subprocess.Popen(list(argv), env=rank_env(r, world, port, one_device, env), preexec_fn=_rank_preexec,
-                                          stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1))
+                                          start_new_session=True, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1))
         threads = [threading.Thread(target=pump, args=(r,), daemon=True) for r in range(world)]
         for t in threads:
             t.start()
@@ -202,6 +218,7 @@ def spawn_ranks(argv, world, one_device=False, timeout=None, echo_stdout=True, e
         sys.stderr.write("[sml_amd.launch] signal %d: stopping the ranks\n" % signum)
         code = 128 + signum
     finally:
+        cleaning.append(0)                         # a second SIGTERM / SIGINT must not abort the kill loop below
         _stop(procs)                               # (no-op for ranks that have exited)
         for sg, h in old_handlers.items():
             signal.signal(sg, h)

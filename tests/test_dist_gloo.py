@@ -383,6 +383,16 @@ def test_launcher_that_is_signalled_takes_its_ranks_with_it(tmp_path, sig):
 def test_visible_gpus_reads_sysfs_and_never_calls_hip(monkeypatch):
     from sml_amd import launch
     monkeypatch.setattr(torch.cuda, "device_count", lambda: (_ for _ in ()).throw(AssertionError("GPU call")))
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
     n = launch.visible_gpus()
     assert n is None or n >= 0
+    if n is not None:               # every variable torch on ROCm honours narrows the count; set-and-empty hides all devices
+        monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "0")
+        assert launch.visible_gpus() == min(n, 1)
+        monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "")
+        assert launch.visible_gpus() == 0
+        monkeypatch.delenv("CUDA_VISIBLE_DEVICES")
+        monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
+        assert launch.visible_gpus() == min(n, 3)
     assert launch.job_timeout(None, 3600.0) == 3600.0 and launch.job_timeout(0, 5.0) is None and launch.job_timeout("7") == 7.0
