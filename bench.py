@@ -200,8 +200,6 @@ def bench_bare_sharded(a, device, dist):
            "roofline": {"kernel": "k_bare_grad<SH> + k_run_update (owner update) per GPU", "bound": "hbm", "achieved": ach,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": None,
                         "end_to_end_achieved": e2e, "end_to_end_frac": e2e / HBM_PEAK_GBS,
-                        # one event pair around a prepared epoch / its batches (no bracket per launch; index lists ready before)
-                        "step_us_epoch_events": step_us_epoch, "frac_epoch_events": ach_epoch / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_triple": a_sgd,
                         # what crosses xGMI per triple: the remote share of 2 item rows read + 2 fp32 gradient rows stored
                         "xgmi_bytes_per_triple": remote * (2 * a.d * s + 2 * a.d * 4),
