@@ -304,10 +304,39 @@ int ensure_sched(sml_ctx* c, float lr, int64_t upto, hipStream_t st) {
     sched_reap(c, false);
     SmlSched* h = nullptr;
     SmlSched* dnew = nullptr;
-    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h), (size_t)len * sizeof(SmlSched), hipHostMallocDefault));
+    // behind the schedule: the closed-form replay tables (sml_dev.h) -- H[len + 1][4], R[SML_RP_N + 1][4] in double, B[SML_RP_N + 1][2] in float
+    const size_t bytes = (size_t)len * sizeof(SmlSched) + ((size_t)len + 1) * 4 * sizeof(double) + (size_t)(SML_RP_N + 1) * (4 * sizeof(double) + 2 * sizeof(float));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h), bytes, hipHostMallocDefault));
     for (int64_t k = 0; k < len; ++k) h[(size_t)k] = sched_entry((double)lr, k);
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&dnew), (size_t)len * sizeof(SmlSched));
-    if (e == hipSuccess) e = hipMemcpyAsync(dnew, h, (size_t)len * sizeof(SmlSched), hipMemcpyHostToDevice, st);
+    {
+        double* H = reinterpret_cast<double*>(h + len);
+        double* R = H + 4 * ((size_t)len + 1);
+        float* B = reinterpret_cast<float*>(R + 4 * (SML_RP_N + 1));
+        // the constants as the loop form rounds them: m <- m - (1 - beta1) m in float, v <- v * beta2, eps * bc2 in float
+        const double b1 = 1.0 - (double)(1.0f - SML_BETA1), b2 = (double)SML_BETA2, sg = std::sqrt(b2), eps = (double)SML_EPS;
+        double rho[4];
+        for (int q = 0; q < 4; ++q) rho[q] = b1 / std::pow(sg, 1.0 + q);
+        // H_q[k0] = sum_{k >= k0} c_k E_k^q rho_q^(k - k0 + 1), backwards; beyond the table the summands are taken as constant (never reached:
+        // every reader stays below `len`, and what the tail contributes to an entry 100 steps below the end is under 1e-5 of it)
+        {
+            const SmlSched z = h[(size_t)len - 1];
+            const double c = (double)z.step_size * (double)z.bc2_sqrt, E = eps * (double)z.bc2_sqrt;
+            double Eq = 1.0;
+            for (int q = 0; q < 4; ++q) { H[4 * (size_t)len + q] = c * Eq * rho[q] / (1.0 - rho[q]); Eq *= E; }
+        }
+        for (int64_t k = len - 1; k >= 0; --k) {
+            const SmlSched z = h[(size_t)k];
+            const double c = k >= 1 ? (double)z.step_size * (double)z.bc2_sqrt : 0.0, E = eps * (double)z.bc2_sqrt;
+            double Eq = 1.0;
+            for (int q = 0; q < 4; ++q) { H[4 * (size_t)k + q] = rho[q] * (c * Eq + H[4 * ((size_t)k + 1) + q]); Eq *= E; }
+        }
+        for (int n = 0; n <= SML_RP_N; ++n) {
+            for (int q = 0; q < 4; ++q) R[4 * n + q] = std::pow(rho[q], (double)n);
+            B[2 * n] = (float)std::pow(b1, (double)n); B[2 * n + 1] = (float)std::pow(b2, (double)n);
+        }
+    }
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&dnew), bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(dnew, h, bytes, hipMemcpyHostToDevice, st);
     SchedRetired r;
     r.dev = c->sched.p; r.host = h; r.done = nullptr;
     if (e == hipSuccess) e = hipEventCreateWithFlags(&r.done, hipEventDisableTiming);
@@ -337,6 +366,12 @@ int wg_tiles(int rows, int mt) { const int r = SML_TM * mt; return (rows + r - 1
 // fill the chip the splits only repeat the gather/prologue work, so large batches keep one
 // workgroup per tile.  (SML_FWD_NS / SML_BWD_SPLIT override the policy for measurements.)
 int env_int(const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; }
+// closed-form replay (sml_dev.h): a launch that replays rows up to step `to` uses the tables behind the schedule when the
+// bias-correction term has flattened (to >= SML_RP_K0; SML_REPLAY_K0 overrides for tests) -- SML_REPLAY_CLOSED=0: the loop everywhere
+int replay_len(const sml_ctx* c, int64_t to) {
+    const int on = env_int("SML_REPLAY_CLOSED", 1), k0 = env_int("SML_REPLAY_K0", SML_RP_K0);
+    return (on != 0 && to >= k0 && to - SML_RP_N >= 1 && to + 1 < c->sched_len) ? c->sched_len : 0;
+}
 int fwd_split(int row_tiles) {
     const int forced = env_int("SML_FWD_NS", 0);
     if (forced == 1 || forced == 2 || forced == 4) return forced;
@@ -874,6 +909,7 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
             }
         }
         f.tiles0 = wg_tiles(B, 1); f.cur_step = cur; f.sched = ctx->sched.p; f.out_pstride = out_pstride; f.k2 = ctx->variant == 1;
+        f.sched_len = mf_bx3 ? replay_len(ctx, cur - 1) : 0;
         const int tiles = f.tiles0 + wg_tiles(2 * B, 1);
         f.tiles_total = tiles;
         ctx->prof.begin(PC_FWD, st);
@@ -989,8 +1025,8 @@ int sml_mf_adam_flush(sml_ctx* ctx, const sml_mf_tables* t, float lr, int64_t st
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if ((rc = ensure_sched(ctx, lr, step + 1, st))) return rc;
-    ctx->prof.begin(PC_FLUSH, st); HIPCHK(sml_launch_adam_flush(ctx->d, t->w_user, t->m_user, t->v_user, t->step_user, t->n_user, ctx->sched.p, (int)step, st));
-    HIPCHK(sml_launch_adam_flush(ctx->d, t->w_item, t->m_item, t->v_item, t->step_item, t->n_item, ctx->sched.p, (int)step, st)); ctx->prof.end(st);
+    ctx->prof.begin(PC_FLUSH, st); HIPCHK(sml_launch_adam_flush(ctx->d, t->w_user, t->m_user, t->v_user, t->step_user, t->n_user, ctx->sched.p, (int)step, replay_len(ctx, step), st));
+    HIPCHK(sml_launch_adam_flush(ctx->d, t->w_item, t->m_item, t->v_item, t->step_item, t->n_item, ctx->sched.p, (int)step, replay_len(ctx, step), st)); ctx->prof.end(st);
     return SML_OK;
 }
 

@@ -771,30 +771,39 @@ __global__ __launch_bounds__(256) void k_hot_apply(SmlRunArgs a) {
     RowVec<T>::store(w + row * D + sub * VEC, p);
 }
 
-// bring every row up to `cur_step` (all pending steps have zero gradient)
+// bring every row up to `cur_step` (all pending steps have zero gradient).  sched_len > 0: the closed-form tables behind the
+// schedule cover this launch (sml_dev.h) -- the workgroup builds its 256 entries first, rows within reach take one evaluation
+// per element instead of one loop trip per pending step.  Grid-stride over row groups: the table is built once per workgroup.
 template <int D>
 __global__ __launch_bounds__(256) void k_adam_flush(float* __restrict__ w, float* __restrict__ mt, float* __restrict__ vt,
                                                     int32_t* __restrict__ last, int64_t rows,
-                                                    const SmlSched* __restrict__ sched, int cur_step) {
+                                                    const SmlSched* __restrict__ sched, int cur_step, int sched_len) {
     constexpr int LPR = D / 4;
     __shared__ SmlSched swin[SML_SW];
+    __shared__ SmlReplayEnt rtab[SML_RP_N];
     sched_window_load(swin, sched, cur_step, threadIdx.x);
+    const bool closed = sched_len > 0;
+    if (closed) replay_table_build(rtab, sched, sched_len, cur_step, threadIdx.x);
     __syncthreads();
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t row = gid / LPR;
-    const int sub = (int)(gid % LPR);
-    if (row >= rows) return;
-    const int from = last[row];
-    if (from < 0 || from >= cur_step) return;          // never touched (state is zero), or already current
-    float p[4], m[4], v[4];
-    RowVec<float>::load(w + row * D + sub * 4, p);
-    RowVec<float>::load(mt + row * D + sub * 4, m);
-    RowVec<float>::load(vt + row * D + sub * 4, v);
-    adam_replay_w4(p, m, v, from, cur_step, sched, swin, cur_step);
-    RowVec<float>::store(w + row * D + sub * 4, p);
-    RowVec<float>::store(mt + row * D + sub * 4, m);
-    RowVec<float>::store(vt + row * D + sub * 4, v);
-    if (sub == 0) last[row] = cur_step;   // the row's lanes share this wavefront: all have read `from`
+    const SmlReplayEnt* tab = closed ? rtab : nullptr;
+    const int64_t total = rows * LPR;
+    for (int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (int64_t)gridDim.x * 256) {
+        const int64_t row = gid / LPR;
+        const int sub = (int)(gid % LPR);
+        const int from = last[row];
+        if (from < 0 || from >= cur_step) continue;          // never touched (state is zero), or already current
+        float p[4], m[4], v[4];
+        RowVec<float>::load(w + row * D + sub * 4, p);
+        RowVec<float>::load(mt + row * D + sub * 4, m);
+        RowVec<float>::load(vt + row * D + sub * 4, v);
+        adam_replay_t4(p, m, v, from, cur_step, sched, swin, cur_step, tab);
+        RowVec<float>::store(w + row * D + sub * 4, p);
+        RowVec<float>::store(mt + row * D + sub * 4, m);
+        RowVec<float>::store(vt + row * D + sub * 4, v);
+        // (the row's lanes share this wavefront and sit in the same trip: all have read `from`.  256 % LPR == 0 and the stride is
+        // a multiple of 256, so a row never straddles two trips or two workgroups)
+        if (sub == 0) last[row] = cur_step;
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1494,10 +1503,11 @@ hipError_t sml_launch_hot_apply(int d, int dtype_bytes, const SmlRunArgs& a, hip
     return hipGetLastError();
 }
 hipError_t sml_launch_adam_flush(int d, float* w, float* m, float* v, int32_t* last, int64_t rows,
-                                 const SmlSched* sched, int cur_step, hipStream_t st) {
+                                 const SmlSched* sched, int cur_step, int sched_len, hipStream_t st) {
     const int lpr = d / 4;
-    const int64_t nb = (rows * lpr + 255) / 256;
-    SML_DISPATCH_D(d, k_adam_flush<DD><<<dim3((unsigned)nb), dim3(256), 0, st>>>(w, m, v, last, rows, sched, cur_step));
+    int64_t nb = (rows * lpr + 255) / 256;
+    if (sched_len > 0 && nb > 2048) nb = 2048;          // closed form: the table is built per workgroup -- eight resident rounds of workgroups, grid-stride
+    SML_DISPATCH_D(d, k_adam_flush<DD><<<dim3((unsigned)nb), dim3(256), 0, st>>>(w, m, v, last, rows, sched, cur_step, sched_len));
     return hipGetLastError();
 }
 hipError_t sml_launch_mf_forward(int d, const float* wu, const float* wi, const int64_t* user, const int64_t* item,

@@ -139,6 +139,9 @@ __device__ __forceinline__ void adam_zero_step(float& p, float& m, float& v, Sml
 __device__ __forceinline__ void adam_replay(float& p, float& m, float& v, int from, int to,
                                             const SmlSched* __restrict__ sched) {
     if (from < 0 || (m == 0.0f && v == 0.0f)) return;
+#ifdef SML_DBG_NOREPLAY      // measurement hook (wrong results): what the replay loops cost the kernels that carry them
+    return;
+#endif
     for (int k = from + 1; k <= to; ++k) adam_zero_step(p, m, v, sched[k]);
 }
 // the same with the most recent SML_SW schedule entries staged in LDS (win[i] = sched[wbase + i]):
@@ -154,6 +157,9 @@ __device__ __forceinline__ void adam_replay_w(float& p, float& m, float& v, int 
     // from < 0: the row was never touched.  m = v = 0: every zero-gradient step leaves p, m, v exactly
     // unchanged (m - 0.1*0 = 0, 0.999*0 = 0, p - c*0 = p), so there is nothing to replay.
     if (from < 0 || (m == 0.0f && v == 0.0f)) return;
+#ifdef SML_DBG_NOREPLAY
+    return;
+#endif
     const int wbase = upto - SML_SW + 1;
     for (int k = from + 1; k <= to; ++k) adam_zero_step(p, m, v, k >= wbase ? win[k - wbase] : sched[k]);
 }
@@ -164,12 +170,87 @@ __device__ __forceinline__ void adam_replay_w(float& p, float& m, float& v, int 
 __device__ __forceinline__ void adam_replay_w4(float (&p)[4], float (&m)[4], float (&v)[4], int from, int to,
                                                const SmlSched* __restrict__ sched, const SmlSched* win, int upto) {
     if (from < 0) return;
+#ifdef SML_DBG_NOREPLAY
+    return;
+#endif
     const int wbase = upto - SML_SW + 1;
     for (int k = from + 1; k <= to; ++k) {
         const SmlSched s = k >= wbase ? win[k - wbase] : sched[k];
 #pragma unroll
         for (int e = 0; e < 4; ++e) adam_zero_step(p[e], m[e], v[e], s);
     }
+}
+
+// ---- closed-form replay (round 6) ----------------------------------------------------------------------------------------
+// n pending zero-gradient steps of a row element (last stepped at f, brought to `to` = f + n) are, exactly,
+//     m_k = beta1^j m_f,  sqrt(v_k) = s sigma^j  (s = sqrt(v_f), sigma = sqrt(beta2), j = k - f),
+//     p_to = p_f - m_f * SUM_j w_j / (s + e_j),   w_j = c_k rho^j,  e_j = eps bc2_k sigma^-j,  c_k = step_size_k bc2_k,  rho = beta1 / sigma
+// -- the loop above walks that sum term by term (74 terms x ~64 issue cycles at the end of an MF epoch: 2.5 us of the MF
+// forward's 16 and most of k_adam_flush, `tools/bench_steps.py --lib ..noreplay..`).  The e_j of one replay differ from
+// their w-weighted mean ebar by a few per cent at most once bc2_k has flattened (k >= SML_RP_K0: under 3 % over the ~30 terms
+// that carry the weight), so with t = s + ebar and the weighted central moments mu2, mu3 of the e_j
+//     SUM_j w_j / (s + e_j) = (M0 / t) * (1 + mu2 / t^2 - mu3 / t^3 + O((delta / t)^4)),        (delta / t)^4 < 1e-6 for EVERY s >= 0
+// (the first-order term vanishes by the choice of ebar).  The raw moments M_q(f, to) = SUM_k c_k E_k^q rho_q^(k-f), rho_q =
+// beta1 sigma^-(1+q), come from ONE-dimensional host tables in double precision -- H_q[k0] = SUM_{k >= k0} c_k E_k^q rho_q^(k-k0+1),
+// so M_q = H_q[f+1] - rho_q^n H_q[to+1] -- appended to the schedule table (ensure_sched): every workgroup turns them into the
+// 256 entries {M0, ebar, mu2 / ebar^2, mu3 / ebar^3, beta1^n, beta2^n} of ITS launch's `to` while its gather is in flight, and
+// an element's replay is one LDS read, one square root, one reciprocal and eight multiply-adds whatever n is.
+// Steps below SML_RP_K0 (the first 1.4 periods of a run, every golden fixture), rows older than SML_RP_N steps and
+// SML_REPLAY_CLOSED=0 keep the loop.  Against a float64 dense Adam the closed form is as close as the loop
+// (tests/test_hip_parity.py::test_closed_form_replay_...).
+#define SML_RP_N 256
+#define SML_RP_K0 1024
+struct __attribute__((aligned(16))) SmlReplayEnt { float M0, ebar, nu2, nu3, b1, b2, pad0, pad1; };
+// layout behind the schedule's `len` entries: H[len + 1][4] doubles, R[SML_RP_N + 1][4] doubles (rho_q^n), B[SML_RP_N + 1][2] floats (beta1^n, beta2^n)
+__device__ __forceinline__ void replay_table_build(SmlReplayEnt* tab, const SmlSched* __restrict__ sched, int len, int to, int tid) {
+    if (tid >= SML_RP_N) return;
+    const int n = tid + 1, f = to - n;
+    SmlReplayEnt e;
+    e.M0 = 0.f; e.ebar = 1.f; e.nu2 = 0.f; e.nu3 = 0.f; e.b1 = 1.f; e.b2 = 1.f; e.pad0 = 0.f; e.pad1 = 0.f;
+    if (f >= 0) {
+        const double* __restrict__ H = reinterpret_cast<const double*>(sched + len);
+        const double* __restrict__ R = H + 4 * ((int64_t)len + 1);
+        const float* __restrict__ B = reinterpret_cast<const float*>(R + 4 * (SML_RP_N + 1));
+        double M[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) M[q] = H[4 * ((int64_t)f + 1) + q] - R[4 * n + q] * H[4 * ((int64_t)to + 1) + q];
+        const double i0 = 1.0 / M[0];
+        const double eb = M[1] * i0, r2 = M[2] * i0, r3 = M[3] * i0;
+        const double ie = 1.0 / eb;
+        const double mu2 = r2 - eb * eb, mu3 = r3 - 3.0 * eb * r2 + 2.0 * eb * eb * eb;
+        e.M0 = (float)M[0]; e.ebar = (float)eb; e.nu2 = (float)(mu2 * ie * ie); e.nu3 = (float)(mu3 * ie * ie * ie);
+        e.b1 = B[2 * n]; e.b2 = B[2 * n + 1];
+    }
+    tab[tid] = e;
+}
+__device__ __forceinline__ void adam_replay_closed(float& p, float& m, float& v, const SmlReplayEnt& e) {
+    const float s = __builtin_amdgcn_sqrtf(v);
+    const float x = __builtin_amdgcn_rcpf(s + e.ebar);
+    const float y = e.ebar * x;                                      // in (0, 1]
+    const float corr = 1.0f + (y * y) * (e.nu2 - e.nu3 * y);
+    p = p - ((m * e.M0) * x) * corr;
+    m = m * e.b1;
+    v = v * e.b2;
+}
+// replay through the table when it covers the row (tab: this launch's entries in LDS, null: the loop), else the loop
+__device__ __forceinline__ void adam_replay_t(float& p, float& m, float& v, int from, int to, const SmlSched* __restrict__ sched,
+                                              const SmlSched* win, int upto, const SmlReplayEnt* tab) {
+    if (from < 0 || (m == 0.0f && v == 0.0f)) return;
+    const int n = to - from;
+    if (tab != nullptr && n >= 1 && n <= SML_RP_N) { adam_replay_closed(p, m, v, tab[n - 1]); return; }
+    adam_replay_w(p, m, v, from, to, sched, win, upto);
+}
+__device__ __forceinline__ void adam_replay_t4(float (&p)[4], float (&m)[4], float (&v)[4], int from, int to,
+                                               const SmlSched* __restrict__ sched, const SmlSched* win, int upto, const SmlReplayEnt* tab) {
+    if (from < 0) return;
+    const int n = to - from;
+    if (tab != nullptr && n >= 1 && n <= SML_RP_N) {
+        const SmlReplayEnt e = tab[n - 1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) adam_replay_closed(p[q], m[q], v[q], e);
+        return;
+    }
+    adam_replay_w4(p, m, v, from, to, sched, win, upto);
 }
 
 // ---- one-shot exchange over peer mappings: device side ------------------------------------------------------------

@@ -62,6 +62,7 @@ struct SmlFwdArgs {
     int tiles_total;
     int k2;                  // ConvTransfer nets: kernel (2,1), the x_com row is zero
     int unit_rows;           // NS = 1 only: rows of seg[0] leave divided by their norm (ConvTransfer's user output)
+    int sched_len;           // > 0: the schedule table is followed by the closed-form replay tables (sml_dev.h) and this launch uses them
     // TR stage, hidden-split form (NS = 4), one GPU: the PREVIOUS batch's conv-parameter Adam step is taken HERE (cs_in !=
     // null).  The merged launch of batch b - 1 left its tail workgroups' compact conv-gradient partials in cg_part
     // (rows [0, cg_split): user net, [cg_split, cg_total): item net; null: nothing pending, the parameters pass through);
@@ -333,7 +334,7 @@ hipError_t sml_launch_hot_apply(int d, int dtype_bytes, const SmlRunArgs& a, hip
 hipError_t sml_launch_run_adam(int d, const SmlRunArgs& a, int64_t max_records, hipStream_t st);
 hipError_t sml_launch_run_sgd(int d, int dtype_bytes, const SmlRunArgs& a, int64_t max_records, hipStream_t st);
 hipError_t sml_launch_adam_flush(int d, float* w, float* m, float* v, int32_t* last, int64_t rows,
-                                 const SmlSched* sched, int cur_step, hipStream_t st);
+                                 const SmlSched* sched, int cur_step, int sched_len, hipStream_t st);
 // key_bytes 4: keys (batch << row_bits) | row in 32 bits; 8: (batch << 32) | row
 hipError_t sml_launch_mark_runs(int key_bytes, const void* keys, const uint32_t* vals, int64_t n, int row_bits, SmlRun* rec,
                                 uint8_t* flag_dup, uint8_t* uniq, int64_t uniq_stride, int64_t uniq_item_base, hipStream_t st);

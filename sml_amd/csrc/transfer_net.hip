@@ -473,6 +473,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __shared__ __attribute__((aligned(16))) unsigned short A2b[3][R][S2B];
     __shared__ float cws[104];
     __shared__ SmlSched swin[SML_SW];
+    __shared__ SmlReplayEnt rtab[SML_RP_N];                      // closed-form replay: this launch's entries (a.sched_len > 0)
     float* part = reinterpret_cast<float*>(&A2b[0][0][0]);       // [8][R][D + 1] fc2 partials, once the a2 tile is done with
     static_assert(sizeof(A2b) >= 8 * R * (D + 1) * sizeof(float), "part fits");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
@@ -502,6 +503,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float xt = sg.xt_tab[idx * D + w], xh = sg.xh_tab[idx * D + w];
     float m = 0.0f, v = 0.0f; int from = -1;
     if (lazy) { m = sg.m_tab[idx * D + w]; v = sg.v_tab[idx * D + w]; from = sg.last_tab[idx]; }
+    const bool closed = lazy && a.sched_len > 0;
+    if (closed) replay_table_build(rtab, a.sched, a.sched_len, a.cur_step - 1, tid);      // (double-precision work under the gather's round trips)
     // fc1 operand planes: wave wv owns column tiles wv * CT + t; a two-deep ring over the KS1 k-steps, behind the gather's loads
     uint4 bw[2][CT][3];
     auto load_b1 = [&](int ks, uint4 (&dst)[CT][3]) {
@@ -523,7 +526,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int off = D / 2; off >= 1; off >>= 1) nr2 += __shfl_xor(nr2, off, 64);
     __syncthreads();                                             // cws and the schedule window are in LDS
     if (lazy) {
-        if (ok) adam_replay_w(xh, m, v, from, a.cur_step - 1, a.sched, swin, a.cur_step - 1);
+        if (ok) adam_replay_t(xh, m, v, from, a.cur_step - 1, a.sched, swin, a.cur_step - 1, closed ? rtab : nullptr);
         if (sg.mrep != nullptr) {                                // the row update continues from these (same tile, same XCD: plain stores)
             sg.mrep[(int64_t)(row0 + r) * D + w] = ok ? m : 0.0f;
             sg.vrep[(int64_t)(row0 + r) * D + w] = ok ? v : 0.0f;

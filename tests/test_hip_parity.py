@@ -208,6 +208,94 @@ def test_lazy_adam_untouched_rows_equal_dense():
     np.testing.assert_array_equal(gu[0], wu[0].numpy())        # never-touched rows: m = v = 0, no motion
 
 
+def _zero_grad_adam_f64(p, m, v, first, last, lr):
+    """`last - first` zero-gradient steps of torch.optim.Adam (steps first+1 .. last) in float64, with the decay constants as
+    fp32 arithmetic applies them (m - fl(1 - 0.9f) m; v * 0.999f) and the schedule the library tabulates (sml_hip.h)."""
+    b1 = 1.0 - float(np.float32(1.0) - np.float32(0.9)); b2 = float(np.float32(0.999))
+    p, m, v = p.astype(np.float64), m.astype(np.float64), v.astype(np.float64)
+    for k in range(first + 1, last + 1):
+        ss = float(np.float32(lr / (1.0 - 0.9 ** k))); bc = float(np.float32(np.sqrt(1.0 - 0.999 ** k)))
+        m = m * b1; v = v * b2
+        p = p - ss * m / (np.sqrt(v) / bc + 1e-8)
+    return p, m, v
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("start", [5000, 1024])
+def test_closed_form_replay_against_float64_and_against_the_loop(start, monkeypatch):
+    """Round 6: pending zero-gradient Adam steps of a row are evaluated in closed form (sml_dev.h: the sum over the steps as a
+    three-term moment expansion around the weighted mean of eps * bc2_k * sigma^-j, raw moments from one-dimensional host tables
+    in double) instead of step by step, once the step counter has passed SML_RP_K0.  (i) Pure replay through the flush kernel:
+    rows carrying a loaded optimiser state sit out 1 .. 200 steps -- tiny second moments included (sqrt(v) far below, around
+    and far above eps) -- against float64 zero-gradient Adam steps: the closed form must be as close as the loop form
+    (SML_REPLAY_CLOSED=0) is.  (ii) Through the MF stage's forward gather (k_mf_fwd_bx3, batches of 1,024): rows touched, left
+    alone for 60 batches and touched again, closed form against loop on the resulting tables and moments."""
+    d, lr = 32, 0.01
+    rng = np.random.RandomState(3)
+    U, I = 512, 4096
+    wu0 = rng.randn(U, d).astype(np.float32) * 0.3
+    wi0 = rng.randn(I, d).astype(np.float32) * 0.3
+    vu = (rng.rand(U, d) * 1e-5).astype(np.float32)
+    vi = (rng.rand(I, d) * 1e-5).astype(np.float32)
+    for c, val in enumerate((0.0, 1e-30, 1e-22, 1e-18, 1e-16, 1e-15, 1e-14, 1e-12, 1e-10, 1e-8)):      # sqrt(v) from 0 over 1e-9 .. 1e-4
+        vu[:, c] = val; vi[:, c] = val
+    mu = (np.sqrt(vu) * rng.uniform(-2.0, 2.0, vu.shape)).astype(np.float32)
+    mi = (np.sqrt(vi) * rng.uniform(-2.0, 2.0, vi.shape)).astype(np.float32)
+    st = dict(m_user=torch.from_numpy(mu), v_user=torch.from_numpy(vu), m_item=torch.from_numpy(mi), v_item=torch.from_numpy(vi), step=start)
+    # (i) batches of 8 triples over users / items 0..7 only; every other row is brought up to date by the flush alone
+    got = {}
+    for n_idle in (1, 7, 74, 200):
+        tri = torch.from_numpy(rng.randint(0, 8, (8 * n_idle, 3)))
+        for mode in ("1", "0"):
+            monkeypatch.setenv("SML_REPLAY_CLOSED", mode)
+            eng = engine(d, 64)
+            mf = make_mf(U, I, d, wu0, wi0, device=DEV)
+            torch.manual_seed(1)
+            net = make_transfer(d, device=DEV)
+            eng.load_optimizer_state(mfbase=mf, mf_state=st)
+            eng.mf_stage_epoch(mf, net, T(wu0 * 0.9, DEV), T(wi0 * 0.9, DEV), tri, 8, lr, 1e-6)
+            eng.mf_flush(mf)
+            torch.cuda.synchronize()
+            got[mode] = (mf.user_laten.weight.detach().cpu().numpy()[8:], eng.mf_state["m_u"].cpu().numpy()[8:], eng.mf_state["v_u"].cpu().numpy()[8:],
+                         mf.item_laten.weight.detach().cpu().numpy()[8:], eng.mf_state["m_i"].cpu().numpy()[8:], eng.mf_state["v_i"].cpu().numpy()[8:])
+            eng.close()
+        for (w0, m0, v0, o) in ((wu0, mu, vu, 0), (wi0, mi, vi, 3)):
+            pr, mr, vr = _zero_grad_adam_f64(w0[8:], m0[8:], v0[8:], start, start + n_idle, lr)
+            move = np.abs(pr - w0[8:]).max()
+            e_closed = np.abs(got["1"][o] - pr).max(); e_loop = np.abs(got["0"][o] - pr).max()
+            # fp32 storage of p (|p| ~ 1: half an ulp = 6e-8) bounds both from below
+            assert e_closed <= max(1.5 * e_loop, 2e-7) + 1e-6 * move, (n_idle, o, e_closed, e_loop, move)
+            np.testing.assert_allclose(got["1"][o + 1], mr, rtol=3e-6, atol=1e-37)
+            np.testing.assert_allclose(got["1"][o + 2], vr, rtol=3e-6, atol=1e-37)
+            assert move > 1e-3 or n_idle == 1
+    # (ii) the forward's gather: rows of set A (users < 256, items < 2048) are touched by 2 batches, then 60 batches over set B, then A again
+    def draw(n, ulo, uhi, ilo, ihi):
+        return np.stack([rng.randint(ulo, uhi, n), rng.randint(ilo, ihi, n), rng.randint(ilo, ihi, n)], 1)
+    tri = torch.from_numpy(np.concatenate([draw(2048, 0, 256, 0, 2048), draw(60 * 1024, 256, 512, 2048, 4096), draw(2048, 0, 256, 0, 2048)]))
+    outs = {}
+    monkeypatch.setenv("SML_TRACE", "1")
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SML_REPLAY_CLOSED", mode)
+        eng = engine(d, 1024)
+        mf = make_mf(U, I, d, wu0, wi0, device=DEV)
+        torch.manual_seed(1)
+        net = make_transfer(d, device=DEV)
+        eng.load_optimizer_state(mfbase=mf, mf_state=st)
+        losses = eng.mf_stage_epoch(mf, net, T(wu0 * 0.9, DEV), T(wi0 * 0.9, DEV), tri, 1024, lr, 1e-6).cpu().numpy()
+        eng.mf_flush(mf)
+        torch.cuda.synchronize()
+        outs[mode] = (losses, mf.user_laten.weight.detach().cpu().numpy(), mf.item_laten.weight.detach().cpu().numpy(),
+                      eng.mf_state["m_u"].cpu().numpy(), eng.mf_state["v_u"].cpu().numpy())
+        eng.close()
+    a, b = outs["1"], outs["0"]
+    np.testing.assert_allclose(a[0], b[0], rtol=2e-6)
+    for x, y in zip(a[1:3], b[1:3]):
+        assert np.abs(x - y).max() < 5e-6 and np.mean(np.abs(x - y) > 5e-7) < 1e-2, (np.abs(x - y).max(), np.mean(np.abs(x - y) > 5e-7))
+    np.testing.assert_allclose(a[3], b[3], rtol=2e-5, atol=1e-12)
+    np.testing.assert_allclose(a[4], b[4], rtol=2e-5, atol=1e-30)
+    assert np.abs(a[1] - wu0).max() > 1e-2
+
+
 # ----------------------------------------------------------------------------- G4 (a9)
 @pytest.mark.parametrize("start", [0, 65536 - 150])
 def test_lazy_adam_replays_longer_than_the_lds_window_and_across_schedule_growth(start):

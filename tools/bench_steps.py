@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--comm", default="none", choices=["none", "peer", "rccl", "torch"],
                     help="drive the multi-GPU exchange path on a forced 1-rank group: the per-step overhead of each carrier "
                          "(peer: one-shot push / poll into the rank's own inbox; rccl: the library's communicator; torch: hooks)")
+    ap.add_argument("--start-step", type=int, default=0, help="MF optimiser starts at this step with a small random Adam state on every row "
+                    "(0: a fresh optimiser; the closed-form replay is used from step 1024 on)")
+    ap.add_argument("--lib", default="", help="another build of the library (same C ABI) instead of the in-tree one: A/B of two builds in one gpurun call")
     a = ap.parse_args()
     import contextlib
     import io
@@ -39,7 +42,11 @@ def main():
     from sml_amd.engine import HipEngine
     from sml_amd.mf import MFbasemode
     dev = torch.device("cuda", 0)
-    eng = HipEngine(dev, a.d, max(a.tr_batch, a.mf_batch))
+    if a.lib:
+        from sml_amd import _lib
+        eng = HipEngine(dev, a.d, max(a.tr_batch, a.mf_batch), lib=_lib.load_other(os.path.abspath(a.lib)))
+    else:
+        eng = HipEngine(dev, a.d, max(a.tr_batch, a.mf_batch))
     torch.manual_seed(2000)
     mf = MFbasemode(a.users, a.items, a.d)
     with torch.no_grad():
@@ -49,6 +56,11 @@ def main():
         net = ConvTransfer_com(a.d, a.d)
     mf, net = mf.to(dev), net.to(dev)
     eng.adopt(net)
+    if a.start_step > 0:
+        g = torch.Generator().manual_seed(5)
+        eng.load_optimizer_state(mfbase=mf, mf_state=dict(
+            m_user=torch.randn(a.users, a.d, generator=g) * 1e-4, v_user=torch.rand(a.users, a.d, generator=g) * 1e-7,
+            m_item=torch.randn(a.items, a.d, generator=g) * 1e-4, v_item=torch.rand(a.items, a.d, generator=g) * 1e-7, step=a.start_step))
     if a.comm != "none":
         import socket
         import torch.distributed as dist
