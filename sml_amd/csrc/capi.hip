@@ -909,7 +909,7 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
             }
         }
         f.tiles0 = wg_tiles(B, 1); f.cur_step = cur; f.sched = ctx->sched.p; f.out_pstride = out_pstride; f.k2 = ctx->variant == 1;
-        f.sched_len = mf_bx3 ? replay_len(ctx, cur - 1) : 0;
+        f.sched_len = replay_len(ctx, cur - 1);
         const int tiles = f.tiles0 + wg_tiles(2 * B, 1);
         f.tiles_total = tiles;
         ctx->prof.begin(PC_FWD, st);

@@ -214,11 +214,13 @@ __device__ __forceinline__ void replay_table_build(SmlReplayEnt* tab, const SmlS
         double M[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) M[q] = H[4 * ((int64_t)f + 1) + q] - R[4 * n + q] * H[4 * ((int64_t)to + 1) + q];
-        const double i0 = 1.0 / M[0];
-        const double eb = M[1] * i0, r2 = M[2] * i0, r3 = M[3] * i0;
-        const double ie = 1.0 / eb;
-        const double mu2 = r2 - eb * eb, mu3 = r3 - 3.0 * eb * r2 + 2.0 * eb * eb * eb;
-        e.M0 = (float)M[0]; e.ebar = (float)eb; e.nu2 = (float)(mu2 * ie * ie); e.nu3 = (float)(mu3 * ie * ie * ie);
+        if (M[0] > 0.0 && M[1] > 0.0) {          // (lr = 0: every weight is zero -- the row does not move, its moments still decay)
+            const double i0 = 1.0 / M[0];
+            const double eb = M[1] * i0, r2 = M[2] * i0, r3 = M[3] * i0;
+            const double ie = 1.0 / eb;
+            const double mu2 = r2 - eb * eb, mu3 = r3 - 3.0 * eb * r2 + 2.0 * eb * eb * eb;
+            e.M0 = (float)M[0]; e.ebar = (float)eb; e.nu2 = (float)(mu2 * ie * ie); e.nu3 = (float)(mu3 * ie * ie * ie);
+        }
         e.b1 = B[2 * n]; e.b2 = B[2 * n + 1];
     }
     tab[tid] = e;

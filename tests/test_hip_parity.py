@@ -221,16 +221,17 @@ def _zero_grad_adam_f64(p, m, v, first, last, lr):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("start", [5000, 1024])
-def test_closed_form_replay_against_float64_and_against_the_loop(start, monkeypatch):
+@pytest.mark.parametrize("start,d", [(5000, 32), (1024, 32), (5000, 64)])
+def test_closed_form_replay_against_float64_and_against_the_loop(start, d, monkeypatch):
     """Round 6: pending zero-gradient Adam steps of a row are evaluated in closed form (sml_dev.h: the sum over the steps as a
     three-term moment expansion around the weighted mean of eps * bc2_k * sigma^-j, raw moments from one-dimensional host tables
     in double) instead of step by step, once the step counter has passed SML_RP_K0.  (i) Pure replay through the flush kernel:
     rows carrying a loaded optimiser state sit out 1 .. 200 steps -- tiny second moments included (sqrt(v) far below, around
     and far above eps) -- against float64 zero-gradient Adam steps: the closed form must be as close as the loop form
     (SML_REPLAY_CLOSED=0) is.  (ii) Through the MF stage's forward gather (k_mf_fwd_bx3, batches of 1,024): rows touched, left
-    alone for 60 batches and touched again, closed form against loop on the resulting tables and moments."""
-    d, lr = 32, 0.01
+    alone for 60 batches and touched again, closed form against loop on the resulting tables and moments (d = 64: the fp32-product
+    forward, transfer_fwd_body.inc, carries the same table)."""
+    lr = 0.01
     rng = np.random.RandomState(3)
     U, I = 512, 4096
     wu0 = rng.randn(U, d).astype(np.float32) * 0.3
