@@ -1006,7 +1006,7 @@ int sml_mf_stage_epoch(sml_ctx* ctx, const float* theta, const sml_mf_tables* t,
             u.dx_i = gathered;
         }
         u.m_user = t->m_user; u.v_user = t->v_user; u.m_item = t->m_item; u.v_item = t->v_item;
-        u.last_user = t->step_user; u.last_item = t->step_item; u.sched = ctx->sched.p; u.cur_step = cur; u.lr = lr;
+        u.last_user = t->step_user; u.last_item = t->step_item; u.sched = ctx->sched.p; u.cur_step = cur; u.lr = lr; u.sched_len = replay_len(ctx, cur - 1);
         // rows continue from the forward's replayed copies (local scratch; the multi-GPU item list's slots index the
         // all-gathered buffer instead, so item rows are replayed from the table there)
         u.rep_x = ctx->xin.p; u.rep_m = ctx->mrep.p; u.rep_v = ctx->vrep.p; u.rep_u = 1; u.rep_i = xchg ? 0 : 1;
@@ -1548,7 +1548,7 @@ int sml_embed_loss_adam_epoch(sml_ctx* ctx, const sml_mf_tables* t, const int64_
         u.run_i = ctx->ix[0].rec_i.p + 2 * b * batch; u.n_i = 2 * B; u.val_i = ctx->ix[0].val_i2.p;
         u.dx = ctx->dx.p; u.dx_i = ctx->dx.p; u.w_user = t->w_user; u.w_item = t->w_item;
         u.m_user = t->m_user; u.v_user = t->v_user; u.m_item = t->m_item; u.v_item = t->v_item;
-        u.last_user = t->step_user; u.last_item = t->step_item; u.sched = ctx->sched.p; u.cur_step = cur; u.lr = lr;
+        u.last_user = t->step_user; u.last_item = t->step_item; u.sched = ctx->sched.p; u.cur_step = cur; u.lr = lr; u.sched_len = replay_len(ctx, cur - 1);
         u.rep_x = ctx->xin.p; u.rep_m = ctx->mrep.p; u.rep_v = ctx->vrep.p; u.rep_u = 1; u.rep_i = 1; u.rep_x_stride = d; u.rep_x_off = 0;
         ctx->prof.begin(PC_SEG_ADAM, st); HIPCHK(sml_launch_run_adam(d, u, (int64_t)3 * B, st)); ctx->prof.end(st);
     }

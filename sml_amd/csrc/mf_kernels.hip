@@ -567,8 +567,11 @@ __global__ __launch_bounds__(256) void k_run_update(SmlRunArgs a) {
     constexpr int LONG = OPT == 0 ? 4 : 8;
     constexpr int LD = (VEC == 4 && !LIGHT) ? 8 : 4;    // ... with LD rows per lane group in flight
     __shared__ SmlSched swin[OPT == 1 ? SML_SW : 1];
+    __shared__ SmlReplayEnt rtab[OPT == 1 ? SML_RP_N : 1];      // closed-form replay entries of this launch (rows this kernel replays itself)
+    const SmlReplayEnt* tab = nullptr;
     if (OPT == 1) {                       // the Adam schedule of the last SML_SW steps, staged once per block
         sched_window_load(swin, a.sched, a.cur_step, threadIdx.x);
+        if (a.sched_len > 0) { replay_table_build(rtab, a.sched, a.sched_len, a.cur_step - 1, threadIdx.x); tab = rtab; }
         __syncthreads();
     }
     // several GPUs (one-shot exchange): the ranks' gradient rows have landed in this rank's inbox slots when its counters
@@ -713,7 +716,7 @@ __global__ __launch_bounds__(256) void k_run_update(SmlRunArgs a) {
             const SmlSched sc = swin[SML_SW - 1];      // = sched[cur_step]
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                adam_replay_w(p[q], m[q], v[q], from, a.cur_step - 1, a.sched, swin, a.cur_step);
+                adam_replay_t(p[q], m[q], v[q], from, a.cur_step - 1, a.sched, swin, a.cur_step, tab);
                 adam_apply(p[q], m[q], v[q], g[q], sc);
             }
             RowVec<T>::store(w + row * D + sub * VEC, p);

@@ -233,6 +233,7 @@ struct SmlRunArgs {
     float* m_user; float* v_user; float* m_item; float* v_item;   // Adam only
     int32_t* last_user; int32_t* last_item;                       // Adam only
     const SmlSched* sched; int cur_step;                          // Adam only
+    int sched_len;                                                // Adam only, > 0: closed-form replay tables behind the schedule (sml_dev.h)
     // Adam, MF stage: the forward already replayed every gathered row's pending zero-gradient steps; it left the
     // replayed row in xin[slot][1] and the moments in rep_m / rep_v [slot]: the update starts from those (no second
     // replay, no table read).  rep_u / rep_i: which of the two lists' slots index that local scratch.

@@ -10,7 +10,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
-PERIOD="bench.py --no-cpu --no-a3 --steps 2 --warmup 1"
+PERIOD="bench.py --no-cpu --no-a3 --steps 4 --warmup 2"      # (the step counter passes 1,024 -- closed-form replay -- in the second period)
 BARE="bench.py --workload bare --users 10000000 --items 1000000 --bare-batch 262144 --steps 2 --warmup 1"
 run() { # name, rocprof args..., -- cmd
     local name=$1; shift
@@ -30,3 +30,9 @@ for z in 0 1; do
     run bare_z${z}_write --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/bare_z${z}_write" -- python3 $BARE --item-zipf $z
 done
 python3 tools/summarize_prof.py "$OUT" "$TAG"
+# gpurun merges at most 64 MiB back: the raw traces of seven periods exceed that -- keep the logs and the summaries
+if [ -z "${KEEP_RAW:-}" ]; then
+    for d in "$OUT"/*/; do
+        case "$d" in */summary/) ;; *) rm -rf "$d" ;; esac
+    done
+fi
