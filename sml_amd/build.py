@@ -8,7 +8,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsml_hip.so")
 SOURCES = ["transfer_net.hip", "mf_kernels.hip", "index_prep.hip", "capi.hip"]
 HEADERS = ["sml_dev.h", "sml_kernels.h", "transfer_fwd_body.inc", os.path.join("..", "..", "include", "sml_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         # leading scalar / pointer kernel parameters arrive in SGPRs with the wavefront (up to 16 SGPRs) instead of behind a
+         # scalar-load round trip of the argument segment: 0.22-0.24 us per dependent kernel (tools/launch_boundary_probe.hip)
+         "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 FLAGS += os.environ.get("SML_EXTRA_FLAGS", "").split()      # measurement builds, e.g. -DSML_TIMELINE (tools/timeline_probe.py)
 
 

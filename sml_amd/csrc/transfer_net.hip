@@ -1627,8 +1627,13 @@ __global__ __launch_bounds__(512) void k_transfer_bwd(SmlBwdArgs a) {
 //                   <= 128 VGPRs, 50 KB of LDS each).  The last tail workgroup to arrive sums the partials in index
 //                   order (deterministic) and takes the conv parameters' Adam step.
 // ------------------------------------------------------------------------------------
+// The leading scalar parameters are what the kernel's first round of loads needs; built with -amdgpu-kernarg-preload-count=16
+// (sml_amd/build.py) they arrive in SGPRs WITH the wavefront instead of behind a scalar-load round trip of the argument
+// segment (tools/launch_boundary_probe.hip: 0.22-0.24 us per dependent kernel on this part); the by-value struct that follows
+// carries the rest, which nothing waits for before the first loads are out.  (13 SGPRs: three pointers, one int64, five ints.)
 template <int D>
-__global__ __launch_bounds__(512) void k_tr_bwd_head(SmlBwdArgs a) {
+__global__ __launch_bounds__(512) void k_tr_bwd_head(const float* __restrict__ p_out_all, const float* __restrict__ p_z1, const float* __restrict__ p_pk,
+                                                     long long p_out_pstride, int p_B, int p_ioff, int p_tiles0, int p_tiles_total, int p_out_np, SmlBwdArgs a) {
     constexpr int R = SML_TM;
     constexpr int HS = 4;                 // hidden slices (workgroups) per row tile
     constexpr int SD = D + 4;
@@ -1645,11 +1650,13 @@ __global__ __launch_bounds__(512) void k_tr_bwd_head(SmlBwdArgs a) {
     // same block -> (tile, slice) map as the hidden-split forward: slice hs on XCDs {2 hs, 2 hs + 1}
     const int x8 = (int)blockIdx.x % 8;
     const int hs = x8 / 2, tile = 2 * ((int)blockIdx.x / 8) + (x8 % 2);
-    if (tile >= a.tiles_total) return;
-    const int sidx = tile >= a.tiles0;
-    const SmlBwdSeg sg = sidx ? a.seg[1] : a.seg[0];
-    const int row0 = (tile - (sidx ? a.tiles0 : 0)) * R;
-    const f32x4* __restrict__ p2b = reinterpret_cast<const f32x4*>(sg.pk + sml_pk_p2b(D));
+    if (tile >= p_tiles_total) return;
+    const int sidx = tile >= p_tiles0;
+    const SmlBwdSeg sg = sidx ? a.seg[1] : a.seg[0];      // (the stores' pointers: needed at the end)
+    const int row0 = (tile - (sidx ? p_tiles0 : 0)) * R;
+    const int n_rows = sidx ? 2 * p_B : p_B;               // = n_rows
+    const float* __restrict__ z1_seg = p_z1 + (sidx ? (int64_t)p_ioff * SML_HID : 0);       // = sg.z1 (slot0 = ioff)
+    const f32x4* __restrict__ p2b = reinterpret_cast<const f32x4*>(p_pk + (sidx ? sml_pk_size(D) : 0) + sml_pk_p2b(D));   // = sg.pk + ...
     const int ct = hs * 8 + wv;           // this wave's dA2 column tile
     // ---- every global load first: the three out rows' planes, this wave's z1 fragment, its W2 operand image
     float vu[EPT][SML_FWD_NS], vi[EPT][SML_FWD_NS], vn[EPT][SML_FWD_NS];
@@ -1657,20 +1664,20 @@ __global__ __launch_bounds__(512) void k_tr_bwd_head(SmlBwdArgs a) {
     for (int q = 0; q < EPT; ++q) {
         const int e = q * 512 + tid, r = e / D, w = e % D;
         const int row = row0 + r;
-        const bool inr = row < sg.n_rows;
-        const int t = !inr ? 0 : ((sg.is_item && row >= a.B) ? row - a.B : row);
-        const float* pu = a.out_all + (int64_t)t * D + w;
-        const float* pi = a.out_all + (int64_t)(a.ioff + t) * D + w;
-        const float* pn = a.out_all + (int64_t)(a.ioff + a.B + t) * D + w;
+        const bool inr = row < n_rows;
+        const int t = !inr ? 0 : ((sidx && row >= p_B) ? row - p_B : row);
+        const float* pu = p_out_all + (int64_t)t * D + w;
+        const float* pi = p_out_all + (int64_t)(p_ioff + t) * D + w;
+        const float* pn = p_out_all + (int64_t)(p_ioff + p_B + t) * D + w;
 #pragma unroll
         for (int p = 0; p < SML_FWD_NS; ++p) {
-            const int64_t po = (int64_t)min(p, a.out_np - 1) * a.out_pstride;
+            const int64_t po = (int64_t)min(p, p_out_np - 1) * p_out_pstride;
             vu[q][p] = pu[po]; vi[q][p] = pi[po]; vn[q][p] = pn[po];
         }
     }
     float z[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) z[q] = sg.z1[(int64_t)(row0 + 4 * g4 + q) * SML_HID + ct * 16 + l15];
+    for (int q = 0; q < 4; ++q) z[q] = z1_seg[(int64_t)(row0 + 4 * g4 + q) * SML_HID + ct * 16 + l15];
     f32x4 ring[KSD];
 #pragma unroll
     for (int ks = 0; ks < KSD; ++ks) ring[ks] = p2b[(ct * KSD + ks) * 64 + lane];
@@ -1678,11 +1685,11 @@ __global__ __launch_bounds__(512) void k_tr_bwd_head(SmlBwdArgs a) {
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
         const int e = q * 512 + tid, r = e / D, w = e % D;
-        const float inr = (row0 + r < sg.n_rows) ? 1.0f : 0.0f;
+        const float inr = (row0 + r < n_rows) ? 1.0f : 0.0f;
         ou[q] = oi[q] = on[q] = 0.0f;
 #pragma unroll
         for (int p = 0; p < SML_FWD_NS; ++p) {      // planes added in index order
-            const float live = p < a.out_np ? inr : 0.0f;
+            const float live = p < p_out_np ? inr : 0.0f;
             ou[q] += live * vu[q][p]; oi[q] += live * vi[q][p]; on[q] += live * vn[q][p];
         }
         if constexpr (D > 64) {
@@ -1701,19 +1708,19 @@ __global__ __launch_bounds__(512) void k_tr_bwd_head(SmlBwdArgs a) {
             pair_terms(SML_LOSS_BPR, (sp - sn) * inv_nu, 0.0f, 1.0f, lt, d0, d1);
             d1 = -d0;
         } else {
-            pair_terms(a.kind, sp, sn, 1.0f / (float)a.B, lt, d0, d1);
+            pair_terms(a.kind, sp, sn, 1.0f / (float)p_B, lt, d0, d1);
         }
     };
     auto dout_of = [&](int row, float d0, float d1, float inv_nu, float cc, float u, float i, float n) {
         float g;
         if (a.kind == SML_LOSS_BPR_NORM || a.kind == SML_LOSS_BPR_UNIT) {
-            if (!sg.is_item) g = d0 * ((i - n) * inv_nu - cc * u);
-            else g = ((row < a.B) ? d0 : d1) * u * inv_nu;
+            if (!sidx) g = d0 * ((i - n) * inv_nu - cc * u);
+            else g = ((row < p_B) ? d0 : d1) * u * inv_nu;
         } else {
-            if (!sg.is_item) g = d0 * i + d1 * n;
-            else g = ((row < a.B) ? d0 : d1) * u;
+            if (!sidx) g = d0 * i + d1 * n;
+            else g = ((row < p_B) ? d0 : d1) * u;
         }
-        return row >= sg.n_rows ? 0.0f : g;
+        return row >= n_rows ? 0.0f : g;
     };
     if constexpr (D <= 64) {
 #pragma unroll
@@ -1728,7 +1735,7 @@ __global__ __launch_bounds__(512) void k_tr_bwd_head(SmlBwdArgs a) {
             float lt, d0, d1, inv_nu, cc;
             coeffs(sp, sn, uu, lt, d0, d1, inv_nu, cc);
             d0 *= a.scale; d1 *= a.scale;
-            if (!sg.is_item && hs == 0 && w == 0 && row < sg.n_rows) lsum += lt * a.scale;
+            if (!sidx && hs == 0 && w == 0 && row < n_rows) lsum += lt * a.scale;
             const float g = dout_of(row, d0, d1, inv_nu, cc, ou[q], oi[q], on[q]);
             dOs[r * SD + w] = g;
             if (hs == 0) st_out<SML_WT_BWD>(&sg.dout[(int64_t)row * D + w], g);
@@ -1747,7 +1754,7 @@ __global__ __launch_bounds__(512) void k_tr_bwd_head(SmlBwdArgs a) {
             float lt, d0, d1, inv_nu, cc;
             coeffs(sp, sn, uu, lt, d0, d1, inv_nu, cc);
             cf[0][tid] = d0 * a.scale; cf[1][tid] = d1 * a.scale; cf[2][tid] = inv_nu; cf[3][tid] = cc;
-            if (!sg.is_item && hs == 0 && row0 + tid < sg.n_rows) lsum = lt * a.scale;
+            if (!sidx && hs == 0 && row0 + tid < n_rows) lsum = lt * a.scale;
         }
         __syncthreads();
 #pragma unroll
@@ -2415,7 +2422,9 @@ hipError_t sml_launch_bwd(int d, int split, const SmlBwdArgs& a, int tiles_total
 int sml_wgrad_grid(int d);
 hipError_t sml_launch_tr_bwd_head(int d, const SmlBwdArgs& a, int tiles_total, hipStream_t st) {
     if (tiles_total <= 0) return hipSuccess;
-    SML_DISPATCH_D(d, k_tr_bwd_head<DD><<<dim3(((tiles_total + 1) / 2) * 8), dim3(512), 0, st>>>(a));
+    // (leading scalars = the struct's own fields; the kernel derives each segment's z1 / pk / n_rows from them: slot0 = ioff, pk + net * size)
+    SML_DISPATCH_D(d, k_tr_bwd_head<DD><<<dim3(((tiles_total + 1) / 2) * 8), dim3(512), 0, st>>>(a.out_all, a.seg[0].z1, a.seg[0].pk, (long long)a.out_pstride,
+                                                                                                   a.B, a.ioff, a.tiles0, a.tiles_total, a.out_np, a));
     return hipGetLastError();
 }
 int sml_wgrad2_pushers(int d) { return sml_wgrad_grid(d) - 2 + 1; }      // every tile workgroup + the last tail workgroup
