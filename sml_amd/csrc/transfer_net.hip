@@ -215,8 +215,28 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // that pass's share of fc2 accumulated in registers -- so the a2 tile in LDS holds 512 / HSEQ columns: a 32-row workgroup
 // then needs 68 KB of LDS and <= 128 VGPRs, TWO fit a CU, and one's gather / conv prologue / epilogues run under the
 // other's MFMA phases (a single 48-row workgroup per CU left the matrix pipe idle 45 % of the time).
+// Round 6 -- the operands of the kernel's FIRST round of loads are leading scalar parameters (16 SGPRs: built with
+// -amdgpu-kernarg-preload-count=16 they arrive with the wavefront; everything else in the by-value struct comes behind one
+// scalar-load round trip of the argument segment, 0.2-0.45 us that the operand rings, the index loads and the pending conv step
+// no longer wait for): the kernel patches its copy of the struct with them and the body reads the struct as before.  The
+// launcher (sml_launch_fwd) fills them from the struct and checks the layout the patch assumes: segment 1 = segment 0 advanced
+// by one net (theta + net size, images + image size), the same triples and batch length, rows of segment 1 = the item columns.
+// p_cg = cg_split | cg_total << 15.
+// (14 dwords is what the hardware preloads: 16 user SGPRs less the argument-segment pointer.)  p_tiles = tiles0 | (segment 1 present: its ceil(2 B / 16) tiles follow) << 31,
+// p_cg = cg_split | cg_total << 15; rows of segment 1: 2 B -- rounded up to whole tiles when segment 0's rows are (the distinct-row form).
+#define SML_FWD_HOT_PARAMS const float* __restrict__ p_pk, const float* __restrict__ p_theta, const int64_t* __restrict__ p_tri,             \
+                           const float* __restrict__ p_cs_in, const float* __restrict__ p_cg_part, int p_B, int p_n0, int p_tiles, int p_cg
+#define SML_FWD_HOT_PATCH(a, D)                                                                                                               \
+    (a).tiles0 = p_tiles & 0x7fffffff; (a).tiles_total = (p_tiles & 0x7fffffff) + (p_tiles < 0 ? (2 * p_B + SML_TM - 1) / SML_TM : 0);       \
+    (a).cs_in = p_cs_in; (a).cg_part = p_cg_part; (a).cg_split = p_cg & 0x7fff; (a).cg_total = (p_cg >> 15) & 0xffff;                         \
+    (a).seg[0].pk = p_pk; (a).seg[1].pk = p_pk + sml_pk_size(D); (a).seg[0].theta = p_theta; (a).seg[1].theta = p_theta + sml_net_size(D); \
+    (a).seg[0].tri = p_tri; (a).seg[1].tri = p_tri; (a).seg[0].B = p_B; (a).seg[1].B = p_B; (a).seg[0].n_rows = p_n0;                        \
+    (a).seg[1].n_rows = p_n0 == p_B ? 2 * p_B : ((2 * p_B + SML_TM - 1) / SML_TM) * SML_TM;                                                   \
+    (a).seg[0].is_item = 0; (a).seg[1].is_item = 1
 template <int D, int MT, int NS, int HSEQ = 1>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HSEQ > 1 ? 4 : 2, HSEQ > 1 ? 4 : 2))) void k_transfer_fwd(SmlFwdArgs a) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(HSEQ > 1 ? 4 : 2, HSEQ > 1 ? 4 : 2))) void k_transfer_fwd(SML_FWD_HOT_PARAMS, SmlFwdArgs a_in) {
+    SmlFwdArgs a = a_in;
+    SML_FWD_HOT_PATCH(a, D);
 #include "transfer_fwd_body.inc"
 }
 // The same table-sized forward under a name of its own: launched by the EVALUATION stream's context (eval_submit_transferred:
@@ -2380,19 +2400,32 @@ hipError_t sml_launch_fwd(int d, int mt, int ns, const SmlFwdArgs& a, int tiles_
         else k_side_transfer_fwd<64><<<dim3(tiles_total), dim3(512), 0, st>>>(a);
         return hipGetLastError();
     }
-    if (mt == 1 && ns == 1) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 1, 1><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }
-    else if (mt == 1 && ns == 4) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 1, 4><<<dim3(((tiles_total + 1) / 2) * 8), dim3(512), 0, st>>>(a)); }
-    else if (mt == 1 && ns == 2) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 1, 2><<<dim3(tiles_total * 2), dim3(512), 0, st>>>(a)); }
+    // the layout the kernel's preloaded leading parameters stand for (k_transfer_fwd): refuse anything else loudly
+    const SmlSeg& s0 = a.seg[0]; const SmlSeg& s1 = a.seg[1];
+    const bool two = tiles_total > a.tiles0 && s1.n_rows > 0;
+    const int tt = a.tiles_total > a.tiles0 ? a.tiles_total : a.tiles0;          // (table-sized calls leave tiles_total unset: nothing reads it there)
+    const int n1 = s0.n_rows == s0.B ? 2 * s0.B : ((2 * s0.B + SML_TM - 1) / SML_TM) * SML_TM;
+    if ((s0.tri != nullptr && s0.is_item != 0) || a.cg_split < 0 || a.cg_split > 0x7fff || a.cg_total < 0 || a.cg_total > 0xffff ||
+        a.tiles0 < 0 || (tt != a.tiles0 && tt != a.tiles0 + (2 * s0.B + SML_TM - 1) / SML_TM) ||
+        (two && (s1.pk != s0.pk + sml_pk_size(d) || s1.theta != s0.theta + sml_net_size(d) || s1.tri != s0.tri || s1.B != s0.B || s1.n_rows != n1 ||
+                 (s1.tri != nullptr && s1.is_item != 1))))
+        return hipErrorInvalidValue;
+#define SML_FWD_HOT_ARGS s0.pk, s0.theta, s0.tri, a.cs_in, a.cg_part, s0.B, s0.n_rows, (int)((unsigned)a.tiles0 | (tt != a.tiles0 ? 0x80000000u : 0u)), \
+                         (a.cg_split | (a.cg_total << 15)), a
+    if (mt == 1 && ns == 1) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 1, 1><<<dim3(tiles_total), dim3(512), 0, st>>>(SML_FWD_HOT_ARGS)); }
+    else if (mt == 1 && ns == 4) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 1, 4><<<dim3(((tiles_total + 1) / 2) * 8), dim3(512), 0, st>>>(SML_FWD_HOT_ARGS)); }
+    else if (mt == 1 && ns == 2) { SML_DISPATCH_D(d, k_transfer_fwd<DD, 1, 2><<<dim3(tiles_total * 2), dim3(512), 0, st>>>(SML_FWD_HOT_ARGS)); }
     else if (mt == 2 && ns == 1) {
         // table-sized calls: two hidden passes, two workgroups per CU (SML_FWD_HSEQ=1: the one-pass form)
         static const bool hseq = !(getenv("SML_FWD_HSEQ") && atoi(getenv("SML_FWD_HSEQ")) == 1);
         // (d = 128: the two-pass form still needs 118 KB of LDS -- one workgroup per CU either way -- so it keeps one pass)
-        if (hseq && d == 32) k_transfer_fwd<32, 2, 1, 2><<<dim3(tiles_total), dim3(512), 0, st>>>(a);
-        else if (hseq && d == 64) k_transfer_fwd<64, 2, 1, 2><<<dim3(tiles_total), dim3(512), 0, st>>>(a);
-        else { SML_DISPATCH_D(d, k_transfer_fwd<DD, 2, 1><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }
+        if (hseq && d == 32) k_transfer_fwd<32, 2, 1, 2><<<dim3(tiles_total), dim3(512), 0, st>>>(SML_FWD_HOT_ARGS);
+        else if (hseq && d == 64) k_transfer_fwd<64, 2, 1, 2><<<dim3(tiles_total), dim3(512), 0, st>>>(SML_FWD_HOT_ARGS);
+        else { SML_DISPATCH_D(d, k_transfer_fwd<DD, 2, 1><<<dim3(tiles_total), dim3(512), 0, st>>>(SML_FWD_HOT_ARGS)); }
     }
-    else if (mt == 3 && ns == 1 && d == 32) { k_transfer_fwd<32, 3, 1><<<dim3(tiles_total), dim3(512), 0, st>>>(a); }
+    else if (mt == 3 && ns == 1 && d == 32) { k_transfer_fwd<32, 3, 1><<<dim3(tiles_total), dim3(512), 0, st>>>(SML_FWD_HOT_ARGS); }
     else return hipErrorInvalidValue;
+#undef SML_FWD_HOT_ARGS
     return hipGetLastError();
 }
 hipError_t sml_launch_bwd(int d, int split, const SmlBwdArgs& a, int tiles_total, hipStream_t st) {
