@@ -482,8 +482,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // the backward keeps the fp32 products (its GEMMs come next).  SML_MF_BX3=0: k_transfer_fwd<32,1,1>.
 // ------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_mf_fwd_bx3(SmlFwdArgs a, const unsigned short* __restrict__ pkx) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_mf_fwd_bx3(const unsigned short* __restrict__ pkx, const float* __restrict__ p_theta,
+        const SmlSched* __restrict__ p_sched, const void* __restrict__ p_idx, const SmlTileHdr* __restrict__ p_hdr, int p_B, int p_cur_step, int p_sched_len,
+        SmlFwdArgs a_in) {
     static_assert(D == 32, "bf16x3 MF forward: d = 32");
+    // (round 6: the first round of loads' operands as 13 preloaded dwords -- see k_transfer_fwd.  p_idx: the distinct-row records
+    // of segment 0 when p_hdr != null, else the triples; segment 1's records / headers follow segment 0's at the item slot /
+    // after the user tiles; rows of a segment = whole tiles in the distinct-row form.  sml_launch_mf_fwd_bx3 checks this layout.)
+    SmlFwdArgs a = a_in;
+    {
+        const bool dn = p_hdr != nullptr;
+        const int t0 = (p_B + SML_TM - 1) / SML_TM;
+        a.tiles0 = t0; a.cur_step = p_cur_step; a.sched = p_sched; a.sched_len = p_sched_len;
+        a.seg[0].theta = p_theta; a.seg[1].theta = p_theta + sml_net_size(D);
+        a.seg[0].tri = a.seg[1].tri = dn ? a_in.seg[0].tri : static_cast<const int64_t*>(p_idx);
+        a.seg[0].B = a.seg[1].B = p_B; a.seg[0].is_item = 0; a.seg[1].is_item = 1;
+        a.seg[0].n_rows = dn ? SML_TM * t0 : p_B; a.seg[1].n_rows = dn ? SML_TM * ((2 * p_B + SML_TM - 1) / SML_TM) : 2 * p_B;
+        a.seg[0].drec = dn ? static_cast<const SmlRun*>(p_idx) : nullptr;
+        a.seg[1].drec = dn ? static_cast<const SmlRun*>(p_idx) + (int64_t)SML_R * ((p_B + SML_R - 1) / SML_R) : nullptr;
+        a.seg[0].hdr = p_hdr; a.seg[1].hdr = dn ? p_hdr + t0 : nullptr;
+    }
     constexpr int R = SML_TM;
     constexpr int K1 = SML_C2 * D, KS1 = K1 / 32;
     constexpr int CT = SML_HID / 16 / 8;                         // fc1 column tiles per wave (4)
@@ -779,8 +797,13 @@ __device__ __forceinline__ void fused_row_update(const SmlBwdArgs& a, int sidx, 
 // coordinate split below): dOut -> (MF stage) dx_hat + l2*x_hat, or (TR stage) dZ1 rows +
 // conv-grad partials.  dx / dz1 scratch is padded to whole tiles (unconditional stores).
 // ------------------------------------------------------------------------------------
+// (round 6: the head's first round of loads -- tile header and entries, the conv weights, the partner rows -- reads through 12
+// preloaded dwords; see k_transfer_fwd.  sml_launch_bwd fills them from the struct.)
 template <int D, int MT, bool TR>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_transfer_bwd_full(SmlBwdArgs a) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_transfer_bwd_full(const SmlTileHdr* __restrict__ p_hdr, const uint2* __restrict__ p_ent,
+        const float* __restrict__ p_theta, const float* __restrict__ p_out_all, int p_tiles0, int p_world, int p_tiles_live, int p_B, SmlBwdArgs a) {
+    // (the struct is NOT copied and patched here as in k_transfer_fwd: SmlFusedUpdate's per-table arrays are indexed dynamically, a local
+    // copy would live in scratch memory; the preloaded values replace the struct's fields by name below)
     constexpr int R = SML_TM * MT;
     constexpr int K1 = SML_C2 * D;
     constexpr int S2 = SML_HID + 4;
@@ -811,13 +834,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
     TL_BEGIN(5); TL_PREV();
-    const int sidx = (int)blockIdx.x >= a.tiles0;
+    const int sidx = (int)blockIdx.x >= p_tiles0;
     const SmlBwdSeg& sg = a.seg[sidx];
-    const int row0 = ((int)blockIdx.x - (sidx ? a.tiles0 : 0)) * R;
+    const float* __restrict__ sg_theta = p_theta + (sidx ? sml_net_size(D) : 0);       // = sg_theta, from the preloaded parameter
+    const int row0 = ((int)blockIdx.x - (sidx ? p_tiles0 : 0)) * R;
     if constexpr (!TR) {
-        if (a.push.world > 0 && (int)blockIdx.x >= a.tiles_live) { peer_signal(a.push); return; }     // (a batch shorter than the cap)
+        if (p_world > 0 && (int)blockIdx.x >= p_tiles_live) { peer_signal(a.push); return; }     // (a batch shorter than the cap)
     }
-    if (tid < 104) cws[tid] = sg.theta[tid];
+    if (tid < 104) cws[tid] = sg_theta[tid];
     // both GEMMs' first operand k-steps are on their way before the pair loss starts (they depend on theta alone)
 #ifndef SML_PREB
 #define SML_PREB 0
@@ -853,7 +877,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // transferred rows of its triple, one thread per row forms the two scores and the loss terms,
     // then dOut is written element-wise.  User tiles own the loss value (each triple once).
     float lsum = 0.0f;
-    const bool dense = DENSEOK && a.dn.hdr != nullptr;               // (kernel-uniform)
+    const bool dense = DENSEOK && p_hdr != nullptr;               // (kernel-uniform)
     int live = R;
     if constexpr (DENSEOK) {
     if (dense) {
@@ -862,11 +886,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // tile's first SML_TILE_ENT entries and then ALL their out rows are each one round trip.
         constexpr int LPR = D / 4, G = 512 / LPR, EPG = SML_TILE_ENT / G;
         const int grp = tid / LPR, sub = tid % LPR;
-        const SmlTileHdr* hp = a.dn.hdr + blockIdx.x;
+        const SmlTileHdr* hp = p_hdr + blockIdx.x;
         const uint4 h0 = *reinterpret_cast<const uint4*>(hp);
         uint2 en[EPG];
 #pragma unroll
-        for (int i = 0; i < EPG; ++i) en[i] = a.dn.ent[(int64_t)blockIdx.x * SML_TILE_ENT + grp + i * G];
+        for (int i = 0; i < EPG; ++i) en[i] = p_ent[(int64_t)blockIdx.x * SML_TILE_ENT + grp + i * G];
         uint32_t mylen = 0;
         if (tid < 16) mylen = hp->len[tid];
         __builtin_amdgcn_sched_barrier(0);
@@ -881,7 +905,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (lane < 16) { rlen[lane] = mylen; rstart[lane] = inc - mylen; }
             if (lane == 15) rstart[16] = inc;
         }
-        const float inv_b = 1.0f / (float)a.B;
+        const float inv_b = 1.0f / (float)p_B;
         float racc[EPT];
 #pragma unroll
         for (int q = 0; q < EPT; ++q) racc[q] = 0.0f;
@@ -902,9 +926,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int i = 0; i < EPG; ++i) {
                 const bool valid = e0 + grp + i * G < count;
                 const uint32_t du = valid ? (en[i].x & 0xffffu) : 0u, di = valid ? (en[i].x >> 16) : 0u, dn = valid ? (en[i].y & 0xffffu) : 0u;
-                U[i] = *reinterpret_cast<const f32x4*>(a.out_all + (int64_t)du * D + sub * 4);
-                I[i] = *reinterpret_cast<const f32x4*>(a.out_all + (int64_t)(a.ioff + di) * D + sub * 4);
-                N[i] = *reinterpret_cast<const f32x4*>(a.out_all + (int64_t)(a.ioff + dn) * D + sub * 4);
+                U[i] = *reinterpret_cast<const f32x4*>(p_out_all + (int64_t)du * D + sub * 4);
+                I[i] = *reinterpret_cast<const f32x4*>(p_out_all + (int64_t)(a.ioff + di) * D + sub * 4);
+                N[i] = *reinterpret_cast<const f32x4*>(p_out_all + (int64_t)(a.ioff + dn) * D + sub * 4);
             }
 #pragma unroll
             for (int i = 0; i < EPG; ++i) {
@@ -1013,10 +1037,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int row = row0 + r;
         ou[q] = oi[q] = on[q] = 0.0f;
         if (row < sg.n_rows) {
-            const int t = (sg.is_item && row >= a.B) ? row - a.B : row;
-            const float* pu = a.out_all + (int64_t)t * D + w;
-            const float* pi = a.out_all + (int64_t)(a.ioff + t) * D + w;
-            const float* pn = a.out_all + (int64_t)(a.ioff + a.B + t) * D + w;
+            const int t = (sg.is_item && row >= p_B) ? row - p_B : row;
+            const float* pu = p_out_all + (int64_t)t * D + w;
+            const float* pi = p_out_all + (int64_t)(a.ioff + t) * D + w;
+            const float* pn = p_out_all + (int64_t)(a.ioff + p_B + t) * D + w;
             // (this kernel runs behind the unsplit forward: one plane, as a rule)
             for (int p = 0; p < a.out_np; ++p) {
                 ou[q] += pu[p * a.out_pstride];
@@ -1048,7 +1072,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             pair_terms(SML_LOSS_BPR, (sp - sn) * inv_nu, 0.0f, 1.0f, lt, d0, d1);
             d1 = -d0;
         } else {
-            pair_terms(a.kind, sp, sn, 1.0f / (float)a.B, lt, d0, d1);
+            pair_terms(a.kind, sp, sn, 1.0f / (float)p_B, lt, d0, d1);
         }
         cf[0][tid] = d0 * a.scale; cf[1][tid] = d1 * a.scale; cf[2][tid] = inv_nu; cf[3][tid] = cc;
         if (!sg.is_item && row0 + tid < sg.n_rows) lsum = lt * a.scale;
@@ -1063,10 +1087,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (a.kind == SML_LOSS_BPR_NORM || a.kind == SML_LOSS_BPR_UNIT) {
             const float inv_nu = cf[2][r], cc = cf[3][r];
             if (!sg.is_item) g = d0 * ((oi[q] - on[q]) * inv_nu - cc * ou[q]);
-            else g = ((row < a.B) ? d0 : d1) * ou[q] * inv_nu;
+            else g = ((row < p_B) ? d0 : d1) * ou[q] * inv_nu;
         } else {
             if (!sg.is_item) g = d0 * oi[q] + d1 * on[q];
-            else g = ((row < a.B) ? d0 : d1) * ou[q];
+            else g = ((row < p_B) ? d0 : d1) * ou[q];
         }
         if (row >= sg.n_rows) g = 0.0f;
         dOs[r * SD + w] = g;
@@ -1207,8 +1231,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             } else {
                 st_out<SML_WT_MFB>(&sg.dx[(int64_t)row * D + w], dxh + a.l2 * x1);
             }
-            if (a.push.world > 0 && sidx && ok) {                    // several GPUs: the row also goes into every rank's inbox
-                for (int q = 0; q < a.push.world; ++q) peer_store(a.push.dst[q] + (int64_t)row * D + w, dxh + a.l2 * x1);
+            if (p_world > 0 && sidx && ok) {                    // several GPUs: the row also goes into every rank's inbox
+                for (int q = 0; q < p_world; ++q) peer_store(a.push.dst[q] + (int64_t)row * D + w, dxh + a.l2 * x1);
             }
             if (ok) lsum += 0.5f * a.l2 * x1 * x1;      // + l2 * 0.5 * sum(x_hat^2), model/transfer.py:486-488
         }
@@ -1283,7 +1307,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         a.loss_part[blockIdx.x] = s;
         TL(7);
     }
-    if constexpr (!TR) { if (a.push.world > 0) peer_signal(a.push); }       // this workgroup's rows are acknowledged: +1 on every rank's counter
+    if constexpr (!TR) { if (p_world > 0) peer_signal(a.push); }       // this workgroup's rows are acknowledged: +1 on every rank's counter
     TL_DONE();
 }
 
@@ -1845,7 +1869,7 @@ __device__ __forceinline__ void pack_store(float* __restrict__ pk, int off, floa
 // one 32x32 weight-gradient tile (+ fused Adam + operand-image refresh): shared by k_transfer_wgrad and k_tr_wgrad2.
 // (xcd, kk): the XCD this workgroup runs on and its index among that XCD's tiles.
 template <int D>
-__device__ __forceinline__ void wgrad_tile(const SmlWgArgs& a, int xcd, int kk, float* smem_wg, long long* tl_rec) {
+__device__ __forceinline__ void wgrad_tile(const SmlWgArgs& a, const SmlWgSeg& sg, int xcd, int kk, float* smem_wg, long long* tl_rec) {
     constexpr int K1 = SML_C2 * D;
     constexpr int KT = K1 / 32;
     constexpr int JT = D / 32;
@@ -1865,7 +1889,7 @@ __device__ __forceinline__ void wgrad_tile(const SmlWgArgs& a, int xcd, int kk, 
     static_assert(TN % 8 == 0 && T2 == 16 * JT, "tile map");
     constexpr int PER = 2 * (KT + JT);                 // tiles per XCD per net
     const int net = 1 - kk / PER, rr = kk % PER;
-    const SmlWgSeg& sg = a.seg[net];
+    // (sg: this tile's net's segment = a.seg[net], handed in by the caller -- k_tr_wgrad2 patches its copies from preloaded parameters)
     const bool is_w1 = rr < 2 * KT;
     int ti, tj;                       // tile along output rows / cols
     if (is_w1) { ti = 2 * xcd + rr / KT; tj = rr % KT; } else { tj = 2 * xcd + (rr - 2 * KT) / JT; ti = (rr - 2 * KT) % JT; }
@@ -1886,14 +1910,6 @@ __device__ __forceinline__ void wgrad_tile(const SmlWgArgs& a, int xcd, int kk, 
     const bool has_bias = (tj == 0 && tid < 32);
     const int boff = is_w1 ? sml_off_f1b(D) + ti * 32 + tid : sml_off_f2b(D) + ti * 32 + tid;
     float bp = 0.f, bm = 0.f, bv2 = 0.f;
-    if (fuse) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int64_t i = (int64_t)net * NS + woff[q];
-            wp[q] = a.theta[i]; wm[q] = a.m[i]; wvv[q] = a.v[i];
-        }
-        if (has_bias) { const int64_t i = (int64_t)net * NS + boff; bp = a.theta[i]; bm = a.m[i]; bv2 = a.v[i]; }
-    }
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
@@ -1926,6 +1942,18 @@ __device__ __forceinline__ void wgrad_tile(const SmlWgArgs& a, int xcd, int kk, 
                 acc = mfma32(av[s4][e], b, acc);
             }
         }
+    }
+    if (fuse) {
+        // the tile's Adam state, BEHIND the operand loads and the products' issue (round 6): the operands' pointers arrive with the
+        // wavefront (k_tr_wgrad2's preloaded parameters), theta / m / v come with the argument segment -- issued first, as before,
+        // these loads held the operands back by that round trip; here their latency runs under the matrix pipe's tail and the
+        // LDS reduction (the state was written by this very tile's workgroup of the previous step: the same XCD's L2)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int64_t i = (int64_t)net * NS + woff[q];
+            wp[q] = a.theta[i]; wm[q] = a.m[i]; wvv[q] = a.v[i];
+        }
+        if (has_bias) { const int64_t i = (int64_t)net * NS + boff; bp = a.theta[i]; bm = a.m[i]; bv2 = a.v[i]; }
     }
     TL(2);
 #pragma unroll
@@ -2047,14 +2075,36 @@ __global__ __launch_bounds__(512) void k_transfer_wgrad(SmlWgArgs a) {
         TL_DONE();
         return;
     }
-    wgrad_tile<D>(a, (int)blockIdx.x % 8, ((int)blockIdx.x - 2) / 8, smem_wg, tl_rec);    // (8 consecutive blocks: one per XCD)
+    {
+        const int kk = ((int)blockIdx.x - 2) / 8;
+        const SmlWgSeg sg = (kk / (2 * (SML_C2 * D / 32 + D / 32))) ? a.seg[0] : a.seg[1];      // net = 1 - kk / PER (wgrad_tile's map)
+        wgrad_tile<D>(a, sg, (int)blockIdx.x % 8, kk, smem_wg, tl_rec);    // (8 consecutive blocks: one per XCD)
+    }
     TL_DONE();
 }
 
 // The merged launch of the restructured TR step (see k_tr_bwd_head).  Workgroups [0, n_tail) are the backward's
 // tail -- they have the longest chain and are dispatched first --, the rest are the weight-gradient tiles.
+// (round 6: the first round of loads' operands as 14 preloaded dwords, as k_transfer_fwd -- both segments' operand arrays are one
+// allocation each with the item segment at slot0 = B rounded up to SML_R rows; the launcher checks exactly that)
 template <int D>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_tr_wgrad2(SmlWgArgs a) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_tr_wgrad2(const float* __restrict__ p_dz1, const float* __restrict__ p_a1,
+        const float* __restrict__ p_dout, const float* __restrict__ p_a2, const float* __restrict__ p_pk_net, const float* __restrict__ p_xin, int p_B, int p_n_tail,
+        SmlWgArgs a) {
+    // (only the two segment descriptors are copied and patched -- plain structs the compiler keeps in SGPRs; the argument struct itself
+    // holds arrays that are indexed dynamically (peer.dst[q]): a local copy of IT would live in scratch memory)
+    SmlWgSeg seg0 = a.seg[0], seg1 = a.seg[1];
+    {
+        const int64_t slot1 = (int64_t)SML_R * ((p_B + SML_R - 1) / SML_R);
+        seg0.dz1 = p_dz1; seg1.dz1 = p_dz1 + slot1 * SML_HID;
+        seg0.a1 = p_a1; seg1.a1 = p_a1 + slot1 * SML_C2 * D;
+        seg0.dout = p_dout; seg1.dout = p_dout + slot1 * D;
+        seg0.a2 = p_a2; seg1.a2 = p_a2 + slot1 * SML_HID;
+        seg0.pk_net = p_pk_net; seg1.pk_net = p_pk_net + sml_pk_size(D);
+        seg0.xin = p_xin; seg1.xin = p_xin + slot1 * 3 * D;
+        seg0.n_rows = p_B; seg1.n_rows = 2 * p_B;
+    }
+    const int h_n_tail = p_n_tail, h_tiles0 = (p_B + SML_TM - 1) / SML_TM, h_tiles_total = h_tiles0 + (2 * p_B + SML_TM - 1) / SML_TM;
     constexpr int R = SML_TM;
     constexpr int CS = D / 16;
     constexpr int S2 = SML_HID + 4;
@@ -2067,9 +2117,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __shared__ int s_last;
     TL_BEGIN(3); TL_PREV();
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
-    if ((int)blockIdx.x >= a.n_tail) {
-        const int vb = (int)blockIdx.x - a.n_tail;
-        wgrad_tile<D>(a, (int)blockIdx.x % 8, vb / 8, smem, tl_rec);
+    if ((int)blockIdx.x >= h_n_tail) {
+        const int vb = (int)blockIdx.x - h_n_tail;
+        const SmlWgSeg sgt = ((vb / 8) / (2 * (SML_C2 * D / 32 + D / 32))) ? SmlWgSeg(seg0) : SmlWgSeg(seg1);      // (by value: net = 1 - kk / PER, wgrad_tile's map)
+        wgrad_tile<D>(a, sgt, (int)blockIdx.x % 8, vb / 8, smem, tl_rec);
         TL_DONE();
         return;
     }
@@ -2081,12 +2132,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     float* red = smem + SZ0 + 104;        // [8][256]
     const int tb = (int)blockIdx.x;
     const int tile = tb / CS, cs = tb % CS;
-    const bool live = tile < a.tiles_total;         // (an empty batch still has one tail workgroup: it elects itself)
+    const bool live = tile < h_tiles_total;         // (an empty batch still has one tail workgroup: it elects itself)
     if (live) {
-        const int sidx = tile >= a.tiles0;
-        const SmlWgSeg sg = sidx ? a.seg[1] : a.seg[0];
-        const int row0 = (tile - (sidx ? a.tiles0 : 0)) * R;
-        if (tid < 104) cws[tid] = sg.theta_net[tid];
+        const int sidx = tile >= h_tiles0;
+        const SmlWgSeg sg = sidx ? seg1 : seg0;
+        const int row0 = (tile - (sidx ? h_tiles0 : 0)) * R;
         const int tr_ = tid >> 4, twl = tid & 15, tw = cs * 16 + twl;       // tail element of threads 0..255
         float x0 = 0.f, x1 = 0.f, x2 = 0.f;
         if (tid < 256) {
@@ -2108,6 +2158,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int t = 0; t < 5; ++t) ring[i][t] = p1b[(tile1(t) * 32 + wv * 4 + i) * 64 + lane];
+        // (the conv weights' pointer is the one operand of this role that comes with the argument segment, not with the wavefront:
+        // its load goes out behind the preloaded ones)
+        __builtin_amdgcn_sched_barrier(0);
+        if (tid < 104) cws[tid] = sg.theta_net[tid];
         __builtin_amdgcn_sched_barrier(0x86);
         __syncthreads();                            // cws is in LDS
         Pro pt;
@@ -2223,7 +2277,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // memory, the arrival counter is an L2-bypassing atomic, and the last arriver reads the partials with sc1 loads.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) s_last = (__hip_atomic_fetch_add(a.arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.n_tail - 1) ? 1 : 0;
+    if (tid == 0) s_last = (__hip_atomic_fetch_add(a.arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == h_n_tail - 1) ? 1 : 0;
     __syncthreads();
     if (!s_last) { TL_DONE(); return; }
     {
@@ -2233,7 +2287,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // t = rg, rg + 21, ... (user-net rows and item-net rows apart), then the 21 row groups meet in LDS and are added
         // in index order -- the summation order is a fixed function of the launch geometry (deterministic).
         constexpr int RG = 21, C4 = SML_CG / 4;          // 21 x 24 = 504 threads
-        const int split = a.tiles0 * CS, total = a.tiles_total * CS;
+        const int split = h_tiles0 * CS, total = h_tiles_total * CS;
         float* P = smem;                                 // [2][RG][SML_CG]
         if (tid < RG * C4) {
             const int rg = tid / C4, c4 = tid % C4;
@@ -2268,7 +2322,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             float g = 0.0f;
 #pragma unroll
             for (int rg = 0; rg < RG; ++rg) g += P[(net * RG + rg) * SML_CG + k];
-            if (a.seg[net].grad) a.seg[net].grad[off] = g;
+            { float* gp = net ? seg1.grad : seg0.grad; if (gp) gp[off] = g; }
             for (int q = 0; q < a.peer.world; ++q) peer_store(a.peer.dst[q] + i, g);
             if (fuse) {
                 adam_apply(p, m, v, adam_wd(g, a.weight_decay, p), sc);
@@ -2447,8 +2501,11 @@ hipError_t sml_launch_bwd(int d, int split, const SmlBwdArgs& a, int tiles_total
         else return hipErrorInvalidValue;
 #undef SML_BWD_LAUNCH
     } else {
-        if (a.convg_part != nullptr) { SML_DISPATCH_D(d, k_transfer_bwd_full<DD, 1, true><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }
-        else { SML_DISPATCH_D(d, k_transfer_bwd_full<DD, 1, false><<<dim3(tiles_total), dim3(512), 0, st>>>(a)); }
+        if (a.seg[1].theta != a.seg[0].theta + sml_net_size(d)) return hipErrorInvalidValue;      // (what the kernel's preloaded parameters assume)
+#define SML_BWDF_HOT a.dn.hdr, a.dn.ent, a.seg[0].theta, a.out_all, a.tiles0, a.push.world, a.tiles_live, a.B, a
+        if (a.convg_part != nullptr) { SML_DISPATCH_D(d, k_transfer_bwd_full<DD, 1, true><<<dim3(tiles_total), dim3(512), 0, st>>>(SML_BWDF_HOT)); }
+        else { SML_DISPATCH_D(d, k_transfer_bwd_full<DD, 1, false><<<dim3(tiles_total), dim3(512), 0, st>>>(SML_BWDF_HOT)); }
+#undef SML_BWDF_HOT
     }
     return hipGetLastError();
 }
@@ -2463,7 +2520,15 @@ hipError_t sml_launch_tr_bwd_head(int d, const SmlBwdArgs& a, int tiles_total, h
 int sml_wgrad2_pushers(int d) { return sml_wgrad_grid(d) - 2 + 1; }      // every tile workgroup + the last tail workgroup
 hipError_t sml_launch_tr_wgrad2(int d, const SmlWgArgs& a, hipStream_t st) {
     const int tiles = sml_wgrad_grid(d) - 2;
-    SML_DISPATCH_D(d, k_tr_wgrad2<DD><<<dim3(a.n_tail + tiles), dim3(512), 0, st>>>(a));
+    // the layout the kernel's preloaded leading parameters stand for: refuse anything else loudly
+    const SmlWgSeg& s0 = a.seg[0]; const SmlWgSeg& s1 = a.seg[1];
+    const int B = s0.n_rows;
+    const int64_t slot1 = (int64_t)SML_R * ((B + SML_R - 1) / SML_R);
+    if (s1.n_rows != 2 * B || s1.dz1 != s0.dz1 + slot1 * SML_HID || s1.a1 != s0.a1 + slot1 * SML_C2 * d || s1.dout != s0.dout + slot1 * d ||
+        s1.a2 != s0.a2 + slot1 * SML_HID || s1.pk_net != s0.pk_net + sml_pk_size(d) || s1.xin != s0.xin + slot1 * 3 * d ||
+        a.tiles0 != (B + SML_TM - 1) / SML_TM || a.tiles_total != a.tiles0 + (2 * B + SML_TM - 1) / SML_TM)
+        return hipErrorInvalidValue;
+    SML_DISPATCH_D(d, k_tr_wgrad2<DD><<<dim3(a.n_tail + tiles), dim3(512), 0, st>>>(s0.dz1, s0.a1, s0.dout, s0.a2, s0.pk_net, s0.xin, B, a.n_tail, a));
     return hipGetLastError();
 }
 int sml_wgrad_grid(int d) {
@@ -2516,7 +2581,17 @@ hipError_t sml_launch_fwd_bx3(int d, const SmlFwdArgs& a, const void* pkx_net, i
 hipError_t sml_launch_mf_fwd_bx3(int d, const SmlFwdArgs& a, const void* pkx, int tiles, hipStream_t st) {
     if (d != 32) return hipErrorInvalidValue;
     if (tiles <= 0) return hipSuccess;           // (several GPUs: a rank whose share of a global batch is empty still takes part in the step)
-    k_mf_fwd_bx3<32><<<dim3(tiles), dim3(512), 0, st>>>(a, (const unsigned short*)pkx);
+    // the layout the kernel's preloaded leading parameters stand for: refuse anything else loudly
+    const SmlSeg& s0 = a.seg[0]; const SmlSeg& s1 = a.seg[1];
+    const bool dn = s0.drec != nullptr;
+    const int B = s0.B, t0 = (B + SML_TM - 1) / SML_TM;
+    if (a.tiles0 != t0 || s1.theta != s0.theta + sml_net_size(d) || s1.B != B || s0.is_item != 0 || s1.is_item != 1 ||
+        (dn ? (s0.hdr == nullptr || s1.hdr != s0.hdr + t0 || s1.drec != s0.drec + (int64_t)SML_R * ((B + SML_R - 1) / SML_R) ||
+               s0.n_rows != SML_TM * t0 || s1.n_rows != SML_TM * ((2 * B + SML_TM - 1) / SML_TM))
+            : (s0.hdr != nullptr || s1.drec != nullptr || s1.tri != s0.tri || s0.n_rows != B || s1.n_rows != 2 * B)))
+        return hipErrorInvalidValue;
+    k_mf_fwd_bx3<32><<<dim3(tiles), dim3(512), 0, st>>>((const unsigned short*)pkx, s0.theta, a.sched, dn ? (const void*)s0.drec : (const void*)s0.tri, s0.hdr,
+                                                         B, a.cur_step, a.sched_len, a);
     return hipGetLastError();
 }
 hipError_t sml_launch_theta_pack(int d, const float* theta, float* pk, hipStream_t st) {
