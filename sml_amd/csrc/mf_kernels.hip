@@ -217,7 +217,9 @@ __global__ __launch_bounds__(256) void k_loss_finalize(const float* __restrict__
 // in registers, nothing written here), every occurrence emits its gradient row, and k_run_update<Adam>
 // finishes the step.
 template <int D, typename T, bool LAZY, bool SH = false>
-__global__ __launch_bounds__(256) void k_bare_grad(SmlBareArgs a) {
+__global__ __launch_bounds__(256) void k_bare_grad(const int64_t* __restrict__ p_tri, const uint8_t* __restrict__ p_uniq, int p_B, SmlBareArgs a) {
+    // (round 6: the first round trip's operands -- the triples, the "occurs once" marks, the batch length -- are leading scalar
+    // parameters: preloaded into SGPRs with the wavefront (sml_amd/build.py), not fetched with the argument segment)
     constexpr int VEC = RowVec<T>::VEC;
     constexpr int LPR = D / VEC;
     __shared__ float sh4[4];
@@ -229,12 +231,12 @@ __global__ __launch_bounds__(256) void k_bare_grad(SmlBareArgs a) {
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const int t = gid / LPR, sub = gid % LPR;
     float contrib = 0.0f;
-    if (t < a.B) {
-        const int64_t iu = a.tri[(int64_t)t * 3], ii = a.tri[(int64_t)t * 3 + 1], in = a.tri[(int64_t)t * 3 + 2];
+    if (t < p_B) {
+        const int64_t iu = p_tri[(int64_t)t * 3], ii = p_tri[(int64_t)t * 3 + 1], in = p_tri[(int64_t)t * 3 + 2];
         // (the "row occurs once" marks ride in the FIRST round trip, with the triple: fetched where they are used they were a
         // third dependent trip ahead of the stores)
         uint8_t mk_u = 0, mk_i = 0, mk_n = 0;
-        if (!LAZY && a.uniq != nullptr) { mk_u = a.uniq[t]; mk_i = a.uniq[a.B + t]; mk_n = a.uniq[2 * a.B + t]; }
+        if (!LAZY && p_uniq != nullptr) { mk_u = p_uniq[t]; mk_i = p_uniq[p_B + t]; mk_n = p_uniq[2 * p_B + t]; }
         __builtin_amdgcn_sched_barrier(0);
         float u[VEC], it[VEC], ng[VEC];
         if (SML_NT & 1) RowVec<T>::load_nt(reinterpret_cast<const T*>(a.w_user) + iu * D + sub * VEC, u);
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256) void k_bare_grad(SmlBareArgs a) {
                 adam_replay_w(ng[k], m[2][k], v[2][k], fn, a.cur_step - 1, a.sched, swin, a.cur_step - 1);
             }
             if (a.xrep != nullptr) {          // the row update continues from these copies: no second replay
-                const int64_t o[3] = {(int64_t)t * D + sub * 4, (int64_t)(a.B + t) * D + sub * 4, (int64_t)(2 * a.B + t) * D + sub * 4};
+                const int64_t o[3] = {(int64_t)t * D + sub * 4, (int64_t)(p_B + t) * D + sub * 4, (int64_t)(2 * p_B + t) * D + sub * 4};
                 RowVec<float>::store(a.xrep + o[0], reinterpret_cast<const float(&)[4]>(u[0]));
                 RowVec<float>::store(a.xrep + o[1], reinterpret_cast<const float(&)[4]>(it[0]));
                 RowVec<float>::store(a.xrep + o[2], reinterpret_cast<const float(&)[4]>(ng[0]));
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(256) void k_bare_grad(SmlBareArgs a) {
         // TERM moves by ~1e-7 absolute, the coefficients by an ulp: far inside the oracle tolerances of every bare-step test.
         // (BCE: a mean over the GLOBAL batch -> inv_b; the BPR sum ignores it.)
         {
-            const float inv_b = a.scale / (float)a.B;
+            const float inv_b = a.scale / (float)p_B;
             if (a.kind == SML_LOSS_BCE) {
                 const float gp = sml_sigmoid(sp), gn = sml_sigmoid(sn);
                 const float ap = gp + 1e-15f, an = (1.0f - gn) + 1e-15f;
@@ -364,11 +366,11 @@ __global__ __launch_bounds__(256) void k_bare_grad(SmlBareArgs a) {
                     if (q >= 0) peer_store16(dst + h * 4, v); else *reinterpret_cast<f32x4*>(dst + h * 4) = v;
                 }
             };
-            push(qi, t, gy, a.dx + (int64_t)(a.B + t) * D + sub * VEC);
-            push(qn, a.B + t, gz, a.dx + (int64_t)(2 * a.B + t) * D + sub * VEC);
+            push(qi, t, gy, a.dx + (int64_t)(p_B + t) * D + sub * VEC);
+            push(qn, p_B + t, gz, a.dx + (int64_t)(2 * p_B + t) * D + sub * VEC);
         } else {
-            emit(one_i, reinterpret_cast<T*>(a.w_item) + ii * D + sub * VEC, it, gy, a.dx + (int64_t)(a.B + t) * D + sub * VEC, (SML_NT & 4) != 0);
-            emit(one_n, reinterpret_cast<T*>(a.w_item) + in * D + sub * VEC, ng, gz, a.dx + (int64_t)(2 * a.B + t) * D + sub * VEC, (SML_NT & 4) != 0);
+            emit(one_i, reinterpret_cast<T*>(a.w_item) + ii * D + sub * VEC, it, gy, a.dx + (int64_t)(p_B + t) * D + sub * VEC, (SML_NT & 4) != 0);
+            emit(one_n, reinterpret_cast<T*>(a.w_item) + in * D + sub * VEC, ng, gz, a.dx + (int64_t)(2 * p_B + t) * D + sub * VEC, (SML_NT & 4) != 0);
         }
         contrib = (sub == 0 ? lt : 0.0f) + 0.5f * (a.lam_user * sq_u + a.lam_item * sq_i);
     }
@@ -454,13 +456,14 @@ __global__ void k_mark_runs(const K* __restrict__ keys, const uint32_t* __restri
 
 // this batch's slice of the run lists
 struct RunLists { const SmlRun* run_u; int n_u; const SmlRun* run_i; int n_i; };
-__device__ __forceinline__ RunLists run_lists(const SmlRunArgs& a) {
-    RunLists L{a.run_u, a.n_u, a.run_i, a.n_i};
-    if (a.off_u != nullptr) {
-        const int u0 = a.off_u[a.batch_index], i0 = a.off_i[a.batch_index];
-        L.run_u += u0; L.n_u = a.off_u[a.batch_index + 1] - u0;
-        L.run_i += i0; L.n_i = a.off_i[a.batch_index + 1] - i0;
-        if (a.cnt_u != nullptr) { L.n_u = a.cnt_u[a.batch_index * SML_PREP_CNT_STRIDE]; L.n_i = a.cnt_i[a.batch_index * SML_PREP_CNT_STRIDE]; }
+__device__ __forceinline__ RunLists run_lists(const SmlRunArgs& a, const SmlRun* run_u, const SmlRun* run_i, const int* off_u, const int* off_i,
+                                              int n_u, int n_i, int batch_index) {
+    RunLists L{run_u, n_u, run_i, n_i};
+    if (off_u != nullptr) {
+        const int u0 = off_u[batch_index], i0 = off_i[batch_index];
+        L.run_u += u0; L.n_u = off_u[batch_index + 1] - u0;
+        L.run_i += i0; L.n_i = off_i[batch_index + 1] - i0;
+        if (a.cnt_u != nullptr) { L.n_u = a.cnt_u[batch_index * SML_PREP_CNT_STRIDE]; L.n_i = a.cnt_i[batch_index * SML_PREP_CNT_STRIDE]; }
     }
     return L;
 }
@@ -556,7 +559,10 @@ __device__ __forceinline__ void hot_partial_body(const SmlRunArgs& a, int block,
 // zero-gradient steps replayed.
 // ------------------------------------------------------------------------------------
 template <int D, typename T, int OPT, bool HOTB>
-__global__ __launch_bounds__(256) void k_run_update(SmlRunArgs a) {
+__global__ __launch_bounds__(256) void k_run_update(const SmlRun* __restrict__ p_run_u, const SmlRun* __restrict__ p_run_i, const int* __restrict__ p_off_u,
+                                                    const int* __restrict__ p_off_i, int p_n_u, int p_n_i, int p_batch_index, int p_known, int p_hot_blocks,
+                                                    SmlRunArgs a) {
+    // (round 6: what the first round trip -- the run records -- needs as 13 preloaded dwords; see transfer_net.hip k_transfer_fwd)
     constexpr int VEC = RowVec<T>::VEC;
     constexpr int LPR = D / VEC;
     constexpr int G = 64 / LPR;             // lane groups (records) per wavefront
@@ -584,21 +590,21 @@ __global__ __launch_bounds__(256) void k_run_update(SmlRunArgs a) {
         __shared__ int pre[SML_HOT_MAXCAP + 1];
         __shared__ int tsum[257];
         __shared__ __attribute__((aligned(16))) float hrows[256 / (D / 4)][D];
-        run_blocks -= a.hot_blocks;
-        if ((int)blockIdx.x < a.hot_blocks) { hot_partial_body<D>(a, (int)blockIdx.x, a.hot_blocks, pre, tsum, hrows); return; }
+        run_blocks -= p_hot_blocks;
+        if ((int)blockIdx.x < p_hot_blocks) { hot_partial_body<D>(a, (int)blockIdx.x, p_hot_blocks, pre, tsum, hrows); return; }
     }
     const int lane = threadIdx.x & 63;
     const int grp = lane / LPR, sub = lane % LPR;
-    const RunLists L = run_lists(a);
+    const RunLists L = run_lists(a, p_run_u, p_run_i, p_off_u, p_off_i, p_n_u, p_n_i, p_batch_index);
     const int total = L.n_u + L.n_i;
-    const int wave_id = (((int)blockIdx.x - ((OPT == 0 && HOTB) ? a.hot_blocks : 0)) * 256 + threadIdx.x) >> 6;
+    const int wave_id = (((int)blockIdx.x - ((OPT == 0 && HOTB) ? p_hot_blocks : 0)) * 256 + threadIdx.x) >> 6;
     const int n_waves = (run_blocks * 256) >> 6;
     // Compacted run lists (bare step): record k = (trip * G + grp) * n_waves + wave -- neighbouring records
     // (hot rows are neighbours in a sorted list when popular rows have neighbouring ids) go to different
     // wavefronts, so their long sums run side by side instead of one after the other in one wave.
     // Per-position records (MF stage): a run of length L is followed by L-1 empty records, which spaces
     // the heads out already; consecutive records per wave keep the record loads coalesced.
-    const bool strided = a.off_u != nullptr || a.known != 0;
+    const bool strided = p_off_u != nullptr || p_known != 0;
     for (int base = 0; base < total; base += n_waves * G) {                 // wave-uniform trip count
         const int k = strided ? base + grp * n_waves + wave_id : base + wave_id * G + grp;
         const bool valid = k < total;
@@ -1428,15 +1434,15 @@ hipError_t sml_launch_bare_grad(int d, int dtype_bytes, const SmlBareArgs& a, in
     if (n_blocks) *n_blocks = nb;
     if (a.sched != nullptr) {            // lazy dense-Adam form (fp32 tables)
         if (dtype_bytes != 4) return hipErrorInvalidValue;
-        SML_DISPATCH_D(d, k_bare_grad<DD, float, true><<<dim3(nb), dim3(256), 0, st>>>(a));
+        SML_DISPATCH_D(d, k_bare_grad<DD, float, true><<<dim3(nb), dim3(256), 0, st>>>(a.tri, a.uniq, a.B, a));
     } else if (a.shard_tab != nullptr) {  // item-sharded form over peer mappings
-        if (dtype_bytes == 4) { SML_DISPATCH_D(d, k_bare_grad<DD, float, false, true><<<dim3(nb), dim3(256), 0, st>>>(a)); }
-        else if (dtype_bytes == 2) { SML_DISPATCH_D(d, k_bare_grad<DD, __half, false, true><<<dim3(nb), dim3(256), 0, st>>>(a)); }
+        if (dtype_bytes == 4) { SML_DISPATCH_D(d, k_bare_grad<DD, float, false, true><<<dim3(nb), dim3(256), 0, st>>>(a.tri, a.uniq, a.B, a)); }
+        else if (dtype_bytes == 2) { SML_DISPATCH_D(d, k_bare_grad<DD, __half, false, true><<<dim3(nb), dim3(256), 0, st>>>(a.tri, a.uniq, a.B, a)); }
         else return hipErrorInvalidValue;
     } else if (dtype_bytes == 4) {
-        SML_DISPATCH_D(d, k_bare_grad<DD, float, false><<<dim3(nb), dim3(256), 0, st>>>(a));
+        SML_DISPATCH_D(d, k_bare_grad<DD, float, false><<<dim3(nb), dim3(256), 0, st>>>(a.tri, a.uniq, a.B, a));
     } else if (dtype_bytes == 2) {
-        SML_DISPATCH_D(d, k_bare_grad<DD, __half, false><<<dim3(nb), dim3(256), 0, st>>>(a));
+        SML_DISPATCH_D(d, k_bare_grad<DD, __half, false><<<dim3(nb), dim3(256), 0, st>>>(a.tri, a.uniq, a.B, a));
     } else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -1478,7 +1484,7 @@ static int run_grid(int64_t records, int lpr, int cap_blocks) {
 }
 hipError_t sml_launch_run_adam(int d, const SmlRunArgs& a, int64_t max_records, hipStream_t st) {
     const int nb = run_grid(max_records, d / 4, 4096);
-    SML_DISPATCH_D(d, k_run_update<DD, float, 1, false><<<dim3(nb), dim3(256), 0, st>>>(a));
+    SML_DISPATCH_D(d, k_run_update<DD, float, 1, false><<<dim3(nb), dim3(256), 0, st>>>(a.run_u, a.run_i, a.off_u, a.off_i, a.n_u, a.n_i, a.batch_index, a.known, a.hot_blocks, a));
     return hipGetLastError();
 }
 hipError_t sml_launch_run_sgd(int d, int dtype_bytes, const SmlRunArgs& a, int64_t max_records, hipStream_t st) {
@@ -1488,11 +1494,11 @@ hipError_t sml_launch_run_sgd(int d, int dtype_bytes, const SmlRunArgs& a, int64
     // Without it the epoch is light-tailed: shallower unrolls, half the registers, no LDS to speak of.
     const bool hotb = a.hot_blocks > 0;
     if (dtype_bytes == 4) {
-        if (hotb) { SML_DISPATCH_D(d, k_run_update<DD, float, 0, true><<<dim3(nb), dim3(256), 0, st>>>(a)); }
-        else { SML_DISPATCH_D(d, k_run_update<DD, float, 0, false><<<dim3(nb), dim3(256), 0, st>>>(a)); }
+        if (hotb) { SML_DISPATCH_D(d, k_run_update<DD, float, 0, true><<<dim3(nb), dim3(256), 0, st>>>(a.run_u, a.run_i, a.off_u, a.off_i, a.n_u, a.n_i, a.batch_index, a.known, a.hot_blocks, a)); }
+        else { SML_DISPATCH_D(d, k_run_update<DD, float, 0, false><<<dim3(nb), dim3(256), 0, st>>>(a.run_u, a.run_i, a.off_u, a.off_i, a.n_u, a.n_i, a.batch_index, a.known, a.hot_blocks, a)); }
     } else if (dtype_bytes == 2) {
-        if (hotb) { SML_DISPATCH_D(d, k_run_update<DD, __half, 0, true><<<dim3(nb), dim3(256), 0, st>>>(a)); }
-        else { SML_DISPATCH_D(d, k_run_update<DD, __half, 0, false><<<dim3(nb), dim3(256), 0, st>>>(a)); }
+        if (hotb) { SML_DISPATCH_D(d, k_run_update<DD, __half, 0, true><<<dim3(nb), dim3(256), 0, st>>>(a.run_u, a.run_i, a.off_u, a.off_i, a.n_u, a.n_i, a.batch_index, a.known, a.hot_blocks, a)); }
+        else { SML_DISPATCH_D(d, k_run_update<DD, __half, 0, false><<<dim3(nb), dim3(256), 0, st>>>(a.run_u, a.run_i, a.off_u, a.off_i, a.n_u, a.n_i, a.batch_index, a.known, a.hot_blocks, a)); }
     } else return hipErrorInvalidValue;
     return hipGetLastError();
 }
