@@ -863,6 +863,19 @@ def test_product_library_has_no_library_sort():
         assert guarded, src
 
 
+def test_no_kernel_spills_or_uses_scratch_memory():
+    """Round 6: several kernels patch a local copy of (part of) their by-value argument struct with preloaded parameters; a copy
+    that is indexed dynamically anywhere cannot live in registers and lands in scratch memory (560 bytes per lane in the first attempt
+    at k_transfer_bwd_full) -- slow, and silent.  The compiler's resource remarks for every kernel of transfer_net.hip / mf_kernels.hip
+    with the product's flags: no spilled VGPR, no scratch (tools/kernel_resources.py; hipcc cross-compiles without a GPU)."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(repo, "tools", "kernel_resources.py")], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:]
+    assert "k_tr_wgrad2<32>" in p.stdout and "k_transfer_bwd_full<32, 1, false>" in p.stdout       # (the report really covered the kernels)
+
+
 def test_tr_with_mf_bias_fails_like_the_reference_does(tmp_path, monkeypatch):
     """--TR_with_MF_bias (model/transfer.py:347-354): the reference gives W_{t-1} d + 1 columns and then multiplies it with d-column MF
     rows in ConvTransfer_com.forward (model/conv_transfer.py:93) -- run here on the reference itself (round 5): RuntimeError "The size of
