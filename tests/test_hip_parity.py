@@ -289,6 +289,18 @@ def test_closed_form_replay_against_float64_and_against_the_loop(start, d, monke
                       eng.mf_state["m_u"].cpu().numpy(), eng.mf_state["v_u"].cpu().numpy())
         eng.close()
     a, b = outs["1"], outs["0"]
+    # ... and both forms against the ORACLE's dense Adam resumed from the same optimiser state (every row stepped every batch,
+    # model/transfer.py:392 semantics; the G3 tolerances): batch losses and tables
+    mf_cpu = make_mf(U, I, d, wu0, wi0)
+    torch.manual_seed(1)
+    net_cpu = make_transfer(d)
+    oeng = O.OracleEngine(d)
+    oeng.load_optimizer_state(mfbase=mf_cpu, mf_state=st)
+    want = oeng.mf_stage_epoch(mf_cpu, net_cpu, torch.from_numpy(wu0 * 0.9), torch.from_numpy(wi0 * 0.9), tri, 1024, lr, 1e-6)
+    for got in (a, b):
+        np.testing.assert_allclose(got[0], want, rtol=1e-4)
+        adam_close(got[1], mf_cpu.user_laten.weight.detach().numpy(), lr, 64)
+        adam_close(got[2], mf_cpu.item_laten.weight.detach().numpy(), lr, 64)
     np.testing.assert_allclose(a[0], b[0], rtol=2e-6)
     for x, y in zip(a[1:3], b[1:3]):
         assert np.abs(x - y).max() < 5e-6 and np.mean(np.abs(x - y) > 5e-7) < 1e-2, (np.abs(x - y).max(), np.mean(np.abs(x - y) > 5e-7))
