@@ -94,6 +94,10 @@ def _banner(args, which):
 
 
 def main(which, argv=None):
+    if os.environ.get("SML_FAULT_DUMP_S"):          # debugging aid: every thread's Python stack to stderr after that many seconds (a hung job says where)
+        import faulthandler
+        import sys
+        faulthandler.dump_traceback_later(float(os.environ["SML_FAULT_DUMP_S"]), repeat=False, file=sys.stderr)
     from data import dataset2
     from model import transfer
 

@@ -2233,11 +2233,25 @@ def test_main_yelp_with_two_rank_processes_prints_the_single_process_log(tmp_pat
     one = buf.getvalue()
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SML_LAUNCHED", "SML_COMM")}
-    env.update(SML_ONE_DEVICE="1", SML_PEER_TIMEOUT_S="60")
-    p = subprocess.run([sys.executable, os.path.join(repo, "main_yelp.py"), "--gpus", str(gpus)] + argv, env=env, cwd=repo,
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
-    assert p.returncode == 0, p.stderr[-3000:]
-    two = p.stdout
+    limit = float(os.environ.get("SML_TEST_JOB_TIMEOUT_S", "900"))
+    # (a job that hangs says where: every rank dumps its threads' Python stacks to stderr shortly before the limit -- sml_amd/cli.py)
+    env.update(SML_ONE_DEVICE="1", SML_PEER_TIMEOUT_S="60", SML_FAULT_DUMP_S=str(max(limit - 40.0, 20.0)))
+    job = subprocess.Popen([sys.executable, os.path.join(repo, "main_yelp.py"), "--gpus", str(gpus)] + argv, env=env, cwd=repo,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        two, err = job.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        job.terminate()                                   # (the launcher stops its ranks' process groups on SIGTERM)
+        try:
+            two, err = job.communicate(timeout=40)
+        except subprocess.TimeoutExpired:
+            job.kill()
+            two, err = job.communicate()
+        os.makedirs(os.path.join(repo, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(repo, "gpurun_out", "main_yelp_%d_rank_processes_hang.txt" % gpus), "w") as f:
+            f.write("stdout (%d lines):\n%s\n\nstderr:\n%s\n" % (len(two.splitlines()), two[-4000:], err))
+        raise AssertionError("main_yelp.py --gpus %d did not finish in %.0f s (%d lines printed); stderr tail:\n%s" % (gpus, limit, len(two.splitlines()), err[-6000:]))
+    assert job.returncode == 0, err[-3000:]
     num = re.compile(r"-?\d+\.\d+(?:e-?\d+)?")
     strip = lambda t: [re.sub(r"\s+", " ", l).replace("[ ", "[").replace(" ]", "]") for l in t.splitlines()
                        if "time cost" not in l and "Namespace(" not in l and not l.startswith("[Gloo]") and l.strip()]
