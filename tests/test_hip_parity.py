@@ -2233,7 +2233,14 @@ def test_main_yelp_with_two_rank_processes_prints_the_single_process_log(tmp_pat
     one = buf.getvalue()
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SML_LAUNCHED", "SML_COMM")}
-    limit = float(os.environ.get("SML_TEST_JOB_TIMEOUT_S", "900"))
+    # Normal wall time of this job: 4 s (two ranks), 10-20 s (four), 1-4 min (eight, time-sliced).  Once in about ten full-suite runs
+    # of round 6 -- on ONE box, for the two- and the four-process job in a row, with every other multi-process test of that run green --
+    # the job printed nothing after the ranks' rendezvous and sat there until the old 900 s limit (not reproduced in 40 later jobs;
+    # the ranks now dump their stacks before the limit, below).  The limit is what a hang may cost the suite; a hang of the
+    # two-process job skips the larger ones on that box instead of waiting for each.
+    if getattr(test_main_yelp_with_two_rank_processes_prints_the_single_process_log, "_hung", False):
+        pytest.skip("a smaller rank-process job already hung on this box (see gpurun_out/main_yelp_*_rank_processes_hang.txt)")
+    limit = float(os.environ.get("SML_TEST_JOB_TIMEOUT_S", "900" if gpus == 8 else "240"))
     # (a job that hangs says where: every rank dumps its threads' Python stacks to stderr shortly before the limit -- sml_amd/cli.py)
     env.update(SML_ONE_DEVICE="1", SML_PEER_TIMEOUT_S="60", SML_FAULT_DUMP_S=str(max(limit - 40.0, 20.0)))
     job = subprocess.Popen([sys.executable, os.path.join(repo, "main_yelp.py"), "--gpus", str(gpus)] + argv, env=env, cwd=repo,
@@ -2250,6 +2257,7 @@ def test_main_yelp_with_two_rank_processes_prints_the_single_process_log(tmp_pat
         os.makedirs(os.path.join(repo, "gpurun_out"), exist_ok=True)
         with open(os.path.join(repo, "gpurun_out", "main_yelp_%d_rank_processes_hang.txt" % gpus), "w") as f:
             f.write("stdout (%d lines):\n%s\n\nstderr:\n%s\n" % (len(two.splitlines()), two[-4000:], err))
+        test_main_yelp_with_two_rank_processes_prints_the_single_process_log._hung = True
         raise AssertionError("main_yelp.py --gpus %d did not finish in %.0f s (%d lines printed); stderr tail:\n%s" % (gpus, limit, len(two.splitlines()), err[-6000:]))
     assert job.returncode == 0, err[-3000:]
     num = re.compile(r"-?\d+\.\d+(?:e-?\d+)?")
@@ -2391,7 +2399,7 @@ def test_clip_grad_on_the_peer_carrier_equals_the_hook_path(monkeypatch):
     assert float(e2.tr_state[0].abs().max()) > 1.5 * float(eng.tr_state[0].abs().max())
 
 
-def _run_bench(args, timeout=900):
+def _run_bench(args, timeout=420):
     """`python bench.py <args>` as the driver runs it (a fresh process that starts its own ranks); returns the ONE JSON line."""
     import json
     import subprocess
@@ -2440,7 +2448,7 @@ def test_bench_under_torchrun_as_the_driver_launches_it(n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "1", "--no-cpu", "--no-a3",
            "--users", "6000", "--items", "12300", "--inter", "7500", "--neg", "99", "--multi_num", "2"]
-    p = subprocess.run(cmd, env=env, cwd=repo, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    p = subprocess.run(cmd, env=env, cwd=repo, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
     assert p.returncode == 0, p.stderr[-4000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
